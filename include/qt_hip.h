@@ -1,0 +1,177 @@
+/*
+ * qt_hip.h -- C ABI of libqt_hip.so, the MI355X (gfx950) fake-quantization engine.
+ *
+ * This is the drop-in boundary for the hot path of jeffreyyu0602/quantized-training.
+ * The reference has no FFI of its own: its operator boundary is the torch.library
+ * namespace `quantized_ops` (src/quantized_training/decomposed.py:16) plus the autograd
+ * function FusedAmaxObsFakeQuantFunction (src/quantized_training/fake_quantize.py:197-252).
+ * Each entry point below names the reference interface it replaces (file:line relative
+ * to the upstream checkout).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add to call them from those Python impls.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross the boundary
+ *   - every function returns 0 (QT_OK) or a negative qt_status / positive hipError_t;
+ *     nothing throws, nothing allocates, no ownership is transferred
+ *   - `*_dev` pointers are device (HBM) addresses owned by the caller; `stream` is a
+ *     hipStream_t passed as void* (NULL = the legacy default stream); launches are async
+ *   - bf16 / fp16 tensors travel as uint16_t bit patterns
+ *   - stateless and thread-safe (the only state is the caller's buffers)
+ */
+#ifndef QT_HIP_H
+#define QT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QT_ABI_VERSION 1
+#define QT_MAP_ENTRIES 65536
+
+typedef enum qt_status {
+    QT_OK = 0,
+    QT_ERR_BAD_DTYPE = -1,   /* reference: ValueError("Unsupported dtype") fake_quantize.py:95 */
+    QT_ERR_BAD_ARG = -2,
+    QT_ERR_UNALIGNED = -3,
+    QT_ERR_NO_DEVICE = -4
+} qt_status;
+
+/* Closed-form rounding selector for kernels that do not need the LDS table.
+ * kind QT_FMT_LUT: use the 65 536-entry table (any dtype).  The other kinds are proven equal
+ * to the table on all 65 536 inputs (tests/test_capi_host.py) and skip the LDS staging. */
+typedef enum qt_fmt_kind {
+    QT_FMT_LUT = 0,
+    QT_FMT_IDENTITY = 1,     /* dtype None / bfloat16 / float32        fake_quantize.py:34-40 */
+    QT_FMT_FP_SAT = 2,       /* e4m3 / e5m2: p0 = mantissa bits, p1 = min normal exponent,
+                                fmax = saturation value                fp8.py:10-67          */
+    QT_FMT_INT = 3           /* intN / uintN: flo, fhi = clamp bounds   fake_quantize.py:43-52 */
+} qt_fmt_kind;
+
+typedef struct qt_format {
+    int32_t kind;
+    int32_t p0;
+    int32_t p1;
+    float flo;
+    float fhi;
+} qt_format;
+
+int qt_abi_version(void);
+const char *qt_status_string(int code);
+
+/* ---- A1: value-map builder (host) ------------------------------------------------------
+ * Replaces get_quantization_map(dtype)                       fake_quantize.py:31-95
+ * (and through it quantize_to_fp8_e4m3/_e5m2 fp8.py:10-67, _quantize_elemwise_core in bf16
+ * arithmetic fp8.py:147-203, quantize_to_posit posit.py:6-67).
+ * out_host[i] = bf16 bits of Q_dtype(bf16_from_bits(i)); NaN entries are 0x7FC0.
+ * dtype NULL or "" = identity.  Unknown dtype -> QT_ERR_BAD_DTYPE. */
+int qt_build_map(const char *dtype, uint16_t *out_host);
+
+/* Closed-form descriptor for `dtype` (kind QT_FMT_LUT when there is none). */
+int qt_format_for(const char *dtype, qt_format *out);
+
+/* Host evaluation of a closed-form descriptor on one bf16 pattern (used by the CPU tests to
+ * prove descriptor == table on all 65 536 inputs). */
+uint16_t qt_format_apply_host(const qt_format *fmt, uint16_t bf16_bits);
+
+/* ---- exported rounding functions on fp32 data (host) -----------------------------------
+ * quantize_to_fp8_e4m3 / _e5m2 (fp8.py:10-67) and quantize_to_posit (posit.py:6-67) called
+ * directly on tensors (package exports, __init__.py:54-56).  n elements, in-place allowed. */
+int qt_round_fp8_host(const float *x, float *y, size_t n, int mbits, float fp8_max, float fp8_min);
+int qt_round_posit_host(const float *x, float *y, size_t n, int nbits, int es);
+/* Same on device buffers. */
+int qt_round_fp8_f32(const float *x_dev, float *y_dev, size_t n, int mbits, float fp8_max, float fp8_min,
+                     void *stream);
+int qt_round_posit_f32(const float *x_dev, float *y_dev, size_t n, int nbits, int es, void *stream);
+
+/* ---- A5: quantized_ops::vmap(Tensor self, Tensor other) -> Tensor   decomposed.py:143-163
+ * y[i] = lut[idx(x[i])], idx = bf16 bits, or hi16(f32 bits) | (lo16 != 0) for fp32 / fp16
+ * (fp16 goes through its fp32 image; the looked-up bf16 value is cast to the output dtype). */
+int qt_vmap_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
+                 const uint16_t *lut_dev, void *stream);
+int qt_vmap_f32(const float *x_dev, float *y_dev, size_t n, const qt_format *fmt,
+                const uint16_t *lut_dev, void *stream);
+int qt_vmap_f16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
+                const uint16_t *lut_dev, void *stream);
+
+/* ---- A6: quantized_ops::quantize / ::dequantize with a per-tensor scale
+ *                                                        decomposed.py:166-210, :213-262
+ * quantize:   y = vmap(x / s [+ zp], lut)
+ * dequantize: y = vmap?((vmap?(x, in_lut) [- zp]) * s, out_lut)
+ * scale_dev / zp_dev point at ONE element of the tensor's own dtype (bf16 bits or float).
+ * zp_dev, in_lut_dev, out_lut_dev may be NULL. */
+int qt_quantize_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
+                     const uint16_t *lut_dev, const uint16_t *scale_dev, const uint16_t *zp_dev, void *stream);
+int qt_quantize_f32(const float *x_dev, float *y_dev, size_t n, const qt_format *fmt,
+                    const uint16_t *lut_dev, const float *scale_dev, const float *zp_dev, void *stream);
+int qt_dequantize_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const uint16_t *scale_dev,
+                       const uint16_t *zp_dev, const uint16_t *in_lut_dev, const uint16_t *out_lut_dev,
+                       void *stream);
+int qt_dequantize_f32(const float *x_dev, float *y_dev, size_t n, const float *scale_dev, const float *zp_dev,
+                      const uint16_t *in_lut_dev, const uint16_t *out_lut_dev, void *stream);
+
+/* ---- A7: FusedAmaxObsFakeQuantFunction.forward              fake_quantize.py:197-248
+ * Split into the two device steps of one call (no host synchronisation anywhere):
+ *
+ * qt_scale_update  (fake_quantize.py:230-242): for each channel c < C
+ *     amax = max_l history[l][c];  history <- roll(history, -1, 0) (when L > 1);
+ *     history[0][c] <- 0 (the fused pass below max-accumulates the current amax into it);
+ *     sf = amax / quant_max, kept at the old scale when amax <= 0 or non-finite,
+ *     optionally 2^ceil(log2 sf);  scale[c] <- sf.
+ * qt_fake_quant_*  (fake_quantize.py:218-223 + :245-246): ONE read of x that
+ *     (a) max-accumulates |x| into amax_bits_dev (uint32 view of history[0]; NULL = observer off)
+ *     (b) writes y = vmap(x / s, lut) * s with s = (input dtype)scale_f32_dev[0]
+ *         (y_dev NULL = observe only).
+ * Per-channel variants view x as [outer][C][inner] and use scale[c] / amax_bits[c]. */
+int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float quant_max, int force_pow2,
+                    void *stream);
+int qt_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
+                       const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
+                       void *stream);
+int qt_fake_quant_f32(const float *x_dev, float *y_dev, size_t n, const qt_format *fmt,
+                      const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
+                      void *stream);
+int qt_fake_quant_pc_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t outer, size_t C, size_t inner,
+                          const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
+                          uint32_t *amax_bits_dev, void *stream);
+int qt_fake_quant_pc_f32(const float *x_dev, float *y_dev, size_t outer, size_t C, size_t inner,
+                         const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
+                         uint32_t *amax_bits_dev, void *stream);
+
+/* ---- A9/A10: fake-quant GEMMs (bf16 in, fp32 accumulate on MFMA, bf16 out) ---------------
+ * qt_linear_fq_bf16 replaces  F.linear(fq_a(x), weight_fake_quant(W), b)
+ *     modules/qat/linear.py:40-41 + the activation pre-hook quantize.py:128-140
+ *     x [M,K] row-major, W [N,K] row-major (nn.Linear layout), bias [N] or NULL, y [M,N].
+ * qt_bmm_fq_bf16 replaces  MatmulFunctional.forward(fq(a), fq(b))
+ *     modules/quantizable/functional_modules.py:22-26 (QK^T and AV)
+ *     a [B,M,K] (row stride lda, batch stride sa), b is [B,K,N] addressed with strides
+ *     (ldb_k, ldb_n, sb) so that K^T needs no copy; y [B,M,N] contiguous.
+ * Operand quantization is applied while the tile is loaded (x/s -> table -> *s, each rounded to
+ * bf16 exactly like the elementwise pass); fmt kind QT_FMT_IDENTITY = operand not quantized.
+ * The amax observers of both operands are accumulated from the tiles as they stream
+ * (amax_*_bits_dev NULL = off). */
+typedef struct qt_operand_q {
+    qt_format fmt;
+    const uint16_t *lut_dev;       /* may be NULL unless fmt.kind == QT_FMT_LUT */
+    const float *scale_f32_dev;    /* NULL = scale 1 */
+    uint32_t *amax_bits_dev;       /* NULL = observer off */
+} qt_operand_q;
+
+int qt_linear_fq_bf16(const uint16_t *x_dev, const uint16_t *w_dev, const uint16_t *bias_dev, uint16_t *y_dev,
+                      int M, int N, int K, const qt_operand_q *qx, const qt_operand_q *qw, void *stream);
+int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev, int B, int M, int N, int K,
+                   long lda, long sa, long ldb_k, long ldb_n, long sb, const qt_operand_q *qa,
+                   const qt_operand_q *qb, void *stream);
+
+/* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
+ * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg). */
+int qt_bench_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
+                             const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
+                             int iters, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QT_HIP_H */

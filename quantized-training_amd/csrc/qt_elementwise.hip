@@ -1,0 +1,558 @@
+// qt_elementwise.hip -- gfx950 kernels for the elementwise fake-quantization hot path.
+//
+// What the reference does per call (fake_quantize.py:217-248 -> decomposed.py:146-163):
+//   amax = max|x|                      one full read
+//   y = qmap[bits(x / s)] * s          Python loop over 65 536-element chunks, ~6 int32 temporaries
+// Here one launch reads x ONCE (16 B per lane, coalesced), max-accumulates |x| for the observer
+// (wavefront reduction -> one atomic per workgroup), rounds through either a closed form or the
+// 65 536-entry value map staged in LDS (128 KiB of the CU's 160 KiB), and writes y once.
+// Algorithmic traffic: 4 B/element bf16, 8 B/element fp32 -> HBM-bound; see DESIGN.md.
+//
+// Numerics contract (bit-exact against the reference CPU path):
+//   bf16 tensors: q = bf16(f32(x) / f32(s_bf16)); r = map[q]; y = bf16(f32(r) * f32(s_bf16))
+//   fp32 tensors: q = x / s (IEEE);  idx = hi16(q) | (lo16(q) != 0);  y = f32(map[idx]) * s
+//   s == 1 skips both the division and the multiplication (x/1 and r*1 are exact).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qt_device.h"
+
+extern "C" float qt_internal_posit_threshold(int nbits, int es);
+extern "C" int qt_internal_fp8_emin(float fp8_min);
+
+namespace {
+
+constexpr int kIoBf16 = 0;
+constexpr int kIoF32 = 1;
+
+constexpr int kLutBlock = 1024;   // one workgroup per CU (128 KiB LDS), 16 waves
+constexpr int kAluBlock = 256;
+constexpr int kUnroll = 4;        // 16-B loads in flight per lane
+
+template <int IO, int KIND, bool UNIT, bool OBS>
+__device__ __forceinline__ uint4 fq_vec(uint4 v, float s, const Rounder<KIND> &rnd, uint32_t &amax) {
+    if constexpr (IO == kIoBf16) {
+        v.x = fq_word_bf16<KIND, UNIT, OBS>(v.x, s, rnd, amax);
+        v.y = fq_word_bf16<KIND, UNIT, OBS>(v.y, s, rnd, amax);
+        v.z = fq_word_bf16<KIND, UNIT, OBS>(v.z, s, rnd, amax);
+        v.w = fq_word_bf16<KIND, UNIT, OBS>(v.w, s, rnd, amax);
+    } else {
+        v.x = fq_word_f32<KIND, UNIT, OBS>(v.x, s, rnd, amax);
+        v.y = fq_word_f32<KIND, UNIT, OBS>(v.y, s, rnd, amax);
+        v.z = fq_word_f32<KIND, UNIT, OBS>(v.z, s, rnd, amax);
+        v.w = fq_word_f32<KIND, UNIT, OBS>(v.w, s, rnd, amax);
+    }
+    return v;
+}
+
+// scalar element (tails, unaligned tensors)
+template <int IO, int KIND, bool OBS>
+__device__ __forceinline__ void fq_one(const void *x, void *y, size_t i, float s, bool unit, const Rounder<KIND> &rnd,
+                                       uint32_t &amax) {
+    if constexpr (IO == kIoBf16) {
+        uint32_t img = (uint32_t)((const uint16_t *)x)[i] << 16;
+        if constexpr (OBS) {
+            uint32_t a = img & 0x7FFFFFFFu;
+            amax = amax > a ? amax : a;
+        }
+        if (!y) return;
+        if (!unit) img = pack_bf16x2(qt_u2f(img) / s, 0.0f) << 16;
+        uint32_t r = rnd(img);
+        ((uint16_t *)y)[i] = unit ? (uint16_t)(r >> 16) : (uint16_t)pack_bf16x2(qt_u2f(r) * s, 0.0f);
+    } else {
+        uint32_t w = ((const uint32_t *)x)[i];
+        if constexpr (OBS) {
+            uint32_t a = w & 0x7FFFFFFFu;
+            amax = amax > a ? amax : a;
+        }
+        if (!y) return;
+        float q = unit ? qt_u2f(w) : qt_u2f(w) / s;
+        float r = qt_u2f(rnd(qt_fold_img(qt_f2u(q))));
+        ((float *)y)[i] = unit ? r : r * s;
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void block_amax_commit(uint32_t amax, uint32_t *out) {
+    __shared__ uint32_t s_part[BLOCK / 64];
+    amax = wave_max_u32(amax);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_part[wave] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = s_part[0];
+#pragma unroll
+        for (int i = 1; i < BLOCK / 64; ++i) m = m > s_part[i] ? m : s_part[i];
+        if (m != 0u) atomicMax(out, m);   // history[0] was zeroed by qt_scale_update
+    }
+}
+
+template <int IO, int KIND, bool UNIT, bool OBS, int BLOCK>
+__device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t nvec, float s,
+                                          const Rounder<KIND> &rnd, uint32_t &amax) {
+    constexpr size_t kTile = (size_t)BLOCK * kUnroll;
+    const size_t nfull = nvec / kTile;
+    for (size_t t = blockIdx.x; t < nfull; t += gridDim.x) {
+        const size_t base = t * kTile + threadIdx.x;
+        uint4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = x[base + (size_t)u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            uint4 r = fq_vec<IO, KIND, UNIT, OBS>(v[u], s, rnd, amax);
+            if (y) y[base + (size_t)u * BLOCK] = r;
+        }
+    }
+    // ragged last tile: the block that would own it in the grid-stride order
+    if (nfull % gridDim.x == blockIdx.x) {
+        for (size_t i = nfull * kTile + threadIdx.x; i < nvec; i += BLOCK) {
+            uint4 r = fq_vec<IO, KIND, UNIT, OBS>(x[i], s, rnd, amax);
+            if (y) y[i] = r;
+        }
+    }
+}
+
+// Fused observe + fake-quantize, per-tensor scale.
+//   x, y      : 16-B aligned base; nvec 16-B vectors followed by `ntail` scalar elements
+//   scale     : fp32 scale on device (NULL = 1); cast to the input dtype like scale.to(X.dtype)
+//   amax_out  : uint32 view of amax_history[0] (NULL when OBS is false)
+template <int IO, int KIND, bool OBS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec,
+                                                  size_t n, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                  const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<KIND> rnd{fmt, nullptr};
+    if constexpr (KIND == QT_FMT_LUT) {
+        __shared__ uint4 s_lut[QT_MAP_ENTRIES * 2 / 16];
+        if (yv) {
+            const uint4 *g = (const uint4 *)lut;
+#pragma unroll
+            for (int i = 0; i < QT_MAP_ENTRIES * 2 / 16 / BLOCK; ++i) s_lut[i * BLOCK + threadIdx.x] = g[i * BLOCK + threadIdx.x];
+        }
+        rnd.lds = (const uint16_t *)s_lut;
+        __syncthreads();
+    }
+    float s = scale ? *scale : 1.0f;
+    if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+    const bool unit = (s == 1.0f);
+    uint32_t amax = 0;
+    const uint4 *x = (const uint4 *)xv;
+    uint4 *y = (uint4 *)yv;
+    if (unit)
+        fq_stream<IO, KIND, true, OBS, BLOCK>(x, y, nvec, s, rnd, amax);
+    else
+        fq_stream<IO, KIND, false, OBS, BLOCK>(x, y, nvec, s, rnd, amax);
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (size_t i = nvec * kPer + threadIdx.x; i < n; i += BLOCK) fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
+    }
+    if constexpr (OBS) block_amax_commit<BLOCK>(amax, amax_out);
+}
+
+// Element-granular variant with the table read from global memory (L1/L2-resident, 128 KiB):
+// tensors that are unaligned or too small to amortise a 128 KiB LDS fill per workgroup.
+template <int IO, int KIND, bool OBS>
+__global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t n,
+                                                       qt_format fmt, const uint16_t *__restrict__ lut,
+                                                       const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<KIND> rnd{fmt, lut};
+    float s = scale ? *scale : 1.0f;
+    if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+    const bool unit = (s == 1.0f);
+    uint32_t amax = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
+    if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
+// ---- per-channel: x viewed as [outer][C][inner], scale[c], amax[c] ---------------------------
+template <int IO, int KIND>
+__global__ __launch_bounds__(256) void fq_pc_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t outer,
+                                                   size_t C, size_t inner, qt_format fmt,
+                                                   const uint16_t *__restrict__ lut, const float *__restrict__ scale,
+                                                   uint32_t *amax_out) {
+    // one workgroup per (outer, c) row segment group: rows = outer*C, each `inner` long
+    Rounder<KIND> rnd{fmt, lut};
+    const size_t rows = outer * C;
+    __shared__ uint32_t s_part[4];
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const size_t c = row % C;
+        float s = scale ? scale[c] : 1.0f;
+        if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+        const bool unit = (s == 1.0f);
+        uint32_t amax = 0;
+        const size_t base = row * inner;
+        if (amax_out) {
+            for (size_t i = threadIdx.x; i < inner; i += 256) fq_one<IO, KIND, true>(xv, yv, base + i, s, unit, rnd, amax);
+            amax = wave_max_u32(amax);
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = amax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t m = s_part[0];
+                for (int i = 1; i < 4; ++i) m = m > s_part[i] ? m : s_part[i];
+                if (m) atomicMax(amax_out + c, m);
+            }
+            __syncthreads();
+        } else {
+            for (size_t i = threadIdx.x; i < inner; i += 256) fq_one<IO, KIND, false>(xv, yv, base + i, s, unit, rnd, amax);
+        }
+    }
+}
+
+// inner == 1 (channel is the fastest dim): element i belongs to channel i % C
+template <int IO, int KIND>
+__global__ __launch_bounds__(256) void fq_pc_last_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t n,
+                                                        size_t C, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                        const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<KIND> rnd{fmt, lut};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t c = i % C;
+        float s = scale ? scale[c] : 1.0f;
+        if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+        uint32_t amax = 0;
+        if (amax_out) {
+            fq_one<IO, KIND, true>(xv, yv, i, s, s == 1.0f, rnd, amax);
+            if (amax) atomicMax(amax_out + c, amax);
+        } else {
+            fq_one<IO, KIND, false>(xv, yv, i, s, s == 1.0f, rnd, amax);
+        }
+    }
+}
+
+// ---- delayed-scaling state machine (fake_quantize.py:230-242), one thread per channel ----------
+__global__ void scale_update_kernel(float *__restrict__ hist, int L, int C, float *__restrict__ scale, float quant_max,
+                                    int pow2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // amax = torch.amax(history, dim=0): NaN propagates
+    float amax = hist[c];
+    bool nan = amax != amax;
+    for (int l = 1; l < L; ++l) {
+        float h = hist[(size_t)l * C + c];
+        nan |= (h != h);
+        amax = h > amax ? h : amax;
+    }
+    if (nan) amax = qt_u2f(QT_NAN32);
+    if (L > 1) {   // roll(history, -1, 0): new[i] = old[i+1], new[L-1] = old[0]
+        float first = hist[c];
+        for (int l = 0; l + 1 < L; ++l) hist[(size_t)l * C + c] = hist[(size_t)(l + 1) * C + c];
+        hist[(size_t)(L - 1) * C + c] = first;
+    }
+    hist[c] = 0.0f;   // slot 0 <- amax_cur, max-accumulated by the fused pass
+    float sf = amax / quant_max;
+    const float old = scale[c];
+    sf = (amax > 0.0f) ? sf : old;
+    sf = (__builtin_isfinite(amax)) ? sf : old;
+    if (pow2) {
+        // torch.pow(2, torch.ceil(torch.log2(sf))) in fp32
+        float lg = (float)log2((double)sf);
+        sf = (float)exp2((double)ceilf(lg));
+    }
+    scale[c] = sf;
+}
+
+// ---- generic quantize / dequantize (decomposed.py:166-262); tables read from global memory ------
+struct QdqArgs {
+    const uint16_t *in_lut;    // applied first (dequantize's input_qmap) or NULL
+    const uint16_t *out_lut;   // applied last (quantize's qmap / dequantize's output_qmap) or NULL
+    qt_format out_fmt;         // closed form for out_lut when kind != LUT and out_lut == NULL
+    int use_out;               // 1 = apply out rounding
+    int mode;                  // 0 = x / s [+ zp], 1 = (x [- zp]) * s
+};
+
+template <int IO>
+__global__ __launch_bounds__(256) void qdq_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t n, QdqArgs a,
+                                                 const void *__restrict__ scale, const void *__restrict__ zp) {
+    float s, z = 0.0f;
+    if constexpr (IO == kIoBf16) {
+        s = qt_bf2f(*(const uint16_t *)scale);
+        if (zp) z = qt_bf2f(*(const uint16_t *)zp);
+    } else {
+        s = *(const float *)scale;
+        if (zp) z = *(const float *)zp;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        // value `v` is kept in the tensor dtype after every op (bf16 ops round to bf16)
+        float v;
+        if constexpr (IO == kIoBf16) v = qt_bf2f(((const uint16_t *)xv)[i]);
+        else v = ((const float *)xv)[i];
+        auto round_io = [](float f) -> float {
+            if constexpr (IO == kIoBf16) return qt_u2f(pack_bf16x2(f, 0.0f) << 16);
+            else return f;
+        };
+        auto lookup = [&](const uint16_t *t, float f) -> float {
+            uint32_t img = (IO == kIoBf16) ? qt_f2u(f) : qt_fold_img(qt_f2u(f));
+            return qt_bf2f(t[img >> 16]);
+        };
+        if (a.in_lut) v = lookup(a.in_lut, v);
+        if (a.mode == 0) {
+            v = round_io(v / s);
+            if (zp) v = round_io(v + z);
+        } else {
+            if (zp) v = round_io(v - z);
+            v = round_io(v * s);
+        }
+        if (a.use_out) {
+            if (a.out_lut) v = lookup(a.out_lut, v);
+            else {
+                uint32_t img = (IO == kIoBf16) ? qt_f2u(v) : qt_fold_img(qt_f2u(v));
+                v = qt_u2f(qt_apply_format_img(a.out_fmt, img));
+            }
+        }
+        if constexpr (IO == kIoBf16) ((uint16_t *)yv)[i] = (uint16_t)(qt_f2u(v) >> 16);
+        else ((float *)yv)[i] = v;
+    }
+}
+
+// fp16 vmap: index through the fp32 image, looked-up bf16 value cast to fp16 (decomposed.py:151-161)
+__global__ __launch_bounds__(256) void vmap_f16_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y, size_t n,
+                                                      qt_format fmt, const uint16_t *__restrict__ lut) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t img = qt_fold_img(qt_f2u((float)x[i]));
+        uint32_t r = lut ? ((uint32_t)lut[img >> 16] << 16) : qt_apply_format_img(fmt, img);
+        y[i] = (_Float16)qt_u2f(r);
+    }
+}
+
+// exported rounding functions on fp32 tensors
+__global__ __launch_bounds__(256) void round_fp8_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
+                                                       int mbits, int emin, float fmax) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = qt_u2f(qt_fp_sat_u32(qt_f2u(x[i]), mbits, emin, fmax));
+}
+__global__ __launch_bounds__(256) void round_posit_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
+                                                         int nbits, int es, float thr) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = qt_u2f(qt_posit_u32(qt_f2u(x[i]), nbits, es, thr));
+}
+
+// ---- launch helpers --------------------------------------------------------------------------
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+inline unsigned grid_for(size_t work_items, size_t per_block, int blocks_per_cu) {
+    size_t want = (work_items + per_block - 1) / per_block;
+    size_t cap = (size_t)num_cus() * blocks_per_cu;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+// Tensors below this many elements use the global-table gather kernel instead of staging 128 KiB per CU.
+constexpr size_t kLutLdsMinElems = (size_t)1 << 21;
+
+template <int IO, int KIND>
+int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const uint16_t *lut, const float *scale,
+                   uint32_t *amax, hipStream_t st) {
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
+    const bool gather = !aligned || (KIND == QT_FMT_LUT && (n < kLutLdsMinElems || y == nullptr)) || n < 4096;
+    if (gather) {
+        // observe-only never touches the table, so KIND is irrelevant there
+        unsigned grid = grid_for(n, 256 * 8, 8);
+        if (amax)
+            fq_gather_kernel<IO, KIND, true><<<grid, 256, 0, st>>>(x, y, n, fmt, lut, scale, amax);
+        else
+            fq_gather_kernel<IO, KIND, false><<<grid, 256, 0, st>>>(x, y, n, fmt, lut, scale, amax);
+        return launch_status();
+    }
+    const size_t nvec = n / kPer;
+    if constexpr (KIND == QT_FMT_LUT) {
+        unsigned grid = grid_for(nvec, (size_t)kLutBlock * kUnroll * 4, 1);
+        if (amax)
+            fq_kernel<IO, KIND, true, kLutBlock><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+        else
+            fq_kernel<IO, KIND, false, kLutBlock><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+    } else {
+        unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, 8);
+        if (amax)
+            fq_kernel<IO, KIND, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+        else
+            fq_kernel<IO, KIND, false, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+    }
+    return launch_status();
+}
+
+template <int IO>
+int launch_fq(const void *x, void *y, size_t n, const qt_format *fmt, const uint16_t *lut, const float *scale,
+              uint32_t *amax, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !fmt || (!y && !amax)) return QT_ERR_BAD_ARG;
+    constexpr size_t esz = IO == kIoBf16 ? 2 : 4;
+    if (((uintptr_t)x % esz) || ((uintptr_t)y % esz)) return QT_ERR_UNALIGNED;
+    hipStream_t st = (hipStream_t)stream;
+    if (!y) {   // observe only: no rounding, no scale
+        qt_format ident = {QT_FMT_IDENTITY, 0, 0, 0.0f, 0.0f};
+        return launch_fq_kind<IO, QT_FMT_IDENTITY>(x, nullptr, n, ident, nullptr, nullptr, amax, st);
+    }
+    switch (fmt->kind) {
+        case QT_FMT_LUT:
+            if (!lut && y) return QT_ERR_BAD_ARG;
+            return launch_fq_kind<IO, QT_FMT_LUT>(x, y, n, *fmt, lut, scale, amax, st);
+        case QT_FMT_FP_SAT: return launch_fq_kind<IO, QT_FMT_FP_SAT>(x, y, n, *fmt, lut, scale, amax, st);
+        case QT_FMT_INT: return launch_fq_kind<IO, QT_FMT_INT>(x, y, n, *fmt, lut, scale, amax, st);
+        case QT_FMT_IDENTITY: return launch_fq_kind<IO, QT_FMT_IDENTITY>(x, y, n, *fmt, lut, scale, amax, st);
+        default: return QT_ERR_BAD_ARG;
+    }
+}
+
+template <int IO, int KIND>
+int launch_pc_kind(const void *x, void *y, size_t outer, size_t C, size_t inner, const qt_format &fmt,
+                   const uint16_t *lut, const float *scale, uint32_t *amax, hipStream_t st) {
+    const size_t n = outer * C * inner;
+    if (inner == 1) {
+        unsigned grid = grid_for(n, 256 * 4, 8);
+        fq_pc_last_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, n, C, fmt, lut, scale, amax);
+    } else {
+        unsigned grid = grid_for(outer * C, 1, 16);
+        fq_pc_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, outer, C, inner, fmt, lut, scale, amax);
+    }
+    return launch_status();
+}
+
+template <int IO>
+int launch_pc(const void *x, void *y, size_t outer, size_t C, size_t inner, const qt_format *fmt, const uint16_t *lut,
+              const float *scale, uint32_t *amax, void *stream) {
+    if (outer * C * inner == 0) return QT_OK;
+    if (!x || !fmt || (!y && !amax)) return QT_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (fmt->kind) {
+        case QT_FMT_LUT:
+            if (!lut && y) return QT_ERR_BAD_ARG;
+            return launch_pc_kind<IO, QT_FMT_LUT>(x, y, outer, C, inner, *fmt, lut, scale, amax, st);
+        case QT_FMT_FP_SAT: return launch_pc_kind<IO, QT_FMT_FP_SAT>(x, y, outer, C, inner, *fmt, lut, scale, amax, st);
+        case QT_FMT_INT: return launch_pc_kind<IO, QT_FMT_INT>(x, y, outer, C, inner, *fmt, lut, scale, amax, st);
+        case QT_FMT_IDENTITY:
+            return launch_pc_kind<IO, QT_FMT_IDENTITY>(x, y, outer, C, inner, *fmt, lut, scale, amax, st);
+        default: return QT_ERR_BAD_ARG;
+    }
+}
+
+template <int IO>
+int launch_qdq(const void *x, void *y, size_t n, const QdqArgs &a, const void *scale, const void *zp, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y || !scale) return QT_ERR_BAD_ARG;
+    unsigned grid = grid_for(n, 256 * 4, 8);
+    qdq_kernel<IO><<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n, a, scale, zp);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float quant_max, int force_pow2, void *stream) {
+    if (!history_dev || !scale_dev || L < 1 || C < 1) return QT_ERR_BAD_ARG;
+    unsigned grid = (unsigned)((C + 127) / 128);
+    scale_update_kernel<<<grid, 128, 0, (hipStream_t)stream>>>(history_dev, L, C, scale_dev, quant_max, force_pow2);
+    return launch_status();
+}
+
+int qt_fake_quant_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut,
+                       const float *scale, uint32_t *amax, void *stream) {
+    return launch_fq<kIoBf16>(x, y, n, fmt, lut, scale, amax, stream);
+}
+int qt_fake_quant_f32(const float *x, float *y, size_t n, const qt_format *fmt, const uint16_t *lut, const float *scale,
+                      uint32_t *amax, void *stream) {
+    return launch_fq<kIoF32>(x, y, n, fmt, lut, scale, amax, stream);
+}
+int qt_fake_quant_pc_bf16(const uint16_t *x, uint16_t *y, size_t outer, size_t C, size_t inner, const qt_format *fmt,
+                          const uint16_t *lut, const float *scale, uint32_t *amax, void *stream) {
+    return launch_pc<kIoBf16>(x, y, outer, C, inner, fmt, lut, scale, amax, stream);
+}
+int qt_fake_quant_pc_f32(const float *x, float *y, size_t outer, size_t C, size_t inner, const qt_format *fmt,
+                         const uint16_t *lut, const float *scale, uint32_t *amax, void *stream) {
+    return launch_pc<kIoF32>(x, y, outer, C, inner, fmt, lut, scale, amax, stream);
+}
+
+// vmap == fake-quant with scale 1 and no observer (x/1 and r*1 are exact)
+int qt_vmap_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut, void *stream) {
+    if (n && !y) return QT_ERR_BAD_ARG;
+    return launch_fq<kIoBf16>(x, y, n, fmt, lut, nullptr, nullptr, stream);
+}
+int qt_vmap_f32(const float *x, float *y, size_t n, const qt_format *fmt, const uint16_t *lut, void *stream) {
+    if (n && !y) return QT_ERR_BAD_ARG;
+    return launch_fq<kIoF32>(x, y, n, fmt, lut, nullptr, nullptr, stream);
+}
+int qt_vmap_f16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y || !fmt || (fmt->kind == QT_FMT_LUT && !lut)) return QT_ERR_BAD_ARG;
+    unsigned grid = grid_for(n, 256 * 4, 8);
+    vmap_f16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const _Float16 *)x, (_Float16 *)y, n, *fmt,
+                                                          fmt->kind == QT_FMT_LUT ? lut : nullptr);
+    return launch_status();
+}
+
+int qt_quantize_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut,
+                     const uint16_t *scale, const uint16_t *zp, void *stream) {
+    if (!fmt || (fmt->kind == QT_FMT_LUT && !lut)) return QT_ERR_BAD_ARG;
+    QdqArgs a{nullptr, fmt->kind == QT_FMT_LUT ? lut : nullptr, *fmt, 1, 0};
+    return launch_qdq<kIoBf16>(x, y, n, a, scale, zp, stream);
+}
+int qt_quantize_f32(const float *x, float *y, size_t n, const qt_format *fmt, const uint16_t *lut, const float *scale,
+                    const float *zp, void *stream) {
+    if (!fmt || (fmt->kind == QT_FMT_LUT && !lut)) return QT_ERR_BAD_ARG;
+    QdqArgs a{nullptr, fmt->kind == QT_FMT_LUT ? lut : nullptr, *fmt, 1, 0};
+    return launch_qdq<kIoF32>(x, y, n, a, scale, zp, stream);
+}
+int qt_dequantize_bf16(const uint16_t *x, uint16_t *y, size_t n, const uint16_t *scale, const uint16_t *zp,
+                       const uint16_t *in_lut, const uint16_t *out_lut, void *stream) {
+    QdqArgs a{in_lut, out_lut, {QT_FMT_LUT, 0, 0, 0.f, 0.f}, out_lut ? 1 : 0, 1};
+    return launch_qdq<kIoBf16>(x, y, n, a, scale, zp, stream);
+}
+int qt_dequantize_f32(const float *x, float *y, size_t n, const float *scale, const float *zp, const uint16_t *in_lut,
+                      const uint16_t *out_lut, void *stream) {
+    QdqArgs a{in_lut, out_lut, {QT_FMT_LUT, 0, 0, 0.f, 0.f}, out_lut ? 1 : 0, 1};
+    return launch_qdq<kIoF32>(x, y, n, a, scale, zp, stream);
+}
+
+int qt_round_fp8_f32(const float *x, float *y, size_t n, int mbits, float fp8_max, float fp8_min, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y || mbits < 1 || mbits > 22 || !(fp8_min > 0.0f)) return QT_ERR_BAD_ARG;
+    unsigned grid = grid_for(n, 256 * 4, 8);
+    round_fp8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n, mbits, qt_internal_fp8_emin(fp8_min), fp8_max);
+    return launch_status();
+}
+int qt_round_posit_f32(const float *x, float *y, size_t n, int nbits, int es, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y || nbits < 3 || nbits > 24 || es < 0 || es > 4 || ((nbits - 2) << es) > 126) return QT_ERR_BAD_ARG;
+    unsigned grid = grid_for(n, 256 * 4, 8);
+    round_posit_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n, nbits, es, qt_internal_posit_threshold(nbits, es));
+    return launch_status();
+}
+
+int qt_bench_fake_quant_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut,
+                             const float *scale, uint32_t *amax, int iters, void *stream, float *ms_out) {
+    if (!ms_out || iters < 1) return QT_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+    int rc = QT_OK;
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < iters && rc == QT_OK; ++i) rc = launch_fq<kIoBf16>(x, y, n, fmt, lut, scale, amax, stream);
+    (void)hipEventRecord(e1, st);
+    e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != QT_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    *ms_out = ms / (float)iters;
+    return QT_OK;
+}
+
+}  // extern "C"

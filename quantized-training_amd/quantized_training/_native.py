@@ -1,0 +1,117 @@
+"""ctypes binding of libqt_hip.so -- the C ABI declared in include/qt_hip.h.
+
+The library is the product: there is no Python or torch fallback for device tensors.
+`lib()` raises if the shared object is missing (build it with `make -C quantized-training_amd`
+or `python __graft_entry__.py`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_uint16, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqt_hip.so")
+
+QT_MAP_ENTRIES = 65536
+QT_FMT_LUT, QT_FMT_IDENTITY, QT_FMT_FP_SAT, QT_FMT_INT = 0, 1, 2, 3
+QT_ERR_BAD_DTYPE = -1
+
+
+class QtFormat(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("p0", ctypes.c_int32), ("p1", ctypes.c_int32),
+                ("flo", c_float), ("fhi", c_float)]
+
+    def key(self):
+        return (self.kind, self.p0, self.p1, self.flo, self.fhi)
+
+
+class QtOperandQ(ctypes.Structure):
+    _fields_ = [("fmt", QtFormat), ("lut_dev", c_void_p), ("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p)]
+
+
+class QtError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_FMT = POINTER(QtFormat)
+_OPQ = POINTER(QtOperandQ)
+
+# name -> (restype, argtypes); mirrors include/qt_hip.h one to one
+SIGNATURES = {
+    "qt_abi_version": (c_int, []),
+    "qt_status_string": (c_char_p, [c_int]),
+    "qt_build_map": (c_int, [c_char_p, _P]),
+    "qt_format_for": (c_int, [c_char_p, _FMT]),
+    "qt_format_apply_host": (c_uint16, [_FMT, c_uint16]),
+    "qt_round_fp8_host": (c_int, [_P, _P, c_size_t, c_int, c_float, c_float]),
+    "qt_round_posit_host": (c_int, [_P, _P, c_size_t, c_int, c_int]),
+    "qt_round_fp8_f32": (c_int, [_P, _P, c_size_t, c_int, c_float, c_float, _P]),
+    "qt_round_posit_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, _P]),
+    "qt_vmap_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),
+    "qt_vmap_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),
+    "qt_vmap_f16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),
+    "qt_quantize_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_quantize_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_dequantize_bf16": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "qt_dequantize_f32": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "qt_scale_update": (c_int, [_P, c_int, c_int, _P, c_float, c_int, _P]),
+    "qt_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_fake_quant_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
+    "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
+                               _OPQ, _OPQ, _P]),
+    "qt_bench_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, c_int, _P, POINTER(c_float)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libqt_hip.so once.  Raises QtError when it is missing -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QtError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `make -C quantized-training_amd` (or `python __graft_entry__.py`).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.qt_abi_version() != 1:
+            raise QtError("libqt_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().qt_status_string(code).decode()
+        if code == QT_ERR_BAD_DTYPE:
+            raise ValueError(f"Unsupported dtype: {what}")
+        raise QtError(f"libqt_hip {what}: {msg} (code {code})")
+
+
+def build_map_u16(dtype):
+    """uint16[65536] numpy array of bf16 bit patterns (host)."""
+    import numpy as np
+    out = np.empty(QT_MAP_ENTRIES, dtype=np.uint16)
+    name = None if dtype is None else str(dtype).encode()
+    code = lib().qt_build_map(name, out.ctypes.data)
+    if code == QT_ERR_BAD_DTYPE:
+        raise ValueError(f"Unsupported dtype: {dtype}")
+    check(code, "qt_build_map")
+    return out
+
+
+def format_for(dtype):
+    f = QtFormat()
+    name = None if dtype is None else str(dtype).encode()
+    code = lib().qt_format_for(name, ctypes.byref(f))
+    if code == QT_ERR_BAD_DTYPE:
+        raise ValueError(f"Unsupported dtype: {dtype}")
+    check(code, "qt_format_for")
+    return f

@@ -1,0 +1,159 @@
+"""The ``quantized_ops`` operator library (upstream src/quantized_training/decomposed.py:16-262).
+
+Schemas are the reference's, verbatim, so converted PT2E graphs that call
+``torch.ops.quantized_ops.quantize.default`` / ``dequantize.default`` keep working.  Device
+tensors dispatch to the HIP kernels of libqt_hip.so (no fallback: a missing library raises);
+CPU tensors use the same formulas in torch ops (host-side plumbing).  Block-scaled (MX) ops and
+conv / pooling pass-throughs are outside this engine's hot path.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch.library import Library
+
+from . import _native
+from .fake_quantize import _cpu_vmap, _stream_ptr, hip_vmap
+
+__all__ = ["vmap", "quantize", "dequantize", "expand", "quantized_decomposed_lib"]
+
+quantized_decomposed_lib = Library("quantized_ops", "DEF")
+_lib = quantized_decomposed_lib
+
+_lib.define("vmap(Tensor self, Tensor other) -> Tensor")
+_lib.define(
+    "quantize(Tensor input, Tensor scale, Tensor? zero_point=None, SymInt[]? axes=None, "
+    "int? block_size=None, Tensor? qmap=None, Tensor? output_code=None) -> Tensor")
+_lib.define(
+    "dequantize(Tensor input, Tensor scale, Tensor? zero_point=None, SymInt[]? axes=None, "
+    "int? block_size=None, Tensor? input_qmap=None, Tensor? output_qmap=None) -> Tensor")
+_lib.define("linear(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor")
+_lib.define("matmul(Tensor self, Tensor other) -> Tensor")
+
+
+def expand(input, shape, block_size):
+    """Broadcast a block-wise parameter to ``shape`` (upstream decomposed.py:127-140)."""
+    while input.ndim < len(shape):
+        input = input.unsqueeze(0)
+    for dim in range(len(shape)):
+        if input.shape[dim] != shape[dim]:
+            input = torch.repeat_interleave(input, block_size, dim)
+    if list(input.shape) != list(shape):
+        input = input[tuple(slice(0, n) for n in shape)]
+    return input
+
+
+# ---- vmap --------------------------------------------------------------------------------------
+def _vmap_cpu(input, qmap):
+    return _cpu_vmap(input, qmap).contiguous()
+
+
+def _vmap_hip(input, qmap):
+    return hip_vmap(input, qmap.contiguous(), None)
+
+
+_lib.impl("vmap", _vmap_cpu, "CPU")
+_lib.impl("vmap", _vmap_hip, "CUDA")
+_lib.impl("vmap", lambda input, qmap: torch.empty_like(input, memory_format=torch.contiguous_format), "Meta")
+
+
+def vmap(input: torch.Tensor, qmap: torch.Tensor, chunk_size=65536) -> torch.Tensor:
+    """``out = qmap[index(input)]`` (upstream decomposed.py:146-163); ``chunk_size`` is accepted and unused."""
+    return torch.ops.quantized_ops.vmap(input, qmap)
+
+
+# ---- quantize / dequantize ------------------------------------------------------------------------
+def _single(t):
+    return t is not None and t.numel() == 1
+
+
+def _scalar_like(t, ref):
+    return t.to(device=ref.device, dtype=ref.dtype).reshape(1).contiguous()
+
+
+def _lut_format():
+    return _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
+
+
+def _quantize_impl(input, scale, zero_point=None, axes=None, block_size=None, qmap=None, output_code=None):
+    assert qmap is not None, "qmap must be provided for quantization"
+    # the fused kernels compute in the tensor's own dtype, which is what torch's type promotion does
+    # only when scale / zero_point already have that dtype
+    fast = (input.device.type == "cuda" and block_size is None and _single(scale)
+            and scale.dtype == input.dtype
+            and (zero_point is None or (_single(zero_point) and zero_point.dtype == input.dtype))
+            and input.dtype in (torch.bfloat16, torch.float32))
+    if fast:
+        L = _native.lib()
+        x = input.contiguous()
+        y = torch.empty_like(x)
+        if x.numel():
+            s = _scalar_like(scale, x)
+            z = _scalar_like(zero_point, x) if zero_point is not None else None
+            fn = L.qt_quantize_bf16 if x.dtype == torch.bfloat16 else L.qt_quantize_f32
+            fmt = _lut_format()
+            _native.check(fn(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), qmap.data_ptr(),
+                             s.data_ptr(), z.data_ptr() if z is not None else None, _stream_ptr(x)), "qt_quantize")
+        return y
+    if block_size is not None:
+        scale = expand(scale, input.shape, block_size)
+        if zero_point is not None:
+            zero_point = expand(zero_point, input.shape, block_size)
+    input = input / scale if zero_point is None else input / scale + zero_point
+    return torch.ops.quantized_ops.vmap(input, qmap)
+
+
+def _dequantize_impl(input, scale, zero_point=None, axes=None, block_size=None, input_qmap=None, output_qmap=None):
+    # the fused kernels compute in the tensor's own dtype, which is what torch's type promotion does
+    # only when scale / zero_point already have that dtype
+    fast = (input.device.type == "cuda" and block_size is None and _single(scale)
+            and scale.dtype == input.dtype
+            and (zero_point is None or (_single(zero_point) and zero_point.dtype == input.dtype))
+            and input.dtype in (torch.bfloat16, torch.float32))
+    if fast:
+        L = _native.lib()
+        x = input.contiguous()
+        y = torch.empty_like(x)
+        if x.numel():
+            s = _scalar_like(scale, x)
+            z = _scalar_like(zero_point, x) if zero_point is not None else None
+            fn = L.qt_dequantize_bf16 if x.dtype == torch.bfloat16 else L.qt_dequantize_f32
+            _native.check(fn(x.data_ptr(), y.data_ptr(), x.numel(), s.data_ptr(),
+                             z.data_ptr() if z is not None else None,
+                             input_qmap.data_ptr() if input_qmap is not None else None,
+                             output_qmap.data_ptr() if output_qmap is not None else None, _stream_ptr(x)),
+                          "qt_dequantize")
+        return y
+    if input_qmap is not None:
+        input = torch.ops.quantized_ops.vmap(input, input_qmap)
+    if block_size is not None:
+        scale = expand(scale, input.shape, block_size)
+        if zero_point is not None:
+            zero_point = expand(zero_point, input.shape, block_size)
+    out = input * scale if zero_point is None else (input - zero_point) * scale
+    if output_qmap is not None:
+        out = torch.ops.quantized_ops.vmap(out, output_qmap)
+    return out
+
+
+for _key in ("CPU", "CUDA"):
+    _lib.impl("quantize", _quantize_impl, _key)
+    _lib.impl("dequantize", _dequantize_impl, _key)
+_lib.impl("quantize", lambda input, *a, **k: torch.empty_like(input, memory_format=torch.contiguous_format), "Meta")
+_lib.impl("dequantize", lambda input, *a, **k: torch.empty_like(input), "Meta")
+
+
+def quantize(input, scale, zero_point=None, axes=None, block_size=None, qmap=None, output_code=None):
+    """``vmap(input / scale [+ zero_point], qmap)`` (upstream decomposed.py:173-210)."""
+    return torch.ops.quantized_ops.quantize(input, scale, zero_point, axes, block_size, qmap, output_code)
+
+
+def dequantize(input, scale, zero_point=None, axes=None, block_size=None, input_qmap=None, output_qmap=None):
+    """``(vmap?(input) [- zero_point]) * scale`` then optional output map (upstream decomposed.py:220-262)."""
+    return torch.ops.quantized_ops.dequantize(input, scale, zero_point, axes, block_size, input_qmap, output_qmap)
+
+
+# ---- GEMM pass-throughs (operands arrive already fake-quantized; upstream decomposed.py:77-94) -----
+_lib.impl("linear", lambda input, weight, bias=None: F.linear(input, weight, bias), "CompositeExplicitAutograd")
+_lib.impl("matmul", lambda self, other: torch.matmul(self, other), "CompositeExplicitAutograd")

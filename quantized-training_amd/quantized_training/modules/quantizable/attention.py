@@ -1,0 +1,205 @@
+"""Quantizable twins of the Hugging Face attention / output blocks.
+
+The reference re-implements whole HF blocks so that QK^T, score scaling, softmax, AV and the
+residual add become hookable sub-modules (upstream modules/quantizable/modeling_bert.py:59-62,118,
+142,148,158,185-190; modeling_mobilebert.py:52-55,80-93,117-176; modeling_llama.py:131-134,228,
+244-246 -- the LLaMA twin is disabled upstream because it imports symbols removed from HF).
+
+Here the HF modules are converted IN PLACE instead, which survives HF version drift:
+  * attention blocks get the sub-modules ``qk_matmul``, ``attn_scaling``, ``softmax``,
+    ``av_matmul`` (same names as upstream, so hook and state-dict keys match) and a private config
+    view that routes HF's ``ALL_ATTENTION_FUNCTIONS`` dispatch to ``quantizable_attention_forward``;
+  * output blocks (``LayerNorm(dense(x) + residual)``) get a ``residual`` AddFunctional and a
+    forward that uses it.
+Every class keeps upstream's ``from_observed(float_module)`` constructor.
+"""
+import torch
+from torch import nn
+
+from .functional_modules import AddFunctional, MatmulFunctional, MulFunctional
+
+__all__ = [
+    "quantizable_attention_forward", "QuantizableAttentionCore", "Fp32Softmax",
+    "BertSelfAttention", "BertSelfOutput", "BertOutput",
+    "MobileBertSelfAttention", "MobileBertSelfOutput", "FFNOutput", "MobileBertOutput",
+    "LlamaAttention",
+]
+
+ATTN_IMPL_NAME = "qt_quantizable"
+
+
+class Fp32Softmax(nn.Softmax):
+    """softmax computed in fp32 and cast back (what HF's LLaMA eager attention does)."""
+
+    def forward(self, input):
+        return nn.functional.softmax(input, dim=self.dim, dtype=torch.float32).to(input.dtype)
+
+
+def _repeat_kv(x, n_rep):
+    if n_rep == 1:
+        return x
+    b, h, s, d = x.shape
+    return x[:, :, None, :, :].expand(b, h, n_rep, s, d).reshape(b, h * n_rep, s, d)
+
+
+def quantizable_attention_forward(module, query, key, value, attention_mask, scaling=None, dropout=0.0, **kwargs):
+    """Drop-in for HF's ``eager_attention_forward`` that goes through the module's hookable ops:
+    ``av_matmul(softmax(attn_scaling(qk_matmul(q, k^T), scale) + mask), v)``."""
+    n_rep = getattr(module, "num_key_value_groups", 1)
+    key = _repeat_kv(key, n_rep)
+    value = _repeat_kv(value, n_rep)
+    if scaling is None:
+        scaling = query.size(-1) ** -0.5
+    scores = module.qk_matmul(query, key.transpose(2, 3))
+    scores = module.attn_scaling(scores, scaling)
+    if attention_mask is not None:
+        scores = scores + attention_mask[..., : key.shape[-2]]
+    probs = module.softmax(scores)
+    probs = nn.functional.dropout(probs, p=dropout, training=module.training)
+    out = module.av_matmul(probs, value)
+    return out.transpose(1, 2).contiguous(), probs
+
+
+def _register_interface():
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+    if ATTN_IMPL_NAME not in ALL_ATTENTION_FUNCTIONS:
+        ALL_ATTENTION_FUNCTIONS.register(ATTN_IMPL_NAME, quantizable_attention_forward)
+
+
+class _AttnConfigView:
+    """The module's config with ``_attn_implementation`` pinned to the quantizable interface.
+    Only the attention block sees it; mask construction keeps using the model's real config."""
+
+    _attn_implementation = ATTN_IMPL_NAME
+
+    def __init__(self, base):
+        object.__setattr__(self, "_base", base)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_base"), name)
+
+
+class QuantizableAttentionCore:
+    """Shared conversion for every HF attention block that dispatches through
+    ``ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, ...)``
+    (BERT, RoBERTa, MobileBERT, LLaMA, ... in the installed transformers)."""
+
+    softmax_cls = nn.Softmax
+
+    @classmethod
+    def from_observed(cls, other):
+        assert hasattr(other, "config"), "The float module must have 'config'"
+        _register_interface()
+        if not hasattr(other, "qk_matmul"):
+            other.qk_matmul = MatmulFunctional()
+            other.av_matmul = MatmulFunctional()
+            other.attn_scaling = MulFunctional()
+            other.softmax = cls.softmax_cls(dim=-1)
+        base = other.config._base if isinstance(other.config, _AttnConfigView) else other.config
+        other.config = _AttnConfigView(base)
+        return other
+
+
+class BertSelfAttention(QuantizableAttentionCore):
+    """BERT / RoBERTa self-attention; softmax in the model dtype (upstream modeling_bert.py:62,148)."""
+
+
+class MobileBertSelfAttention(QuantizableAttentionCore):
+    """upstream modeling_mobilebert.py:52-55,80-93"""
+
+
+class LlamaAttention(QuantizableAttentionCore):
+    """HF LLaMA upcasts the softmax to fp32; grouped-query heads are repeated before QK^T."""
+
+    softmax_cls = Fp32Softmax
+
+
+# ---- output blocks: LayerNorm(dense(x) + residual) ------------------------------------------------
+def _bert_output_forward(self, hidden_states, input_tensor):
+    hidden_states = self.dropout(self.dense(hidden_states))
+    return self.LayerNorm(self.residual(hidden_states, input_tensor))
+
+
+def _mobilebert_self_output_forward(self, hidden_states, residual_tensor):
+    out = self.dense(hidden_states)
+    if not self.use_bottleneck:
+        out = self.dropout(out)
+    return self.LayerNorm(self.residual(out, residual_tensor))
+
+
+def _ffn_output_forward(self, hidden_states, residual_tensor):
+    return self.LayerNorm(self.residual(self.dense(hidden_states), residual_tensor))
+
+
+def _mobilebert_output_forward(self, intermediate_states, residual_tensor_1, residual_tensor_2):
+    out = self.dense(intermediate_states)
+    if not self.use_bottleneck:
+        out = self.dropout(out)
+        return self.LayerNorm(out + residual_tensor_1)       # not hooked upstream either (modeling_mobilebert.py:163-165)
+    out = self.LayerNorm(self.residual(out, residual_tensor_1))
+    return self.bottleneck(out, residual_tensor_2)
+
+
+_TWIN_CACHE = {}
+
+
+def _swap_forward(module, forward):
+    """Re-class ``module`` to a subclass of its own HF class whose forward is ``forward``."""
+    base = type(module)
+    if getattr(base, "_qt_twin", False):
+        return module
+    key = (base, forward)
+    twin = _TWIN_CACHE.get(key)
+    if twin is None:
+        twin = type(base.__name__, (base,), {"forward": forward, "_qt_twin": True, "__module__": __name__})
+        _TWIN_CACHE[key] = twin
+    module.__class__ = twin
+    return module
+
+
+class _ResidualOutput:
+    forward_fn = None
+
+    @classmethod
+    def from_observed(cls, other):
+        if not hasattr(other, "residual"):
+            other.residual = AddFunctional()
+        return _swap_forward(other, cls.forward_fn)
+
+
+class BertSelfOutput(_ResidualOutput):
+    """upstream modeling_bert.py:174-190"""
+    forward_fn = _bert_output_forward
+
+
+class BertOutput(_ResidualOutput):
+    """upstream modeling_bert.py:201-214"""
+    forward_fn = _bert_output_forward
+
+
+class MobileBertSelfOutput(_ResidualOutput):
+    """upstream modeling_mobilebert.py:109-123"""
+    forward_fn = _mobilebert_self_output_forward
+
+
+class FFNOutput(_ResidualOutput):
+    """upstream modeling_mobilebert.py:190-200"""
+    forward_fn = _ffn_output_forward
+
+
+class MobileBertOutput(_ResidualOutput):
+    """upstream modeling_mobilebert.py:148-186 (its inner OutputBottleneck gets a residual too, :134-146)"""
+    forward_fn = _mobilebert_output_forward
+
+    @classmethod
+    def from_observed(cls, other):
+        inner = getattr(other, "bottleneck", None)
+        if inner is not None and not hasattr(inner, "residual"):
+            inner.residual = AddFunctional()
+            _swap_forward(inner, _mobilebert_self_output_forward_bottleneck)
+        return super().from_observed(other)
+
+
+def _mobilebert_self_output_forward_bottleneck(self, hidden_states, residual_tensor):
+    out = self.dropout(self.dense(hidden_states))
+    return self.LayerNorm(self.residual(out, residual_tensor))

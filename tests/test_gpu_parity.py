@@ -1,0 +1,377 @@
+"""GPU parity: the HIP kernels (called through the C ABI of include/qt_hip.h) against the CPU oracle
+and the committed golden vectors.  Bit-exact for every elementwise path (NaNs compared as NaN);
+the GEMMs are compared within an fp32-accumulation tolerance stated in the test.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qt_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def nv():
+    from quantized_training import _native
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    _native.lib()
+    return _native
+
+
+def dev_u16(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).cuda()
+
+
+def dev_f32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host_u16(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def host_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+LUT_FMT = (0, 0, 0, 0.0, 0.0)
+
+DTYPES = ["int8", "int4", "uint8", "e4m3", "e5m2", "fp8_e4m3", "fp8_e5m2", "fp6_e3m2", "fp4_e2m1",
+          "posit8_0", "posit8_1", "posit8_2", "posit16_1"]
+
+
+def run_fq_bf16(nv, xbits, dtype, scale, force_lut=False, observe=False):
+    L = nv.lib()
+    x = dev_u16(xbits)
+    y = torch.empty_like(x)
+    lut = dev_u16(nv.build_map_u16(dtype))
+    fmt = nv.QtFormat(*LUT_FMT) if force_lut else nv.format_for(dtype)
+    s = dev_f32(np.array([scale], np.float32))
+    amax = torch.zeros(1, dtype=torch.int32, device="cuda") if observe else None
+    nv.check(L.qt_fake_quant_bf16(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(),
+                                  s.data_ptr(), amax.data_ptr() if observe else None, stream()), "fq")
+    torch.cuda.synchronize()
+    return host_u16(y), (host_u32(amax)[0] if observe else None)
+
+
+def run_fq_f32(nv, x, dtype, scale, force_lut=False, observe=False):
+    L = nv.lib()
+    xd = dev_f32(x)
+    y = torch.empty_like(xd)
+    lut = dev_u16(nv.build_map_u16(dtype))
+    fmt = nv.QtFormat(*LUT_FMT) if force_lut else nv.format_for(dtype)
+    s = dev_f32(np.array([scale], np.float32))
+    amax = torch.zeros(1, dtype=torch.int32, device="cuda") if observe else None
+    nv.check(L.qt_fake_quant_f32(xd.data_ptr(), y.data_ptr(), xd.numel(), ctypes.byref(fmt), lut.data_ptr(),
+                                 s.data_ptr(), amax.data_ptr() if observe else None, stream()), "fq")
+    torch.cuda.synchronize()
+    return host_u32(y), (host_u32(amax)[0] if observe else None)
+
+
+def expect_bf16(xbits, dtype, scale):
+    qmap = o.get_quantization_map(dtype)
+    sb = o.f32_to_bf16(np.array([scale], np.float32))
+    return o.canon_nan16(o.fq_bf16(xbits, qmap, sb))
+
+
+def expect_f32(x, dtype, scale):
+    qmap = o.get_quantization_map(dtype)
+    return o.canon_nan32(o.fq_f32(x, qmap, np.float32(scale)).view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", [1.0, 0.037, 0.125, 3.5, 1e-3])
+def test_exhaustive_bf16_all_patterns(nv, dtype, scale):
+    """All 65 536 bf16 inputs, closed form (where there is one) and table kernels."""
+    x = o.all_bf16_patterns()
+    exp = expect_bf16(x, dtype, scale)
+    for force_lut in (False, True):
+        got, _ = run_fq_bf16(nv, x, dtype, scale, force_lut)
+        assert np.array_equal(o.canon_nan16(got), exp), (dtype, scale, force_lut)
+
+
+@pytest.mark.parametrize("dtype", ["int8", "e4m3", "e5m2", "posit8_1", "fp8_e4m3", "posit16_1", "uint8"])
+def test_closed_form_equals_table_on_device(nv, dtype):
+    x = o.all_bf16_patterns()
+    a, _ = run_fq_bf16(nv, x, dtype, 1.0, False)
+    b, _ = run_fq_bf16(nv, x, dtype, 1.0, True)
+    assert np.array_equal(o.canon_nan16(a), o.canon_nan16(b))
+    assert np.array_equal(o.canon_nan16(a), o.get_quantization_map(dtype))
+
+
+def _sample_f32(n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(n // 2).astype(np.float32) * np.float32(10.0) ** rng.uniform(-3, 3, n // 2).astype(np.float32)
+    b = (np.sign(rng.standard_normal(n - n // 2)) * 2.0 ** rng.uniform(-30, 30, n - n // 2)).astype(np.float32)
+    x = np.concatenate([a, b]).astype(np.float32)
+    u = x.view(np.uint32).copy()
+    u[::7] &= 0xFFFF0000                       # exactly bf16-representable
+    u[1::7] = (u[1::7] & 0xFFFF0000) | 1       # sticky fold
+    x = u.view(np.float32)
+    x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 100.7, 127.5, -128.5]
+    return x
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", [1.0, 0.0123, 2.0])
+def test_f32_inputs(nv, dtype, scale):
+    x = _sample_f32(1 << 16, 3)
+    exp = expect_f32(x, dtype, scale)
+    for force_lut in (False, True):
+        got, _ = run_fq_f32(nv, x, dtype, scale, force_lut)
+        assert np.array_equal(o.canon_nan32(got), exp), (dtype, scale, force_lut)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 4095, 4096, 4097, (1 << 21) + 13, (1 << 22) + 8 * 1024 * 5 + 3])
+@pytest.mark.parametrize("dtype", ["e4m3", "posit8_1"])
+def test_sizes_and_tails_bf16(nv, n, dtype):
+    """Empty, ragged and multi-tile sizes: vector body, ragged last tile, scalar tail, table-in-LDS kernel."""
+    rng = np.random.default_rng(n + 1)
+    x = rng.integers(0, 65536, n, dtype=np.uint32).astype(np.uint16)
+    if n == 0:
+        L = nv.lib()
+        fmt = nv.format_for(dtype)
+        assert L.qt_fake_quant_bf16(None, None, 0, ctypes.byref(fmt), None, None, None, stream()) == 0
+        return
+    for scale in (1.0, 0.3):
+        got, amax = run_fq_bf16(nv, x, dtype, scale, observe=True)
+        assert np.array_equal(o.canon_nan16(got), expect_bf16(x, dtype, scale)), (n, scale)
+        finite = x[(x & 0x7FFF) <= 0x7F80]
+        nan_in = np.any((x & 0x7FFF) > 0x7F80)
+        if nan_in:
+            assert (amax & 0x7FFFFFFF) > 0x7F800000
+        else:
+            assert amax == (int((finite & 0x7FFF).max()) << 16)
+
+
+@pytest.mark.parametrize("n", [5, 4099, (1 << 21) + 5])
+def test_sizes_and_tails_f32(nv, n):
+    x = _sample_f32(max(n, 16), n)[:n]
+    x = np.where(np.isnan(x), np.float32(1.0), x).astype(np.float32)
+    for dtype in ("e4m3", "posit8_1", "int8"):
+        got, amax = run_fq_f32(nv, x, dtype, 0.25, observe=True)
+        assert np.array_equal(o.canon_nan32(got), expect_f32(x, dtype, 0.25))
+        assert amax == int(np.abs(x).max().view(np.uint32))
+
+
+def test_unaligned_pointers(nv):
+    """Views at odd element offsets take the element-granular kernel."""
+    L = nv.lib()
+    xb = np.random.default_rng(0).integers(0, 65536, 10001, dtype=np.uint32).astype(np.uint16)
+    x = dev_u16(xb)
+    y = torch.zeros_like(x)
+    fmt = nv.format_for("e4m3")
+    nv.check(L.qt_fake_quant_bf16(x.data_ptr() + 2, y.data_ptr() + 6, 9000, ctypes.byref(fmt), None, None, None, stream()), "fq")
+    torch.cuda.synchronize()
+    assert np.array_equal(o.canon_nan16(host_u16(y)[3:9003]), expect_bf16(xb[1:9001], "e4m3", 1.0))
+
+
+def test_vmap_golden(nv):
+    d = np.load(os.path.join(G, "vmap.npz"))
+    L = nv.lib()
+    for dt in ["int8", "int4", "e4m3", "e5m2", "fp8_e4m3", "fp4_e2m1", "posit8_1", "posit16_1"]:
+        lut = dev_u16(nv.build_map_u16(dt))
+        fmt = nv.format_for(dt)
+        x = dev_u16(d["xb"]); y = torch.empty_like(x)
+        nv.check(L.qt_vmap_bf16(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(), stream()), "vmap")
+        assert np.array_equal(o.canon_nan16(host_u16(y)), d[f"yb_{dt}"]), dt
+        x = torch.from_numpy(d["x32"].view(np.float32)).cuda(); y = torch.empty_like(x)
+        nv.check(L.qt_vmap_f32(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(), stream()), "vmap")
+        assert np.array_equal(o.canon_nan32(host_u32(y)), d[f"y32_{dt}"]), dt
+        x = dev_u16(d["xh"]); y = torch.empty_like(x)
+        nv.check(L.qt_vmap_f16(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(), stream()), "vmap")
+        got, exp = host_u16(y), d[f"yh_{dt}"]
+        nan = ((exp & 0x7C00) == 0x7C00) & ((exp & 0x3FF) != 0)
+        assert np.array_equal(got[~nan], exp[~nan]), dt
+        assert np.all(((got[nan] & 0x7C00) == 0x7C00) & ((got[nan] & 0x3FF) != 0))
+
+
+def test_direct_rounding_golden(nv):
+    d = np.load(os.path.join(G, "direct_fns.npz"))
+    L = nv.lib()
+    x = torch.from_numpy(d["x"].view(np.float32)).cuda()
+    y = torch.empty_like(x)
+    nv.check(L.qt_round_fp8_f32(x.data_ptr(), y.data_ptr(), x.numel(), 3, 448.0, 2.0 ** -6, stream()), "fp8")
+    assert np.array_equal(o.canon_nan32(host_u32(y)), d["e4m3"])
+    nv.check(L.qt_round_fp8_f32(x.data_ptr(), y.data_ptr(), x.numel(), 2, 57344.0, 2.0 ** -14, stream()), "fp8")
+    assert np.array_equal(o.canon_nan32(host_u32(y)), d["e5m2"])
+    for nb, es in [(8, 0), (8, 1), (8, 2), (16, 1), (16, 2), (6, 1)]:
+        nv.check(L.qt_round_posit_f32(x.data_ptr(), y.data_ptr(), x.numel(), nb, es, stream()), "posit")
+        assert np.array_equal(o.canon_nan32(host_u32(y)), d[f"posit{nb}_{es}"]), (nb, es)
+
+
+def test_ops_quantize_dequantize_golden(nv):
+    """torch.ops.quantized_ops.quantize / dequantize on device tensors against the reference's outputs."""
+    import quantized_training as qt
+    d = np.load(os.path.join(G, "quant_dequant.npz"))
+    cases = json.load(open(os.path.join(G, "quant_dequant.json")))
+    q = torch.ops.quantized_ops
+    for c in cases:
+        n = c["name"]
+        qmap = qt.get_quantization_map(c["dtype"], "cuda")
+        if c["in"] == "f32":
+            x = torch.from_numpy(d["x32"].view(np.float32)).cuda()
+            s = torch.from_numpy(d[n + "_scale"].view(np.float32)).cuda()
+            can = lambda t: o.canon_nan32(host_u32(t))  # noqa: E731
+        else:
+            x = dev_u16(d["xb"]).view(torch.bfloat16)
+            s = dev_u16(d[n + "_scale"]).view(torch.bfloat16)
+            can = lambda t: o.canon_nan16(host_u16(t.view(torch.int16)))  # noqa: E731
+        yq = q.quantize(x, s, None, None, None, qmap)
+        assert np.array_equal(can(yq), d[n + "_q"]), n
+        assert np.array_equal(can(q.dequantize(yq, s, None, None, None, None, None)), d[n + "_dq"]), n
+        assert np.array_equal(can(q.dequantize(x, s, None, None, None, qmap, qmap)), d[n + "_dq2"]), n
+    qmap = qt.get_quantization_map("uint8", "cuda")
+    x = torch.from_numpy(d["x32"].view(np.float32)).cuda()
+    s, z = torch.tensor([0.05], device="cuda"), torch.tensor([128.0], device="cuda")
+    yq = q.quantize(x, s, z, None, None, qmap)
+    assert np.array_equal(o.canon_nan32(host_u32(yq)), d["zp_q"])
+    assert np.array_equal(o.canon_nan32(host_u32(q.dequantize(yq, s, z, None, None, None, None))), d["zp_dq"])
+
+
+FQ_META = json.load(open(os.path.join(G, "fake_quant.json")))
+
+
+@pytest.mark.parametrize("case", FQ_META, ids=[c["name"] for c in FQ_META])
+def test_module_traces_golden(nv, case):
+    """FusedAmaxObsFakeQuantize on device tensors reproduces the reference's multi-call traces:
+    outputs, scale and amax_history after every call (delayed scaling, per-channel, pow2, NaN / zero guards)."""
+    from dataclasses import asdict
+    import quantized_training as qt
+    d = np.load(os.path.join(G, "fake_quant.npz"))
+    kw = asdict(qt.QuantizationSpec.from_str(case["spec"]))
+    m = qt.FusedAmaxObsFakeQuantize(**kw, force_scale_power_of_two=case["pow2"], device="cuda")
+    bf16 = case["in"] == "bf16"
+    for ci in range(case["n_calls"]):
+        k = f"{case['name']}__{ci}__"
+        if bf16:
+            x = dev_u16(d[k + "x"]).view(torch.bfloat16).reshape(case["shape"])
+        else:
+            x = torch.from_numpy(d[k + "x"].view(np.float32)).cuda().reshape(case["shape"])
+        with torch.no_grad():
+            y = m(x)
+        assert y.dtype == x.dtype and y.shape == x.shape
+        if bf16:
+            assert np.array_equal(o.canon_nan16(host_u16(y.contiguous().view(torch.int16))).reshape(-1), d[k + "y"].reshape(-1)), ci
+        else:
+            assert np.array_equal(o.canon_nan32(host_u32(y.contiguous())).reshape(-1), d[k + "y"].reshape(-1)), ci
+        assert np.array_equal(host_u32(m.scale.reshape(-1)), d[k + "scale"]), (ci, m.scale)
+        if m._observe:
+            assert np.array_equal(o.canon_nan32(host_u32(m.amax_history.reshape(-1))), d[k + "hist"]), ci
+            assert list(m.amax_history.shape) == case["calls"][ci]["hist_shape"]
+            assert list(m.scale.shape) == case["calls"][ci]["scale_shape"]
+    assert sorted(m.state_dict().keys()) == sorted(case["state_dict"].keys())
+
+
+def _oracle_fq_matrix(xbits, dtype, scale):
+    return o.bf16_to_f32(o.fq_bf16(xbits, o.get_quantization_map(dtype), o.f32_to_bf16(np.array([scale], np.float32))))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (100, 72, 136), (1, 16, 8), (333, 130, 1000)])
+@pytest.mark.parametrize("wdtype,wscale", [("e4m3", 1.0), ("int8", 0.02), ("posit8_1", 1.0), (None, 1.0)])
+def test_linear_fq_gemm(nv, M, N, K, wdtype, wscale):
+    """y = x @ fq(W)^T + b: operands quantized exactly like the oracle, fp32 accumulation.
+    Tolerance: |err| <= 2^-7 * |y| + 1e-2 * sqrt(K) * 2^-8 (one bf16 output rounding + accumulation order)."""
+    L = nv.lib()
+    rng = np.random.default_rng(M * 131 + N * 7 + K)
+    xb = o.f32_to_bf16(rng.standard_normal((M, K)).astype(np.float32))
+    wb = o.f32_to_bf16((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+    bb = o.f32_to_bf16(rng.standard_normal(N).astype(np.float32))
+    x, w, b = dev_u16(xb), dev_u16(wb), dev_u16(bb)
+    y = torch.empty((M, N), dtype=torch.int16, device="cuda")
+    qx = nv.QtOperandQ(); qx.fmt = nv.QtFormat(nv.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
+    qw = nv.QtOperandQ()
+    amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+    keep = []
+    if wdtype is None:
+        qw.fmt = nv.QtFormat(nv.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
+        wq = o.bf16_to_f32(wb)
+    else:
+        qw.fmt = nv.format_for(wdtype)
+        lut = dev_u16(nv.build_map_u16(wdtype)); keep.append(lut)
+        qw.lut_dev = lut.data_ptr()
+        s = dev_f32(np.array([wscale], np.float32)); keep.append(s)
+        qw.scale_f32_dev = s.data_ptr()
+        qw.amax_bits_dev = amax.data_ptr()
+        wq = _oracle_fq_matrix(wb, wdtype, wscale)
+    nv.check(L.qt_linear_fq_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K,
+                                 ctypes.byref(qx), ctypes.byref(qw), stream()), "linear")
+    torch.cuda.synchronize()
+    got = o.bf16_to_f32(host_u16(y))
+    ref = o.bf16_to_f32(xb).astype(np.float64) @ wq.astype(np.float64).T + o.bf16_to_f32(bb).astype(np.float64)
+    tol = 2.0 ** -7 * np.abs(ref) + 1e-2 * np.sqrt(K) * 2.0 ** -8
+    assert np.all(np.abs(got - ref) <= tol), float(np.max(np.abs(got - ref) - tol))
+    if wdtype is not None:
+        assert host_u32(amax)[0] == (int((wb & 0x7FFF).max()) << 16)
+
+
+@pytest.mark.parametrize("nn_layout", [False, True])
+def test_bmm_fq_gemm(nv, nn_layout):
+    """Batched QK^T-style (k-contiguous B) and AV-style (n-contiguous B) products with both operands quantized."""
+    L = nv.lib()
+    B, M, N, K = 3, 200, 136, 72
+    rng = np.random.default_rng(5)
+    ab = o.f32_to_bf16(rng.standard_normal((B, M, K)).astype(np.float32))
+    if nn_layout:
+        bb = o.f32_to_bf16(rng.standard_normal((B, K, N)).astype(np.float32))
+        ldb_k, ldb_n = N, 1
+    else:
+        bb = o.f32_to_bf16(rng.standard_normal((B, N, K)).astype(np.float32))
+        ldb_k, ldb_n = 1, K
+    a, b = dev_u16(ab), dev_u16(bb)
+    y = torch.empty((B, M, N), dtype=torch.int16, device="cuda")
+    lut = dev_u16(nv.build_map_u16("e4m3"))
+    amax_a = torch.zeros(1, dtype=torch.int32, device="cuda")
+    amax_b = torch.zeros(1, dtype=torch.int32, device="cuda")
+    qa = nv.QtOperandQ(); qa.fmt = nv.format_for("e4m3"); qa.amax_bits_dev = amax_a.data_ptr()
+    qb = nv.QtOperandQ(); qb.fmt = nv.QtFormat(*LUT_FMT); qb.lut_dev = lut.data_ptr(); qb.amax_bits_dev = amax_b.data_ptr()
+    nv.check(L.qt_bmm_fq_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), B, M, N, K, K, M * K, ldb_k, ldb_n, N * K,
+                              ctypes.byref(qa), ctypes.byref(qb), stream()), "bmm")
+    torch.cuda.synchronize()
+    aq = _oracle_fq_matrix(ab, "e4m3", 1.0).astype(np.float64)
+    bq = _oracle_fq_matrix(bb, "e4m3", 1.0).astype(np.float64)
+    ref = aq @ (bq if nn_layout else bq.transpose(0, 2, 1))
+    got = o.bf16_to_f32(host_u16(y))
+    tol = 2.0 ** -7 * np.abs(ref) + 1e-2 * np.sqrt(K) * 2.0 ** -8
+    assert np.all(np.abs(got - ref) <= tol)
+    assert host_u32(amax_a)[0] == (int((ab & 0x7FFF).max()) << 16)
+    assert host_u32(amax_b)[0] == (int((bb & 0x7FFF).max()) << 16)
+
+
+def test_full_size_properties(nv):
+    """LLaMA-2-7B sized tensor (4096 x 11008 bf16): size-independent properties --
+    idempotence fq(fq(x)) == fq(x), the output only takes map values, and amax == max|x|."""
+    L = nv.lib()
+    torch.manual_seed(0)
+    x = (torch.randn(4096, 11008, device="cuda") * 0.02).bfloat16()
+    for dtype in ("e4m3", "posit8_1"):
+        fmt = nv.format_for(dtype)
+        lut = dev_u16(nv.build_map_u16(dtype))
+        y = torch.empty_like(x); z = torch.empty_like(x)
+        amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+        nv.check(L.qt_fake_quant_bf16(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(), None,
+                                      amax.data_ptr(), stream()), "fq")
+        nv.check(L.qt_fake_quant_bf16(y.data_ptr(), z.data_ptr(), x.numel(), ctypes.byref(fmt), lut.data_ptr(), None,
+                                      None, stream()), "fq")
+        assert torch.equal(y.view(torch.int16), z.view(torch.int16))
+        assert amax.view(torch.float32).item() == x.abs().max().float().item()
+        # spot-check 1M elements against the oracle
+        idx = torch.randint(0, x.numel(), (1 << 20,), device="cuda")
+        xs = host_u16(x.view(-1)[idx].view(torch.int16))
+        ys = host_u16(y.view(-1)[idx].view(torch.int16))
+        assert np.array_equal(ys, expect_bf16(xs, dtype, 1.0))
+        vals = torch.unique(y.view(torch.int16)).cpu().numpy().view(np.uint16)
+        assert np.all(np.isin(vals, o.get_quantization_map(dtype)))
