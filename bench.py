@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fake-quant hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch: the forward of ONE WikiText-style window
+(B=1, S=1024) through a LLaMA-2-7B-shaped model with E4M3 fake-quant on every GEMM input and
+weight (`--activation e4m3 --weight e4m3 --bf16 --quantize_forward gemm`, the reference's
+"full fusion" column), weights re-quantized every forward exactly as the reference does.
+Metric (BASELINE.json): quantized elements / s = sum over fake-quant applications of numel(input)
+/ wall time.  N > 1: one process per GPU, windows sharded round-robin, no data-path collective;
+value = units of all ranks / max-over-ranks time (weak scaling).
+
+Synthetic data: no checkpoint or dataset exists offline -> weights ~ N(0, 0.02) from a fixed seed,
+token ids uniform random.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0) with `roofline` (dominant elementwise pass, HIP events on the launch
+stream, rotating over a > 256 MiB pool so HBM rather than Infinity-Cache traffic is timed) and
+`cpu_baseline` (the C restatement of the reference path on this host's cores, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "quantized-training_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="llama-2-7b")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the line is then marked invalid)")
+    ap.add_argument("--max_length", type=int, default=1024)
+    ap.add_argument("--stride", type=int, default=512)
+    ap.add_argument("--activation", default="e4m3")
+    ap.add_argument("--weight", default="e4m3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def roofline_leg(device):
+    """Dominant kernel of the path: the fused fake-quant pass on a 4096 x 11008 bf16 tensor
+    (LLaMA-2-7B gate/up/down weight).  Algorithmic bytes: 4 B/element (2 read + 2 written)."""
+    from quantized_training import _native as nv
+    import quantized_training as qt
+    L = nv.lib()
+    rows, cols, pool = 4096, 11008, 8                       # 8 x 90 MB in + 8 x 90 MB out = 1.44 GB
+    n = rows * cols
+    x = (torch.randn(pool, rows, cols, device=device, dtype=torch.float32) * 0.02).bfloat16() \
+        if False else torch.empty(pool, rows, cols, device=device, dtype=torch.bfloat16).normal_(0.0, 0.02)
+    y = torch.empty_like(x)
+    fmt = nv.format_for("e4m3")
+    lut = qt.get_quantization_map("e4m3", device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    ms = ctypes.c_float(0.0)
+    for iters in (pool, 5 * pool):                           # warm-up pass, then the timed region
+        nv.check(L.qt_bench_fake_quant_bf16(x.data_ptr(), y.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(),
+                                            None, None, iters, n, pool, st, ctypes.byref(ms)), "bench")
+    achieved = n * 4 / (ms.value * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    del x, y
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "kernel": "fq_kernel<bf16,FP_SAT> e4m3 4096x11008", "ms_per_launch": round(ms.value, 5),
+            "algorithmic_bytes_per_launch": n * 4}
+
+
+def cpu_baseline_leg():
+    """The reference-semantics path (C restatement, oracle/qt_oracle.c, validated against the
+    reference's golden vectors) on this host's cores, bounded sample of the same workload:
+    the bf16 4096 x 11008 E4M3 tensor quantized repeatedly for about 10-20 s."""
+    import numpy as np
+    from oracle import c_oracle, qt_oracle
+    rng = np.random.default_rng(0)
+    n = 4096 * 11008
+    x = qt_oracle.f32_to_bf16((rng.standard_normal(n) * 0.02).astype(np.float32))
+    y = np.empty_like(x)
+    qmap = qt_oracle.get_quantization_map("e4m3")
+    one = int(qt_oracle.f32_to_bf16(np.array([1.0], np.float32))[0])
+    c_oracle.fake_quant_bf16(x[: 1 << 20], qmap, one)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        c_oracle.fake_quant_bf16(x, qmap, one, out=y)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or reps >= 400:
+            break
+    return {"value": reps * n / el, "unit": "elements/s", "cores": c_oracle.num_threads(), "kind": "port",
+            "sample": f"{reps} x bf16[4096,11008] E4M3 fake-quant passes (scale 1), {el:.1f} s, OpenMP static"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import quantized_training as qt
+    from quantized_training import harness
+    from quantized_training.fake_quantize import STATS
+
+    model = harness.build_causal_lm(a.model, device=device, seed=0, num_layers=a.layers)
+    qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--bf16",
+                                            "--quantize_forward", "gemm"])
+    qt.quantize(model, qargs)
+
+    vocab = model.config.vocab_size
+    gen = torch.Generator().manual_seed(0)
+    tokens = torch.randint(0, vocab, (1, 341_469), generator=gen)         # wikitext-2 test length in LLaMA tokens
+    windows = harness.wikitext_windows(tokens.shape[1], a.max_length, a.stride)
+    mine = harness.shard_round_robin(windows, rank, world)
+    need = a.warmup + a.steps
+    assert len(mine) >= need, "not enough windows"
+    batches = [(tokens[:, b:e].to(device), t) for (b, e, t) in mine[:need]]   # resident before timing
+
+    nlls = []
+    with torch.no_grad():
+        for i in range(a.warmup):                     # first call creates the per-tensor fake-quantizers
+            harness.window_nll(model, *batches[i])
+        STATS.reset()
+        harness.window_nll(model, *batches[0])
+        torch.cuda.synchronize()
+        elems_per_step = STATS.elements
+        calls_per_step = STATS.calls
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            nlls.append(harness.window_nll(model, *batches[a.warmup + i]))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    t = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    local = torch.stack(nlls)
+    allnll = harness.gather_in_order(local, a.steps * world, rank, world) if world > 1 else local
+
+    out = None
+    if rank == 0:
+        total_elems = elems_per_step * a.steps * world
+        hidden, layers = model.config.hidden_size, model.config.num_hidden_layers
+        full = a.layers is None
+        out = {
+            "metric": "quantized_elements_per_sec",
+            "value": total_elems / el,
+            "unit": "elements/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.model}-shaped LLaMA ({layers} layers, hidden {hidden}, random init) "
+                                   f"WikiText-style window eval B=1 S={a.max_length} stride {a.stride}, "
+                                   f"fake-quant activation={a.activation} weight={a.weight}, --quantize_forward gemm "
+                                   f"(weights re-quantized every forward)",
+                       "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
+                       "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
+                       "valid": bool(full)},
+            "mean_window_nll": float(allnll.double().mean().item()),
+        }
+    if rank == 0 and world == 1:
+        del model
+        torch.cuda.empty_cache()
+        if not a.no_roofline:
+            out["roofline"] = roofline_leg(device)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

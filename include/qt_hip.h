@@ -133,6 +133,14 @@ int qt_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const q
 int qt_fake_quant_f32(const float *x_dev, float *y_dev, size_t n, const qt_format *fmt,
                       const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
                       void *stream);
+/* Same pass for e4m3 / e5m2 that ALSO (or only) emits the quantized code q = vmap(x / s) as one OCP
+ * FP8 byte per element (y8_dev; exact, every e4m3/e5m2 value is an FP8 value), for FP8-MFMA GEMMs:
+ * (q, s) is what the reference's converted graphs feed the GEMM (quantize -> GEMM ->
+ * dequantize(s_x * s_w), quantize_pt2e.py:323-446).  y_dev (bf16 fake-quantized tensor) may be NULL.
+ * n must be a multiple of 8; fmt must be the e4m3 or e5m2 descriptor of qt_format_for. */
+int qt_fake_quant_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n,
+                           const qt_format *fmt, const float *scale_f32_dev, uint32_t *amax_bits_dev,
+                           void *stream);
 int qt_fake_quant_pc_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t outer, size_t C, size_t inner,
                           const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
                           uint32_t *amax_bits_dev, void *stream);
@@ -166,10 +174,12 @@ int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev
                    const qt_operand_q *qb, void *stream);
 
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
- * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg). */
+ * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
+ * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride
+ * (elements), so a pool larger than the 256 MiB Infinity Cache measures HBM, not cache, traffic. */
 int qt_bench_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
                              const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
-                             int iters, void *stream, float *ms_out);
+                             int iters, size_t pool_stride, int pool_count, void *stream, float *ms_out);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,34 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// x / s for a wave-uniform divisor, bit-identical to the IEEE fp32 division torch performs.
+// Fast path: r = RN(1/s) once per thread, then q = x*r refined by two FMA residual steps (the same
+// correction chain as the hardware v_div_* sequence, started from an exactly rounded reciprocal).
+// It is exact when no intermediate can underflow or overflow: 2^-25 <= |s| <= 2^20 and
+// (x == 0 or 2^-102 <= |x| <= 2^100); everything else (incl. Inf / NaN) takes the full division.
+struct UniformDiv {
+    float s, r;
+    bool safe;
+    __device__ __forceinline__ explicit UniformDiv(float scale) : s(scale), r(1.0f / scale) {
+        const uint32_t as = qt_f2u(scale) & 0x7FFFFFFFu;
+        safe = as >= ((127u - 25u) << 23) && as <= ((127u + 20u) << 23);
+    }
+    __device__ __forceinline__ float operator()(float x) const {
+        const uint32_t ax = qt_f2u(x) & 0x7FFFFFFFu;
+        constexpr uint32_t lo = (127u - 102u) << 23, hi = (127u + 100u) << 23;
+        const bool ok = safe && (((ax - lo) <= (hi - lo)) || ax == 0u);
+        if (__builtin_expect(ok, 1)) {
+            const float q0 = x * r;
+            float e = __builtin_fmaf(-q0, s, x);
+            float q = __builtin_fmaf(e, r, q0);
+            e = __builtin_fmaf(-q, s, x);
+            q = __builtin_fmaf(e, r, q);
+            return ax == 0u ? q0 : q;            // the residual steps would turn -0 into +0
+        }
+        return x / s;
+    }
+};
+
 template <int KIND>
 struct Rounder {
     qt_format fmt;
@@ -44,7 +72,8 @@ __device__ __forceinline__ uint32_t fq_word_bf16(uint32_t w, float s, const Roun
         amax = amax > a1 ? amax : a1;
     }
     if constexpr (!UNIT) {
-        uint32_t q = pack_bf16x2(qt_u2f(lo) / s, qt_u2f(hi) / s);
+        const UniformDiv dv(s);   // loop-invariant: hoisted out of the streaming loop
+        uint32_t q = pack_bf16x2(dv(qt_u2f(lo)), dv(qt_u2f(hi)));
         lo = q << 16;
         hi = q & 0xFFFF0000u;
     }
@@ -60,7 +89,7 @@ __device__ __forceinline__ uint32_t fq_word_f32(uint32_t w, float s, const Round
         amax = amax > a ? amax : a;
     }
     float q = qt_u2f(w);
-    if constexpr (!UNIT) q = q / s;
+    if constexpr (!UNIT) q = UniformDiv(s)(q);
     float r = qt_u2f(rnd(qt_fold_img(qt_f2u(q))));
     if constexpr (!UNIT) r = r * s;
     return qt_f2u(r);

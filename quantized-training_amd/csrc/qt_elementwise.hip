@@ -27,7 +27,7 @@ constexpr int kIoF32 = 1;
 
 constexpr int kLutBlock = 1024;   // one workgroup per CU (128 KiB LDS), 16 waves
 constexpr int kAluBlock = 256;
-constexpr int kUnroll = 4;        // 16-B loads in flight per lane
+constexpr int kUnroll = 1;        // 16-B loads per lane per tile (measured best: many small tiles)
 
 template <int IO, int KIND, bool UNIT, bool OBS>
 __device__ __forceinline__ uint4 fq_vec(uint4 v, float s, const Rounder<KIND> &rnd, uint32_t &amax) {
@@ -83,11 +83,35 @@ __device__ __forceinline__ void block_amax_commit(uint32_t amax, uint32_t *out) 
         uint32_t m = s_part[0];
 #pragma unroll
         for (int i = 1; i < BLOCK / 64; ++i) m = m > s_part[i] ? m : s_part[i];
-        if (m != 0u) atomicMax(out, m);   // history[0] was zeroed by qt_scale_update
+        // history[0] was zeroed by qt_scale_update.  Thousands of same-address atomics serialise (~12 ns each),
+        // so a block only issues one when it can raise the running max (a stale read just costs an atomic).
+        if (m != 0u && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
     }
 }
 
-template <int IO, int KIND, bool UNIT, bool OBS, int BLOCK>
+__device__ __forceinline__ uint4 ld_vec(const uint4 *p, bool nt) {
+    if (nt) {
+        uint4 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        v.z = __builtin_nontemporal_load(&p->z);
+        v.w = __builtin_nontemporal_load(&p->w);
+        return v;
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_vec(uint4 *p, uint4 v, bool nt) {
+    if (nt) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z);
+        __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
+
+template <int IO, int KIND, bool UNIT, bool OBS, int BLOCK, int kUnroll, int NT>
 __device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t nvec, float s,
                                           const Rounder<KIND> &rnd, uint32_t &amax) {
     constexpr size_t kTile = (size_t)BLOCK * kUnroll;
@@ -96,11 +120,11 @@ __device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__
         const size_t base = t * kTile + threadIdx.x;
         uint4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = x[base + (size_t)u * BLOCK];
+        for (int u = 0; u < kUnroll; ++u) v[u] = ld_vec(x + base + (size_t)u * BLOCK, NT & 1);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             uint4 r = fq_vec<IO, KIND, UNIT, OBS>(v[u], s, rnd, amax);
-            if (y) y[base + (size_t)u * BLOCK] = r;
+            if (y) st_vec(y + base + (size_t)u * BLOCK, r, NT & 2);
         }
     }
     // ragged last tile: the block that would own it in the grid-stride order
@@ -116,7 +140,7 @@ __device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__
 //   x, y      : 16-B aligned base; nvec 16-B vectors followed by `ntail` scalar elements
 //   scale     : fp32 scale on device (NULL = 1); cast to the input dtype like scale.to(X.dtype)
 //   amax_out  : uint32 view of amax_history[0] (NULL when OBS is false)
-template <int IO, int KIND, bool OBS, int BLOCK>
+template <int IO, int KIND, bool OBS, int BLOCK, int kUnroll = 4, int NT = 0>
 __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec,
                                                   size_t n, qt_format fmt, const uint16_t *__restrict__ lut,
                                                   const float *__restrict__ scale, uint32_t *amax_out) {
@@ -138,9 +162,9 @@ __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, 
     const uint4 *x = (const uint4 *)xv;
     uint4 *y = (uint4 *)yv;
     if (unit)
-        fq_stream<IO, KIND, true, OBS, BLOCK>(x, y, nvec, s, rnd, amax);
+        fq_stream<IO, KIND, true, OBS, BLOCK, kUnroll, NT>(x, y, nvec, s, rnd, amax);
     else
-        fq_stream<IO, KIND, false, OBS, BLOCK>(x, y, nvec, s, rnd, amax);
+        fq_stream<IO, KIND, false, OBS, BLOCK, kUnroll, NT>(x, y, nvec, s, rnd, amax);
     constexpr int kPer = IO == kIoBf16 ? 8 : 4;
     if (blockIdx.x == gridDim.x - 1) {
         for (size_t i = nvec * kPer + threadIdx.x; i < n; i += BLOCK) fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
@@ -161,6 +185,76 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__
     uint32_t amax = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
+    if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
+// ---- OCP FP8 side output ------------------------------------------------------------------------
+// For e4m3 / e5m2 every fake-quantized value q = map[x / s] is exactly representable as an OCP FP8
+// byte (gfx950's v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 convert an on-grid value exactly), so the pass
+// can hand the GEMM one byte per element: y8 = fp8(q), and optionally the usual y = bf16(q * s).
+// (q, s) is what the reference's converted graphs feed to the GEMM: quantize -> GEMM ->
+// dequantize(s_x * s_w), quantize_pt2e.py:323-446.
+template <bool E5M2>
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int w = 0;
+    if constexpr (E5M2) {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    }
+    return (uint32_t)w;
+}
+
+template <bool OBS, bool BOTH, bool E5M2>
+__global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, uint2 *__restrict__ y8,
+                                                  size_t nvec, qt_format fmt, const float *__restrict__ scale,
+                                                  uint32_t *amax_out) {
+    float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
+    const bool unit = (s == 1.0f);
+    const UniformDiv dv(s);
+    uint32_t amax = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 v = x[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
+            if constexpr (OBS) {
+                uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+                amax = amax > a0 ? amax : a0;
+                amax = amax > a1 ? amax : a1;
+            }
+            if (!unit) {
+                uint32_t p = pack_bf16x2(dv(qt_u2f(lo)), dv(qt_u2f(hi)));
+                lo = p << 16;
+                hi = p & 0xFFFF0000u;
+            }
+            q[2 * j] = qt_u2f(qt_fp_sat_u32(lo, fmt.p0, fmt.p1, fmt.fhi));
+            q[2 * j + 1] = qt_u2f(qt_fp_sat_u32(hi, fmt.p0, fmt.p1, fmt.fhi));
+        }
+        uint2 o8;
+        o8.x = pack_fp8x4<E5M2>(q[0], q[1], q[2], q[3]);
+        o8.y = pack_fp8x4<E5M2>(q[4], q[5], q[6], q[7]);
+        y8[i] = o8;
+        if constexpr (BOTH) {
+            uint4 o;
+            if (unit) {
+                o.x = (qt_f2u(q[0]) >> 16) | (qt_f2u(q[1]) & 0xFFFF0000u);
+                o.y = (qt_f2u(q[2]) >> 16) | (qt_f2u(q[3]) & 0xFFFF0000u);
+                o.z = (qt_f2u(q[4]) >> 16) | (qt_f2u(q[5]) & 0xFFFF0000u);
+                o.w = (qt_f2u(q[6]) >> 16) | (qt_f2u(q[7]) & 0xFFFF0000u);
+            } else {
+                o.x = pack_bf16x2(q[0] * s, q[1] * s);
+                o.y = pack_bf16x2(q[2] * s, q[3] * s);
+                o.z = pack_bf16x2(q[4] * s, q[5] * s);
+                o.w = pack_bf16x2(q[6] * s, q[7] * s);
+            }
+            y[i] = o;
+        }
+    }
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
 
@@ -352,6 +446,22 @@ inline unsigned grid_for(size_t work_items, size_t per_block, int blocks_per_cu)
 // Tensors below this many elements use the global-table gather kernel instead of staging 128 KiB per CU.
 constexpr size_t kLutLdsMinElems = (size_t)1 << 21;
 
+int g_variant = 0;        // tuning only (tools/exp_stream.py): selects a launch geometry for bf16 closed-form passes
+int g_blocks_per_cu = 32;
+
+template <int IO, int KIND, int BLOCK, int UNR, int NT>
+int launch_variant(const void *x, void *y, size_t n, const qt_format &fmt, const uint16_t *lut, const float *scale,
+                   uint32_t *amax, hipStream_t st) {
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    const size_t nvec = n / kPer;
+    unsigned grid = grid_for(nvec, (size_t)BLOCK * UNR, g_blocks_per_cu);
+    if (amax)
+        fq_kernel<IO, KIND, true, BLOCK, UNR, NT><<<grid, BLOCK, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+    else
+        fq_kernel<IO, KIND, false, BLOCK, UNR, NT><<<grid, BLOCK, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+    return launch_status();
+}
+
 template <int IO, int KIND>
 int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const uint16_t *lut, const float *scale,
                    uint32_t *amax, hipStream_t st) {
@@ -375,7 +485,29 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
         else
             fq_kernel<IO, KIND, false, kLutBlock><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
     } else {
-        unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, 8);
+        if constexpr (IO == kIoBf16 && KIND == QT_FMT_FP_SAT) {
+            switch (g_variant) {
+                case 1: return launch_variant<IO, KIND, 256, 4, 2>(x, y, n, fmt, lut, scale, amax, st);
+                case 2: return launch_variant<IO, KIND, 256, 4, 3>(x, y, n, fmt, lut, scale, amax, st);
+                case 3: return launch_variant<IO, KIND, 256, 8, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 4: return launch_variant<IO, KIND, 512, 4, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 5: return launch_variant<IO, KIND, 256, 2, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 6: return launch_variant<IO, KIND, 256, 1, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 7: return launch_variant<IO, KIND, 1024, 2, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 8: return launch_variant<IO, KIND, 256, 8, 3>(x, y, n, fmt, lut, scale, amax, st);
+                case 9: return launch_variant<IO, KIND, 256, 2, 3>(x, y, n, fmt, lut, scale, amax, st);
+                case 10: return launch_variant<IO, KIND, 256, 4, 1>(x, y, n, fmt, lut, scale, amax, st);
+                case 11: return launch_variant<IO, KIND, 256, 1, 2>(x, y, n, fmt, lut, scale, amax, st);
+                case 12: return launch_variant<IO, KIND, 256, 1, 3>(x, y, n, fmt, lut, scale, amax, st);
+                case 13: return launch_variant<IO, KIND, 512, 1, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 14: return launch_variant<IO, KIND, 1024, 1, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 15: return launch_variant<IO, KIND, 128, 1, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 16: return launch_variant<IO, KIND, 128, 2, 0>(x, y, n, fmt, lut, scale, amax, st);
+                case 17: return launch_variant<IO, KIND, 64, 1, 0>(x, y, n, fmt, lut, scale, amax, st);
+                default: break;
+            }
+        }
+        unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, g_blocks_per_cu);
         if (amax)
             fq_kernel<IO, KIND, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
         else
@@ -452,6 +584,11 @@ int launch_qdq(const void *x, void *y, size_t n, const QdqArgs &a, const void *s
 
 extern "C" {
 
+void qt_internal_set_variant(int variant, int blocks_per_cu) {
+    g_variant = variant;
+    g_blocks_per_cu = blocks_per_cu > 0 ? blocks_per_cu : 32;
+}
+
 int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float quant_max, int force_pow2, void *stream) {
     if (!history_dev || !scale_dev || L < 1 || C < 1) return QT_ERR_BAD_ARG;
     unsigned grid = (unsigned)((C + 127) / 128);
@@ -474,6 +611,33 @@ int qt_fake_quant_pc_bf16(const uint16_t *x, uint16_t *y, size_t outer, size_t C
 int qt_fake_quant_pc_f32(const float *x, float *y, size_t outer, size_t C, size_t inner, const qt_format *fmt,
                          const uint16_t *lut, const float *scale, uint32_t *amax, void *stream) {
     return launch_pc<kIoF32>(x, y, outer, C, inner, fmt, lut, scale, amax, stream);
+}
+
+int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt,
+                           const float *scale, uint32_t *amax, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y8 || !fmt || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if ((n & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = n / 8;
+    const unsigned grid = grid_for(nvec, 256, 32);
+    hipStream_t st = (hipStream_t)stream;
+    const uint4 *xv = (const uint4 *)x;
+    uint4 *yv = (uint4 *)y;
+    uint2 *y8v = (uint2 *)y8;
+#define QT_FQ8(OBS, BOTH, E5)                                                                                  \
+    fq8_kernel<OBS, BOTH, E5><<<grid, 256, 0, st>>>(xv, yv, y8v, nvec, *fmt, scale, amax)
+    if (e5m2) {
+        if (amax) { if (y) QT_FQ8(true, true, true); else QT_FQ8(true, false, true); }
+        else      { if (y) QT_FQ8(false, true, true); else QT_FQ8(false, false, true); }
+    } else {
+        if (amax) { if (y) QT_FQ8(true, true, false); else QT_FQ8(true, false, false); }
+        else      { if (y) QT_FQ8(false, true, false); else QT_FQ8(false, false, false); }
+    }
+#undef QT_FQ8
+    return launch_status();
 }
 
 // vmap == fake-quant with scale 1 and no observer (x/1 and r*1 are exact)
@@ -533,8 +697,9 @@ int qt_round_posit_f32(const float *x, float *y, size_t n, int nbits, int es, vo
 }
 
 int qt_bench_fake_quant_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_format *fmt, const uint16_t *lut,
-                             const float *scale, uint32_t *amax, int iters, void *stream, float *ms_out) {
-    if (!ms_out || iters < 1) return QT_ERR_BAD_ARG;
+                             const float *scale, uint32_t *amax, int iters, size_t pool_stride, int pool_count,
+                             void *stream, float *ms_out) {
+    if (!ms_out || iters < 1 || pool_count < 1) return QT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e;
@@ -542,7 +707,10 @@ int qt_bench_fake_quant_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_
     if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
     int rc = QT_OK;
     (void)hipEventRecord(e0, st);
-    for (int i = 0; i < iters && rc == QT_OK; ++i) rc = launch_fq<kIoBf16>(x, y, n, fmt, lut, scale, amax, stream);
+    for (int i = 0; i < iters && rc == QT_OK; ++i) {
+        const size_t off = (size_t)(i % pool_count) * pool_stride;
+        rc = launch_fq<kIoBf16>(x + off, y ? y + off : nullptr, n, fmt, lut, scale, amax, stream);
+    }
     (void)hipEventRecord(e1, st);
     e = hipEventSynchronize(e1);
     float ms = 0.0f;

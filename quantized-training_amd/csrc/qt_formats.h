@@ -38,24 +38,25 @@ QT_HD uint32_t qt_fold_img(uint32_t u) { return (u & 0xFFFF0000u) | ((u & 0xFFFF
 // ---- e4m3 / e5m2 "NVIDIA-style" saturating RNE cast (fp8.py:10-67) ---------------------------
 //   mbits : mantissa bits kept (3 / 2);  emin : min normal exponent (-6 / -14);  fmax : 448 / 57344
 // Works on ANY fp32 pattern (the exported quantize_to_fp8_* take fp32 tensors), images included.
-// Normal range: integer RNE on the fp32 bits.  Below 2^emin the grid is uniform with spacing
-// 2^(emin-mbits), so adding and subtracting 2^(emin-mbits+23) lets the FP adder do the RNE; this
-// also flushes |x| <= 2^(emin-mbits-1) to zero (fp8.py:33).  Zero results are +0 (fp8.py:33-35).
+// Branch-free: the grid spacing at |x| in [2^e, 2^(e+1)) is 2^(max(e, emin) - mbits); adding and
+// subtracting 2^(max(e, emin) - mbits + 23) makes the FP adder perform the round-to-nearest-even,
+// in the normal and the subnormal range alike; this also flushes |x| <= 2^(emin-mbits-1) to zero
+// (fp8.py:33).
 QT_HD uint32_t qt_fp_sat_u32(uint32_t u, int mbits, int emin, float fmax) {
-    uint32_t a = u & 0x7FFFFFFFu;
-    if (a >= 0x7F800000u) return QT_NAN32;                       // fp8.py:36 non-finite -> NaN
-    float r;
-    if (a < ((uint32_t)(emin + 127) << 23)) {
-        float c = qt_u2f((uint32_t)(emin - mbits + 23 + 127) << 23);
-        r = (qt_u2f(a) + c) - c;
-    } else {
-        int sh = 23 - mbits;
-        uint32_t t = a + ((a >> sh) & 1u) + ((1u << (sh - 1)) - 1u);
-        r = qt_u2f(t & ~((1u << sh) - 1u));
-    }
-    r = r > fmax ? fmax : r;                                     // fp8.py:32
+    const uint32_t a = u & 0x7FFFFFFFu;
+    const uint32_t fmax_bits = qt_f2u(fmax);
+    // Pre-clamp: rounding is monotone, so round(min(a, fmax)) then min(.., fmax) == min(round(a), fmax)
+    // (fp8.py:32); it also keeps the magic constant below finite.
+    const uint32_t ac = a < fmax_bits ? a : fmax_bits;
+    uint32_t eb = ac & 0x7F800000u;
+    const uint32_t emin_b = (uint32_t)(emin + 127) << 23;
+    eb = eb > emin_b ? eb : emin_b;
+    const float c = qt_u2f(eb + ((uint32_t)(23 - mbits) << 23));   // 2^(max(e, emin) - mbits + 23)
+    float r = (qt_u2f(ac) + c) - c;                                // the FP adder rounds to nearest even at 2^(max(e,emin)-mbits)
+    r = r > fmax ? fmax : r;
     uint32_t ru = qt_f2u(r);
-    return ru == 0u ? 0u : (ru | (u & 0x80000000u));
+    ru = ru == 0u ? 0u : (ru | (u & 0x80000000u));                 // fp8.py:33-35: zero results are +0
+    return a >= 0x7F800000u ? QT_NAN32 : ru;                       // fp8.py:36: non-finite -> NaN
 }
 
 // ---- intN / uintN: clamp(round_half_even(v), lo, hi) on the bf16 value (fake_quantize.py:43-52)

@@ -57,12 +57,14 @@ SIGNATURES = {
     "qt_scale_update": (c_int, [_P, c_int, c_int, _P, c_float, c_int, _P]),
     "qt_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
+    "qt_fake_quant_bf16_fp8": (c_int, [_P, _P, _P, c_size_t, _FMT, _P, _P, _P]),
     "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
                                _OPQ, _OPQ, _P]),
-    "qt_bench_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, c_int, _P, POINTER(c_float)]),
+    "qt_bench_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, c_int, c_size_t, c_int, _P,
+                                        POINTER(c_float)]),
 }
 
 _lib = None

@@ -34,6 +34,25 @@ __all__ = [
 
 logger = logging.getLogger(__name__)
 
+class _Stats:
+    """Counts fake-quant applications the way the metric 'quantized elements/s' does
+    (sum of numel(input) over fake-quant calls)."""
+    elements = 0
+    calls = 0
+
+    @classmethod
+    def reset(cls):
+        cls.elements = 0
+        cls.calls = 0
+
+    @classmethod
+    def add(cls, numel):
+        cls.elements += int(numel)
+        cls.calls += 1
+
+
+STATS = _Stats
+
 _MAP_CACHE = {}      # (dtype, device) -> bf16 tensor [65536]
 _FORMAT_CACHE = {}   # dtype -> _native.QtFormat
 
@@ -369,6 +388,9 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             raise NotImplementedError(
                 f"qscheme {self.qscheme.value} (block-scaled formats) is not part of this engine yet")
 
+        if not self._observe and not self._quantize:
+            return X
+        _Stats.add(X.numel())
         X = FusedAmaxObsFakeQuantFunction.apply(
             X, self._observe, self._quantize, self.qmap, self.amax_history, self.scale,
             self.amax_history_len, self.quant_max, self.ch_axis, self.is_per_channel,

@@ -10,14 +10,14 @@ import os
 import torch
 
 from . import _native
-from .fake_quantize import FusedAmaxObsFakeQuantize, _stream_ptr
+from .fake_quantize import STATS, FusedAmaxObsFakeQuantize, _stream_ptr
 from .quantizer.quantizer import QScheme
 
 _IDENTITY = _native.QtFormat(_native.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
 
 
 def fused_gemm_enabled():
-    return os.environ.get("QT_FUSED_GEMM", "1") != "0"
+    return os.environ.get("QT_FUSED_GEMM", "0") == "1"
 
 
 def _operand(fq, device):
@@ -72,4 +72,5 @@ def fused_linear_or_none(layer, x):
                                layer.bias.data_ptr() if layer.bias is not None else None,
                                y.data_ptr(), M, N, K, ctypes.byref(qx), ctypes.byref(qw), st)
     _native.check(code, "qt_linear_fq_bf16")
+    STATS.add(W.numel())
     return y.reshape(*x.shape[:-1], N)

@@ -1,0 +1,118 @@
+"""Evaluation loops around the hot path, data-parallel over the GPUs of one node.
+
+Counterparts of the reference's drivers (which this repo does not copy):
+  * WikiText sliding-window perplexity      examples/language_modeling/wikitext.py:138-167
+  * SQuAD-style batched logits collection   examples/question_answering/run_qa_no_trainer.py:914-959
+Windows / batches are independent units, so they are sharded round-robin over ranks with NO
+collective on the data path; one all_gather of the per-unit metric at the end (RCCL over xGMI when
+the process group is `nccl`, gloo on CPU).  Exact only when the fake-quantizers are stateless
+(no `qs`) or their observers are frozen: with live delayed scaling every rank's amax history sees a
+different subsequence of windows.
+"""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["wikitext_windows", "shard_round_robin", "window_nll", "evaluate_perplexity", "gather_in_order",
+           "build_causal_lm", "LLAMA_SHAPES"]
+
+
+def wikitext_windows(seq_len: int, max_length: int, stride: int) -> List[Tuple[int, int, int]]:
+    """(begin, end, trg_len) per window, exactly the schedule of wikitext.py:143-165: windows start
+    every `stride` tokens while begin < seq_len - max_length; only the last `trg_len` tokens of a
+    window are scored (the first window scores all of them)."""
+    rows, prev_end = [], 0
+    for begin in range(0, seq_len - max_length, stride):
+        end = min(begin + max_length, seq_len)
+        rows.append((begin, end, end - prev_end))
+        prev_end = end
+        if end == seq_len:
+            break
+    return rows
+
+
+def shard_round_robin(items: Sequence, rank: int, world: int) -> List:
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+@torch.no_grad()
+def window_nll(model, input_ids: torch.Tensor, trg_len: int) -> torch.Tensor:
+    """Mean NLL over the scored labels of one window (labels masked to -100 outside the last
+    trg_len positions; the model shifts labels internally), wikitext.py:146-158."""
+    target = input_ids.clone()
+    target[:, :-trg_len] = -100
+    out = model(input_ids, labels=target, use_cache=False)
+    return out.loss.float()
+
+
+def gather_in_order(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """All ranks hold values for units rank, rank+world, ...; returns all n_total values in unit order.
+    One all_gather of a padded fp32 vector (<= a few KB): latency-bound, not bandwidth-bound."""
+    if world == 1:
+        return local
+    per = (n_total + world - 1) // world
+    buf = torch.full((per,), float("nan"), dtype=torch.float32, device=local.device)
+    buf[: local.numel()] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    out = torch.empty(n_total, dtype=torch.float32, device=local.device)
+    for r in range(world):
+        cnt = len(range(r, n_total, world))
+        out[r::world] = parts[r][:cnt]
+    return out
+
+
+@torch.no_grad()
+def evaluate_perplexity(model, token_ids: torch.Tensor, max_length: int = 1024, stride: int = 512,
+                        device=None, rank: int = 0, world: int = 1, group=None,
+                        max_windows: Optional[int] = None):
+    """Sliding-window perplexity, windows sharded over ranks.  Returns (ppl, nlls[all windows])
+    with ppl = exp(unweighted mean of per-window NLLs), wikitext.py:167."""
+    assert token_ids.dim() == 2 and token_ids.shape[0] == 1
+    windows = wikitext_windows(token_ids.shape[1], max_length, stride)
+    if max_windows is not None:
+        windows = windows[:max_windows]
+    mine = shard_round_robin(list(enumerate(windows)), rank, world)
+    device = device if device is not None else next(model.parameters()).device
+    local = torch.empty(len(mine), dtype=torch.float32, device=device)
+    for j, (_, (begin, end, trg_len)) in enumerate(mine):
+        local[j] = window_nll(model, token_ids[:, begin:end].to(device), trg_len)
+    nlls = gather_in_order(local, len(windows), rank, world, group)
+    return math.exp(nlls.double().mean().item()), nlls
+
+
+# name -> (hidden, layers, heads, kv_heads, ffn, vocab)        SURVEY.md section 8 sizes
+LLAMA_SHAPES = {
+    "llama-2-7b": (4096, 32, 32, 32, 11008, 32000),
+    "llama-2-13b": (5120, 40, 40, 40, 13824, 32000),
+    "llama-tiny": (128, 2, 4, 4, 352, 512),
+}
+
+
+def build_causal_lm(shape: str = "llama-2-7b", device="cuda", dtype=torch.bfloat16, seed: int = 0,
+                    num_layers: Optional[int] = None):
+    """A LLaMA-architecture model built from its config only (no checkpoint is available offline):
+    weights ~ N(0, 0.02) from `seed`, eager attention like the reference driver (wikitext.py:60-65)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    h, L, nh, nkv, ffn, vocab = LLAMA_SHAPES[shape]
+    cfg = LlamaConfig(hidden_size=h, num_hidden_layers=num_layers or L, num_attention_heads=nh,
+                      num_key_value_heads=nkv, intermediate_size=ffn, vocab_size=vocab,
+                      max_position_embeddings=4096, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                      attn_implementation="eager")
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(device):
+            model = LlamaForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02, generator=gen)
+    model.eval()
+    return model

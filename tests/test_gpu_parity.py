@@ -103,6 +103,23 @@ def test_exhaustive_bf16_all_patterns(nv, dtype, scale):
         assert np.array_equal(o.canon_nan16(got), exp), (dtype, scale, force_lut)
 
 
+@pytest.mark.parametrize("dtype", ["e4m3", "int8"])
+def test_division_by_many_scales(nv, dtype):
+    """x / s must be torch's correctly rounded fp32 division for every scale: sweep scales across the
+    fast (refined reciprocal) and the guarded (full division) ranges, bf16 (all patterns) and fp32."""
+    rng = np.random.default_rng(42)
+    scales = list(2.0 ** rng.uniform(-24, 19, 24)) + [2.0 ** -25, 2.0 ** 20, 2.0 ** -30, 2.0 ** 40, 1e-38, 3e38,
+                                                      0.1, 1.0 / 3.0, 448.0, 1.0 / 448.0, 127.0, 5e-7]
+    xb = o.all_bf16_patterns()
+    x32 = _sample_f32(1 << 15, 9)
+    for s in scales:
+        s = float(np.float32(s))
+        got, _ = run_fq_bf16(nv, xb, dtype, s)
+        assert np.array_equal(o.canon_nan16(got), expect_bf16(xb, dtype, s)), ("bf16", s)
+        got, _ = run_fq_f32(nv, x32, dtype, s)
+        assert np.array_equal(o.canon_nan32(got), expect_f32(x32, dtype, s)), ("f32", s)
+
+
 @pytest.mark.parametrize("dtype", ["int8", "e4m3", "e5m2", "posit8_1", "fp8_e4m3", "posit16_1", "uint8"])
 def test_closed_form_equals_table_on_device(nv, dtype):
     x = o.all_bf16_patterns()
