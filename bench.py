@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--stride", type=int, default=512)
     ap.add_argument("--activation", default="e4m3")
     ap.add_argument("--weight", default="e4m3")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -144,20 +145,42 @@ def main():
     batches = [(tokens[:, b:e].to(device), t) for (b, e, t) in mine[:need]]   # resident before timing
 
     nlls = []
+    graph_used = False
     with torch.no_grad():
-        for i in range(a.warmup):                     # first call creates the per-tensor fake-quantizers
-            harness.window_nll(model, *batches[i])
+        for i in range(max(a.warmup, 1)):             # first call creates the per-tensor fake-quantizers
+            harness.window_nll(model, *batches[min(i, need - 1)])
         STATS.reset()
         harness.window_nll(model, *batches[0])
         torch.cuda.synchronize()
         elems_per_step = STATS.elements
         calls_per_step = STATS.calls
+        # The whole window forward is launch-bound on the host (~2 500 small launches), and nothing in
+        # it synchronises with the host, so it is captured once into a hipGraph and replayed per window.
+        step = None
+        if not a.no_graph:
+            try:
+                step = harness.GraphedWindow(model, a.max_length, batches[0][1] if False else None, device)
+                step.capture(batches[0][0])
+                graph_used = True
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
+                step = None
+
+        def run_window(ids, trg_len):
+            if step is not None and ids.shape[1] == a.max_length:
+                return step.replay(ids, trg_len)
+            return harness.window_nll(model, ids, trg_len)
+
+        for i in range(a.warmup):
+            run_window(*batches[i])
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            nlls.append(harness.window_nll(model, *batches[a.warmup + i]))
+            nlls.append(run_window(*batches[a.warmup + i]).clone())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -189,6 +212,7 @@ def main():
                                    f"(weights re-quantized every forward)",
                        "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
+                       "launch": "hipGraph replay" if graph_used else "eager",
                        "valid": bool(full)},
             "mean_window_nll": float(allnll.double().mean().item()),
         }

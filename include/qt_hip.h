@@ -173,6 +173,19 @@ int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev
                    long lda, long sa, long ldb_k, long ldb_n, long sb, const qt_operand_q *qa,
                    const qt_operand_q *qb, void *stream);
 
+/* ---- A10: attention-score path between the two attention GEMMs ------------------------------
+ * Replaces, for one attention block, the chain
+ *     attn_scaling(scores, scaling) ; + attention_mask ; softmax(fp32) ; .to(bf16) ; fq(probs)
+ *     modules/quantizable/modeling_bert.py:142-158 (MulFunctional, mask add, nn.Softmax, av_matmul's
+ *     input hook quantize.py:128-140) -- six passes over the S x S tensor -- by one read and one write.
+ * scores / out: bf16 [batch, heads, q_len, cols] contiguous; mask: additive bf16 addressed as
+ * mask + b*mask_sb + h*mask_sh + q*mask_sq + col (NULL = none).  fmt / lut / scale / amax describe the
+ * fake-quantizer applied to the probabilities (fmt kind IDENTITY = plain softmax).  cols <= 4096, cols % 8 == 0. */
+int qt_softmax_fq_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uint16_t *out_dev, long batch,
+                       int heads, int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling,
+                       const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
+                       uint32_t *amax_bits_dev, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

@@ -140,7 +140,7 @@ __device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__
 //   x, y      : 16-B aligned base; nvec 16-B vectors followed by `ntail` scalar elements
 //   scale     : fp32 scale on device (NULL = 1); cast to the input dtype like scale.to(X.dtype)
 //   amax_out  : uint32 view of amax_history[0] (NULL when OBS is false)
-template <int IO, int KIND, bool OBS, int BLOCK, int kUnroll = 4, int NT = 0>
+template <int IO, int KIND, bool OBS, int BLOCK, int kUnroll = 1, int NT = 0>
 __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec,
                                                   size_t n, qt_format fmt, const uint16_t *__restrict__ lut,
                                                   const float *__restrict__ scale, uint32_t *amax_out) {
@@ -479,11 +479,11 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     }
     const size_t nvec = n / kPer;
     if constexpr (KIND == QT_FMT_LUT) {
-        unsigned grid = grid_for(nvec, (size_t)kLutBlock * kUnroll * 4, 1);
+        unsigned grid = grid_for(nvec, (size_t)kLutBlock * 4 * 4, 1);
         if (amax)
-            fq_kernel<IO, KIND, true, kLutBlock><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+            fq_kernel<IO, KIND, true, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
         else
-            fq_kernel<IO, KIND, false, kLutBlock><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+            fq_kernel<IO, KIND, false, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
     } else {
         if constexpr (IO == kIoBf16 && KIND == QT_FMT_FP_SAT) {
             switch (g_variant) {

@@ -1,0 +1,190 @@
+// qt_softmax.hip -- fused attention-score path: scale -> (+ mask) -> softmax -> fake-quantize.
+//
+// In the reference's quantizable attention blocks (modules/quantizable/modeling_bert.py:142-158,
+// modeling_llama.py:228-246) the S x S score tensor makes six full trips through memory between the
+// two attention GEMMs: attn_scaling (MulFunctional), mask add, fp32 up-cast, softmax, down-cast, and
+// the fake-quant of the probabilities in av_matmul's input hook.  When only the GEMM inputs are
+// quantized (`--quantize_forward gemm`, the reference default) nothing observes the intermediate
+// tensors, so this kernel reads the raw QK^T scores once and writes the fake-quantized
+// probabilities once (4 B/element instead of ~32 B/element):
+//     t = bf16(bf16(score * scaling) + mask)            MulFunctional + mask add, each rounded to bf16
+//     p = bf16(exp(t - max_row) / sum_row)              softmax evaluated in fp32 (what torch does for
+//                                                       bf16 inputs and what HF LLaMA asks for explicitly)
+//     y = fq(p)                                         same per-element function as qt_fake_quant_bf16,
+//                                                       amax(p) max-accumulated for the observer
+// One wavefront owns one row: 16-B loads, lane-local + __shfl_xor reductions, no LDS.
+// Numerics: every step except exp / the row-sum order is bit-defined; p can differ from torch's by at
+// most one bf16 ULP in rare ties (tests/test_gpu_parity.py::test_softmax_fq states the tolerance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qt_device.h"
+
+namespace {
+
+constexpr int kMaxVec = 8;   // 16-B vectors per lane -> rows up to 64 * 8 * 8 = 4096 columns
+
+struct SoftmaxArgs {
+    const uint16_t *scores;
+    const uint16_t *mask;     // additive, bf16, or NULL
+    uint16_t *out;
+    long rows, cols;
+    int heads, q_len;         // row = (b * heads + h) * q_len + q
+    long mask_sb, mask_sh, mask_sq;   // element strides of the mask for (b, h, q); columns are contiguous
+    float scaling;
+    qt_format fmt;
+    const uint16_t *lut;
+    const float *scale;
+    uint32_t *amax;
+};
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int KIND, int NV>
+__global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Rounder<KIND> rnd{a.fmt, a.lut};
+    const float s = a.scale ? qt_bf2f(qt_f2bf(*a.scale)) : 1.0f;
+    const bool unit = s == 1.0f;
+    const UniformDiv dv(s);
+    const int nvec_row = (int)(a.cols / 8);
+    uint32_t amax = 0;
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
+        const uint4 *src = (const uint4 *)(a.scores + row * a.cols);
+        const uint4 *msk = nullptr;
+        if (a.mask) {
+            const long q = row % a.q_len, bh = row / a.q_len;
+            const long h = bh % a.heads, b = bh / a.heads;
+            msk = (const uint4 *)(a.mask + b * a.mask_sb + h * a.mask_sh + q * a.mask_sq);
+        }
+        float t[NV][8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int iv = v * 64 + lane;
+            if (iv < nvec_row) {
+                const uint4 x = src[iv];
+                uint4 m = {0u, 0u, 0u, 0u};
+                if (msk) m = msk[iv];
+                const uint32_t xw[4] = {x.x, x.y, x.z, x.w}, mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // bf16(score * scaling), then bf16(. + mask)
+                    uint32_t p = pack_bf16x2(qt_u2f(xw[j] << 16) * a.scaling, qt_u2f(xw[j] & 0xFFFF0000u) * a.scaling);
+                    float lo = qt_u2f(p << 16), hi = qt_u2f(p & 0xFFFF0000u);
+                    if (msk) {
+                        p = pack_bf16x2(lo + qt_u2f(mw[j] << 16), hi + qt_u2f(mw[j] & 0xFFFF0000u));
+                        lo = qt_u2f(p << 16);
+                        hi = qt_u2f(p & 0xFFFF0000u);
+                    }
+                    t[v][2 * j] = lo;
+                    t[v][2 * j + 1] = hi;
+                    mx = fmaxf(mx, fmaxf(lo, hi));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[v][j] = -INFINITY;
+            }
+        }
+        mx = wave_max_f32(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t[v][j] = expf(t[v][j] - mx);
+                sum += t[v][j];
+            }
+        sum = wave_sum_f32(sum);
+        uint4 *dst = (uint4 *)(a.out + row * a.cols);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int iv = v * 64 + lane;
+            if (iv < nvec_row) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t p = pack_bf16x2(t[v][2 * j] / sum, t[v][2 * j + 1] / sum);   // probabilities, bf16
+                    if (a.amax) {
+                        uint32_t a0 = (p << 16) & 0x7FFFFFFFu, a1 = p & 0x7FFF0000u;
+                        amax = amax > a0 ? amax : a0;
+                        amax = amax > a1 ? amax : a1;
+                    }
+                    uint32_t lo = p << 16, hi = p & 0xFFFF0000u;
+                    if (!unit) {
+                        uint32_t qd = pack_bf16x2(dv(qt_u2f(lo)), dv(qt_u2f(hi)));
+                        lo = qd << 16;
+                        hi = qd & 0xFFFF0000u;
+                    }
+                    const uint32_t r0 = rnd(lo), r1 = rnd(hi);
+                    w[j] = unit ? ((r0 >> 16) | (r1 & 0xFFFF0000u)) : pack_bf16x2(qt_u2f(r0) * s, qt_u2f(r1) * s);
+                }
+                dst[iv] = uint4{w[0], w[1], w[2], w[3]};
+            }
+        }
+    }
+    if (a.amax) {
+        amax = wave_max_u32(amax);
+        if (lane == 0 && amax != 0u && amax > __hip_atomic_load(a.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.amax, amax);
+    }
+}
+
+template <int KIND>
+int launch_softmax(const SoftmaxArgs &a, hipStream_t st) {
+    const long nvec_row = a.cols / 8;
+    const int nv = (int)((nvec_row + 63) / 64);
+    static int cus = 0;      // queried once (never inside a stream capture after the first call)
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                  ? p.multiProcessorCount : 256;
+    }
+    long want = (a.rows + 3) / 4;
+    long cap = (long)cus * 16;
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    switch (nv) {
+        case 1: softmax_fq_kernel<KIND, 1><<<grid, 256, 0, st>>>(a); break;
+        case 2: softmax_fq_kernel<KIND, 2><<<grid, 256, 0, st>>>(a); break;
+        case 3: case 4: softmax_fq_kernel<KIND, 4><<<grid, 256, 0, st>>>(a); break;
+        default: softmax_fq_kernel<KIND, kMaxVec><<<grid, 256, 0, st>>>(a); break;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, uint16_t *out, long batch, int heads,
+                                  int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling,
+                                  const qt_format *fmt, const uint16_t *lut, const float *scale, uint32_t *amax,
+                                  void *stream) {
+    const long rows = batch * heads * q_len;
+    if (rows == 0 || cols == 0) return QT_OK;
+    if (!scores || !out || !fmt || batch < 0 || heads < 1 || q_len < 1 || cols < 0) return QT_ERR_BAD_ARG;
+    if (fmt->kind == QT_FMT_LUT && !lut) return QT_ERR_BAD_ARG;
+    if (cols > 64L * 8 * kMaxVec) return QT_ERR_BAD_ARG;
+    if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)out | (uintptr_t)mask) & 15u) ||
+        (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
+        return QT_ERR_UNALIGNED;
+    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax};
+    hipStream_t st = (hipStream_t)stream;
+    switch (fmt->kind) {
+        case QT_FMT_LUT: return launch_softmax<QT_FMT_LUT>(a, st);
+        case QT_FMT_FP_SAT: return launch_softmax<QT_FMT_FP_SAT>(a, st);
+        case QT_FMT_INT: return launch_softmax<QT_FMT_INT>(a, st);
+        case QT_FMT_IDENTITY: return launch_softmax<QT_FMT_IDENTITY>(a, st);
+        default: return QT_ERR_BAD_ARG;
+    }
+}

@@ -106,6 +106,21 @@ def _as_flag(v):
     return bool(v)
 
 
+def _dense_or_contiguous(t):
+    """Per-tensor fake-quant is elementwise, so any dense, non-overlapping layout (e.g. a transposed
+    view such as K^T) is processed in storage order and the result keeps the input's strides -- no
+    .contiguous() copy.  Anything else is made contiguous first."""
+    if t.is_contiguous():
+        return t
+    try:
+        from torch._prims_common import is_non_overlapping_and_dense
+        if is_non_overlapping_and_dense(t):
+            return t
+    except Exception:  # noqa: BLE001
+        pass
+    return t.contiguous()
+
+
 def _channel_view(shape, ch_axis):
     ax = ch_axis + len(shape) if ch_axis < 0 else ch_axis
     outer = 1
@@ -195,7 +210,7 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, observer_enabled, fake_quant_enabled, qmap, amax_history, scale,
                 amax_history_len, quant_max, ch_axis=None, per_row_fake_quant=False,
-                force_scale_power_of_two=False, qt_format=None):
+                force_scale_power_of_two=False, qt_format=None, emit_fp8=None):
         observe = _as_flag(observer_enabled)
         quantize = _as_flag(fake_quant_enabled)
         if not observe and not quantize:
@@ -214,6 +229,9 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
             return _forward_cpu(input, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis,
                                 per_row_fake_quant, force_scale_power_of_two)
 
+        # NB: a dense permuted layout could be processed in storage order without this copy, but the
+        # batched GEMMs that consume q / k^T / v run markedly slower on permuted strides (measured), so the
+        # canonical contiguous layout is produced here, as the reference's vmap does (decomposed.py:155).
         x = input.contiguous()
         if x.dtype not in (torch.bfloat16, torch.float32):
             return _forward_other_dtype(x, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis,
@@ -225,6 +243,20 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
             _native.check(L.qt_scale_update(amax_history.data_ptr(), int(amax_history.shape[0]), int(C),
                                             scale.data_ptr(), float(quant_max), int(bool(force_scale_power_of_two)),
                                             _stream_ptr(x)), "qt_scale_update")
+        if (emit_fp8 is not None and quantize and not per_row_fake_quant and x.dtype == torch.bfloat16
+                and x.numel() % 8 == 0 and x.numel() > 0):
+            # one pass: bf16 fake-quantized tensor (unless emit_fp8 == "only") + the same values as FP8 bytes
+            only = emit_fp8 == "only"
+            y = None if only else torch.empty_like(x)
+            y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            _native.check(L.qt_fake_quant_bf16_fp8(
+                x.data_ptr(), y.data_ptr() if y is not None else None, y8.data_ptr(), x.numel(), ctypes.byref(fmt),
+                scale.data_ptr(), amax_history.data_ptr() if observe else None, _stream_ptr(x)), "qt_fake_quant_bf16_fp8")
+            y8 = y8.view(torch.float8_e5m2 if fmt.p0 == 2 else torch.float8_e4m3fn)
+            if only:
+                return y8
+            ctx.mark_non_differentiable(y8)
+            return y, y8            # the module attaches y8 to y for the QAT Linear that owns the hook (fused.py)
         y = torch.empty_like(x) if quantize else None
         per_channel = bool(per_row_fake_quant)
         if per_channel and scale.numel() != _channel_view(tuple(x.shape), ch_axis)[1]:
@@ -236,8 +268,8 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
         return y if quantize else input
 
     @staticmethod
-    def backward(ctx, grad_output):
-        return (grad_output,) + (None,) * 11
+    def backward(ctx, grad_output, *unused):
+        return (grad_output,) + (None,) * 12
 
 
 def _forward_cpu(input, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis, per_channel, pow2):
@@ -322,6 +354,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         # host mirrors of the uint8[1] enable buffers: forward() never reads the device copies
         self._observe = False
         self._quantize = True
+        self._emit_fp8 = None          # set by fused.py when the consumer is an FP8-capable GEMM
         self.enable_observer(self.qscheme is not None)
 
     # -- enable flags: keep the buffers (state_dict compatibility) and the host mirrors in step --
@@ -338,6 +371,13 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
 
     def disable_observer(self):
         self.enable_observer(False)
+
+    def fp8_exact(self):
+        """True when every fake-quantized value is an OCP FP8 value AND the scale is identically 1
+        (specs without `qs`), i.e. fq(x) can be handed to an FP8 GEMM without changing any product."""
+        return (self._qt_format.kind == _native.QT_FMT_FP_SAT and self.qscheme is None
+                and self.outlier_threshold is None and not self._observe and self._quantize
+                and getattr(self, "_scale_is_one", True))
 
     def sync_flags_from_buffers(self):
         """Re-read the enable buffers (one host sync); call after writing them directly."""
@@ -395,7 +435,11 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             X, self._observe, self._quantize, self.qmap, self.amax_history, self.scale,
             self.amax_history_len, self.quant_max, self.ch_axis, self.is_per_channel,
             self.force_scale_power_of_two, self._qt_format,
+            self._emit_fp8 if (self._emit_fp8 and self.fp8_exact()) else None,
         )
+        if isinstance(X, tuple):
+            X, x8 = X
+            X._qt_fp8 = x8
 
         if self.outlier_threshold is not None:                              # upstream :401-402
             X = torch.where(mask, X, orig_X)
@@ -414,6 +458,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict,
                                       missing_keys, unexpected_keys, error_msgs)
         self.sync_flags_from_buffers()
+        self._scale_is_one = bool((self.scale == 1.0).all().item())
 
 
 class _DerivedObserverOrFakeQuantize(FakeQuantizeBase):

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _native
-from .fake_quantize import STATS, FusedAmaxObsFakeQuantize, _stream_ptr
+from .fake_quantize import STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr
 from .quantizer.quantizer import QScheme
 
 _IDENTITY = _native.QtFormat(_native.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
@@ -18,6 +18,63 @@ _IDENTITY = _native.QtFormat(_native.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
 
 def fused_gemm_enabled():
     return os.environ.get("QT_FUSED_GEMM", "0") == "1"
+
+
+def fp8_gemm_enabled():
+    return os.environ.get("QT_FP8_GEMM", "1") != "0"
+
+
+def mark_fp8_producer(consumer, act_fq):
+    """Called when the activation fake-quantizer of `consumer` is created: if `consumer` is a QAT Linear
+    whose weight fake-quantizer and this activation fake-quantizer both produce exact FP8 values with
+    scale 1 (e4m3 / e5m2 specs without `qs`), the activation pass also emits FP8 bytes for the GEMM."""
+    from .modules.qat.linear import Linear as QATLinear
+    if not (fp8_gemm_enabled() and isinstance(consumer, QATLinear)):
+        return
+    wfq = consumer.weight_fake_quant
+    if isinstance(wfq, FusedAmaxObsFakeQuantize) and isinstance(act_fq, FusedAmaxObsFakeQuantize) \
+            and wfq.fp8_exact() and act_fq.fp8_exact():
+        act_fq._emit_fp8 = "both"
+
+
+def fp8_linear_or_none(layer, x):
+    """E4M3 / E5M2 fake-quant Linear with scale 1 on the FP8 matrix cores: the activation pass already
+    produced FP8 bytes (x._qt_fp8), the weight pass writes FP8 only (3 B/element of traffic instead of
+    4 and nothing for the GEMM to re-read in bf16), and the products q_x * q_w are exactly the
+    reference's bf16 products; fp32 accumulation, bf16 output.  Library FP8 GEMM (hipBLASLt through
+    torch._scaled_mm) -- a plain GEMM on already-quantized operands."""
+    x8 = getattr(x, "_qt_fp8", None)
+    fq = layer.weight_fake_quant
+    if x8 is None or not fp8_gemm_enabled() or not isinstance(fq, FusedAmaxObsFakeQuantize) or not fq.fp8_exact():
+        return None
+    if torch.is_grad_enabled() and (layer.weight.requires_grad or x.requires_grad):
+        return None
+    W = layer.weight
+    K = W.shape[1]
+    if W.dtype != torch.bfloat16 or not W.is_contiguous() or K % 16 != 0 or W.shape[0] % 16 != 0:
+        return None
+    if layer.bias is not None and layer.bias.dtype != torch.bfloat16:
+        return None
+    fq._move_to(x.device)
+    STATS.add(W.numel())
+    w8 = FusedAmaxObsFakeQuantFunction.apply(W.detach(), False, True, fq.qmap, fq.amax_history, fq.scale,
+                                             fq.amax_history_len, fq.quant_max, None, False, False,
+                                             fq._qt_format, "only")
+    one = _one(x.device)
+    x2 = x8.reshape(-1, K)
+    y = torch._scaled_mm(x2, w8.t(), scale_a=one, scale_b=one, bias=layer.bias, out_dtype=torch.bfloat16)
+    return y.reshape(*x.shape[:-1], W.shape[0])
+
+
+_ONES = {}
+
+
+def _one(device):
+    t = _ONES.get(device)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _ONES[device] = t
+    return t
 
 
 def _operand(fq, device):
@@ -33,6 +90,9 @@ def _operand(fq, device):
 def fused_linear_or_none(layer, x):
     """y = x @ fq(W)^T + b with W fake-quantized while its tiles are staged (qt_linear_fq_bf16).
     Applies to bf16 device tensors under no_grad with a per-tensor weight fake-quantizer."""
+    out = fp8_linear_or_none(layer, x)
+    if out is not None:
+        return out
     fq = layer.weight_fake_quant
     W = layer.weight
     if not (fused_gemm_enabled() and isinstance(fq, FusedAmaxObsFakeQuantize)):
@@ -74,3 +134,80 @@ def fused_linear_or_none(layer, x):
     _native.check(code, "qt_linear_fq_bf16")
     STATS.add(W.numel())
     return y.reshape(*x.shape[:-1], N)
+
+
+def _has_hooks(mod, name):
+    holder = getattr(mod, name, None)
+    return holder is not None
+
+
+def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout, value):
+    """scale -> +mask -> softmax -> fake-quant(probabilities) in ONE HIP pass (qt_softmax_fq_bf16), then
+    av_matmul on the quantized probabilities.  Applies when nothing observes the intermediate tensors:
+    `attn_scaling` and `softmax` carry no activation hooks (the `--quantize_forward gemm` default), no
+    dropout is active, bf16 device tensors, and av_matmul's per-tensor fake-quantizers already exist
+    (they are created by the first, unfused, call).  Returns (probs_q, attn_output) or None."""
+    if os.environ.get("QT_FUSED_SOFTMAX", "1") == "0":
+        return None
+    if not (scores.device.type == "cuda" and scores.dtype == torch.bfloat16 and scores.dim() == 4):
+        return None
+    if torch.is_grad_enabled() and scores.requires_grad:
+        return None
+    if dropout and attn.training:
+        return None
+    if _has_hooks(attn.attn_scaling, "activation_pre_process") or _has_hooks(attn.softmax, "activation_pre_process"):
+        return None
+    if attn.attn_scaling._forward_hooks or attn.softmax._forward_hooks or attn.av_matmul._forward_hooks:
+        return None
+    holder = getattr(attn.av_matmul, "activation_pre_process", None)
+    fq_p = fq_v = None
+    if holder is not None:
+        if "0" not in holder or "1" not in holder:
+            return None                       # first call: let the hook create them
+        fq_p, fq_v = holder["0"], holder["1"]
+        if not isinstance(fq_p, FusedAmaxObsFakeQuantize) or fq_p.is_per_channel or fq_p.outlier_threshold is not None \
+                or fq_p.record_histogram or fq_p.qscheme in (QScheme.MICROSCALING, QScheme.GROUP_WISE_AFFINE):
+            return None
+    if len(attn.av_matmul._forward_pre_hooks) > (1 if holder is not None else 0):
+        return None
+    B, H, Q, C = scores.shape
+    if C % 8 != 0 or C > 4096 or not scores.is_contiguous():
+        return None
+    mask = None
+    msb = msh = msq = 0
+    if attention_mask is not None:
+        m = attention_mask[..., :C]
+        if m.dtype != torch.bfloat16 or m.dim() != 4 or m.stride(-1) != 1 or m.device != scores.device:
+            return None
+        if m.shape[0] not in (1, B) or m.shape[1] not in (1, H) or m.shape[2] not in (1, Q):
+            return None
+        msb = m.stride(0) if m.shape[0] == B and B > 1 else 0
+        msh = m.stride(1) if m.shape[1] == H and H > 1 else 0
+        msq = m.stride(2) if m.shape[2] == Q and Q > 1 else 0
+        if (msb | msh | msq) % 8 != 0 or m.data_ptr() % 16 != 0:
+            return None
+        mask = m
+    L = _native.lib()
+    st = _stream_ptr(scores)
+    out = torch.empty_like(scores)
+    if fq_p is not None and (fq_p._observe or fq_p._quantize):
+        fq_p._move_to(scores.device)
+        fmt = fq_p._qt_format if fq_p._quantize else _IDENTITY
+        if fq_p._observe:
+            if fq_p.amax_history.numel() == 0:
+                fq_p.amax_history.resize_((fq_p.amax_history_len,)).fill_(0.0)
+                fq_p.scale.resize_(()).fill_(1.0)
+            _native.check(L.qt_scale_update(fq_p.amax_history.data_ptr(), int(fq_p.amax_history.shape[0]), 1,
+                                            fq_p.scale.data_ptr(), float(fq_p.quant_max),
+                                            int(bool(fq_p.force_scale_power_of_two)), st), "qt_scale_update")
+        lut = fq_p.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
+        scale_ptr = fq_p.scale.data_ptr() if fq_p._quantize else None
+        amax_ptr = fq_p.amax_history.data_ptr() if fq_p._observe else None
+        STATS.add(scores.numel())
+    else:
+        fmt, lut, scale_ptr, amax_ptr = _IDENTITY, None, None, None
+    _native.check(L.qt_softmax_fq_bf16(scores.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                       B, H, Q, C, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut, scale_ptr,
+                                       amax_ptr, st), "qt_softmax_fq_bf16")
+    v = fq_v(value) if fq_v is not None else value
+    return out, torch.matmul(out, v)

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["wikitext_windows", "shard_round_robin", "window_nll", "evaluate_perplexity", "gather_in_order",
+__all__ = ["wikitext_windows", "shard_round_robin", "window_nll", "evaluate_perplexity", "gather_in_order", "GraphedWindow",
            "build_causal_lm", "LLAMA_SHAPES"]
 
 
@@ -45,6 +45,56 @@ def window_nll(model, input_ids: torch.Tensor, trg_len: int) -> torch.Tensor:
     target[:, :-trg_len] = -100
     out = model(input_ids, labels=target, use_cache=False)
     return out.loss.float()
+
+
+class GraphedWindow:
+    """One window forward (+ loss) captured into a hipGraph.  The path has no host synchronisation
+    (scales, amax and enable flags stay on the device), so the ~2 500 kernel launches of a LLaMA
+    window replay back-to-back instead of being issued one by one from Python.  The label mask
+    (positions scored) is an input buffer, so windows with different `trg_len` share the graph."""
+
+    def __init__(self, model, max_length, _unused=None, device=None):
+        self.model = model
+        self.device = device if device is not None else next(model.parameters()).device
+        self.ids = torch.zeros((1, max_length), dtype=torch.long, device=self.device)
+        self.labels = torch.zeros((1, max_length), dtype=torch.long, device=self.device)
+        # HF builds the causal mask with a host->device scalar copy, which a stream capture forbids; a
+        # ready-made 4-D additive mask (same values: 0 / finfo.min) is passed through unchanged instead.
+        dtype = next(model.parameters()).dtype
+        self.mask = torch.full((max_length, max_length), torch.finfo(dtype).min, dtype=torch.float32,
+                               device=self.device).triu(1).to(dtype)[None, None]
+        self.graph = None
+        self.loss = None
+
+    @torch.no_grad()
+    def _forward(self):
+        out = self.model(self.ids, attention_mask=self.mask, labels=self.labels, use_cache=False)
+        return out.loss.float()
+
+    @torch.no_grad()
+    def capture(self, example_ids):
+        self._set(example_ids, example_ids.shape[1])
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._forward()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._forward()
+
+    def _set(self, ids, trg_len):
+        self.ids.copy_(ids)
+        self.labels.copy_(ids)
+        self.labels[:, : ids.shape[1] - trg_len] = -100
+
+    @torch.no_grad()
+    def replay(self, ids, trg_len):
+        self._set(ids, trg_len)
+        self.graph.replay()
+        return self.loss
 
 
 def gather_in_order(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:

@@ -51,6 +51,11 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     if scaling is None:
         scaling = query.size(-1) ** -0.5
     scores = module.qk_matmul(query, key.transpose(2, 3))
+    from ...fused import fused_scores_to_probs_or_none
+    fused = fused_scores_to_probs_or_none(module, scores, attention_mask, scaling, dropout, value)
+    if fused is not None:
+        probs, out = fused
+        return out.transpose(1, 2).contiguous(), probs
     scores = module.attn_scaling(scores, scaling)
     if attention_mask is not None:
         scores = scores + attention_mask[..., : key.shape[-2]]

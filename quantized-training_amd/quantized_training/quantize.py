@@ -106,10 +106,11 @@ class _TensorArgQuantizer:
     """The hook body: fake-quantize every Tensor positional argument with its own lazily created
     fake-quantizer, keyed by argument index (upstream quantize.py:128-140)."""
 
-    def __init__(self, owner_dict, ctr, qualified_name):
+    def __init__(self, owner_dict, ctr, qualified_name, forward_side=False):
         self.fqs = owner_dict
         self.ctr = ctr
         self.name = qualified_name
+        self.forward_side = forward_side
 
     def __call__(self, module, tensors):
         out = []
@@ -122,6 +123,9 @@ class _TensorArgQuantizer:
                 fq = self.ctr(device=t.device)
                 fq.name = f"{self.name}.{key}"
                 self.fqs[key] = fq
+                if self.forward_side:
+                    from .fused import mark_fp8_producer
+                    mark_fp8_producer(module, fq)
             out.append(self.fqs[key](t))
         return tuple(out)
 
@@ -131,7 +135,7 @@ def _register_module_hook(module, hook_name, name):
     holder = nn.ModuleDict()
     module.add_module(hook_name, holder)
     ctr = module.qconfig.activation if hook_name == "activation_pre_process" else module.qconfig.error
-    body = _TensorArgQuantizer(holder, ctr, name)
+    body = _TensorArgQuantizer(holder, ctr, name, forward_side=(hook_name == "activation_pre_process"))
     if hook_name == "activation_pre_process":
         module.register_forward_pre_hook(body)
     elif hook_name == "error_pre_process":

@@ -392,3 +392,141 @@ def test_full_size_properties(nv):
         assert np.array_equal(ys, expect_bf16(xs, dtype, 1.0))
         vals = torch.unique(y.view(torch.int16)).cpu().numpy().view(np.uint16)
         assert np.all(np.isin(vals, o.get_quantization_map(dtype)))
+
+
+@pytest.mark.parametrize("dtype,tdtype", [("e4m3", torch.float8_e4m3fn), ("e5m2", torch.float8_e5m2)])
+@pytest.mark.parametrize("scale", [1.0, 0.25, 0.037])
+def test_fp8_side_output(nv, dtype, tdtype, scale):
+    """qt_fake_quant_bf16_fp8: the FP8 bytes decode (OCP, torch's float8 types) to exactly the oracle's
+    quantized code q = map[x / s]; the optional bf16 output is the usual fake-quantized tensor."""
+    L = nv.lib()
+    xb = o.all_bf16_patterns()
+    x = dev_u16(xb)
+    fmt = nv.format_for(dtype)
+    s = dev_f32(np.array([scale], np.float32))
+    qmap = o.get_quantization_map(dtype)
+    sb = o.f32_to_bf16(np.array([scale], np.float32))
+    q_exp = o.canon_nan16(o.quantize_bf16(xb, qmap, sb))
+    for both in (True, False):
+        y = torch.zeros_like(x)
+        y8 = torch.zeros(x.numel(), dtype=torch.uint8, device="cuda")
+        amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+        nv.check(L.qt_fake_quant_bf16_fp8(x.data_ptr(), y.data_ptr() if both else None, y8.data_ptr(), x.numel(),
+                                          ctypes.byref(fmt), s.data_ptr(), amax.data_ptr(), stream()), "fq8")
+        torch.cuda.synchronize()
+        dec = y8.view(tdtype).float().bfloat16().view(torch.int16)
+        assert np.array_equal(o.canon_nan16(host_u16(dec)), q_exp), (dtype, scale, both)
+        if both:
+            assert np.array_equal(o.canon_nan16(host_u16(y)), expect_bf16(xb, dtype, scale))
+        assert (host_u32(amax)[0] & 0x7FFFFFFF) > 0x7F800000      # the pattern sweep contains NaNs
+
+
+def test_fp8_linear_path(nv):
+    """quantize(model) with e4m3 act+weight (no qs): the QAT Linear runs activation pass (bf16 + FP8),
+    FP8-only weight pass and an FP8 GEMM; result equals the oracle-quantized operands' product within
+    fp32-accumulation + one bf16 output rounding."""
+    import quantized_training as qt
+    from quantized_training import fused
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 384).cuda()
+    model = torch.nn.Sequential(lin)
+    args = qt.add_qspec_args().parse_args(["--activation", "e4m3", "--weight", "e4m3", "--bf16"])
+    qt.quantize(model, args)
+    x = (torch.randn(4, 96, 512, device="cuda") * 2).bfloat16()
+    with torch.no_grad():
+        y = model(x)
+        assert model[0].activation_pre_process["0"]._emit_fp8 == "both"
+        qmap = o.get_quantization_map("e4m3")
+        fq = lambda t: torch.from_numpy(o.bf16_to_f32(o.vmap_bf16(host_u16(t.contiguous().view(torch.int16)), qmap))).cuda()  # noqa: E731
+        ref = torch.nn.functional.linear(fq(x).double(), fq(model[0].weight).double(), model[0].bias.double())
+    err = (y.double() - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 1e-2 * (512 ** 0.5) * 2.0 ** -8
+    assert bool((err <= tol).all()), float((err - tol).max())
+    os.environ["QT_FP8_GEMM"] = "0"
+    try:
+        with torch.no_grad():
+            y2 = model(x)
+    finally:
+        del os.environ["QT_FP8_GEMM"]
+    assert bool(((y2.double() - ref).abs() <= tol).all())
+
+
+def _bf16_ulp_diff(a, b):
+    """|a - b| in units of bf16 ULPs of the larger magnitude (a, b bf16 tensors, finite)."""
+    ai = a.view(torch.int16).to(torch.int32) & 0xFFFF
+    bi = b.view(torch.int16).to(torch.int32) & 0xFFFF
+    key = lambda t: torch.where(t >= 0x8000, 0x8000 - t, t)  # noqa: E731  monotone integer key
+    return (key(ai) - key(bi)).abs()
+
+
+@pytest.mark.parametrize("shape,mask_kind", [((2, 4, 128, 128), "causal"), ((1, 32, 1024, 1024), "causal"),
+                                              ((16, 12, 384, 384), "padding"), ((2, 3, 40, 72), None)])
+def test_softmax_fq(nv, shape, mask_kind):
+    """qt_softmax_fq_bf16 vs the unfused torch chain it replaces.  Everything is bit-defined except
+    exp() and the order of the row sum, so the plain-softmax output may differ from torch's by at most
+    1 bf16 ULP on a small fraction of elements; after E4M3 fake-quantization the two results are equal
+    except where such a 1-ULP difference straddles an E4M3 rounding boundary (<= 1 E4M3 step)."""
+    L = nv.lib()
+    B, H, Q, C = shape
+    torch.manual_seed(1)
+    scores = (torch.randn(shape, device="cuda") * 3).bfloat16()
+    scaling = 0.08838834764831845
+    mask = None
+    minv = torch.finfo(torch.bfloat16).min
+    if mask_kind == "causal":
+        mask = torch.full((Q, C), minv, device="cuda").triu(1).bfloat16()[None, None]
+    elif mask_kind == "padding":
+        mask = torch.zeros(B, 1, 1, C, device="cuda", dtype=torch.bfloat16)
+        mask[:, :, :, C - 37:] = minv
+    ref = scores * scaling
+    if mask is not None:
+        ref = ref + mask
+    ref = torch.softmax(ref, dim=-1, dtype=torch.float32).to(torch.bfloat16)
+    msb = msh = msq = 0
+    if mask is not None:
+        msb = mask.stride(0) if mask.shape[0] > 1 else 0
+        msq = mask.stride(2) if mask.shape[2] > 1 else 0
+    for dtype in (None, "e4m3", "posit8_1"):
+        fmt = nv.format_for(dtype)
+        lut = dev_u16(nv.build_map_u16(dtype))
+        out = torch.empty_like(scores)
+        amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+        nv.check(L.qt_softmax_fq_bf16(scores.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                      B, H, Q, C, msb, msh, msq, scaling, ctypes.byref(fmt), lut.data_ptr(), None,
+                                      amax.data_ptr(), stream()), "softmax")
+        torch.cuda.synchronize()
+        if dtype is None:
+            ulp = _bf16_ulp_diff(out, ref)
+            assert int(ulp.max()) <= 1
+            assert float((ulp > 0).float().mean()) < 0.02
+            assert abs(amax.view(torch.float32).item() - ref.max().float().item()) <= 2.0 ** -8 * ref.max().float().item()
+        else:
+            qmap = torch.from_numpy(o.get_quantization_map(dtype).view(np.int16)).cuda().view(torch.bfloat16)
+            expq = qmap[(ref.view(torch.int16).to(torch.int32) & 0xFFFF).long()]
+            diff = (out.float() - expq.float()).abs()
+            assert float((diff > 0).float().mean()) < 0.02
+            assert bool((diff <= 0.13 * expq.float().abs() + 2.0 ** -9).all())
+
+
+def test_llama_attention_fused_vs_unfused(nv):
+    """Tiny LLaMA through quantize(): the fused score path (one HIP pass) and the unfused module chain
+    give the same logits up to the 1-ULP softmax caveat; hooks, names and element counts are unchanged."""
+    import quantized_training as qt
+    from quantized_training import harness
+    from quantized_training.fake_quantize import STATS
+    model = harness.build_causal_lm("llama-tiny", device="cuda", seed=0)
+    args = qt.add_qspec_args().parse_args(["--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"])
+    qt.quantize(model, args)
+    ids = torch.randint(0, 512, (1, 256), device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    with torch.no_grad():
+        model(ids)                                     # creates the per-tensor fake-quantizers
+        STATS.reset(); a = model(ids).logits.float(); n_fused = STATS.elements
+        os.environ["QT_FUSED_SOFTMAX"] = "0"
+        try:
+            STATS.reset(); b = model(ids).logits.float(); n_unfused = STATS.elements
+        finally:
+            del os.environ["QT_FUSED_SOFTMAX"]
+    assert n_fused == n_unfused
+    assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max())
+    names = [n for n, _ in model.named_modules() if n.endswith("av_matmul.activation_pre_process.0")]
+    assert len(names) == 2
