@@ -16,32 +16,36 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-// x / s for a wave-uniform divisor, bit-identical to the IEEE fp32 division torch performs.
-// Fast path: r = RN(1/s) once per thread, then q = x*r refined by two FMA residual steps (the same
-// correction chain as the hardware v_div_* sequence, started from an exactly rounded reciprocal).
-// It is exact when no intermediate can underflow or overflow: 2^-25 <= |s| <= 2^20 and
-// (x == 0 or 2^-102 <= |x| <= 2^100); everything else (incl. Inf / NaN) takes the full division.
+// x / s for a wave-uniform divisor, bit-identical to what torch computes.
+//
+// The quotient is only ever consumed through a 16-bit view: rounded to bf16 (bf16 tensors) or folded
+// to hi16 | (lo16 != 0) (fp32 tensors, decomposed.py:151-153).  q = x * RN(1/s) is within 2 fp32 ULPs of
+// the correctly rounded x / s, so it yields the same 16-bit view unless its low half lies within 3 ULPs
+// of the decision point (0x8000 for the bf16 rounding, 0x0000 for the fold).  Those elements (4e-5 of
+// random bf16 data; validated on 2e8 cases incl. subnormals / Inf) set `bad`, and the caller redoes the
+// 16-B vector with the full IEEE division -- one rarely taken branch per vector, none per element.
+// Power-of-two scales make x * (1/s) exact, so nothing is flagged; scales whose reciprocal is not a
+// normal number use the full division throughout.
 struct UniformDiv {
     float s, r;
-    bool safe;
+    bool safe, pow2;
     __device__ __forceinline__ explicit UniformDiv(float scale) : s(scale), r(1.0f / scale) {
         const uint32_t as = qt_f2u(scale) & 0x7FFFFFFFu;
-        safe = as >= ((127u - 25u) << 23) && as <= ((127u + 20u) << 23);
+        safe = as >= ((127u - 100u) << 23) && as <= ((127u + 100u) << 23);
+        pow2 = (as & 0x007FFFFFu) == 0u;
     }
-    __device__ __forceinline__ float operator()(float x) const {
-        const uint32_t ax = qt_f2u(x) & 0x7FFFFFFFu;
-        constexpr uint32_t lo = (127u - 102u) << 23, hi = (127u + 100u) << 23;
-        const bool ok = safe && (((ax - lo) <= (hi - lo)) || ax == 0u);
-        if (__builtin_expect(ok, 1)) {
-            const float q0 = x * r;
-            float e = __builtin_fmaf(-q0, s, x);
-            float q = __builtin_fmaf(e, r, q0);
-            e = __builtin_fmaf(-q, s, x);
-            q = __builtin_fmaf(e, r, q);
-            return ax == 0u ? q0 : q;            // the residual steps would turn -0 into +0
-        }
-        return x / s;
+    __device__ __forceinline__ float fast16(float x, bool &bad) const {    // result feeds a bf16 rounding
+        const float q = x * r;
+        bad |= (((qt_f2u(q) + 3u - 0x8000u) & 0xFFFFu) <= 6u) & !pow2;
+        return q;
     }
+    __device__ __forceinline__ float fast32(float x, bool &bad) const {    // result feeds the fp32 -> index fold
+        const float q = x * r;
+        bad |= (((qt_f2u(q) + 3u) & 0xFFFFu) <= 6u) & !pow2;
+        return q;
+    }
+    __device__ __forceinline__ float exact(float x) const { return x / s; }
+    __device__ __forceinline__ float operator()(float x) const { return x / s; }
 };
 
 template <int KIND>
@@ -80,6 +84,46 @@ __device__ __forceinline__ uint32_t fq_word_bf16(uint32_t w, float s, const Roun
     uint32_t r0 = rnd(lo), r1 = rnd(hi);
     if constexpr (!UNIT) return pack_bf16x2(qt_u2f(r0) * s, qt_u2f(r1) * s);
     return (r0 >> 16) | (r1 & 0xFFFF0000u);
+}
+
+// Vector-level variants.  DIV: 0 = scale 1 (no division / multiply), 1 = fast quotient (sets `bad`),
+// 2 = full IEEE division.
+constexpr int kDivUnit = 0, kDivFast = 1, kDivExact = 2;
+
+template <int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint32_t fq_word_bf16_d(uint32_t w, const UniformDiv &dv, const Rounder<KIND> &rnd,
+                                                   uint32_t &amax, bool &bad) {
+    uint32_t lo = w << 16, hi = w & 0xFFFF0000u;
+    if constexpr (OBS) {
+        uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+        amax = amax > a0 ? amax : a0;
+        amax = amax > a1 ? amax : a1;
+    }
+    if constexpr (DIV != kDivUnit) {
+        uint32_t q;
+        if constexpr (DIV == kDivFast) q = pack_bf16x2(dv.fast16(qt_u2f(lo), bad), dv.fast16(qt_u2f(hi), bad));
+        else q = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
+        lo = q << 16;
+        hi = q & 0xFFFF0000u;
+    }
+    uint32_t r0 = rnd(lo), r1 = rnd(hi);
+    if constexpr (DIV != kDivUnit) return pack_bf16x2(qt_u2f(r0) * dv.s, qt_u2f(r1) * dv.s);
+    return (r0 >> 16) | (r1 & 0xFFFF0000u);
+}
+
+template <int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint32_t fq_word_f32_d(uint32_t w, const UniformDiv &dv, const Rounder<KIND> &rnd,
+                                                  uint32_t &amax, bool &bad) {
+    if constexpr (OBS) {
+        uint32_t a = w & 0x7FFFFFFFu;
+        amax = amax > a ? amax : a;
+    }
+    float q = qt_u2f(w);
+    if constexpr (DIV == kDivFast) q = dv.fast32(q, bad);
+    else if constexpr (DIV == kDivExact) q = dv.exact(q);
+    float r = qt_u2f(rnd(qt_fold_img(qt_f2u(q))));
+    if constexpr (DIV != kDivUnit) r = r * dv.s;
+    return qt_f2u(r);
 }
 
 template <int KIND, bool UNIT, bool OBS>

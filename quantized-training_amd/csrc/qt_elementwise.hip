@@ -29,20 +29,35 @@ constexpr int kLutBlock = 1024;   // one workgroup per CU (128 KiB LDS), 16 wave
 constexpr int kAluBlock = 256;
 constexpr int kUnroll = 1;        // 16-B loads per lane per tile (measured best: many small tiles)
 
-template <int IO, int KIND, bool UNIT, bool OBS>
-__device__ __forceinline__ uint4 fq_vec(uint4 v, float s, const Rounder<KIND> &rnd, uint32_t &amax) {
+template <int IO, int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint4 fq_vec_d(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax, bool &bad) {
     if constexpr (IO == kIoBf16) {
-        v.x = fq_word_bf16<KIND, UNIT, OBS>(v.x, s, rnd, amax);
-        v.y = fq_word_bf16<KIND, UNIT, OBS>(v.y, s, rnd, amax);
-        v.z = fq_word_bf16<KIND, UNIT, OBS>(v.z, s, rnd, amax);
-        v.w = fq_word_bf16<KIND, UNIT, OBS>(v.w, s, rnd, amax);
+        v.x = fq_word_bf16_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
+        v.y = fq_word_bf16_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
+        v.z = fq_word_bf16_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
+        v.w = fq_word_bf16_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
     } else {
-        v.x = fq_word_f32<KIND, UNIT, OBS>(v.x, s, rnd, amax);
-        v.y = fq_word_f32<KIND, UNIT, OBS>(v.y, s, rnd, amax);
-        v.z = fq_word_f32<KIND, UNIT, OBS>(v.z, s, rnd, amax);
-        v.w = fq_word_f32<KIND, UNIT, OBS>(v.w, s, rnd, amax);
+        v.x = fq_word_f32_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
+        v.y = fq_word_f32_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
+        v.z = fq_word_f32_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
+        v.w = fq_word_f32_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
     }
     return v;
+}
+
+// One 16-B vector.  With a non-unit scale the fast quotient is tried first and the whole vector is redone
+// with the full division only if one of its elements left the range where the fast form is exact.
+template <int IO, int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint4 fq_vec(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
+    bool bad = false;
+    uint4 r = fq_vec_d<IO, KIND, DIV, OBS>(v, dv, rnd, amax, bad);
+    if constexpr (DIV == kDivFast) {
+        if (__builtin_expect(bad, 0)) {
+            uint32_t unused = 0;
+            r = fq_vec_d<IO, KIND, kDivExact, false>(v, dv, rnd, unused, bad);
+        }
+    }
+    return r;
 }
 
 // scalar element (tails, unaligned tensors)
@@ -111,8 +126,8 @@ __device__ __forceinline__ void st_vec(uint4 *p, uint4 v, bool nt) {
     }
 }
 
-template <int IO, int KIND, bool UNIT, bool OBS, int BLOCK, int kUnroll, int NT>
-__device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t nvec, float s,
+template <int IO, int KIND, int DIV, bool OBS, int BLOCK, int kUnroll, int NT>
+__device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t nvec, const UniformDiv &dv,
                                           const Rounder<KIND> &rnd, uint32_t &amax) {
     constexpr size_t kTile = (size_t)BLOCK * kUnroll;
     const size_t nfull = nvec / kTile;
@@ -123,14 +138,14 @@ __device__ __forceinline__ void fq_stream(const uint4 *__restrict__ x, uint4 *__
         for (int u = 0; u < kUnroll; ++u) v[u] = ld_vec(x + base + (size_t)u * BLOCK, NT & 1);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            uint4 r = fq_vec<IO, KIND, UNIT, OBS>(v[u], s, rnd, amax);
+            uint4 r = fq_vec<IO, KIND, DIV, OBS>(v[u], dv, rnd, amax);
             if (y) st_vec(y + base + (size_t)u * BLOCK, r, NT & 2);
         }
     }
     // ragged last tile: the block that would own it in the grid-stride order
     if (nfull % gridDim.x == blockIdx.x) {
         for (size_t i = nfull * kTile + threadIdx.x; i < nvec; i += BLOCK) {
-            uint4 r = fq_vec<IO, KIND, UNIT, OBS>(x[i], s, rnd, amax);
+            uint4 r = fq_vec<IO, KIND, DIV, OBS>(x[i], dv, rnd, amax);
             if (y) y[i] = r;
         }
     }
@@ -161,10 +176,13 @@ __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, 
     uint32_t amax = 0;
     const uint4 *x = (const uint4 *)xv;
     uint4 *y = (uint4 *)yv;
+    const UniformDiv dv(s);
     if (unit)
-        fq_stream<IO, KIND, true, OBS, BLOCK, kUnroll, NT>(x, y, nvec, s, rnd, amax);
+        fq_stream<IO, KIND, kDivUnit, OBS, BLOCK, kUnroll, NT>(x, y, nvec, dv, rnd, amax);
+    else if (dv.safe)
+        fq_stream<IO, KIND, kDivFast, OBS, BLOCK, kUnroll, NT>(x, y, nvec, dv, rnd, amax);
     else
-        fq_stream<IO, KIND, false, OBS, BLOCK, kUnroll, NT>(x, y, nvec, s, rnd, amax);
+        fq_stream<IO, KIND, kDivExact, OBS, BLOCK, kUnroll, NT>(x, y, nvec, dv, rnd, amax);
     constexpr int kPer = IO == kIoBf16 ? 8 : 4;
     if (blockIdx.x == gridDim.x - 1) {
         for (size_t i = nvec * kPer + threadIdx.x; i < n; i += BLOCK) fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
@@ -218,23 +236,37 @@ __global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, u
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         const uint4 v = x[i];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        float q[8];
+        uint32_t img[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
+            img[2 * j] = w[j] << 16;
+            img[2 * j + 1] = w[j] & 0xFFFF0000u;
             if constexpr (OBS) {
-                uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+                uint32_t a0 = img[2 * j] & 0x7FFFFFFFu, a1 = img[2 * j + 1] & 0x7FFFFFFFu;
                 amax = amax > a0 ? amax : a0;
                 amax = amax > a1 ? amax : a1;
             }
-            if (!unit) {
-                uint32_t p = pack_bf16x2(dv(qt_u2f(lo)), dv(qt_u2f(hi)));
-                lo = p << 16;
-                hi = p & 0xFFFF0000u;
-            }
-            q[2 * j] = qt_u2f(qt_fp_sat_u32(lo, fmt.p0, fmt.p1, fmt.fhi));
-            q[2 * j + 1] = qt_u2f(qt_fp_sat_u32(hi, fmt.p0, fmt.p1, fmt.fhi));
         }
+        if (!unit) {
+            bool bad = !dv.safe;
+            uint32_t qd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qd[j] = pack_bf16x2(dv.fast16(qt_u2f(img[2 * j]), bad), dv.fast16(qt_u2f(img[2 * j + 1]), bad));
+            if (__builtin_expect(bad, 0)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    qd[j] = pack_bf16x2(dv.exact(qt_u2f(img[2 * j])), dv.exact(qt_u2f(img[2 * j + 1])));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                img[2 * j] = qd[j] << 16;
+                img[2 * j + 1] = qd[j] & 0xFFFF0000u;
+            }
+        }
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = qt_u2f(qt_fp_sat_u32(img[j], fmt.p0, fmt.p1, fmt.fhi));
         uint2 o8;
         o8.x = pack_fp8x4<E5M2>(q[0], q[1], q[2], q[3]);
         o8.y = pack_fp8x4<E5M2>(q[4], q[5], q[6], q[7]);

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["wikitext_windows", "shard_round_robin", "window_nll", "evaluate_perplexity", "gather_in_order", "GraphedWindow",
+           "collect_qa_logits", "train_steps",
            "build_causal_lm", "LLAMA_SHAPES"]
 
 
@@ -166,3 +167,69 @@ def build_causal_lm(shape: str = "llama-2-7b", device="cuda", dtype=torch.bfloat
                 p.normal_(0.0, 0.02, generator=gen)
     model.eval()
     return model
+
+
+# ---- H2: SQuAD-style evaluation (run_qa_no_trainer.py:914-959) ---------------------------------------
+@torch.no_grad()
+def collect_qa_logits(model, batches, device=None, rank: int = 0, world: int = 1, group=None):
+    """Runs every batch (dict of tensors with `input_ids`, optional `attention_mask` / `token_type_ids`)
+    through a question-answering model exactly as the reference's `run_eval` does -- `model.eval()`,
+    `no_grad`, placeholder `start_positions` / `end_positions` of ones, logits collected as fp32 -- with the
+    batches sharded round-robin over ranks and the fp32 logits all-gathered back into dataloader order.
+    Returns (start_logits [N_features, S], end_logits [N_features, S]) on every rank; the HF
+    post-processing / metric step consumes them unchanged."""
+    model.eval()
+    device = device if device is not None else next(model.parameters()).device
+    mine = shard_round_robin(list(enumerate(batches)), rank, world)
+    starts, ends = [], []
+    for _, batch in mine:
+        batch = {k: v.to(device) for k, v in batch.items()}
+        bsz = batch["input_ids"].size(0)
+        pos = torch.ones(bsz, dtype=torch.long, device=device)
+        out = model(**batch, start_positions=pos, end_positions=pos.clone())
+        starts.append(out.start_logits.float())
+        ends.append(out.end_logits.float())
+    if world == 1:
+        return torch.cat(starts).cpu(), torch.cat(ends).cpu()
+    seq = batches[0]["input_ids"].shape[1]
+    sizes = [b["input_ids"].shape[0] for b in batches]
+    per_rank_rows = max(sum(sizes[r::world]) for r in range(world))
+    local = torch.zeros((2, per_rank_rows, seq), dtype=torch.float32, device=device)
+    if starts:
+        n = sum(t.shape[0] for t in starts)
+        local[0, :n] = torch.cat(starts)
+        local[1, :n] = torch.cat(ends)
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)                      # one collective: <= 2 x N x S fp32 (~33 MB for SQuAD v1.1)
+    out_s = [None] * len(batches)
+    out_e = [None] * len(batches)
+    for r in range(world):
+        off = 0
+        for i in range(r, len(batches), world):
+            out_s[i] = parts[r][0, off:off + sizes[i]]
+            out_e[i] = parts[r][1, off:off + sizes[i]]
+            off += sizes[i]
+    return torch.cat(out_s).cpu(), torch.cat(out_e).cpu()
+
+
+# ---- H3: GLUE-style fine-tuning loop (run_glue_no_trainer.py:647-667) ---------------------------------
+def train_steps(model, batches, optimizer, lr_scheduler=None, max_grad_norm: float = 1.0,
+                gradient_accumulation_steps: int = 1):
+    """The reference's inner training loop: forward (hooks fake-quantize activations and weights),
+    `loss.backward()` (backward-pre hooks quantize incoming gradients, backward hooks the residual branch),
+    clip_grad_norm_(1.0, error_if_nonfinite=True), optimizer / scheduler step.  Returns the per-step losses."""
+    model.train()
+    device = next(model.parameters()).device
+    losses = []
+    for step, batch in enumerate(batches):
+        batch = {k: v.to(device) for k, v in batch.items()}
+        loss = model(**batch).loss
+        losses.append(float(loss.detach().float()))
+        (loss / gradient_accumulation_steps).backward()
+        if step % gradient_accumulation_steps == 0 or step == len(batches) - 1:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm, error_if_nonfinite=True)
+            optimizer.step()
+            if lr_scheduler is not None:
+                lr_scheduler.step()
+            optimizer.zero_grad()
+    return losses

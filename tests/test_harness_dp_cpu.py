@@ -79,3 +79,67 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
 def test_gather_in_order_single_rank_identity():
     x = torch.arange(5, dtype=torch.float32)
     assert torch.equal(harness.gather_in_order(x, 5, 0, 1), x)
+
+
+def _qa_model():
+    from transformers import BertConfig, BertForQuestionAnswering
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100,
+                     max_position_embeddings=64)
+    m = BertForQuestionAnswering(cfg).eval()
+    qt.quantize(m, qt.add_qspec_args().parse_args(["--activation", "posit8_1", "--weight", "posit8_1"]))
+    return m
+
+
+def _qa_batches():
+    g = torch.Generator().manual_seed(9)
+    sizes = [4, 4, 4, 4, 3]                                   # ragged last batch, like a real dataloader
+    return [{"input_ids": torch.randint(3, 100, (n, 32), generator=g),
+             "attention_mask": torch.ones(n, 32, dtype=torch.long)} for n in sizes]
+
+
+def _qa_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    s, e = harness.collect_qa_logits(_qa_model(), _qa_batches(), rank=rank, world=world)
+    if rank == 1:
+        torch.save((s, e), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_qa_logit_collection_two_ranks(tmp_path):
+    torch.set_num_threads(2)
+    s1, e1 = harness.collect_qa_logits(_qa_model(), _qa_batches())
+    assert s1.shape == (19, 32) and s1.dtype == torch.float32
+    out = str(tmp_path / "qa.pt")
+    mp.spawn(_qa_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    s2, e2 = torch.load(out)
+    assert torch.equal(s1, s2) and torch.equal(e1, e2)
+
+
+def test_glue_style_training_loop_with_quantized_backward():
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100,
+                        max_position_embeddings=66, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = RobertaForSequenceClassification(cfg)
+    args = qt.add_qspec_args().parse_args([
+        "--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
+        "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10",
+        "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual"])
+    qt.quantize(m, args)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 100, (8, 16), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)}
+               for _ in range(6)]
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    losses = harness.train_steps(m, batches, opt)
+    assert len(losses) == 6 and all(l == l and l < 10 for l in losses)
+    mods = dict(m.named_modules())
+    fq = mods["roberta.encoder.layer.0.attention.self.query.error_pre_process.0"]
+    assert fq.dtype == "fp8_e5m2" and float(fq.amax_history.max()) > 0 and float(fq.scale) != 1.0
+    assert "roberta.encoder.layer.0.attention.self.query.error_post_process.0" in mods       # residual-feeding layer
+    assert "roberta.encoder.layer.0.output.residual.error_post_process.0" in mods
