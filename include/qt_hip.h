@@ -137,10 +137,17 @@ int qt_fake_quant_f32(const float *x_dev, float *y_dev, size_t n, const qt_forma
  * FP8 byte per element (y8_dev; exact, every e4m3/e5m2 value is an FP8 value), for FP8-MFMA GEMMs:
  * (q, s) is what the reference's converted graphs feed the GEMM (quantize -> GEMM ->
  * dequantize(s_x * s_w), quantize_pt2e.py:323-446).  y_dev (bf16 fake-quantized tensor) may be NULL.
- * n must be a multiple of 8; fmt must be the e4m3 or e5m2 descriptor of qt_format_for. */
+ * n must be a multiple of 16; fmt must be the e4m3 or e5m2 descriptor of qt_format_for. */
 int qt_fake_quant_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n,
                            const qt_format *fmt, const float *scale_f32_dev, uint32_t *amax_bits_dev,
                            void *stream);
+/* Same pass reading a permuted view: x is a logical [d0, d1, d2, inner] bf16 tensor with element strides
+ * (s0, s1, s2, 1) -- e.g. attention's q / k / v, [B, S, H, D] storage viewed as [B, H, S, D] -- and y is
+ * written contiguous, which is the layout the reference's vmap returns (decomposed.py:155).  Saves the
+ * separate .contiguous() copy.  inner and the strides must be multiples of 8. */
+int qt_fake_quant_rows_bf16(const uint16_t *x_dev, uint16_t *y_dev, long d0, long d1, long d2, long inner,
+                            long s0, long s1, long s2, const qt_format *fmt, const uint16_t *lut_dev,
+                            const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
 int qt_fake_quant_pc_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t outer, size_t C, size_t inner,
                           const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
                           uint32_t *amax_bits_dev, void *stream);

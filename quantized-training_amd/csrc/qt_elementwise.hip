@@ -225,67 +225,117 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
     return (uint32_t)w;
 }
 
+// Quantise one 16-B vector of bf16 to eight fp32 images of q = map[x / s].
+__device__ __forceinline__ void fq8_vec(const uint4 v, const qt_format &fmt, const UniformDiv &dv, bool unit, bool obs,
+                                        uint32_t &amax, float (&q)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t img[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        img[2 * j] = w[j] << 16;
+        img[2 * j + 1] = w[j] & 0xFFFF0000u;
+        if (obs) {
+            uint32_t a0 = img[2 * j] & 0x7FFFFFFFu, a1 = img[2 * j + 1] & 0x7FFFFFFFu;
+            amax = amax > a0 ? amax : a0;
+            amax = amax > a1 ? amax : a1;
+        }
+    }
+    if (!unit) {
+        bool bad = !dv.safe;
+        uint32_t qd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            qd[j] = pack_bf16x2(dv.fast16(qt_u2f(img[2 * j]), bad), dv.fast16(qt_u2f(img[2 * j + 1]), bad));
+        if (__builtin_expect(bad, 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qd[j] = pack_bf16x2(dv.exact(qt_u2f(img[2 * j])), dv.exact(qt_u2f(img[2 * j + 1])));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            img[2 * j] = qd[j] << 16;
+            img[2 * j + 1] = qd[j] & 0xFFFF0000u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = qt_u2f(qt_fp_sat_u32(img[j], fmt.p0, fmt.p1, fmt.fhi));
+}
+
+__device__ __forceinline__ uint4 bf16_vec_from(const float (&q)[8], float s, bool unit) {
+    uint4 o;
+    if (unit) {
+        o.x = (qt_f2u(q[0]) >> 16) | (qt_f2u(q[1]) & 0xFFFF0000u);
+        o.y = (qt_f2u(q[2]) >> 16) | (qt_f2u(q[3]) & 0xFFFF0000u);
+        o.z = (qt_f2u(q[4]) >> 16) | (qt_f2u(q[5]) & 0xFFFF0000u);
+        o.w = (qt_f2u(q[6]) >> 16) | (qt_f2u(q[7]) & 0xFFFF0000u);
+    } else {
+        o.x = pack_bf16x2(q[0] * s, q[1] * s);
+        o.y = pack_bf16x2(q[2] * s, q[3] * s);
+        o.z = pack_bf16x2(q[4] * s, q[5] * s);
+        o.w = pack_bf16x2(q[6] * s, q[7] * s);
+    }
+    return o;
+}
+
+// Each lane handles 16 consecutive elements: two 16-B loads -> one 16-B FP8 store (+ two bf16 stores).
 template <bool OBS, bool BOTH, bool E5M2>
-__global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, uint2 *__restrict__ y8,
-                                                  size_t nvec, qt_format fmt, const float *__restrict__ scale,
+__global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, uint4 *__restrict__ y8,
+                                                  size_t npair, qt_format fmt, const float *__restrict__ scale,
                                                   uint32_t *amax_out) {
     float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
     const bool unit = (s == 1.0f);
     const UniformDiv dv(s);
     uint32_t amax = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const uint4 v = x[i];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t img[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            img[2 * j] = w[j] << 16;
-            img[2 * j + 1] = w[j] & 0xFFFF0000u;
-            if constexpr (OBS) {
-                uint32_t a0 = img[2 * j] & 0x7FFFFFFFu, a1 = img[2 * j + 1] & 0x7FFFFFFFu;
-                amax = amax > a0 ? amax : a0;
-                amax = amax > a1 ? amax : a1;
-            }
-        }
-        if (!unit) {
-            bool bad = !dv.safe;
-            uint32_t qd[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                qd[j] = pack_bf16x2(dv.fast16(qt_u2f(img[2 * j]), bad), dv.fast16(qt_u2f(img[2 * j + 1]), bad));
-            if (__builtin_expect(bad, 0)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    qd[j] = pack_bf16x2(dv.exact(qt_u2f(img[2 * j])), dv.exact(qt_u2f(img[2 * j + 1])));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                img[2 * j] = qd[j] << 16;
-                img[2 * j + 1] = qd[j] & 0xFFFF0000u;
-            }
-        }
-        float q[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = qt_u2f(qt_fp_sat_u32(img[j], fmt.p0, fmt.p1, fmt.fhi));
-        uint2 o8;
-        o8.x = pack_fp8x4<E5M2>(q[0], q[1], q[2], q[3]);
-        o8.y = pack_fp8x4<E5M2>(q[4], q[5], q[6], q[7]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (size_t)gridDim.x * 256) {
+        const uint4 v0 = x[2 * i], v1 = x[2 * i + 1];
+        float q0[8], q1[8];
+        fq8_vec(v0, fmt, dv, unit, OBS, amax, q0);
+        fq8_vec(v1, fmt, dv, unit, OBS, amax, q1);
+        uint4 o8;
+        o8.x = pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
+        o8.y = pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
+        o8.z = pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
+        o8.w = pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
         y8[i] = o8;
         if constexpr (BOTH) {
-            uint4 o;
-            if (unit) {
-                o.x = (qt_f2u(q[0]) >> 16) | (qt_f2u(q[1]) & 0xFFFF0000u);
-                o.y = (qt_f2u(q[2]) >> 16) | (qt_f2u(q[3]) & 0xFFFF0000u);
-                o.z = (qt_f2u(q[4]) >> 16) | (qt_f2u(q[5]) & 0xFFFF0000u);
-                o.w = (qt_f2u(q[6]) >> 16) | (qt_f2u(q[7]) & 0xFFFF0000u);
-            } else {
-                o.x = pack_bf16x2(q[0] * s, q[1] * s);
-                o.y = pack_bf16x2(q[2] * s, q[3] * s);
-                o.z = pack_bf16x2(q[4] * s, q[5] * s);
-                o.w = pack_bf16x2(q[6] * s, q[7] * s);
-            }
-            y[i] = o;
+            y[2 * i] = bf16_vec_from(q0, s, unit);
+            y[2 * i + 1] = bf16_vec_from(q1, s, unit);
         }
+    }
+    if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
+// ---- strided rows -> contiguous ----------------------------------------------------------------------
+// Attention hands the hooks permuted views (q / k / v are [B, S, H, D] storage seen as [B, H, S, D]).  The
+// reference's vmap returns a contiguous tensor (decomposed.py:155), i.e. the layout change is part of the
+// op; doing it inside the pass saves the separate .contiguous() copy (2 + 2 B/element) in front of it.
+// x is a logical [d0, d1, d2, inner] tensor with element strides (s0, s1, s2, 1); y is contiguous.
+struct RowsArgs {
+    const uint16_t *x;
+    uint16_t *y;
+    long d1, d2, vpr;       // vpr = inner / 8 (16-B vectors per row)
+    long s0, s1, s2;
+    size_t nvec;
+};
+
+template <int KIND, bool OBS>
+__global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                      const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<KIND> rnd{fmt, lut};
+    float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
+    const bool unit = (s == 1.0f);
+    const UniformDiv dv(s);
+    uint32_t amax = 0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < a.nvec; v += (size_t)gridDim.x * 256) {
+        const long row = (long)(v / (size_t)a.vpr), c = (long)(v % (size_t)a.vpr);
+        const long i2 = row % a.d2, t = row / a.d2;
+        const long i1 = t % a.d1, i0 = t / a.d1;
+        const uint4 in = *(const uint4 *)(a.x + i0 * a.s0 + i1 * a.s1 + i2 * a.s2 + c * 8);
+        uint4 r;
+        if (unit) r = fq_vec<kIoBf16, KIND, kDivUnit, OBS>(in, dv, rnd, amax);
+        else if (dv.safe) r = fq_vec<kIoBf16, KIND, kDivFast, OBS>(in, dv, rnd, amax);
+        else r = fq_vec<kIoBf16, KIND, kDivExact, OBS>(in, dv, rnd, amax);
+        ((uint4 *)a.y)[v] = r;
     }
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
@@ -652,13 +702,13 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
     const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
     if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
-    if ((n & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
-    const size_t nvec = n / 8;
+    if ((n & 15) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)y8) & 15u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = n / 16;
     const unsigned grid = grid_for(nvec, 256, 32);
     hipStream_t st = (hipStream_t)stream;
     const uint4 *xv = (const uint4 *)x;
     uint4 *yv = (uint4 *)y;
-    uint2 *y8v = (uint2 *)y8;
+    uint4 *y8v = (uint4 *)y8;
 #define QT_FQ8(OBS, BOTH, E5)                                                                                  \
     fq8_kernel<OBS, BOTH, E5><<<grid, 256, 0, st>>>(xv, yv, y8v, nvec, *fmt, scale, amax)
     if (e5m2) {
@@ -669,6 +719,32 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
         else      { if (y) QT_FQ8(false, true, false); else QT_FQ8(false, false, false); }
     }
 #undef QT_FQ8
+    return launch_status();
+}
+
+int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, long d2, long inner, long s0, long s1,
+                            long s2, const qt_format *fmt, const uint16_t *lut, const float *scale, uint32_t *amax,
+                            void *stream) {
+    if (d0 * d1 * d2 * inner == 0) return QT_OK;
+    if (!x || !y || !fmt || d0 < 0 || d1 < 0 || d2 < 0 || inner < 0) return QT_ERR_BAD_ARG;
+    if (fmt->kind == QT_FMT_LUT && !lut) return QT_ERR_BAD_ARG;
+    if ((inner & 7) || ((s0 | s1 | s2) & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u)) return QT_ERR_UNALIGNED;
+    RowsArgs a{x, y, d1, d2, inner / 8, s0, s1, s2, (size_t)(d0 * d1 * d2 * (inner / 8))};
+    const unsigned grid = grid_for(a.nvec, 256, 32);
+    hipStream_t st = (hipStream_t)stream;
+#define QT_ROWS(K)                                                                           \
+    do {                                                                                     \
+        if (amax) fq_rows_kernel<K, true><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);  \
+        else fq_rows_kernel<K, false><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);      \
+    } while (0)
+    switch (fmt->kind) {
+        case QT_FMT_LUT: QT_ROWS(QT_FMT_LUT); break;
+        case QT_FMT_FP_SAT: QT_ROWS(QT_FMT_FP_SAT); break;
+        case QT_FMT_INT: QT_ROWS(QT_FMT_INT); break;
+        case QT_FMT_IDENTITY: QT_ROWS(QT_FMT_IDENTITY); break;
+        default: return QT_ERR_BAD_ARG;
+    }
+#undef QT_ROWS
     return launch_status();
 }
 

@@ -13,8 +13,8 @@
 //     y = fq(p)                                         same per-element function as qt_fake_quant_bf16,
 //                                                       amax(p) max-accumulated for the observer
 // One wavefront owns one row: 16-B loads, lane-local + __shfl_xor reductions, no LDS.
-// Numerics: every step except exp / the row-sum order is bit-defined; p can differ from torch's by at
-// most one bf16 ULP in rare ties (tests/test_gpu_parity.py::test_softmax_fq states the tolerance).
+// Numerics: every step except exp, the row-sum order and e * (1/sum) vs e / sum is bit-defined; p can differ
+// from torch's by at most one bf16 ULP on a small fraction of elements (tests/test_gpu_parity.py::test_softmax_fq states the tolerance).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                t[v][j] = expf(t[v][j] - mx);
+                t[v][j] = __expf(t[v][j] - mx);     // v_exp_f32 path; within the 1-bf16-ULP budget stated above
                 sum += t[v][j];
             }
         sum = wave_sum_f32(sum);
+        const float inv = 1.0f / sum;                 // one division per row; p = e * inv (<= 1 fp32 ULP from e / sum)
         uint4 *dst = (uint4 *)(a.out + row * a.cols);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    uint32_t p = pack_bf16x2(t[v][2 * j] / sum, t[v][2 * j + 1] / sum);   // probabilities, bf16
+                    uint32_t p = pack_bf16x2(t[v][2 * j] * inv, t[v][2 * j + 1] * inv);   // probabilities, bf16
                     if (a.amax) {
                         uint32_t a0 = (p << 16) & 0x7FFFFFFFu, a1 = p & 0x7FFF0000u;
                         amax = amax > a0 ? amax : a0;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                     }
                     uint32_t lo = p << 16, hi = p & 0xFFFF0000u;
                     if (!unit) {
-                        uint32_t qd = pack_bf16x2(dv(qt_u2f(lo)), dv(qt_u2f(hi)));
+                        uint32_t qd = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
                         lo = qd << 16;
                         hi = qd & 0xFFFF0000u;
                     }

@@ -121,6 +121,39 @@ def _dense_or_contiguous(t):
     return t.contiguous()
 
 
+def _rows_view(t):
+    """(view, transposed) when `t` is a non-contiguous bf16 device tensor whose rows are contiguous:
+    either its last dim has stride 1, or its last two dims are a transposed pair (K^T)."""
+    if t.is_contiguous() or t.dtype != torch.bfloat16 or t.dim() < 2 or t.dim() > 4 or t.numel() == 0:
+        return None
+    v, transposed = t, False
+    if v.stride(-1) != 1:
+        if v.stride(-2) != 1:
+            return None
+        v, transposed = v.transpose(-1, -2), True
+    if v.shape[-1] % 8 != 0 or any(st % 8 != 0 for st in v.stride()[:-1]) or v.data_ptr() % 16 != 0:
+        return None
+    return v, transposed
+
+
+def _forward_rows(input, rows, observe, qmap, amax_history, scale, quant_max, pow2, fmt):
+    v, transposed = rows
+    L = _native.lib()
+    st = _stream_ptr(v)
+    fmt = fmt if fmt is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
+    if observe:
+        _native.check(L.qt_scale_update(amax_history.data_ptr(), int(amax_history.shape[0]), int(scale.numel()),
+                                        scale.data_ptr(), float(quant_max), int(bool(pow2)), st), "qt_scale_update")
+    y = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    shp = [1] * (4 - v.dim()) + list(v.shape)
+    strd = [0] * (4 - v.dim()) + list(v.stride())
+    _native.check(L.qt_fake_quant_rows_bf16(v.data_ptr(), y.data_ptr(), shp[0], shp[1], shp[2], shp[3],
+                                            strd[0], strd[1], strd[2], ctypes.byref(fmt),
+                                            qmap.data_ptr() if qmap is not None else None, scale.data_ptr(),
+                                            amax_history.data_ptr() if observe else None, st), "qt_fake_quant_rows_bf16")
+    return y.transpose(-1, -2) if transposed else y
+
+
 def _channel_view(shape, ch_axis):
     ax = ch_axis + len(shape) if ch_axis < 0 else ch_axis
     outer = 1
@@ -229,9 +262,12 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
             return _forward_cpu(input, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis,
                                 per_row_fake_quant, force_scale_power_of_two)
 
-        # NB: a dense permuted layout could be processed in storage order without this copy, but the
-        # batched GEMMs that consume q / k^T / v run markedly slower on permuted strides (measured), so the
-        # canonical contiguous layout is produced here, as the reference's vmap does (decomposed.py:155).
+        # Permuted attention views (q / k^T / v): the pass itself writes the canonical contiguous layout
+        # (what the reference's vmap returns, decomposed.py:155) instead of a .contiguous() copy first.
+        rows = None if (per_row_fake_quant or emit_fp8 is not None) else _rows_view(input)
+        if rows is not None and quantize:
+            return _forward_rows(input, rows, observe, qmap, amax_history, scale, quant_max,
+                                 force_scale_power_of_two, qt_format)
         x = input.contiguous()
         if x.dtype not in (torch.bfloat16, torch.float32):
             return _forward_other_dtype(x, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis,
@@ -244,7 +280,7 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
                                             scale.data_ptr(), float(quant_max), int(bool(force_scale_power_of_two)),
                                             _stream_ptr(x)), "qt_scale_update")
         if (emit_fp8 is not None and quantize and not per_row_fake_quant and x.dtype == torch.bfloat16
-                and x.numel() % 8 == 0 and x.numel() > 0):
+                and x.numel() % 16 == 0 and x.numel() > 0):
             # one pass: bf16 fake-quantized tensor (unless emit_fp8 == "only") + the same values as FP8 bytes
             only = emit_fp8 == "only"
             y = None if only else torch.empty_like(x)

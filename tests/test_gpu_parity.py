@@ -530,3 +530,31 @@ def test_llama_attention_fused_vs_unfused(nv):
     assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max())
     names = [n for n, _ in model.named_modules() if n.endswith("av_matmul.activation_pre_process.0")]
     assert len(names) == 2
+
+
+@pytest.mark.parametrize("spec", ["e4m3", "posit8_1", "int8,qs=per_tensor_symmetric"])
+def test_permuted_views_through_module(nv, spec):
+    """Attention-style permuted views ([B,S,H,D] storage seen as [B,H,S,D], and its K^T transpose): the
+    module returns the same VALUES as on the contiguous copy, bit-exactly, observer state included."""
+    from dataclasses import asdict
+    import quantized_training as qt
+    torch.manual_seed(3)
+    base = (torch.randn(2, 48, 4, 64, device="cuda") * 2).bfloat16()        # [B, S, H, D]
+    q_view = base.transpose(1, 2)                                            # [B, H, S, D], rows contiguous
+    kt_view = q_view.transpose(2, 3)                                         # [B, H, D, S], transposed pair
+    for view in (q_view, kt_view, base[:, :, 1:3, :].transpose(1, 2)):
+        kw = asdict(qt.QuantizationSpec.from_str(spec))
+        m1 = qt.FusedAmaxObsFakeQuantize(**kw, device="cuda")
+        m2 = qt.FusedAmaxObsFakeQuantize(**kw, device="cuda")
+        for rep in range(2):
+            y1 = m1(view * (1 + rep))
+            y2 = m2((view * (1 + rep)).contiguous())
+            assert y1.shape == y2.shape
+            assert torch.equal(y1.contiguous().view(torch.int16), y2.view(torch.int16))
+            assert torch.equal(m1.scale, m2.scale) and torch.equal(m1.amax_history, m2.amax_history)
+        xb = host_u16((view * 2).contiguous().view(torch.int16))
+        st = o.FakeQuantState(kw["amax_history_len"], kw["quant_max"], observer=kw["qscheme"] is not None)
+        qmap = o.get_quantization_map(spec.split(",")[0])
+        o.fake_quant_forward(o.bf16_to_f32(host_u16(view.contiguous().view(torch.int16))).reshape(view.shape), True, qmap, st)
+        exp = o.f32_to_bf16(o.fake_quant_forward(o.bf16_to_f32(xb).reshape(view.shape), True, qmap, st))
+        assert np.array_equal(o.canon_nan16(host_u16(y1.contiguous().view(torch.int16))).reshape(-1), o.canon_nan16(exp).reshape(-1))
