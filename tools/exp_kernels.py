@@ -57,9 +57,11 @@ def time_gemm(M, N, K, wdtype, fused, iters=10):
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     wq = torch.empty_like(w)
     fmt = nv.format_for(wdtype)
-    lut = qt.get_quantization_map(wdtype, dev)
+    lut = qt.get_quantization_map(wdtype or 'e4m3', dev)
     qx = nv.QtOperandQ(); qx.fmt = nv.QtFormat(nv.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
     qw = nv.QtOperandQ(); qw.fmt = fmt; qw.lut_dev = lut.data_ptr()
+    sc = torch.tensor([0.02], device=dev)
+    if wdtype == 'int8': qw.scale_f32_dev = sc.data_ptr()
 
     def run_fused():
         nv.check(L.qt_linear_fq_bf16(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), M, N, K,
@@ -91,21 +93,21 @@ def main():
     out = {"elementwise": [], "gemm": []}
     shapes = [(1024, 4096), (4096, 4096), (4096, 11008), (32000, 4096), (1, 32, 1024, 1024), (1, 32, 1024, 128),
               (6144, 768), (6144, 3072), (16, 12, 384, 384)]
-    for shp in shapes:
+    for shp in []:
         for dt, sc, obs, lutf in [("e4m3", 1.0, False, False), ("e4m3", 1.0, False, True), ("posit8_1", 1.0, False, False),
                                   ("fp8_e4m3", 0.01, True, False), ("int8", 0.01, True, False), ("e4m3", 0.01, True, False)]:
             r = time_fq(shp, dt, "bf16", sc, obs, lutf)
             out["elementwise"].append(r)
             print(r, flush=True)
-    for shp in [(4096, 11008), (1024, 4096)]:
+    for shp in []:
         for dt, sc, obs in [("e4m3", 1.0, False), ("posit8_1", 1.0, False), ("int8", 0.01, True)]:
             r = time_fq(shp, dt, "f32", sc, obs)
             out["elementwise"].append(r)
             print(r, flush=True)
     for (M, N, K) in [(1024, 4096, 4096), (1024, 11008, 4096), (1024, 4096, 11008), (1024, 32000, 4096),
                       (6144, 768, 768), (6144, 3072, 768), (6144, 768, 3072)]:
-        for mode in ("fused", "unfused", "plain"):
-            r = time_gemm(M, N, K, "e4m3", mode)
+        for mode, wd in (("fused", "e4m3"), ("fused", "int8"), ("fused", None), ("unfused", "e4m3"), ("plain", "e4m3")):
+            r = time_gemm(M, N, K, wd, mode)
             out["gemm"].append(r)
             print(r, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
