@@ -108,7 +108,7 @@ def cpu_baseline_leg():
         c_oracle.fake_quant_bf16(x, qmap, one, out=y)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or reps >= 400:
+        if el > 12.0:
             break
     return {"value": reps * n / el, "unit": "elements/s", "cores": c_oracle.num_threads(), "kind": "port",
             "sample": f"{reps} x bf16[4096,11008] E4M3 fake-quant passes (scale 1), {el:.1f} s, OpenMP static"}

@@ -1,15 +1,13 @@
 #!/bin/bash
-# One GPU session: headline bench, kernel-trace profile of the same command, PMC traffic passes.
-set -x
+# One GPU session: headline bench, kernel-trace profile of the same command, PMC traffic passes for the
+# dominant elementwise kernel.  Outputs land in gpurun_out/ and are copied into profiles/ by hand.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
-tail -3 gpurun_out/bench_n1.err; cat gpurun_out/bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
-tail -2 gpurun_out/prof_bench.log
+cat gpurun_out/bench_n1.json
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_roofline -- python3 tools/roofline_only.py > gpurun_out/prof_roofline.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/roofline_only.py > gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/roofline_only.py > gpurun_out/pmc_write.log 2>&1
-find gpurun_out -name "*.csv" | head -30
-du -sh gpurun_out
+find gpurun_out -name "*stats.csv" -newer gpurun_out/bench_n1.json | head
