@@ -155,6 +155,20 @@ int qt_fake_quant_pc_f32(const float *x_dev, float *y_dev, size_t outer, size_t 
                          const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
                          uint32_t *amax_bits_dev, void *stream);
 
+/* ---- block-scaled formats: MXFakeQuantFunction.forward            fake_quantize.py:98-133
+ * (= calculate_mx_qparam + quantize + multiply, decomposed.py:365-448) for blocks of `block_size`
+ * consecutive elements of the last axis of a contiguous [rows, cols] tensor:
+ *   s = amax(block) / quant_max; s = scale_lut ? vmap(s, scale_lut) : s; s = s > 0 ? s : 1;
+ *   y = vmap(x / s, lut) * s          (all in the tensor's dtype)
+ * sf_dev receives the rows * cols / block_size block scales in the tensor's dtype.
+ * block_size: power of two, 8..512 (bf16) / 4..256 (fp32); cols % block_size == 0. */
+int qt_fake_quant_mx_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint16_t *sf_dev, size_t rows, size_t cols,
+                          int block_size, const qt_format *fmt, const uint16_t *lut_dev, float quant_max,
+                          const uint16_t *scale_lut_dev, void *stream);
+int qt_fake_quant_mx_f32(const float *x_dev, float *y_dev, float *sf_dev, size_t rows, size_t cols,
+                         int block_size, const qt_format *fmt, const uint16_t *lut_dev, float quant_max,
+                         const uint16_t *scale_lut_dev, void *stream);
+
 /* ---- A9/A10: fake-quant GEMMs (bf16 in, fp32 accumulate on MFMA, bf16 out) ---------------
  * qt_linear_fq_bf16 replaces  F.linear(fq_a(x), weight_fake_quant(W), b)
  *     modules/qat/linear.py:40-41 + the activation pre-hook quantize.py:128-140

@@ -387,3 +387,72 @@ def wikitext_windows(seq_len, max_length, stride):
         if end == seq_len:
             break
     return rows
+
+
+# --------------------------------------------------------------------------
+# Block-scaled formats (SURVEY 8(f) item 2): microscaling and group-wise affine fake-quant
+#   MXFakeQuantFunction            fake_quantize.py:98-133
+#   calculate_mx_qparam/quantize_mx decomposed.py:365-448,  _reshape_to_blocks mx_utils.py:58-118
+#   GroupWiseAffineFakeQuantFunction fake_quantize.py:136-194
+# Every torch op on a bf16 tensor rounds its result to bf16; `rd` applies that rounding.
+# --------------------------------------------------------------------------
+def _to_blocks(x, axis, bs):
+    """[..., n, ...] -> [..., nblk, bs, ...] zero-padded along `axis` (mx_utils.py:58-118)."""
+    ax = axis % x.ndim
+    n = x.shape[ax]
+    pad = (-n) % bs
+    if pad:
+        w = [(0, 0)] * x.ndim
+        w[ax] = (0, pad)
+        x = np.pad(x, w)
+    shp = list(x.shape)
+    shp[ax:ax + 1] = [x.shape[ax] // bs, bs]
+    return x.reshape(shp), ax
+
+
+def _expand_blocks(s, ax, bs, n):
+    return np.repeat(s, bs, axis=ax).take(np.arange(n), axis=ax)
+
+
+def mx_fake_quant(x, is_bf16, qmap, axis, block_size, quant_max, pow2=False, scale_qmap=None):
+    """Returns (y, scale) like MXFakeQuantFunction.forward + the `scale` buffer it fills."""
+    rd = rbf if is_bf16 else (lambda a: np.asarray(a, F32))
+    x = np.ascontiguousarray(x, dtype=F32)
+    blocks, ax = _to_blocks(x, axis, block_size)
+    with np.errstate(all="ignore"):
+        amax = np.max(np.abs(blocks), axis=ax + 1)
+        if not pow2:
+            scale = rd((amax / F32(quant_max)).astype(F32))                                # decomposed.py:414-415
+            if scale_qmap is not None:                                                     # :418-419
+                scale = bf16_to_f32(vmap_bf16(f32_to_bf16(scale), scale_qmap)) if is_bf16 else vmap_f32(scale, scale_qmap)
+        else:
+            t = rd(amax + F32(2.0 ** -126) * (amax == 0))                                  # mx_utils.py:43-47
+            e = np.floor(rd(np.log2(t).astype(F32)))
+            e = rd(e - F32(math.floor(math.log2(quant_max))))                              # decomposed.py:405
+            scale = rd(np.exp2(e.astype(np.float64)).astype(F32))                          # :411
+        scale = np.where(scale > 0.0, scale, F32(1.0)).astype(F32)                         # :421
+        se = _expand_blocks(scale, ax, block_size, x.shape[ax])
+        if is_bf16:
+            q = bf16_to_f32(vmap_bf16(f32_to_bf16((x / se).astype(F32)), qmap))            # quantize, decomposed.py:205-210
+        else:
+            q = vmap_f32((x / se).astype(F32), qmap)
+        y = rd((q * se).astype(F32))                                                       # fake_quantize.py:128
+    return y, scale
+
+
+def group_wise_affine_fake_quant(x, is_bf16, axis, block_size, quant_min, quant_max):
+    """Returns (y, scale, zero_point) like GroupWiseAffineFakeQuantFunction.forward (no scale_qmap)."""
+    rd = rbf if is_bf16 else (lambda a: np.asarray(a, F32))
+    x = np.ascontiguousarray(x, dtype=F32)
+    blocks, ax = _to_blocks(x, axis, block_size)
+    with np.errstate(all="ignore"):
+        mn = np.min(blocks, axis=ax + 1)                                                   # fake_quantize.py:166-167
+        mx = np.max(blocks, axis=ax + 1)
+        sf = rd(rd(mx - mn) / F32(quant_max - quant_min))                                  # :169
+        sf = np.where(sf > 0.0, sf, F32(1.0)).astype(F32)                                  # :170
+        zp = rd(rd(rd(-mn) / sf) + F32(quant_min))                                         # :171
+        se = _expand_blocks(sf, ax, block_size, x.shape[ax])
+        ze = _expand_blocks(zp, ax, block_size, x.shape[ax])
+        q = _clamp(np.rint(rd(rd(x / se) + ze)), F32(quant_min), F32(quant_max))           # :185
+        y = rd(rd(q - ze) * se)                                                            # :188
+    return y.astype(F32), sf, zp

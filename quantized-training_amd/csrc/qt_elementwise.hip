@@ -340,6 +340,63 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
 
+// ---- microscaling: one scale per block of `bs` consecutive elements of the last axis -----------------
+// MXFakeQuantFunction (fake_quantize.py:98-133) = calculate_mx_qparam + quantize + multiply
+// (decomposed.py:365-448): s = amax(block) / quant_max [-> scale table], s = (s > 0 ? s : 1),
+// y = map[x / s] * s, every op in the tensor's dtype.  A block is bs/8 (bf16) or bs/4 (fp32) adjacent
+// lanes of one wavefront, so the block amax is a sub-wave __shfl_xor reduction: one read, one write,
+// plus bs-times-smaller scale output.
+template <int IO, int KIND>
+__global__ __launch_bounds__(256) void fq_mx_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, void *__restrict__ sf_out,
+                                                    size_t nvec, int group, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                    float quant_max, const uint16_t *__restrict__ scale_lut) {
+    Rounder<KIND> rnd{fmt, lut};
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t iters = (nvec + stride - 1) / stride;
+    for (size_t it = 0; it < iters; ++it) {
+        const size_t v = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const bool live = v < nvec;
+        uint4 in = {0u, 0u, 0u, 0u};
+        if (live) in = x[v];
+        const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        uint32_t am = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (IO == kIoBf16) {
+                uint32_t a0 = (w[j] << 16) & 0x7FFFFFFFu, a1 = w[j] & 0x7FFF0000u;
+                am = am > a0 ? am : a0;
+                am = am > a1 ? am : a1;
+            } else {
+                uint32_t a0 = w[j] & 0x7FFFFFFFu;
+                am = am > a0 ? am : a0;
+            }
+        }
+        for (int off = 1; off < group; off <<= 1) {           // block amax over `group` adjacent lanes
+            uint32_t o = (uint32_t)__shfl_xor((int)am, off, 64);
+            am = am > o ? am : o;
+        }
+        // torch.amax propagates NaN: the integer max already does (NaN patterns are the largest)
+        float s = qt_u2f(am) / quant_max;                      // amax / quant_max   (decomposed.py:415)
+        if constexpr (IO == kIoBf16) s = qt_u2f(pack_bf16x2(s, 0.0f) << 16);
+        if (scale_lut) {                                       // :418-419
+            const uint32_t img = IO == kIoBf16 ? qt_f2u(s) : qt_fold_img(qt_f2u(s));
+            s = qt_bf2f(scale_lut[img >> 16]);
+        }
+        s = s > 0.0f ? s : 1.0f;                               // :421
+        if (live && (threadIdx.x & (group - 1)) == 0) {
+            const size_t blk = v / (size_t)group;
+            if constexpr (IO == kIoBf16) ((uint16_t *)sf_out)[blk] = (uint16_t)(qt_f2u(s) >> 16);
+            else ((float *)sf_out)[blk] = s;
+        }
+        const UniformDiv dv(s);                                // per-lane divisor; same fast/exact contract
+        uint32_t unused = 0;
+        uint4 r;
+        if (dv.safe) r = fq_vec<IO, KIND, kDivFast, false>(in, dv, rnd, unused);
+        else r = fq_vec<IO, KIND, kDivExact, false>(in, dv, rnd, unused);
+        if (live) y[v] = r;
+    }
+}
+
 // ---- per-channel: x viewed as [outer][C][inner], scale[c], amax[c] ---------------------------
 template <int IO, int KIND>
 __global__ __launch_bounds__(256) void fq_pc_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t outer,
@@ -662,6 +719,31 @@ int launch_qdq(const void *x, void *y, size_t n, const QdqArgs &a, const void *s
     return launch_status();
 }
 
+
+template <int IO>
+int launch_mx(const void *x, void *y, void *sf, size_t rows, size_t cols, int bs, const qt_format *fmt, const uint16_t *lut,
+              float quant_max, const uint16_t *scale_lut, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    if (!x || !y || !sf || !fmt || bs < kPer || (bs & (bs - 1)) || bs > 64 * kPer) return QT_ERR_BAD_ARG;
+    if (fmt->kind == QT_FMT_LUT && !lut) return QT_ERR_BAD_ARG;
+    if ((cols % (size_t)bs) || (((uintptr_t)x | (uintptr_t)y) & 15u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = rows * cols / kPer;
+    const int group = bs / kPer;
+    const unsigned grid = grid_for(nvec, 256, 32);
+    const uint4 *xv = (const uint4 *)x;
+    uint4 *yv = (uint4 *)y;
+    hipStream_t st = (hipStream_t)stream;
+    switch (fmt->kind) {
+        case QT_FMT_LUT: fq_mx_kernel<IO, QT_FMT_LUT><<<grid, 256, 0, st>>>(xv, yv, sf, nvec, group, *fmt, lut, quant_max, scale_lut); break;
+        case QT_FMT_FP_SAT: fq_mx_kernel<IO, QT_FMT_FP_SAT><<<grid, 256, 0, st>>>(xv, yv, sf, nvec, group, *fmt, lut, quant_max, scale_lut); break;
+        case QT_FMT_INT: fq_mx_kernel<IO, QT_FMT_INT><<<grid, 256, 0, st>>>(xv, yv, sf, nvec, group, *fmt, lut, quant_max, scale_lut); break;
+        case QT_FMT_IDENTITY: fq_mx_kernel<IO, QT_FMT_IDENTITY><<<grid, 256, 0, st>>>(xv, yv, sf, nvec, group, *fmt, lut, quant_max, scale_lut); break;
+        default: return QT_ERR_BAD_ARG;
+    }
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -746,6 +828,17 @@ int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, lo
     }
 #undef QT_ROWS
     return launch_status();
+}
+
+int qt_fake_quant_mx_bf16(const uint16_t *x, uint16_t *y, uint16_t *sf, size_t rows, size_t cols, int block_size,
+                          const qt_format *fmt, const uint16_t *lut, float quant_max, const uint16_t *scale_lut,
+                          void *stream) {
+    return launch_mx<kIoBf16>(x, y, sf, rows, cols, block_size, fmt, lut, quant_max, scale_lut, stream);
+}
+int qt_fake_quant_mx_f32(const float *x, float *y, float *sf, size_t rows, size_t cols, int block_size,
+                         const qt_format *fmt, const uint16_t *lut, float quant_max, const uint16_t *scale_lut,
+                         void *stream) {
+    return launch_mx<kIoF32>(x, y, sf, rows, cols, block_size, fmt, lut, quant_max, scale_lut, stream);
 }
 
 // vmap == fake-quant with scale 1 and no observer (x/1 and r*1 are exact)

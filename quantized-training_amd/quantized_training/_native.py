@@ -59,6 +59,8 @@ SIGNATURES = {
     "qt_fake_quant_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_bf16_fp8": (c_int, [_P, _P, _P, c_size_t, _FMT, _P, _P, _P]),
     "qt_fake_quant_rows_bf16": (c_int, [_P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _P, _P, _P, _P]),
+    "qt_fake_quant_mx_bf16": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, _P, _P]),
+    "qt_fake_quant_mx_f32": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, _P, _P]),
     "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),

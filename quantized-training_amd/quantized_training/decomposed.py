@@ -16,7 +16,7 @@ from torch.library import Library
 from . import _native
 from .fake_quantize import _cpu_vmap, _stream_ptr, hip_vmap
 
-__all__ = ["vmap", "quantize", "dequantize", "expand", "quantized_decomposed_lib"]
+__all__ = ["vmap", "quantize", "dequantize", "expand", "calculate_mx_qparam", "quantize_mx", "quantized_decomposed_lib"]
 
 quantized_decomposed_lib = Library("quantized_ops", "DEF")
 _lib = quantized_decomposed_lib
@@ -152,6 +152,64 @@ def quantize(input, scale, zero_point=None, axes=None, block_size=None, qmap=Non
 def dequantize(input, scale, zero_point=None, axes=None, block_size=None, input_qmap=None, output_qmap=None):
     """``(vmap?(input) [- zero_point]) * scale`` then optional output map (upstream decomposed.py:220-262)."""
     return torch.ops.quantized_ops.dequantize(input, scale, zero_point, axes, block_size, input_qmap, output_qmap)
+
+
+# ---- block-scaled (microscaling) parameters (upstream decomposed.py:365-448) ----------------------------
+_lib.define("calculate_mx_qparam(Tensor self, SymInt[] axes, int block_size, float quant_max, "
+            "bool force_scale_power_of_two=False, Tensor? scale_qmap=None) -> Tensor")
+_lib.define("quantize_mx(Tensor self, Tensor qmap, SymInt[] axes, int block_size, float quant_max, "
+            "bool force_scale_power_of_two=False, Tensor? scale_qmap=None, Tensor? output_code=None) -> (Tensor, Tensor)")
+
+
+def _const_like(value, ref):
+    # a 0-dim tensor on ref's device: `tensor / python_scalar` multiplies by a rounded reciprocal on the
+    # GPU, `tensor / tensor` is the IEEE division the reference's CPU path performs
+    return torch.tensor(value, dtype=ref.dtype, device=ref.device)
+
+
+def _calculate_mx_qparam_impl(input, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None):
+    from .mx_utils import _reshape_to_blocks, _shared_exponents
+    import math
+    assert block_size > 0
+    axes = [axes] if type(axes) == int else list(axes)
+    axes = [x + input.ndim if x < 0 else x for x in axes]
+    blocks, axes, _, _ = _reshape_to_blocks(input, axes, block_size)
+    block_axes = [x + 1 for x in axes]
+    if force_scale_power_of_two:
+        shared_exp = _shared_exponents(blocks, method="max", axes=block_axes, ebits=0)
+        shared_exp = shared_exp - math.floor(math.log2(quant_max))
+        for ax in reversed(axes):
+            shared_exp = torch.squeeze(shared_exp, dim=ax + 1)
+        scale = 2 ** shared_exp
+    else:
+        amax = torch.amax(torch.abs(blocks), dim=block_axes)
+        scale = amax / _const_like(quant_max, amax)
+        if scale_qmap is not None:
+            scale = torch.ops.quantized_ops.vmap(scale, scale_qmap)
+    return torch.where(scale > 0.0, scale, _const_like(1.0, scale))
+
+
+def _quantize_mx_impl(input, qmap, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None,
+                      output_code=None):
+    scale = torch.ops.quantized_ops.calculate_mx_qparam(input, axes, block_size, quant_max, force_scale_power_of_two,
+                                                        scale_qmap)
+    q = torch.ops.quantized_ops.quantize(input, scale, None, axes, block_size, qmap)
+    return scale, q
+
+
+_lib.impl("calculate_mx_qparam", _calculate_mx_qparam_impl, "CompositeExplicitAutograd")
+_lib.impl("quantize_mx", _quantize_mx_impl, "CompositeExplicitAutograd")
+
+
+def calculate_mx_qparam(input, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None):
+    axes = [axes] if isinstance(axes, int) else list(axes)
+    return torch.ops.quantized_ops.calculate_mx_qparam(input, axes, block_size, quant_max, force_scale_power_of_two, scale_qmap)
+
+
+def quantize_mx(input, qmap, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None, output_code=None):
+    axes = [axes] if isinstance(axes, int) else list(axes)
+    return torch.ops.quantized_ops.quantize_mx(input, qmap, axes, block_size, quant_max, force_scale_power_of_two,
+                                               scale_qmap, output_code)
 
 
 # ---- GEMM pass-throughs (operands arrive already fake-quantized; upstream decomposed.py:77-94) -----

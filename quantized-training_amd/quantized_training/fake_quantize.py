@@ -308,6 +308,93 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
         return (grad_output,) + (None,) * 12
 
 
+class MXFakeQuantFunction(torch.autograd.Function):
+    """Microscaling fake-quant: one scale per block of `block_size` elements along `axes`, from the block's
+    amax (or its shared exponent), then `qmap[x / s] * s` (upstream fake_quantize.py:98-133).  The fused HIP
+    pass (qt_fake_quant_mx_*) covers blocks along the last axis of a contiguous bf16 / fp32 device tensor;
+    other layouts use the same formulas as torch ops with the table lookup on the HIP vmap kernel."""
+
+    @staticmethod
+    def forward(ctx, input, fake_quant_enabled, scale, qmap, axes, block_size, quant_max,
+                force_scale_power_of_two=False, scale_qmap=None, qt_format=None):
+        if not _as_flag(fake_quant_enabled):
+            return input
+        from .decomposed import expand, quantize_mx
+        out = _hip_mx_or_none(input, scale, qmap, axes, block_size, quant_max, force_scale_power_of_two,
+                              scale_qmap, qt_format)
+        if out is not None:
+            return out
+        sf, q = quantize_mx(input, qmap, axes, block_size, quant_max, force_scale_power_of_two, scale_qmap=scale_qmap)
+        scale.resize_(sf.shape).copy_(sf)
+        return q * expand(sf, q.shape, block_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (grad_output,) + (None,) * 9
+
+
+def _hip_mx_or_none(input, scale, qmap, axes, block_size, quant_max, pow2, scale_qmap, fmt):
+    """Fused device pass for the common layout; None when it does not apply."""
+    if not _is_device(input) or input.dtype not in (torch.bfloat16, torch.float32) or input.dim() < 1:
+        return None
+    ax = axes if isinstance(axes, int) else (axes[0] if len(axes) == 1 else None)
+    if ax is None or (ax % input.dim()) != input.dim() - 1:
+        return None
+    if not isinstance(block_size, int) or block_size not in (8, 16, 32, 64, 128) or pow2:
+        return None
+    cols = input.shape[-1]
+    if cols % block_size != 0 or cols == 0 or input.numel() == 0:
+        return None
+    L = _native.lib()
+    x = input.contiguous()
+    y = torch.empty_like(x)
+    nblk = cols // block_size
+    sf = torch.empty(x.shape[:-1] + (nblk,), dtype=x.dtype, device=x.device)
+    fmt = fmt if fmt is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
+    fn = L.qt_fake_quant_mx_bf16 if x.dtype == torch.bfloat16 else L.qt_fake_quant_mx_f32
+    _native.check(fn(x.data_ptr(), y.data_ptr(), sf.data_ptr(), x.numel() // cols, cols, block_size,
+                     ctypes.byref(fmt), qmap.data_ptr() if qmap is not None else None, float(quant_max),
+                     scale_qmap.data_ptr() if scale_qmap is not None else None, _stream_ptr(x)), "qt_fake_quant_mx")
+    scale.resize_(sf.shape).copy_(sf)
+    return y
+
+
+class GroupWiseAffineFakeQuantFunction(torch.autograd.Function):
+    """Asymmetric block-wise integer fake-quant with per-block scale and zero point
+    (upstream fake_quantize.py:136-194); plain torch ops in the tensor's dtype."""
+
+    @staticmethod
+    def forward(ctx, input, fake_quant_enabled, scale, zero_point, axes, block_size, quant_min, quant_max,
+                scale_qmap=None):
+        if not _as_flag(fake_quant_enabled):
+            return input
+        from .decomposed import expand, _const_like
+        from .mx_utils import _reshape_to_blocks
+        assert block_size > 0
+        axes = [axes] if type(axes) == int else list(axes)
+        axes = [x + input.ndim if x < 0 else x for x in axes]
+        blocks, baxes, _, _ = _reshape_to_blocks(input, axes, block_size)
+        block_axes = [x + 1 for x in baxes]
+        lo = torch.amin(blocks, dim=block_axes)
+        hi = torch.amax(blocks, dim=block_axes)
+        sf = (hi - lo) / _const_like(quant_max - quant_min, hi)
+        sf = torch.where(sf > 0.0, sf, _const_like(1.0, sf))
+        zp = -lo / sf + quant_min
+        if scale_qmap is not None:
+            sf = torch.ops.quantized_ops.vmap(sf, scale_qmap)
+            zp = torch.ops.quantized_ops.vmap(zp, scale_qmap)
+        scale.resize_(sf.shape).copy_(sf)
+        zero_point.resize_(zp.shape).copy_(zp)
+        sfe = expand(sf, input.shape, block_size)
+        zpe = expand(zp, input.shape, block_size)
+        q = torch.clamp(torch.round(input / sfe + zpe), quant_min, quant_max)
+        return (q - zpe) * sfe
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (grad_output,) + (None,) * 8
+
+
 def _forward_cpu(input, observe, quantize, qmap, amax_history, scale, quant_max, ch_axis, per_channel, pow2):
     if observe:
         if per_channel:
@@ -460,9 +547,19 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             outlier_pct = mask.bitwise_not().sum().item() / X.numel()
             self.max_outlier_pct = max(outlier_pct, getattr(self, "max_outlier_pct", 0.0))
 
+        if self.qscheme == QScheme.MICROSCALING:
+            X = MXFakeQuantFunction.apply(X, self._quantize, self.scale, self.qmap, self.ch_axis, self.block_size,
+                                          self.quant_max, self.force_scale_power_of_two, self.scale_qmap,
+                                          self._qt_format)
+            if self._quantize:
+                _Stats.add(X.numel())
+        elif self.qscheme == QScheme.GROUP_WISE_AFFINE:
+            X = GroupWiseAffineFakeQuantFunction.apply(X, self._quantize, self.scale, self.zero_point, self.ch_axis,
+                                                       self.block_size, self.quant_min, self.quant_max, self.scale_qmap)
         if self.qscheme in (QScheme.MICROSCALING, QScheme.GROUP_WISE_AFFINE):
-            raise NotImplementedError(
-                f"qscheme {self.qscheme.value} (block-scaled formats) is not part of this engine yet")
+            if self.outlier_threshold is not None:
+                X = torch.where(mask, X, orig_X)
+            return X
 
         if not self._observe and not self._quantize:
             return X

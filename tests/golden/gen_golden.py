@@ -250,6 +250,52 @@ def gen_fake_quant(ref, out):
         json.dump(meta, f, indent=1)
 
 
+MX_CASES = [
+    # name, spec, input dtype, shape, force_pow2
+    ("mx_int8_bs32_bf16", "int8,qs=microscaling,bs=32,ax=-1", "bf16", (6, 128), False),
+    ("mx_int8_bs32_f32", "int8,qs=microscaling,bs=32,ax=-1", "f32", (6, 128), False),
+    ("mx_fp4_bs16_bf16", "fp4_e2m1,qs=microscaling,bs=16,ax=-1", "bf16", (4, 5, 64), False),
+    ("mx_fp8_pow2_bf16", "fp8_e4m3,qs=microscaling,bs=32,ax=-1", "bf16", (8, 96), True),
+    ("mx_int6_pow2_f32", "int6,qs=microscaling,bs=64,ax=-1", "f32", (3, 192), True),
+    ("mx_int6_ax_m2_bf16", "int6,qs=microscaling,bs=64,ax=-2", "bf16", (2, 128, 24), False),
+    ("mx_int4_ragged_f32", "int4,qs=microscaling,bs=32,ax=-1", "f32", (5, 80), False),
+    ("mx_int8_scaleq_bf16", "int8,qs=microscaling,bs=32,ax=-1,scale=fp8_e5m3", "bf16", (6, 128), False),
+    ("gwa_uint4_bs32_f32", "uint4,qs=group_wise_affine,bs=32,ax=-1", "f32", (6, 128), False),
+    ("gwa_uint8_bs64_bf16", "uint8,qs=group_wise_affine,bs=64,ax=-1", "bf16", (4, 128), False),
+]
+
+
+def gen_mx(ref, out):
+    """Block-scaled fake-quant traces: MXFakeQuantFunction / GroupWiseAffineFakeQuantFunction through the
+    module (fake_quantize.py:98-194, decomposed.py:365-448)."""
+    from dataclasses import asdict
+    rng = np.random.default_rng(31)
+    meta, arrays = [], {}
+    for name, spec, indt, shape, pow2 in MX_CASES:
+        kw = asdict(ref.quantizer.QuantizationSpec.from_str(spec))
+        m = ref.fake_quantize.FusedAmaxObsFakeQuantize(**kw, force_scale_power_of_two=pow2)
+        td = torch.bfloat16 if indt == "bf16" else torch.float32
+        x = (rng.standard_normal(shape) * 10.0 ** rng.uniform(-2, 1, shape[:-1] + (1,))).astype(np.float32)
+        x.flat[:4] = [0.0, -0.0, 1.0, -3.5]
+        x[..., -1, :] = 0.0 if len(shape) > 1 else x[..., -1, :]           # an all-zero row -> scale 1
+        xt = torch.from_numpy(x).to(td)
+        with torch.no_grad():
+            y = m(xt)
+        arrays[name + "/x"] = tensor_bits(xt) if td == torch.bfloat16 else f32_bits(xt)
+        arrays[name + "/y"] = tensor_bits(y)
+        arrays[name + "/scale"] = canon_nan32(f32_bits(m.scale.detach().float().reshape(-1)))
+        e = {"name": name, "spec": spec, "in": indt, "shape": list(shape), "pow2": pow2,
+             "scale_shape": list(m.scale.shape), "quant_max": kw["quant_max"], "quant_min": kw["quant_min"],
+             "block_size": kw["block_size"], "ch_axis": kw["ch_axis"], "scale_dtype": kw["scale_dtype"]}
+        if "group_wise" in spec:
+            arrays[name + "/zp"] = canon_nan32(f32_bits(m.zero_point.detach().float().reshape(-1)))
+            e["zp_shape"] = list(m.zero_point.shape)
+        meta.append(e)
+    np.savez_compressed(os.path.join(out, "mx.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "mx.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def _toy(ref):
     import torch.nn as nn
     fm = ref.functional_modules
@@ -449,6 +495,7 @@ def main():
         "vmap": lambda: gen_vmap(ref, a.out),
         "qdq": lambda: gen_quant_dequant(ref, a.out),
         "fq": lambda: gen_fake_quant(ref, a.out),
+        "mx": lambda: gen_mx(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),
         "windows": lambda: gen_windows(a.out),

@@ -558,3 +558,62 @@ def test_permuted_views_through_module(nv, spec):
         o.fake_quant_forward(o.bf16_to_f32(host_u16(view.contiguous().view(torch.int16))).reshape(view.shape), True, qmap, st)
         exp = o.f32_to_bf16(o.fake_quant_forward(o.bf16_to_f32(xb).reshape(view.shape), True, qmap, st))
         assert np.array_equal(o.canon_nan16(host_u16(y1.contiguous().view(torch.int16))).reshape(-1), o.canon_nan16(exp).reshape(-1))
+
+
+MX_META = json.load(open(os.path.join(G, "mx.json")))
+
+
+@pytest.mark.parametrize("case", MX_META, ids=[c["name"] for c in MX_META])
+def test_block_scaled_module_golden(nv, case):
+    """Microscaling (fused HIP pass for last-axis blocks, composite otherwise) and group-wise affine on device
+    tensors reproduce the reference's outputs and block scales bit-exactly."""
+    from dataclasses import asdict
+    import quantized_training as qt
+    d = np.load(os.path.join(G, "mx.npz"))
+    n = case["name"]
+    kw = asdict(qt.QuantizationSpec.from_str(case["spec"]))
+    m = qt.FusedAmaxObsFakeQuantize(**kw, force_scale_power_of_two=case["pow2"], device="cuda")
+    bf16 = case["in"] == "bf16"
+    if bf16:
+        x = dev_u16(d[n + "__x"]).view(torch.bfloat16).reshape(case["shape"])
+    else:
+        x = torch.from_numpy(d[n + "__x"].view(np.float32)).cuda().reshape(case["shape"])
+    y = m(x).contiguous()
+    got = o.canon_nan16(host_u16(y.view(torch.int16))) if bf16 else o.canon_nan32(host_u32(y))
+    assert np.array_equal(got.reshape(-1), d[n + "__y"].reshape(-1))
+    assert list(m.scale.shape) == case["scale_shape"]
+    assert np.array_equal(o.canon_nan32(host_u32(m.scale.float().reshape(-1))), d[n + "__scale"])
+
+
+@pytest.mark.parametrize("dtype,bs,io", [("int8", 32, "bf16"), ("int6", 64, "bf16"), ("fp4_e2m1", 16, "bf16"),
+                                          ("int8", 32, "f32"), ("fp8_e4m3", 128, "bf16"), ("int4", 8, "f32")])
+def test_mx_fused_kernel_vs_oracle(nv, dtype, bs, io):
+    """qt_fake_quant_mx_* on a 1 M-element tensor with per-row magnitudes spanning 1e-3..1e2, zero blocks and
+    an Inf: outputs and block scales equal the oracle's."""
+    L = nv.lib()
+    rng = np.random.default_rng(bs)
+    rows, cols = 2048, 512
+    x = (rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-3, 2, (rows, 1))).astype(np.float32)
+    x[5, :bs] = 0.0
+    x[7, 3] = np.inf
+    qmax = {"int8": 127.0, "int6": 31.0, "int4": 7.0, "fp4_e2m1": 6.0, "fp8_e4m3": 448.0}[dtype]
+    qmap = o.get_quantization_map(dtype)
+    fmt = nv.format_for(dtype)
+    lut = dev_u16(nv.build_map_u16(dtype))
+    if io == "bf16":
+        xb = o.f32_to_bf16(x)
+        xd = dev_u16(xb.reshape(-1)); yd = torch.empty_like(xd)
+        sf = torch.empty(rows * cols // bs, dtype=torch.int16, device="cuda")
+        nv.check(L.qt_fake_quant_mx_bf16(xd.data_ptr(), yd.data_ptr(), sf.data_ptr(), rows, cols, bs, ctypes.byref(fmt),
+                                         lut.data_ptr(), qmax, None, stream()), "mx")
+        ey, es = o.mx_fake_quant(o.bf16_to_f32(xb), True, qmap, -1, bs, qmax)
+        assert np.array_equal(o.canon_nan16(host_u16(yd)), o.canon_nan16(o.f32_to_bf16(ey)).reshape(-1))
+        assert np.array_equal(o.canon_nan16(host_u16(sf)), o.canon_nan16(o.f32_to_bf16(es)).reshape(-1))
+    else:
+        xd = dev_f32(x.reshape(-1)); yd = torch.empty_like(xd)
+        sf = torch.empty(rows * cols // bs, dtype=torch.float32, device="cuda")
+        nv.check(L.qt_fake_quant_mx_f32(xd.data_ptr(), yd.data_ptr(), sf.data_ptr(), rows, cols, bs, ctypes.byref(fmt),
+                                        lut.data_ptr(), qmax, None, stream()), "mx")
+        ey, es = o.mx_fake_quant(x, False, qmap, -1, bs, qmax)
+        assert np.array_equal(o.canon_nan32(host_u32(yd)), o.canon_nan32(ey.astype(np.float32).view(np.uint32)).reshape(-1))
+        assert np.array_equal(o.canon_nan32(host_u32(sf)), o.canon_nan32(es.astype(np.float32).view(np.uint32)).reshape(-1))

@@ -281,3 +281,25 @@ def test_convert_shares_parameters_and_prepare_is_idempotent_on_names():
     assert isinstance(f, nn.Linear) and torch.equal(f.weight, w)
     with pytest.raises(AssertionError):
         qt.prepare(Toy(), True, "bogus_op", None)
+
+
+MX_META = json.load(open(os.path.join(G, "mx.json")))
+
+
+@pytest.mark.parametrize("case", MX_META, ids=[c["name"] for c in MX_META])
+def test_block_scaled_module_cpu(case):
+    """qs=microscaling / qs=group_wise_affine through the module on CPU tensors vs the reference's outputs."""
+    d = np.load(os.path.join(G, "mx.npz"))
+    n = case["name"]
+    kw = asdict(qt.QuantizationSpec.from_str(case["spec"]))
+    m = qt.FusedAmaxObsFakeQuantize(**kw, force_scale_power_of_two=case["pow2"])
+    if case["in"] == "bf16":
+        x = torch.from_numpy(d[n + "__x"].view(np.int16)).view(torch.bfloat16).reshape(case["shape"])
+    else:
+        x = torch.from_numpy(d[n + "__x"].view(np.float32)).reshape(case["shape"])
+    y = m(x)
+    assert np.array_equal(_bits(y).reshape(-1), d[n + "__y"].reshape(-1))
+    assert list(m.scale.shape) == case["scale_shape"]
+    assert np.array_equal(_canon32(m.scale.float().reshape(-1).view(torch.int32).numpy().view(np.uint32)), d[n + "__scale"])
+    if "group_wise" in case["spec"]:
+        assert np.array_equal(_canon32(m.zero_point.float().reshape(-1).view(torch.int32).numpy().view(np.uint32)), d[n + "__zp"])
