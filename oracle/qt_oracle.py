@@ -234,7 +234,47 @@ def get_quantization_map(dtype):
     m = re.fullmatch(r"posit(\d+)_(\d+)", dtype)                   # :84-86
     if m:
         return canon_nan16(f32_to_bf16(quantize_to_posit(vals, int(m.group(1)), int(m.group(2)))))
+    m = re.fullmatch(r"nf(\d+)(?:_(\d+))?", dtype)                # :90-93 (flattened: values[indices])
+    if m:
+        return canon_nan16(nf_value_map(int(m.group(1)), int(m.group(2)) if m.group(2) else None))
     raise ValueError(f"Unsupported dtype: {dtype}")                # :95
+
+
+# --------------------------------------------------------------------------
+# NormalFloat code books (normal_float.py:4-62): 2^k levels at evenly spaced N(0,1) quantiles
+# --------------------------------------------------------------------------
+def nf_levels(k=4, int_bits=None, offset=0.9677083):
+    from scipy.stats import norm
+    half = 2 ** (k - 1)
+
+    def lin(steps):          # torch.linspace(offset, 0.5, steps) in float32 (two-sided evaluation)
+        step = (F32(0.5) - F32(offset)) / F32(steps - 1)
+        i = np.arange(steps, dtype=F32)
+        return np.where(np.arange(steps) < steps // 2, F32(offset) + step * i,
+                        F32(0.5) - step * (F32(steps - 1) - i)).astype(F32)
+
+    v = np.concatenate([norm.ppf(lin(half + 1)[:-1]), [0.0], -norm.ppf(lin(half)[:-1])]).astype(F32)   # :13-16
+    v = np.sort(v)
+    v = (v / v.max()).astype(F32)                                                                        # :26-27
+    if int_bits is not None:
+        v = np.rint(v * F32(2 ** (int_bits - 1) - 1)).astype(F32)                                        # :52-54
+    return v
+
+
+def nf_value_map(k=4, int_bits=None):
+    """bf16 bits of values[argmin |values - clamp(x)|] for every bf16 pattern (normal_float.py:56-60)."""
+    levels = rbf(nf_levels(k, int_bits))                                                                 # values.to(bf16)
+    x = bf16_to_f32(all_bf16_patterns())
+    with np.errstate(invalid="ignore"):
+        xc = _clamp(x, levels.min(), levels.max())
+        dist = np.abs(rbf(levels[None, :] - xc[:, None]))                                                # bf16 subtraction
+        dist = np.where(np.isnan(dist), F32(np.inf), dist)
+        nanrow = np.isnan(xc)
+        idx = np.argmin(dist, axis=1)
+    out = f32_to_bf16(levels[idx])
+    # torch.argmin on an all-NaN row returns the first NaN position (index 0)
+    out[nanrow] = f32_to_bf16(levels[:1])[0]
+    return out
 
 
 # --------------------------------------------------------------------------

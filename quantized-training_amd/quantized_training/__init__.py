@@ -18,6 +18,7 @@ from .fake_quantize import (  # noqa: F401
 from .decomposed import vmap, quantize as quantize_op, dequantize, expand  # noqa: F401
 from .fp8 import quantize_to_fp8_e4m3, quantize_to_fp8_e5m2  # noqa: F401
 from .posit import quantize_to_posit  # noqa: F401
+from .normal_float import quantize_to_nf, create_normal_map  # noqa: F401
 from .qconfig import QConfig, get_qconfig  # noqa: F401
 from .quantize import (  # noqa: F401
     convert, get_quantized_model, prepare, propagate_config, quantize, replace_softmax, swap_module,
@@ -29,7 +30,7 @@ from . import modules  # noqa: F401
 __all__ = [
     "FusedAmaxObsFakeQuantize", "QConfig", "QuantizationSpec", "add_qspec_args", "convert",
     "get_qconfig", "get_quantized_model", "prepare", "propagate_config", "quantize",
-    "quantize_to_fp8_e4m3", "quantize_to_fp8_e5m2", "quantize_to_posit", "replace_softmax",
+    "quantize_to_fp8_e4m3", "quantize_to_fp8_e5m2", "quantize_to_posit", "quantize_to_nf", "replace_softmax",
     "setup_logging", "get_quantization_map", "vmap", "dequantize",
 ]
 

@@ -53,6 +53,10 @@ class _Stats:
 
 STATS = _Stats
 
+import re as _re
+
+_RE_NF = _re.compile(r"nf(\d+)(?:_(\d+))?")
+
 _MAP_CACHE = {}      # (dtype, device) -> bf16 tensor [65536]
 _FORMAT_CACHE = {}   # dtype -> _native.QtFormat
 
@@ -60,9 +64,26 @@ _FORMAT_CACHE = {}   # dtype -> _native.QtFormat
 def _format_for(dtype):
     f = _FORMAT_CACHE.get(dtype)
     if f is None:
-        f = _native.format_for(dtype)
+        if isinstance(dtype, str) and _RE_NF.fullmatch(dtype):
+            f = _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)       # code-book dtype: table only
+        else:
+            f = _native.format_for(dtype)
         _FORMAT_CACHE[dtype] = f
     return f
+
+
+def _table_for(dtype, device):
+    """The [65536] bf16 value map as one tensor (NormalFloat's (indices, values) pair is flattened)."""
+    m = get_quantization_map(dtype, device)
+    if isinstance(m, tuple):
+        key = (dtype, "flat", torch.device(device) if device is not None else torch.device("cpu"))
+        flat = _MAP_CACHE.get(key)
+        if flat is None:
+            idx, vals = m
+            flat = vals[idx].contiguous()
+            _MAP_CACHE[key] = flat
+        return flat
+    return m
 
 
 def get_quantization_map(dtype, device=None):
@@ -71,9 +92,18 @@ def get_quantization_map(dtype, device=None):
     ``table[bits(v)]`` is the nearest representable value of ``dtype`` to the bf16 value ``v``.
     Raises ``ValueError`` for an unknown dtype.  The returned tensor is shared: do not modify it.
     """
-    if isinstance(dtype, str) and dtype.lower().startswith("nf"):
-        raise ValueError(f"Unsupported dtype: {dtype} (NormalFloat code books are not part of this engine yet)")
     dev = torch.device(device) if device is not None else torch.device("cpu")
+    nf = _RE_NF.fullmatch(dtype) if isinstance(dtype, str) else None
+    if nf:      # NormalFloat: (indices, values), as upstream returns for this family (fake_quantize.py:90-93)
+        key = (dtype, dev)
+        hit = _MAP_CACHE.get(key)
+        if hit is None:
+            from .normal_float import quantize_to_nf
+            patterns = torch.arange(2 ** 16, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+            idx, vals = quantize_to_nf(patterns, int(nf.group(1)), int_bits=int(nf.group(2)) if nf.group(2) else None)
+            hit = (idx.to(dev), vals.to(dev))
+            _MAP_CACHE[key] = hit
+        return hit
     key = (dtype, dev)
     hit = _MAP_CACHE.get(key)
     if hit is None:
@@ -464,8 +494,8 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         if device is None and isinstance(kwargs.get("factory_kwargs"), dict):
             device = kwargs["factory_kwargs"].get("device", None)
         self._qt_format = _format_for(dtype)                                  # raises ValueError on a bad dtype
-        self.register_buffer("qmap", get_quantization_map(dtype, device), persistent=False)
-        scale_map = get_quantization_map(scale_dtype, device) if scale_dtype is not None else None
+        self.register_buffer("qmap", _table_for(dtype, device), persistent=False)
+        scale_map = _table_for(scale_dtype, device) if scale_dtype is not None else None
         self.register_buffer("scale_qmap", scale_map, persistent=False)
         fk = {"device": device, "dtype": torch.float}
         self.register_buffer("amax_history", torch.tensor([], **fk))
@@ -529,9 +559,9 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         if self.scale.device != device or self.amax_history.device != device:
             self.to(device)
         if self.qmap.device != device:
-            self.qmap = get_quantization_map(self.dtype, device)
+            self.qmap = _table_for(self.dtype, device)
             if self.scale_qmap is not None:
-                self.scale_qmap = get_quantization_map(self.scale_dtype, device)
+                self.scale_qmap = _table_for(self.scale_dtype, device)
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
         self._move_to(X.device)

@@ -106,6 +106,12 @@ def gen_maps(ref, out):
         key = "none" if dt is None else dt
         maps[key] = bits
         shas[key] = hashlib.sha256(bits.astype("<u2").tobytes()).hexdigest()
+    for dt in ["nf4", "nf4_6", "nf3", "nf2_4"]:
+        idx, vals = ref.fake_quantize.get_quantization_map(dt)
+        maps[dt] = canon_nan16(bf16_bits(vals[idx]))
+        maps[dt + "__values"] = canon_nan16(bf16_bits(vals))
+        maps[dt + "__indices"] = idx.numpy().astype(np.uint16)
+        shas[dt] = hashlib.sha256(maps[dt].astype("<u2").tobytes()).hexdigest()
     np.savez_compressed(os.path.join(out, "maps.npz"), **maps)
     with open(os.path.join(out, "maps_sha256.json"), "w") as f:
         json.dump(shas, f, indent=1, sort_keys=True)
@@ -262,6 +268,9 @@ MX_CASES = [
     ("mx_int8_scaleq_bf16", "int8,qs=microscaling,bs=32,ax=-1,scale=fp8_e5m3", "bf16", (6, 128), False),
     ("gwa_uint4_bs32_f32", "uint4,qs=group_wise_affine,bs=32,ax=-1", "f32", (6, 128), False),
     ("gwa_uint8_bs64_bf16", "uint8,qs=group_wise_affine,bs=64,ax=-1", "bf16", (4, 128), False),
+    ("mx_nf4_bs64_bf16", "nf4,qs=microscaling,bs=64,ax=-1", "bf16", (6, 128), False),
+    ("mx_nf4_6_scaleq_bf16", "nf4_6,qs=microscaling,bs=64,ax=-1,scale=fp8_e5m3", "bf16", (6, 128), False),
+    ("mx_nf4_ax_m2_f32", "nf4,qs=microscaling,bs=64,ax=-2", "f32", (2, 128, 16), False),
 ]
 
 

@@ -30,7 +30,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.qt_status_string(0) == b"ok"
 
 
-@pytest.mark.parametrize("key", sorted(MAPS.files))
+_C_KEYS = sorted(k for k in MAPS.files if "__" not in k and not k.startswith("nf"))
+
+
+@pytest.mark.parametrize("key", _C_KEYS)
 def test_build_map_bit_exact(key):
     m = _native.build_map_u16(None if key == "none" else key)
     assert np.array_equal(m, MAPS[key])
@@ -38,7 +41,7 @@ def test_build_map_bit_exact(key):
     assert hashlib.sha256(m.astype("<u2").tobytes()).hexdigest() == sha
 
 
-@pytest.mark.parametrize("key", sorted(MAPS.files))
+@pytest.mark.parametrize("key", _C_KEYS)
 def test_closed_form_descriptor_equals_table(key):
     """Every closed-form descriptor the kernels may use instead of the table reproduces the table on
     all 65 536 inputs."""

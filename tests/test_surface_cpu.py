@@ -303,3 +303,16 @@ def test_block_scaled_module_cpu(case):
     assert np.array_equal(_canon32(m.scale.float().reshape(-1).view(torch.int32).numpy().view(np.uint32)), d[n + "__scale"])
     if "group_wise" in case["spec"]:
         assert np.array_equal(_canon32(m.zero_point.float().reshape(-1).view(torch.int32).numpy().view(np.uint32)), d[n + "__zp"])
+
+
+@pytest.mark.parametrize("dt", ["nf4", "nf4_6", "nf3", "nf2_4"])
+def test_normal_float_maps(dt):
+    """NormalFloat code books: (indices, values) like the reference, flattened table equal to its values[indices]."""
+    g = np.load(os.path.join(G, "maps.npz"))
+    idx, vals = qt.get_quantization_map(dt)
+    assert np.array_equal(_canon16(vals[idx].view(torch.int16).numpy().view(np.uint16)), g[dt])
+    assert np.array_equal(idx.numpy().astype(np.uint16), g[dt + "__indices"])
+    m = qt.FusedAmaxObsFakeQuantize(dt)
+    assert np.array_equal(_canon16(m.qmap.view(torch.int16).numpy().view(np.uint16)), g[dt])
+    i2, v2 = qt.quantize_to_nf(torch.tensor([0.3, -2.0, 0.0], dtype=torch.bfloat16), 4)
+    assert v2.numel() == 16 and float(v2[i2[1]]) == -1.0 and float(v2[i2[2]]) == 0.0
