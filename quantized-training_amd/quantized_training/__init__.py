@@ -23,6 +23,10 @@ from .qconfig import QConfig, get_qconfig  # noqa: F401
 from .quantize import (  # noqa: F401
     convert, get_quantized_model, prepare, propagate_config, quantize, replace_softmax, swap_module,
 )
+from .quantize_pt2e import (  # noqa: F401
+    convert_pt2e, derive_bias_qparams_fn, export_model, get_default_quantizer, prepare_pt2e,
+)
+from .quantizer import XNNPACKQuantizer, QuantizationConfig, get_node_name_to_scope  # noqa: F401
 from .training_args import add_qspec_args  # noqa: F401
 from .utils import setup_logging  # noqa: F401
 from . import modules  # noqa: F401
@@ -32,6 +36,8 @@ __all__ = [
     "get_qconfig", "get_quantized_model", "prepare", "propagate_config", "quantize",
     "quantize_to_fp8_e4m3", "quantize_to_fp8_e5m2", "quantize_to_posit", "quantize_to_nf", "replace_softmax",
     "setup_logging", "get_quantization_map", "vmap", "dequantize",
+    "get_default_quantizer", "prepare_pt2e", "convert_pt2e", "export_model", "derive_bias_qparams_fn",
+    "get_node_name_to_scope",
 ]
 
 

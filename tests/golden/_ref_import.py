@@ -90,6 +90,12 @@ def load_reference(with_quantize=False):
         }
         sys.modules["quantized_training.quantization_mappings"] = qm
         ns.quantize = importlib.import_module("quantized_training.quantize")
+        try:      # PT2E: the accelerator package must be imported first (circular import otherwise)
+            importlib.import_module("quantized_training.codegen")
+            ns.quantize_pt2e = importlib.import_module("quantized_training.quantize_pt2e")
+        except Exception as e:  # noqa: BLE001
+            ns.quantize_pt2e = None
+            ns.pt2e_error = e
         ns.functional_modules = fm
         ns.nnqat = nnqat
     return ns

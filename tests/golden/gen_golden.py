@@ -433,6 +433,76 @@ def gen_eager(ref, out):
         json.dump(meta, f, indent=1)
 
 
+def _graph_rows(gm):
+    def nm(a):
+        if isinstance(a, torch.fx.Node):
+            return a.name
+        if isinstance(a, (list, tuple)):
+            return [nm(x) for x in a]
+        return a if isinstance(a, (int, float, str, bool, type(None))) else str(a)
+    return [[n.op, n.name, str(n.target), nm(list(n.args))] for n in gm.graph.nodes]
+
+
+def gen_pt2e(ref, out):
+    """PT2E flow on a toy model: prepared graph (inserted fake-quant modules), calibrated outputs and
+    scales, converted graph and outputs (quantize_pt2e.py:155-273, 323-446, 975-1002)."""
+    import torch.nn as nn
+    qp = ref.quantize_pt2e
+    assert qp is not None, getattr(ref, "pt2e_error", None)
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(16, 32)
+            self.fc2 = nn.Linear(32, 16)
+            self.ln = nn.LayerNorm(16)
+
+        def forward(self, x):
+            h = torch.relu(self.fc1(x))
+            y = self.fc2(h)
+            y = y + x
+            a = torch.matmul(y, y.transpose(-1, -2))
+            return self.ln(torch.matmul(torch.softmax(a, -1), y))
+
+    rng = np.random.default_rng(17)
+    arrays, meta = {}, {}
+    xs = [(rng.standard_normal((4, 8, 16)) * (i + 1)).astype(np.float32) for i in range(4)]
+    for i, x in enumerate(xs):
+        arrays[f"x{i}"] = f32_bits(torch.from_numpy(x))
+    runs = [("int8", dict(input_activation="int8,qs=per_tensor_symmetric", weight="int8,qs=per_tensor_symmetric", bias="int24"), None),
+            ("fp8", dict(input_activation="fp8_e4m3,qs=per_tensor_symmetric", weight="fp8_e4m3,qs=per_tensor_symmetric", bias="float32"), "bfloat16"),
+            ("e4m3_noqs", dict(input_activation="e4m3", weight="e4m3"), None)]
+    for name, kw, out_dtype in runs:
+        m = Toy().eval()
+        r = np.random.default_rng(3)
+        with torch.no_grad():
+            for n, p in sorted(m.named_parameters()):
+                p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+        if name == "int8":
+            for n, p in m.named_parameters():
+                arrays["param/" + n] = f32_bits(p.detach())
+        q = qp.get_default_quantizer(**kw)
+        gm = qp.prepare_pt2e(m, q, (torch.from_numpy(xs[0]),))
+        info = {"kw": kw, "output_dtype": out_dtype, "prepared_graph": _graph_rows(gm),
+                "fq_modules": [n for n, mod in gm.named_modules() if isinstance(mod, torch.ao.quantization.FakeQuantizeBase)]}
+        with torch.no_grad():
+            for i in range(3):
+                gm(torch.from_numpy(xs[i]))
+            y1 = gm(torch.from_numpy(xs[3]))
+        arrays[f"{name}/y_prepared"] = tensor_bits(y1)
+        info["scales"] = {k: [float(t) for t in v.reshape(-1)] for k, v in gm.state_dict().items() if k.endswith(".scale")}
+        gc = qp.convert_pt2e(gm, out_dtype) if out_dtype else qp.convert_pt2e(gm)
+        info["converted_graph"] = _graph_rows(gc)
+        with torch.no_grad():
+            y2 = gc(torch.from_numpy(xs[3]))
+        arrays[f"{name}/y_converted"] = tensor_bits(y2)
+        info["converted_buffers"] = {k: [float(t) for t in v.reshape(-1)][:4] for k, v in gc.named_buffers() if "scale" in k}
+        meta[name] = info
+    np.savez_compressed(os.path.join(out, "pt2e.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "pt2e.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_spec(ref, out):
     """QuantizationSpec.from_str / get_quant_min_max / add_qspec_args defaults."""
     from dataclasses import asdict
@@ -505,6 +575,7 @@ def main():
         "qdq": lambda: gen_quant_dequant(ref, a.out),
         "fq": lambda: gen_fake_quant(ref, a.out),
         "mx": lambda: gen_mx(ref, a.out),
+        "pt2e": lambda: gen_pt2e(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),
         "windows": lambda: gen_windows(a.out),

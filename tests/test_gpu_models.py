@@ -94,3 +94,32 @@ def test_bert_squad_style_batch_parity():
         outs[dev] = (o.start_logits.float().cpu(), o.end_logits.float().cpu())
     for a, b in zip(outs["cpu"], outs["cuda"]):
         assert float((a - b).abs().max()) <= 0.06 * float(a.abs().max()) + 0.02
+
+
+def test_pt2e_llama_on_device():
+    """The reference's current LLaMA driver flow (wikitext.py:68-136) on a tiny LLaMA: get_default_quantizer,
+    rotary matmul excluded, torch.export with a dynamic sequence length, prepare_pt2e, calibration, observers
+    frozen, evaluation -- device tensors (HIP fake-quant modules inside the exported graph) vs CPU tensors."""
+    from quantized_training import quantize_pt2e as qp
+    res = {}
+    for dev in ("cpu", "cuda"):
+        m = _llama(dev, torch.float32)
+        q = qp.get_default_quantizer("int8,qs=per_tensor_symmetric", None, "int8,qs=per_tensor_symmetric", "int24")
+        q.set_module_name_object_type_order(r"model\.rotary_emb", torch.ops.aten.matmul.default, 0, None)
+        ids = TOK[:, :64].to(dev)
+        seq = torch.export.Dim("seq_length", min=3, max=256)
+        with torch.no_grad():
+            gm = qp.prepare_pt2e(m, q, (ids,), {"labels": ids.clone(), "use_cache": False},
+                                 {"input_ids": {1: seq}, "labels": {1: seq}, "use_cache": None})
+        n_fq = sum(isinstance(mod, torch.ao.quantization.FakeQuantizeBase) for mod in gm.modules())
+        with torch.no_grad():
+            for i in range(3):                                        # calibration
+                w = TOK[:, i * 32: i * 32 + 96].to(dev)
+                gm(w, labels=w.clone(), use_cache=False)
+            for mod in gm.modules():
+                if isinstance(mod, torch.ao.quantization.FakeQuantizeBase):
+                    mod.disable_observer()
+            w = TOK[:, 200:328].to(dev)
+            res[dev] = (float(gm(w, labels=w.clone(), use_cache=False).loss), n_fq)
+    assert res["cpu"][1] == res["cuda"][1] and res["cpu"][1] > 20
+    assert abs(res["cpu"][0] - res["cuda"][0]) <= 0.01 / 5.36 * res["cpu"][0]
