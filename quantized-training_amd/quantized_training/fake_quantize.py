@@ -136,21 +136,6 @@ def _as_flag(v):
     return bool(v)
 
 
-def _dense_or_contiguous(t):
-    """Per-tensor fake-quant is elementwise, so any dense, non-overlapping layout (e.g. a transposed
-    view such as K^T) is processed in storage order and the result keeps the input's strides -- no
-    .contiguous() copy.  Anything else is made contiguous first."""
-    if t.is_contiguous():
-        return t
-    try:
-        from torch._prims_common import is_non_overlapping_and_dense
-        if is_non_overlapping_and_dense(t):
-            return t
-    except Exception:  # noqa: BLE001
-        pass
-    return t.contiguous()
-
-
 def _rows_view(t):
     """(view, transposed) when `t` is a non-contiguous bf16 device tensor whose rows are contiguous:
     either its last dim has stride 1, or its last two dims are a transposed pair (K^T)."""

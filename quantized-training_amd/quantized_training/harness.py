@@ -118,9 +118,11 @@ def gather_in_order(local: torch.Tensor, n_total: int, rank: int, world: int, gr
 @torch.no_grad()
 def evaluate_perplexity(model, token_ids: torch.Tensor, max_length: int = 1024, stride: int = 512,
                         device=None, rank: int = 0, world: int = 1, group=None,
-                        max_windows: Optional[int] = None):
+                        max_windows: Optional[int] = None, use_graph: bool = False):
     """Sliding-window perplexity, windows sharded over ranks.  Returns (ppl, nlls[all windows])
-    with ppl = exp(unweighted mean of per-window NLLs), wikitext.py:167."""
+    with ppl = exp(unweighted mean of per-window NLLs), wikitext.py:167.  `use_graph` replays a captured
+    hipGraph for every full-length window on a GPU (the first call of each fake-quantizer must already
+    have happened, e.g. by one eager window, which this function runs itself)."""
     assert token_ids.dim() == 2 and token_ids.shape[0] == 1
     windows = wikitext_windows(token_ids.shape[1], max_length, stride)
     if max_windows is not None:
@@ -128,8 +130,17 @@ def evaluate_perplexity(model, token_ids: torch.Tensor, max_length: int = 1024, 
     mine = shard_round_robin(list(enumerate(windows)), rank, world)
     device = device if device is not None else next(model.parameters()).device
     local = torch.empty(len(mine), dtype=torch.float32, device=device)
+    graphed = None
     for j, (_, (begin, end, trg_len)) in enumerate(mine):
-        local[j] = window_nll(model, token_ids[:, begin:end].to(device), trg_len)
+        ids = token_ids[:, begin:end].to(device)
+        if use_graph and torch.device(device).type == "cuda" and end - begin == max_length:
+            if graphed is None and j > 0:           # window 0 ran eagerly and created the fake-quantizers
+                graphed = GraphedWindow(model, max_length, None, torch.device(device))
+                graphed.capture(ids)
+            if graphed is not None:
+                local[j] = graphed.replay(ids, trg_len)
+                continue
+        local[j] = window_nll(model, ids, trg_len)
     nlls = gather_in_order(local, len(windows), rank, world, group)
     return math.exp(nlls.double().mean().item()), nlls
 
