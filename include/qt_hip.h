@@ -207,6 +207,17 @@ int qt_softmax_fq_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uin
                        const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
                        uint32_t *amax_bits_dev, void *stream);
 
+/* Whole attention core for already fake-quantized q, k, v (bf16 [B, H, S, D] contiguous, D = 64 or 128):
+ *     O = av_matmul( fq_P( softmax( attn_scaling(qk_matmul(q, k^T), scaling) + mask ) ), v )
+ * with every bf16 rounding point of the reference chain kept (modules/quantizable/modeling_bert.py:118-158,
+ * functional_modules.py:22-26) and the S x S tensor never written.  mask as in qt_softmax_fq_bf16 (strides % 4
+ * == 0).  fmt / lut / scale / amax: fake-quantizer of the probabilities.  out: bf16 [B, Sq, H, D] contiguous
+ * (the transposed layout the attention block needs next). */
+int qt_attention_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, const uint16_t *mask_dev,
+                         uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
+                         long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut_dev,
+                         const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

@@ -68,6 +68,8 @@ SIGNATURES = {
                                _OPQ, _OPQ, _P]),
     "qt_softmax_fq_bf16": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P,
                                   _P, _P]),
+    "qt_attention_fq_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
+                                    _FMT, _P, _P, _P, _P]),
     "qt_bench_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, c_int, c_size_t, c_int, _P,
                                         POINTER(c_float)]),
 }

@@ -309,3 +309,100 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
                                        amax_ptr, st), "qt_softmax_fq_bf16")
     v = fq_v(value) if fq_v is not None else value
     return out, torch.matmul(out, v)
+
+
+def _mask_strides(attention_mask, B, H, Q, C, device, align):
+    """(mask view, stride_b, stride_h, stride_q) of a broadcastable additive bf16 mask, or False if it cannot
+    be consumed in place; None mask -> (None, 0, 0, 0)."""
+    if attention_mask is None:
+        return None, 0, 0, 0
+    m = attention_mask[..., :C]
+    if m.dtype != torch.bfloat16 or m.dim() != 4 or m.stride(-1) != 1 or m.device != device:
+        return False
+    if m.shape[0] not in (1, B) or m.shape[1] not in (1, H) or m.shape[2] not in (1, Q):
+        return False
+    sb = m.stride(0) if m.shape[0] == B and B > 1 else 0
+    sh = m.stride(1) if m.shape[1] == H and H > 1 else 0
+    sq = m.stride(2) if m.shape[2] == Q and Q > 1 else 0
+    if (sb | sh | sq) % align != 0 or m.data_ptr() % (2 * align) != 0:
+        return False
+    return m, sb, sh, sq
+
+
+def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dropout):
+    """The whole attention core in ONE HIP launch (qt_attention_fq_bf16): QK^T, scaling, mask, softmax,
+    fake-quant of the probabilities and P.V on the matrix cores, the S x S tensor never written.  q, k, v go
+    through their own per-tensor fake-quantizers first (elementwise passes that also write the contiguous
+    [B, H, S, D] layout).  Same applicability rules as the fused score path, plus head_dim in {64, 128};
+    returns the attention output already in [B, Sq, H, D], or None.
+
+    QT_FUSED_ATTENTION: "0" never, "1" whenever applicable, unset = only head_dim 64, where the kernel measured
+    faster than the library-GEMM chain (B16 H12 S384: 85 vs 113 us); at head_dim 128 the chain wins (92 vs 122 us at
+    B1 H32 S1024), so the chain stays the default there."""
+    mode = os.environ.get("QT_FUSED_ATTENTION", "auto")
+    if mode == "0" or (mode != "1" and query.shape[-1] != 64):
+        return None
+    if not (query.device.type == "cuda" and query.dtype == torch.bfloat16 and query.dim() == 4):
+        return None
+    if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
+        return None
+    if dropout and attn.training:
+        return None
+    B, H, Q, D = query.shape
+    C = key.shape[2]
+    if D not in (64, 128) or C % 4 != 0 or key.shape != (B, H, C, D) or value.shape != (B, H, C, D) or B * H > 65535:
+        return None
+    for mod in (attn.attn_scaling, attn.softmax):
+        if _has_hooks(mod, "activation_pre_process") or mod._forward_hooks or mod._forward_pre_hooks:
+            return None
+    for mod in (attn.qk_matmul, attn.av_matmul):
+        if mod._forward_hooks:
+            return None
+    hq, hv = getattr(attn.qk_matmul, "activation_pre_process", None), getattr(attn.av_matmul, "activation_pre_process", None)
+    if (hq is None) != (hv is None):
+        return None
+    fq_q = fq_k = fq_p = fq_v = None
+    if hq is not None:
+        if not all(k in hq for k in ("0", "1")) or not all(k in hv for k in ("0", "1")):
+            return None                       # first call: let the hooks create the fake-quantizers
+        fq_q, fq_k, fq_p, fq_v = hq["0"], hq["1"], hv["0"], hv["1"]
+        for f in (fq_q, fq_k, fq_p, fq_v):
+            if not isinstance(f, FusedAmaxObsFakeQuantize) or f.is_per_channel or f.outlier_threshold is not None \
+                    or f.record_histogram or f.qscheme in (QScheme.MICROSCALING, QScheme.GROUP_WISE_AFFINE):
+                return None
+        if len(attn.qk_matmul._forward_pre_hooks) != 1 or len(attn.av_matmul._forward_pre_hooks) != 1:
+            return None
+    elif attn.qk_matmul._forward_pre_hooks or attn.av_matmul._forward_pre_hooks:
+        return None
+    mk = _mask_strides(attention_mask, B, H, Q, C, query.device, 4)
+    if mk is False:
+        return None
+    mask, msb, msh, msq = mk
+    L = _native.lib()
+    st = _stream_ptr(query)
+    qq = (fq_q(query) if fq_q is not None else query).contiguous()
+    kq = (fq_k(key) if fq_k is not None else key).contiguous()          # K, not K^T: elementwise, same statistics
+    vq = (fq_v(value) if fq_v is not None else value).contiguous()
+    out = torch.empty((B, Q, H, D), dtype=torch.bfloat16, device=query.device)
+    if fq_p is not None and (fq_p._observe or fq_p._quantize):
+        fq_p._move_to(query.device)
+        fmt = fq_p._qt_format if fq_p._quantize else _IDENTITY
+        if fq_p._observe:
+            if fq_p.amax_history.numel() == 0:
+                fq_p.amax_history.resize_((fq_p.amax_history_len,)).fill_(0.0)
+                fq_p.scale.resize_(()).fill_(1.0)
+            _native.check(L.qt_scale_update(fq_p.amax_history.data_ptr(), int(fq_p.amax_history.shape[0]), 1,
+                                            fq_p.scale.data_ptr(), float(fq_p.quant_max),
+                                            int(bool(fq_p.force_scale_power_of_two)), st), "qt_scale_update")
+        lut = fq_p.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
+        unit_scale = fq_p.qscheme is None and getattr(fq_p, "_scale_is_one", True)      # no scale tensor at all
+        scale_ptr = fq_p.scale.data_ptr() if (fq_p._quantize and not unit_scale) else None
+        amax_ptr = fq_p.amax_history.data_ptr() if fq_p._observe else None
+        STATS.add(B * H * Q * C)
+    else:
+        fmt, lut, scale_ptr, amax_ptr = _IDENTITY, None, None, None
+    _native.check(L.qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(),
+                                         mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                         B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut,
+                                         scale_ptr, amax_ptr, st), "qt_attention_fq_bf16")
+    return out

@@ -50,8 +50,11 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     value = _repeat_kv(value, n_rep)
     if scaling is None:
         scaling = query.size(-1) ** -0.5
+    from ...fused import fused_attention_or_none, fused_scores_to_probs_or_none
+    core = fused_attention_or_none(module, query, key, value, attention_mask, scaling, dropout)
+    if core is not None:
+        return core, None                      # probabilities are never materialised on this path
     scores = module.qk_matmul(query, key.transpose(2, 3))
-    from ...fused import fused_scores_to_probs_or_none
     fused = fused_scores_to_probs_or_none(module, scores, attention_mask, scaling, dropout, value)
     if fused is not None:
         probs, out = fused

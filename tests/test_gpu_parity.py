@@ -617,3 +617,75 @@ def test_mx_fused_kernel_vs_oracle(nv, dtype, bs, io):
         ey, es = o.mx_fake_quant(x, False, qmap, -1, bs, qmax)
         assert np.array_equal(o.canon_nan32(host_u32(yd)), o.canon_nan32(ey.astype(np.float32).view(np.uint32)).reshape(-1))
         assert np.array_equal(o.canon_nan32(host_u32(sf)), o.canon_nan32(es.astype(np.float32).view(np.uint32)).reshape(-1))
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,mask_kind", [(1, 4, 128, 128, 128, "causal"), (2, 3, 200, 200, 64, "padding"),
+                                                    (1, 2, 64, 320, 128, None), (1, 32, 1024, 1024, 128, "causal")])
+@pytest.mark.parametrize("pdtype", [None, "e4m3", "posit8_1"])
+def test_fused_attention_kernel(nv, B, H, Sq, Sk, D, mask_kind, pdtype):
+    """qt_attention_fq_bf16 vs the torch chain it replaces (bf16 matmul -> *scaling -> +mask -> fp32 softmax ->
+    bf16 -> fake-quant -> bf16 matmul) on already-quantized q, k, v.  Not bit-defined (MFMA accumulation order,
+    exp, row-sum order), so the check is on the attention OUTPUT: |err| <= 2 % of the row's output scale + 1e-2."""
+    L = nv.lib()
+    torch.manual_seed(B * 7 + H)
+    qmap_in = torch.from_numpy(o.get_quantization_map("e4m3").view(np.int16)).cuda().view(torch.bfloat16)
+    fqin = lambda t: qmap_in[(t.view(torch.int16).to(torch.int32) & 0xFFFF).long()]  # noqa: E731
+    q = fqin((torch.randn(B, H, Sq, D, device="cuda")).bfloat16())
+    k = fqin((torch.randn(B, H, Sk, D, device="cuda")).bfloat16())
+    v = fqin((torch.randn(B, H, Sk, D, device="cuda")).bfloat16())
+    scaling = D ** -0.5
+    mask = None
+    minv = torch.finfo(torch.bfloat16).min
+    msb = msq = 0
+    if mask_kind == "causal":
+        mask = torch.full((Sq, Sk), minv, device="cuda").triu(1).bfloat16()[None, None]
+        msq = mask.stride(2)
+    elif mask_kind == "padding":
+        mask = torch.zeros(B, 1, 1, Sk, device="cuda", dtype=torch.bfloat16)
+        mask[:, :, :, Sk - 29:] = minv
+        msb = mask.stride(0)
+    s = torch.matmul(q, k.transpose(2, 3)) * scaling
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, dim=-1, dtype=torch.float32).to(torch.bfloat16)
+    pmax = float(p.float().max())
+    if pdtype is not None:
+        qm = torch.from_numpy(o.get_quantization_map(pdtype).view(np.int16)).cuda().view(torch.bfloat16)
+        p = qm[(p.view(torch.int16).to(torch.int32) & 0xFFFF).long()]
+    ref = torch.matmul(p, v).transpose(1, 2).contiguous().float()
+    fmt = nv.format_for(pdtype)
+    lut = dev_u16(nv.build_map_u16(pdtype))
+    out = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device="cuda")
+    amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nv.check(L.qt_attention_fq_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                    out.data_ptr(), B, H, Sq, Sk, D, msb, 0, msq, scaling, ctypes.byref(fmt), lut.data_ptr(),
+                                    None, amax.data_ptr(), stream()), "attention")
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    tol = 0.02 * ref.abs().amax(dim=-1, keepdim=True) + 1e-2
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert abs(amax.view(torch.float32).item() - pmax) <= 2.0 ** -6 * pmax      # observer sees max(p)
+
+
+def test_llama_fused_attention_vs_module_chain(nv):
+    """Tiny LLaMA (head_dim 64) through quantize(): fused attention core vs the unfused module chain."""
+    import quantized_training as qt
+    from quantized_training import harness
+    from quantized_training.fake_quantize import STATS
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      intermediate_size=512, vocab_size=512, attn_implementation="eager")
+    model = LlamaForCausalLM(cfg).cuda().bfloat16().eval()
+    qt.quantize(model, qt.add_qspec_args().parse_args(["--activation", "e4m3", "--weight", "e4m3", "--bf16"]))
+    ids = torch.randint(0, 512, (2, 192), device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    with torch.no_grad():
+        model(ids)
+        STATS.reset(); a = model(ids).logits.float(); n_fused = STATS.elements
+        os.environ["QT_FUSED_ATTENTION"] = "0"
+        try:
+            STATS.reset(); b = model(ids).logits.float(); n_unfused = STATS.elements
+        finally:
+            del os.environ["QT_FUSED_ATTENTION"]
+    assert n_fused == n_unfused
+    assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max())
