@@ -3,8 +3,10 @@
 Schemas are the reference's, verbatim, so converted PT2E graphs that call
 ``torch.ops.quantized_ops.quantize.default`` / ``dequantize.default`` keep working.  Device
 tensors dispatch to the HIP kernels of libqt_hip.so (no fallback: a missing library raises);
-CPU tensors use the same formulas in torch ops (host-side plumbing).  Block-scaled (MX) ops and
-conv / pooling pass-throughs are outside this engine's hot path.
+CPU tensors use the same formulas in torch ops (host-side plumbing).  The block-scaled GEMMs
+(linear_mx / matmul_mx, upstream :304-363) run on gfx950's scaled MFMA when the element format and
+the scales are ones the instruction takes natively (see mx_gemm.py); conv / pooling pass-throughs
+are outside this engine's hot path.
 """
 import ctypes
 from typing import Optional, Tuple
@@ -16,7 +18,8 @@ from torch.library import Library
 from . import _native
 from .fake_quantize import _cpu_vmap, _stream_ptr, hip_vmap
 
-__all__ = ["vmap", "quantize", "dequantize", "expand", "calculate_mx_qparam", "quantize_mx", "quantized_decomposed_lib"]
+__all__ = ["vmap", "quantize", "dequantize", "expand", "calculate_mx_qparam", "quantize_mx", "linear_mx", "matmul_mx",
+           "conv2d_mx", "quantized_decomposed_lib"]
 
 quantized_decomposed_lib = Library("quantized_ops", "DEF")
 _lib = quantized_decomposed_lib
@@ -215,3 +218,66 @@ def quantize_mx(input, qmap, axes, block_size, quant_max, force_scale_power_of_t
 # ---- GEMM pass-throughs (operands arrive already fake-quantized; upstream decomposed.py:77-94) -----
 _lib.impl("linear", lambda input, weight, bias=None: F.linear(input, weight, bias), "CompositeExplicitAutograd")
 _lib.impl("matmul", lambda self, other: torch.matmul(self, other), "CompositeExplicitAutograd")
+
+
+# ---- block-scaled GEMMs (upstream decomposed.py:265-363) ----------------------------------------------------
+_MX_KW = ("*, Tensor? input_scale=None, Tensor? weight_scale=None, int? block_size=None, "
+          "Tensor? input_code=None, Tensor? weight_code=None) -> Tensor")
+_lib.define("conv2d_mx(Tensor input, Tensor weight, Tensor? bias=None, SymInt[2] stride=1, SymInt[2] padding=0, "
+            "SymInt[2] dilation=1, SymInt groups=1, " + _MX_KW)
+_lib.define("linear_mx(Tensor input, Tensor weight, Tensor? bias=None, " + _MX_KW)
+_lib.define("matmul_mx(Tensor self, Tensor other, " + _MX_KW)
+
+
+def _mx_operand(x, scale, code, block_size):
+    """Codebook lookup, then the block scales broadcast over their blocks (what every *_mx op does to an operand)."""
+    if code is not None:
+        x = code[x.to(torch.long)].to(x.dtype)
+    if scale is not None:
+        x = x * expand(scale, x.shape, block_size)
+    return x
+
+
+def _conv2d_mx_impl(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, *, input_scale=None,
+                    weight_scale=None, block_size=None, input_code=None, weight_code=None):
+    return F.conv2d(_mx_operand(input, input_scale, input_code, block_size),
+                    _mx_operand(weight, weight_scale, weight_code, block_size), bias, stride, padding, dilation, groups)
+
+
+def _linear_mx_impl(input, weight, bias=None, *, input_scale=None, weight_scale=None, block_size=None,
+                    input_code=None, weight_code=None):
+    if input.device.type == "cuda":
+        from .mx_gemm import mx_linear_or_none
+        out = mx_linear_or_none(input, weight, bias, input_scale, weight_scale, block_size, input_code, weight_code)
+        if out is not None:
+            return out
+    return F.linear(_mx_operand(input, input_scale, input_code, block_size),
+                    _mx_operand(weight, weight_scale, weight_code, block_size), bias)
+
+
+def _matmul_mx_impl(self, other, *, input_scale=None, weight_scale=None, block_size=None, input_code=None,
+                    weight_code=None):
+    if self.device.type == "cuda":
+        from .mx_gemm import mx_matmul_or_none
+        out = mx_matmul_or_none(self, other, input_scale, weight_scale, block_size, input_code, weight_code)
+        if out is not None:
+            return out
+    return torch.matmul(_mx_operand(self, input_scale, input_code, block_size),
+                        _mx_operand(other, weight_scale, weight_code, block_size))
+
+
+_lib.impl("conv2d_mx", _conv2d_mx_impl, "CompositeExplicitAutograd")
+_lib.impl("linear_mx", _linear_mx_impl, "CompositeExplicitAutograd")
+_lib.impl("matmul_mx", _matmul_mx_impl, "CompositeExplicitAutograd")
+
+
+def linear_mx(input, weight, bias=None, **kw):
+    return torch.ops.quantized_ops.linear_mx(input, weight, bias, **kw)
+
+
+def matmul_mx(self, other, **kw):
+    return torch.ops.quantized_ops.matmul_mx(self, other, **kw)
+
+
+def conv2d_mx(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, **kw):
+    return torch.ops.quantized_ops.conv2d_mx(input, weight, bias, stride, padding, dilation, groups, **kw)

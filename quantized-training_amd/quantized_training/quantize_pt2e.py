@@ -8,11 +8,16 @@ Same entry points as upstream src/quantized_training/quantize_pt2e.py:
   convert_pt2e (:975-1002)           replace each fake-quant module by real
                                      quantize -> GEMM -> dequantize(s_x * s_w) nodes (:323-446)
 The fake-quant modules and the quantize / dequantize operators are the same HIP-backed ones as in eager mode.
-Not covered here: microscaling / group-wise conversion to *_mx operators and the dequantize-sinking
-clean-up pass (accelerator code generation concerns).
+Block-scaled fake-quantizers lower to quantize_mx / calculate_mx_qparam + quantize nodes whose consumers become
+linear_mx / matmul_mx / conv2d_mx (:456-700); group-wise affine weights lower to stored codes + dequantize (:754-826).
+Not covered here: outlier splitting into a CSR side path (filter_outlier / spmm_csr) and the dequantize-sinking
+clean-up pass, which depends on the accelerator code generator.
 """
 import copy
 import logging
+import operator
+import re
+from collections import OrderedDict
 from dataclasses import asdict, replace
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -20,7 +25,7 @@ import torch
 from torch import Tensor
 from torch.fx import GraphModule, Node
 
-from .fake_quantize import FusedAmaxObsFakeQuantize, _DerivedObserverOrFakeQuantize, _table_for
+from .fake_quantize import FusedAmaxObsFakeQuantize, _DerivedObserverOrFakeQuantize, _table_for, get_quantization_map
 from .quantizer.quantizer import DerivedQuantizationSpec, QScheme, QuantizationSpec
 from .quantizer.xnnpack_quantizer import XNNPACKQuantizer
 from .quantizer.xnnpack_quantizer_utils import QuantizationConfig
@@ -226,9 +231,185 @@ def _lower_fake_quant(model: GraphModule, node: Node, fq, output_dtype):
             user.replace_input_with(qnode, dq)
 
 
+def _mx_op_mapping():
+    return {torch.ops.aten.conv2d.default: torch.ops.quantized_ops.conv2d_mx.default,
+            torch.ops.aten.linear.default: torch.ops.quantized_ops.linear_mx.default,
+            torch.ops.aten.matmul.default: torch.ops.quantized_ops.matmul_mx.default}
+
+
+def _param_or_buffer(model, target):
+    try:
+        return model.get_parameter(target)
+    except AttributeError:
+        return model.get_buffer(target)
+
+
+def _lower_mx_fake_quant(model: GraphModule, node: Node, fq):
+    """One microscaling fake-quant node -> (block scales, element codes) + a block-scaled GEMM consumer
+    (upstream :456-700).  Weights are quantized once and stored with their scales; activations get a fused
+    quantize_mx when the blocks run along the last axis (channel axis for a conv), else calculate_mx_qparam +
+    quantize.  Each consumer (linear / matmul / conv2d) becomes its *_mx twin with the scale / code kwargs."""
+    graph = model.graph
+    device = next(iter(fq.buffers())).device
+    src = node.args[0]
+    src_dtype = fq.dtype
+    if fq.outlier_threshold is not None:
+        raise NotImplementedError("outlier splitting (filter_outlier / spmm_csr) is not part of this engine")
+    if isinstance(fq.ch_axis, int):
+        fq.ch_axis = (fq.ch_axis,)
+    fuse = False
+    if len(fq.ch_axis) == 1:
+        axis = fq.ch_axis[0]
+        if any(u.target == torch.ops.aten.conv2d.default for u in node.users):
+            fuse = axis in (1, -3)
+        else:
+            fuse = axis == -1 or ("val" in src.meta and axis == src.meta["val"].ndim - 1)
+
+    quant_map = get_quantization_map(fq.dtype, device)
+    dequant_code = quant_code = None
+    if isinstance(quant_map, tuple):                     # NormalFloat: indices in the graph, values as a codebook
+        digits = re.findall(r"\d+", fq.dtype)
+        fq.dtype = f"int{digits[0]}"
+        indices, values = quant_map
+        fq.qmap = indices
+        with graph.inserting_before(node):
+            dequant_code = _buffer_node(model, graph, "code", values)
+            if src.op != "get_attr":
+                quant_code = _buffer_node(model, graph, "code", (values[:-1] + values[1:]) / 2)
+        if len(digits) > 1:
+            dequant_code.meta["dtype"] = f"int{digits[1]}"
+
+    if src.op == "get_attr":
+        param = _param_or_buffer(model, src.target)
+        scale = torch.ops.quantized_ops.calculate_mx_qparam(param.data, list(fq.ch_axis), fq.block_size, fq.quant_max,
+                                                            fq.force_scale_power_of_two, fq.scale_qmap)
+        weight = torch.ops.quantized_ops.quantize(param.data, scale, None, list(fq.ch_axis), fq.block_size, fq.qmap)
+        with graph.inserting_before(node):
+            q_node = _buffer_node(model, graph, src.name + "_" + src_dtype, weight)
+            s_node = _buffer_node(model, graph, src.name + "_scale", scale)
+    elif fuse:
+        with graph.inserting_before(node):
+            m_node = _buffer_node(model, graph, "qmap", fq.qmap)
+            sm_node = _buffer_node(model, graph, "qmap", fq.scale_qmap) if fq.scale_qmap is not None else None
+            mx = graph.call_function(torch.ops.quantized_ops.quantize_mx.default,
+                                     (src, m_node, fq.ch_axis, fq.block_size, fq.quant_max, fq.force_scale_power_of_two,
+                                      sm_node, quant_code))
+            s_node = graph.call_function(operator.getitem, (mx, 0))
+            q_node = graph.call_function(operator.getitem, (mx, 1))
+        mx.meta["dtype"] = ("fp8_e8m0" if fq.force_scale_power_of_two else fq.scale_dtype, fq.dtype)
+        _tag(mx)
+    else:
+        with graph.inserting_before(node):
+            args = [src, fq.ch_axis, fq.block_size, fq.quant_max, fq.force_scale_power_of_two]
+            if fq.scale_qmap is not None:
+                args.append(_buffer_node(model, graph, "qmap", fq.scale_qmap))
+            s_node = graph.call_function(torch.ops.quantized_ops.calculate_mx_qparam.default, tuple(args), {})
+            if fq.scale_dtype is not None:
+                s_node.meta["dtype"] = fq.scale_dtype
+            m_node = _buffer_node(model, graph, "qmap", fq.qmap)
+            q_node = graph.call_function(torch.ops.quantized_ops.quantize.default,
+                                         (src, s_node, None, fq.ch_axis, fq.block_size, m_node, quant_code))
+        _tag(q_node)
+    q_node.meta["dtype"] = fq.dtype
+    if fq.force_scale_power_of_two:
+        s_node.meta["dtype"] = "fp8_e8m0"
+    elif fq.scale_dtype is not None:
+        s_node.meta["dtype"] = fq.scale_dtype
+
+    users = list(node.users.keys())
+    node.replace_all_uses_with(q_node)
+    graph.erase_node(node)
+    if len(src.users) == 0:
+        graph.erase_node(src)
+
+    mapping = _mx_op_mapping()
+    for user in users:
+        code_arg, scale_arg = dequant_code, s_node
+        if user.target == torch.Tensor.to:               # device-alignment hop: move the side inputs with it
+            with graph.inserting_before(user):
+                if code_arg is not None:
+                    code_arg = graph.call_function(torch.Tensor.to, (dequant_code, user.args[1]))
+                scale_arg = graph.call_function(torch.Tensor.to, (s_node, user.args[1]))
+            user = next(iter(user.users))
+        kwargs = OrderedDict(user.kwargs)
+        kwargs.setdefault("block_size", fq.block_size)
+        if src.op == "get_attr" or (len(user.args) > 1 and q_node is user.args[1]):
+            kwargs.setdefault("weight_code", code_arg)
+            kwargs.setdefault("weight_scale", scale_arg)
+        else:
+            kwargs.setdefault("input_code", code_arg)
+            kwargs.setdefault("input_scale", scale_arg)
+        order = ["input_scale", "weight_scale", "block_size", "input_code", "weight_code"]
+        kwargs = OrderedDict((k, kwargs[k]) for k in order if k in kwargs)
+        if user.target in mapping:
+            with graph.inserting_before(user):
+                mx_op = graph.call_function(mapping[user.target], user.args, kwargs)
+            user.replace_all_uses_with(mx_op)
+            graph.erase_node(user)
+            mx_op.meta = user.meta
+            stack = mx_op.meta.setdefault("source_fn_stack", [])
+            stack.append((mx_op.name, stack[-1][1] if stack else mx_op.target))
+        elif user.target in mapping.values():
+            user.kwargs = kwargs
+        else:
+            raise RuntimeError(f"Unsupported user node {user.target} for quantization, expected one of "
+                               f"{list(mapping.keys())}")
+
+
+def _lower_group_wise_affine(model: GraphModule, node: Node, fq):
+    """Group-wise affine weight fake-quant -> stored codes, scales, zero points + one dequantize node
+    (upstream :754-826; activations are not supported there either)."""
+    graph = model.graph
+    if isinstance(fq.ch_axis, int):
+        fq.ch_axis = (fq.ch_axis,)
+    src = node.args[0]
+    if src.op != "get_attr":
+        raise NotImplementedError
+    param = _param_or_buffer(model, src.target)
+    fq(param.data)
+    scale, zero_point = fq.calculate_qparams()
+    scale, zero_point = scale.to(param.data.dtype), zero_point.to(param.data.dtype)
+    weight = torch.ops.quantized_ops.quantize(param.data, scale, zero_point, list(fq.ch_axis), fq.block_size, fq.qmap)
+    with graph.inserting_before(node):
+        q_node = _buffer_node(model, graph, src.name + "_" + fq.dtype, weight)
+        s_node = _buffer_node(model, graph, src.name + "_scale", scale)
+        z_node = _buffer_node(model, graph, src.name + "_zero_point", zero_point)
+    q_node.meta["dtype"] = fq.dtype
+    if fq.scale_dtype is not None:
+        s_node.meta["dtype"] = z_node.meta["dtype"] = fq.scale_dtype
+    with graph.inserting_before(node):
+        dq = graph.call_function(torch.ops.quantized_ops.dequantize.default, (q_node, s_node, z_node, fq.ch_axis, fq.block_size))
+    _tag(dq)
+    node.replace_all_uses_with(dq)
+    graph.erase_node(node)
+    if len(src.users) == 0:
+        graph.erase_node(src)
+
+
+def _eliminate_dequantize_with_no_effect(model: GraphModule):
+    """Drop dequantize nodes whose stored scale is all ones and that do not re-quantize their output (upstream :829-853)."""
+    for node in list(model.graph.nodes):
+        if node.target != torch.ops.quantized_ops.dequantize.default:
+            continue
+        s_node = node.args[1]
+        if s_node.op != "get_attr" or torch.any(model.get_buffer(s_node.target) != 1):
+            continue
+        out_map = node.args[6] if len(node.args) > 6 else node.kwargs.get("output_qmap")
+        if out_map is not None:
+            continue
+        node.replace_all_uses_with(node.args[0])
+        model.graph.erase_node(node)
+        logger.info(f"Eliminate dequantize node {node} with no effect")
+    model.graph.lint()
+    model.graph.eliminate_dead_code()
+    model.recompile()
+    return model
+
+
 def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effect: bool = True):
     """Lower every FusedAmaxObsFakeQuantize `call_module` of a prepared (and calibrated) graph to
-    quantized_ops.quantize / dequantize nodes (upstream :975-1002)."""
+    quantized_ops nodes (upstream :975-1002): quantize / dequantize for per-tensor and per-channel specs,
+    quantize_mx + *_mx GEMMs for microscaling, stored codes + dequantize for group-wise affine weights."""
     modules = dict(model.named_modules(remove_duplicate=False))
     for node in list(model.graph.nodes):
         if node.op != "call_module":
@@ -236,10 +417,14 @@ def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effe
         mod = modules.get(str(node.target))
         if not isinstance(mod, torch.ao.quantization.FakeQuantizeBase):
             continue
-        if mod.qscheme in (QScheme.MICROSCALING, QScheme.GROUP_WISE_AFFINE):
-            raise NotImplementedError("convert_pt2e lowers per-tensor / per-channel fake-quantizers; block-scaled "
-                                      "formats stay fake-quantized (prepare_pt2e output) in this engine")
-        _lower_fake_quant(model, node, mod, output_dtype)
+        if mod.qscheme == QScheme.MICROSCALING:
+            _lower_mx_fake_quant(model, node, mod)
+        elif mod.qscheme == QScheme.GROUP_WISE_AFFINE:
+            _lower_group_wise_affine(model, node, mod)
+        else:
+            _lower_fake_quant(model, node, mod, output_dtype)
+    if eliminate_no_effect:
+        _eliminate_dequantize_with_no_effect(model)
     model.graph.lint()
     model.graph.eliminate_dead_code(is_impure_node=lambda n: n.op in {"placeholder", "output"})
     model.recompile()

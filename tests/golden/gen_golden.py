@@ -503,6 +503,82 @@ def gen_pt2e(ref, out):
         json.dump(meta, f, indent=1)
 
 
+def gen_pt2e_mx(ref, out):
+    """PT2E flow with block-scaled (microscaling) specs: prepared outputs, the converted graph with
+    quantize_mx / linear_mx / matmul_mx nodes, quantized weight + scale buffers and converted outputs
+    (quantize_pt2e.py:94-116, 456-700; decomposed.py:265-448)."""
+    import torch.nn as nn
+    qp = ref.quantize_pt2e
+    assert qp is not None, getattr(ref, "pt2e_error", None)
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(64, 128)
+            self.fc2 = nn.Linear(128, 64)
+
+        def forward(self, x):
+            h = torch.relu(self.fc1(x))
+            y = self.fc2(h) + x
+            a = torch.matmul(y, y.transpose(-1, -2))
+            return torch.matmul(torch.softmax(a, -1), y)
+
+    rng = np.random.default_rng(23)
+    arrays, meta = {}, {}
+    xs = [(rng.standard_normal((2, 32, 64)) * (i + 1)).astype(np.float32) for i in range(2)]
+    for i, x in enumerate(xs):
+        arrays[f"x{i}"] = f32_bits(torch.from_numpy(x))
+    runs = [("mxfp8", dict(input_activation="fp8_e4m3,qs=microscaling,bs=32,ax=-1", weight="fp8_e4m3,qs=microscaling,bs=32,ax=-1",
+                           force_scale_power_of_two=True), torch.float32),
+            ("mxfp4_bf16", dict(input_activation="fp4_e2m1,qs=microscaling,bs=32,ax=-1", weight="fp4_e2m1,qs=microscaling,bs=32,ax=-1",
+                                force_scale_power_of_two=True), torch.bfloat16),
+            ("mxfp6_w_int", dict(input_activation="fp6_e3m2,qs=microscaling,bs=32,ax=-1", weight="int4,qs=microscaling,bs=32,ax=-1",
+                                 force_scale_power_of_two=True), torch.float32),
+            ("nvfp4_like", dict(input_activation="fp4_e2m1,qs=microscaling,bs=16,ax=-1,scale=fp8_e4m3",
+                                weight="fp4_e2m1,qs=microscaling,bs=16,ax=-1,scale=fp8_e4m3"), torch.float32),
+            ("nf4_weight", dict(input_activation="int8,qs=microscaling,bs=32,ax=-1", weight="nf4_6,qs=microscaling,bs=32,ax=-1",
+                                force_scale_power_of_two=True), torch.float32)]
+    for name, kw, dt in runs:
+        m = Toy().eval()
+        r = np.random.default_rng(3)
+        with torch.no_grad():
+            for n, p in sorted(m.named_parameters()):
+                p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+        if name == "mxfp8":
+            for n, p in m.named_parameters():
+                arrays["param/" + n] = f32_bits(p.detach())
+        m = m.to(dt)
+        x0, x1 = (torch.from_numpy(x).to(dt) for x in xs)
+        try:
+            q = qp.get_default_quantizer(**kw)
+            gm = qp.prepare_pt2e(m, q, (x0,))
+            info = {"kw": kw, "dtype": str(dt).replace("torch.", ""), "prepared_graph": _graph_rows(gm),
+                    "fq_modules": {n: [mod.dtype, str(mod.ch_axis), str(mod.block_size)] for n, mod in gm.named_modules()
+                                   if isinstance(mod, torch.ao.quantization.FakeQuantizeBase)}}
+            with torch.no_grad():
+                gm(x0)
+                y1 = gm(x1)
+            arrays[f"{name}/y_prepared"] = tensor_bits(y1)
+            gc = qp.convert_pt2e(gm)
+            info["converted_graph"] = _graph_rows(gc)
+            info["converted_kwargs"] = {n.name: {k: (v.name if isinstance(v, torch.fx.Node) else v) for k, v in n.kwargs.items()}
+                                        for n in gc.graph.nodes if n.kwargs}
+            info["node_dtype"] = {n.name: (list(n.meta["dtype"]) if isinstance(n.meta["dtype"], tuple) else n.meta["dtype"])
+                                  for n in gc.graph.nodes if n.meta.get("dtype") is not None}
+            with torch.no_grad():
+                y2 = gc(x1)
+            arrays[f"{name}/y_converted"] = tensor_bits(y2)
+            for k, v in gc.named_buffers():
+                arrays[f"{name}/buf/{k}"] = tensor_bits(v)
+            info["buffers"] = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in gc.named_buffers()}
+        except Exception as e:  # noqa: BLE001 - record what the reference does with this spec
+            info = {"kw": kw, "dtype": str(dt).replace("torch.", ""), "error": f"{type(e).__name__}: {e}"[:300]}
+        meta[name] = info
+    np.savez_compressed(os.path.join(out, "pt2e_mx.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "pt2e_mx.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_spec(ref, out):
     """QuantizationSpec.from_str / get_quant_min_max / add_qspec_args defaults."""
     from dataclasses import asdict
@@ -576,6 +652,7 @@ def main():
         "fq": lambda: gen_fake_quant(ref, a.out),
         "mx": lambda: gen_mx(ref, a.out),
         "pt2e": lambda: gen_pt2e(ref, a.out),
+        "pt2e_mx": lambda: gen_pt2e_mx(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),
         "windows": lambda: gen_windows(a.out),

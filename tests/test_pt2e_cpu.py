@@ -103,3 +103,95 @@ def test_quantizer_selectors_and_exclusion():
     assert lin[0].args[0].op == "call_module" and lin[1].args[0].op != "call_module"
     with pytest.raises(AssertionError):
         qp.get_default_quantizer("int8,qs=per_tensor_symmetric", None, "int8,qs=per_tensor_symmetric", None)
+
+
+# ---- block-scaled specs: quantize_mx / linear_mx / matmul_mx graphs (upstream quantize_pt2e.py:456-700) --------
+META_MX = json.load(open(os.path.join(G, "pt2e_mx.json")))
+
+
+class ToyMX(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(64, 128)
+        self.fc2 = nn.Linear(128, 64)
+
+    def forward(self, x):
+        h = torch.relu(self.fc1(x))
+        y = self.fc2(h) + x
+        a = torch.matmul(y, y.transpose(-1, -2))
+        return torch.matmul(torch.softmax(a, -1), y)
+
+
+def _bits(t):
+    if t.dtype == torch.bfloat16:
+        b = t.detach().contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+        b[((b & 0x7F80) == 0x7F80) & ((b & 0x7F) != 0)] = 0x7FC0
+        return b
+    return _canon32(t)
+
+
+def mx_setup(name, arr, device="cpu"):
+    info = META_MX[name]
+    dt = getattr(torch, info["dtype"])
+    m = ToyMX().eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(arr["param__" + n].view(np.float32)))
+    xs = [torch.from_numpy(arr[f"x{i}"].view(np.float32)).to(dt).to(device) for i in range(2)]
+    return info, m.to(dt).to(device), xs
+
+
+@pytest.mark.parametrize("name", sorted(META_MX))
+def test_pt2e_microscaling_flow_matches_reference(name):
+    arr = np.load(os.path.join(G, "pt2e_mx.npz"))
+    info, m, xs = mx_setup(name, arr)
+    gm = qp.prepare_pt2e(m, qp.get_default_quantizer(**info["kw"]), (xs[0],))
+    assert _rows(gm) == info["prepared_graph"]
+    fq = {n: [mod.dtype, str(mod.ch_axis), str(mod.block_size)] for n, mod in gm.named_modules()
+          if isinstance(mod, torch.ao.quantization.FakeQuantizeBase)}
+    assert fq == info["fq_modules"]
+    with torch.no_grad():
+        gm(xs[0])
+        y1 = gm(xs[1])
+    assert np.array_equal(_bits(y1), arr[f"{name}__y_prepared"])
+    gc = qp.convert_pt2e(gm)
+    assert _rows(gc) == info["converted_graph"]
+    kw = {n.name: {k: (v.name if isinstance(v, torch.fx.Node) else v) for k, v in n.kwargs.items()}
+          for n in gc.graph.nodes if n.kwargs}
+    assert kw == info["converted_kwargs"]
+    nd = {n.name: (list(n.meta["dtype"]) if isinstance(n.meta["dtype"], tuple) else n.meta["dtype"])
+          for n in gc.graph.nodes if n.meta.get("dtype") is not None}
+    assert nd == info["node_dtype"]
+    bufs = dict(gc.named_buffers())
+    assert {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in bufs.items()} == info["buffers"]
+    for k, v in bufs.items():
+        assert np.array_equal(_bits(v), arr[f"{name}__buf__{k}"]), k
+    with torch.no_grad():
+        y2 = gc(xs[1])
+    assert np.array_equal(_bits(y2), arr[f"{name}__y_converted"])
+
+
+def test_group_wise_affine_weights_convert_to_codes_and_dequantize():
+    """Weights with a group-wise affine spec become stored codes + scale + zero point and one dequantize node
+    (upstream quantize_pt2e.py:754-826); the converted module computes what the prepared one did."""
+    from quantized_training.quantizer.quantizer import QuantizationSpec
+    from quantized_training.quantizer.xnnpack_quantizer import XNNPACKQuantizer
+    from quantized_training.quantizer.xnnpack_quantizer_utils import QuantizationConfig
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    w = QuantizationSpec.from_str("uint4,qs=group_wise_affine,bs=32,ax=-1")
+    w.observer_or_fake_quant_ctr = FusedAmaxObsFakeQuantize
+    q = XNNPACKQuantizer().set_object_type(torch.ops.aten.linear.default, QuantizationConfig(None, None, w, None))
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(64, 32)).eval()
+    x = torch.randn(3, 64)
+    gm = qp.prepare_pt2e(m, q, (x,))
+    with torch.no_grad():
+        y1 = gm(x)
+    gc = qp.convert_pt2e(gm)
+    targets = [str(n.target) for n in gc.graph.nodes]
+    assert "quantized_ops.dequantize.default" in targets
+    names = dict(gc.named_buffers())
+    assert any(k.endswith("_uint4") for k in names) and any(k.endswith("_zero_point") for k in names)
+    with torch.no_grad():
+        y2 = gc(x)
+    assert torch.allclose(y1, y2, atol=1e-5, rtol=1e-5)
