@@ -218,6 +218,30 @@ int qt_attention_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uin
                          long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut_dev,
                          const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
 
+/* ---- section 8(f).2: block-scaled (microscaling) GEMMs on the scaled matrix instruction ---------------------
+ * Replaces linear_mx / matmul_mx (decomposed.py:304-363: operand * expand(block scale) twice, then F.linear /
+ * torch.matmul) when both operands are in a format v_mfma_scale_f32_16x16x128_f8f6f4 takes -- element formats
+ * QT_MX_E4M3 / E5M2 (the reference's fp8_e4m3 / fp8_e5m2), E2M3 / E3M2 (fp6_e2m3 / fp6_e3m2), E2M1 (fp4_e2m1) with
+ * power-of-two scales (force_scale_power_of_two, "fp8_e8m0") over blocks of 32 k (or a multiple of 32).
+ *
+ * Packed operand: codes[rows][K * bits / 8] (element i of a row in bits [i*bits, (i+1)*bits), little-endian),
+ * e8m0[rows][K / 32] (scale 2^(byte - 127)).
+ *
+ * qt_mx_pack: values + block scales, as the reference's quantize / quantize_mx return them (bf16 or fp32, addressed
+ * with element strides so that a [K, N] operand of matmul_mx is packed as [N, K]), -> packed operand.  *bad_dev
+ * (nullable, caller-zeroed) is set to 1 when a value is not exactly representable in elem_format or a scale is not
+ * 2^e with -127 <= e <= 127: the caller must then keep the dequantize + GEMM path.
+ * qt_mx_gemm: C[b][M][N] = A[b][M][K] . B[b][N][K]^T (+ bias[N]), fp32 accumulation, C / bias bf16 or fp32.  Batch
+ * strides are given in rows (0 = operand shared by every batch).  Returns QT_ERR_BAD_DTYPE for a format pair
+ * without a kernel, QT_ERR_UNALIGNED unless K * bits / 8 is a multiple of 16 and the code pointers are 16-byte aligned. */
+enum { QT_MX_E4M3 = 0, QT_MX_E5M2 = 1, QT_MX_E2M3 = 2, QT_MX_E3M2 = 3, QT_MX_E2M1 = 4 };
+int qt_mx_pack(const void *x_dev, const void *scale_dev, int is_f32, uint8_t *codes_dev, uint8_t *e8m0_dev, long batch,
+               long rows, long K, long x_batch_stride, long x_row_stride, long x_k_stride, long s_batch_stride,
+               long s_row_stride, long s_k_stride, int block_size, int elem_format, int *bad_dev, void *stream);
+int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, const uint8_t *b_codes, const uint8_t *b_e8m0,
+               int b_format, void *c_dev, int c_is_f32, const void *bias_dev, long batch, int M, int N, int K,
+               long a_batch_stride_rows, long b_batch_stride_rows, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

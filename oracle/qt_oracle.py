@@ -496,3 +496,61 @@ def group_wise_affine_fake_quant(x, is_bf16, axis, block_size, quant_min, quant_
         q = _clamp(np.rint(rd(rd(x / se) + ze)), F32(quant_min), F32(quant_max))           # :185
         y = rd(rd(q - ze) * se)                                                            # :188
     return y.astype(F32), sf, zp
+
+
+# ---- packed block-scaled operands (OCP MX element codes + E8M0 scales) --------------------------------------
+# What linear_mx / matmul_mx consume is (values, block scales) (decomposed.py:304-363).  The matrix instruction
+# wants the same numbers as element codes and one exponent byte per 32 elements; this is that re-encoding,
+# restated on the host so the device packer can be checked bit for bit.
+MX_ELEM = {"fp8_e4m3": (0, 4, 3, 7), "fp8_e5m2": (1, 5, 2, 15), "fp6_e2m3": (2, 2, 3, 1), "fp6_e3m2": (3, 3, 2, 3),
+           "fp4_e2m1": (4, 2, 1, 1)}      # name -> (hardware format id, exponent bits, mantissa bits, bias)
+
+
+def mx_decode(code, fmt):
+    """Element code -> float64 value (OCP MX v1.0 element formats; no Inf/NaN codes are produced by mx_encode)."""
+    _, eb, mb, bias = MX_ELEM[fmt]
+    code = np.asarray(code, dtype=np.int64)
+    s = (code >> (eb + mb)) & 1
+    e = (code >> mb) & ((1 << eb) - 1)
+    m = code & ((1 << mb) - 1)
+    v = np.where(e == 0, np.ldexp(m.astype(np.float64), 1 - bias - mb), np.ldexp(((1 << mb) | m).astype(np.float64), e - bias - mb))
+    return np.where(s == 1, -v, v)
+
+
+def mx_encode(values, fmt):
+    """float values that are exactly representable in `fmt` -> element codes; raises if one is not."""
+    _, eb, mb, bias = MX_ELEM[fmt]
+    v = np.asarray(values, dtype=np.float64)
+    table = mx_decode(np.arange(1 << (eb + mb)), fmt)          # non-negative half, increasing
+    finite = table[: {"fp8_e4m3": 0x7F, "fp8_e5m2": 0x7C}.get(fmt, len(table))]     # drop the NaN / Inf codes of the 8-bit formats
+    idx = np.searchsorted(finite, np.abs(v))
+    idx = np.clip(idx, 0, len(finite) - 1)
+    if not np.array_equal(finite[idx], np.abs(v)):
+        raise ValueError(f"value not representable in {fmt}")
+    return (idx | (np.signbit(v).astype(np.int64) << (eb + mb))).astype(np.uint32)
+
+
+def mx_pack(values, scales, fmt, block_size=32):
+    """values [rows, K], scales [rows, K / block_size] (powers of two) -> (codes uint8 [rows, K*bits/8], e8m0 uint8 [rows, K/32]).
+    Element i of a row occupies bits [i*bits, (i+1)*bits) of the row, little-endian."""
+    _, eb, mb, _ = MX_ELEM[fmt]
+    bits = 1 + eb + mb
+    values = np.asarray(values, dtype=np.float64)
+    rows, K = values.shape
+    codes = mx_encode(values, fmt).astype(np.uint64)
+    bitpos = np.arange(K, dtype=np.uint64) * np.uint64(bits)
+    out = np.zeros((rows, K * bits // 8), dtype=np.uint8)
+    for b in range(bits):
+        pos = bitpos + np.uint64(b)
+        byte, off = (pos >> np.uint64(3)).astype(np.int64), (pos & np.uint64(7)).astype(np.uint8)
+        bitv = ((codes >> np.uint64(b)) & np.uint64(1)).astype(np.uint8)
+        np.bitwise_or.at(out, (np.arange(rows)[:, None], byte[None, :]), bitv << off[None, :])
+    s = np.asarray(scales, dtype=np.float64)
+    m, e = np.frexp(s)                                            # s = m * 2^e, m in [0.5, 1)
+    if not np.all(m == 0.5):
+        raise ValueError("scale is not a power of two")
+    e8 = (e - 1 + 127)
+    if np.any(e8 < 0) or np.any(e8 > 254):
+        raise ValueError("scale outside E8M0")
+    e8 = np.repeat(e8.astype(np.uint8), block_size // 32, axis=1)
+    return out, e8

@@ -1,0 +1,312 @@
+// Block-scaled (microscaling) GEMMs on gfx950's scaled matrix instruction.
+//
+// Replaces, for operands whose element format and scales the hardware takes natively,
+//     linear_mx / matmul_mx          decomposed.py:304-363
+//         x = x * expand(input_scale, x.shape, block_size); w = w * expand(weight_scale, ...); F.linear / matmul
+// i.e. two dequantize passes over the operands plus a bf16 GEMM, by v_mfma_scale_f32_16x16x128_f8f6f4 reading the
+// 8 / 6 / 4-bit element codes and one E8M0 scale per 32 elements directly.
+//
+// Operand memory layout ("packed MX operand"): codes[rows][K * bits / 8] row-major, K contiguous, element i of a row
+// in bits [i*bits, (i+1)*bits) little-endian; scales[rows][K / 32] E8M0 bytes (2^(byte - 127)).
+// Fragment layout of the instruction (measured, tools/probe_mx_mfma*.hip): lane l = (row r = l & 15, group g = l >> 4)
+//   fp6 / fp4: k = 32 g + [0, 32) of the 128-deep step;   fp8: bytes 0-15 <- k = 16 g + [0, 16), bytes 16-31 <- k = 64 + 16 g + [0, 16)
+//   scale register byte 0 of lane (r, g) = scale of row r, k in [32 g, 32 g + 32);   D: col = l & 15, row = 4 (l >> 4) + i.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qt_hip.h"
+#include "qt_formats.h"
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 128;      // block tile (elements)
+constexpr int kPad = 16;                            // LDS row padding (bytes): rows 16 apart land on distinct banks
+
+__host__ __device__ constexpr int tile_row_bytes(int f) { return f < 2 ? 128 : (f < 4 ? 96 : 64); }
+__host__ __device__ constexpr int elem_bits(int f) { return f < 2 ? 8 : (f < 4 ? 6 : 4); }
+
+struct MxGemmArgs {
+    const uint8_t *A, *B;        // packed codes [batch][M][K*bitsA/8], [batch][N][K*bitsB/8]
+    const uint8_t *sA, *sB;      // E8M0 [batch][M][K/32], [batch][N][K/32]
+    void *C;                     // [batch][M][N] bf16 or f32
+    const void *bias;            // [N] in C's dtype, or NULL
+    int M, N, K;
+    long bA, bB, bsA, bsB, bC;   // batch strides: bytes for A / B / scales, elements for C
+    int out_f32;
+};
+
+template <int F>
+__device__ __forceinline__ v8i read_frag(const uint8_t *row_base, int g) {
+    v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (F < 2) {
+        const uint4 lo = *(const uint4 *)(row_base + 16 * g);
+        const uint4 hi = *(const uint4 *)(row_base + 64 + 16 * g);
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else if constexpr (F < 4) {
+        const uint2 a = *(const uint2 *)(row_base + 24 * g);
+        const uint2 b = *(const uint2 *)(row_base + 24 * g + 8);
+        const uint2 c = *(const uint2 *)(row_base + 24 * g + 16);
+        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
+    } else {
+        const uint4 lo = *(const uint4 *)(row_base + 16 * g);
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+    }
+    return f;
+}
+
+template <int FA, int FB>
+__global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
+    constexpr int RA = tile_row_bytes(FA), RB = tile_row_bytes(FB);
+    constexpr int LA = RA + kPad, LB = RB + kPad;
+    constexpr int CA = RA / 16, CB = RB / 16;            // 16-byte chunks per tile row
+    constexpr int NA = kBM * CA / 256, NB = kBN * CB / 256;   // chunks per thread
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    auto s_a = [&](int buf) __attribute__((always_inline)) { return lds + buf * (kBM * LA); };
+    auto s_b = [&](int buf) __attribute__((always_inline)) { return lds + 2 * kBM * LA + buf * (kBN * LB); };
+
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int r = l & 15, g = l >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const long bz = blockIdx.z;
+    const long kbA = (long)a.K * elem_bits(FA) / 8, kbB = (long)a.K * elem_bits(FB) / 8;   // bytes per row
+    const int nblk = a.K / 32;
+    const uint8_t *Ab = a.A + bz * a.bA, *Bb = a.B + bz * a.bB;
+    const uint8_t *sAb = a.sA + bz * a.bsA, *sBb = a.sB + bz * a.bsB;
+    const int nk = (a.K + kBK - 1) / kBK;
+
+    uint4 ra[NA], rb[NB];
+    int sca[4], scb[4];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = t + 256 * i, row = c / CA, cc = c % CA;
+            const long off = (long)kt * RA + cc * 16;
+            ra[i] = (m0 + row < a.M && off < kbA) ? *(const uint4 *)(Ab + (long)(m0 + row) * kbA + off) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = t + 256 * i, row = c / CB, cc = c % CB;
+            const long off = (long)kt * RB + cc * 16;
+            rb[i] = (n0 + row < a.N && off < kbB) ? *(const uint4 *)(Bb + (long)(n0 + row) * kbB + off) : uint4{0u, 0u, 0u, 0u};
+        }
+        const int kb = min(kt * 4 + g, nblk - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(m0 + wm * 64 + i * 16 + r, a.M - 1);
+            sca[i] = sAb[(long)row * nblk + kb];
+            const int col = min(n0 + wn * 64 + i * 16 + r, a.N - 1);
+            scb[i] = sBb[(long)col * nblk + kb];
+        }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = t + 256 * i, row = c / CA, cc = c % CA;
+            *(uint4 *)(s_a(buf) + row * LA + cc * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = t + 256 * i, row = c / CB, cc = c % CB;
+            *(uint4 *)(s_b(buf) + row * LB + cc * 16) = rb[i];
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    int cs_a[4], cs_b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cs_a[i] = sca[i]; cs_b[i] = scb[i]; }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);               // in flight during this tile's MFMAs
+        v8i fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<FA>(s_a(cur) + (wm * 64 + i * 16 + r) * LA, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<FB>(s_b(cur) + (wn * 64 + j * 16 + r) * LB, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, cs_a[i], 0, cs_b[j]);
+        if (kt + 1 < nk) {
+            store_tile(cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cs_a[i] = sca[i]; cs_b[i] = scb[i]; }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D col = l & 15, row = 4 g + e
+    const long cbase = bz * a.bC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= a.N) continue;
+        float bv = 0.f;
+        if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wm * 64 + i * 16 + 4 * g + e;
+                if (row >= a.M) continue;
+                const float v = acc[i][j][e] + bv;
+                const long idx = cbase + (long)row * a.N + col;
+                if (a.out_f32) ((float *)a.C)[idx] = v;
+                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+            }
+        }
+    }
+}
+
+// ---- packing: (values, block scales) -> element codes + E8M0 ------------------------------------------------
+// A value that the format holds exactly converts exactly; anything else (and a scale that is not a power of
+// two) raises the `bad` flag so the caller can fall back to the dequantize + GEMM path.
+__device__ __forceinline__ uint32_t encode_elem(int f, float v, bool &bad) {
+    const uint32_t u = qt_f2u(v), s = u >> 31, au = u & 0x7FFFFFFFu;
+    const float m = qt_u2f(au);
+    const int E = (int)(au >> 23) - 127;
+    int ebits, mbits, bias;
+    float maxv;
+    switch (f) {
+        case 0: ebits = 4; mbits = 3; bias = 7; maxv = 448.f; break;
+        case 1: ebits = 5; mbits = 2; bias = 15; maxv = 57344.f; break;
+        case 2: ebits = 2; mbits = 3; bias = 1; maxv = 7.5f; break;
+        case 3: ebits = 3; mbits = 2; bias = 3; maxv = 28.f; break;
+        default: ebits = 2; mbits = 1; bias = 1; maxv = 6.f; break;
+    }
+    if (!(m <= maxv)) { bad = true; return 0; }          // also catches NaN
+    uint32_t code;
+    float back;
+    if (E < 1 - bias) {                                  // subnormal of the target: multiples of 2^(1 - bias - mbits)
+        const float q = m * qt_u2f((uint32_t)(127 - (1 - bias - mbits)) << 23);
+        code = (uint32_t)q;
+        back = (float)code * qt_u2f((uint32_t)(127 + (1 - bias - mbits)) << 23);
+    } else {
+        const uint32_t mant = (au >> (23 - mbits)) & ((1u << mbits) - 1u);
+        code = ((uint32_t)(E + bias) << mbits) | mant;
+        back = qt_u2f(au & ~((1u << (23 - mbits)) - 1u));
+    }
+    if (back != m) bad = true;
+    (void)ebits;
+    return code | (s << (ebits + mbits));
+}
+
+struct PackArgs {
+    const void *x, *scale;       // values and block scales, bf16 or f32
+    uint8_t *codes, *e8m0;
+    long rows, K;                // logical [rows][K]
+    long x_rs, x_ks;             // element strides of x
+    long s_rs, s_ks;             // element strides of scale ([rows][K / block_size])
+    long batch, x_bs, s_bs;      // leading batch dimension (strides in elements)
+    int block_size, fmt, f32;
+    int *bad;
+};
+
+// one thread per (row, 32-element block)
+__global__ __launch_bounds__(256) void mx_pack_kernel(PackArgs p) {
+    const long nb = p.K / 32;
+    const long total = p.batch * p.rows * nb;
+    const long rows_fast = p.x_rs == 1 ? 1 : 0;          // adjacent threads walk the contiguous dimension
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long b, row, blk;
+        if (rows_fast) { row = i % p.rows; blk = (i / p.rows) % nb; b = i / (p.rows * nb); }
+        else { blk = i % nb; row = (i / nb) % p.rows; b = i / (p.rows * nb); }
+        bool bad = false;
+        const long sidx = b * p.s_bs + row * p.s_rs + (blk * 32 / p.block_size) * p.s_ks;
+        const float s = p.f32 ? ((const float *)p.scale)[sidx] : qt_bf2f(((const uint16_t *)p.scale)[sidx]);
+        const uint32_t su = qt_f2u(s);
+        const uint32_t eb = (su >> 23) & 0xFFu;
+        const bool pow2 = (su >> 31) == 0 && eb != 0xFFu && eb != 0 && (su & 0x7FFFFFu) == 0;
+        const bool tiny = (su >> 31) == 0 && eb == 0 && su != 0;      // below 2^-126: fine only in front of an all-zero block
+        if (!pow2 && !tiny) bad = true;
+        const int bits = elem_bits(p.fmt);
+        uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool allzero = true;
+        for (int e = 0; e < 32; ++e) {
+            const long xi = b * p.x_bs + row * p.x_rs + (blk * 32 + e) * p.x_ks;
+            const float v = p.f32 ? ((const float *)p.x)[xi] : qt_bf2f(((const uint16_t *)p.x)[xi]);
+            const uint32_t code = encode_elem(p.fmt, v, bad);
+            allzero = allzero && ((code & ((1u << (bits - 1)) - 1u)) == 0);
+            const int pos = e * bits;
+            out[pos >> 5] |= code << (pos & 31);
+            if ((pos & 31) + bits > 32) out[(pos >> 5) + 1] |= code >> (32 - (pos & 31));
+        }
+        if (tiny && !allzero) bad = true;
+        const long obytes = (long)bits * 4;               // bytes per 32 elements
+        uint32_t *dst = (uint32_t *)(p.codes + ((b * p.rows + row) * nb + blk) * obytes);
+        for (int q = 0; q < bits; ++q) dst[q] = out[q];
+        p.e8m0[(b * p.rows + row) * nb + blk] = (uint8_t)eb;
+        if (bad && p.bad) atomicOr(p.bad, 1);
+    }
+}
+
+int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_mx_pack(const void *x_dev, const void *scale_dev, int is_f32, uint8_t *codes_dev, uint8_t *e8m0_dev, long batch,
+               long rows, long K, long x_batch_stride, long x_row_stride, long x_k_stride, long s_batch_stride,
+               long s_row_stride, long s_k_stride, int block_size, int elem_format, int *bad_dev, void *stream) {
+    if (batch * rows * K == 0) return QT_OK;
+    if (!x_dev || !scale_dev || !codes_dev || !e8m0_dev || batch < 0 || rows < 0 || K < 0) return QT_ERR_BAD_ARG;
+    if (elem_format < 0 || elem_format > 4 || block_size < 32 || block_size % 32 != 0 || K % 32 != 0) return QT_ERR_BAD_ARG;
+    PackArgs p{x_dev, scale_dev, codes_dev, e8m0_dev, rows, K, x_row_stride, x_k_stride, s_row_stride, s_k_stride,
+               batch, x_batch_stride, s_batch_stride, block_size, elem_format, is_f32, bad_dev};
+    const long total = batch * rows * (K / 32);
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 65535u * 4u) grid = 65535u * 4u;
+    mx_pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    return launch_status();
+}
+
+int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, const uint8_t *b_codes, const uint8_t *b_e8m0,
+               int b_format, void *c_dev, int c_is_f32, const void *bias_dev, long batch, int M, int N, int K,
+               long a_batch_stride_rows, long b_batch_stride_rows, void *stream) {
+    if (batch * M * N == 0) return QT_OK;
+    if (!a_codes || !a_e8m0 || !b_codes || !b_e8m0 || !c_dev || batch < 0 || batch > 65535 || M < 0 || N < 0 || K < 32 || K % 32)
+        return QT_ERR_BAD_ARG;
+    if (a_format < 0 || a_format > 4 || b_format < 0 || b_format > 4) return QT_ERR_BAD_ARG;
+    const long kbA = (long)K * elem_bits(a_format) / 8, kbB = (long)K * elem_bits(b_format) / 8;
+    if ((kbA & 15) || (kbB & 15) || (((uintptr_t)a_codes | (uintptr_t)b_codes) & 15u)) return QT_ERR_UNALIGNED;
+    MxGemmArgs g{a_codes, b_codes, a_e8m0, b_e8m0, c_dev, bias_dev, M, N, K,
+                 a_batch_stride_rows * kbA, b_batch_stride_rows * kbB, a_batch_stride_rows * (K / 32), b_batch_stride_rows * (K / 32),
+                 (long)M * N, c_is_f32};
+    const dim3 grid((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, (unsigned)batch);
+    hipStream_t st = (hipStream_t)stream;
+#define QT_MX(FA, FB)                                                                                              \
+    if (a_format == FA && b_format == FB) {                                                                        \
+        constexpr int kLds = 2 * kBM * (tile_row_bytes(FA) + kPad) + 2 * kBN * (tile_row_bytes(FB) + kPad);        \
+        static bool configured = false;                                                                            \
+        if (!configured) {                                                                                         \
+            const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_kernel<FA, FB>,                         \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds);            \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            configured = true;                                                                                     \
+        }                                                                                                          \
+        mx_gemm_kernel<FA, FB><<<grid, 256, kLds, st>>>(g);                                                        \
+        return launch_status();                                                                                    \
+    }
+    QT_MX(0, 0) QT_MX(0, 1) QT_MX(1, 0) QT_MX(1, 1) QT_MX(2, 2) QT_MX(3, 3) QT_MX(4, 4) QT_MX(0, 4) QT_MX(2, 4) QT_MX(3, 4)
+#undef QT_MX
+    return QT_ERR_BAD_DTYPE;          // element-format pair without a kernel: caller dequantizes
+}
+
+}  // extern "C"

@@ -689,3 +689,119 @@ def test_llama_fused_attention_vs_module_chain(nv):
             del os.environ["QT_FUSED_ATTENTION"]
     assert n_fused == n_unfused
     assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max())
+
+
+# ---- block-scaled GEMMs on the scaled matrix instruction (qt_mx_pack / qt_mx_gemm) ----------------------------
+MX_FMT_ID = {"fp8_e4m3": 0, "fp8_e5m2": 1, "fp6_e2m3": 2, "fp6_e3m2": 3, "fp4_e2m1": 4}
+
+
+def _mx_operand(rows, K, fmt, block, dtype, seed, sigma=1.0):
+    """Random operand through the engine's own quantize_mx: (block scales, element values) as the converted graphs hold them."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import get_quantization_map
+    from quantized_training.quantizer.quantizer import get_quant_min_max
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = (torch.randn(rows, K, device="cuda", generator=g) * sigma).to(dtype)
+    qmap = get_quantization_map(fmt, "cuda")
+    qmax = get_quant_min_max(fmt)[1]
+    scale, q = torch.ops.quantized_ops.quantize_mx(x, qmap, [-1], block, float(qmax), True, None, None)
+    return scale, q
+
+
+def _pack(nv, q, scale, fmt, block, transpose=False):
+    L = nv.lib()
+    if transpose:                                     # q is [K, N]: pack as [N, K]
+        K, rows = q.shape
+        xs = (0, 1, q.stride(0))
+        ss = (0, 1, scale.stride(0))
+    else:
+        rows, K = q.shape
+        xs = (0, q.stride(0), 1)
+        ss = (0, scale.stride(0), 1)
+    bits = {0: 8, 1: 8, 2: 6, 3: 6, 4: 4}[MX_FMT_ID[fmt]]
+    codes = torch.empty(rows, K * bits // 8, dtype=torch.uint8, device="cuda")
+    e8 = torch.empty(rows, K // 32, dtype=torch.uint8, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nv.check(L.qt_mx_pack(q.data_ptr(), scale.data_ptr(), int(q.dtype == torch.float32), codes.data_ptr(), e8.data_ptr(),
+                          1, rows, K, *xs, *ss, block, MX_FMT_ID[fmt], bad.data_ptr(), stream()), "qt_mx_pack")
+    return codes, e8, int(bad.item())
+
+
+@pytest.mark.parametrize("fmt", sorted(MX_FMT_ID))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_mx_pack_matches_host_restatement(nv, fmt, dtype):
+    for block in (32, 64):
+        scale, q = _mx_operand(24, 256, fmt, block, dtype, seed=block, sigma=3.0)
+        codes, e8, bad = _pack(nv, q, scale, fmt, block)
+        assert bad == 0
+        want_codes, want_e8 = o.mx_pack(q.float().cpu().numpy(), scale.float().cpu().numpy(), fmt, block)
+        assert np.array_equal(codes.cpu().numpy(), want_codes)
+        assert np.array_equal(e8.cpu().numpy(), want_e8)
+    # a value outside the format, or a scale that is not a power of two, raises the flag instead of packing garbage
+    q2 = q.clone(); q2[3, 5] = 0.3
+    assert _pack(nv, q2, scale, fmt, 64)[2] == 1
+    s2 = scale.clone(); s2[1, 1] = 3.0
+    assert _pack(nv, q, s2, fmt, 64)[2] == 1
+
+
+@pytest.mark.parametrize("fa,fb", [("fp8_e4m3", "fp8_e4m3"), ("fp8_e4m3", "fp8_e5m2"), ("fp8_e5m2", "fp8_e4m3"),
+                                   ("fp8_e5m2", "fp8_e5m2"), ("fp6_e2m3", "fp6_e2m3"), ("fp6_e3m2", "fp6_e3m2"),
+                                   ("fp4_e2m1", "fp4_e2m1"), ("fp8_e4m3", "fp4_e2m1"), ("fp6_e2m3", "fp4_e2m1"),
+                                   ("fp6_e3m2", "fp4_e2m1")])
+@pytest.mark.parametrize("shape", [(128, 128, 128), (200, 328, 448), (1, 64, 64), (1024, 512, 1024)])
+def test_mx_gemm_vs_dequantized_reference(nv, fa, fb, shape):
+    """C = (a * expand(sa)) @ (b * expand(sb))^T exactly as linear_mx states it.  Products of MX elements and
+    power-of-two scales are exact; the instruction adds the 128 products of a step in an aligned fixed-point tree that
+    keeps fewer bits than an fp32 chain (measured: up to 2^-16 of sum|a||b|), so the bound is |err| <= 2^-14 * sum|a||b|
+    for the fp32 result; the bf16 result adds one rounding (2^-9 relative, 2^-8 allowed)."""
+    L = nv.lib()
+    M, N, K = shape
+    sa, qa = _mx_operand(M, K, fa, 32, torch.float32, seed=1, sigma=2.0)
+    sb, qb = _mx_operand(N, K, fb, 32, torch.float32, seed=2, sigma=0.5)
+    ca, ea, bad_a = _pack(nv, qa, sa, fa, 32)
+    cb, eb, bad_b = _pack(nv, qb, sb, fb, 32)
+    assert bad_a == 0 and bad_b == 0
+    da = (qa * sa.repeat_interleave(32, 1)).double()
+    db = (qb * sb.repeat_interleave(32, 1)).double()
+    ref = da @ db.t()
+    mag = da.abs() @ db.abs().t()
+    bias = torch.randn(N, device="cuda")
+    for out_dtype in (torch.float32, torch.bfloat16):
+        for use_bias in (False, True):
+            c = torch.full((M, N), float("nan"), dtype=out_dtype, device="cuda")
+            b = bias.to(out_dtype) if use_bias else None
+            nv.check(L.qt_mx_gemm(ca.data_ptr(), ea.data_ptr(), MX_FMT_ID[fa], cb.data_ptr(), eb.data_ptr(), MX_FMT_ID[fb],
+                                  c.data_ptr(), int(out_dtype == torch.float32), b.data_ptr() if use_bias else None,
+                                  1, M, N, K, 0, 0, stream()), "qt_mx_gemm")
+            want = ref + (b.double() if use_bias else 0.0)
+            err = (c.double() - want).abs()
+            tol = 2.0 ** -14 * mag + (2.0 ** -8 * want.abs() if out_dtype == torch.bfloat16 else 0.0) + 1e-30
+            assert bool((err <= tol).all()), float((err / tol).max())
+
+
+def test_mx_gemm_batched_and_transposed_operand(nv):
+    """matmul_mx's second operand arrives as [K, N] with blocks along K (axis -2): packed through strides as [N, K]."""
+    L = nv.lib()
+    B, M, N, K = 3, 96, 80, 64
+    import quantized_training as qt
+    from quantized_training.fake_quantize import get_quantization_map
+    qmap = get_quantization_map("fp8_e4m3", "cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(B, M, K, device="cuda", generator=g).bfloat16()
+    b = torch.randn(B, K, N, device="cuda", generator=g).bfloat16()
+    sa, qa = torch.ops.quantized_ops.quantize_mx(a, qmap, [-1], 32, 448.0, True, None, None)
+    sb = torch.ops.quantized_ops.calculate_mx_qparam(b, [-2], 32, 448.0, True)
+    qb = torch.ops.quantized_ops.quantize(b, sb, None, [-2], 32, qmap)
+    ca = torch.empty(B, M, K, dtype=torch.uint8, device="cuda"); ea = torch.empty(B, M, K // 32, dtype=torch.uint8, device="cuda")
+    cb = torch.empty(B, N, K, dtype=torch.uint8, device="cuda"); eb = torch.empty(B, N, K // 32, dtype=torch.uint8, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nv.check(L.qt_mx_pack(qa.data_ptr(), sa.data_ptr(), 0, ca.data_ptr(), ea.data_ptr(), B, M, K, qa.stride(0), qa.stride(1), 1,
+                          sa.stride(0), sa.stride(1), 1, 32, 0, bad.data_ptr(), stream()), "pack a")
+    nv.check(L.qt_mx_pack(qb.data_ptr(), sb.data_ptr(), 0, cb.data_ptr(), eb.data_ptr(), B, N, K, qb.stride(0), 1, qb.stride(1),
+                          sb.stride(0), 1, sb.stride(1), 32, 0, bad.data_ptr(), stream()), "pack b")
+    assert int(bad.item()) == 0
+    c = torch.empty(B, M, N, dtype=torch.bfloat16, device="cuda")
+    nv.check(L.qt_mx_gemm(ca.data_ptr(), ea.data_ptr(), 0, cb.data_ptr(), eb.data_ptr(), 0, c.data_ptr(), 0, None, B, M, N, K,
+                          M, N, stream()), "qt_mx_gemm")
+    ref = torch.matmul((qa * sa.repeat_interleave(32, -1)).float(), (qb * sb.repeat_interleave(32, -2)).float())
+    assert torch.allclose(c.float(), ref, rtol=2.0 ** -7, atol=1e-3)
