@@ -13,6 +13,7 @@
 //   scale register byte 0 of lane (r, g) = scale of row r, k in [32 g, 32 g + 32);   D: col = l & 15, row = 4 (l >> 4) + i.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/qt_hip.h"
 #include "qt_formats.h"
@@ -23,7 +24,6 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 128, kBN = 128, kBK = 128;      // block tile (elements)
-constexpr int kPad = 16;                            // LDS row padding (bytes): rows 16 apart land on distinct banks
 
 __host__ __device__ constexpr int tile_row_bytes(int f) { return f < 2 ? 128 : (f < 4 ? 96 : 64); }
 __host__ __device__ constexpr int elem_bits(int f) { return f < 2 ? 8 : (f < 4 ? 6 : 4); }
@@ -38,20 +38,39 @@ struct MxGemmArgs {
     int out_f32;
 };
 
+// LDS image of a 128-row operand tile.  8- and 4-bit tiles are unpadded with the 16-byte chunk index XOR-swizzled by
+// the row so that the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ... : sixteen different rows, half of
+// them one chunk further along k) each touch sixteen different 16-byte slots of the 256-byte bank row; 6-bit tiles
+// (96-byte rows, read with ds_read_b64) use a 112-byte pitch, conflict-free for the two 32-lane halves.
 template <int F>
-__device__ __forceinline__ v8i read_frag(const uint8_t *row_base, int g) {
+struct Tile {
+    static constexpr int kRow = tile_row_bytes(F);                  // bytes of one row of a 128-deep tile
+    static constexpr int kPitch = (F == 2 || F == 3) ? kRow + 16 : kRow;
+    static constexpr int kChunks = kRow / 16;
+    static constexpr int kBytes = 128 * kPitch;
+    static __device__ __forceinline__ int chunk_off(int row, int chunk) {
+        if constexpr (F < 2) return row * kPitch + ((chunk ^ ((row >> 1) & 7)) << 4);
+        else if constexpr (F < 4) return row * kPitch + (chunk << 4);
+        else return row * kPitch + ((chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 4);     // f = [0,2,3,1], see below
+    }
+};
+// fp4 swizzle: rows r and r' of one lane group with r & 3 == r' & 3 collide when f(r >> 2) ^ f(r' >> 2) == 1 for a
+// row pair that sits on different k chunks; those pairs are (0|3, 1|2), so f must pair 0 with 3 and 1 with 2:
+// f = [0, 2, 3, 1] (packed two bits each, low first, in 0x78).
+
+template <int F>
+__device__ __forceinline__ v8i read_frag(const uint8_t *tile, int row, int g) {
     v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (F < 2) {
-        const uint4 lo = *(const uint4 *)(row_base + 16 * g);
-        const uint4 hi = *(const uint4 *)(row_base + 64 + 16 * g);
+        const uint4 lo = *(const uint4 *)(tile + Tile<F>::chunk_off(row, g));
+        const uint4 hi = *(const uint4 *)(tile + Tile<F>::chunk_off(row, 4 + g));
         f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
     } else if constexpr (F < 4) {
-        const uint2 a = *(const uint2 *)(row_base + 24 * g);
-        const uint2 b = *(const uint2 *)(row_base + 24 * g + 8);
-        const uint2 c = *(const uint2 *)(row_base + 24 * g + 16);
+        const uint8_t *p = tile + row * Tile<F>::kPitch + 24 * g;
+        const uint2 a = *(const uint2 *)(p), b = *(const uint2 *)(p + 8), c = *(const uint2 *)(p + 16);
         f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
     } else {
-        const uint4 lo = *(const uint4 *)(row_base + 16 * g);
+        const uint4 lo = *(const uint4 *)(tile + Tile<F>::chunk_off(row, g));
         f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
     }
     return f;
@@ -59,59 +78,98 @@ __device__ __forceinline__ v8i read_frag(const uint8_t *row_base, int g) {
 
 template <int FA, int FB>
 __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
-    constexpr int RA = tile_row_bytes(FA), RB = tile_row_bytes(FB);
-    constexpr int LA = RA + kPad, LB = RB + kPad;
-    constexpr int CA = RA / 16, CB = RB / 16;            // 16-byte chunks per tile row
-    constexpr int NA = kBM * CA / 256, NB = kBN * CB / 256;   // chunks per thread
+    using TA = Tile<FA>;
+    using TB = Tile<FB>;
+    constexpr int RA = TA::kRow, RB = TB::kRow;
+    constexpr int CA = TA::kChunks, CB = TB::kChunks;            // 16-byte chunks per tile row
+    constexpr int NA = kBM * CA / 256, NB = kBN * CB / 256;       // chunks per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    auto s_a = [&](int buf) __attribute__((always_inline)) { return lds + buf * (kBM * LA); };
-    auto s_b = [&](int buf) __attribute__((always_inline)) { return lds + 2 * kBM * LA + buf * (kBN * LB); };
+    auto s_a = [&](int buf) __attribute__((always_inline)) { return lds + buf * TA::kBytes; };
+    auto s_b = [&](int buf) __attribute__((always_inline)) { return lds + 2 * TA::kBytes + buf * TB::kBytes; };
 
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int r = l & 15, g = l >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
-    const long bz = blockIdx.z;
+    // Workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles, and walk the tiles in
+    // groups of 8 M-tiles per N-tile column so that a run re-uses its A and B panels out of that XCD's L2.
+    const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBN - 1) / kBN;
+    const int ntiles = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;                  // XCD x owns [x*per + min(x, rem), ...)
+    }
+    constexpr int kGroup = 8;
+    const int width = kGroup * tiles_n, grp = id / width, first_m = grp * kGroup;
+    const int gsize = min(tiles_m - first_m, kGroup);
+    const int m0 = (first_m + (id % width) % gsize) * kBM, n0 = ((id % width) / gsize) * kBN;
+    const long bz = blockIdx.y;
     const long kbA = (long)a.K * elem_bits(FA) / 8, kbB = (long)a.K * elem_bits(FB) / 8;   // bytes per row
     const int nblk = a.K / 32;
     const uint8_t *Ab = a.A + bz * a.bA, *Bb = a.B + bz * a.bB;
     const uint8_t *sAb = a.sA + bz * a.bsA, *sBb = a.sB + bz * a.bsB;
     const int nk = (a.K + kBK - 1) / kBK;
 
+    // per-thread staging geometry (fixed over the k loop); rows beyond M / N re-read the last row (never stored)
+    const uint8_t *ga[NA], *gb[NB];
+    int la[NA], lb[NB], ca[NA], cb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = t + 256 * i, row = c / CA, cc = c % CA;
+        ga[i] = Ab + (long)min(m0 + row, a.M - 1) * kbA + cc * 16;
+        la[i] = TA::chunk_off(row, cc);
+        ca[i] = cc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int c = t + 256 * i, row = c / CB, cc = c % CB;
+        gb[i] = Bb + (long)min(n0 + row, a.N - 1) * kbB + cc * 16;
+        lb[i] = TB::chunk_off(row, cc);
+        cb[i] = cc * 16;
+    }
+    const uint8_t *psa[4], *psb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        psa[i] = sAb + (long)min(m0 + wm * 64 + i * 16 + r, a.M - 1) * nblk;
+        psb[i] = sBb + (long)min(n0 + wn * 64 + i * 16 + r, a.N - 1) * nblk;
+    }
+
     uint4 ra[NA], rb[NB];
     int sca[4], scb[4];
     auto load_tile = [&](int kt) __attribute__((always_inline)) {
+        // the k tail (K % 128 != 0) re-reads chunk 0 of the row and is zeroed when it is stored
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int c = t + 256 * i, row = c / CA, cc = c % CA;
-            const long off = (long)kt * RA + cc * 16;
-            ra[i] = (m0 + row < a.M && off < kbA) ? *(const uint4 *)(Ab + (long)(m0 + row) * kbA + off) : uint4{0u, 0u, 0u, 0u};
+            const long off = (long)kt * RA + ca[i];
+            ra[i] = *(const uint4 *)(ga[i] + (off < kbA ? (long)kt * RA : -(long)ca[i]));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int c = t + 256 * i, row = c / CB, cc = c % CB;
-            const long off = (long)kt * RB + cc * 16;
-            rb[i] = (n0 + row < a.N && off < kbB) ? *(const uint4 *)(Bb + (long)(n0 + row) * kbB + off) : uint4{0u, 0u, 0u, 0u};
+            const long off = (long)kt * RB + cb[i];
+            rb[i] = *(const uint4 *)(gb[i] + (off < kbB ? (long)kt * RB : -(long)cb[i]));
         }
         const int kb = min(kt * 4 + g, nblk - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = min(m0 + wm * 64 + i * 16 + r, a.M - 1);
-            sca[i] = sAb[(long)row * nblk + kb];
-            const int col = min(n0 + wn * 64 + i * 16 + r, a.N - 1);
-            scb[i] = sBb[(long)col * nblk + kb];
+            sca[i] = psa[i][kb];
+            scb[i] = psb[i][kb];
         }
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    auto store_tile = [&](int buf, int kt) __attribute__((always_inline)) {
+        // branch-free so that the k loop stays one basic block (the scheduling fences below only act inside one)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int c = t + 256 * i, row = c / CA, cc = c % CA;
-            *(uint4 *)(s_a(buf) + row * LA + cc * 16) = ra[i];
+            const bool live = (long)kt * RA + ca[i] < kbA;
+            uint4 v = ra[i];
+            v.x = live ? v.x : 0u; v.y = live ? v.y : 0u; v.z = live ? v.z : 0u; v.w = live ? v.w : 0u;
+            *(uint4 *)(s_a(buf) + la[i]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int c = t + 256 * i, row = c / CB, cc = c % CB;
-            *(uint4 *)(s_b(buf) + row * LB + cc * 16) = rb[i];
+            const bool live = (long)kt * RB + cb[i] < kbB;
+            uint4 v = rb[i];
+            v.x = live ? v.x : 0u; v.y = live ? v.y : 0u; v.z = live ? v.z : 0u; v.w = live ? v.w : 0u;
+            *(uint4 *)(s_b(buf) + lb[i]) = v;
         }
     };
 
@@ -122,33 +180,153 @@ __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
     int cs_a[4], cs_b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { cs_a[i] = sca[i]; cs_b[i] = scb[i]; }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);               // in flight during this tile's MFMAs
+    auto compute = [&](int cur) __attribute__((always_inline)) {
         v8i fa[4], fb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = read_frag<FA>(s_a(cur) + (wm * 64 + i * 16 + r) * LA, g);
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<FA>(s_a(cur), wm * 64 + i * 16 + r, g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = read_frag<FB>(s_b(cur) + (wn * 64 + j * 16 + r) * LB, g);
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<FB>(s_b(cur), wn * 64 + j * 16 + r, g);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, cs_a[i], 0, cs_b[j]);
-        if (kt + 1 < nk) {
-            store_tile(cur ^ 1);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);                                // in flight during this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);                // keep the LDS refill (and its wait on the loads) behind the MFMAs
+        store_tile(cur ^ 1, kt + 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { cs_a[i] = sca[i]; cs_b[i] = scb[i]; }
+        for (int i = 0; i < 4; ++i) { cs_a[i] = sca[i]; cs_b[i] = scb[i]; }
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    // epilogue: D col = l & 15, row = 4 g + e
+    const long cbase = bz * a.bC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= a.N) continue;
+        float bv = 0.f;
+        if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wm * 64 + i * 16 + 4 * g + e;
+                if (row >= a.M) continue;
+                const float v = acc[i][j][e] + bv;
+                const long idx = cbase + (long)row * a.N + col;
+                if (a.out_f32) ((float *)a.C)[idx] = v;
+                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+            }
         }
+    }
+}
+
+// ---- LDS-DMA variant: 8- and 4-bit operands, K % 128 == 0 -------------------------------------------------
+// Tiles and their scale bytes go global -> LDS with global_load_lds (no staging registers, so three workgroups fit
+// per CU and cover each other's load latency); the XOR swizzle is applied on the per-lane SOURCE address because
+// the DMA writes a wave's 64 x 16 bytes linearly.  One 128-deep tile per step, two barriers per step.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int F>
+struct DmaTile {                                    // 1 KiB wave-instruction = kRows rows of the tile
+    static constexpr int kRow = tile_row_bytes(F), kChunks = kRow / 16, kRows = 64 / kChunks;
+    static constexpr int kInstr = 128 / kRows / 4;  // wave-instructions per wave per tile (4 for fp8, 2 for fp4)
+};
+
+template <int FA, int FB>
+__global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
+    using TA = Tile<FA>;
+    using TB = Tile<FB>;
+    using DA = DmaTile<FA>;
+    using DB = DmaTile<FB>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *const s_a = lds, *const s_b = lds + TA::kBytes, *const s_sa = lds + TA::kBytes + TB::kBytes, *const s_sb = s_sa + 512;
+
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int r = l & 15, g = l >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBN - 1) / kBN;
+    const int ntiles = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    constexpr int kGroup = 8;
+    const int width = kGroup * tiles_n, grp = id / width, first_m = grp * kGroup;
+    const int gsize = min(tiles_m - first_m, kGroup);
+    const int m0 = (first_m + (id % width) % gsize) * kBM, n0 = ((id % width) / gsize) * kBN;
+    const long bz = blockIdx.y;
+    const long kbA = (long)a.K * elem_bits(FA) / 8, kbB = (long)a.K * elem_bits(FB) / 8;
+    const int nblk = a.K / 32, nk = a.K / kBK;
+
+    // source addresses of this lane's DMA pieces (k tile 0); LDS destinations are wave-uniform
+    const uint8_t *ga[DA::kInstr], *gb[DB::kInstr];
+#pragma unroll
+    for (int i = 0; i < DA::kInstr; ++i) {
+        const int row = (w * DA::kInstr + i) * DA::kRows + l / DA::kChunks, cs = l % DA::kChunks;
+        const int chunk = (TA::chunk_off(row, cs) - row * TA::kPitch) >> 4;        // the swizzle is an involution
+        ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * kbA + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < DB::kInstr; ++i) {
+        const int row = (w * DB::kInstr + i) * DB::kRows + l / DB::kChunks, cs = l % DB::kChunks;
+        const int chunk = (TB::chunk_off(row, cs) - row * TB::kPitch) >> 4;
+        gb[i] = a.B + bz * a.bB + (long)min(n0 + row, a.N - 1) * kbB + chunk * 16;
+    }
+    // scale bytes of the tile: 128 rows x 4 bytes per operand; waves 0,1 fetch A's, waves 2,3 fetch B's
+    const int srow = (w & 1) * 64 + l;
+    const uint8_t *gs = w < 2 ? a.sA + bz * a.bsA + (long)min(m0 + srow, a.M - 1) * nblk
+                              : a.sB + bz * a.bsB + (long)min(n0 + srow, a.N - 1) * nblk;
+    uint8_t *const s_dst = (w < 2 ? s_sa : s_sb) + (w & 1) * 256;
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < DA::kInstr; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow), (lds_void *)(s_a + (w * DA::kInstr + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < DB::kInstr; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow), (lds_void *)(s_b + (w * DB::kInstr + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)s_dst, 4, 0, 0);
+        __syncthreads();
+        int sa[4], sb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[i] = s_sa[(wm * 64 + i * 16 + r) * 4 + g];
+            sb[i] = s_sb[(wn * 64 + i * 16 + r) * 4 + g];
+        }
+        v8i fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<FA>(s_a, wm * 64 + i * 16 + r, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<FB>(s_b, wn * 64 + j * 16 + r, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
         __syncthreads();
     }
 
-    // epilogue: D col = l & 15, row = 4 g + e
     const long cbase = bz * a.bC;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -289,11 +467,21 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     MxGemmArgs g{a_codes, b_codes, a_e8m0, b_e8m0, c_dev, bias_dev, M, N, K,
                  a_batch_stride_rows * kbA, b_batch_stride_rows * kbB, a_batch_stride_rows * (K / 32), b_batch_stride_rows * (K / 32),
                  (long)M * N, c_is_f32};
-    const dim3 grid((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, (unsigned)batch);
+    const dim3 grid(((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM), (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_dma = getenv("QT_MX_NO_DMA") != nullptr;        // tuning / A-B switch
+    const bool dma_ok = !no_dma && K % kBK == 0 && (((uintptr_t)a_e8m0 | (uintptr_t)b_e8m0) & 3u) == 0;
+#define QT_MX_DMA(FA, FB)                                                                                          \
+    if (dma_ok && a_format == FA && b_format == FB) {                                                              \
+        constexpr int kLds = Tile<FA>::kBytes + Tile<FB>::kBytes + 1024;                                           \
+        mx_gemm_dma_kernel<FA, FB><<<grid, 256, kLds, st>>>(g);                                                    \
+        return launch_status();                                                                                    \
+    }
+    QT_MX_DMA(0, 0) QT_MX_DMA(0, 1) QT_MX_DMA(1, 0) QT_MX_DMA(1, 1) QT_MX_DMA(4, 4) QT_MX_DMA(0, 4)
+#undef QT_MX_DMA
 #define QT_MX(FA, FB)                                                                                              \
     if (a_format == FA && b_format == FB) {                                                                        \
-        constexpr int kLds = 2 * kBM * (tile_row_bytes(FA) + kPad) + 2 * kBN * (tile_row_bytes(FB) + kPad);        \
+        constexpr int kLds = 2 * Tile<FA>::kBytes + 2 * Tile<FB>::kBytes;                                          \
         static bool configured = false;                                                                            \
         if (!configured) {                                                                                         \
             const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_kernel<FA, FB>,                         \
