@@ -53,6 +53,9 @@ def _vmap_cpu(input, qmap):
 
 
 def _vmap_hip(input, qmap):
+    if qmap.dtype != torch.bfloat16 or qmap.numel() != 65536:
+        # index tables (NormalFloat codes are int64, fake_quantize.py:90-93): same gather in torch device ops
+        return _cpu_vmap(input, qmap).contiguous()
     return hip_vmap(input, qmap.contiguous(), None)
 
 
@@ -99,12 +102,17 @@ def _quantize_impl(input, scale, zero_point=None, axes=None, block_size=None, qm
             _native.check(fn(x.data_ptr(), y.data_ptr(), x.numel(), ctypes.byref(fmt), qmap.data_ptr(),
                              s.data_ptr(), z.data_ptr() if z is not None else None, _stream_ptr(x)), "qt_quantize")
         return y
+    pow2 = getattr(scale, "_qt_pow2", False)
     if block_size is not None:
         scale = expand(scale, input.shape, block_size)
         if zero_point is not None:
             zero_point = expand(zero_point, input.shape, block_size)
     input = input / scale if zero_point is None else input / scale + zero_point
-    return torch.ops.quantized_ops.vmap(input, qmap)
+    out = torch.ops.quantized_ops.vmap(input, qmap)
+    if pow2 and zero_point is None and out.device.type == "cuda":
+        from .mx_gemm import remember_format
+        remember_format(out, qmap)                     # lets linear_mx / matmul_mx take the element codes directly
+    return out
 
 
 def _dequantize_impl(input, scale, zero_point=None, axes=None, block_size=None, input_qmap=None, output_qmap=None):
@@ -189,7 +197,10 @@ def _calculate_mx_qparam_impl(input, axes, block_size, quant_max, force_scale_po
         scale = amax / _const_like(quant_max, amax)
         if scale_qmap is not None:
             scale = torch.ops.quantized_ops.vmap(scale, scale_qmap)
-    return torch.where(scale > 0.0, scale, _const_like(1.0, scale))
+    scale = torch.where(scale > 0.0, scale, _const_like(1.0, scale))
+    if force_scale_power_of_two:
+        scale._qt_pow2 = True                          # an E8M0-representable scale, by construction
+    return scale
 
 
 def _quantize_mx_impl(input, qmap, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None,

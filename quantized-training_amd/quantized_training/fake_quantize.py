@@ -111,8 +111,10 @@ def get_quantization_map(dtype, device=None):
         if host is None:
             table = _native.build_map_u16(dtype)          # raises ValueError on unknown dtype
             host = torch.from_numpy(table.view("int16")).view(torch.bfloat16)
+            host._qt_dtype = dtype
             _MAP_CACHE[(dtype, torch.device("cpu"))] = host
         hit = host if dev.type == "cpu" else host.to(dev)
+        hit._qt_dtype = dtype    # lets the block-scaled GEMMs recognise the element format of values rounded with this map
         _MAP_CACHE[key] = hit
     return hit
 
@@ -224,7 +226,7 @@ def hip_vmap(x, qmap, fmt=None):
 
 
 # ----------------------------------------------------------------------------------------------
-# CPU-tensor formulas (host plumbing only; device tensors never come here)
+# CPU-tensor formulas (host plumbing; the one device use is _cpu_vmap's gather for non-bf16 index tables, decomposed.py)
 # ----------------------------------------------------------------------------------------------
 def _cpu_vmap(x, qmap):
     if x.dtype == torch.bfloat16:

@@ -163,7 +163,11 @@ def _fresh_attr(module, prefix):
 
 def _buffer_node(model, graph, prefix, value):
     name = _fresh_attr(model, prefix)
-    model.register_buffer(name, value.clone().detach() if isinstance(value, Tensor) else torch.tensor(value))
+    buf = value.clone().detach() if isinstance(value, Tensor) else torch.tensor(value)
+    for tag in ("_qt_dtype", "_qt_pow2", "_qt_mx_fmt"):        # hints for the block-scaled GEMMs (mx_gemm.py)
+        if hasattr(value, tag):
+            setattr(buf, tag, getattr(value, tag))
+    model.register_buffer(name, buf)
     return graph.create_node("get_attr", name)
 
 
