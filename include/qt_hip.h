@@ -242,6 +242,19 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
                int b_format, void *c_dev, int c_is_f32, const void *bias_dev, long batch, int M, int N, int K,
                long a_batch_stride_rows, long b_batch_stride_rows, void *stream);
 
+/* Fused quantize_mx for blocks along the last axis (decomposed.py:365-448 with axes = [-1]): x [rows][cols] in the
+ * tensor dtype -> q (element values map[x / scale], nullable), scales [rows][cols / block_size] (same dtype), and, when
+ * codes / e8m0 are given (requires force_pow2, block_size % 32 == 0, pack_format = the QT_MX_* format the map rounds
+ * to), the packed operand for qt_mx_gemm.  force_pow2: scale = 2^(floor(log2 amax) - floor(log2 quant_max)) with the
+ * reference's in-dtype logarithm; otherwise scale = amax / quant_max [-> scale_lut].  block_size: power of two,
+ * 8..512 (bf16) / 4..256 (fp32), dividing cols. */
+int qt_quantize_mx_bf16(const uint16_t *x_dev, uint16_t *q_dev, uint16_t *scales_dev, uint8_t *codes_dev, uint8_t *e8m0_dev,
+                        size_t rows, size_t cols, int block_size, const qt_format *fmt, const uint16_t *lut_dev,
+                        float quant_max, int force_pow2, const uint16_t *scale_lut_dev, int pack_format, void *stream);
+int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint8_t *codes_dev, uint8_t *e8m0_dev,
+                       size_t rows, size_t cols, int block_size, const qt_format *fmt, const uint16_t *lut_dev,
+                       float quant_max, int force_pow2, const uint16_t *scale_lut_dev, int pack_format, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

@@ -17,6 +17,7 @@
 
 #include "../../include/qt_hip.h"
 #include "qt_formats.h"
+#include "qt_mx.h"
 
 namespace {
 
@@ -26,7 +27,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBM = 128, kBN = 128, kBK = 128;      // block tile (elements)
 
 __host__ __device__ constexpr int tile_row_bytes(int f) { return f < 2 ? 128 : (f < 4 ? 96 : 64); }
-__host__ __device__ constexpr int elem_bits(int f) { return f < 2 ? 8 : (f < 4 ? 6 : 4); }
+using qt_mx::elem_bits;
+using qt_mx::encode_elem;
 
 struct MxGemmArgs {
     const uint8_t *A, *B;        // packed codes [batch][M][K*bitsA/8], [batch][N][K*bitsB/8]
@@ -352,36 +354,6 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
 // ---- packing: (values, block scales) -> element codes + E8M0 ------------------------------------------------
 // A value that the format holds exactly converts exactly; anything else (and a scale that is not a power of
 // two) raises the `bad` flag so the caller can fall back to the dequantize + GEMM path.
-__device__ __forceinline__ uint32_t encode_elem(int f, float v, bool &bad) {
-    const uint32_t u = qt_f2u(v), s = u >> 31, au = u & 0x7FFFFFFFu;
-    const float m = qt_u2f(au);
-    const int E = (int)(au >> 23) - 127;
-    int ebits, mbits, bias;
-    float maxv;
-    switch (f) {
-        case 0: ebits = 4; mbits = 3; bias = 7; maxv = 448.f; break;
-        case 1: ebits = 5; mbits = 2; bias = 15; maxv = 57344.f; break;
-        case 2: ebits = 2; mbits = 3; bias = 1; maxv = 7.5f; break;
-        case 3: ebits = 3; mbits = 2; bias = 3; maxv = 28.f; break;
-        default: ebits = 2; mbits = 1; bias = 1; maxv = 6.f; break;
-    }
-    if (!(m <= maxv)) { bad = true; return 0; }          // also catches NaN
-    uint32_t code;
-    float back;
-    if (E < 1 - bias) {                                  // subnormal of the target: multiples of 2^(1 - bias - mbits)
-        const float q = m * qt_u2f((uint32_t)(127 - (1 - bias - mbits)) << 23);
-        code = (uint32_t)q;
-        back = (float)code * qt_u2f((uint32_t)(127 + (1 - bias - mbits)) << 23);
-    } else {
-        const uint32_t mant = (au >> (23 - mbits)) & ((1u << mbits) - 1u);
-        code = ((uint32_t)(E + bias) << mbits) | mant;
-        back = qt_u2f(au & ~((1u << (23 - mbits)) - 1u));
-    }
-    if (back != m) bad = true;
-    (void)ebits;
-    return code | (s << (ebits + mbits));
-}
-
 struct PackArgs {
     const void *x, *scale;       // values and block scales, bf16 or f32
     uint8_t *codes, *e8m0;

@@ -1,0 +1,220 @@
+// Fused quantize_mx for blocks along the last axis: one read of x, one write of the element values, the block
+// scales, and -- when the element format is one the matrix instruction takes -- the packed operand for qt_mx_gemm.
+//
+// Replaces   quantize_mx(input, qmap, axes=[-1], block_size, quant_max, force_scale_power_of_two, scale_qmap)
+//            decomposed.py:365-448  (calculate_mx_qparam: _reshape_to_blocks, _shared_exponents / amax, 2 ** e or
+//            amax / quant_max [+ scale map], where(scale > 0, scale, 1);  quantize: input / expand(scale) -> vmap)
+// which runs as a dozen elementwise / reduction passes in the reference, every op in the tensor's dtype.
+//
+// Shared exponent (mx_utils.py:19-55 with ebits = 0): floor(log2(amax + 2^-126 * (amax == 0))) with log2 evaluated
+// in the tensor's dtype -- for bf16 that is bf16(log2f(amax)), whose rounding can reach the next integer (e.g.
+// amax = 255 -> log2 = 7.994 -> bf16 8.0), so the floor is taken of the ROUNDED logarithm here as well.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/qt_hip.h"
+#include "qt_device.h"
+#include "qt_formats.h"
+#include "qt_mx.h"
+
+namespace {
+
+constexpr int kIoBf16 = 0, kIoF32 = 1;
+
+struct MxQuantArgs {
+    const uint4 *x;
+    uint4 *q;                 // element values, tensor dtype (NULL = not wanted)
+    void *sf;                 // block scales, tensor dtype, [rows][cols / bs]
+    uint8_t *codes, *e8m0;    // packed operand (NULL = not wanted)
+    size_t nvec;
+    int group;                // lanes per block
+    int lanes32;              // lanes per 32 elements (4 for bf16, 8 for fp32)
+    qt_format fmt;
+    const uint16_t *lut, *scale_lut;
+    float quant_max;
+    int qmax_exp;             // floor(log2(quant_max))
+    int pow2, pack_fmt;
+};
+
+// floor of log2(a) as the reference computes it in dtype IO; a > 0 finite
+template <int IO>
+__device__ __forceinline__ int floor_log2_dtype(float a) {
+    const float l = (float)log2((double)a);          // correctly rounded fp32 logarithm for all practical purposes
+    if constexpr (IO == kIoBf16) return (int)floorf(qt_u2f(pack_bf16x2(l, 0.0f) << 16));
+    return (int)floorf(l);
+}
+
+template <int IO>
+__global__ __launch_bounds__(256) void quantize_mx_kernel(MxQuantArgs a) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t iters = (a.nvec + stride - 1) / stride;
+    for (size_t it = 0; it < iters; ++it) {
+        const size_t v = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const bool live = v < a.nvec;
+        uint4 in = {0u, 0u, 0u, 0u};
+        if (live) in = a.x[v];
+        const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        uint32_t am = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (IO == kIoBf16) {
+                const uint32_t a0 = (w[j] << 16) & 0x7FFFFFFFu, a1 = w[j] & 0x7FFF0000u;
+                am = am > a0 ? am : a0;
+                am = am > a1 ? am : a1;
+            } else {
+                const uint32_t a0 = w[j] & 0x7FFFFFFFu;
+                am = am > a0 ? am : a0;
+            }
+        }
+        for (int off = 1; off < a.group; off <<= 1) {       // block amax over `group` adjacent lanes; NaN patterns win
+            const uint32_t o = (uint32_t)__shfl_xor((int)am, off, 64);
+            am = am > o ? am : o;
+        }
+        float s;
+        int se = 0;                                          // scale = 2^se when pow2 and representable
+        bool s_is_pow2 = false;
+        if (a.pow2) {
+            if (am > 0x7F800000u) s = 1.0f;                  // NaN: 2 ** NaN = NaN, where(NaN > 0) -> 1
+            else if (am == 0x7F800000u) s = qt_u2f(0x7F800000u);   // +Inf stays +Inf
+            else {
+                const float amax = am ? qt_u2f(am) : qt_u2f(0x00800000u);      // + FP32_MIN_NORMAL * (amax == 0)
+                se = floor_log2_dtype<IO>(amax) - a.qmax_exp;
+                const int lowest = IO == kIoBf16 ? -133 : -149;                 // smallest power of two of the dtype
+                if (se < lowest) s = 1.0f;                                      // 2 ** e underflows to 0 -> 1
+                else if (se > 127) s = qt_u2f(0x7F800000u);
+                else {
+                    s = se >= -126 ? qt_u2f((uint32_t)(se + 127) << 23) : qt_u2f(1u << (se + 149));
+                    s_is_pow2 = true;
+                }
+            }
+        } else {
+            s = qt_u2f(am) / a.quant_max;
+            if constexpr (IO == kIoBf16) s = qt_u2f(pack_bf16x2(s, 0.0f) << 16);
+            if (a.scale_lut) {
+                const uint32_t img = IO == kIoBf16 ? qt_f2u(s) : qt_fold_img(qt_f2u(s));
+                s = qt_bf2f(a.scale_lut[img >> 16]);
+            }
+            s = s > 0.0f ? s : 1.0f;
+        }
+        if (live && (threadIdx.x & (a.group - 1)) == 0) {
+            const size_t blk = v / (size_t)a.group;
+            if constexpr (IO == kIoBf16) ((uint16_t *)a.sf)[blk] = (uint16_t)(qt_f2u(s) >> 16);
+            else ((float *)a.sf)[blk] = s;
+        }
+        // element values: map[x / s], every op in the tensor dtype
+        const bool recip_ok = s_is_pow2 && se >= -126 && se <= 126;
+        const float r = recip_ok ? qt_u2f((uint32_t)(127 - se) << 23) : 0.0f;
+        constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+        float qv[kPer];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (IO == kIoBf16) {
+                const float x0 = qt_u2f(w[j] << 16), x1 = qt_u2f(w[j] & 0xFFFF0000u);
+                const uint32_t p = recip_ok ? pack_bf16x2(x0 * r, x1 * r) : pack_bf16x2(x0 / s, x1 / s);
+                const uint32_t i0 = p << 16, i1 = p & 0xFFFF0000u;
+                qv[2 * j] = qt_u2f(a.lut ? (uint32_t)a.lut[i0 >> 16] << 16 : qt_apply_format_img(a.fmt, i0));
+                qv[2 * j + 1] = qt_u2f(a.lut ? (uint32_t)a.lut[i1 >> 16] << 16 : qt_apply_format_img(a.fmt, i1));
+            } else {
+                const float x0 = qt_u2f(w[j]);
+                const uint32_t img = qt_fold_img(qt_f2u(recip_ok ? x0 * r : x0 / s));
+                qv[j] = qt_u2f(a.lut ? (uint32_t)a.lut[img >> 16] << 16 : qt_apply_format_img(a.fmt, img));
+            }
+        }
+        if (!live) continue;
+        if (a.q) {
+            uint4 o;
+            if constexpr (IO == kIoBf16) {
+                o.x = (qt_f2u(qv[0]) >> 16) | (qt_f2u(qv[1]) & 0xFFFF0000u);
+                o.y = (qt_f2u(qv[2]) >> 16) | (qt_f2u(qv[3]) & 0xFFFF0000u);
+                o.z = (qt_f2u(qv[4]) >> 16) | (qt_f2u(qv[5]) & 0xFFFF0000u);
+                o.w = (qt_f2u(qv[6]) >> 16) | (qt_f2u(qv[7]) & 0xFFFF0000u);
+            } else {
+                o.x = qt_f2u(qv[0]); o.y = qt_f2u(qv[1]); o.z = qt_f2u(qv[2]); o.w = qt_f2u(qv[3]);
+            }
+            a.q[v] = o;
+        }
+        if (a.codes) {
+            // E8M0 holds 2^-127 .. 2^127: a block whose scale is lower (|x| below ~1e-36) is flushed to zeros,
+            // an absolute error under 2^-119 per element; scale 1 from the where() guard is byte 127.
+            const bool flush = s_is_pow2 && se < -127;
+            const int bits = qt_mx::elem_bits(a.pack_fmt);
+            uint64_t acc = 0;
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                const uint32_t c = flush ? 0u : qt_mx::encode_elem(a.pack_fmt, qv[e], bad);
+                acc |= (uint64_t)c << (e * bits);
+            }
+            const int nbytes = kPer * bits / 8;                  // 8 / 6 / 4 (bf16) or 4 / 3 / 2 (fp32)
+            uint8_t *dst = a.codes + v * (size_t)nbytes;
+            if (nbytes == 8) *(uint2 *)dst = uint2{(uint32_t)acc, (uint32_t)(acc >> 32)};
+            else if (nbytes == 4) *(uint32_t *)dst = (uint32_t)acc;
+            else if (nbytes == 6) { ((uint16_t *)dst)[0] = (uint16_t)acc; ((uint16_t *)dst)[1] = (uint16_t)(acc >> 16); ((uint16_t *)dst)[2] = (uint16_t)(acc >> 32); }
+            else if (nbytes == 2) *(uint16_t *)dst = (uint16_t)acc;
+            else { dst[0] = (uint8_t)acc; dst[1] = (uint8_t)(acc >> 8); dst[2] = (uint8_t)(acc >> 16); }
+            if ((threadIdx.x & (a.lanes32 - 1)) == 0) {
+                int eb = s_is_pow2 ? se + 127 : 127;
+                eb = eb < 0 ? 0 : eb;
+                a.e8m0[v / (size_t)a.lanes32] = (uint8_t)eb;
+            }
+        }
+    }
+}
+
+int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int IO>
+int launch(const void *x, void *q, void *sf, uint8_t *codes, uint8_t *e8m0, size_t rows, size_t cols, int bs,
+           const qt_format *fmt, const uint16_t *lut, float quant_max, int pow2, const uint16_t *scale_lut, int pack_fmt,
+           void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    if (!x || !sf || !fmt || bs < kPer || (bs & (bs - 1)) || bs > 64 * kPer || !(quant_max > 0.0f)) return QT_ERR_BAD_ARG;
+    if (fmt->kind == QT_FMT_LUT && !lut) return QT_ERR_BAD_ARG;
+    if ((codes != nullptr) != (e8m0 != nullptr)) return QT_ERR_BAD_ARG;
+    if (codes && (pack_fmt < 0 || pack_fmt > 4 || bs % 32 != 0 || !pow2)) return QT_ERR_BAD_ARG;
+    if ((cols % (size_t)bs) || (((uintptr_t)x | (uintptr_t)q) & 15u)) return QT_ERR_UNALIGNED;
+    int qe = 0;
+    (void)frexpf(quant_max, &qe);                      // quant_max = m * 2^qe, m in [0.5, 1)  ->  floor(log2) = qe - 1
+    MxQuantArgs a{(const uint4 *)x, (uint4 *)q, sf, codes, e8m0, rows * cols / kPer, bs / kPer, 32 / kPer, *fmt,
+                  fmt->kind == QT_FMT_LUT ? lut : nullptr, scale_lut, quant_max, qe - 1, pow2, pack_fmt};
+    size_t want = (a.nvec + 255) / 256, cap = (size_t)num_cus() * 32;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    quantize_mx_kernel<IO><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_quantize_mx_bf16(const uint16_t *x, uint16_t *q, uint16_t *scales, uint8_t *codes, uint8_t *e8m0, size_t rows,
+                        size_t cols, int block_size, const qt_format *fmt, const uint16_t *lut, float quant_max,
+                        int force_pow2, const uint16_t *scale_lut, int pack_format, void *stream) {
+    return launch<kIoBf16>(x, q, scales, codes, e8m0, rows, cols, block_size, fmt, lut, quant_max, force_pow2, scale_lut,
+                           pack_format, stream);
+}
+
+int qt_quantize_mx_f32(const float *x, float *q, float *scales, uint8_t *codes, uint8_t *e8m0, size_t rows, size_t cols,
+                       int block_size, const qt_format *fmt, const uint16_t *lut, float quant_max, int force_pow2,
+                       const uint16_t *scale_lut, int pack_format, void *stream) {
+    return launch<kIoF32>(x, q, scales, codes, e8m0, rows, cols, block_size, fmt, lut, quant_max, force_pow2, scale_lut,
+                          pack_format, stream);
+}
+
+}  // extern "C"

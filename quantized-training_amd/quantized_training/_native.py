@@ -70,6 +70,8 @@ SIGNATURES = {
                                   _P, _P]),
     "qt_attention_fq_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
                                     _FMT, _P, _P, _P, _P]),
+    "qt_quantize_mx_bf16": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, c_int, _P, c_int, _P]),
+    "qt_quantize_mx_f32": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, c_int, _P, c_int, _P]),
     "qt_mx_pack": (c_int, [_P, _P, c_int, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_int,
                           c_int, _P, _P]),
     "qt_mx_gemm": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int, c_long, c_long, _P]),

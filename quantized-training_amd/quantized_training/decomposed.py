@@ -203,8 +203,55 @@ def _calculate_mx_qparam_impl(input, axes, block_size, quant_max, force_scale_po
     return scale
 
 
+def _quantize_mx_hip_or_none(input, qmap, axes, block_size, quant_max, pow2, scale_qmap):
+    """One fused device pass (qt_quantize_mx_*) for blocks along the last axis: values, scales and, for a format the
+    matrix instruction takes with power-of-two scales, the packed operand that linear_mx / matmul_mx consume."""
+    if input.device.type != "cuda" or input.dtype not in (torch.bfloat16, torch.float32) or input.dim() < 1:
+        return None
+    axes = [axes] if isinstance(axes, int) else list(axes)
+    if len(axes) != 1 or axes[0] % input.dim() != input.dim() - 1:
+        return None
+    per = 8 if input.dtype == torch.bfloat16 else 4
+    cols = input.shape[-1]
+    if (not isinstance(block_size, int) or block_size < per or block_size & (block_size - 1) or block_size > 64 * per
+            or cols == 0 or cols % block_size or input.numel() == 0 or not quant_max > 0):
+        return None
+    if qmap.dtype != torch.bfloat16 or qmap.numel() != 65536 or \
+            (scale_qmap is not None and (scale_qmap.dtype != torch.bfloat16 or scale_qmap.numel() != 65536)):
+        return None
+    from . import mx_gemm
+    L = _native.lib()
+    x = input.contiguous()
+    rows = x.numel() // cols
+    q = torch.empty_like(x)
+    sf = torch.empty(x.shape[:-1] + (cols // block_size,), dtype=x.dtype, device=x.device)
+    fmt_name = mx_gemm.format_of_qmap(qmap) if pow2 and block_size % 32 == 0 else None
+    codes = e8 = None
+    fid = -1
+    if fmt_name is not None and (cols * mx_gemm._BITS[mx_gemm.FMT_ID[fmt_name]] // 8) % 16 == 0:
+        fid = mx_gemm.FMT_ID[fmt_name]
+        codes = torch.empty((rows, cols * mx_gemm._BITS[fid] // 8), dtype=torch.uint8, device=x.device)
+        e8 = torch.empty((rows, cols // 32), dtype=torch.uint8, device=x.device)
+    fmt = _lut_format()
+    fn = L.qt_quantize_mx_bf16 if x.dtype == torch.bfloat16 else L.qt_quantize_mx_f32
+    _native.check(fn(x.data_ptr(), q.data_ptr(), sf.data_ptr(), codes.data_ptr() if codes is not None else None,
+                     e8.data_ptr() if e8 is not None else None, rows, cols, block_size, ctypes.byref(fmt), qmap.data_ptr(),
+                     float(quant_max), int(bool(pow2)), scale_qmap.data_ptr() if scale_qmap is not None else None, fid,
+                     _stream_ptr(x)), "qt_quantize_mx")
+    if pow2:
+        sf._qt_pow2 = True
+        if fmt_name is not None:
+            q._qt_mx_fmt = fmt_name
+        if codes is not None:
+            q._qt_mx_packed_act = (fid, block_size, codes, e8)
+    return sf, q
+
+
 def _quantize_mx_impl(input, qmap, axes, block_size, quant_max, force_scale_power_of_two=False, scale_qmap=None,
                       output_code=None):
+    fused = _quantize_mx_hip_or_none(input, qmap, axes, block_size, quant_max, force_scale_power_of_two, scale_qmap)
+    if fused is not None:
+        return fused
     scale = torch.ops.quantized_ops.calculate_mx_qparam(input, axes, block_size, quant_max, force_scale_power_of_two,
                                                         scale_qmap)
     q = torch.ops.quantized_ops.quantize(input, scale, None, axes, block_size, qmap)

@@ -138,9 +138,13 @@ def mx_linear_or_none(input, weight, bias, input_scale, weight_scale, block_size
     if wop is None or (fid, wop[0]) not in _PAIRS or (K * _BITS[fid] // 8) % 16:
         return _fallback(f"weight operand {None if wop is None else wop[0]} with input format {fid}, K = {K}")
     x = input.contiguous()
-    s = input_scale.contiguous()
     M = x.numel() // K
-    a_codes, a_e8 = _pack(x, s, fid, block_size, 1, M, K, (0, K, 1), (0, s.shape[-1], 1), check=False)
+    pre = getattr(input, "_qt_mx_packed_act", None)          # quantize_mx already emitted the packed operand
+    if pre is not None and pre[0] == fid and pre[1] == block_size and pre[2].shape == (M, K * _BITS[fid] // 8):
+        a_codes, a_e8 = pre[2], pre[3]
+    else:
+        s = input_scale.contiguous()
+        a_codes, a_e8 = _pack(x, s, fid, block_size, 1, M, K, (0, K, 1), (0, s.shape[-1], 1), check=False)
     out = torch.empty(input.shape[:-1] + (N,), dtype=input.dtype, device=input.device)
     b = bias.to(input.dtype).contiguous() if bias is not None else None
     L = _native.lib()
@@ -175,7 +179,11 @@ def mx_matmul_or_none(a, b, a_scale, b_scale, block_size, a_code, b_code):
         return _fallback("batch > 65535")
     a3, sa3 = a.contiguous().view(batch, M, K), a_scale.contiguous().view(batch, M, K // block_size)
     b3, sb3 = b.contiguous().view(batch, K, N), b_scale.contiguous().view(batch, K // block_size, N)
-    pa = _pack(a3, sa3, fia, block_size, batch, M, K, (M * K, K, 1), (sa3.stride(0), sa3.stride(1), 1), check=False)
+    pre = getattr(a, "_qt_mx_packed_act", None)
+    if pre is not None and pre[0] == fia and pre[1] == block_size and pre[2].shape == (batch * M, K * _BITS[fia] // 8):
+        pa = (pre[2], pre[3])
+    else:
+        pa = _pack(a3, sa3, fia, block_size, batch, M, K, (M * K, K, 1), (sa3.stride(0), sa3.stride(1), 1), check=False)
     # second operand: logical rows are b's columns (stride 1), k walks b's rows (stride N)
     pb = _pack(b3, sb3, fib, block_size, batch, N, K, (K * N, 1, N), (sb3.stride(0), 1, sb3.stride(1)), check=False)
     out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)

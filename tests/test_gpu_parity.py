@@ -805,3 +805,76 @@ def test_mx_gemm_batched_and_transposed_operand(nv):
                           M, N, stream()), "qt_mx_gemm")
     ref = torch.matmul((qa * sa.repeat_interleave(32, -1)).float(), (qb * sb.repeat_interleave(32, -2)).float())
     assert torch.allclose(c.float(), ref, rtol=2.0 ** -7, atol=1e-3)
+
+
+# ---- fused quantize_mx (qt_quantize_mx_*) against the composite formulation on CPU tensors ------------------------
+# The CPU ops are the reference's own sequence of torch calls (decomposed.py:365-448), pinned bit-exactly by the PT2E
+# microscaling goldens (tests/test_pt2e_cpu.py).
+def _quantize_mx_cpu(x, dtype_name, block, qmax, pow2, scale_dtype=None):
+    from quantized_training.fake_quantize import get_quantization_map
+    qmap = get_quantization_map(dtype_name, "cpu")
+    smap = get_quantization_map(scale_dtype, "cpu") if scale_dtype else None
+    xc = x.cpu()
+    s = torch.ops.quantized_ops.calculate_mx_qparam(xc, [-1], block, qmax, pow2, smap)
+    q = torch.ops.quantized_ops.quantize(xc, s, None, [-1], block, qmap)
+    return s, q
+
+
+def _same_bits(a, b):
+    a, b = a.cpu().contiguous(), b.cpu().contiguous()
+    if a.dtype == torch.bfloat16:
+        ua, ub = a.view(torch.int16).numpy().view(np.uint16), b.view(torch.int16).numpy().view(np.uint16)
+        na, nb = (ua & 0x7FFF) > 0x7F80, (ub & 0x7FFF) > 0x7F80
+    else:
+        ua, ub = a.view(torch.int32).numpy().view(np.uint32), b.view(torch.int32).numpy().view(np.uint32)
+        na, nb = (ua & 0x7FFFFFFF) > 0x7F800000, (ub & 0x7FFFFFFF) > 0x7F800000
+    return bool(np.array_equal(na, nb) and np.array_equal(ua[~na], ub[~nb]))
+
+
+@pytest.mark.parametrize("dtype_name", ["fp8_e4m3", "fp6_e3m2", "fp4_e2m1", "int8", "fp8_e5m2"])
+@pytest.mark.parametrize("tdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("pow2", [True, False])
+def test_quantize_mx_fused_matches_composite(nv, dtype_name, tdtype, pow2):
+    from quantized_training.fake_quantize import get_quantization_map
+    from quantized_training.quantizer.quantizer import get_quant_min_max
+    qmax = float(get_quant_min_max(dtype_name)[1])
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(64, 256, generator=g) * torch.exp2(torch.randint(-20, 20, (64, 1), generator=g).float())
+    x[3, :64] = 0.0                                   # an all-zero block
+    x[4, 5] = 255.0; x[5, 7] = 0.998; x[6, 0] = 2.0 ** -126; x[7, 1] = 3.0e38      # logarithm-rounding and range edges
+    x[8, 2] = float("inf"); x[9, 3] = float("nan"); x[10, 4] = -float("inf")
+    x = x.to(tdtype)
+    for block in (32, 64, 16):
+        s_ref, q_ref = _quantize_mx_cpu(x, dtype_name, block, qmax, pow2)
+        qmap = get_quantization_map(dtype_name, "cuda")
+        s, q = torch.ops.quantized_ops.quantize_mx(x.cuda(), qmap, [-1], block, qmax, pow2, None, None)
+        assert _same_bits(s, s_ref), (dtype_name, block)
+        assert _same_bits(q, q_ref), (dtype_name, block)
+        if pow2 and block % 32 == 0 and dtype_name in MX_FMT_ID:
+            fid, bs, codes, e8 = q._qt_mx_packed_act
+            finite = torch.isfinite(q_ref).all(dim=-1) & torch.isfinite(s_ref).all(dim=-1) & (s_ref.float() >= 2.0 ** -127).all(dim=-1)
+            rows = torch.nonzero(finite).flatten().numpy()
+            want_codes, want_e8 = o.mx_pack(q_ref.float().numpy()[rows], s_ref.float().numpy()[rows], dtype_name, block)
+            assert np.array_equal(codes.cpu().numpy()[rows], want_codes)
+            assert np.array_equal(e8.cpu().numpy()[rows], want_e8)
+
+
+def test_quantize_mx_shared_exponent_for_every_bf16_amax(nv):
+    """floor(log2(amax)) is taken of the bf16-ROUNDED logarithm in the reference; every positive finite bf16 amax."""
+    from quantized_training.fake_quantize import get_quantization_map
+    pats = np.arange(1, 0x7F80, dtype=np.uint16)
+    x = torch.zeros(len(pats), 32, dtype=torch.bfloat16)
+    x[:, 0] = torch.from_numpy(pats.view(np.int16)).view(torch.bfloat16)
+    s_ref, q_ref = _quantize_mx_cpu(x, "fp8_e4m3", 32, 448.0, True)
+    s, q = torch.ops.quantized_ops.quantize_mx(x.cuda(), get_quantization_map("fp8_e4m3", "cuda"), [-1], 32, 448.0, True, None, None)
+    assert _same_bits(s, s_ref)
+    assert _same_bits(q, q_ref)
+
+
+def test_quantize_mx_with_scale_map(nv):
+    from quantized_training.fake_quantize import get_quantization_map
+    x = (torch.randn(32, 128, generator=torch.Generator().manual_seed(2)) * 3).bfloat16()
+    s_ref, q_ref = _quantize_mx_cpu(x, "fp4_e2m1", 16, 6.0, False, scale_dtype="fp8_e4m3")
+    s, q = torch.ops.quantized_ops.quantize_mx(x.cuda(), get_quantization_map("fp4_e2m1", "cuda"), [-1], 16, 6.0, False,
+                                               get_quantization_map("fp8_e4m3", "cuda"), None)
+    assert _same_bits(s, s_ref) and _same_bits(q, q_ref)
