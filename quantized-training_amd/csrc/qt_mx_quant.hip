@@ -17,6 +17,7 @@
 #include "qt_device.h"
 #include "qt_formats.h"
 #include "qt_mx.h"
+#include "qt_mx_log2_tables.h"
 
 namespace {
 
@@ -37,20 +38,48 @@ struct MxQuantArgs {
     int pow2, pack_fmt;
 };
 
-// floor of log2(a) as the reference computes it in dtype IO; a > 0 finite
+// floor of log2(a) as the reference computes it in dtype IO (a > 0 finite, given as its fp32 bit image): the exponent,
+// plus one when the mantissa is high enough for the dtype-rounded logarithm to reach the next integer
+// (thresholds: qt_mx_log2_tables.h, generated from torch's own CPU log2 by tools/gen_mx_log2_tables.py).
 template <int IO>
-__device__ __forceinline__ int floor_log2_dtype(float a) {
-    const float l = (float)log2((double)a);          // correctly rounded fp32 logarithm for all practical purposes
-    if constexpr (IO == kIoBf16) return (int)floorf(qt_u2f(pack_bf16x2(l, 0.0f) << 16));
-    return (int)floorf(l);
+__device__ __forceinline__ int floor_log2_dtype(uint32_t au) {
+    const uint32_t E = au >> 23, M = au & 0x7FFFFFu;
+    int e;
+    uint32_t mn;
+    if (E) { e = (int)E - 127; mn = M; }
+    else { const int p = 31 - __clz((int)M); e = p - 149; mn = (M << (23 - p)) & 0x7FFFFFu; }
+    const uint32_t thr = (IO == kIoBf16 ? kMxLog2ThrBf16 : kMxLog2ThrF32)[e + 1 - kMxLog2Lo];
+    return e + (mn >= thr ? 1 : 0);
 }
 
-template <int IO>
-__global__ __launch_bounds__(256) void quantize_mx_kernel(MxQuantArgs a) {
-    const size_t stride = (size_t)gridDim.x * 256;
+// LDS_TABLE: the 128 KiB value map is staged in LDS once per workgroup (one 1024-thread workgroup per CU), so the
+// per-element lookups are LDS reads instead of L2 gathers; worth it from a few million elements up.
+// value (exactly representable in the target format) -> element code; mbits / bias / ebits of the target at run time
+__device__ __forceinline__ uint32_t encode_exact(float v, int ebits, int mbits, int bias) {
+    const uint32_t u = qt_f2u(v), au = u & 0x7FFFFFFFu;
+    const int E = (int)(au >> 23) - 127;
+    const uint32_t normal = ((uint32_t)(E + bias) << mbits) | ((au >> (23 - mbits)) & ((1u << mbits) - 1u));
+    const uint32_t sub = (uint32_t)(qt_u2f(au) * qt_u2f((uint32_t)(127 + bias - 1 + mbits) << 23));     // multiples of 2^(1 - bias - mbits)
+    return (E >= 1 - bias ? normal : sub) | ((u >> 31) << (ebits + mbits));
+}
+
+// PACK_BITS: 0 = no packed operand, else the element width (8 / 6 / 4) -- compile-time so the packing is straight-line.
+template <int IO, bool LDS_TABLE, int PACK_BITS>
+__global__ __launch_bounds__(LDS_TABLE ? 1024 : 256) void quantize_mx_kernel(MxQuantArgs a) {
+    constexpr int kThreads = LDS_TABLE ? 1024 : 256;
+    if constexpr (LDS_TABLE) {
+        extern __shared__ __attribute__((aligned(16))) uint16_t s_table[];
+        const uint4 *src = (const uint4 *)a.lut;
+        uint4 *dst = (uint4 *)s_table;
+#pragma unroll
+        for (int i = 0; i < 65536 * 2 / 16 / kThreads; ++i) dst[threadIdx.x + i * kThreads] = src[threadIdx.x + i * kThreads];
+        __syncthreads();
+        a.lut = s_table;
+    }
+    const size_t stride = (size_t)gridDim.x * kThreads;
     const size_t iters = (a.nvec + stride - 1) / stride;
     for (size_t it = 0; it < iters; ++it) {
-        const size_t v = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t v = it * stride + (size_t)blockIdx.x * kThreads + threadIdx.x;
         const bool live = v < a.nvec;
         uint4 in = {0u, 0u, 0u, 0u};
         if (live) in = a.x[v];
@@ -78,8 +107,7 @@ __global__ __launch_bounds__(256) void quantize_mx_kernel(MxQuantArgs a) {
             if (am > 0x7F800000u) s = 1.0f;                  // NaN: 2 ** NaN = NaN, where(NaN > 0) -> 1
             else if (am == 0x7F800000u) s = qt_u2f(0x7F800000u);   // +Inf stays +Inf
             else {
-                const float amax = am ? qt_u2f(am) : qt_u2f(0x00800000u);      // + FP32_MIN_NORMAL * (amax == 0)
-                se = floor_log2_dtype<IO>(amax) - a.qmax_exp;
+                se = floor_log2_dtype<IO>(am ? am : 0x00800000u) - a.qmax_exp;   // + FP32_MIN_NORMAL * (amax == 0)
                 const int lowest = IO == kIoBf16 ? -133 : -149;                 // smallest power of two of the dtype
                 if (se < lowest) s = 1.0f;                                      // 2 ** e underflows to 0 -> 1
                 else if (se > 127) s = qt_u2f(0x7F800000u);
@@ -134,25 +162,38 @@ __global__ __launch_bounds__(256) void quantize_mx_kernel(MxQuantArgs a) {
             }
             a.q[v] = o;
         }
-        if (a.codes) {
+        if constexpr (PACK_BITS != 0) {
             // E8M0 holds 2^-127 .. 2^127: a block whose scale is lower (|x| below ~1e-36) is flushed to zeros,
             // an absolute error under 2^-119 per element; scale 1 from the where() guard is byte 127.
             const bool flush = s_is_pow2 && se < -127;
-            const int bits = qt_mx::elem_bits(a.pack_fmt);
-            uint64_t acc = 0;
-            bool bad = false;
+            const int f = a.pack_fmt;
+            const int ebits = PACK_BITS == 8 ? (f == 0 ? 4 : 5) : (PACK_BITS == 6 ? (f == 2 ? 2 : 3) : 2);
+            const int mbits = PACK_BITS - 1 - ebits;
+            const int bias = (1 << (ebits - 1)) - 1;
+            uint32_t c[kPer];
 #pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                const uint32_t c = flush ? 0u : qt_mx::encode_elem(a.pack_fmt, qv[e], bad);
-                acc |= (uint64_t)c << (e * bits);
-            }
-            const int nbytes = kPer * bits / 8;                  // 8 / 6 / 4 (bf16) or 4 / 3 / 2 (fp32)
+            for (int e = 0; e < kPer; ++e) c[e] = flush ? 0u : encode_exact(qv[e], ebits, mbits, bias);
+            constexpr int nbytes = kPer * PACK_BITS / 8;         // 8 / 6 / 4 (bf16) or 4 / 3 / 2 (fp32)
             uint8_t *dst = a.codes + v * (size_t)nbytes;
-            if (nbytes == 8) *(uint2 *)dst = uint2{(uint32_t)acc, (uint32_t)(acc >> 32)};
-            else if (nbytes == 4) *(uint32_t *)dst = (uint32_t)acc;
-            else if (nbytes == 6) { ((uint16_t *)dst)[0] = (uint16_t)acc; ((uint16_t *)dst)[1] = (uint16_t)(acc >> 16); ((uint16_t *)dst)[2] = (uint16_t)(acc >> 32); }
-            else if (nbytes == 2) *(uint16_t *)dst = (uint16_t)acc;
-            else { dst[0] = (uint8_t)acc; dst[1] = (uint8_t)(acc >> 8); dst[2] = (uint8_t)(acc >> 16); }
+            if constexpr (PACK_BITS == 8) {
+                const uint32_t lo = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+                if constexpr (kPer == 8) *(uint2 *)dst = uint2{lo, c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24)};
+                else *(uint32_t *)dst = lo;
+            } else if constexpr (PACK_BITS == 4) {
+                const uint32_t lo = c[0] | (c[1] << 4) | (c[2] << 8) | (c[3] << 12);
+                if constexpr (kPer == 8) *(uint32_t *)dst = lo | (c[4] << 16) | (c[5] << 20) | (c[6] << 24) | (c[7] << 28);
+                else *(uint16_t *)dst = (uint16_t)lo;
+            } else {
+                const uint32_t lo = c[0] | (c[1] << 6) | (c[2] << 12) | (c[3] << 18);       // 24 bits
+                if constexpr (kPer == 8) {
+                    const uint32_t hi = c[4] | (c[5] << 6) | (c[6] << 12) | (c[7] << 18);
+                    ((uint16_t *)dst)[0] = (uint16_t)lo;
+                    ((uint16_t *)dst)[1] = (uint16_t)((lo >> 16) | (hi << 8));
+                    ((uint16_t *)dst)[2] = (uint16_t)(hi >> 8);
+                } else {
+                    dst[0] = (uint8_t)lo; dst[1] = (uint8_t)(lo >> 8); dst[2] = (uint8_t)(lo >> 16);
+                }
+            }
             if ((threadIdx.x & (a.lanes32 - 1)) == 0) {
                 int eb = s_is_pow2 ? se + 127 : 127;
                 eb = eb < 0 ? 0 : eb;
@@ -193,10 +234,29 @@ int launch(const void *x, void *q, void *sf, uint8_t *codes, uint8_t *e8m0, size
     (void)frexpf(quant_max, &qe);                      // quant_max = m * 2^qe, m in [0.5, 1)  ->  floor(log2) = qe - 1
     MxQuantArgs a{(const uint4 *)x, (uint4 *)q, sf, codes, e8m0, rows * cols / kPer, bs / kPer, 32 / kPer, *fmt,
                   fmt->kind == QT_FMT_LUT ? lut : nullptr, scale_lut, quant_max, qe - 1, pow2, pack_fmt};
-    size_t want = (a.nvec + 255) / 256, cap = (size_t)num_cus() * 32;
-    const unsigned grid = (unsigned)(want < cap ? want : cap);
-    quantize_mx_kernel<IO><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-    return launch_status();
+    const int pb = codes ? qt_mx::elem_bits(pack_fmt) : 0;
+    const bool lds = a.lut && rows * cols >= ((size_t)1 << 22) && (((uintptr_t)a.lut) & 15u) == 0;
+    hipStream_t st = (hipStream_t)stream;
+#define QT_MXQ(PB)                                                                                                 \
+    if (pb == PB) {                                                                                                \
+        if (lds) {                                                                                                 \
+            static bool configured = false;                                                                        \
+            if (!configured) {                                                                                     \
+                const hipError_t e = hipFuncSetAttribute((const void *)quantize_mx_kernel<IO, true, PB>,           \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2);   \
+                if (e != hipSuccess) return (int)e;                                                                \
+                configured = true;                                                                                 \
+            }                                                                                                      \
+            quantize_mx_kernel<IO, true, PB><<<(unsigned)num_cus(), 1024, 65536 * 2, st>>>(a);                     \
+        } else {                                                                                                   \
+            size_t want = (a.nvec + 255) / 256, cap = (size_t)num_cus() * 32;                                      \
+            quantize_mx_kernel<IO, false, PB><<<(unsigned)(want < cap ? want : cap), 256, 0, st>>>(a);             \
+        }                                                                                                          \
+        return launch_status();                                                                                    \
+    }
+    QT_MXQ(0) QT_MXQ(8) QT_MXQ(6) QT_MXQ(4)
+#undef QT_MXQ
+    return QT_ERR_BAD_ARG;
 }
 
 }  // namespace
