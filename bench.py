@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--activation", default="e4m3")
     ap.add_argument("--weight", default="e4m3")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--cache-eval-weights", action="store_true",
+                    help="side experiment (line marked invalid): keep fq(W) across windows instead of re-quantizing, "
+                         "which the reference does not do")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -134,6 +137,9 @@ def main():
     qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--bf16",
                                             "--quantize_forward", "gemm"])
     qt.quantize(model, qargs)
+    if a.cache_eval_weights:
+        model.eval()
+        harness.cache_quantized_weights(True)
 
     vocab = model.config.vocab_size
     gen = torch.Generator().manual_seed(0)
@@ -209,11 +215,12 @@ def main():
             "config": {"workload": f"{a.model}-shaped LLaMA ({layers} layers, hidden {hidden}, random init) "
                                    f"WikiText-style window eval B=1 S={a.max_length} stride {a.stride}, "
                                    f"fake-quant activation={a.activation} weight={a.weight}, --quantize_forward gemm "
-                                   f"(weights re-quantized every forward)",
+                                   + ("(weights re-quantized every forward)" if not a.cache_eval_weights
+                                      else "(EXPERIMENT: quantized weights cached across windows)"),
                        "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
                        "launch": "hipGraph replay" if graph_used else "eager",
-                       "valid": bool(full)},
+                       "valid": bool(full) and not a.cache_eval_weights},
             "mean_window_nll": float(allnll.double().mean().item()),
         }
     if rank == 0 and world == 1:

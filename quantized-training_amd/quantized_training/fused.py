@@ -121,6 +121,36 @@ def prefetch_enabled():
     return os.environ.get("QT_WEIGHT_PREFETCH", "0") == "1"
 
 
+_WEIGHT_CACHE = {"on": os.environ.get("QT_CACHE_EVAL_WEIGHTS", "0") == "1", "epoch": 0}
+
+
+def cache_quantized_weights(enable: bool = True):
+    """Opt-in: in eval mode, with the weight fake-quantizer's observer off (stateless spec or frozen
+    after calibration), fq(W) is a constant -- keep it instead of re-quantizing W on every forward.  Off by default
+    because the reference re-quantizes every time (and the headline metric counts those elements).  Entries follow
+    the tensors' version counters (optimizer steps, load_state_dict, in-place ops); a write through `.data` is not
+    visible to them -- call this function again to drop every entry."""
+    _WEIGHT_CACHE["on"] = bool(enable)
+    _WEIGHT_CACHE["epoch"] += 1
+
+
+def cached_weight(layer, kind, make):
+    """make() -> quantized weight; cached on the layer while nothing it depends on changes."""
+    fq = layer.weight_fake_quant
+    W = layer.weight
+    if (not _WEIGHT_CACHE["on"] or layer.training or getattr(fq, "_observe", True)
+            or (torch.is_grad_enabled() and W.requires_grad)):
+        return make()
+    key = (kind, _WEIGHT_CACHE["epoch"], W.data_ptr(), W._version, fq.scale._version, bool(getattr(fq, "_quantize", True)),
+           str(W.device))
+    hit = layer.__dict__.get("_qt_wcache")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = make()
+    layer.__dict__["_qt_wcache"] = (key, w)
+    return w
+
+
 def fp8_linear_or_none(layer, x):
     """E4M3 / E5M2 fake-quant Linear with scale 1 on the FP8 matrix cores: the activation pass already
     produced FP8 bytes (x._qt_fp8), the weight pass writes FP8 only (3 B/element of traffic instead of
@@ -140,7 +170,6 @@ def fp8_linear_or_none(layer, x):
     if layer.bias is not None and layer.bias.dtype != torch.bfloat16:
         return None
     fq._move_to(x.device)
-    STATS.add(W.numel())
     pf = _PREFETCH if prefetch_enabled() else None
     slot = None
     w8 = None
@@ -150,10 +179,14 @@ def fp8_linear_or_none(layer, x):
         if ready is not None:
             w8, done, slot = ready
             torch.cuda.current_stream(x.device).wait_event(done)       # join
+            STATS.add(W.numel())
     if w8 is None:
-        w8 = FusedAmaxObsFakeQuantFunction.apply(W.detach(), False, True, fq.qmap, fq.amax_history, fq.scale,
-                                                 fq.amax_history_len, fq.quant_max, None, False, False,
-                                                 fq._qt_format, "only")
+        def make():
+            STATS.add(W.numel())
+            return FusedAmaxObsFakeQuantFunction.apply(W.detach(), False, True, fq.qmap, fq.amax_history, fq.scale,
+                                                       fq.amax_history_len, fq.quant_max, None, False, False,
+                                                       fq._qt_format, "only")
+        w8 = cached_weight(layer, "fp8", make)
     one = _one(x.device)
     x2 = x8.reshape(-1, K)
     y = torch._scaled_mm(x2, w8.t(), scale_a=one, scale_b=one, bias=layer.bias, out_dtype=torch.bfloat16)

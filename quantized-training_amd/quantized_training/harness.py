@@ -16,8 +16,8 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["wikitext_windows", "shard_round_robin", "window_nll", "evaluate_perplexity", "gather_in_order", "GraphedWindow",
-           "collect_qa_logits", "train_steps",
-           "build_causal_lm", "LLAMA_SHAPES"]
+           "collect_qa_logits", "train_steps", "calibrate", "freeze_observers", "save_checkpoint", "load_checkpoint",
+           "cache_quantized_weights", "build_causal_lm", "LLAMA_SHAPES"]
 
 
 def wikitext_windows(seq_len: int, max_length: int, stride: int) -> List[Tuple[int, int, int]]:
@@ -244,3 +244,59 @@ def train_steps(model, batches, optimizer, lr_scheduler=None, max_grad_norm: flo
                 lr_scheduler.step()
             optimizer.zero_grad()
     return losses
+
+
+# ---- calibration flow and checkpoints (upstream examples/question_answering/run_qa_no_trainer.py:826-847, 961-990) ----
+def calibrate(model, batches, steps: int, device=None):
+    """Run `steps` forward passes in eval / no_grad so the delayed-scaling observers fill their amax histories, then
+    freeze every observer (the reference's `calibrate()` + `disable_observer()` loop, :834-847).  `batches` yields
+    dicts of tensors (a HF dataloader) or plain input-id tensors.  Returns the number of batches consumed."""
+    was_training = model.training
+    model.eval()
+    n = 0
+    with torch.no_grad():
+        for batch in batches:
+            if n >= steps:
+                break
+            if isinstance(batch, dict):
+                model(**{k: (v.to(device) if device is not None else v) for k, v in batch.items()})
+            else:
+                model(batch.to(device) if device is not None else batch)
+            n += 1
+    freeze_observers(model)
+    model.train(was_training)
+    return n
+
+
+def freeze_observers(model):
+    """`module.disable_observer()` on every fake-quantizer: scales stay at their calibrated values."""
+    for m in model.modules():
+        if isinstance(m, torch.ao.quantization.FakeQuantizeBase):
+            m.disable_observer()
+
+
+def save_checkpoint(path, model, optimizer=None, lr_scheduler=None, best_metric=None, run_id=None):
+    """`checkpoint.tar` with the reference's keys (:975-981), so either side can resume the other's runs."""
+    torch.save({"model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict() if optimizer is not None else None,
+                "scheduler_state_dict": lr_scheduler.state_dict() if lr_scheduler is not None else None,
+                "best_metric": best_metric, "run_id": run_id}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, map_location=None):
+    """Counterpart of the reference's `load_state` (:985-990).  Lazily sized fake-quant buffers (`amax_history`,
+    `scale`) take the checkpoint's shapes (fake_quantize.py:406-435); per-argument fake-quantizers that only exist
+    after a first forward must have been created (run one batch first, as the reference does at :826-832)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ckpt["model_state_dict"])
+    if optimizer is not None and ckpt.get("optimizer_state_dict") is not None:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    if lr_scheduler is not None and ckpt.get("scheduler_state_dict") is not None:
+        lr_scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+    return ckpt
+
+
+def cache_quantized_weights(enable: bool = True):
+    """Opt-in eval optimisation: keep fq(W) of every QAT Linear while its inputs cannot change (see fused.py)."""
+    from . import fused
+    fused.cache_quantized_weights(enable)

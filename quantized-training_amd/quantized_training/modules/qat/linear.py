@@ -28,11 +28,12 @@ class Linear(nn.Linear):
         self.weight_fake_quant = qconfig.weight(factory_kwargs={"device": fq_device, "dtype": dtype})
 
     def forward(self, input):
-        from ...fused import fused_linear_or_none
+        from ...fused import cached_weight, fused_linear_or_none
         out = fused_linear_or_none(self, input)
         if out is not None:
             return out
-        return F.linear(input, self.weight_fake_quant(self.weight), self.bias)
+        # (opt-in) in eval with a frozen / stateless weight fake-quantizer the quantized weight is kept, see fused.py
+        return F.linear(input, cached_weight(self, "dense", lambda: self.weight_fake_quant(self.weight)), self.bias)
 
     @classmethod
     def from_float(cls, mod):

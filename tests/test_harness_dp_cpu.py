@@ -143,3 +143,84 @@ def test_glue_style_training_loop_with_quantized_backward():
     assert fq.dtype == "fp8_e5m2" and float(fq.amax_history.max()) > 0 and float(fq.scale) != 1.0
     assert "roberta.encoder.layer.0.attention.self.query.error_post_process.0" in mods       # residual-feeding layer
     assert "roberta.encoder.layer.0.output.residual.error_post_process.0" in mods
+
+
+# ---- calibration flow, checkpoints, eval weight cache ---------------------------------------------
+def _toy_qat(seed=0):
+    import quantized_training as qt
+    torch.manual_seed(seed)
+    m = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+    args = qt.add_qspec_args().parse_args(["--activation", "int8,qs=per_tensor_symmetric,ahl=4",
+                                           "--weight", "int8,qs=per_tensor_symmetric,ahl=4"])
+    qt.quantize(m, args)
+    return m
+
+
+def _scales(m):
+    return {k: v.clone() for k, v in m.state_dict().items() if k.endswith(".scale")}
+
+
+def test_calibrate_then_observers_are_frozen():
+    from quantized_training import harness
+    m = _toy_qat()
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randn(4, 16, generator=g) * (i + 1) for i in range(6)]
+    assert harness.calibrate(m, batches, steps=4) == 4
+    for mod in m.modules():
+        if isinstance(mod, torch.ao.quantization.FakeQuantizeBase):
+            assert int(mod.observer_enabled[0]) == 0 and int(mod.fake_quant_enabled[0]) == 1
+    before = _scales(m)
+    assert any(float(v) != 1.0 for v in before.values())          # calibration moved the scales
+    with torch.no_grad():
+        m(batches[5] * 100)
+    after = _scales(m)
+    assert all(torch.equal(before[k], after[k]) for k in before)   # ... and they no longer follow the data
+
+
+def test_checkpoint_round_trip_restores_lazy_fake_quant_state(tmp_path):
+    from quantized_training import harness
+    m = _toy_qat()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(3))
+    for _ in range(3):
+        m(x).sum().backward(); opt.step(); opt.zero_grad()
+    path = str(tmp_path / "checkpoint.tar")
+    harness.save_checkpoint(path, m, opt, best_metric={"f1": 1.0})
+    want = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = _toy_qat(seed=5)
+    m2(x)                                                            # creates the per-argument fake-quantizers
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3)
+    ck = harness.load_checkpoint(path, m2, opt2)
+    assert sorted(ck) == ["best_metric", "model_state_dict", "optimizer_state_dict", "run_id", "scheduler_state_dict"]
+    got = m2.state_dict()
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), k
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m2(x))
+
+
+def test_eval_weight_cache_is_bit_identical_and_skips_the_weight_pass():
+    from quantized_training import harness
+    from quantized_training.fake_quantize import STATS
+    m = _toy_qat()
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(7))
+    harness.calibrate(m, [x, 2 * x], steps=2)
+    m.eval()
+    with torch.no_grad():
+        STATS.reset(); y0 = m(x); full = STATS.elements
+        harness.cache_quantized_weights(True)
+        try:
+            m(x)
+            STATS.reset(); y1 = m(x); cached = STATS.elements
+            assert torch.equal(y0, y1)
+            assert cached == full - sum(mod.weight.numel() for mod in m.modules() if hasattr(mod, "weight_fake_quant"))
+            m[0].weight.mul_(2.0)                                   # an in-place update invalidates the entry
+            STATS.reset(); y2 = m(x)
+            assert STATS.elements == cached + m[0].weight.numel() and not torch.equal(y2, y1)
+            m.train()                                               # training always re-quantizes
+            STATS.reset(); m(x)
+            assert STATS.elements == full
+        finally:
+            harness.cache_quantized_weights(False)
