@@ -25,7 +25,7 @@ def _llama(device, dtype):
 TOK = torch.randint(0, 512, (1, 1300), generator=torch.Generator().manual_seed(5))
 
 
-@pytest.mark.parametrize("spec", ["e4m3", "posit8_1", "int8,qs=per_tensor_symmetric"])
+@pytest.mark.parametrize("spec", ["e4m3", "posit8_1", "posit8_2", "int8,qs=per_tensor_symmetric"])
 def test_perplexity_parity_fp32(spec):
     """fp32 model: fake-quant is bit-exact on both sides; the fp32 GEMMs differ by accumulation order
     (~1e-6), which occasionally flips an element across a rounding boundary.  Bar: the north star's +-0.01
@@ -161,3 +161,35 @@ def test_pt2e_microscaling_converted_graph_on_device(name):
     ref = ref.reshape(y.shape)
     err = (y.float().cpu() - ref).norm() / ref.norm()
     assert float(err) <= (0.08 if "fp4" in name or "nf4" in name else 0.02), float(err)
+
+
+def test_roberta_mrpc_style_training_on_device_matches_cpu():
+    """BASELINE config 5 in miniature: RoBERTa sequence classifier, int8 activations + weights with delayed scaling,
+    E5M2 gradients (quantized backward, gemm + residual), AdamW, clip 1.0 -- six steps with CPU tensors and with device
+    tensors from the same initial weights and batches.  fp32 model: the fake-quant passes are bit-exact on both sides,
+    the GEMMs and reductions differ in accumulation order, and int8 rounding amplifies a last-bit difference into one
+    quantization step on isolated elements; the loss curves must agree to 2 % per step and the delayed-scaling state
+    (scale of the first gradient fake-quantizer) to 2 %."""
+    import copy
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100,
+                        max_position_embeddings=66, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base = RobertaForSequenceClassification(cfg)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 100, (8, 16), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)}
+               for _ in range(6)]
+    res = {}
+    for dev in ("cpu", "cuda"):
+        m = copy.deepcopy(base).to(dev)
+        qt.quantize(m, _args("--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
+                             "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10",
+                             "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual"))
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+        losses = harness.train_steps(m, batches, opt)
+        fq = dict(m.named_modules())["roberta.encoder.layer.0.attention.self.query.error_pre_process.0"]
+        res[dev] = (losses, float(fq.scale), float(fq.amax_history.max()))
+    (l0, s0, a0), (l1, s1, a1) = res["cpu"], res["cuda"]
+    assert all(abs(x - y) <= 0.02 * abs(x) for x, y in zip(l0, l1)), (l0, l1)
+    assert abs(s0 - s1) <= 0.02 * s0 and abs(a0 - a1) <= 0.02 * a0, (s0, s1, a0, a1)
+    assert s0 != 1.0
