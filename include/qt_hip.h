@@ -255,6 +255,20 @@ int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint
                        size_t rows, size_t cols, int block_size, const qt_format *fmt, const uint16_t *lut_dev,
                        float quant_max, int force_pow2, const uint16_t *scale_lut_dev, int pack_format, void *stream);
 
+/* ---- the model's own elementwise chains between the fake-quantized GEMMs (Hugging Face LLaMA block) -----------
+ * Not part of the reference package: its examples run HF's modeling_llama as is, where each of these is 3-8 torch
+ * kernels.  Same operation order and bf16 rounding points as those chains (transformers modeling_llama.py:
+ * LlamaRMSNorm.forward, LlamaMLP.forward, apply_rotary_pos_emb / rotate_half).
+ *   qt_rmsnorm_bf16:  y[r][c] = bf16(w[c] * bf16(x32 * rsqrt(mean_c(x32^2) + eps))); cols % 8 == 0, cols <= 16384
+ *   qt_silu_mul_bf16: y = bf16(bf16(silu(gate)) * up), n % 8 == 0
+ *   qt_rope_bf16:     q, k in [B][S][H][D] memory order (the transposed views HF passes), cos / sin [B][S][D];
+ *                     out = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin)); D % 16 == 0 */
+int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, long rows, long cols, float eps,
+                    void *stream);
+int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t n, void *stream);
+int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
+                 uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

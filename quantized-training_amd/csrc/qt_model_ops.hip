@@ -1,0 +1,171 @@
+// The model's own elementwise chains between the fake-quantized GEMMs of a LLaMA block, one launch each.
+// Hugging Face runs them as 3-8 torch kernels apiece (~9 of the 24 ms of a LLaMA-2-7B window once everything on the
+// fake-quant path was fused); the arithmetic below repeats their operation order and every bf16 rounding point:
+//   RMSNorm      x32 = float(x); v = mean(x32^2); h = bf16(x32 * rsqrt(v + eps)); y = bf16(w * h)
+//   SiLU * up    a = bf16(g32 / (1 + exp(-g32)));  y = bf16(a * u)
+//   rotary       y = bf16( bf16(x * cos) + bf16(rotate_half(x) * sin) ),  rotate_half(x) = cat(-x[D/2:], x[:D/2])
+// SiLU*up and rotary are bit-identical to the torch chains; RMSNorm differs only through the summation order of the
+// mean (last-bit differences of v can move isolated outputs by one bf16 ulp).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qt_hip.h"
+#include "qt_device.h"
+#include "qt_formats.h"
+
+namespace {
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return qt_u2f(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return qt_u2f(w & 0xFFFF0000u); }
+__device__ __forceinline__ float rbf(float f) { return qt_u2f(pack_bf16x2(f, 0.0f) << 16); }      // round to bf16, keep as float
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxVec = 8;        // 16-byte vectors per thread: rows up to 256 * 8 * 8 = 16384 elements
+
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ w,
+                                                               uint4 *__restrict__ y, int nvec, float inv_cols, float eps) {
+    __shared__ float s_part[kNormThreads / 64];
+    const size_t row = blockIdx.x;
+    const uint4 *xr = x + row * (size_t)nvec;
+    uint4 v[kNormMaxVec];
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNormMaxVec; ++i) {
+        const int c = threadIdx.x + i * kNormThreads;
+        if (c < nvec) {
+            v[i] = xr[c];
+            const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(q[j]), b = bf_hi(q[j]);
+                ss += a * a;
+                ss += b * b;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNormThreads / 64; ++i) tot += s_part[i];
+    const float r = rsqrtf(tot * inv_cols + eps);
+#pragma unroll
+    for (int i = 0; i < kNormMaxVec; ++i) {
+        const int c = threadIdx.x + i * kNormThreads;
+        if (c < nvec) {
+            const uint4 ww = w[c];
+            const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, g[4] = {ww.x, ww.y, ww.z, ww.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h0 = rbf(bf_lo(q[j]) * r), h1 = rbf(bf_hi(q[j]) * r);
+                o[j] = pack_bf16x2(bf_lo(g[j]) * h0, bf_hi(g[j]) * h1);
+            }
+            y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ u,
+                                                       uint4 *__restrict__ y, size_t nvec) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 a = g[i], b = u[i];
+        const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
+            const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+            o[j] = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));
+        }
+        y[i] = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+struct RopeArgs {
+    const uint16_t *x;       // [B][S][H][D] memory order
+    uint16_t *y;
+    const uint16_t *cos, *sin;   // [B][S][D]
+    long B, S, H, D;
+    size_t nvec;             // B * S * H * D / 8
+};
+
+__device__ __forceinline__ void rope_one(const RopeArgs &a, size_t i) {
+    const long dv = a.D / 8;                             // vectors per head row
+    const long d8 = (long)(i % dv);
+    const size_t bsh = i / dv;
+    const size_t bs = bsh / (size_t)a.H;
+    const long half = dv / 2;
+    const bool low = d8 < half;
+    const uint4 xv = *(const uint4 *)(a.x + i * 8);
+    const uint4 pv = *(const uint4 *)(a.x + (bsh * dv + (low ? d8 + half : d8 - half)) * 8);     // rotate_half partner
+    const uint4 cv = *(const uint4 *)(a.cos + (bs * dv + d8) * 8);
+    const uint4 sv = *(const uint4 *)(a.sin + (bs * dv + d8) * 8);
+    const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
+    const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
+    const float sgn = low ? -1.0f : 1.0f;
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+        const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
+        o[j] = pack_bf16x2(a0 + b0, a1 + b1);
+    }
+    *(uint4 *)(a.y + i * 8) = uint4{o[0], o[1], o[2], o[3]};
+}
+
+__global__ __launch_bounds__(256) void rope_kernel(RopeArgs q, RopeArgs k) {
+    const size_t total = q.nvec + k.nvec;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (i < q.nvec) rope_one(q, i);
+        else rope_one(k, i - q.nvec);
+    }
+}
+
+int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_rmsnorm_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, long rows, long cols, float eps, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15u))
+        return QT_ERR_UNALIGNED;
+    rmsnorm_kernel<<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+                                                                             (int)(cols / 8), 1.0f / (float)cols, eps);
+    return launch_status();
+}
+
+int qt_silu_mul_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, size_t n, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!gate || !up || !y) return QT_ERR_BAD_ARG;
+    if ((n & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = n / 8;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    silu_mul_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, nvec);
+    return launch_status();
+}
+
+int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
+                 uint16_t *k_out, long B, long S, long Hq, long Hk, long D, void *stream) {
+    if (B * S * D == 0) return QT_OK;
+    if (!q || !k || !cos || !sin || !q_out || !k_out || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
+    if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
+        return QT_ERR_UNALIGNED;
+    RopeArgs aq{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8)};
+    RopeArgs ak{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8)};
+    size_t blocks = (aq.nvec + ak.nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    rope_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""One-launch versions of the elementwise chains a Hugging Face LLaMA block runs between its (fake-quantized) GEMMs.
+
+Not part of the reference package -- its examples run HF's modeling_llama unchanged, where RMSNorm is eight torch
+kernels, rotary embedding ten and SiLU * up two.  Once everything on the fake-quant path was fused these chains were
+~9 of the 24 ms of a LLaMA-2-7B evaluation window, so `quantize()` swaps them for the HIP kernels of
+csrc/qt_model_ops.hip when that changes nothing observable:
+  * only for bf16 device tensors under torch.no_grad() (no backward is provided -- training keeps HF's code);
+  * only when nothing hooks the intermediate values (an `--quantize_forward activation` hook on the SiLU, say);
+  * same operation order and bf16 rounding points: SiLU * up and rotary are bit-identical to the torch chains, RMSNorm
+    differs only through the summation order of its mean (isolated outputs move by one bf16 ulp).
+`QT_FUSED_MODEL_OPS=0` keeps HF's own code everywhere.
+"""
+import os
+
+import torch
+
+from . import _native
+from .fake_quantize import _stream_ptr
+
+__all__ = ["apply_llama_fusions", "rmsnorm", "silu_mul", "rope"]
+
+
+def _enabled():
+    return os.environ.get("QT_FUSED_MODEL_OPS", "1") != "0"
+
+
+def _eligible(*tensors):
+    if not _enabled() or torch.is_grad_enabled():
+        return False
+    return all(t.device.type == "cuda" and t.dtype == torch.bfloat16 for t in tensors)
+
+
+def _hooked(mod):
+    return bool(mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks)
+
+
+# ---- kernels behind tensor-level functions ------------------------------------------------------------------------
+def rmsnorm(x, weight, eps):
+    cols = x.shape[-1]
+    x2 = x.contiguous()
+    y = torch.empty_like(x2)
+    _native.check(_native.lib().qt_rmsnorm_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), x2.numel() // cols, cols,
+                                                float(eps), _stream_ptr(x2)), "qt_rmsnorm_bf16")
+    return y
+
+
+def silu_mul(gate, up):
+    g, u = gate.contiguous(), up.contiguous()
+    y = torch.empty_like(g)
+    _native.check(_native.lib().qt_silu_mul_bf16(g.data_ptr(), u.data_ptr(), y.data_ptr(), g.numel(), _stream_ptr(g)),
+                  "qt_silu_mul_bf16")
+    return y
+
+
+def rope(q, k, cos, sin):
+    """q [B, Hq, S, D], k [B, Hk, S, D] as the transposed views of [B, S, H, D] buffers that HF's attention holds;
+    returns tensors with the same shape and memory order, as the torch chain would."""
+    B, Hq, S, D = q.shape
+    Hk = k.shape[1]
+    qb, kb = q.transpose(1, 2), k.transpose(1, 2)              # [B, S, H, D]
+    q_out, k_out = torch.empty_like(qb), torch.empty_like(kb)
+    _native.check(_native.lib().qt_rope_bf16(qb.data_ptr(), kb.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(),
+                                             k_out.data_ptr(), B, S, Hq, Hk, D, _stream_ptr(q)), "qt_rope_bf16")
+    return q_out.transpose(1, 2), k_out.transpose(1, 2)
+
+
+# ---- module-level swaps -------------------------------------------------------------------------------------------
+def _rmsnorm_forward(self, hidden_states):
+    w = self.weight
+    if (_eligible(hidden_states, w) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384
+            and hidden_states.numel() > 0 and w.is_contiguous()):
+        return rmsnorm(hidden_states, w, self.variance_epsilon)
+    return self._qt_hf_forward(hidden_states)
+
+
+def _mlp_forward(self, x):
+    if not _hooked(self.act_fn) and getattr(self.act_fn, "__class__", None).__name__ in ("SiLU", "SiLUActivation"):
+        gate = self.gate_proj(x)
+        up = self.up_proj(x)
+        if _eligible(gate, up) and gate.shape == up.shape and gate.numel() % 8 == 0 and gate.numel() > 0:
+            return self.down_proj(silu_mul(gate, up))
+        return self.down_proj(self.act_fn(gate) * up)
+    return self._qt_hf_forward(x)
+
+
+def _bind(module, fn):
+    """Keep the class (isinstance checks, state-dict keys, hooks) and replace only this instance's forward."""
+    if getattr(module, "_qt_hf_forward", None) is None:
+        module._qt_hf_forward = module.forward
+        module.forward = fn.__get__(module, type(module))
+
+
+_ROPE_PATCHED = {"done": False}
+
+
+def _patch_rope():
+    """HF's LlamaAttention.forward calls the module-level apply_rotary_pos_emb; route it through the fused kernel when
+    the tensors are the layout it produces ([B, S, H, D] buffers seen as [B, H, S, D], cos / sin [B, S, D])."""
+    if _ROPE_PATCHED["done"]:
+        return
+    try:
+        from transformers.models.llama import modeling_llama as ml
+    except Exception:  # noqa: BLE001
+        return
+    original = ml.apply_rotary_pos_emb
+
+    def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
+        ok = (unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and _eligible(q, k, cos, sin)
+              and q.shape[-1] % 16 == 0 and q.shape[-1] == k.shape[-1] == cos.shape[-1] and cos.shape == sin.shape
+              and cos.shape[0] in (1, q.shape[0]) and cos.shape[1] == q.shape[2] and k.shape[2] == q.shape[2]
+              and q.transpose(1, 2).is_contiguous() and k.transpose(1, 2).is_contiguous()
+              and cos.is_contiguous() and sin.is_contiguous() and q.numel() > 0 and k.shape[0] == q.shape[0])
+        if ok:
+            if cos.shape[0] != q.shape[0]:                      # position ids shared by the batch
+                cos, sin = cos.expand(q.shape[0], -1, -1).contiguous(), sin.expand(q.shape[0], -1, -1).contiguous()
+            return rope(q, k, cos, sin)
+        return original(q, k, cos, sin, unsqueeze_dim)
+
+    apply_rotary_pos_emb._qt_original = original
+    ml.apply_rotary_pos_emb = apply_rotary_pos_emb
+    _ROPE_PATCHED["done"] = True
+
+
+def apply_llama_fusions(model):
+    """Called by quantize(): swap the forwards of every LlamaRMSNorm / LlamaMLP of `model` and route rotary embedding
+    through the fused kernel.  Returns the number of modules touched."""
+    try:
+        from transformers.models.llama import modeling_llama as ml
+    except Exception:  # noqa: BLE001
+        return 0
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, ml.LlamaRMSNorm):
+            _bind(mod, _rmsnorm_forward)
+            n += 1
+        elif isinstance(mod, ml.LlamaMLP):
+            _bind(mod, _mlp_forward)
+            n += 1
+    if n:
+        _patch_rope()
+    return n

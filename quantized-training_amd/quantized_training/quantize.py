@@ -87,6 +87,9 @@ def quantize(model, args, inplace=True):
     propagate_config(model, "qconfig", qconfig)
     convert(model, mapping=DEFAULT_QAT_MODULE_MAPPINGS, inplace=True)
     prepare(model, True, args.quantize_forward, args.quantize_backprop, getattr(args, "op_fusion", None))
+    if _is_hf_model(model):
+        from .model_fusions import apply_llama_fusions
+        apply_llama_fusions(model)          # inference-only one-launch RMSNorm / rotary / SiLU*up (no-op off device)
     return model
 
 

@@ -193,3 +193,26 @@ def test_roberta_mrpc_style_training_on_device_matches_cpu():
     assert all(abs(x - y) <= 0.02 * abs(x) for x, y in zip(l0, l1)), (l0, l1)
     assert abs(s0 - s1) <= 0.02 * s0 and abs(a0 - a1) <= 0.02 * a0, (s0, s1, a0, a1)
     assert s0 != 1.0
+
+
+def test_llama_model_fusions_vs_hf_chains():
+    """quantize() routes LlamaRMSNorm / rotary / SiLU*up through one-launch kernels under no_grad; with
+    QT_FUSED_MODEL_OPS=0 HF's own torch chains run.  Same quantized-element count, window NLLs within 1e-3 relative
+    (the only non-bit-identical piece is the RMSNorm mean's summation order)."""
+    from quantized_training.fake_quantize import STATS
+    res = {}
+    for flag in ("1", "0"):
+        os.environ["QT_FUSED_MODEL_OPS"] = flag
+        try:
+            m = _llama("cuda", torch.bfloat16)
+            qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+            with torch.no_grad():
+                harness.window_nll(m, TOK[:, :256].cuda(), 256)
+                STATS.reset()
+                nll = [float(harness.window_nll(m, TOK[:, b:e].cuda(), t)) for (b, e, t) in harness.wikitext_windows(TOK.shape[1], 256, 128)]
+            res[flag] = (nll, STATS.elements)
+        finally:
+            os.environ.pop("QT_FUSED_MODEL_OPS", None)
+    (a, na), (b, nb) = res["1"], res["0"]
+    assert na == nb
+    assert all(abs(x - y) <= 1e-3 * abs(y) for x, y in zip(a, b)), (a, b)

@@ -878,3 +878,46 @@ def test_quantize_mx_with_scale_map(nv):
     s, q = torch.ops.quantized_ops.quantize_mx(x.cuda(), get_quantization_map("fp4_e2m1", "cuda"), [-1], 16, 6.0, False,
                                                get_quantization_map("fp8_e4m3", "cuda"), None)
     assert _same_bits(s, s_ref) and _same_bits(q, q_ref)
+
+
+# ---- one-launch model ops (csrc/qt_model_ops.hip) against the torch chains of HF's modeling_llama ------------------
+def test_silu_mul_and_rotary_are_bit_identical_to_the_torch_chains(nv):
+    from quantized_training import model_fusions as mf
+    from transformers.models.llama import modeling_llama as ml
+    g = torch.Generator(device="cuda").manual_seed(0)
+    gate = (torch.randn(1024, 11008, device="cuda", generator=g) * 3).bfloat16()
+    up = torch.randn(1024, 11008, device="cuda", generator=g).bfloat16()
+    with torch.no_grad():
+        want = torch.nn.functional.silu(gate) * up
+        got = mf.silu_mul(gate, up)
+    assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+    for (B, H, Hk, S, D) in ((1, 32, 32, 1024, 128), (3, 8, 2, 77, 64)):
+        q = torch.randn(B, S, H, D, device="cuda", generator=g).bfloat16().transpose(1, 2)
+        k = torch.randn(B, S, Hk, D, device="cuda", generator=g).bfloat16().transpose(1, 2)
+        ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+        cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+        orig = getattr(ml.apply_rotary_pos_emb, "_qt_original", ml.apply_rotary_pos_emb)
+        with torch.no_grad():
+            wq, wk = orig(q, k, cos, sin)
+            gq, gk = mf.rope(q, k, cos, sin)
+        assert gq.shape == wq.shape and gq.stride() == wq.stride()
+        assert torch.equal(wq.contiguous().view(torch.int16), gq.contiguous().view(torch.int16))
+        assert torch.equal(wk.contiguous().view(torch.int16), gk.contiguous().view(torch.int16))
+
+
+def test_rmsnorm_within_bf16_rounding_of_the_torch_chain(nv):
+    from quantized_training import model_fusions as mf
+    from transformers.models.llama import modeling_llama as ml
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for cols in (4096, 5120, 256, 11008):
+        x = (torch.randn(512, cols, device="cuda", generator=g) * 2).bfloat16()
+        norm = ml.LlamaRMSNorm(cols, eps=1e-5).cuda().bfloat16()
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.1 * torch.randn(cols, device="cuda", generator=g))
+            want = ml.LlamaRMSNorm.forward(norm, x)
+            got = mf.rmsnorm(x, norm.weight, norm.variance_epsilon)
+        a, b = want.view(torch.int16).int(), got.view(torch.int16).int()
+        # a last-bit difference of the mean can move h = bf16(x * r) to the neighbouring value on isolated elements;
+        # the weight multiply then rounds once more, so y is at most two bf16 codes away, on isolated elements
+        assert int((a - b).abs().max()) <= 2
+        assert float((a != b).float().mean()) <= 2e-3
