@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cache-eval-weights", action="store_true",
                     help="side experiment (line marked invalid): keep fq(W) across windows instead of re-quantizing, "
                          "which the reference does not do")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: initialise torch.distributed (nccl) and take the multi-rank code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -125,7 +127,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         dist.init_process_group("nccl", device_id=device)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -181,23 +184,23 @@ def main():
 
         for i in range(a.warmup):
             run_window(*batches[i])
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
             nlls.append(run_window(*batches[a.warmup + i]).clone())
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     t = torch.tensor([el], device=device, dtype=torch.float64)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     local = torch.stack(nlls)
-    allnll = harness.gather_in_order(local, a.steps * world, rank, world) if world > 1 else local
+    allnll = harness.gather_in_order(local, a.steps * world, rank, world) if multi else local
 
     out = None
     if rank == 0:
@@ -230,7 +233,7 @@ def main():
             out["roofline"] = roofline_leg(device)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
