@@ -276,6 +276,11 @@ int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *c
 int qt_bench_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
                              const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
                              int iters, size_t pool_stride, int pool_count, void *stream, float *ms_out);
+/* Same, for the pass that emits the quantized code as FP8 bytes (qt_fake_quant_bf16_fp8; y_dev NULL = FP8 output
+ * only, which is how the weight pass of the FP8 GEMM route runs): y8 pool addressed like x. */
+int qt_bench_fake_quant_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n, const qt_format *fmt,
+                                 const float *scale_f32_dev, uint32_t *amax_bits_dev, int iters, size_t pool_stride,
+                                 int pool_count, void *stream, float *ms_out);
 
 #ifdef __cplusplus
 }

@@ -786,7 +786,7 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
     if ((n & 15) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)y8) & 15u)) return QT_ERR_UNALIGNED;
     const size_t nvec = n / 16;
-    const unsigned grid = grid_for(nvec, 256, 32);
+    const unsigned grid = grid_for(nvec, 256, g_blocks_per_cu);
     hipStream_t st = (hipStream_t)stream;
     const uint4 *xv = (const uint4 *)x;
     uint4 *yv = (uint4 *)y;
@@ -911,6 +911,33 @@ int qt_bench_fake_quant_bf16(const uint16_t *x, uint16_t *y, size_t n, const qt_
     for (int i = 0; i < iters && rc == QT_OK; ++i) {
         const size_t off = (size_t)(i % pool_count) * pool_stride;
         rc = launch_fq<kIoBf16>(x + off, y ? y + off : nullptr, n, fmt, lut, scale, amax, stream);
+    }
+    (void)hipEventRecord(e1, st);
+    e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != QT_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    *ms_out = ms / (float)iters;
+    return QT_OK;
+}
+
+int qt_bench_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt,
+                                 const float *scale, uint32_t *amax, int iters, size_t pool_stride, int pool_count,
+                                 void *stream, float *ms_out) {
+    if (!ms_out || iters < 1 || pool_count < 1) return QT_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess) return (int)e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+    int rc = QT_OK;
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < iters && rc == QT_OK; ++i) {
+        const size_t off = (size_t)(i % pool_count) * pool_stride;
+        rc = qt_fake_quant_bf16_fp8(x + off, y ? y + off : nullptr, y8 + off, n, fmt, scale, amax, stream);
     }
     (void)hipEventRecord(e1, st);
     e = hipEventSynchronize(e1);

@@ -28,27 +28,36 @@ def pmc(path, name, kernel="fq_kernel"):
 shutil.copy(one("prof_bench/*/*kernel_stats.csv"), os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(one("prof_roofline/*/*kernel_stats.csv"), os.path.join(out, f"{tag}_roofline_kernel_stats.csv"))
 shutil.copy(os.path.join(ROOT, "gpurun_out", "bench_n1.json"), os.path.join(out, f"{tag}_bench_n1.json"))
-fetch, nf = pmc(one("pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
-write, nw = pmc(one("pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
 rows = list(csv.DictReader(open(os.path.join(out, f"{tag}_roofline_kernel_stats.csv"))))
-k = [r for r in rows if "fq_kernel" in r["Name"]][0]
 bench = json.load(open(os.path.join(out, f"{tag}_bench_n1.json")))
 n = 4096 * 11008
-res = {
-    "kernel": k["Name"][:120],
-    "tensor": "bf16[4096,11008], 8-tensor rotating pool (1.44 GB)",
+
+
+def traffic_of(kernel, bytes_per_elem, bench_ms):
+    fetch, nf = pmc(one("pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE", kernel)
+    write, nw = pmc(one("pmc_write/*/*counter_collection.csv"), "WRITE_SIZE", kernel)
+    k = [r for r in rows if kernel in r["Name"]][0]
+    return {
+        "kernel": k["Name"][:120],
+        "launches_sampled": [nf, nw],
+        "FETCH_SIZE_KB_raw_per_launch": fetch,
+        "fetch_bytes_per_launch": int(fetch * 1024 * 2),
+        "WRITE_SIZE_KB_per_launch": write,
+        "write_bytes_per_launch": int(write * 1024),
+        "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+        "algorithmic_bytes_per_launch": n * bytes_per_elem,
+        "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / (n * bytes_per_elem),
+        "kernel_avg_duration_us_rocprof": float(k["AverageNs"]) / 1e3,
+        "kernel_avg_duration_us_hip_events_in_bench": bench_ms * 1e3,
+    }
+
+
+res = traffic_of("fq_kernel", 4, bench["roofline"]["bf16_out"]["ms_per_launch"])
+res.update({
+    "tensor": "bf16[4096,11008], 8-tensor rotating pool (1.44 GB in + out)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/roofline_only.py",
-    "launches_sampled": [nf, nw],
-    "FETCH_SIZE_KB_raw_per_launch": fetch,
     "FETCH_SIZE_correction": "x2 on gfx950 (16 B/lane coalesced streaming reads are tallied at half)",
-    "fetch_bytes_per_launch": int(fetch * 1024 * 2),
-    "WRITE_SIZE_KB_per_launch": write,
-    "write_bytes_per_launch": int(write * 1024),
-    "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
-    "algorithmic_bytes_per_launch": n * 4,
-    "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / (n * 4),
-    "kernel_avg_duration_us_rocprof": float(k["AverageNs"]) / 1e3,
-    "kernel_avg_duration_us_hip_events_in_bench": bench["roofline"]["ms_per_launch"] * 1e3,
-}
+    "fp8_only": traffic_of("fq8_kernel", 3, bench["roofline"]["ms_per_launch"]),
+})
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
