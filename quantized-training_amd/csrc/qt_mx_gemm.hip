@@ -43,17 +43,25 @@ struct MxGemmArgs {
 // LDS image of a 128-row operand tile.  8- and 4-bit tiles are unpadded with the 16-byte chunk index XOR-swizzled by
 // the row so that the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ... : sixteen different rows, half of
 // them one chunk further along k) each touch sixteen different 16-byte slots of the 256-byte bank row; 6-bit tiles
-// (96-byte rows, read with ds_read_b64) use a 112-byte pitch, conflict-free for the two 32-lane halves.
+// (96-byte rows, read with three ds_read_b64) are stored in groups of 8 rows (768 bytes) followed by 16 bytes of
+// padding: a fragment's rows r and r + 8 then sit 2 eight-byte slots apart modulo the 32-slot bank row, which makes the
+// two 32-lane halves of ds_read_b64 conflict-free (unpadded 96-byte rows collide pairwise: 12 r mod 32 has period 8),
+// and one 48-lane LDS-DMA instruction fills exactly one group.
 template <int F>
 struct Tile {
     static constexpr int kRow = tile_row_bytes(F);                  // bytes of one row of a 128-deep tile
-    static constexpr int kPitch = (F == 2 || F == 3) ? kRow + 16 : kRow;
+    static constexpr bool kSix = (F == 2 || F == 3);
+    static constexpr int kGroup = 8 * kRow + 16;                    // 6-bit tiles: 8 rows + pad
     static constexpr int kChunks = kRow / 16;
-    static constexpr int kBytes = 128 * kPitch;
+    static constexpr int kBytes = kSix ? 16 * kGroup : 128 * kRow;
+    static __device__ __forceinline__ int row_off(int row) {
+        if constexpr (kSix) return (row >> 3) * kGroup + (row & 7) * kRow;
+        else return row * kRow;
+    }
     static __device__ __forceinline__ int chunk_off(int row, int chunk) {
-        if constexpr (F < 2) return row * kPitch + ((chunk ^ ((row >> 1) & 7)) << 4);
-        else if constexpr (F < 4) return row * kPitch + (chunk << 4);
-        else return row * kPitch + ((chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 4);     // f = [0,2,3,1], see below
+        if constexpr (F < 2) return row * kRow + ((chunk ^ ((row >> 1) & 7)) << 4);
+        else if constexpr (F < 4) return row_off(row) + (chunk << 4);
+        else return row * kRow + ((chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 4);     // f = [0,2,3,1], see below
     }
 };
 // fp4 swizzle: rows r and r' of one lane group with r & 3 == r' & 3 collide when f(r >> 2) ^ f(r' >> 2) == 1 for a
@@ -68,7 +76,7 @@ __device__ __forceinline__ v8i read_frag(const uint8_t *tile, int row, int g) {
         const uint4 hi = *(const uint4 *)(tile + Tile<F>::chunk_off(row, 4 + g));
         f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
     } else if constexpr (F < 4) {
-        const uint8_t *p = tile + row * Tile<F>::kPitch + 24 * g;
+        const uint8_t *p = tile + Tile<F>::row_off(row) + 24 * g;
         const uint2 a = *(const uint2 *)(p), b = *(const uint2 *)(p + 8), c = *(const uint2 *)(p + 16);
         f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
     } else {
@@ -243,10 +251,19 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 template <int F>
-struct DmaTile {                                    // 1 KiB wave-instruction = kRows rows of the tile
-    static constexpr int kRow = tile_row_bytes(F), kChunks = kRow / 16, kRows = 64 / kChunks;
-    static constexpr int kInstr = 128 / kRows / 4;  // wave-instructions per wave per tile (4 for fp8, 2 for fp4)
+struct DmaTile {                                    // one wave-instruction = kRows rows of the tile
+    static constexpr int kRow = tile_row_bytes(F), kChunks = kRow / 16;
+    static constexpr int kRows = Tile<F>::kSix ? 8 : 64 / kChunks;     // fp8: 8 rows, fp6: 8 rows (48 lanes), fp4: 16 rows
+    static constexpr int kLanes = kRows * kChunks;                      // active lanes of the instruction
+    static constexpr int kStride = Tile<F>::kSix ? Tile<F>::kGroup : 1024;   // LDS bytes from one instruction's block to the next
+    static constexpr int kInstr = 128 / kRows / 4;  // wave-instructions per wave per tile (4 for fp8 / fp6, 2 for fp4)
 };
+
+// which source chunk of `row` belongs in LDS slot `cs` of that row (the XOR swizzles are involutions)
+template <int F>
+__device__ __forceinline__ int swz_chunk(int row, int cs) {
+    return (Tile<F>::chunk_off(row, cs) - Tile<F>::row_off(row)) >> 4;
+}
 
 template <int FA, int FB>
 __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
@@ -279,15 +296,15 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
     const uint8_t *ga[DA::kInstr], *gb[DB::kInstr];
 #pragma unroll
     for (int i = 0; i < DA::kInstr; ++i) {
-        const int row = (w * DA::kInstr + i) * DA::kRows + l / DA::kChunks, cs = l % DA::kChunks;
-        const int chunk = (TA::chunk_off(row, cs) - row * TA::kPitch) >> 4;        // the swizzle is an involution
-        ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * kbA + chunk * 16;
+        const int ll = min(l, DA::kLanes - 1);
+        const int row = (w * DA::kInstr + i) * DA::kRows + ll / DA::kChunks, cs = ll % DA::kChunks;
+        ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * kbA + swz_chunk<FA>(row, cs) * 16;
     }
 #pragma unroll
     for (int i = 0; i < DB::kInstr; ++i) {
-        const int row = (w * DB::kInstr + i) * DB::kRows + l / DB::kChunks, cs = l % DB::kChunks;
-        const int chunk = (TB::chunk_off(row, cs) - row * TB::kPitch) >> 4;
-        gb[i] = a.B + bz * a.bB + (long)min(n0 + row, a.N - 1) * kbB + chunk * 16;
+        const int ll = min(l, DB::kLanes - 1);
+        const int row = (w * DB::kInstr + i) * DB::kRows + ll / DB::kChunks, cs = ll % DB::kChunks;
+        gb[i] = a.B + bz * a.bB + (long)min(n0 + row, a.N - 1) * kbB + swz_chunk<FB>(row, cs) * 16;
     }
     // scale bytes of the tile: 128 rows x 4 bytes per operand; waves 0,1 fetch A's, waves 2,3 fetch B's
     const int srow = (w & 1) * 64 + l;
@@ -304,10 +321,14 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < DA::kInstr; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow), (lds_void *)(s_a + (w * DA::kInstr + i) * 1024), 16, 0, 0);
+            if (DA::kLanes == 64 || l < DA::kLanes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow),
+                                                 (lds_void *)(s_a + (w * DA::kInstr + i) * DA::kStride), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < DB::kInstr; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow), (lds_void *)(s_b + (w * DB::kInstr + i) * 1024), 16, 0, 0);
+            if (DB::kLanes == 64 || l < DB::kLanes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow),
+                                                 (lds_void *)(s_b + (w * DB::kInstr + i) * DB::kStride), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)s_dst, 4, 0, 0);
         __syncthreads();
         int sa[4], sb[4];
@@ -450,6 +471,7 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
         return launch_status();                                                                                    \
     }
     QT_MX_DMA(0, 0) QT_MX_DMA(0, 1) QT_MX_DMA(1, 0) QT_MX_DMA(1, 1) QT_MX_DMA(4, 4) QT_MX_DMA(0, 4)
+    QT_MX_DMA(2, 2) QT_MX_DMA(3, 3) QT_MX_DMA(2, 4) QT_MX_DMA(3, 4)
 #undef QT_MX_DMA
 #define QT_MX(FA, FB)                                                                                              \
     if (a_format == FA && b_format == FB) {                                                                        \
