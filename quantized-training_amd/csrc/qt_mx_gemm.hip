@@ -265,14 +265,18 @@ __device__ __forceinline__ int swz_chunk(int row, int cs) {
     return (Tile<F>::chunk_off(row, cs) - Tile<F>::row_off(row)) >> 4;
 }
 
-template <int FA, int FB>
-__global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
+// STAGES == 1: one LDS stage, two barriers per step -- relies on >= 3 resident workgroups per CU covering each other's
+// load latency (large grids).  STAGES == 2: the DMA of tile k+1 is in flight while tile k is multiplied; the wait is a
+// counted s_waitcnt vmcnt(pieces of one stage) followed by a raw s_barrier (a __syncthreads() would drain the
+// prefetch) -- for grids of only one or two workgroups per CU.
+template <int FA, int FB, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void mx_gemm_dma_kernel(MxGemmArgs a) {
     using TA = Tile<FA>;
     using TB = Tile<FB>;
     using DA = DmaTile<FA>;
     using DB = DmaTile<FB>;
+    constexpr int kStage = TA::kBytes + TB::kBytes + 1024;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *const s_a = lds, *const s_b = lds + TA::kBytes, *const s_sa = lds + TA::kBytes + TB::kBytes, *const s_sb = s_sa + 512;
 
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int r = l & 15, g = l >> 4;
@@ -310,7 +314,6 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
     const int srow = (w & 1) * 64 + l;
     const uint8_t *gs = w < 2 ? a.sA + bz * a.bsA + (long)min(m0 + srow, a.M - 1) * nblk
                               : a.sB + bz * a.bsB + (long)min(n0 + srow, a.N - 1) * nblk;
-    uint8_t *const s_dst = (w < 2 ? s_sa : s_sb) + (w & 1) * 256;
 
     v4f acc[4][4];
 #pragma unroll
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt) {
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        uint8_t *const s_a = lds + stage * kStage, *const s_b = s_a + TA::kBytes, *const s_s = s_b + TB::kBytes;
 #pragma unroll
         for (int i = 0; i < DA::kInstr; ++i)
             if (DA::kLanes == 64 || l < DA::kLanes)
@@ -329,8 +333,11 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
             if (DB::kLanes == 64 || l < DB::kLanes)
                 __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow),
                                                  (lds_void *)(s_b + (w * DB::kInstr + i) * DB::kStride), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)s_dst, 4, 0, 0);
-        __syncthreads();
+        __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)(s_s + (w < 2 ? 0 : 512) + (w & 1) * 256), 4, 0, 0);
+    };
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const uint8_t *const s_a = lds + stage * kStage, *const s_b = s_a + TA::kBytes, *const s_sa = s_b + TB::kBytes,
+                      *const s_sb = s_sa + 512;
         int sa[4], sb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -347,7 +354,33 @@ __global__ __launch_bounds__(256, 3) void mx_gemm_dma_kernel(MxGemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
-        __syncthreads();
+    };
+    if constexpr (STAGES == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(kt, 0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        constexpr int kPieces = DA::kInstr + DB::kInstr + 1;         // DMA instructions one wave issues per stage
+        static_assert(kPieces == 9 || kPieces == 7 || kPieces == 5, "vmcnt immediates below");
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                issue(kt + 1, (kt + 1) & 1);
+                // tile kt's pieces are the older ones: wait until only the kPieces just issued remain
+                if constexpr (kPieces == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if constexpr (kPieces == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                            // every wave's pieces of tile kt have landed
+            compute(kt & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // stage kt & 1 may be refilled (by the DMA of tile kt + 2)
+        }
     }
 
     const long cbase = bz * a.bC;
@@ -464,10 +497,24 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     hipStream_t st = (hipStream_t)stream;
     static const bool no_dma = getenv("QT_MX_NO_DMA") != nullptr;        // tuning / A-B switch
     const bool dma_ok = !no_dma && K % kBK == 0 && (((uintptr_t)a_e8m0 | (uintptr_t)b_e8m0) & 3u) == 0;
+    static const int force_stages = getenv("QT_MX_STAGES") ? atoi(getenv("QT_MX_STAGES")) : 0;          // tuning / A-B switch
+    const long nblocks = (long)grid.x * grid.y;
+    const bool two = force_stages ? force_stages == 2 : nblocks <= 2L * 256;        // <= 2 workgroups per CU: prefetch
 #define QT_MX_DMA(FA, FB)                                                                                          \
     if (dma_ok && a_format == FA && b_format == FB) {                                                              \
         constexpr int kLds = Tile<FA>::kBytes + Tile<FB>::kBytes + 1024;                                           \
-        mx_gemm_dma_kernel<FA, FB><<<grid, 256, kLds, st>>>(g);                                                    \
+        if (two) {                                                                                                 \
+            static bool configured = false;                                                                        \
+            if (!configured) {                                                                                     \
+                const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_dma_kernel<FA, FB, 2>,              \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLds);    \
+                if (e != hipSuccess) return (int)e;                                                                \
+                configured = true;                                                                                 \
+            }                                                                                                      \
+            mx_gemm_dma_kernel<FA, FB, 2><<<grid, 256, 2 * kLds, st>>>(g);                                         \
+        } else {                                                                                                   \
+            mx_gemm_dma_kernel<FA, FB, 1><<<grid, 256, kLds, st>>>(g);                                             \
+        }                                                                                                          \
         return launch_status();                                                                                    \
     }
     QT_MX_DMA(0, 0) QT_MX_DMA(0, 1) QT_MX_DMA(1, 0) QT_MX_DMA(1, 1) QT_MX_DMA(4, 4) QT_MX_DMA(0, 4)
