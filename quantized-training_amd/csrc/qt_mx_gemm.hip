@@ -259,24 +259,87 @@ struct DmaTile {                                    // one wave-instruction = kR
     static constexpr int kInstr = 128 / kRows / 4;  // wave-instructions per wave per tile (4 for fp8 / fp6, 2 for fp4)
 };
 
+// Fragment reads for the prefetch ring, as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every ds_read it can
+// see while an LDS-DMA is in flight (the DMA's LDS store carries no alias scope, so nothing can be proven about it),
+// which would drain the ring on every step.  An asm ds_read has no memory operand for that rule to act on; the price is
+// that the lgkmcnt wait before the first use is ours to place (one s_waitcnt lgkmcnt(0) after the batch of reads).
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ uint4 asm_ds_read_b128(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ uint2 asm_ds_read_b64(uint32_t addr) {
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ int asm_ds_read_u8(uint32_t addr) {
+    int v;
+    asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int F>
+__device__ __forceinline__ v8i read_frag_asm(uint32_t tile, int row, int g) {
+    v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (F < 2) {
+        const uint4 lo = asm_ds_read_b128(tile + Tile<F>::chunk_off(row, g));
+        const uint4 hi = asm_ds_read_b128(tile + Tile<F>::chunk_off(row, 4 + g));
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else if constexpr (F < 4) {
+        const uint32_t p = tile + Tile<F>::row_off(row) + 24 * g;
+        const uint2 a = asm_ds_read_b64(p), b = asm_ds_read_b64(p + 8), c = asm_ds_read_b64(p + 16);
+        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
+    } else {
+        const uint4 lo = asm_ds_read_b128(tile + Tile<F>::chunk_off(row, g));
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+    }
+    return f;
+}
+
 // which source chunk of `row` belongs in LDS slot `cs` of that row (the XOR swizzles are involutions)
 template <int F>
 __device__ __forceinline__ int swz_chunk(int row, int cs) {
     return (Tile<F>::chunk_off(row, cs) - Tile<F>::row_off(row)) >> 4;
 }
 
+// One __shared__ object per ring stage: hipcc orders a ds_read after an in-flight LDS-DMA with s_waitcnt vmcnt(0) unless it
+// can prove they touch different objects (distinct LDS globals carry distinct alias scopes; offsets into one array do
+// not), which would drain the prefetch ring on every step.
+template <int S, int BYTES>
+__device__ __forceinline__ uint8_t *ring_stage() {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[BYTES];
+    return buf;
+}
+template <int BYTES>
+__device__ __forceinline__ uint8_t *ring_stage_of(int s) {
+    switch (s) {                     // s is a compile-time constant wherever this is called (unrolled ring)
+        case 0: return ring_stage<0, BYTES>();
+        case 1: return ring_stage<1, BYTES>();
+        case 2: return ring_stage<2, BYTES>();
+        case 3: return ring_stage<3, BYTES>();
+        case 4: return ring_stage<4, BYTES>();
+        case 5: return ring_stage<5, BYTES>();
+        case 6: return ring_stage<6, BYTES>();
+        default: return ring_stage<7, BYTES>();
+    }
+}
+
 // STAGES == 1: one LDS stage, two barriers per step -- relies on >= 3 resident workgroups per CU covering each other's
-// load latency (large grids).  STAGES == 2: the DMA of tile k+1 is in flight while tile k is multiplied; the wait is a
-// counted s_waitcnt vmcnt(pieces of one stage) followed by a raw s_barrier (a __syncthreads() would drain the
-// prefetch) -- for grids of only one or two workgroups per CU.
+// load latency (large grids).  STAGES > 1: a ring of LDS stages with the DMA of the next STAGES - 1 tiles in flight
+// while a tile is multiplied; the wait is a counted s_waitcnt vmcnt(pieces still allowed in flight) followed by a raw
+// s_barrier (a __syncthreads() would drain the prefetch) -- for grids of about one workgroup per CU, where a tile's
+// ~1.5 us load latency is otherwise fully exposed.
 template <int FA, int FB, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void mx_gemm_dma_kernel(MxGemmArgs a) {
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void mx_gemm_dma_kernel(MxGemmArgs a) {
     using TA = Tile<FA>;
     using TB = Tile<FB>;
     using DA = DmaTile<FA>;
     using DB = DmaTile<FB>;
     constexpr int kStage = TA::kBytes + TB::kBytes + 1024;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // STAGES == 1 only (dynamic); rings use ring_stage<>
 
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int r = l & 15, g = l >> 4;
@@ -321,8 +384,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void mx_gemm_dma_kernel(M
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-        uint8_t *const s_a = lds + stage * kStage, *const s_b = s_a + TA::kBytes, *const s_s = s_b + TB::kBytes;
+    auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
+        uint8_t *const s_a = stage, *const s_b = s_a + TA::kBytes, *const s_s = s_b + TB::kBytes;
 #pragma unroll
         for (int i = 0; i < DA::kInstr; ++i)
             if (DA::kLanes == 64 || l < DA::kLanes)
@@ -335,8 +398,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void mx_gemm_dma_kernel(M
                                                  (lds_void *)(s_b + (w * DB::kInstr + i) * DB::kStride), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)(s_s + (w < 2 ? 0 : 512) + (w & 1) * 256), 4, 0, 0);
     };
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        const uint8_t *const s_a = lds + stage * kStage, *const s_b = s_a + TA::kBytes, *const s_sa = s_b + TB::kBytes,
+    auto compute = [&](const uint8_t *stage) __attribute__((always_inline)) {
+        const uint8_t *const s_a = stage, *const s_b = s_a + TA::kBytes, *const s_sa = s_b + TB::kBytes,
                       *const s_sb = s_sa + 512;
         int sa[4], sb[4];
 #pragma unroll
@@ -355,31 +418,58 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void mx_gemm_dma_kernel(M
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
     };
+    auto compute_ring = [&](const uint8_t *stage) __attribute__((always_inline)) {
+        const uint32_t s_a = lds_addr(stage), s_b = s_a + TA::kBytes, s_sa = s_b + TB::kBytes, s_sb = s_sa + 512;
+        int sa[4], sb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[i] = asm_ds_read_u8(s_sa + (wm * 64 + i * 16 + r) * 4 + g);
+            sb[i] = asm_ds_read_u8(s_sb + (wn * 64 + i * 16 + r) * 4 + g);
+        }
+        v8i fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag_asm<FA>(s_a, wm * 64 + i * 16 + r, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag_asm<FB>(s_b, wn * 64 + j * 16 + r, g);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);               // no MFMA above the wait: the asm results are not tracked
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
+    };
     if constexpr (STAGES == 1) {
         for (int kt = 0; kt < nk; ++kt) {
-            issue(kt, 0);
+            issue(kt, lds);
             __syncthreads();
-            compute(0);
+            compute(lds);
             __syncthreads();
         }
     } else {
+        // ring of STAGES tiles: tiles kt+1 .. kt+STAGES-1 are in flight while tile kt is multiplied
         constexpr int kPieces = DA::kInstr + DB::kInstr + 1;         // DMA instructions one wave issues per stage
-        static_assert(kPieces == 9 || kPieces == 7 || kPieces == 5, "vmcnt immediates below");
-        issue(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) {
-                issue(kt + 1, (kt + 1) & 1);
-                // tile kt's pieces are the older ones: wait until only the kPieces just issued remain
-                if constexpr (kPieces == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else if constexpr (kPieces == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < nk) issue(p, ring_stage_of<kStage>(p));
+        for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+            for (int sidx = 0; sidx < STAGES; ++sidx) {              // unrolled: every stage is a compile-time object
+                const int kt = kt0 + sidx;
+                if (kt < nk) {
+                    const int ahead = kt + STAGES - 1;
+                    if (ahead < nk) {
+                        issue(ahead, ring_stage_of<kStage>((sidx + STAGES - 1) % STAGES));
+                        // tile kt's pieces are the oldest: wait until only the (STAGES - 1) younger tiles' pieces remain
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * kPieces) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // pipeline drain: the last STAGES - 1 tiles
+                    }
+                    __builtin_amdgcn_s_barrier();                    // every wave's pieces of tile kt have landed
+                    compute_ring(ring_stage_of<kStage>(sidx));
+                    __builtin_amdgcn_s_barrier();                    // this stage may be refilled by the next issue
+                }
             }
-            __builtin_amdgcn_s_barrier();                            // every wave's pieces of tile kt have landed
-            compute(kt & 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                            // stage kt & 1 may be refilled (by the DMA of tile kt + 2)
         }
     }
 
@@ -499,19 +589,15 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     const bool dma_ok = !no_dma && K % kBK == 0 && (((uintptr_t)a_e8m0 | (uintptr_t)b_e8m0) & 3u) == 0;
     static const int force_stages = getenv("QT_MX_STAGES") ? atoi(getenv("QT_MX_STAGES")) : 0;          // tuning / A-B switch
     const long nblocks = (long)grid.x * grid.y;
-    const bool two = force_stages ? force_stages == 2 : nblocks <= 2L * 256;        // <= 2 workgroups per CU: prefetch
+    // Up to two workgroups per CU: the two-stage prefetch ring (a tile's load latency would otherwise be exposed on
+    // every step).  Larger grids: one stage, three resident workgroups per CU cover each other.  Deeper rings
+    // (4-8 stages at one workgroup per CU) measured no better than two stages at two workgroups per CU.
+    const bool ring = force_stages ? force_stages >= 2 : nblocks <= 2L * 256;
 #define QT_MX_DMA(FA, FB)                                                                                          \
     if (dma_ok && a_format == FA && b_format == FB) {                                                              \
         constexpr int kLds = Tile<FA>::kBytes + Tile<FB>::kBytes + 1024;                                           \
-        if (two) {                                                                                                 \
-            static bool configured = false;                                                                        \
-            if (!configured) {                                                                                     \
-                const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_dma_kernel<FA, FB, 2>,              \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLds);    \
-                if (e != hipSuccess) return (int)e;                                                                \
-                configured = true;                                                                                 \
-            }                                                                                                      \
-            mx_gemm_dma_kernel<FA, FB, 2><<<grid, 256, 2 * kLds, st>>>(g);                                         \
+        if (ring) {                                                                                                \
+            mx_gemm_dma_kernel<FA, FB, 2><<<grid, 256, 0, st>>>(g);              /* static LDS, one object per stage */ \
         } else {                                                                                                   \
             mx_gemm_dma_kernel<FA, FB, 1><<<grid, 256, kLds, st>>>(g);                                             \
         }                                                                                                          \
