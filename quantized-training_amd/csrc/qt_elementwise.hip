@@ -431,6 +431,51 @@ __global__ __launch_bounds__(256) void fq_pc_kernel(const void *__restrict__ xv,
     }
 }
 
+// Vectorised form for rows made of whole 16-byte vectors (weights [C, K] with K % 8 == 0, conv weights, ...): one
+// workgroup per (outer, c) row, 16-B loads / stores, the row's scale in a register, per-channel amax by one atomicMax.
+template <int IO, int KIND>
+__global__ __launch_bounds__(256) void fq_pc_vec_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t rows,
+                                                       size_t C, size_t vpr, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                       const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<KIND> rnd{fmt, lut};
+    __shared__ uint32_t s_part[4];
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const size_t c = row % C;
+        float s = scale ? scale[c] : 1.0f;
+        if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+        const bool unit = (s == 1.0f);
+        const UniformDiv dv(s);
+        uint32_t amax = 0;
+        const uint4 *xr = x + row * vpr;
+        uint4 *yr = y ? y + row * vpr : nullptr;
+        for (size_t i = threadIdx.x; i < vpr; i += 256) {
+            const uint4 in = xr[i];
+            uint4 r;
+            if (amax_out) {
+                if (unit) r = fq_vec<IO, KIND, kDivUnit, true>(in, dv, rnd, amax);
+                else if (dv.safe) r = fq_vec<IO, KIND, kDivFast, true>(in, dv, rnd, amax);
+                else r = fq_vec<IO, KIND, kDivExact, true>(in, dv, rnd, amax);
+            } else {
+                if (unit) r = fq_vec<IO, KIND, kDivUnit, false>(in, dv, rnd, amax);
+                else if (dv.safe) r = fq_vec<IO, KIND, kDivFast, false>(in, dv, rnd, amax);
+                else r = fq_vec<IO, KIND, kDivExact, false>(in, dv, rnd, amax);
+            }
+            if (yr) yr[i] = r;
+        }
+        if (amax_out) {
+            amax = wave_max_u32(amax);
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = amax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t m = s_part[0];
+                for (int i = 1; i < 4; ++i) m = m > s_part[i] ? m : s_part[i];
+                if (m) atomicMax(amax_out + c, m);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // inner == 1 (channel is the fastest dim): element i belongs to channel i % C
 template <int IO, int KIND>
 __global__ __launch_bounds__(256) void fq_pc_last_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t n,
@@ -682,9 +727,14 @@ template <int IO, int KIND>
 int launch_pc_kind(const void *x, void *y, size_t outer, size_t C, size_t inner, const qt_format &fmt,
                    const uint16_t *lut, const float *scale, uint32_t *amax, hipStream_t st) {
     const size_t n = outer * C * inner;
+    constexpr size_t kPer = IO == kIoBf16 ? 8 : 4;
     if (inner == 1) {
         unsigned grid = grid_for(n, 256 * 4, 8);
         fq_pc_last_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, n, C, fmt, lut, scale, amax);
+    } else if (inner % kPer == 0 && inner >= 64 * kPer && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0)) {
+        unsigned grid = grid_for(outer * C, 1, 16);
+        fq_pc_vec_kernel<IO, KIND><<<grid, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, outer * C, C, inner / kPer, fmt, lut,
+                                                         scale, amax);
     } else {
         unsigned grid = grid_for(outer * C, 1, 16);
         fq_pc_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, outer, C, inner, fmt, lut, scale, amax);

@@ -921,3 +921,31 @@ def test_rmsnorm_within_bf16_rounding_of_the_torch_chain(nv):
         # the weight multiply then rounds once more, so y is at most two bf16 codes away, on isolated elements
         assert int((a - b).abs().max()) <= 2
         assert float((a != b).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype_name", ["int8", "e4m3", "posit8_1"])
+@pytest.mark.parametrize("tdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape,axis", [((96, 1024), 0), ((5, 24, 640), 1), ((64, 100), 0)])
+def test_per_channel_module_device_vs_cpu(nv, dtype_name, tdtype, shape, axis):
+    """per_channel_symmetric fake-quant (fake_quantize.py:218-221): rows of whole 16-byte vectors take the vectorised
+    kernel, the last shape the element-wise one; outputs, scales and amax history identical to the CPU formulas."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    from quantized_training.quantizer.quantizer import QuantizationSpec
+    from quantized_training.quantizer.quantizer import QScheme, get_quant_min_max
+    if dtype_name == "e4m3":                      # the reference has no default range for the bare name
+        qmin, qmax = -448.0, 448.0
+    else:
+        qmin, qmax = get_quant_min_max(dtype_name)
+    g = torch.Generator().manual_seed(4)
+    xs = [(torch.randn(*shape, generator=g) * (3.0 ** i)).to(tdtype) for i in range(3)]
+    outs = {}
+    for dev in ("cpu", "cuda"):
+        fq = FusedAmaxObsFakeQuantize(dtype=dtype_name, qscheme=QScheme.PER_CHANNEL_SYMMETRIC, quant_min=qmin, quant_max=qmax,
+                                      amax_history_len=3, ch_axis=axis).to(dev)
+        ys = [fq(x.to(dev)) for x in xs]
+        outs[dev] = (ys, fq.scale.clone(), fq.amax_history.clone())
+    (y0, s0, a0), (y1, s1, a1) = outs["cpu"], outs["cuda"]
+    for a, b in zip(y0, y1):
+        assert _same_bits(a, b)
+    assert torch.equal(s0, s1.cpu()) and torch.equal(a0, a1.cpu())
