@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/qt_hip.h"
 #include "qt_formats.h"
 #include "qt_mx.h"
@@ -281,6 +283,37 @@ __device__ __forceinline__ int asm_ds_read_u8(uint32_t addr) {
     asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// Immediate-offset forms: within a wave's column of 16-row fragment tiles the swizzle depends on the lane only, so
+// tile i is the lane's base address + i * (16 rows), a compile-time offset -- one address register per operand
+// instead of one per read.
+template <int OFF>
+__device__ __forceinline__ uint4 asm_ds_read_b128_off(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ int asm_ds_read_u8_off(uint32_t addr) {
+    int v;
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// bytes from one 16-row fragment tile to the next in the LDS image of format F (8- and 4-bit tiles only)
+template <int F>
+constexpr int frag_step() { return 16 * Tile<F>::kRow; }
+template <int F, int I>
+__device__ __forceinline__ v8i read_frag_imm(uint32_t lane_lo, uint32_t lane_hi) {
+    static_assert(F < 2 || F == 4, "immediate-offset reads: fp8 / fp4 images");
+    v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4 lo = asm_ds_read_b128_off<I * frag_step<F>()>(lane_lo);
+    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+    if constexpr (F < 2) {
+        const uint4 hi = asm_ds_read_b128_off<I * frag_step<F>()>(lane_hi);
+        f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    }
+    return f;
+}
+
 template <int F>
 __device__ __forceinline__ v8i read_frag_asm(uint32_t tile, int row, int g) {
     v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -495,6 +528,158 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
     }
 }
 
+// ---- 256 x 256 tiles for large GEMMs --------------------------------------------------------------------------
+// At 128 x 128 the 8192^3 GEMMs are bound by operand re-reads through L2 (~12.5 TB/s); a 256 x 256 tile halves them.
+// 8 waves x (128 x 64): 32 accumulator tiles per wave (128 accumulator registers) leave room for two waves per SIMD,
+// one workgroup per CU, two-stage LDS-DMA ring (2 x 66 KiB), fragment reads as immediate-offset inline asm.
+template <int FA, int FB>
+__global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
+    using TA = Tile<FA>;
+    using TB = Tile<FB>;
+    using DA = DmaTile<FA>;
+    using DB = DmaTile<FB>;
+    constexpr int kTM = 256, kTN = 256, kWaves = 8;
+    constexpr int kABytes = 2 * TA::kBytes, kBBytes = 2 * TB::kBytes;          // 256 rows each
+    constexpr int kStage = kABytes + kBBytes + 2048;                           // + 256 x 4 scale bytes per operand
+    constexpr int NA = kTM / DA::kRows / kWaves, NB = kTN / DB::kRows / kWaves; // DMA pieces per wave
+    constexpr int kPieces = NA + NB + 1;
+
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int r = l & 15, g = l >> 4;
+    const int wm = w >> 2, wn = w & 3;
+    const int tiles_m = (a.M + kTM - 1) / kTM, tiles_n = (a.N + kTN - 1) / kTN;
+    const int ntiles = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    constexpr int kGroup = 4;
+    const int width = kGroup * tiles_n, grp = id / width, first_m = grp * kGroup;
+    const int gsize = min(tiles_m - first_m, kGroup);
+    const int m0 = (first_m + (id % width) % gsize) * kTM, n0 = ((id % width) / gsize) * kTN;
+    const long bz = blockIdx.y;
+    const long kbA = (long)a.K * elem_bits(FA) / 8, kbB = (long)a.K * elem_bits(FB) / 8;
+    const int nblk = a.K / 32, nk = a.K / kBK;
+
+    const uint8_t *ga[NA], *gb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (w * NA + i) * DA::kRows + l / DA::kChunks, cs = l % DA::kChunks;
+        ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * kbA + swz_chunk<FA>(row, cs) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (w * NB + i) * DB::kRows + l / DB::kChunks, cs = l % DB::kChunks;
+        gb[i] = a.B + bz * a.bB + (long)min(n0 + row, a.N - 1) * kbB + swz_chunk<FB>(row, cs) * 16;
+    }
+    // scale bytes: 256 rows x 4 bytes per operand = 8 pieces of 64 rows; waves 0-3 fetch A's, waves 4-7 fetch B's
+    const int srow = (w & 3) * 64 + l;
+    const uint8_t *gs = w < 4 ? a.sA + bz * a.bsA + (long)min(m0 + srow, a.M - 1) * nblk
+                              : a.sB + bz * a.bsB + (long)min(n0 + srow, a.N - 1) * nblk;
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
+        uint8_t *const s_a = stage, *const s_b = s_a + kABytes, *const s_s = s_b + kBBytes;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow), (lds_void *)(s_a + (w * NA + i) * DA::kStride), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow), (lds_void *)(s_b + (w * NB + i) * DB::kStride), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)(s_s + w * 256), 4, 0, 0);
+    };
+    // lane-constant parts of the fragment addresses (row r of fragment tile 0 of this wave's band, chunks g and 4 + g)
+    const uint32_t a_lo = TA::chunk_off(wm * 128 + r, g), a_hi = TA::chunk_off(wm * 128 + r, (FA < 2 ? 4 : 0) + g);
+    const uint32_t b_lo = TB::chunk_off(wn * 64 + r, g), b_hi = TB::chunk_off(wn * 64 + r, (FB < 2 ? 4 : 0) + g);
+    const uint32_t sa_off = (wm * 128 + r) * 4 + g, sb_off = (wn * 64 + r) * 4 + g;
+    // A fragments are read in two halves of four row tiles so that at most 8 fragments (64 registers for 8-bit
+    // operands) are live next to the 128 accumulator registers: with all 12 live the 8-bit kernels spilled, and scratch
+    // traffic shares the vmcnt queue with the LDS-DMA ring (every spill reload would drain it).
+    int sa[4], sb[4];
+    v8i fa[4], fb[4];
+    auto read_a = [&](uint32_t base, uint32_t sbase, auto idx, auto half) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx)::value, H = decltype(half)::value;
+        sa[I] = asm_ds_read_u8_off<(4 * H + I) * 64>(sbase + sa_off);
+        fa[I] = read_frag_imm<FA, 4 * H + I>(base + a_lo, base + a_hi);
+    };
+    auto read_b = [&](uint32_t base, uint32_t sbase, auto idx) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx)::value;
+        sb[I] = asm_ds_read_u8_off<I * 64>(sbase + sb_off);
+        fb[I] = read_frag_imm<FB, I>(base + b_lo, base + b_hi);
+    };
+#define QT_I(n) std::integral_constant<int, n>{}
+    auto compute = [&](const uint8_t *stage) __attribute__((always_inline)) {
+        const uint32_t s_a = lds_addr(stage), s_b = s_a + kABytes, s_sa = s_b + kBBytes, s_sb = s_sa + 1024;
+        read_b(s_b, s_sb, QT_I(0)); read_b(s_b, s_sb, QT_I(1)); read_b(s_b, s_sb, QT_I(2)); read_b(s_b, s_sb, QT_I(3));
+        read_a(s_a, s_sa, QT_I(0), QT_I(0)); read_a(s_a, s_sa, QT_I(1), QT_I(0));
+        read_a(s_a, s_sa, QT_I(2), QT_I(0)); read_a(s_a, s_sa, QT_I(3), QT_I(0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(s_a, s_sa, QT_I(0), QT_I(1)); read_a(s_a, s_sa, QT_I(1), QT_I(1));
+        read_a(s_a, s_sa, QT_I(2), QT_I(1)); read_a(s_a, s_sa, QT_I(3), QT_I(1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[4 + i][j], FA, FB, 0, sa[i], 0, sb[j]);
+    };
+#undef QT_I
+
+    issue(0, ring_stage_of<kStage>(0));
+    for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int kt = kt0 + sidx;
+            if (kt < nk) {
+                if (kt + 1 < nk) {
+                    issue(kt + 1, ring_stage_of<kStage>(sidx ^ 1));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                compute(ring_stage_of<kStage>(sidx));
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    const long cbase = bz * a.bC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= a.N) continue;
+        float bv = 0.f;
+        if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wm * 128 + i * 16 + 4 * g + e;
+                if (row >= a.M) continue;
+                const float v = acc[i][j][e] + bv;
+                const long idx = cbase + (long)row * a.N + col;
+                if (a.out_f32) ((float *)a.C)[idx] = v;
+                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+            }
+        }
+    }
+}
+
 // ---- packing: (values, block scales) -> element codes + E8M0 ------------------------------------------------
 // A value that the format holds exactly converts exactly; anything else (and a scale that is not a power of
 // two) raises the `bad` flag so the caller can fall back to the dequantize + GEMM path.
@@ -593,6 +778,17 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     // every step).  Larger grids: one stage, three resident workgroups per CU cover each other.  Deeper rings
     // (4-8 stages at one workgroup per CU) measured no better than two stages at two workgroups per CU.
     const bool ring = force_stages ? force_stages >= 2 : nblocks <= 2L * 256;
+    static const int force_big = getenv("QT_MX_BIG") ? atoi(getenv("QT_MX_BIG")) : -1;                      // tuning / A-B switch
+    const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = dma_ok && (force_big >= 0 ? force_big == 1 : (M >= 512 && N >= 512 && big_tiles >= 192));
+#define QT_MX_BIG(FA, FB)                                                                                          \
+    if (big && a_format == FA && b_format == FB) {                                                                 \
+        const dim3 bgrid((unsigned)big_tiles, (unsigned)batch);                                                    \
+        mx_gemm_big_kernel<FA, FB><<<bgrid, 512, 0, st>>>(g);                                                      \
+        return launch_status();                                                                                    \
+    }
+    QT_MX_BIG(0, 0) QT_MX_BIG(0, 1) QT_MX_BIG(1, 0) QT_MX_BIG(1, 1) QT_MX_BIG(4, 4) QT_MX_BIG(0, 4)
+#undef QT_MX_BIG
 #define QT_MX_DMA(FA, FB)                                                                                          \
     if (dma_ok && a_format == FA && b_format == FB) {                                                              \
         constexpr int kLds = Tile<FA>::kBytes + Tile<FB>::kBytes + 1024;                                           \
