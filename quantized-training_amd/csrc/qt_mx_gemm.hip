@@ -298,13 +298,25 @@ __device__ __forceinline__ int asm_ds_read_u8_off(uint32_t addr) {
     asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// bytes from one 16-row fragment tile to the next in the LDS image of format F (8- and 4-bit tiles only)
+template <int OFF>
+__device__ __forceinline__ uint2 asm_ds_read_b64_off(uint32_t addr) {
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// bytes from one 16-row fragment tile to the next in the LDS image of format F (6-bit: two 8-row groups)
 template <int F>
-constexpr int frag_step() { return 16 * Tile<F>::kRow; }
+constexpr int frag_step() { return Tile<F>::kSix ? 2 * Tile<F>::kGroup : 16 * Tile<F>::kRow; }
 template <int F, int I>
 __device__ __forceinline__ v8i read_frag_imm(uint32_t lane_lo, uint32_t lane_hi) {
-    static_assert(F < 2 || F == 4, "immediate-offset reads: fp8 / fp4 images");
     v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (Tile<F>::kSix) {                       // lane_lo = row offset + 24 g; three 8-byte reads
+        const uint2 a = asm_ds_read_b64_off<I * frag_step<F>()>(lane_lo);
+        const uint2 b = asm_ds_read_b64_off<I * frag_step<F>() + 8>(lane_lo);
+        const uint2 c = asm_ds_read_b64_off<I * frag_step<F>() + 16>(lane_lo);
+        f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y;
+        return f;
+    }
     const uint4 lo = asm_ds_read_b128_off<I * frag_step<F>()>(lane_lo);
     f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
     if constexpr (F < 2) {
@@ -565,12 +577,14 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
     const uint8_t *ga[NA], *gb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (w * NA + i) * DA::kRows + l / DA::kChunks, cs = l % DA::kChunks;
+        const int ll = min(l, DA::kLanes - 1);
+        const int row = (w * NA + i) * DA::kRows + ll / DA::kChunks, cs = ll % DA::kChunks;
         ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * kbA + swz_chunk<FA>(row, cs) * 16;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (w * NB + i) * DB::kRows + l / DB::kChunks, cs = l % DB::kChunks;
+        const int ll = min(l, DB::kLanes - 1);
+        const int row = (w * NB + i) * DB::kRows + ll / DB::kChunks, cs = ll % DB::kChunks;
         gb[i] = a.B + bz * a.bB + (long)min(n0 + row, a.N - 1) * kbB + swz_chunk<FB>(row, cs) * 16;
     }
     // scale bytes: 256 rows x 4 bytes per operand = 8 pieces of 64 rows; waves 0-3 fetch A's, waves 4-7 fetch B's
@@ -588,15 +602,19 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
         uint8_t *const s_a = stage, *const s_b = s_a + kABytes, *const s_s = s_b + kBBytes;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow), (lds_void *)(s_a + (w * NA + i) * DA::kStride), 16, 0, 0);
+            if (DA::kLanes == 64 || l < DA::kLanes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * TA::kRow), (lds_void *)(s_a + (w * NA + i) * DA::kStride), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow), (lds_void *)(s_b + (w * NB + i) * DB::kStride), 16, 0, 0);
+            if (DB::kLanes == 64 || l < DB::kLanes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + (long)kt * TB::kRow), (lds_void *)(s_b + (w * NB + i) * DB::kStride), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void *)(gs + kt * 4), (lds_void *)(s_s + w * 256), 4, 0, 0);
     };
     // lane-constant parts of the fragment addresses (row r of fragment tile 0 of this wave's band, chunks g and 4 + g)
-    const uint32_t a_lo = TA::chunk_off(wm * 128 + r, g), a_hi = TA::chunk_off(wm * 128 + r, (FA < 2 ? 4 : 0) + g);
-    const uint32_t b_lo = TB::chunk_off(wn * 64 + r, g), b_hi = TB::chunk_off(wn * 64 + r, (FB < 2 ? 4 : 0) + g);
+    const uint32_t a_lo = TA::kSix ? TA::row_off(wm * 128 + r) + 24 * g : TA::chunk_off(wm * 128 + r, g);
+    const uint32_t a_hi = TA::chunk_off(wm * 128 + r, (FA < 2 ? 4 : 0) + g);
+    const uint32_t b_lo = TB::kSix ? TB::row_off(wn * 64 + r) + 24 * g : TB::chunk_off(wn * 64 + r, g);
+    const uint32_t b_hi = TB::chunk_off(wn * 64 + r, (FB < 2 ? 4 : 0) + g);
     const uint32_t sa_off = (wm * 128 + r) * 4 + g, sb_off = (wn * 64 + r) * 4 + g;
     // A fragments are read in two halves of four row tiles so that at most 8 fragments (64 registers for 8-bit
     // operands) are live next to the 128 accumulator registers: with all 12 live the 8-bit kernels spilled, and scratch
@@ -788,6 +806,7 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
         return launch_status();                                                                                    \
     }
     QT_MX_BIG(0, 0) QT_MX_BIG(0, 1) QT_MX_BIG(1, 0) QT_MX_BIG(1, 1) QT_MX_BIG(4, 4) QT_MX_BIG(0, 4)
+    QT_MX_BIG(2, 2) QT_MX_BIG(3, 3) QT_MX_BIG(2, 4) QT_MX_BIG(3, 4)
 #undef QT_MX_BIG
 #define QT_MX_DMA(FA, FB)                                                                                          \
     if (dma_ok && a_format == FA && b_format == FB) {                                                              \
