@@ -748,12 +748,14 @@ def test_mx_pack_matches_host_restatement(nv, fmt, dtype):
                                    ("fp8_e5m2", "fp8_e5m2"), ("fp6_e2m3", "fp6_e2m3"), ("fp6_e3m2", "fp6_e3m2"),
                                    ("fp4_e2m1", "fp4_e2m1"), ("fp8_e4m3", "fp4_e2m1"), ("fp6_e2m3", "fp4_e2m1"),
                                    ("fp6_e3m2", "fp4_e2m1")])
-@pytest.mark.parametrize("shape", [(128, 128, 128), (200, 328, 448), (1, 64, 64), (1024, 512, 1024)])
+@pytest.mark.parametrize("shape", [(128, 128, 128), (200, 328, 448), (1, 64, 64), (1024, 512, 1024), (3600, 3400, 256)])
 def test_mx_gemm_vs_dequantized_reference(nv, fa, fb, shape):
     """C = (a * expand(sa)) @ (b * expand(sb))^T exactly as linear_mx states it.  Products of MX elements and
     power-of-two scales are exact; the instruction adds the 128 products of a step in an aligned fixed-point tree that
     keeps fewer bits than an fp32 chain (measured: up to 2^-16 of sum|a||b|), so the bound is |err| <= 2^-14 * sum|a||b|
-    for the fp32 result; the bf16 result adds one rounding (2^-9 relative, 2^-8 allowed)."""
+    for the fp32 result; the bf16 result adds one rounding (2^-9 relative, 2^-8 allowed).  The shapes reach every
+    kernel variant: register-staged (ragged K), one-stage and two-stage LDS-DMA at 128 x 128, and the 256 x 256 ring
+    kernel with ragged M and N (3600 x 3400: 15 x 14 tiles)."""
     L = nv.lib()
     M, N, K = shape
     sa, qa = _mx_operand(M, K, fa, 32, torch.float32, seed=1, sigma=2.0)
