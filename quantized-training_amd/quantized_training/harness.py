@@ -83,7 +83,9 @@ class GraphedWindow:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a collective library's watchdog thread (multi-GPU runs) may issue its own event queries while
+        # this thread captures; only this thread's calls belong to the graph
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._forward()
 
     def _set(self, ids, trg_len):
