@@ -211,6 +211,9 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
         const uint16_t *mrow = a.mask + b * a.mask_sb + h * a.mask_sh + (long)(qr < a.Sq ? qr : a.Sq - 1) * a.mask_sq;
         // bf16 pattern >= 0xF14A  <=>  value <= -1e30 (negative, magnitude >= 1e30; -inf and NaN-free masks)
         const bool vec_ok = ((a.mask_sb | a.mask_sh | a.mask_sq) % 8 == 0) && (((uintptr_t)a.mask & 15u) == 0) && (a.Sk % 8 == 0);
+        // every thread scans its 16-key slice of all tiles first (loads independent of each other, no barrier in
+        // between), then ONE block-wide AND of the per-thread "tile is dead" bit sets
+        unsigned long long dead_bits = 0ull;
         for (int kt = 0; kt < ntiles; ++kt) {
             bool dead = true;
             const int kb = kt * kBK + (tid & 3) * 16;
@@ -228,8 +231,20 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
                 for (int e = 0; e < 16; ++e)
                     if (kb + e < a.Sk) dead &= mrow[kb + e] >= 0xF14Au;
             }
-            if (!__syncthreads_and(dead)) live |= 1ull << kt;
+            if (dead) dead_bits |= 1ull << kt;
         }
+        // wave AND by shuffles, then across the four waves through LDS
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)dead_bits, off, 64), hi = __shfl_xor((unsigned)(dead_bits >> 32), off, 64);
+            dead_bits &= ((unsigned long long)hi << 32) | lo;
+        }
+        unsigned long long *s_dead = (unsigned long long *)lds;              // LDS is not in use yet
+        if (lane == 0) s_dead[wave] = dead_bits;
+        __syncthreads();
+        dead_bits = s_dead[0] & s_dead[1] & s_dead[2] & s_dead[3];
+        __syncthreads();
+        live = ~dead_bits & (ntiles == 64 ? ~0ull : ((1ull << ntiles) - 1ull));
+        if (live == (ntiles == 64 ? ~0ull : ((1ull << ntiles) - 1ull))) live = ~0ull;     // nothing to skip
     }
 
     // ---- pass 1: row max and row sum ----------------------------------------------------------------
