@@ -15,8 +15,8 @@ os.makedirs(out, exist_ok=True)
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)))
-    return f[-1] if f else None
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return max(f, key=os.path.getmtime) if f else None          # the latest session's file, whatever its numeric prefix
 
 
 def pmc(path, name, kernel="fq_kernel"):
