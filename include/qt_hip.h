@@ -266,6 +266,11 @@ int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint
 int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, long rows, long cols, float eps,
                     void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t n, void *stream);
+/* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:
+ * y = fq(bf16(bf16(silu(gate)) * up)) as bf16 plus its FP8 code -- what the down-projection's input hook would compute
+ * from the unfused result (quantize.py:128-140), bit for bit. */
+int qt_silu_mul_fq8_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n,
+                         const qt_format *fmt, void *stream);
 int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
                  uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, void *stream);
 

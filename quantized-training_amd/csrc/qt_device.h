@@ -16,6 +16,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// four on-grid values -> four OCP FP8 bytes (exact for values the format holds)
+template <bool E5M2>
+__device__ __forceinline__ uint32_t qt_pack_fp8x4(float a, float b, float c, float d) {
+    int w = 0;
+    if constexpr (E5M2) {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    }
+    return (uint32_t)w;
+}
+
 // x / s for a wave-uniform divisor, bit-identical to what torch computes.
 //
 // The quotient is only ever consumed through a 16-bit view: rounded to bf16 (bf16 tensors) or folded

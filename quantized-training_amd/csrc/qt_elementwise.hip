@@ -212,19 +212,6 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__
 // can hand the GEMM one byte per element: y8 = fp8(q), and optionally the usual y = bf16(q * s).
 // (q, s) is what the reference's converted graphs feed to the GEMM: quantize -> GEMM ->
 // dequantize(s_x * s_w), quantize_pt2e.py:323-446.
-template <bool E5M2>
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    int w = 0;
-    if constexpr (E5M2) {
-        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
-        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
-    } else {
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    }
-    return (uint32_t)w;
-}
-
 // Quantise one 16-B vector of bf16 to eight fp32 images of q = map[x / s].
 __device__ __forceinline__ void fq8_vec(const uint4 v, const qt_format &fmt, const UniformDiv &dv, bool unit, bool obs,
                                         uint32_t &amax, float (&q)[8]) {
@@ -292,10 +279,10 @@ __global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, u
         fq8_vec(v0, fmt, dv, unit, OBS, amax, q0);
         fq8_vec(v1, fmt, dv, unit, OBS, amax, q1);
         uint4 o8;
-        o8.x = pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
-        o8.y = pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
-        o8.z = pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
-        o8.w = pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
+        o8.x = qt_pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
+        o8.y = qt_pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
+        o8.z = qt_pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
+        o8.w = qt_pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
         y8[i] = o8;
         if constexpr (BOTH) {
             y[2 * i] = bf16_vec_from(q0, s, unit);

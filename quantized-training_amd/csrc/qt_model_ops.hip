@@ -84,6 +84,33 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint4 *__restrict__
     }
 }
 
+// SiLU * up with the consumer's fake-quantizer (stateless E4M3 / E5M2, unit scale) applied to the product on the way
+// out: writes the quantized bf16 tensor and its FP8 code, i.e. silu_mul_kernel + fq8_kernel without the round trip of
+// the intermediate through HBM.  Same values as the two-kernel sequence, bit for bit.
+template <bool E5M2>
+__global__ __launch_bounds__(256) void silu_mul_fq8_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ u,
+                                                           uint4 *__restrict__ y, uint2 *__restrict__ y8, size_t nvec,
+                                                           qt_format fmt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 a = g[i], b = u[i];
+        const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
+            const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+            const uint32_t h = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));            // the unquantized product, bf16
+            const uint32_t r0 = qt_fp_sat_u32(h << 16, fmt.p0, fmt.p1, fmt.fhi), r1 = qt_fp_sat_u32(h & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
+            o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+            r[2 * j] = qt_u2f(r0);
+            r[2 * j + 1] = qt_u2f(r1);
+        }
+        y[i] = uint4{o[0], o[1], o[2], o[3]};
+        y8[i] = uint2{qt_pack_fp8x4<E5M2>(r[0], r[1], r[2], r[3]), qt_pack_fp8x4<E5M2>(r[4], r[5], r[6], r[7])};
+    }
+}
+
 struct RopeArgs {
     const uint16_t *x;       // [B][S][H][D] memory order
     uint16_t *y;
@@ -151,6 +178,24 @@ int qt_silu_mul_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, size
     size_t blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     silu_mul_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, nvec);
+    return launch_status();
+}
+
+int qt_silu_mul_fq8_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt,
+                         void *stream) {
+    if (n == 0) return QT_OK;
+    if (!gate || !up || !y || !y8 || !fmt || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if ((n & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = n / 8;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (e5m2)
+        silu_mul_fq8_kernel<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
+    else
+        silu_mul_fq8_kernel<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
     return launch_status();
 }
 

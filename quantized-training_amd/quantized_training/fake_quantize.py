@@ -550,7 +550,19 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             if self.scale_qmap is not None:
                 self.scale_qmap = _table_for(self.scale_dtype, device)
 
+    def producer_fusable(self) -> bool:
+        """True when this fake-quantizer is a pure stateless function a producing kernel may apply on its behalf
+        (model_fusions.py): quantize on, observer off, per-tensor, unit scale, closed-form E4M3 / E5M2."""
+        return (self._quantize and not self._observe and self.qscheme is None and not self.is_per_channel
+                and not self.record_histogram and self.outlier_threshold is None and self.fp8_exact())
+
     def forward(self, X: torch.Tensor) -> torch.Tensor:
+        done_by = getattr(X, "_qt_fq_done_by", None)
+        if done_by is self:
+            # the kernel that produced X already applied this fake-quantizer (and attached X._qt_fp8): the call the
+            # reference issues here is satisfied by that fused computation, counted once
+            _Stats.add(X.numel())
+            return X
         self._move_to(X.device)
 
         if self.record_histogram:                                            # upstream :348-350

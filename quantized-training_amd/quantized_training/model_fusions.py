@@ -10,12 +10,13 @@ csrc/qt_model_ops.hip when that changes nothing observable:
     differs only through the summation order of its mean (isolated outputs move by one bf16 ulp).
 `QT_FUSED_MODEL_OPS=0` keeps HF's own code everywhere.
 """
+import ctypes
 import os
 
 import torch
 
 from . import _native
-from .fake_quantize import _stream_ptr
+from .fake_quantize import FusedAmaxObsFakeQuantize, _stream_ptr
 
 __all__ = ["apply_llama_fusions", "rmsnorm", "silu_mul", "rope"]
 
@@ -52,6 +53,35 @@ def silu_mul(gate, up):
     return y
 
 
+def consumer_fq(linear):
+    """The input fake-quantizer of a QAT Linear when a producing kernel may apply it (see
+    FusedAmaxObsFakeQuantize.producer_fusable), else None.  It exists only after the layer's first call."""
+    holder = getattr(linear, "activation_pre_process", None)
+    if holder is None or len(linear._forward_pre_hooks) != 1 or "0" not in holder or len(holder) != 1:
+        return None
+    fq = holder["0"]
+    if not isinstance(fq, FusedAmaxObsFakeQuantize) or not fq.producer_fusable():
+        return None
+    return fq
+
+
+def _fp8_view(t8, fq):
+    return t8.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn)
+
+
+def silu_mul_fq(gate, up, fq):
+    """SiLU * up with `fq` (the down-projection's input fake-quantizer) applied in the same pass; the result is
+    marked so that the hook returns it unchanged."""
+    g, u = gate.contiguous(), up.contiguous()
+    y = torch.empty_like(g)
+    y8 = torch.empty(g.shape, dtype=torch.uint8, device=g.device)
+    _native.check(_native.lib().qt_silu_mul_fq8_bf16(g.data_ptr(), u.data_ptr(), y.data_ptr(), y8.data_ptr(), g.numel(),
+                                                     ctypes.byref(fq._qt_format), _stream_ptr(g)), "qt_silu_mul_fq8_bf16")
+    y._qt_fp8 = _fp8_view(y8, fq)
+    y._qt_fq_done_by = fq
+    return y
+
+
 def rope(q, k, cos, sin):
     """q [B, Hq, S, D], k [B, Hk, S, D] as the transposed views of [B, S, H, D] buffers that HF's attention holds;
     returns tensors with the same shape and memory order, as the torch chain would."""
@@ -78,6 +108,9 @@ def _mlp_forward(self, x):
         gate = self.gate_proj(x)
         up = self.up_proj(x)
         if _eligible(gate, up) and gate.shape == up.shape and gate.numel() % 8 == 0 and gate.numel() > 0:
+            fq = consumer_fq(self.down_proj)
+            if fq is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0":
+                return self.down_proj(silu_mul_fq(gate, up, fq))
             return self.down_proj(silu_mul(gate, up))
         return self.down_proj(self.act_fn(gate) * up)
     return self._qt_hf_forward(x)

@@ -951,3 +951,28 @@ def test_per_channel_module_device_vs_cpu(nv, dtype_name, tdtype, shape, axis):
     for a, b in zip(y0, y1):
         assert _same_bits(a, b)
     assert torch.equal(s0, s1.cpu()) and torch.equal(a0, a1.cpu())
+
+
+def test_producer_fused_fake_quant_matches_the_hook(nv):
+    """SiLU * up with the down-projection's input fake-quantizer applied by the producing kernel: same bf16 values and
+    the same FP8 bytes as the unfused kernel followed by the hook's own pass; the hook then returns the tensor as is
+    and still counts the call."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize, STATS
+    g = torch.Generator(device="cuda").manual_seed(3)
+    gate = (torch.randn(512, 11008, device="cuda", generator=g) * 4).bfloat16()
+    up = (torch.randn(512, 11008, device="cuda", generator=g) * 100).bfloat16()      # reaches the saturation range
+    for dtype in ("e4m3", "e5m2"):
+        fq = FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+        fq._emit_fp8 = "both"
+        assert fq.producer_fusable()
+        with torch.no_grad():
+            want = fq(mf.silu_mul(gate, up))
+            got = mf.silu_mul_fq(gate, up, fq)
+            assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+            assert torch.equal(want._qt_fp8.view(torch.uint8), got._qt_fp8.view(torch.uint8))
+            STATS.reset()
+            again = fq(got)
+            assert again is got and STATS.elements == got.numel()
+            other = FusedAmaxObsFakeQuantize(dtype=dtype).cuda()               # a different fake-quantizer does its own pass
+            assert other(got) is not got
