@@ -305,9 +305,10 @@ struct RowsArgs {
     size_t nvec;
 };
 
-template <int KIND, bool OBS>
+template <int KIND, bool OBS, int FP8 = 0>          // FP8: 0 none, 1 also write E4M3 bytes, 2 E5M2 bytes (unit scale, FP_SAT kinds)
 __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt, const uint16_t *__restrict__ lut,
-                                                      const float *__restrict__ scale, uint32_t *amax_out) {
+                                                      const float *__restrict__ scale, uint32_t *amax_out,
+                                                      uint2 *__restrict__ y8 = nullptr) {
     Rounder<KIND> rnd{fmt, lut};
     float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
     const bool unit = (s == 1.0f);
@@ -323,6 +324,10 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
         else if (dv.safe) r = fq_vec<kIoBf16, KIND, kDivFast, OBS>(in, dv, rnd, amax);
         else r = fq_vec<kIoBf16, KIND, kDivExact, OBS>(in, dv, rnd, amax);
         ((uint4 *)a.y)[v] = r;
+        if constexpr (FP8 != 0) {                        // r holds on-grid values: their FP8 bytes are exact
+            y8[v] = uint2{qt_pack_fp8x4<FP8 == 2>(qt_u2f(r.x << 16), qt_u2f(r.x & 0xFFFF0000u), qt_u2f(r.y << 16), qt_u2f(r.y & 0xFFFF0000u)),
+                          qt_pack_fp8x4<FP8 == 2>(qt_u2f(r.z << 16), qt_u2f(r.z & 0xFFFF0000u), qt_u2f(r.w << 16), qt_u2f(r.w & 0xFFFF0000u))};
+        }
     }
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
@@ -864,6 +869,22 @@ int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, lo
         default: return QT_ERR_BAD_ARG;
     }
 #undef QT_ROWS
+    return launch_status();
+}
+
+int qt_fake_quant_rows_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, long d0, long d1, long d2, long inner, long s0,
+                                long s1, long s2, const qt_format *fmt, void *stream) {
+    if (d0 * d1 * d2 * inner == 0) return QT_OK;
+    if (!x || !y || !y8 || !fmt || d0 < 0 || d1 < 0 || d2 < 0 || inner < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if ((inner & 7) || ((s0 | s1 | s2) & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
+    RowsArgs a{x, y, d1, d2, inner / 8, s0, s1, s2, (size_t)(d0 * d1 * d2 * (inner / 8))};
+    const unsigned grid = grid_for(a.nvec, 256, 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (e5m2) fq_rows_kernel<QT_FMT_FP_SAT, false, 2><<<grid, 256, 0, st>>>(a, *fmt, nullptr, nullptr, nullptr, (uint2 *)y8);
+    else fq_rows_kernel<QT_FMT_FP_SAT, false, 1><<<grid, 256, 0, st>>>(a, *fmt, nullptr, nullptr, nullptr, (uint2 *)y8);
     return launch_status();
 }
 

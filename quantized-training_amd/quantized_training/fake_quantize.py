@@ -550,6 +550,11 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             if self.scale_qmap is not None:
                 self.scale_qmap = _table_for(self.scale_dtype, device)
 
+    def expect_prequantized(self, tensor, x8):
+        """A producing kernel wrote fq(values) into `tensor` (and the FP8 code into x8) for this fake-quantizer's NEXT
+        call; see forward()."""
+        self.__dict__["_qt_expected"] = (tensor.data_ptr(), tensor.numel(), tensor._version, x8)
+
     def producer_fusable(self) -> bool:
         """True when this fake-quantizer is a pure stateless function a producing kernel may apply on its behalf
         (model_fusions.py): quantize on, observer off, per-tensor, unit scale, closed-form E4M3 / E5M2."""
@@ -563,6 +568,16 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             # reference issues here is satisfied by that fused computation, counted once
             _Stats.add(X.numel())
             return X
+        expect = self.__dict__.get("_qt_expected")
+        if expect is not None:
+            # same hand-over when the producer's tensor reaches the hook as a view (a reshape in between drops Python
+            # attributes): the producer left the storage it wrote, valid for this -- the very next -- call only
+            self.__dict__["_qt_expected"] = None
+            ptr, numel, version, x8 = expect
+            if X.data_ptr() == ptr and X.numel() == numel and X._version == version and X.is_contiguous():
+                _Stats.add(numel)
+                X._qt_fp8 = x8
+                return X
         self._move_to(X.device)
 
         if self.record_histogram:                                            # upstream :348-350

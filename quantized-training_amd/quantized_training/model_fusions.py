@@ -82,6 +82,34 @@ def silu_mul_fq(gate, up, fq):
     return y
 
 
+def transpose_fq(out, fq):
+    """out [B, H, S, D] (what the P.V product returns) -> contiguous [B, S, H, D] with `fq` (the output projection's
+    input fake-quantizer) applied in the same pass; replaces `.transpose(1, 2).contiguous()` + the hook's own pass.
+    HF reshapes the result before the projection sees it, so the hand-over goes through fq.expect_prequantized."""
+    B, H, S, D = out.shape
+    src = out.transpose(1, 2)                                   # [B, S, H, D] view of the [B, H, S, D] buffer
+    y = torch.empty((B, S, H, D), dtype=out.dtype, device=out.device)
+    y8 = torch.empty((B, S, H, D), dtype=torch.uint8, device=out.device)
+    _native.check(_native.lib().qt_fake_quant_rows_bf16_fp8(out.data_ptr(), y.data_ptr(), y8.data_ptr(), B, S, H, D,
+                                                            src.stride(0), src.stride(1), src.stride(2),
+                                                            ctypes.byref(fq._qt_format), _stream_ptr(out)),
+                  "qt_fake_quant_rows_bf16_fp8")
+    fq.expect_prequantized(y, _fp8_view(y8, fq))
+    return y
+
+
+def attention_output(module, out):
+    """[B, H, S, D] attention result -> the [B, S, H, D] tensor HF's attention block expects, fused with the output
+    projection's input fake-quantizer when that is a stateless FP8 one (LLaMA-style blocks with `o_proj`)."""
+    proj = getattr(module, "o_proj", None)
+    if (proj is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" and _eligible(out) and out.dim() == 4
+            and out.is_contiguous() and out.shape[-1] % 8 == 0 and out.numel() > 0):
+        fq = consumer_fq(proj)
+        if fq is not None:
+            return transpose_fq(out, fq)
+    return out.transpose(1, 2).contiguous()
+
+
 def rope(q, k, cos, sin):
     """q [B, Hq, S, D], k [B, Hk, S, D] as the transposed views of [B, S, H, D] buffers that HF's attention holds;
     returns tensors with the same shape and memory order, as the torch chain would."""

@@ -58,7 +58,8 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     fused = fused_scores_to_probs_or_none(module, scores, attention_mask, scaling, dropout, value)
     if fused is not None:
         probs, out = fused
-        return out.transpose(1, 2).contiguous(), probs
+        from ...model_fusions import attention_output
+        return attention_output(module, out), probs
     scores = module.attn_scaling(scores, scaling)
     if attention_mask is not None:
         scores = scores + attention_mask[..., : key.shape[-2]]

@@ -976,3 +976,31 @@ def test_producer_fused_fake_quant_matches_the_hook(nv):
             assert again is got and STATS.elements == got.numel()
             other = FusedAmaxObsFakeQuantize(dtype=dtype).cuda()               # a different fake-quantizer does its own pass
             assert other(got) is not got
+
+
+def test_attention_output_fused_with_projection_input_fake_quant(nv):
+    """[B, H, S, D] -> [B, S, H, D] with the output projection's input fake-quantizer applied in the layout pass; the
+    hook receives a reshaped VIEW of that tensor (as HF's attention block does) and must hand it through with its FP8
+    code -- once; any other tensor, or a second call, takes the normal pass."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize, STATS
+    g = torch.Generator(device="cuda").manual_seed(9)
+    out = (torch.randn(2, 8, 96, 64, device="cuda", generator=g) * 3).bfloat16()
+    fq = FusedAmaxObsFakeQuantize(dtype="e4m3").cuda()
+    fq._emit_fp8 = "both"
+    with torch.no_grad():
+        ref_in = out.transpose(1, 2).contiguous().reshape(2, 96, -1)
+        want = fq(ref_in)
+        y = mf.transpose_fq(out, fq)
+        view = y.reshape(2, 96, -1).contiguous()                # what LlamaAttention.forward does next
+        STATS.reset()
+        got = fq(view)
+        assert got is view and STATS.elements == view.numel()
+        assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+        assert torch.equal(want._qt_fp8.view(torch.uint8).reshape(-1), got._qt_fp8.view(torch.uint8).reshape(-1))
+        again = fq(view)                                        # the expectation was for one call only
+        assert again is not view and torch.equal(again.view(torch.int16), got.view(torch.int16))
+        mf.transpose_fq(out, fq)
+        other = fq(ref_in)                                      # a different tensor: normal pass, expectation dropped
+        assert torch.equal(other.view(torch.int16), want.view(torch.int16))
+        assert fq.__dict__.get("_qt_expected") is None
