@@ -277,6 +277,11 @@ int qt_silu_mul_fq8_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint1
                          const qt_format *fmt, void *stream);
 int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
                  uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, void *stream);
+/* qt_rope_bf16 followed by the two stateless E4M3 / E5M2 fake-quantizers of qk_matmul's inputs, outputs contiguous in
+ * [B][H][S][D] order (what those hooks' permuted-view pass would write): three launches in one. */
+int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
+                    uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D,
+                    const qt_format *fmt_q, const qt_format *fmt_k, void *stream);
 
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).

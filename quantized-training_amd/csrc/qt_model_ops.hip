@@ -151,6 +151,54 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeArgs q, RopeArgs k) {
     }
 }
 
+// rotary + the two qk_matmul input fake-quantizers (stateless E4M3 / E5M2, unit scale): output in [B][H][S][D]
+// order, contiguous -- the layout the fake-quant pass of a permuted view produces (csrc/qt_elementwise.hip,
+// fq_rows_kernel) -- so rope_kernel + two fq_rows_kernel launches become one.
+struct RopeFqArgs {
+    RopeArgs r;              // r.y is the [B][H][S][D] output
+    qt_format fmt;
+};
+
+__device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
+    const long dv = a.r.D / 8;
+    const long d8 = (long)(o % dv);
+    const size_t bhs = o / dv;
+    const long s = (long)(bhs % (size_t)a.r.S);
+    const size_t bh = bhs / (size_t)a.r.S;
+    const long h = (long)(bh % (size_t)a.r.H);
+    const size_t b = bh / (size_t)a.r.H;
+    const size_t bs = b * a.r.S + s;
+    const size_t in_row = (bs * a.r.H + h) * dv;                 // vector index of x[b][s][h][0]
+    const long half = dv / 2;
+    const bool low = d8 < half;
+    const uint4 xv = *(const uint4 *)(a.r.x + (in_row + d8) * 8);
+    const uint4 pv = *(const uint4 *)(a.r.x + (in_row + (low ? d8 + half : d8 - half)) * 8);
+    const uint4 cv = *(const uint4 *)(a.r.cos + (bs * dv + d8) * 8);
+    const uint4 sv = *(const uint4 *)(a.r.sin + (bs * dv + d8) * 8);
+    const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
+    const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
+    const float sgn = low ? -1.0f : 1.0f;
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+        const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
+        const uint32_t e = pack_bf16x2(a0 + b0, a1 + b1);            // the rotary output, bf16
+        const uint32_t r0 = qt_fp_sat_u32(e << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+        const uint32_t r1 = qt_fp_sat_u32(e & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+        out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+    }
+    *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
+}
+
+__global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k) {
+    const size_t total = q.r.nvec + k.r.nvec;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (i < q.r.nvec) rope_fq_one(q, i);
+        else rope_fq_one(k, i - q.r.nvec);
+    }
+}
+
 int launch_status() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
@@ -210,6 +258,22 @@ int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, cons
     size_t blocks = (aq.nvec + ak.nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     rope_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
+    return launch_status();
+}
+
+int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
+                    uint16_t *k_out, long B, long S, long Hq, long Hk, long D, const qt_format *fmt_q, const qt_format *fmt_k,
+                    void *stream) {
+    if (B * S * D == 0) return QT_OK;
+    if (!q || !k || !cos || !sin || !q_out || !k_out || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
+    if (fmt_q->kind != QT_FMT_FP_SAT || fmt_k->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
+        return QT_ERR_UNALIGNED;
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8)}, *fmt_q};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8)}, *fmt_k};
+    size_t blocks = (aq.r.nvec + ak.r.nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
     return launch_status();
 }
 

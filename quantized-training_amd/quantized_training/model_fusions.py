@@ -122,6 +122,52 @@ def rope(q, k, cos, sin):
     return q_out.transpose(1, 2), k_out.transpose(1, 2)
 
 
+def rope_fq(q, k, cos, sin, fq_q, fq_k):
+    """Rotary embedding with qk_matmul's two input fake-quantizers applied in the same pass; outputs are contiguous
+    [B, H, S, D] (the layout those hooks write) and marked as done for fq_q / fq_k."""
+    B, Hq, S, D = q.shape
+    Hk = k.shape[1]
+    qb, kb = q.transpose(1, 2), k.transpose(1, 2)              # the [B, S, H, D] buffers
+    q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
+    _native.check(_native.lib().qt_rope_fq_bf16(qb.data_ptr(), kb.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                q_out.data_ptr(), k_out.data_ptr(), B, S, Hq, Hk, D,
+                                                ctypes.byref(fq_q._qt_format), ctypes.byref(fq_k._qt_format),
+                                                _stream_ptr(q)), "qt_rope_fq_bf16")
+    q_out._qt_fq_done_by = fq_q
+    k_out._qt_fq_done_by = fq_k
+    return q_out, k_out
+
+
+# The attention block whose forward is running (set by hooks on the converted LlamaAttention modules): HF calls the
+# module-level apply_rotary_pos_emb from inside it, and the fused rotary needs that block's qk_matmul fake-quantizers.
+_CURRENT_ATTN = []
+
+
+def _attn_enter(module, args, kwargs):
+    _CURRENT_ATTN.append(module)
+
+
+def _attn_exit(module, args, kwargs, output):
+    if _CURRENT_ATTN and _CURRENT_ATTN[-1] is module:
+        _CURRENT_ATTN.pop()
+
+
+def _qk_fqs(attn):
+    """(fq_q, fq_k) of attn.qk_matmul when both may be applied by the rotary kernel, else None."""
+    mm = getattr(attn, "qk_matmul", None)
+    holder = getattr(mm, "activation_pre_process", None) if mm is not None else None
+    if holder is None or len(mm._forward_pre_hooks) != 1 or mm._forward_hooks or set(holder.keys()) != {"0", "1"}:
+        return None
+    fq_q, fq_k = holder["0"], holder["1"]
+    for f in (fq_q, fq_k):
+        if not isinstance(f, FusedAmaxObsFakeQuantize) or not f.producer_fusable():
+            return None
+    if getattr(attn, "num_key_value_groups", 1) != 1:
+        return None                  # keys are repeated (new tensors) between the rotary and qk_matmul
+    return fq_q, fq_k
+
+
 # ---- module-level swaps -------------------------------------------------------------------------------------------
 def _rmsnorm_forward(self, hidden_states):
     w = self.weight
@@ -174,6 +220,10 @@ def _patch_rope():
         if ok:
             if cos.shape[0] != q.shape[0]:                      # position ids shared by the batch
                 cos, sin = cos.expand(q.shape[0], -1, -1).contiguous(), sin.expand(q.shape[0], -1, -1).contiguous()
+            if _CURRENT_ATTN and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0":
+                fqs = _qk_fqs(_CURRENT_ATTN[-1])
+                if fqs is not None:
+                    return rope_fq(q, k, cos, sin, *fqs)
             return rope(q, k, cos, sin)
         return original(q, k, cos, sin, unsqueeze_dim)
 
@@ -197,6 +247,10 @@ def apply_llama_fusions(model):
         elif isinstance(mod, ml.LlamaMLP):
             _bind(mod, _mlp_forward)
             n += 1
+        elif isinstance(mod, ml.LlamaAttention) and not getattr(mod, "_qt_ctx_hooks", False):
+            mod.register_forward_pre_hook(_attn_enter, with_kwargs=True)
+            mod.register_forward_hook(_attn_exit, with_kwargs=True, always_call=True)
+            mod._qt_ctx_hooks = True
     if n:
         _patch_rope()
     return n

@@ -54,7 +54,10 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     core = fused_attention_or_none(module, query, key, value, attention_mask, scaling, dropout)
     if core is not None:
         return core, None                      # probabilities are never materialised on this path
-    scores = module.qk_matmul(query, key.transpose(2, 3))
+    key_t = key.transpose(2, 3)
+    if getattr(key, "_qt_fq_done_by", None) is not None:
+        key_t._qt_fq_done_by = key._qt_fq_done_by          # fake-quant is elementwise: done for K means done for K^T
+    scores = module.qk_matmul(query, key_t)
     fused = fused_scores_to_probs_or_none(module, scores, attention_mask, scaling, dropout, value)
     if fused is not None:
         probs, out = fused

@@ -1004,3 +1004,24 @@ def test_attention_output_fused_with_projection_input_fake_quant(nv):
         other = fq(ref_in)                                      # a different tensor: normal pass, expectation dropped
         assert torch.equal(other.view(torch.int16), want.view(torch.int16))
         assert fq.__dict__.get("_qt_expected") is None
+
+
+def test_rotary_fused_with_qk_fake_quant(nv):
+    """rope_fq == rotary kernel followed by the two qk_matmul input hooks' permuted-view passes (values and layout)."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    g = torch.Generator(device="cuda").manual_seed(12)
+    for (B, H, Hk, S, D) in ((1, 32, 32, 1024, 128), (2, 8, 8, 77, 64)):
+        q = (torch.randn(B, S, H, D, device="cuda", generator=g) * 20).bfloat16().transpose(1, 2)
+        k = (torch.randn(B, S, Hk, D, device="cuda", generator=g) * 300).bfloat16().transpose(1, 2)
+        ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+        cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+        fq_q, fq_k = FusedAmaxObsFakeQuantize(dtype="e4m3").cuda(), FusedAmaxObsFakeQuantize(dtype="e5m2").cuda()
+        with torch.no_grad():
+            rq, rk = mf.rope(q, k, cos, sin)
+            want_q, want_k = fq_q(rq), fq_k(rk)
+            got_q, got_k = mf.rope_fq(q, k, cos, sin, fq_q, fq_k)
+        assert got_q.is_contiguous() and got_k.is_contiguous() and got_q.shape == q.shape
+        assert torch.equal(want_q.contiguous().view(torch.int16), got_q.view(torch.int16))
+        assert torch.equal(want_k.contiguous().view(torch.int16), got_k.view(torch.int16))
+        assert fq_q(got_q) is got_q and fq_k(got_k) is got_k
