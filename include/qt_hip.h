@@ -269,6 +269,11 @@ int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint
  *                     out = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin)); D % 16 == 0 */
 int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, long rows, long cols, float eps,
                     void *stream);
+/* qt_rmsnorm_bf16 with the FIRST consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result (bf16 + FP8
+ * code).  Its sibling consumers (k/v projections beside q, up beside gate) still run their own passes on the result;
+ * those formats are idempotent, so what they compute is unchanged. */
+int qt_rmsnorm_fq8_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, uint8_t *y8_dev, long rows,
+                        long cols, float eps, const qt_format *fmt, void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t n, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:
  * y = fq(bf16(bf16(silu(gate)) * up)) as bf16 plus its FP8 code -- what the down-projection's input hook would compute

@@ -22,8 +22,12 @@ __device__ __forceinline__ float rbf(float f) { return qt_u2f(pack_bf16x2(f, 0.0
 constexpr int kNormThreads = 256;
 constexpr int kNormMaxVec = 8;        // 16-byte vectors per thread: rows up to 256 * 8 * 8 = 16384 elements
 
+// FQ: 0 plain; 1 / 2 = the first consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result, which is
+// written as bf16 plus its FP8 code (producer-fused fake-quant, model_fusions.py)
+template <int FQ>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ w,
-                                                               uint4 *__restrict__ y, int nvec, float inv_cols, float eps) {
+                                                               uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
+                                                               uint2 *__restrict__ y8, qt_format fmt) {
     __shared__ float s_part[kNormThreads / 64];
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
@@ -62,6 +66,18 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
             for (int j = 0; j < 4; ++j) {
                 const float h0 = rbf(bf_lo(q[j]) * r), h1 = rbf(bf_hi(q[j]) * r);
                 o[j] = pack_bf16x2(bf_lo(g[j]) * h0, bf_hi(g[j]) * h1);
+            }
+            if constexpr (FQ != 0) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, fmt.p0, fmt.p1, fmt.fhi);
+                    const uint32_t r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
+                    o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+                    f[2 * j] = qt_u2f(r0);
+                    f[2 * j + 1] = qt_u2f(r1);
+                }
+                y8[row * (size_t)nvec + c] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
             }
             y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
         }
@@ -213,8 +229,28 @@ int qt_rmsnorm_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, long
     if (!x || !weight || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
     if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15u))
         return QT_ERR_UNALIGNED;
-    rmsnorm_kernel<<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
-                                                                             (int)(cols / 8), 1.0f / (float)cols, eps);
+    rmsnorm_kernel<0><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+                                                                                (int)(cols / 8), 1.0f / (float)cols, eps, nullptr,
+                                                                                qt_format{});
+    return launch_status();
+}
+
+int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, uint8_t *y8, long rows, long cols, float eps,
+                        const qt_format *fmt, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !y || !y8 || !fmt || rows < 0 || cols < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15u) ||
+        ((uintptr_t)y8 & 7u))
+        return QT_ERR_UNALIGNED;
+    if (e5m2)
+        rmsnorm_kernel<2><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+                                                                                    (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
+    else
+        rmsnorm_kernel<1><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+                                                                                    (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
     return launch_status();
 }
 

@@ -45,6 +45,38 @@ def rmsnorm(x, weight, eps):
     return y
 
 
+def rmsnorm_fq(x, weight, eps, fq):
+    """RMSNorm with `fq` (the first consumer's input fake-quantizer) applied to the result."""
+    cols = x.shape[-1]
+    x2 = x.contiguous()
+    y = torch.empty_like(x2)
+    y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+    _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(),
+                                                    x2.numel() // cols, cols, float(eps), ctypes.byref(fq._qt_format),
+                                                    _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
+    y._qt_fp8 = _fp8_view(y8, fq)
+    y._qt_fq_done_by = fq
+    return y
+
+
+def _norm_consumer_fq(norm):
+    """The fake-quantizer the norm kernel may apply: every Linear fed by this norm must quantize its input with the
+    same stateless format (then the first one's pass is fused here and the siblings', run on the already quantized
+    tensor, reproduce it -- the formats are idempotent)."""
+    consumers = norm.__dict__.get("_qt_consumers")
+    if not consumers or os.environ.get("QT_FUSED_PRODUCER_FQ", "1") == "0":
+        return None
+    fqs = [consumer_fq(lin) for lin in consumers]
+    if any(f is None for f in fqs):
+        return None
+    f0 = fqs[0]._qt_format
+    for f in fqs[1:]:
+        g = f._qt_format
+        if (g.kind, g.p0, g.p1, g.flo, g.fhi) != (f0.kind, f0.p0, f0.p1, f0.flo, f0.fhi):
+            return None
+    return fqs[0]
+
+
 def silu_mul(gate, up):
     g, u = gate.contiguous(), up.contiguous()
     y = torch.empty_like(g)
@@ -173,6 +205,9 @@ def _rmsnorm_forward(self, hidden_states):
     w = self.weight
     if (_eligible(hidden_states, w) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384
             and hidden_states.numel() > 0 and w.is_contiguous()):
+        fq = _norm_consumer_fq(self)
+        if fq is not None:
+            return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq)
         return rmsnorm(hidden_states, w, self.variance_epsilon)
     return self._qt_hf_forward(hidden_states)
 
@@ -251,6 +286,12 @@ def apply_llama_fusions(model):
             mod.register_forward_pre_hook(_attn_enter, with_kwargs=True)
             mod.register_forward_hook(_attn_exit, with_kwargs=True, always_call=True)
             mod._qt_ctx_hooks = True
+    # which Linears consume each norm's output (plain references kept out of the module tree)
+    for mod in model.modules():
+        if isinstance(mod, ml.LlamaDecoderLayer):
+            att, mlp = mod.self_attn, mod.mlp
+            mod.input_layernorm.__dict__["_qt_consumers"] = [att.q_proj, att.k_proj, att.v_proj]
+            mod.post_attention_layernorm.__dict__["_qt_consumers"] = [mlp.gate_proj, mlp.up_proj]
     if n:
         _patch_rope()
     return n

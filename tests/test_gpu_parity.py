@@ -1025,3 +1025,27 @@ def test_rotary_fused_with_qk_fake_quant(nv):
         assert torch.equal(want_q.contiguous().view(torch.int16), got_q.view(torch.int16))
         assert torch.equal(want_k.contiguous().view(torch.int16), got_k.view(torch.int16))
         assert fq_q(got_q) is got_q and fq_k(got_k) is got_k
+
+
+def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
+    """rmsnorm_fq == the norm kernel followed by the consumer's pass, and a sibling consumer's pass over the already
+    quantized tensor reproduces it (the stateless formats are idempotent), FP8 bytes included."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = (torch.randn(1024, 4096, device="cuda", generator=g) * 50).bfloat16()
+    w = (1 + 0.2 * torch.randn(4096, device="cuda", generator=g)).bfloat16()
+    for dtype in ("e4m3", "e5m2"):
+        fq, sibling = FusedAmaxObsFakeQuantize(dtype=dtype).cuda(), FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+        fq._emit_fp8 = sibling._emit_fp8 = "both"
+        with torch.no_grad():
+            plain = mf.rmsnorm(x, w, 1e-5)
+            want = fq(plain)
+            got = mf.rmsnorm_fq(x, w, 1e-5, fq)
+            assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+            assert torch.equal(want._qt_fp8.view(torch.uint8), got._qt_fp8.view(torch.uint8))
+            assert fq(got) is got
+            sib_from_plain, sib_from_q = sibling(plain), sibling(got)
+            assert sib_from_q is not got
+            assert torch.equal(sib_from_plain.view(torch.int16), sib_from_q.view(torch.int16))
+            assert torch.equal(sib_from_plain._qt_fp8.view(torch.uint8), sib_from_q._qt_fp8.view(torch.uint8))
