@@ -288,6 +288,18 @@ int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t
                     uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D,
                     const qt_format *fmt_q, const qt_format *fmt_k, void *stream);
 
+/* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
+ * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose
+ * values are exactly the fake-quantized bf16 values (unit scale), so the products are the reference's.  b_is_kn = 0: B
+ * is [N][K] row-major (a Linear weight, or K for Q.K^T); 1: B is [K][N] row-major (V for P.V).  Batch strides in
+ * elements (0 = shared).  `workspace` is caller-owned scratch for the library (64 MiB is plenty; may be NULL).  With
+ * tune != 0 the library's top suggestions for this problem are timed once (skipped while the stream is capturing) and
+ * the fastest is cached.  Returns QT_ERR_NO_DEVICE when libhipblaslt cannot be resolved in the process and
+ * QT_ERR_BAD_DTYPE when it has no kernel for the problem -- the caller then keeps its other route. */
+int qt_fp8_gemm(const uint8_t *a8_dev, int a_format, const uint8_t *b8_dev, int b_format, int b_is_kn, void *c_bf16_dev,
+                const void *bias_bf16_dev, long batch, int M, int N, int K, long a_batch_stride, long b_batch_stride,
+                long c_batch_stride, void *workspace_dev, size_t workspace_bytes, int tune, void *stream);
+
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).
  * Launch i works on x_dev + (i % pool_count) * pool_stride and y_dev + (i % pool_count) * pool_stride

@@ -189,12 +189,55 @@ def fp8_linear_or_none(layer, x):
         w8 = cached_weight(layer, "fp8", make)
     one = _one(x.device)
     x2 = x8.reshape(-1, K)
-    y = torch._scaled_mm(x2, w8.t(), scale_a=one, scale_b=one, bias=layer.bias, out_dtype=torch.bfloat16)
+    y = lt_fp8_gemm(x2, w8, layer.bias)
+    if y is None:
+        y = torch._scaled_mm(x2, w8.t(), scale_a=one, scale_b=one, bias=layer.bias, out_dtype=torch.bfloat16)
     if pf is not None:
         if slot is not None:
             pf.mark_read(slot, x.device)
         pf.launch(pos + 1, x.device)          # no wrap-around: the first layer of a forward runs its pass inline
     return y.reshape(*x.shape[:-1], W.shape[0])
+
+
+_LT = {"ok": os.environ.get("QT_LT_GEMM", "1") != "0", "ws": {}}
+
+
+def lt_fp8_gemm(a8, b8, bias=None, b_is_kn=False):
+    """C = A . op(B) on FP8 operands through qt_fp8_gemm (hipBLASLt with a measured algorithm choice).  a8 [.., M, K];
+    b8 [N, K] (b_is_kn False) or [.., K, N] (True); leading dims of a8 / b8 are a batch.  None when the library route is
+    unavailable for this problem (the caller falls back to torch._scaled_mm / bf16)."""
+    if not _LT["ok"]:
+        return None
+    dev = a8.device
+    ws = _LT["ws"].get(dev)
+    if ws is None:
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        _LT["ws"][dev] = ws
+    fmt = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}
+    if a8.dtype not in fmt or b8.dtype not in fmt or not a8.is_contiguous() or not b8.is_contiguous():
+        return None
+    M, K = a8.shape[-2], a8.shape[-1]
+    if b_is_kn:
+        N = b8.shape[-1]
+        if b8.shape[-2] != K or b8.shape[:-2] != a8.shape[:-2]:
+            return None
+    else:
+        N = b8.shape[-2]
+        if b8.shape[-1] != K or (b8.dim() > 2 and b8.shape[:-2] != a8.shape[:-2]):
+            return None
+    batch = 1
+    for d in a8.shape[:-2]:
+        batch *= d
+    b_stride = 0 if b8.dim() == 2 else N * K
+    out = torch.empty(a8.shape[:-1] + (N,), dtype=torch.bfloat16, device=dev)
+    rc = _native.lib().qt_fp8_gemm(a8.data_ptr(), fmt[a8.dtype], b8.data_ptr(), fmt[b8.dtype], int(b_is_kn), out.data_ptr(),
+                                   bias.data_ptr() if bias is not None else None, batch, M, N, K, M * K, b_stride, M * N,
+                                   ws.data_ptr(), ws.numel(), 1, _stream_ptr(a8))
+    if rc != 0:
+        if rc in (_native.QT_ERR_NO_DEVICE,):
+            _LT["ok"] = False                      # the library cannot be resolved in this process: stop trying
+        return None
+    return out
 
 
 _ONES = {}

@@ -1049,3 +1049,39 @@ def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
             assert sib_from_q is not got
             assert torch.equal(sib_from_plain.view(torch.int16), sib_from_q.view(torch.int16))
             assert torch.equal(sib_from_plain._qt_fp8.view(torch.uint8), sib_from_q._qt_fp8.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(1024, 4096, 4096, False), (256, 768, 3072, True), (1000, 1008, 512, True)])
+def test_lt_fp8_gemm_matches_scaled_mm(nv, M, N, K, bias):
+    """qt_fp8_gemm (hipBLASLt, measured algorithm choice) against the exact product of the FP8 operands; bf16 output.
+    The library's bias epilogue adds the bias to the already rounded product, so with a bias there are two bf16
+    roundings (of the product and of the sum); torch._scaled_mm drives the same epilogue."""
+    from quantized_training import fused
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.float8_e4m3fn)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.float8_e4m3fn)
+    bv = torch.randn(N, device="cuda", generator=g).bfloat16() if bias else None
+    y = fused.lt_fp8_gemm(a, b, bv)
+    assert y is not None, "hipBLASLt route unavailable"
+    ref = a.float().double() @ b.float().double().t() + (bv.double() if bias else 0.0)
+    mag = a.float().double().abs() @ b.float().double().abs().t()
+    err = (y.double() - ref).abs()
+    prod = (ref - bv.double()).abs() if bias else 0.0
+    assert bool((err <= 2.0 ** -8 * (ref.abs() + prod) + 2.0 ** -20 * mag + 1e-6).all()), float(err.max())
+    y2 = fused.lt_fp8_gemm(a, b, bv)                  # cached plan, same result
+    assert torch.equal(y, y2)
+
+
+def test_lt_fp8_gemm_batched_both_layouts(nv):
+    from quantized_training import fused
+    g = torch.Generator(device="cuda").manual_seed(8)
+    q = torch.randn(6, 128, 64, device="cuda", generator=g).to(torch.float8_e4m3fn)
+    k = torch.randn(6, 96, 64, device="cuda", generator=g).to(torch.float8_e4m3fn)
+    s = fused.lt_fp8_gemm(q, k)                        # Q . K^T, B given as [N, K] per batch
+    assert s is not None and s.shape == (6, 128, 96)
+    assert torch.allclose(s.float(), torch.matmul(q.float(), k.float().transpose(1, 2)), rtol=2 ** -7, atol=1e-2)
+    p = torch.rand(6, 128, 96, device="cuda", generator=g).to(torch.float8_e4m3fn)
+    v = torch.randn(6, 96, 64, device="cuda", generator=g).to(torch.float8_e4m3fn)
+    o = fused.lt_fp8_gemm(p, v, b_is_kn=True)          # P . V, B given as [K, N] per batch
+    assert o is not None and o.shape == (6, 128, 64)
+    assert torch.allclose(o.float(), torch.matmul(p.float(), v.float()), rtol=2 ** -7, atol=1e-2)
