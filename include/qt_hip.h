@@ -210,6 +210,12 @@ int qt_softmax_fq_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uin
                        int heads, int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling,
                        const qt_format *fmt, const uint16_t *lut_dev, const float *scale_f32_dev,
                        uint32_t *amax_bits_dev, void *stream);
+/* Same pass for a stateless E4M3 / E5M2 fake-quantizer of the probabilities (unit scale, no observer) that writes their
+ * FP8 code (out8, contiguous like scores; out_dev may be NULL): the P.V product then runs as an FP8 GEMM (qt_fp8_gemm)
+ * and the S x S tensor costs 1 byte per element to write and read instead of 2. */
+int qt_softmax_fq_bf16_fp8(const uint16_t *scores_dev, const uint16_t *mask_dev, uint16_t *out_dev, uint8_t *out8_dev,
+                           long batch, int heads, int q_len, long cols, long mask_sb, long mask_sh, long mask_sq,
+                           float scaling, const qt_format *fmt, void *stream);
 
 /* Whole attention core for already fake-quantized q, k, v (bf16 [B, H, S, D] contiguous, D = 64 or 128):
  *     O = av_matmul( fq_P( softmax( attn_scaling(qk_matmul(q, k^T), scaling) + mask ) ), v )

@@ -36,6 +36,8 @@ struct SoftmaxArgs {
     const uint16_t *lut;
     const float *scale;
     uint32_t *amax;
+    uint8_t *out8;            // optional FP8 code of the quantized probabilities (E4M3 / E5M2 spec, unit scale)
+    int out8_e5m2;
 };
 
 __device__ __forceinline__ float wave_max_f32(float v) {
@@ -106,12 +108,14 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
             }
         sum = wave_sum_f32(sum);
         const float inv = 1.0f / sum;                 // one division per row; p = e * inv (<= 1 fp32 ULP from e / sum)
-        uint4 *dst = (uint4 *)(a.out + row * a.cols);
+        uint4 *dst = a.out ? (uint4 *)(a.out + row * a.cols) : nullptr;
+        uint2 *dst8 = a.out8 ? (uint2 *)(a.out8 + row * a.cols) : nullptr;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int iv = v * 64 + lane;
             if (iv < nvec_row) {
                 uint32_t w[4];
+                float f8[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t p = pack_bf16x2(t[v][2 * j] * inv, t[v][2 * j + 1] * inv);   // probabilities, bf16
@@ -128,8 +132,14 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                     }
                     const uint32_t r0 = rnd(lo), r1 = rnd(hi);
                     w[j] = unit ? ((r0 >> 16) | (r1 & 0xFFFF0000u)) : pack_bf16x2(qt_u2f(r0) * s, qt_u2f(r1) * s);
+                    f8[2 * j] = qt_u2f(r0);
+                    f8[2 * j + 1] = qt_u2f(r1);
                 }
-                dst[iv] = uint4{w[0], w[1], w[2], w[3]};
+                if (dst) dst[iv] = uint4{w[0], w[1], w[2], w[3]};
+                if (dst8) {
+                    if (a.out8_e5m2) dst8[iv] = uint2{qt_pack_fp8x4<true>(f8[0], f8[1], f8[2], f8[3]), qt_pack_fp8x4<true>(f8[4], f8[5], f8[6], f8[7])};
+                    else dst8[iv] = uint2{qt_pack_fp8x4<false>(f8[0], f8[1], f8[2], f8[3]), qt_pack_fp8x4<false>(f8[4], f8[5], f8[6], f8[7])};
+                }
             }
         }
     }
@@ -179,7 +189,7 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
     if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)out | (uintptr_t)mask) & 15u) ||
         (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
         return QT_ERR_UNALIGNED;
-    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax};
+    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     switch (fmt->kind) {
         case QT_FMT_LUT: return launch_softmax<QT_FMT_LUT>(a, st);
@@ -188,4 +198,22 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
         case QT_FMT_IDENTITY: return launch_softmax<QT_FMT_IDENTITY>(a, st);
         default: return QT_ERR_BAD_ARG;
     }
+}
+
+extern "C" int qt_softmax_fq_bf16_fp8(const uint16_t *scores, const uint16_t *mask, uint16_t *out, uint8_t *out8, long batch,
+                                      int heads, int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling,
+                                      const qt_format *fmt, void *stream) {
+    const long rows = batch * heads * q_len;
+    if (rows == 0 || cols == 0) return QT_OK;
+    if (!scores || !out8 || !fmt || batch < 0 || heads < 1 || q_len < 1 || cols < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if (cols > 64L * 8 * kMaxVec) return QT_ERR_BAD_ARG;
+    if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)out | (uintptr_t)mask) & 15u) || ((uintptr_t)out8 & 7u) ||
+        (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
+        return QT_ERR_UNALIGNED;
+    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, nullptr, nullptr, nullptr,
+                  out8, e5m2 ? 1 : 0};
+    return launch_softmax<QT_FMT_FP_SAT>(a, (hipStream_t)stream);
 }

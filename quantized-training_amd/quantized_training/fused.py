@@ -363,6 +363,9 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
         mask = m
     L = _native.lib()
     st = _stream_ptr(scores)
+    fp8_out = _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value)
+    if fp8_out is not None:
+        return None, fp8_out                  # the probabilities exist only as FP8 codes on this path
     out = torch.empty_like(scores)
     if fq_p is not None and (fq_p._observe or fq_p._quantize):
         fq_p._move_to(scores.device)
@@ -385,6 +388,45 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
                                        amax_ptr, st), "qt_softmax_fq_bf16")
     v = fq_v(value) if fq_v is not None else value
     return out, torch.matmul(out, v)
+
+
+def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value):
+    """When the probabilities' and the values' fake-quantizers are stateless E4M3 / E5M2 ones, both tensors are exactly
+    FP8: the score pass writes the probabilities' FP8 code only (1 B/element instead of 2), the value pass writes FP8
+    next to bf16, and P.V runs as a batched FP8 GEMM (qt_fp8_gemm).  Same products, fp32 accumulation."""
+    if os.environ.get("QT_FP8_ATTENTION", "1") == "0" or not _LT["ok"] or fq_p is None or fq_v is None:
+        return None
+    if not (isinstance(fq_v, FusedAmaxObsFakeQuantize) and fq_p.producer_fusable() and fq_v.producer_fusable()):
+        return None
+    B, H, Q, C = scores.shape
+    if value.dim() != 4 or value.shape[:3] != (B, H, C) or value.dtype != torch.bfloat16 or value.stride(-1) != 1:
+        return None
+    D = value.shape[-1]
+    if D % 16 or C % 16 or any(s % 8 for s in value.stride()[:3]) or value.data_ptr() % 16 or B * H > 65535:
+        return None
+    if (B * H, Q, C, D) in _LT.setdefault("no_pv", set()):
+        return None                            # the library had no kernel for this problem last time
+    done = getattr(value, "_qt_fq_done_by", None)
+    v8 = getattr(value, "_qt_fp8", None)
+    if not (done is fq_v and v8 is not None and value.is_contiguous()):
+        vq = torch.empty((B, H, C, D), dtype=torch.bfloat16, device=value.device)
+        v8u = torch.empty((B, H, C, D), dtype=torch.uint8, device=value.device)
+        _native.check(L.qt_fake_quant_rows_bf16_fp8(value.data_ptr(), vq.data_ptr(), v8u.data_ptr(), B, H, C, D,
+                                                    value.stride(0), value.stride(1), value.stride(2),
+                                                    ctypes.byref(fq_v._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
+        v8 = v8u.view(torch.float8_e5m2 if fq_v._qt_format.p0 == 2 else torch.float8_e4m3fn)
+    p8u = torch.empty((B, H, Q, C), dtype=torch.uint8, device=scores.device)
+    _native.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr() if mask is not None else None, None,
+                                           p8u.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling),
+                                           ctypes.byref(fq_p._qt_format), st), "qt_softmax_fq_bf16_fp8")
+    p8 = p8u.view(torch.float8_e5m2 if fq_p._qt_format.p0 == 2 else torch.float8_e4m3fn)
+    out = lt_fp8_gemm(p8.view(B * H, Q, C), v8.view(B * H, C, D), None, b_is_kn=True)
+    if out is None:
+        _LT["no_pv"].add((B * H, Q, C, D))     # the bf16 path redoes (and counts) the two passes
+        return None
+    STATS.add(value.numel())                   # the two fake-quant calls the reference issues here (av_matmul's inputs)
+    STATS.add(scores.numel())
+    return out.view(B, H, Q, D)
 
 
 def _mask_strides(attention_mask, B, H, Q, C, device, align):
