@@ -99,13 +99,26 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
         }
         mx = wave_max_f32(mx);
         float sum = 0.0f;
+        // A 16-byte vector whose eight logits all lie more than 110 below the row maximum (a causal mask's -3.4e38)
+        // contributes exp(.) == 0 exactly -- v_exp_f32 of anything below -158 is 0 -- so its exponentials, roundings and
+        // fake-quant are skipped and zeros are stored: half of all vectors under a causal mask.  The comparison is false
+        // for NaN, so NaN logits still take the full path.
+        bool dead[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
+        for (int v = 0; v < NV; ++v) {
+            const float cut = mx - 110.0f;
+            bool d = true;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                t[v][j] = __expf(t[v][j] - mx);     // v_exp_f32 path; within the 1-bf16-ULP budget stated above
-                sum += t[v][j];
+            for (int j = 0; j < 8; ++j) d = d && (t[v][j] < cut);
+            dead[v] = d;
+            if (!d) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    t[v][j] = __expf(t[v][j] - mx);     // v_exp_f32 path; within the 1-bf16-ULP budget stated above
+                    sum += t[v][j];
+                }
             }
+        }
         sum = wave_sum_f32(sum);
         const float inv = 1.0f / sum;                 // one division per row; p = e * inv (<= 1 fp32 ULP from e / sum)
         uint4 *dst = a.out ? (uint4 *)(a.out + row * a.cols) : nullptr;
@@ -113,7 +126,10 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int iv = v * 64 + lane;
-            if (iv < nvec_row) {
+            if (iv < nvec_row && dead[v]) {                  // fq(0) = +0, FP8 code 0; amax unaffected
+                if (dst) dst[iv] = uint4{0u, 0u, 0u, 0u};
+                if (dst8) dst8[iv] = uint2{0u, 0u};
+            } else if (iv < nvec_row) {
                 uint32_t w[4];
                 float f8[8];
 #pragma unroll
