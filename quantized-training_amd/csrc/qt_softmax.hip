@@ -141,6 +141,16 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                         amax = amax > a1 ? amax : a1;
                     }
                     uint32_t lo = p << 16, hi = p & 0xFFFF0000u;
+                    if constexpr (KIND == QT_FMT_FP_SAT) {
+                        if (!dst && dst8) {
+                            // FP8 code only: for a probability (finite, 0 <= p <= 1: no saturation, no sign) the format's
+                            // round-to-nearest-even IS the hardware conversion of the bf16 value, so the 12-operation
+                            // closed form is not needed (checked against it in tests/test_gpu_parity.py)
+                            f8[2 * j] = qt_u2f(lo);
+                            f8[2 * j + 1] = qt_u2f(hi);
+                            continue;
+                        }
+                    }
                     if (!unit) {
                         uint32_t qd = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
                         lo = qd << 16;

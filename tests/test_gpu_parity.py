@@ -1085,3 +1085,29 @@ def test_lt_fp8_gemm_batched_both_layouts(nv):
     o = fused.lt_fp8_gemm(p, v, b_is_kn=True)          # P . V, B given as [K, N] per batch
     assert o is not None and o.shape == (6, 128, 64)
     assert torch.allclose(o.float(), torch.matmul(p.float(), v.float()), rtol=2 ** -7, atol=1e-2)
+
+
+def test_score_pass_fp8_only_equals_closed_form_path(nv):
+    """qt_softmax_fq_bf16_fp8 with and without the bf16 output: the FP8-only variant converts the bf16 probability with
+    the hardware's round-to-nearest-even instead of the closed form; same bytes for probabilities of every magnitude
+    (rows of logits at several scales, with and without a causal mask), and the bytes decode to the bf16 output."""
+    L = nv.lib()
+    B, H, S = 2, 4, 512
+    fmt8 = {"e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+    g = torch.Generator(device="cuda").manual_seed(4)
+    mask = torch.full((S, S), torch.finfo(torch.bfloat16).min, device="cuda").triu(1).bfloat16()[None, None].contiguous()
+    for dtype in ("e4m3", "e5m2"):
+        fmt = nv.format_for(dtype)
+        for sigma in (0.3, 3.0, 12.0, 40.0):
+            scores = (torch.randn(B, H, S, S, device="cuda", generator=g) * sigma).bfloat16()
+            for m in (None, mask):
+                mp = m.data_ptr() if m is not None else None
+                out = torch.empty_like(scores)
+                a8 = torch.empty(B, H, S, S, dtype=torch.uint8, device="cuda")
+                b8 = torch.empty_like(a8)
+                nv.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mp, out.data_ptr(), a8.data_ptr(), B, H, S, S, 0, 0,
+                                                  S if m is not None else 0, 0.125, ctypes.byref(fmt), stream()), "both")
+                nv.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mp, None, b8.data_ptr(), B, H, S, S, 0, 0,
+                                                  S if m is not None else 0, 0.125, ctypes.byref(fmt), stream()), "fp8 only")
+                assert torch.equal(a8, b8), (dtype, sigma, m is not None)
+                assert torch.equal(a8.view(fmt8[dtype]).float(), out.float())
