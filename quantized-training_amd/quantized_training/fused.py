@@ -199,14 +199,14 @@ def fp8_linear_or_none(layer, x):
     return y.reshape(*x.shape[:-1], W.shape[0])
 
 
-_LT = {"ok": os.environ.get("QT_LT_GEMM", "1") != "0", "ws": {}}
+_LT = {"ok": True, "ws": {}}                  # "ok" turns False when libhipblaslt cannot be resolved in the process
 
 
 def lt_fp8_gemm(a8, b8, bias=None, b_is_kn=False):
     """C = A . op(B) on FP8 operands through qt_fp8_gemm (hipBLASLt with a measured algorithm choice).  a8 [.., M, K];
     b8 [N, K] (b_is_kn False) or [.., K, N] (True); leading dims of a8 / b8 are a batch.  None when the library route is
     unavailable for this problem (the caller falls back to torch._scaled_mm / bf16)."""
-    if not _LT["ok"]:
+    if not _LT["ok"] or os.environ.get("QT_LT_GEMM", "1") == "0":
         return None
     dev = a8.device
     ws = _LT["ws"].get(dev)
@@ -394,7 +394,8 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
     """When the probabilities' and the values' fake-quantizers are stateless E4M3 / E5M2 ones, both tensors are exactly
     FP8: the score pass writes the probabilities' FP8 code only (1 B/element instead of 2), the value pass writes FP8
     next to bf16, and P.V runs as a batched FP8 GEMM (qt_fp8_gemm).  Same products, fp32 accumulation."""
-    if os.environ.get("QT_FP8_ATTENTION", "1") == "0" or not _LT["ok"] or fq_p is None or fq_v is None:
+    if (os.environ.get("QT_FP8_ATTENTION", "1") == "0" or os.environ.get("QT_LT_GEMM", "1") == "0" or not _LT["ok"]
+            or fq_p is None or fq_v is None):
         return None
     if not (isinstance(fq_v, FusedAmaxObsFakeQuantize) and fq_p.producer_fusable() and fq_v.producer_fusable()):
         return None

@@ -43,11 +43,14 @@ def test_perplexity_parity_fp32(spec):
 
 
 def test_perplexity_parity_bf16_fast_paths():
-    """bf16 model with e4m3 act+weight: FP8 GEMM, fused softmax and hipGraph replay all active vs the plain
-    path (QT_FP8_GEMM=0, QT_FUSED_SOFTMAX=0, eager).  Different GEMM accumulation orders and the 1-ULP softmax
+    """bf16 model with e4m3 act+weight: every fast path active (FP8 GEMMs through qt_fp8_gemm, fused score pass with FP8
+    probabilities, one-launch model ops with producer-fused fake-quant, hipGraph replay) vs the plain path (all of them
+    off, eager launches).  Different GEMM accumulation orders, the RMSNorm mean's summation order and the 1-ULP softmax
     caveat give a relative NLL difference <= 2e-3 (= +-0.01 at the reference's LLaMA-2-7B perplexity 5.36)."""
+    toggles = ("QT_FP8_GEMM", "QT_FUSED_SOFTMAX", "QT_FUSED_MODEL_OPS", "QT_FUSED_PRODUCER_FQ", "QT_FP8_ATTENTION", "QT_LT_GEMM")
+
     def run(fast):
-        for k in ("QT_FP8_GEMM", "QT_FUSED_SOFTMAX"):
+        for k in toggles:
             os.environ[k] = "1" if fast else "0"
         try:
             m = _llama("cuda", torch.bfloat16)
@@ -64,7 +67,7 @@ def test_perplexity_parity_bf16_fast_paths():
                     out.append(float(g.replay(ids, t) if fast else harness.window_nll(m, ids, t)))
             return out
         finally:
-            for k in ("QT_FP8_GEMM", "QT_FUSED_SOFTMAX"):
+            for k in toggles:
                 os.environ.pop(k, None)
     a, b = run(True), run(False)
     ma, mb = sum(a) / len(a), sum(b) / len(b)
