@@ -145,6 +145,11 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_d
  * (s0, s1, s2, 1) -- e.g. attention's q / k / v, [B, S, H, D] storage viewed as [B, H, S, D] -- and y is
  * written contiguous, which is the layout the reference's vmap returns (decomposed.py:155).  Saves the
  * separate .contiguous() copy.  inner and the strides must be multiples of 8. */
+/* FP8-only pass (stateless E4M3 / E5M2, unit scale) over up to four bf16 tensors in ONE launch, their codes written
+ * back to back into y8 (tensor i at element offset ns[0] + ... + ns[i-1]): the weight passes of sibling Linears that
+ * share an input (q / k / v projections), feeding one concatenated FP8 GEMM.  xs / ns are host arrays. */
+int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs_dev, const size_t *ns, int count, uint8_t *y8_dev,
+                                 const qt_format *fmt, void *stream);
 int qt_fake_quant_rows_bf16(const uint16_t *x_dev, uint16_t *y_dev, long d0, long d1, long d2, long inner,
                             long s0, long s1, long s2, const qt_format *fmt, const uint16_t *lut_dev,
                             const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
@@ -271,8 +276,10 @@ int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint
  * LlamaRMSNorm.forward, LlamaMLP.forward, apply_rotary_pos_emb / rotate_half).
  *   qt_rmsnorm_bf16:  y[r][c] = bf16(w[c] * bf16(x32 * rsqrt(mean_c(x32^2) + eps))); cols % 8 == 0, cols <= 16384
  *   qt_silu_mul_bf16: y = bf16(bf16(silu(gate)) * up), n % 8 == 0
- *   qt_rope_bf16:     q, k in [B][S][H][D] memory order (the transposed views HF passes), cos / sin [B][S][D];
- *                     out = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin)); D % 16 == 0 */
+ *   qt_rope_bf16:     q, k in [B][S][H][D] memory order (the transposed views HF passes) with a (b, s) row every
+ *                     q_row_stride / k_row_stride elements (H * D when contiguous; larger when the projection is a
+ *                     column slice of a wider GEMM output), cos / sin [B][S][D];
+ *                     out (contiguous [B][S][H][D]) = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin)); D % 16 == 0 */
 int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, long rows, long cols, float eps,
                     void *stream);
 /* qt_rmsnorm_bf16 with the FIRST consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result (bf16 + FP8
@@ -287,12 +294,13 @@ int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t 
 int qt_silu_mul_fq8_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n,
                          const qt_format *fmt, void *stream);
 int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
-                 uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, void *stream);
+                 uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride,
+                 long k_row_stride, void *stream);
 /* qt_rope_bf16 followed by the two stateless E4M3 / E5M2 fake-quantizers of qk_matmul's inputs, outputs contiguous in
  * [B][H][S][D] order (what those hooks' permuted-view pass would write): three launches in one. */
 int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
-                    uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D,
-                    const qt_format *fmt_q, const qt_format *fmt_k, void *stream);
+                    uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride,
+                    long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, void *stream);
 
 /* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
  * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose

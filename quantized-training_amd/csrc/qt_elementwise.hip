@@ -292,6 +292,36 @@ __global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, u
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
 
+// Several tensors, one launch: the FP8-only weight pass of sibling Linears (q / k / v projections) whose FP8 codes are
+// written back to back into one buffer, so that one GEMM can multiply by all of them.  The three 4096 x 4096 passes of
+// a LLaMA-2-7B layer are 12.5 us launches at 4.0 TB/s each; together they stream at the large-tensor rate.
+struct MultiArgs {
+    const uint4 *x[4];
+    size_t npair[4];          // 32-byte input pairs per tensor
+    size_t first[5];          // prefix sums of npair
+};
+
+template <bool E5M2>
+__global__ __launch_bounds__(256) void fq8_multi_kernel(MultiArgs a, uint4 *__restrict__ y8, qt_format fmt) {
+    const UniformDiv dv(1.0f);
+    uint32_t unused = 0;
+    const size_t total = a.first[4];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int t = (i >= a.first[1]) + (i >= a.first[2]) + (i >= a.first[3]);
+        const size_t j = i - a.first[t];
+        const uint4 v0 = a.x[t][2 * j], v1 = a.x[t][2 * j + 1];
+        float q0[8], q1[8];
+        fq8_vec(v0, fmt, dv, true, false, unused, q0);
+        fq8_vec(v1, fmt, dv, true, false, unused, q1);
+        uint4 o8;
+        o8.x = qt_pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
+        o8.y = qt_pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
+        o8.z = qt_pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
+        o8.w = qt_pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
+        y8[i] = o8;
+    }
+}
+
 // ---- strided rows -> contiguous ----------------------------------------------------------------------
 // Attention hands the hooks permuted views (q / k / v are [B, S, H, D] storage seen as [B, H, S, D]).  The
 // reference's vmap returns a contiguous tensor (decomposed.py:155), i.e. the layout change is part of the
@@ -869,6 +899,34 @@ int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, lo
         default: return QT_ERR_BAD_ARG;
     }
 #undef QT_ROWS
+    return launch_status();
+}
+
+int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs, const size_t *ns, int count, uint8_t *y8, const qt_format *fmt,
+                                 void *stream) {
+    if (!xs || !ns || !y8 || !fmt || count < 1 || count > 4 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    MultiArgs a{};
+    size_t run = 0;
+    for (int i = 0; i < 4; ++i) {
+        a.first[i] = run;
+        if (i < count) {
+            if (!xs[i]) return QT_ERR_BAD_ARG;
+            if ((ns[i] & 15) || ((uintptr_t)xs[i] & 15u)) return QT_ERR_UNALIGNED;
+            a.x[i] = (const uint4 *)xs[i];
+            a.npair[i] = ns[i] / 16;
+            run += a.npair[i];
+        }
+    }
+    a.first[4] = run;
+    if (run == 0) return QT_OK;
+    if ((uintptr_t)y8 & 15u) return QT_ERR_UNALIGNED;
+    const unsigned grid = grid_for(run, 256, g_blocks_per_cu);
+    hipStream_t st = (hipStream_t)stream;
+    if (e5m2) fq8_multi_kernel<true><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
+    else fq8_multi_kernel<false><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
     return launch_status();
 }
 

@@ -128,11 +128,13 @@ __global__ __launch_bounds__(256) void silu_mul_fq8_kernel(const uint4 *__restri
 }
 
 struct RopeArgs {
-    const uint16_t *x;       // [B][S][H][D] memory order
+    const uint16_t *x;       // [B][S][H][D] order; a (b, s) row starts every `rsv` vectors (>= H * D / 8: the projections
+                             // may be column slices of one wider GEMM output)
     uint16_t *y;
     const uint16_t *cos, *sin;   // [B][S][D]
     long B, S, H, D;
     size_t nvec;             // B * S * H * D / 8
+    long rsv;
 };
 
 __device__ __forceinline__ void rope_one(const RopeArgs &a, size_t i) {
@@ -142,8 +144,9 @@ __device__ __forceinline__ void rope_one(const RopeArgs &a, size_t i) {
     const size_t bs = bsh / (size_t)a.H;
     const long half = dv / 2;
     const bool low = d8 < half;
-    const uint4 xv = *(const uint4 *)(a.x + i * 8);
-    const uint4 pv = *(const uint4 *)(a.x + (bsh * dv + (low ? d8 + half : d8 - half)) * 8);     // rotate_half partner
+    const size_t in_row = bs * (size_t)a.rsv + (bsh % (size_t)a.H) * dv;      // vector index of x[b][s][h][0]
+    const uint4 xv = *(const uint4 *)(a.x + (in_row + d8) * 8);
+    const uint4 pv = *(const uint4 *)(a.x + (in_row + (low ? d8 + half : d8 - half)) * 8);     // rotate_half partner
     const uint4 cv = *(const uint4 *)(a.cos + (bs * dv + d8) * 8);
     const uint4 sv = *(const uint4 *)(a.sin + (bs * dv + d8) * 8);
     const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
@@ -184,7 +187,7 @@ __device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
     const long h = (long)(bh % (size_t)a.r.H);
     const size_t b = bh / (size_t)a.r.H;
     const size_t bs = b * a.r.S + s;
-    const size_t in_row = (bs * a.r.H + h) * dv;                 // vector index of x[b][s][h][0]
+    const size_t in_row = bs * (size_t)a.r.rsv + h * dv;         // vector index of x[b][s][h][0]
     const long half = dv / 2;
     const bool low = d8 < half;
     const uint4 xv = *(const uint4 *)(a.r.x + (in_row + d8) * 8);
@@ -284,13 +287,14 @@ int qt_silu_mul_fq8_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, 
 }
 
 int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
-                 uint16_t *k_out, long B, long S, long Hq, long Hk, long D, void *stream) {
+                 uint16_t *k_out, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, void *stream) {
     if (B * S * D == 0) return QT_OK;
     if (!q || !k || !cos || !sin || !q_out || !k_out || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
         return QT_ERR_UNALIGNED;
-    RopeArgs aq{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8)};
-    RopeArgs ak{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8)};
+    if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
+    RopeArgs aq{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8};
+    RopeArgs ak{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8};
     size_t blocks = (aq.nvec + ak.nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     rope_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
@@ -298,15 +302,16 @@ int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, cons
 }
 
 int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
-                    uint16_t *k_out, long B, long S, long Hq, long Hk, long D, const qt_format *fmt_q, const qt_format *fmt_k,
-                    void *stream) {
+                    uint16_t *k_out, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                    const qt_format *fmt_q, const qt_format *fmt_k, void *stream) {
     if (B * S * D == 0) return QT_OK;
     if (!q || !k || !cos || !sin || !q_out || !k_out || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
     if (fmt_q->kind != QT_FMT_FP_SAT || fmt_k->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
         return QT_ERR_UNALIGNED;
-    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8)}, *fmt_q};
-    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8)}, *fmt_k};
+    if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k};
     size_t blocks = (aq.r.nvec + ak.r.nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);

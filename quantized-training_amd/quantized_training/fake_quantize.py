@@ -608,6 +608,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         if not self._observe and not self._quantize:
             return X
         _Stats.add(X.numel())
+        orig_in = X
         X = FusedAmaxObsFakeQuantFunction.apply(
             X, self._observe, self._quantize, self.qmap, self.amax_history, self.scale,
             self.amax_history_len, self.quant_max, self.ch_axis, self.is_per_channel,
@@ -615,8 +616,10 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             self._emit_fp8 if (self._emit_fp8 and self.fp8_exact()) else None,
         )
         if isinstance(X, tuple):
+            src = orig_in
             X, x8 = X
             X._qt_fp8 = x8
+            X._qt_origin = (src.data_ptr(), src._version, tuple(src.shape))    # which tensor this is fq(.) of (sibling GEMMs)
 
         if self.outlier_threshold is not None:                              # upstream :401-402
             X = torch.where(mask, X, orig_X)

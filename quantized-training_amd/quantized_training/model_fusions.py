@@ -142,15 +142,26 @@ def attention_output(module, out):
     return out.transpose(1, 2).contiguous()
 
 
+def _row_stride(x):
+    """x [B, H, S, D] as the transposed view of a [B, S, H, D]-ordered buffer whose (b, s) rows may be wider than H * D
+    (a column slice of a fused projection's output): the row stride in elements, or None if x is something else."""
+    B, H, S, D = x.shape
+    sb, sh, ss, sd = x.stride()
+    if sd != 1 or sh != D or ss < H * D or ss % 8 or (B > 1 and sb != S * ss) or x.data_ptr() % 16:
+        return None
+    return ss
+
+
 def rope(q, k, cos, sin):
     """q [B, Hq, S, D], k [B, Hk, S, D] as the transposed views of [B, S, H, D] buffers that HF's attention holds;
     returns tensors with the same shape and memory order, as the torch chain would."""
     B, Hq, S, D = q.shape
     Hk = k.shape[1]
-    qb, kb = q.transpose(1, 2), k.transpose(1, 2)              # [B, S, H, D]
-    q_out, k_out = torch.empty_like(qb), torch.empty_like(kb)
-    _native.check(_native.lib().qt_rope_bf16(qb.data_ptr(), kb.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(),
-                                             k_out.data_ptr(), B, S, Hq, Hk, D, _stream_ptr(q)), "qt_rope_bf16")
+    q_out = torch.empty((B, S, Hq, D), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((B, S, Hk, D), dtype=k.dtype, device=k.device)
+    _native.check(_native.lib().qt_rope_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(),
+                                             k_out.data_ptr(), B, S, Hq, Hk, D, _row_stride(q), _row_stride(k),
+                                             _stream_ptr(q)), "qt_rope_bf16")
     return q_out.transpose(1, 2), k_out.transpose(1, 2)
 
 
@@ -159,13 +170,12 @@ def rope_fq(q, k, cos, sin, fq_q, fq_k):
     [B, H, S, D] (the layout those hooks write) and marked as done for fq_q / fq_k."""
     B, Hq, S, D = q.shape
     Hk = k.shape[1]
-    qb, kb = q.transpose(1, 2), k.transpose(1, 2)              # the [B, S, H, D] buffers
     q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
     k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
-    _native.check(_native.lib().qt_rope_fq_bf16(qb.data_ptr(), kb.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                q_out.data_ptr(), k_out.data_ptr(), B, S, Hq, Hk, D,
-                                                ctypes.byref(fq_q._qt_format), ctypes.byref(fq_k._qt_format),
-                                                _stream_ptr(q)), "qt_rope_fq_bf16")
+    _native.check(_native.lib().qt_rope_fq_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                q_out.data_ptr(), k_out.data_ptr(), B, S, Hq, Hk, D, _row_stride(q),
+                                                _row_stride(k), ctypes.byref(fq_q._qt_format),
+                                                ctypes.byref(fq_k._qt_format), _stream_ptr(q)), "qt_rope_fq_bf16")
     q_out._qt_fq_done_by = fq_q
     k_out._qt_fq_done_by = fq_k
     return q_out, k_out
@@ -250,7 +260,7 @@ def _patch_rope():
         ok = (unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and _eligible(q, k, cos, sin)
               and q.shape[-1] % 16 == 0 and q.shape[-1] == k.shape[-1] == cos.shape[-1] and cos.shape == sin.shape
               and cos.shape[0] in (1, q.shape[0]) and cos.shape[1] == q.shape[2] and k.shape[2] == q.shape[2]
-              and q.transpose(1, 2).is_contiguous() and k.transpose(1, 2).is_contiguous()
+              and _row_stride(q) is not None and _row_stride(k) is not None
               and cos.is_contiguous() and sin.is_contiguous() and q.numel() > 0 and k.shape[0] == q.shape[0])
         if ok:
             if cos.shape[0] != q.shape[0]:                      # position ids shared by the batch
@@ -291,6 +301,11 @@ def apply_llama_fusions(model):
         if isinstance(mod, ml.LlamaDecoderLayer):
             att, mlp = mod.self_attn, mod.mlp
             mod.input_layernorm.__dict__["_qt_consumers"] = [att.q_proj, att.k_proj, att.v_proj]
+            if all(hasattr(l, "weight_fake_quant") for l in (att.q_proj, att.k_proj, att.v_proj)):
+                from .fused import SiblingGroup
+                group = SiblingGroup([att.q_proj, att.k_proj, att.v_proj])
+                for lin in group.layers:
+                    lin.__dict__["_qt_sibling_group"] = group
             mod.post_attention_layernorm.__dict__["_qt_consumers"] = [mlp.gate_proj, mlp.up_proj]
     if n:
         _patch_rope()
