@@ -275,7 +275,8 @@ int qt_quantize_mx_f32(const float *x_dev, float *q_dev, float *scales_dev, uint
  * kernels.  Same operation order and bf16 rounding points as those chains (transformers modeling_llama.py:
  * LlamaRMSNorm.forward, LlamaMLP.forward, apply_rotary_pos_emb / rotate_half).
  *   qt_rmsnorm_bf16:  y[r][c] = bf16(w[c] * bf16(x32 * rsqrt(mean_c(x32^2) + eps))); cols % 8 == 0, cols <= 16384
- *   qt_silu_mul_bf16: y = bf16(bf16(silu(gate)) * up), n % 8 == 0
+ *   qt_silu_mul_bf16: y[rows][cols] = bf16(bf16(silu(gate)) * up); gate / up rows start every *_row_stride elements
+ *                     (cols when contiguous, more when they are column slices of one fused projection); cols % 8 == 0
  *   qt_rope_bf16:     q, k in [B][S][H][D] memory order (the transposed views HF passes) with a (b, s) row every
  *                     q_row_stride / k_row_stride elements (H * D when contiguous; larger when the projection is a
  *                     column slice of a wider GEMM output), cos / sin [B][S][D];
@@ -287,12 +288,13 @@ int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t 
  * those formats are idempotent, so what they compute is unchanged. */
 int qt_rmsnorm_fq8_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, uint8_t *y8_dev, long rows,
                         long cols, float eps, const qt_format *fmt, void *stream);
-int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t n, void *stream);
+int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols,
+                     size_t gate_row_stride, size_t up_row_stride, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:
  * y = fq(bf16(bf16(silu(gate)) * up)) as bf16 plus its FP8 code -- what the down-projection's input hook would compute
  * from the unfused result (quantize.py:128-140), bit for bit. */
-int qt_silu_mul_fq8_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n,
-                         const qt_format *fmt, void *stream);
+int qt_silu_mul_fq8_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t rows,
+                         size_t cols, size_t gate_row_stride, size_t up_row_stride, const qt_format *fmt, void *stream);
 int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
                  uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride,
                  long k_row_stride, void *stream);

@@ -84,10 +84,13 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
     }
 }
 
+// gate / up rows may be column slices of one wider GEMM output: row r of an operand starts at r * rs vectors (rs = cv,
+// the row length in vectors, when contiguous); the result is always contiguous
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ u,
-                                                       uint4 *__restrict__ y, size_t nvec) {
+                                                       uint4 *__restrict__ y, size_t nvec, size_t cv, size_t rs_g, size_t rs_u) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const uint4 a = g[i], b = u[i];
+        const size_t row = i / cv, col = i - row * cv;
+        const uint4 a = g[row * rs_g + col], b = u[row * rs_u + col];
         const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
         uint32_t o[4];
 #pragma unroll
@@ -106,9 +109,10 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint4 *__restrict__
 template <bool E5M2>
 __global__ __launch_bounds__(256) void silu_mul_fq8_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ u,
                                                            uint4 *__restrict__ y, uint2 *__restrict__ y8, size_t nvec,
-                                                           qt_format fmt) {
+                                                           qt_format fmt, size_t cv, size_t rs_g, size_t rs_u) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-        const uint4 a = g[i], b = u[i];
+        const size_t row = i / cv, col = i - row * cv;
+        const uint4 a = g[row * rs_g + col], b = u[row * rs_u + col];
         const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
         uint32_t o[4];
         float r[8];
@@ -257,32 +261,42 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, 
     return launch_status();
 }
 
-int qt_silu_mul_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, size_t n, void *stream) {
+int qt_silu_mul_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, size_t rows, size_t cols, size_t gate_row_stride,
+                     size_t up_row_stride, void *stream) {
+    const size_t n = rows * cols;
     if (n == 0) return QT_OK;
-    if (!gate || !up || !y) return QT_ERR_BAD_ARG;
-    if ((n & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u)) return QT_ERR_UNALIGNED;
+    if (!gate || !up || !y || gate_row_stride < cols || up_row_stride < cols) return QT_ERR_BAD_ARG;
+    if ((cols & 7) || ((gate_row_stride | up_row_stride) & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u))
+        return QT_ERR_UNALIGNED;
     const size_t nvec = n / 8;
     size_t blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    silu_mul_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, nvec);
+    silu_mul_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, nvec,
+                                                                       cols / 8, gate_row_stride / 8, up_row_stride / 8);
     return launch_status();
 }
 
-int qt_silu_mul_fq8_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt,
-                         void *stream) {
+int qt_silu_mul_fq8_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, uint8_t *y8, size_t rows, size_t cols,
+                         size_t gate_row_stride, size_t up_row_stride, const qt_format *fmt, void *stream) {
+    const size_t n = rows * cols;
     if (n == 0) return QT_OK;
-    if (!gate || !up || !y || !y8 || !fmt || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    if (!gate || !up || !y || !y8 || !fmt || fmt->kind != QT_FMT_FP_SAT || gate_row_stride < cols || up_row_stride < cols)
+        return QT_ERR_BAD_ARG;
     const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
     const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
     if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
-    if ((n & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
+    if ((cols & 7) || ((gate_row_stride | up_row_stride) & 7) || (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u) ||
+        ((uintptr_t)y8 & 7u))
+        return QT_ERR_UNALIGNED;
     const size_t nvec = n / 8;
     size_t blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (e5m2)
-        silu_mul_fq8_kernel<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
+        silu_mul_fq8_kernel<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt,
+                                                                                     cols / 8, gate_row_stride / 8, up_row_stride / 8);
     else
-        silu_mul_fq8_kernel<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
+        silu_mul_fq8_kernel<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, (uint2 *)y8, nvec, *fmt,
+                                                                                      cols / 8, gate_row_stride / 8, up_row_stride / 8);
     return launch_status();
 }
 
