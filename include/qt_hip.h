@@ -299,10 +299,12 @@ int qt_rope_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *c
                  uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride,
                  long k_row_stride, void *stream);
 /* qt_rope_bf16 followed by the two stateless E4M3 / E5M2 fake-quantizers of qk_matmul's inputs, outputs contiguous in
- * [B][H][S][D] order (what those hooks' permuted-view pass would write): three launches in one. */
+ * [B][H][S][D] order (what those hooks' permuted-view pass would write): three launches in one.  q_out8 / k_out8
+ * (nullable) receive the FP8 codes in the same order, for Q.K^T as an FP8 GEMM. */
 int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev,
-                    uint16_t *q_out_dev, uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride,
-                    long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, void *stream);
+                    uint16_t *q_out_dev, uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S,
+                    long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt_q,
+                    const qt_format *fmt_k, void *stream);
 
 /* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
  * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeArgs q, RopeArgs k) {
 struct RopeFqArgs {
     RopeArgs r;              // r.y is the [B][H][S][D] output
     qt_format fmt;
+    uint8_t *y8;             // optional FP8 code of the output, same order (NULL = not wanted)
+    int e5m2;
 };
 
 __device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
@@ -212,6 +214,13 @@ __device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
         out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
     }
     *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
+    if (a.y8) {                                          // the values are on the format's grid: their FP8 bytes are exact
+        const float f0 = qt_u2f(out[0] << 16), f1 = qt_u2f(out[0] & 0xFFFF0000u), f2 = qt_u2f(out[1] << 16),
+                    f3 = qt_u2f(out[1] & 0xFFFF0000u), f4 = qt_u2f(out[2] << 16), f5 = qt_u2f(out[2] & 0xFFFF0000u),
+                    f6 = qt_u2f(out[3] << 16), f7 = qt_u2f(out[3] & 0xFFFF0000u);
+        *(uint2 *)(a.y8 + o * 8) = a.e5m2 ? uint2{qt_pack_fp8x4<true>(f0, f1, f2, f3), qt_pack_fp8x4<true>(f4, f5, f6, f7)}
+                                          : uint2{qt_pack_fp8x4<false>(f0, f1, f2, f3), qt_pack_fp8x4<false>(f4, f5, f6, f7)};
+    }
 }
 
 __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k) {
@@ -316,16 +325,20 @@ int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, cons
 }
 
 int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
-                    uint16_t *k_out, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
-                    const qt_format *fmt_q, const qt_format *fmt_k, void *stream) {
+                    uint16_t *k_out, uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D,
+                    long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, void *stream) {
     if (B * S * D == 0) return QT_OK;
     if (!q || !k || !cos || !sin || !q_out || !k_out || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
     if (fmt_q->kind != QT_FMT_FP_SAT || fmt_k->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
         return QT_ERR_UNALIGNED;
     if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
-    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q};
-    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k};
+    if (((uintptr_t)q_out8 | (uintptr_t)k_out8) & 7u) return QT_ERR_UNALIGNED;
+    auto is_e5m2 = [](const qt_format *f) { return f->p0 == 2 && f->p1 == -14 && f->fhi == 57344.0f; };
+    auto is_e4m3 = [](const qt_format *f) { return f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f; };
+    if ((q_out8 && !is_e5m2(fmt_q) && !is_e4m3(fmt_q)) || (k_out8 && !is_e5m2(fmt_k) && !is_e4m3(fmt_k))) return QT_ERR_BAD_ARG;
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0};
     size_t blocks = (aq.r.nvec + ak.r.nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);

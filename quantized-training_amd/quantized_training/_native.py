@@ -80,8 +80,8 @@ SIGNATURES = {
     "qt_fake_quant_rows_bf16_fp8": (c_int, [_P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _P]),
     "qt_silu_mul_fq8_bf16": (c_int, [_P, _P, _P, _P, c_size_t, c_size_t, c_size_t, c_size_t, _FMT, _P]),
     "qt_rope_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _P]),
-    "qt_rope_fq_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _FMT,
-                               _P]),
+    "qt_rope_fq_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT,
+                               _FMT, _P]),
     "qt_fp8_gemm": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_long, c_int, c_int, c_int, c_long, c_long, c_long, _P,
                            c_size_t, c_int, _P]),
     "qt_mx_pack": (c_int, [_P, _P, c_int, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_int,

@@ -193,12 +193,16 @@ def rope_fq(q, k, cos, sin, fq_q, fq_k):
     Hk = k.shape[1]
     q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
     k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
+    q8 = torch.empty((B, Hq, S, D), dtype=torch.uint8, device=q.device)
+    k8 = torch.empty((B, Hk, S, D), dtype=torch.uint8, device=k.device)
     _native.check(_native.lib().qt_rope_fq_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                q_out.data_ptr(), k_out.data_ptr(), B, S, Hq, Hk, D, _row_stride(q),
-                                                _row_stride(k), ctypes.byref(fq_q._qt_format),
+                                                q_out.data_ptr(), k_out.data_ptr(), q8.data_ptr(), k8.data_ptr(), B, S, Hq,
+                                                Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fq_q._qt_format),
                                                 ctypes.byref(fq_k._qt_format), _stream_ptr(q)), "qt_rope_fq_bf16")
     q_out._qt_fq_done_by = fq_q
     k_out._qt_fq_done_by = fq_k
+    q_out._qt_fp8 = _fp8_view(q8, fq_q)                 # Q.K^T can then run as an FP8 GEMM (functional_modules.py)
+    k_out._qt_fp8 = _fp8_view(k8, fq_k)
     return q_out, k_out
 
 

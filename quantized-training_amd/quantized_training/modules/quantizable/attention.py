@@ -57,6 +57,8 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     key_t = key.transpose(2, 3)
     if getattr(key, "_qt_fq_done_by", None) is not None:
         key_t._qt_fq_done_by = key._qt_fq_done_by          # fake-quant is elementwise: done for K means done for K^T
+        if getattr(key, "_qt_fp8", None) is not None:
+            key_t._qt_fp8_of_transpose = key._qt_fp8        # FP8 code of K itself ([B, H, S, D], contiguous)
     scores = module.qk_matmul(query, key_t)
     fused = fused_scores_to_probs_or_none(module, scores, attention_mask, scaling, dropout, value)
     if fused is not None:

@@ -1025,6 +1025,7 @@ def test_rotary_fused_with_qk_fake_quant(nv):
         assert torch.equal(want_q.contiguous().view(torch.int16), got_q.view(torch.int16))
         assert torch.equal(want_k.contiguous().view(torch.int16), got_k.view(torch.int16))
         assert fq_q(got_q) is got_q and fq_k(got_k) is got_k
+        assert torch.equal(got_q._qt_fp8.float(), got_q.float()) and torch.equal(got_k._qt_fp8.float(), got_k.float())
 
 
 def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
