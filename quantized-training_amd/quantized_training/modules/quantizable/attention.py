@@ -42,6 +42,24 @@ def _repeat_kv(x, n_rep):
     return x[:, :, None, :, :].expand(b, h, n_rep, s, d).reshape(b, h * n_rep, s, d)
 
 
+def _additive_mask(mask, dtype):
+    """HF builds a BOOLEAN keep-mask when the model was loaded with its default (sdpa) attention
+    implementation -- always under stream capture, and in eager mode whenever the batch holds padding.
+    The upstream blocks add the mask to the scores (modeling_bert.py:142-145), so turn a boolean mask
+    into the additive form once per forward (every layer receives the same tensor object)."""
+    if mask is None or mask.dtype != torch.bool:
+        return mask
+    cached = getattr(mask, "_qt_additive", None)
+    if cached is not None and cached.dtype == dtype:
+        return cached
+    keep = mask
+    if keep.dim() == 4 and keep.shape[2] > 1 and keep.stride(2) == 0:
+        keep = keep[:, :, :1]                   # query-broadcast view: keep it broadcast
+    add = torch.zeros(keep.shape, dtype=dtype, device=keep.device).masked_fill_(~keep, torch.finfo(dtype).min)
+    mask._qt_additive = add
+    return add
+
+
 def quantizable_attention_forward(module, query, key, value, attention_mask, scaling=None, dropout=0.0, **kwargs):
     """Drop-in for HF's ``eager_attention_forward`` that goes through the module's hookable ops:
     ``av_matmul(softmax(attn_scaling(qk_matmul(q, k^T), scale) + mask), v)``."""
@@ -50,6 +68,7 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     value = _repeat_kv(value, n_rep)
     if scaling is None:
         scaling = query.size(-1) ** -0.5
+    attention_mask = _additive_mask(attention_mask, query.dtype)
     from ...fused import fused_attention_or_none, fused_scores_to_probs_or_none
     core = fused_attention_or_none(module, query, key, value, attention_mask, scaling, dropout)
     if core is not None:

@@ -106,6 +106,26 @@ def test_conversion_alone_preserves_the_float_model():
         assert torch.allclose(_first_logits(m), ref, atol=1e-6, rtol=1e-5)
 
 
+def test_padded_batch_with_the_default_attention_implementation():
+    """A model built with HF's default attention implementation hands the blocks a BOOLEAN keep-mask when the batch
+    holds padding; the twins must treat it as the additive mask the upstream blocks add to the scores."""
+    from quantized_training.quantization_mappings import TRANSFORMER_MODULE_MAPPINGS
+    att = torch.ones_like(IDS)
+    att[0, 9:] = 0
+    att[1, 13:] = 0
+    for build in (_bert, _roberta):
+        m = build()
+        with torch.no_grad():
+            ref = m(IDS, attention_mask=att)
+        ref = ref.start_logits if hasattr(ref, "start_logits") else ref.logits
+        qt.propagate_config(m, "config", m.config)
+        qt.convert(m, inplace=True, custom_module_class_mapping=TRANSFORMER_MODULE_MAPPINGS)
+        with torch.no_grad():
+            out = m(IDS, attention_mask=att)
+        out = out.start_logits if hasattr(out, "start_logits") else out.logits
+        assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5), (out - ref).abs().max()
+
+
 def test_op_fusion_skips_named_modules_and_weights_only():
     m = _bert()
     qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--quantize_forward", "gemm,residual",
