@@ -3,7 +3,8 @@ each ``--quantize_forward`` / ``--quantize_backprop`` op group covers
 (upstream src/quantized_training/quantization_mappings.py:16-72).
 
 HF model families are looked up lazily and only if `transformers` provides them; families whose
-twins this engine does not build (DistilBERT, GPT-2, Whisper, LoRA / conv QAT) are absent.
+twins this engine does not build (DistilBERT, GPT-2, Whisper, conv QAT) are absent.  The LoRA QAT layer is
+registered for ``peft.tuners.lora.Linear`` when ``peft`` imports (upstream :20).
 """
 import importlib
 from typing import Any, Callable, Dict
@@ -20,6 +21,14 @@ __all__ = [
 DEFAULT_QAT_MODULE_MAPPINGS: Dict[Callable, Any] = {
     nn.Linear: nnqat.Linear,
 }
+
+
+try:                                                     # optional dependency (upstream imports it unconditionally)
+    from peft.tuners import lora as _peft_lora
+    nnqat.LoraLinear._FLOAT_MODULE = _peft_lora.Linear
+    DEFAULT_QAT_MODULE_MAPPINGS[_peft_lora.Linear] = nnqat.LoraLinear
+except Exception:  # noqa: BLE001
+    _peft_lora = None
 
 
 def _hf(module, name):

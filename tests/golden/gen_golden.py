@@ -637,6 +637,66 @@ def gen_windows(out):
         json.dump(res, f, indent=1)
 
 
+LORA_CASES = [
+    # name, weight spec, fan_in_fan_out, rank, (in, out)
+    ("lora_int8_delayed", "int8,qs=per_tensor_symmetric,ahl=3", False, 4, (48, 32)),
+    ("lora_e4m3", "e4m3", False, 8, (64, 40)),
+    ("lora_fp8_pow2_fanin", "fp8_e4m3,qs=per_tensor_symmetric", True, 4, (32, 48)),
+]
+
+
+def gen_lora(ref, out):
+    """Three training steps through the LoRA QAT layer's forward (modules/qat/lora.py:34-55).  peft is not
+    installed, so the layer object is assembled by hand around the reference class (its __init__ needs peft's
+    base class) and only the reference's own forward runs."""
+    import importlib
+    from dataclasses import asdict
+    import torch.nn as nn
+    lora = importlib.import_module("quantized_training.modules.qat.lora")
+    arrays, meta = {}, []
+    for name, spec, fifo, r, (fin, fout) in LORA_CASES:
+        torch.manual_seed(7)
+        kw = asdict(ref.quantizer.QuantizationSpec.from_str(spec))
+        layer = lora.Linear.__new__(lora.Linear)
+        nn.Module.__init__(layer)
+        w = torch.randn(fout, fin) * 0.1
+        layer.weight = nn.Parameter((w.T.contiguous() if fifo else w).to(torch.bfloat16), requires_grad=False)
+        layer.bias = nn.Parameter((torch.randn(fout) * 0.1).to(torch.bfloat16), requires_grad=False)
+        a, b = nn.Linear(fin, r, bias=False), nn.Linear(r, fout, bias=False)
+        with torch.no_grad():
+            b.weight.copy_(torch.randn(fout, r) * 0.05)
+        layer.lora_A = nn.ModuleDict({"default": a.to(torch.bfloat16)})
+        layer.lora_B = nn.ModuleDict({"default": b.to(torch.bfloat16)})
+        layer.scaling = {"default": 2.0}
+        layer.active_adapters = ["default"]
+        layer.merged = False
+        layer.disable_adapters = False
+        layer.fan_in_fan_out = fifo
+        layer.weight_fake_quant = ref.fake_quantize.FusedAmaxObsFakeQuantize(**kw)
+        arrays[f"{name}/w"] = tensor_bits(layer.weight.data)
+        arrays[f"{name}/b"] = tensor_bits(layer.bias.data)
+        arrays[f"{name}/A"] = tensor_bits(a.weight.data)
+        arrays[f"{name}/B"] = tensor_bits(b.weight.data)
+        opt = torch.optim.SGD([a.weight, b.weight], lr=0.5)
+        for step in range(3):
+            x = (torch.randn(5, fin) * (1.0 + step)).to(torch.bfloat16)
+            y = layer(x)
+            opt.zero_grad()
+            y.float().square().mean().backward()
+            arrays[f"{name}/{step}/x"] = tensor_bits(x)
+            arrays[f"{name}/{step}/y"] = tensor_bits(y.detach())
+            arrays[f"{name}/{step}/gA"] = tensor_bits(a.weight.grad)
+            arrays[f"{name}/{step}/gB"] = tensor_bits(b.weight.grad)
+            arrays[f"{name}/{step}/scale"] = f32_bits(layer.weight_fake_quant.scale.detach().clone().float().reshape(-1))
+            opt.step()
+        assert layer.weight.grad is None
+        meta.append({"name": name, "spec": spec, "fan_in_fan_out": fifo, "r": r, "in": fin, "out": fout, "steps": 3,
+                     "scaling": 2.0, "lr": 0.5})
+    np.savez_compressed(os.path.join(out, "lora.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "lora.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
@@ -654,6 +714,7 @@ def main():
         "pt2e": lambda: gen_pt2e(ref, a.out),
         "pt2e_mx": lambda: gen_pt2e_mx(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
+        "lora": lambda: gen_lora(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),
         "windows": lambda: gen_windows(a.out),
     }

@@ -219,3 +219,30 @@ def test_llama_model_fusions_vs_hf_chains():
     (a, na), (b, nb) = res["1"], res["0"]
     assert na == nb
     assert all(abs(x - y) <= 1e-3 * abs(y) for x, y in zip(a, b)), (a, b)
+
+
+def test_lora_qat_linear_on_device_matches_golden_forward():
+    """The LoRA QAT layer on device tensors: the three weight fake-quant calls run through the HIP kernels; the
+    first forward of each golden case (reference run, tests/golden/gen_golden.py gen_lora) is reproduced up to the
+    accumulation order of the two bf16 matmuls (|dy| <= 2^-6 (|y| + 1))."""
+    from test_surface_cpu import LORA, LORA_NPZ, _PeftStyleLoraLinear, _from_bits16
+    from quantized_training.modules.qat import LoraLinear
+    for case in LORA:
+        n, fin, fout, r = case["name"], case["in"], case["out"], case["r"]
+        key = lambda k: LORA_NPZ[(n + "/" + k).replace("/", "__")]
+        flt = _PeftStyleLoraLinear(fin, fout, r, case["fan_in_fan_out"])
+        with torch.no_grad():
+            flt.base_layer.weight.copy_(_from_bits16(key("w"), flt.base_layer.weight.shape))
+            flt.base_layer.bias.copy_(_from_bits16(key("b"), (fout,)))
+            flt.lora_A["default"].weight.copy_(_from_bits16(key("A"), (r, fin)))
+            flt.lora_B["default"].weight.copy_(_from_bits16(key("B"), (fout, r)))
+        flt.qconfig = qt.get_qconfig(None, qt.QuantizationSpec.from_str(case["spec"]), None)
+        layer = LoraLinear.from_float(flt).cuda()
+        x = _from_bits16(key("0/x"), (5, fin)).cuda()
+        y = layer(x)
+        y.float().square().mean().backward()
+        ref = _from_bits16(key("0/y"), (5, fout)).float()
+        assert ((y.detach().float().cpu() - ref).abs() <= 2.0 ** -6 * (ref.abs() + 1)).all(), n
+        g = flt.lora_B["default"].weight.grad
+        gref = _from_bits16(key("0/gB"), (fout, r)).float()
+        assert g is not None and ((g.float().cpu() - gref).abs() <= 2.0 ** -5 * (gref.abs() + gref.abs().max())).all(), n

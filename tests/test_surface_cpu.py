@@ -316,3 +316,69 @@ def test_normal_float_maps(dt):
     assert np.array_equal(_canon16(m.qmap.view(torch.int16).numpy().view(np.uint16)), g[dt])
     i2, v2 = qt.quantize_to_nf(torch.tensor([0.3, -2.0, 0.0], dtype=torch.bfloat16), 4)
     assert v2.numel() == 16 and float(v2[i2[1]]) == -1.0 and float(v2[i2[2]]) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LoRA QAT layer (upstream modules/qat/lora.py) against three reference training steps
+LORA = json.load(open(os.path.join(G, "lora.json")))
+LORA_NPZ = np.load(os.path.join(G, "lora.npz"))
+
+
+def _from_bits16(a, shape):
+    return torch.from_numpy(a.astype(np.uint16).view(np.int16).copy()).view(torch.bfloat16).reshape(shape)
+
+
+class _PeftStyleLoraLinear(nn.Module):
+    """The attributes peft's LoRA linear layer exposes (current layout: frozen projection under base_layer)."""
+
+    def __init__(self, fin, fout, r, fan_in_fan_out):
+        super().__init__()
+        self.base_layer = nn.Linear(fin, fout).to(torch.bfloat16)
+        if fan_in_fan_out:
+            self.base_layer.weight = nn.Parameter(torch.empty(fin, fout, dtype=torch.bfloat16))
+        self.base_layer.weight.requires_grad_(False)
+        self.base_layer.bias.requires_grad_(False)
+        self.in_features, self.out_features = fin, fout
+        self.lora_A = nn.ModuleDict({"default": nn.Linear(fin, r, bias=False).to(torch.bfloat16)})
+        self.lora_B = nn.ModuleDict({"default": nn.Linear(r, fout, bias=False).to(torch.bfloat16)})
+        self.scaling = {"default": 2.0}
+        self.r, self.lora_alpha = {"default": r}, {"default": 2 * r}
+        self.active_adapters = ["default"]
+        self.merged_adapters = []
+        self.disable_adapters = False
+        self.fan_in_fan_out = fan_in_fan_out
+
+
+@pytest.mark.parametrize("case", LORA, ids=[c["name"] for c in LORA])
+def test_lora_qat_linear_matches_reference_steps(case):
+    from quantized_training.modules.qat import LoraLinear
+    n, fin, fout, r = case["name"], case["in"], case["out"], case["r"]
+    key = lambda k: LORA_NPZ[(n + "/" + k).replace("/", "__")]
+    flt = _PeftStyleLoraLinear(fin, fout, r, case["fan_in_fan_out"])
+    with torch.no_grad():
+        flt.base_layer.weight.copy_(_from_bits16(key("w"), flt.base_layer.weight.shape))
+        flt.base_layer.bias.copy_(_from_bits16(key("b"), (fout,)))
+        flt.lora_A["default"].weight.copy_(_from_bits16(key("A"), (r, fin)))
+        flt.lora_B["default"].weight.copy_(_from_bits16(key("B"), (fout, r)))
+    flt.qconfig = qt.get_qconfig(None, qt.QuantizationSpec.from_str(case["spec"]), None)
+    layer = LoraLinear.from_float(flt)
+    assert layer.weight is flt.base_layer.weight and layer.lora_A is flt.lora_A
+    a, b = flt.lora_A["default"].weight, flt.lora_B["default"].weight
+    opt = torch.optim.SGD([a, b], lr=case["lr"])
+    for step in range(case["steps"]):
+        x = _from_bits16(key(f"{step}/x"), (5, fin))
+        y = layer(x)
+        opt.zero_grad()
+        y.float().square().mean().backward()
+        assert np.array_equal(_bits(y.detach()), key(f"{step}/y")), step
+        assert np.array_equal(_bits(a.grad), key(f"{step}/gA")), step
+        assert np.array_equal(_bits(b.grad), key(f"{step}/gB")), step
+        assert np.array_equal(layer.weight_fake_quant.scale.detach().float().reshape(-1).view(torch.int32).numpy().view(np.uint32),
+                              key(f"{step}/scale")), step
+        opt.step()
+    assert layer.weight.grad is None
+    # adapters disabled -> the plain projection
+    layer.enable_adapters(False)
+    x = _from_bits16(key("0/x"), (5, fin))
+    w = layer.weight.T if case["fan_in_fan_out"] else layer.weight
+    assert torch.equal(layer(x), torch.nn.functional.linear(x, w, layer.bias))
