@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP8_PEAK_TFLOPS = 5000.0        # MI355X_MICROARCH.md: FP8 MFMA ~5 PF dense (sparse figures are never used)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
@@ -96,13 +97,43 @@ def roofline_leg(device):
             pass
     del x, y, y8
     torch.cuda.empty_cache()
+    gemm = gemm_leg(device)
     return {"bound": "hbm", "achieved": round(achieved8, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved8 / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "kernel": "fq8_kernel<obs off, fp8 only> e4m3 4096x11008 (weight pass of the FP8 GEMM route)",
             "ms_per_launch": round(ms8.value, 5), "algorithmic_bytes_per_launch": n * 3,
             "bf16_out": {"kernel": "fq_kernel<bf16,FP_SAT> e4m3 4096x11008", "achieved": round(achieved, 1),
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "ms_per_launch": round(ms.value, 5),
-                         "algorithmic_bytes_per_launch": n * 4, "traffic": traffic_bf16}}
+                         "algorithmic_bytes_per_launch": n * 4, "traffic": traffic_bf16},
+            "gemm": gemm}
+
+
+def gemm_leg(device):
+    """MFMA side of the window: the FP8 GEMM that consumes the weight pass's codes, at the gate/up projection's
+    shape (tokens 1024 x out 11008 x in 4096; one of the 225 linear GEMMs of a window, 2 M N K = 92.3 GFLOP), through
+    qt_fp8_gemm (hipBLASLt, algorithm chosen by measurement), timed with events on the launch stream while rotating
+    over 8 weight tensors (8 x 45 MB, more than the Infinity Cache).  Peak: the guide's dense FP8 figure (~5 PFLOP/s)."""
+    from quantized_training.fused import lt_fp8_gemm
+    M, N, K, pool = 1024, 11008, 4096, 8
+    a8 = torch.randn(M, K, device=device).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(pool, N, K, device=device) * 0.02).to(torch.float8_e4m3fn)
+    if lt_fp8_gemm(a8, b8[0]) is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for iters in (pool, 5 * pool):
+        e0.record()
+        for i in range(iters):
+            lt_fp8_gemm(a8, b8[i % pool])
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    del a8, b8
+    torch.cuda.empty_cache()
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP8_PEAK_TFLOPS, 4), "ms_per_launch": round(ms, 5),
+            "kernel": "FP8 E4M3 GEMM 1024x11008x4096 (gate/up projection), fp32 accumulate, bf16 out",
+            "flops_per_launch": 2 * M * N * K}
 
 
 def cpu_baseline_leg():
@@ -237,12 +268,12 @@ def main():
                        "valid": bool(full) and not a.cache_eval_weights},
             "mean_window_nll": float(allnll.double().mean().item()),
         }
-    if rank == 0 and world == 1:
+    if rank == 0:                                   # outside the timed region; the other ranks wait at the barrier below
         del model
         torch.cuda.empty_cache()
         if not a.no_roofline:
             out["roofline"] = roofline_leg(device)
-        if not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
     if multi:
         dist.barrier()
