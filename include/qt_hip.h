@@ -288,6 +288,18 @@ int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t 
  * those formats are idempotent, so what they compute is unchanged. */
 int qt_rmsnorm_fq8_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, uint8_t *y8_dev, long rows,
                         long cols, float eps, const qt_format *fmt, void *stream);
+/* BERT-style blocks (transformers modeling_bert.py BertSelfOutput / BertOutput / BertIntermediate, and the twins of
+ * upstream modules/quantizable/modeling_bert.py:174-214): `LayerNorm(dense(x) + residual)` and the erf-form GELU.
+ *   qt_layernorm_bf16: s = bf16(x + residual) (residual may be NULL: s = x); y = bf16(w * (rstd * (s - mean)) + b) with the
+ *                      row mean / biased variance in fp32; cols % 8 == 0, cols <= 16384.  With yq / y8 (both or neither) the
+ *                      consumer's stateless E4M3 / E5M2 fake-quantizer `fmt` is applied as well: yq = fq(y) as bf16, y8 its
+ *                      FP8 code; y itself stays unquantized (it also feeds the next residual connection).
+ *   qt_gelu_bf16:      y = bf16((x * 0.5) * (1 + erf(x * sqrt(1/2)))); with y8 the consumer's fake-quantizer is applied on
+ *                      the way out (y = fq(gelu(x)) as bf16, y8 its FP8 code); n % 8 == 0 */
+int qt_layernorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, const uint16_t *bias_dev,
+                      uint16_t *y_dev, uint16_t *yq_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt,
+                      void *stream);
+int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n, const qt_format *fmt, void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols,
                      size_t gate_row_stride, size_t up_row_stride, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:

@@ -231,6 +231,143 @@ __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k
     }
 }
 
+// ---- BERT-style blocks: LayerNorm(dense(x) + residual) and GELU between the fake-quantized GEMMs ----------------
+//   add + LayerNorm   s = bf16(x + res);  y = bf16(w * (rstd * (s32 - mean)) + b),  mean / biased variance over the row
+//                     in fp32 (two passes over registers), rstd = rsqrt(var + eps)   [torch: add, native_layer_norm]
+//   GELU (erf form)   y = bf16((x32 * 0.5) * (1 + erf(x32 * sqrt(1/2))))                    [torch: GeluCUDAKernelImpl]
+// With FQ the consumer's stateless E4M3 / E5M2 fake-quantizer is applied on the way out.  A LayerNorm result also feeds
+// the next residual connection unquantized, so that kernel writes three tensors: y, fq(y) as bf16 and its FP8 code.
+struct LnArgs {
+    const uint4 *x, *res, *w, *b;
+    uint4 *y, *yq;
+    uint2 *y8;
+    long rows;
+    int nvec;
+    float inv_cols, eps;
+    qt_format fmt;
+};
+
+// G threads per row (64: one wavefront, rows up to 1024 elements keep <= 2 vectors per lane; 256: the whole workgroup)
+template <int G, int FQ, bool ADD>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+    constexpr int RPB = 256 / G;
+    __shared__ float s_part[2][4];
+    const int sub = threadIdx.x / G, lane = threadIdx.x % G;
+    const long row = (long)blockIdx.x * RPB + sub;
+    if (G == 64 && row >= a.rows) return;                    // whole wavefronts leave; no workgroup barrier on this path
+    const size_t base = (size_t)row * (size_t)a.nvec;
+    uint4 v[kNormMaxVec];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNormMaxVec; ++i) {
+        const int c = lane + i * G;
+        if (c < a.nvec) {
+            v[i] = a.x[base + c];
+            if constexpr (ADD) {
+                const uint4 r = a.res[base + c];
+                v[i].x = pack_bf16x2(bf_lo(v[i].x) + bf_lo(r.x), bf_hi(v[i].x) + bf_hi(r.x));
+                v[i].y = pack_bf16x2(bf_lo(v[i].y) + bf_lo(r.y), bf_hi(v[i].y) + bf_hi(r.y));
+                v[i].z = pack_bf16x2(bf_lo(v[i].z) + bf_lo(r.z), bf_hi(v[i].z) + bf_hi(r.z));
+                v[i].w = pack_bf16x2(bf_lo(v[i].w) + bf_lo(r.w), bf_hi(v[i].w) + bf_hi(r.w));
+            }
+            sum += (bf_lo(v[i].x) + bf_hi(v[i].x)) + (bf_lo(v[i].y) + bf_hi(v[i].y)) + (bf_lo(v[i].z) + bf_hi(v[i].z)) +
+                   (bf_lo(v[i].w) + bf_hi(v[i].w));
+        }
+    }
+    auto reduce = [&](float t, int slot) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if constexpr (G == 256) {
+            if ((threadIdx.x & 63) == 0) s_part[slot][threadIdx.x >> 6] = t;
+            __syncthreads();
+            t = (s_part[slot][0] + s_part[slot][1]) + (s_part[slot][2] + s_part[slot][3]);
+        }
+        return t;
+    };
+    const float mean = reduce(sum, 0) * a.inv_cols;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNormMaxVec; ++i) {
+        const int c = lane + i * G;
+        if (c < a.nvec) {
+            const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d0 = bf_lo(q[j]) - mean, d1 = bf_hi(q[j]) - mean;
+                sq += d0 * d0;
+                sq += d1 * d1;
+            }
+        }
+    }
+    const float rstd = rsqrtf(reduce(sq, 1) * a.inv_cols + a.eps);
+#pragma unroll
+    for (int i = 0; i < kNormMaxVec; ++i) {
+        const int c = lane + i * G;
+        if (c < a.nvec) {
+            const uint4 ww = a.w[c], bb = a.b[c];
+            const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, g[4] = {ww.x, ww.y, ww.z, ww.w}, h[4] = {bb.x, bb.y, bb.z, bb.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack_bf16x2(bf_lo(g[j]) * (rstd * (bf_lo(q[j]) - mean)) + bf_lo(h[j]),
+                                   bf_hi(g[j]) * (rstd * (bf_hi(q[j]) - mean)) + bf_hi(h[j]));
+            a.y[base + c] = uint4{o[0], o[1], o[2], o[3]};
+            if constexpr (FQ != 0) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+                    const uint32_t r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+                    o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+                    f[2 * j] = qt_u2f(r0);
+                    f[2 * j + 1] = qt_u2f(r1);
+                }
+                a.yq[base + c] = uint4{o[0], o[1], o[2], o[3]};
+                a.y8[base + c] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int FQ>
+__global__ __launch_bounds__(256) void gelu_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, uint2 *__restrict__ y8,
+                                                   size_t nvec, qt_format fmt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 a = x[i];
+        const uint32_t p[4] = {a.x, a.y, a.z, a.w};
+        uint32_t o[4];
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = pack_bf16x2(gelu_erf(bf_lo(p[j])), gelu_erf(bf_hi(p[j])));
+            if constexpr (FQ != 0) {
+                const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, fmt.p0, fmt.p1, fmt.fhi), r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
+                o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+                f[2 * j] = qt_u2f(r0);
+                f[2 * j + 1] = qt_u2f(r1);
+            }
+        }
+        y[i] = uint4{o[0], o[1], o[2], o[3]};
+        if constexpr (FQ != 0) y8[i] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
+    }
+}
+
+int fp8_code_of(const qt_format *f) {                       // 1 E4M3, 2 E5M2, 0 neither
+    if (!f || f->kind != QT_FMT_FP_SAT) return 0;
+    if (f->p0 == 2 && f->p1 == -14 && f->fhi == 57344.0f) return 2;
+    if (f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f) return 1;
+    return 0;
+}
+
+template <int G, bool ADD>
+void launch_layernorm(const LnArgs &a, int fq, unsigned blocks, hipStream_t st) {
+    if (fq == 2) layernorm_kernel<G, 2, ADD><<<blocks, 256, 0, st>>>(a);
+    else if (fq == 1) layernorm_kernel<G, 1, ADD><<<blocks, 256, 0, st>>>(a);
+    else layernorm_kernel<G, 0, ADD><<<blocks, 256, 0, st>>>(a);
+}
+
 int launch_status() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
@@ -267,6 +404,45 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, 
     else
         rmsnorm_kernel<1><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
                                                                                     (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
+    return launch_status();
+}
+
+int qt_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, const uint16_t *bias, uint16_t *y,
+                      uint16_t *yq, uint8_t *y8, long rows, long cols, float eps, const qt_format *fmt, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !bias || !y || rows < 0 || cols < 0 || ((yq != nullptr) != (y8 != nullptr))) return QT_ERR_BAD_ARG;
+    const int fq = yq ? fp8_code_of(fmt) : 0;
+    if (yq && !fq) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)yq) & 15u) || ((uintptr_t)y8 & 7u))
+        return QT_ERR_UNALIGNED;
+    LnArgs a{(const uint4 *)x, (const uint4 *)residual, (const uint4 *)weight, (const uint4 *)bias, (uint4 *)y, (uint4 *)yq, (uint2 *)y8,
+             rows, (int)(cols / 8), 1.0f / (float)cols, eps, fmt && fq ? *fmt : qt_format{}};
+    hipStream_t st = (hipStream_t)stream;
+    if (a.nvec <= 128) {
+        const unsigned blocks = (unsigned)((rows + 3) / 4);
+        if (residual) launch_layernorm<64, true>(a, fq, blocks, st);
+        else launch_layernorm<64, false>(a, fq, blocks, st);
+    } else {
+        if (residual) launch_layernorm<256, true>(a, fq, (unsigned)rows, st);
+        else launch_layernorm<256, false>(a, fq, (unsigned)rows, st);
+    }
+    return launch_status();
+}
+
+int qt_gelu_bf16(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y) return QT_ERR_BAD_ARG;
+    const int fq = y8 ? fp8_code_of(fmt) : 0;
+    if (y8 && !fq) return QT_ERR_BAD_ARG;
+    if ((n & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
+    const size_t nvec = n / 8;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (fq == 2) gelu_kernel<2><<<(unsigned)blocks, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
+    else if (fq == 1) gelu_kernel<1><<<(unsigned)blocks, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, (uint2 *)y8, nvec, *fmt);
+    else gelu_kernel<0><<<(unsigned)blocks, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, nullptr, nvec, qt_format{});
     return launch_status();
 }
 

@@ -550,10 +550,12 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             if self.scale_qmap is not None:
                 self.scale_qmap = _table_for(self.scale_dtype, device)
 
-    def expect_prequantized(self, tensor, x8):
-        """A producing kernel wrote fq(values) into `tensor` (and the FP8 code into x8) for this fake-quantizer's NEXT
-        call; see forward()."""
-        self.__dict__["_qt_expected"] = (tensor.data_ptr(), tensor.numel(), tensor._version, x8)
+    def expect_prequantized(self, tensor, x8, replacement=None):
+        """A producing kernel computed fq(tensor) for this fake-quantizer's NEXT call; see forward().  Without
+        `replacement` the quantized values were written into `tensor` itself (FP8 code in x8); with it `tensor` holds
+        the unquantized values (it has other readers, e.g. a residual connection) and `replacement` = fq(tensor) as
+        bf16.  The tensor is kept referenced until that call so that its storage cannot be recycled in between."""
+        self.__dict__["_qt_expected"] = (tensor.data_ptr(), tensor.numel(), tensor._version, x8, replacement, tensor)
 
     def producer_fusable(self) -> bool:
         """True when this fake-quantizer is a pure stateless function a producing kernel may apply on its behalf
@@ -573,9 +575,14 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             # same hand-over when the producer's tensor reaches the hook as a view (a reshape in between drops Python
             # attributes): the producer left the storage it wrote, valid for this -- the very next -- call only
             self.__dict__["_qt_expected"] = None
-            ptr, numel, version, x8 = expect
+            ptr, numel, version, x8, replacement, _keep = expect
             if X.data_ptr() == ptr and X.numel() == numel and X._version == version and X.is_contiguous():
                 _Stats.add(numel)
+                if replacement is not None:
+                    out = replacement.view(X.shape)
+                    out._qt_fp8 = x8.view(X.shape)
+                    out._qt_origin = (ptr, version, tuple(X.shape))       # fq(.) of X, for sibling GEMMs
+                    return out
                 X._qt_fp8 = x8
                 return X
         self._move_to(X.device)

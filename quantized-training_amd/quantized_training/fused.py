@@ -165,6 +165,7 @@ class SiblingGroup:
     def __init__(self, layers):
         self.layers = list(layers)
         self.buf = None
+        self.bias = None                       # (key of the members' bias versions, concatenated bias [sum N])
         self.stash = None                      # (origin key, product [M, sum N], taken flags)
 
     def eligible(self):
@@ -172,9 +173,12 @@ class SiblingGroup:
             return (f.kind, f.p0, f.p1, f.flo, f.fhi)
         K = self.layers[0].weight.shape[1]
         w_fmt = a_fmt = None
+        with_bias = self.layers[0].bias is not None
         for l in self.layers:
             W, fq = l.weight, l.weight_fake_quant
-            if not (isinstance(fq, FusedAmaxObsFakeQuantize) and fq.fp8_exact() and l.bias is None and W.dtype == torch.bfloat16
+            if (l.bias is not None) != with_bias or (with_bias and (l.bias.dtype != torch.bfloat16 or l.bias.device != W.device)):
+                return False
+            if not (isinstance(fq, FusedAmaxObsFakeQuantize) and fq.fp8_exact() and W.dtype == torch.bfloat16
                     and W.is_contiguous() and W.shape[1] == K and K % 16 == 0 and W.shape[0] % 16 == 0
                     and not (torch.is_grad_enabled() and W.requires_grad)):
                 return False
@@ -187,6 +191,17 @@ class SiblingGroup:
             elif fmt_key(fq._qt_format) != w_fmt or fmt_key(afq._qt_format) != a_fmt:
                 return False
         return True
+
+    def bias_or_none(self):
+        """The members' biases as one [sum N] vector (BERT-style projections), rebuilt when any of them changes."""
+        if self.layers[0].bias is None:
+            return None
+        key = tuple((l.bias.data_ptr(), l.bias._version) for l in self.layers)
+        if self.bias is None or self.bias[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return False                   # no allocation that outlives the graph from inside a capture
+            self.bias = (key, torch.cat([l.bias.detach() for l in self.layers]))
+        return self.bias[1]
 
 
 def _origin_key(x):
@@ -230,7 +245,10 @@ def _sibling_linear_or_none(layer, x, x8):
     _native.check(L.qt_fake_quant_bf16_fp8_multi(xs, ns, n, group.buf.data_ptr(), ctypes.byref(fq._qt_format),
                                                  _stream_ptr(x)), "qt_fake_quant_bf16_fp8_multi")
     w8 = group.buf.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn)
-    y = lt_fp8_gemm(x8.reshape(-1, K), w8, None)
+    bias = group.bias_or_none()
+    if bias is False:
+        return None
+    y = lt_fp8_gemm(x8.reshape(-1, K), w8, bias)
     if y is None:
         return None                            # library route unavailable: every member takes the ordinary path
     STATS.add(layer.weight.numel())

@@ -1,4 +1,5 @@
-"""One-launch versions of the elementwise chains a Hugging Face LLaMA block runs between its (fake-quantized) GEMMs.
+"""One-launch versions of the elementwise chains a Hugging Face LLaMA / BERT block runs between its (fake-quantized)
+GEMMs.
 
 Not part of the reference package -- its examples run HF's modeling_llama unchanged, where RMSNorm is eight torch
 kernels, rotary embedding ten and SiLU * up two.  Once everything on the fake-quant path was fused these chains were
@@ -8,6 +9,10 @@ csrc/qt_model_ops.hip when that changes nothing observable:
   * only when nothing hooks the intermediate values (an `--quantize_forward activation` hook on the SiLU, say);
   * same operation order and bf16 rounding points: SiLU * up and rotary are bit-identical to the torch chains, RMSNorm
     differs only through the summation order of its mean (isolated outputs move by one bf16 ulp).
+BERT / RoBERTa blocks (the twins of modules/quantizable/attention.py) get the same treatment: `LayerNorm(dense(x) +
+residual)` and the erf GELU run as one launch each, with the next Linear's stateless FP8 input fake-quantizer applied on
+the way out, and query / key / value share one batched weight pass + one FP8 GEMM (fused.SiblingGroup).  LayerNorm
+differs from torch's kernel only through the summation order of its mean / variance.
 `QT_FUSED_MODEL_OPS=0` keeps HF's own code everywhere.
 """
 import ctypes
@@ -18,7 +23,7 @@ import torch
 from . import _native
 from .fake_quantize import FusedAmaxObsFakeQuantize, _stream_ptr
 
-__all__ = ["apply_llama_fusions", "rmsnorm", "silu_mul", "rope"]
+__all__ = ["apply_llama_fusions", "apply_bert_fusions", "rmsnorm", "silu_mul", "rope", "layernorm", "gelu"]
 
 
 def _enabled():
@@ -204,6 +209,122 @@ def rope_fq(q, k, cos, sin, fq_q, fq_k):
     q_out._qt_fp8 = _fp8_view(q8, fq_q)                 # Q.K^T can then run as an FP8 GEMM (functional_modules.py)
     k_out._qt_fp8 = _fp8_view(k8, fq_k)
     return q_out, k_out
+
+
+# ---- BERT-style blocks -----------------------------------------------------------------------------------------------
+def layernorm(x, norm, residual=None, fq=None):
+    """LayerNorm(x [+ residual]) in one launch.  With `fq` (the first consuming Linear's input fake-quantizer) the kernel
+    also writes fq(y) as bf16 + FP8 code and leaves them for that fake-quantizer's next call; y itself stays
+    unquantized because the next residual connection reads it too."""
+    cols = x.shape[-1]
+    x2 = x.contiguous()
+    r2 = residual.contiguous() if residual is not None else None
+    y = torch.empty_like(x2)
+    yq = y8 = None
+    if fq is not None:
+        yq = torch.empty_like(x2)
+        y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+    _native.check(_native.lib().qt_layernorm_bf16(
+        x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
+        yq.data_ptr() if yq is not None else None, y8.data_ptr() if y8 is not None else None, x2.numel() // cols, cols,
+        float(norm.eps), ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)), "qt_layernorm_bf16")
+    if fq is not None:
+        fq.expect_prequantized(y, _fp8_view(y8, fq), replacement=yq)
+    return y
+
+
+def gelu(x, fq=None):
+    """erf-form GELU; with `fq` (the consuming Linear's input fake-quantizer) applied in the same pass (result marked)."""
+    x2 = x.contiguous()
+    y = torch.empty_like(x2)
+    y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) if fq is not None else None
+    _native.check(_native.lib().qt_gelu_bf16(x2.data_ptr(), y.data_ptr(), y8.data_ptr() if y8 is not None else None, x2.numel(),
+                                             ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)),
+                  "qt_gelu_bf16")
+    if fq is not None:
+        y._qt_fp8 = _fp8_view(y8, fq)
+        y._qt_fq_done_by = fq
+    return y
+
+
+def _layernorm_ok(norm, x, residual=None):
+    w, b = getattr(norm, "weight", None), getattr(norm, "bias", None)
+    if type(norm) is not torch.nn.LayerNorm or w is None or b is None or _hooked(norm) or len(norm.normalized_shape) != 1:
+        return False
+    ts = (x, w, b) if residual is None else (x, residual, w, b)
+    cols = x.shape[-1]
+    return (_eligible(*ts) and cols == norm.normalized_shape[0] and cols % 8 == 0 and cols <= 16384 and x.numel() > 0
+            and w.is_contiguous() and b.is_contiguous() and (residual is None or residual.shape == x.shape))
+
+
+def add_layernorm_or_none(block, hidden, residual):
+    """`block.LayerNorm(block.residual(hidden, residual))` of a BERT-style output block in one launch, or None when the
+    add is hooked (`--quantize_forward residual`), gradients are needed, or the tensors are not bf16 device tensors."""
+    add = getattr(block, "residual", None)
+    norm = getattr(block, "LayerNorm", None)
+    if norm is None or add is None or _hooked(add) or not _layernorm_ok(norm, hidden, residual):
+        return None
+    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm))
+
+
+def _layernorm_forward(self, x):
+    if _layernorm_ok(self, x):
+        return layernorm(x, self, None, _norm_consumer_fq(self))
+    return self._qt_hf_forward(x)
+
+
+def _is_erf_gelu(act):
+    return (type(act).__name__ == "GELUActivation" and getattr(act, "act", None) is torch.nn.functional.gelu) or \
+        (type(act) is torch.nn.GELU and act.approximate == "none")
+
+
+def _intermediate_forward(self, hidden_states):
+    act = self.intermediate_act_fn
+    if isinstance(act, torch.nn.Module) and not _hooked(act) and _is_erf_gelu(act):
+        h = self.dense(hidden_states)
+        if _eligible(h) and h.numel() % 8 == 0 and h.numel() > 0:
+            consumer = self.__dict__.get("_qt_consumer")
+            fq = consumer_fq(consumer) if consumer is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None
+            return gelu(h, fq)
+        return act(h)
+    return self._qt_hf_forward(hidden_states)
+
+
+def apply_bert_fusions(model):
+    """Called by quantize(): BERT / RoBERTa encoder layers (anything shaped like HF's BertLayer) get the one-launch
+    LayerNorm / GELU forwards and a q / k / v sibling group.  Returns the number of layers touched."""
+    layers = []
+    for mod in model.modules():
+        att = getattr(mod, "attention", None)
+        inner = getattr(att, "self", None) if att is not None else None
+        if (inner is not None and all(hasattr(inner, n) for n in ("query", "key", "value"))
+                and hasattr(getattr(att, "output", None), "LayerNorm") and hasattr(getattr(mod, "intermediate", None), "dense")
+                and hasattr(getattr(mod, "output", None), "LayerNorm") and hasattr(mod.output, "dense")):
+            layers.append(mod)
+    prev_norm = None
+    for mod in model.modules():                                   # the embedding LayerNorm feeds the first layer
+        if type(mod).__name__.endswith("Embeddings") and isinstance(getattr(mod, "LayerNorm", None), torch.nn.LayerNorm):
+            prev_norm = mod.LayerNorm
+            break
+    for i, mod in enumerate(layers):
+        inner = mod.attention.self
+        qkv = [inner.query, inner.key, inner.value]
+        if all(hasattr(l, "weight_fake_quant") for l in qkv) and "_qt_sibling_group" not in inner.query.__dict__:
+            from .fused import SiblingGroup
+            group = SiblingGroup(qkv)
+            for lin in qkv:
+                lin.__dict__["_qt_sibling_group"] = group
+        if prev_norm is not None:
+            prev_norm.__dict__["_qt_consumers"] = qkv
+        mod.attention.output.LayerNorm.__dict__["_qt_consumers"] = [mod.intermediate.dense]
+        mod.output.LayerNorm.__dict__.pop("_qt_consumers", None)  # set by the next layer (the last one has no Linear behind it)
+        mod.intermediate.__dict__["_qt_consumer"] = mod.output.dense
+        _bind(mod.intermediate, _intermediate_forward)
+        for norm in (prev_norm, mod.attention.output.LayerNorm, mod.output.LayerNorm):
+            if type(norm) is torch.nn.LayerNorm:
+                _bind(norm, _layernorm_forward)
+        prev_norm = mod.output.LayerNorm
+    return len(layers)
 
 
 # The attention block whose forward is running (set by hooks on the converted LlamaAttention modules): HF calls the

@@ -150,6 +150,10 @@ class LlamaAttention(QuantizableAttentionCore):
 # ---- output blocks: LayerNorm(dense(x) + residual) ------------------------------------------------
 def _bert_output_forward(self, hidden_states, input_tensor):
     hidden_states = self.dropout(self.dense(hidden_states))
+    from ...model_fusions import add_layernorm_or_none
+    fused = add_layernorm_or_none(self, hidden_states, input_tensor)      # one launch on device under no_grad
+    if fused is not None:
+        return fused
     return self.LayerNorm(self.residual(hidden_states, input_tensor))
 
 

@@ -88,8 +88,9 @@ def quantize(model, args, inplace=True):
     convert(model, mapping=DEFAULT_QAT_MODULE_MAPPINGS, inplace=True)
     prepare(model, True, args.quantize_forward, args.quantize_backprop, getattr(args, "op_fusion", None))
     if _is_hf_model(model):
-        from .model_fusions import apply_llama_fusions
+        from .model_fusions import apply_bert_fusions, apply_llama_fusions
         apply_llama_fusions(model)          # inference-only one-launch RMSNorm / rotary / SiLU*up (no-op off device)
+        apply_bert_fusions(model)           # same for BERT-style blocks: add + LayerNorm, GELU, q / k / v sibling group
     return model
 
 

@@ -246,3 +246,59 @@ def test_lora_qat_linear_on_device_matches_golden_forward():
         g = flt.lora_B["default"].weight.grad
         gref = _from_bits16(key("0/gB"), (fout, r)).float()
         assert g is not None and ((g.float().cpu() - gref).abs() <= 2.0 ** -5 * (gref.abs() + gref.abs().max())).all(), n
+
+
+@pytest.mark.parametrize("family", ["bert", "roberta"])
+def test_bert_block_fusions_vs_hf_chains(family):
+    """BERT / RoBERTa encoder, E4M3 act+weight, `--quantize_forward gemm`, padded batch: the one-launch add+LayerNorm /
+    GELU kernels with producer-fused fake-quant and the q/k/v sibling group against the same model with every such
+    toggle off (HF's torch chains, one GEMM per projection).  Same number of quantized elements and fake-quant calls;
+    logits within the bf16 noise of two LayerNorm summation orders; eager and captured-graph replays agree exactly."""
+    import copy
+    from quantized_training.fake_quantize import STATS
+    if family == "bert":
+        from transformers import BertConfig as Cfg, BertForQuestionAnswering as Model
+    else:
+        from transformers import RobertaConfig as Cfg, RobertaForQuestionAnswering as Model
+    torch.manual_seed(0)
+    cfg = Cfg(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024, vocab_size=300,
+              max_position_embeddings=200)
+    base = Model(cfg).eval().bfloat16()
+    ids = torch.randint(3, 300, (4, 192), generator=torch.Generator().manual_seed(1)).cuda()
+    att = torch.ones_like(ids)
+    att[1, 150:] = 0
+    att[3, 17:] = 0
+    toggles = ("QT_FUSED_MODEL_OPS", "QT_FUSED_PRODUCER_FQ", "QT_SIBLING_GEMM")
+    res = {}
+    for fast in (True, False):
+        for k in toggles:
+            if not fast:
+                os.environ[k] = "0"
+        try:
+            m = copy.deepcopy(base).cuda()
+            qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+            with torch.no_grad():
+                m(ids, attention_mask=att)
+                STATS.reset()
+                o = m(ids, attention_mask=att)
+                torch.cuda.synchronize()
+                res[fast] = (o.start_logits.float(), o.end_logits.float(), STATS.elements, STATS.calls)
+                if fast:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        m(ids, attention_mask=att)
+                    torch.cuda.current_stream().wait_stream(s)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        og = m(ids, attention_mask=att)
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    assert torch.equal(og.start_logits.float(), res[fast][0]) and torch.equal(og.end_logits.float(), res[fast][1])
+        finally:
+            for k in toggles:
+                os.environ.pop(k, None)
+    (s1, e1, n1, c1), (s0, e0, n0, c0) = res[True], res[False]
+    assert (n1, c1) == (n0, c0), (n1, c1, n0, c0)
+    for a, b in ((s1, s0), (e1, e0)):
+        assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01, float((a - b).abs().max())

@@ -1112,3 +1112,68 @@ def test_score_pass_fp8_only_equals_closed_form_path(nv):
                                                   S if m is not None else 0, 0.125, ctypes.byref(fmt), stream()), "fp8 only")
                 assert torch.equal(a8, b8), (dtype, sigma, m is not None)
                 assert torch.equal(a8.view(fmt8[dtype]).float(), out.float())
+
+
+@pytest.mark.parametrize("cols", [768, 1024, 3072, 4096, 264])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_layernorm_kernel_vs_torch_chain(nv, cols, with_residual):
+    """qt_layernorm_bf16 against torch's add + layer_norm on bf16: same rounding points (the sum, then the affine
+    result); the row statistics are summed in a different order, which moves isolated results to the neighbouring
+    bf16 value.  With a consumer fake-quantizer: yq / y8 are exactly fq(y) of the y the kernel wrote, and the hand-over
+    (fq's next call on y returns yq) is one-shot."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    g = torch.Generator(device="cuda").manual_seed(cols)
+    rows = 518                                   # not a multiple of the 4 rows a workgroup takes at cols <= 1024
+    x = (torch.randn(rows, cols, device="cuda", generator=g) * 3).bfloat16()
+    res = (torch.randn(rows, cols, device="cuda", generator=g) * 2 + 0.5).bfloat16() if with_residual else None
+    norm = torch.nn.LayerNorm(cols, eps=1e-12).cuda().bfloat16()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(cols, device="cuda", generator=g))
+        norm.bias.copy_(0.1 * torch.randn(cols, device="cuda", generator=g))
+        want = norm(x + res if with_residual else x)
+        got = mf.layernorm(x, norm, res)
+        # one bf16 ulp where the result is O(1); where w * xhat + b cancels, the fp32 difference of the two summation
+        # orders (~1e-6 of the operands) is what remains
+        assert bool(((want.float() - got.float()).abs() <= 2.0 ** -7 * want.float().abs() + 1e-5).all())
+        assert float((want.view(torch.int16) != got.view(torch.int16)).float().mean()) <= 2e-3
+        for dtype in ("e4m3", "e5m2"):
+            fq, ref_fq = FusedAmaxObsFakeQuantize(dtype=dtype).cuda(), FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+            ref_fq._emit_fp8 = "both"
+            y = mf.layernorm(x, norm, res, fq)
+            assert torch.equal(y.view(torch.int16), got.view(torch.int16))            # y itself stays unquantized
+            yq = fq(y.view(rows, cols))                                               # reaches the hook as a view
+            assert yq is not y and yq.data_ptr() != y.data_ptr()
+            wq = ref_fq(got)
+            assert torch.equal(yq.view(torch.int16), wq.view(torch.int16))
+            assert torch.equal(yq._qt_fp8.view(torch.uint8), wq._qt_fp8.view(torch.uint8))
+            assert yq._qt_origin == (y.data_ptr(), y._version, tuple(y.shape))
+            again = fq(y)                                                             # one-shot: now an ordinary pass
+            assert again.data_ptr() not in (y.data_ptr(), yq.data_ptr())
+            assert torch.equal(again.view(torch.int16), wq.view(torch.int16))
+
+
+def test_gelu_kernel_vs_torch(nv):
+    """qt_gelu_bf16 against torch's erf GELU on bf16 (same fp32 expression, one rounding): every finite bf16 input and a
+    BERT-sized tensor; fused with the consumer's fake-quantizer == the two-step sequence, bit for bit."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    allbits = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).cuda().view(torch.bfloat16)
+    allbits = allbits[torch.isfinite(allbits)]
+    allbits = allbits[: allbits.numel() // 8 * 8].contiguous()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = (torch.randn(6144, 3072, device="cuda", generator=g) * 1.5).bfloat16()
+    for x in (allbits, big):
+        want = torch.nn.functional.gelu(x)
+        got = mf.gelu(x)
+        a, b = want.view(torch.int16).int(), got.view(torch.int16).int()
+        assert int((a - b).abs().max()) <= 1 and float((a != b).float().mean()) <= 1e-4, float((a != b).float().mean())
+        for dtype in ("e4m3", "e5m2"):
+            fq, ref_fq = FusedAmaxObsFakeQuantize(dtype=dtype).cuda(), FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+            ref_fq._emit_fp8 = "both"
+            with torch.no_grad():
+                y = mf.gelu(x, fq)
+                wq = ref_fq(got)
+                assert fq(y) is y
+            assert torch.equal(y.view(torch.int16), wq.view(torch.int16))
+            assert torch.equal(y._qt_fp8.view(torch.uint8), wq._qt_fp8.view(torch.uint8))
