@@ -30,6 +30,61 @@ __device__ __forceinline__ uint32_t qt_pack_fp8x4(float a, float b, float c, flo
     return (uint32_t)w;
 }
 
+// ---- hardware FP8 conversion for the unit-scale E4M3 / E5M2 fake-quantizers (see fq8_fast16 in qt_elementwise.hip) ------
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+
+template <bool E5M2>
+__device__ __forceinline__ uint32_t fq8_fast_word4(uint32_t w0, uint32_t w1) {          // four bf16 -> four FP8 bytes
+    constexpr float F = E5M2 ? 57344.0f : 448.0f;
+    const float a = __builtin_amdgcn_fmed3f(qt_u2f(w0 << 16), -F, F), b = __builtin_amdgcn_fmed3f(qt_u2f(w0 & 0xFFFF0000u), -F, F);
+    const float c = __builtin_amdgcn_fmed3f(qt_u2f(w1 << 16), -F, F), d = __builtin_amdgcn_fmed3f(qt_u2f(w1 & 0xFFFF0000u), -F, F);
+    const uint32_t q = qt_pack_fp8x4<E5M2>(a, b, c, d);
+    const uint32_t t = q & 0x7F7F7F7Fu;                                   // zero results are +0: clear the sign of 0x80 bytes
+    const uint32_t nz = ((t + 0x7F7F7F7Fu) | t) & 0x80808080u;            // 0x80 in every byte whose magnitude is not zero
+    return q & (nz | 0x7F7F7F7Fu);
+}
+
+// Eight bf16 values (four packed words, IN: the unquantized values, OUT: fq(values) as bf16) -> their eight FP8 bytes.
+// Finite inputs take the hardware conversion (decode of the code gives the quantized value back exactly); a vector
+// holding a non-finite value takes the closed form (qt_fp_sat_u32), bit for bit what every producer kernel did before.
+template <bool E5M2>
+__device__ __forceinline__ uint2 fq8_hw_vec8(uint32_t (&o)[4], const qt_format &fmt) {
+    const uint32_t m = pk_max_u16(pk_max_u16(o[0] & 0x7FFF7FFFu, o[1] & 0x7FFF7FFFu), pk_max_u16(o[2] & 0x7FFF7FFFu, o[3] & 0x7FFF7FFFu));
+    if (__builtin_expect(((m & 0xFFFFu) >= 0x7F80u) | ((m >> 16) >= 0x7F80u), 0)) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, fmt.p0, fmt.p1, fmt.fhi), r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
+            o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+            f[2 * j] = qt_u2f(r0);
+            f[2 * j + 1] = qt_u2f(r1);
+        }
+        return uint2{qt_pack_fp8x4<E5M2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<E5M2>(f[4], f[5], f[6], f[7])};
+    }
+    const uint32_t c0 = fq8_fast_word4<E5M2>(o[0], o[1]), c1 = fq8_fast_word4<E5M2>(o[2], o[3]);
+    float2_t a, b, c, d;
+    if constexpr (E5M2) {
+        a = __builtin_amdgcn_cvt_pk_f32_bf8((int)c0, false);
+        b = __builtin_amdgcn_cvt_pk_f32_bf8((int)c0, true);
+        c = __builtin_amdgcn_cvt_pk_f32_bf8((int)c1, false);
+        d = __builtin_amdgcn_cvt_pk_f32_bf8((int)c1, true);
+    } else {
+        a = __builtin_amdgcn_cvt_pk_f32_fp8((int)c0, false);
+        b = __builtin_amdgcn_cvt_pk_f32_fp8((int)c0, true);
+        c = __builtin_amdgcn_cvt_pk_f32_fp8((int)c1, false);
+        d = __builtin_amdgcn_cvt_pk_f32_fp8((int)c1, true);
+    }
+    o[0] = pack_bf16x2(a.x, a.y);
+    o[1] = pack_bf16x2(b.x, b.y);
+    o[2] = pack_bf16x2(c.x, c.y);
+    o[3] = pack_bf16x2(d.x, d.y);
+    return uint2{c0, c1};
+}
+
 // x / s for a wave-uniform divisor, bit-identical to what torch computes.
 //
 // The quotient is only ever consumed through a 16-bit view: rounded to bf16 (bf16 tensors) or folded

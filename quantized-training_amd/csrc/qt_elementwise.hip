@@ -14,6 +14,7 @@
 //   s == 1 skips both the division and the multiplication (x/1 and r*1 are exact).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qt_device.h"
 
@@ -264,15 +265,87 @@ __device__ __forceinline__ uint4 bf16_vec_from(const float (&q)[8], float s, boo
     return o;
 }
 
+// FP8-only output at unit scale (the weight pass of the FP8 GEMM route): for a FINITE input the format's saturating
+// round-to-nearest-even is the hardware conversion of the value clamped to +-fmax (v_med3_f32 + v_cvt_pk_fp8_f32 /
+// v_cvt_pk_bf8_f32, subnormals and the flush of |x| <= half the smallest subnormal included), followed by the
+// reference's "+0 for zero results" (fp8.py:33-35) done on the packed bytes.  That is ~4.5 VALU operations per element
+// instead of the ~13.5 of the closed form + pack -- the pass was issue-limited at ~0.6 of its VALU rate while a
+// no-arithmetic 2:1 narrowing copy with the same geometry streams 5.6 TB/s (tools/exp_rw_mix.hip).  Non-finite inputs
+// (the reference maps them to NaN; the hardware keeps E5M2 infinities and the clamp would hide them) are found from the
+// packed magnitude maximum that also serves the observer, and that vector pair takes the closed form.
+// 16 elements (two 16-B vectors) -> 16 FP8 bytes; mag accumulates the packed |x| maxima (observer); returns false when
+// a non-finite input was seen (the caller redoes this pair with the closed form)
+template <bool E5M2>
+__device__ __forceinline__ bool fq8_fast16(const uint4 v0, const uint4 v1, uint32_t &mag, uint4 &o8) {
+    uint32_t m = pk_max_u16(v0.x & 0x7FFF7FFFu, v0.y & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v0.z & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v0.w & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v1.x & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v1.y & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v1.z & 0x7FFF7FFFu);
+    m = pk_max_u16(m, v1.w & 0x7FFF7FFFu);
+    mag = pk_max_u16(mag, m);
+    o8.x = fq8_fast_word4<E5M2>(v0.x, v0.y);
+    o8.y = fq8_fast_word4<E5M2>(v0.z, v0.w);
+    o8.z = fq8_fast_word4<E5M2>(v1.x, v1.y);
+    o8.w = fq8_fast_word4<E5M2>(v1.z, v1.w);
+    return ((m & 0xFFFFu) < 0x7F80u) & ((m >> 16) < 0x7F80u);
+}
+
+template <bool E5M2>
+__device__ __forceinline__ uint4 fq8_closed16(const uint4 v0, const uint4 v1, const qt_format &fmt) {
+    const UniformDiv dv(1.0f);
+    uint32_t unused = 0;
+    float q0[8], q1[8];
+    fq8_vec(v0, fmt, dv, true, false, unused, q0);
+    fq8_vec(v1, fmt, dv, true, false, unused, q1);
+    uint4 o8;
+    o8.x = qt_pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
+    o8.y = qt_pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
+    o8.z = qt_pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
+    o8.w = qt_pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
+    return o8;
+}
+
 // Each lane handles 16 consecutive elements: two 16-B loads -> one 16-B FP8 store (+ two bf16 stores).
 template <bool OBS, bool BOTH, bool E5M2>
 __global__ __launch_bounds__(256) void fq8_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, uint4 *__restrict__ y8,
                                                   size_t npair, qt_format fmt, const float *__restrict__ scale,
-                                                  uint32_t *amax_out) {
+                                                  uint32_t *amax_out, bool hw) {
     float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
     const bool unit = (s == 1.0f);
     const UniformDiv dv(s);
     uint32_t amax = 0;
+    if constexpr (!BOTH) {
+        if (unit && hw) {                             // FP8 code only, scale 1: hardware conversion (see fq8_fast16)
+            uint32_t mag = 0;
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (size_t)gridDim.x * 256) {
+                const uint4 v0 = x[2 * i], v1 = x[2 * i + 1];
+                uint4 o8;
+                if (__builtin_expect(!fq8_fast16<E5M2>(v0, v1, mag, o8), 0)) o8 = fq8_closed16<E5M2>(v0, v1, fmt);
+                y8[i] = o8;
+            }
+            if constexpr (OBS) {
+                const uint32_t lo = mag << 16, hi = mag & 0xFFFF0000u;
+                amax = lo > hi ? lo : hi;
+                block_amax_commit<256>(amax, amax_out);
+            }
+            return;
+        }
+    }
+    if constexpr (BOTH && !OBS) {
+        if (unit && hw) {                             // bf16 + FP8 code, scale 1: same conversion, decoded back for the bf16 copy
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (size_t)gridDim.x * 256) {
+                const uint4 v0 = x[2 * i], v1 = x[2 * i + 1];
+                uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+                const uint2 c0 = fq8_hw_vec8<E5M2>(a, fmt), c1 = fq8_hw_vec8<E5M2>(b, fmt);
+                y8[i] = uint4{c0.x, c0.y, c1.x, c1.y};
+                y[2 * i] = uint4{a[0], a[1], a[2], a[3]};
+                y[2 * i + 1] = uint4{b[0], b[1], b[2], b[3]};
+            }
+            return;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (size_t)gridDim.x * 256) {
         const uint4 v0 = x[2 * i], v1 = x[2 * i + 1];
         float q0[8], q1[8];
@@ -303,21 +376,14 @@ struct MultiArgs {
 
 template <bool E5M2>
 __global__ __launch_bounds__(256) void fq8_multi_kernel(MultiArgs a, uint4 *__restrict__ y8, qt_format fmt) {
-    const UniformDiv dv(1.0f);
-    uint32_t unused = 0;
+    uint32_t mag = 0;
     const size_t total = a.first[4];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int t = (i >= a.first[1]) + (i >= a.first[2]) + (i >= a.first[3]);
         const size_t j = i - a.first[t];
         const uint4 v0 = a.x[t][2 * j], v1 = a.x[t][2 * j + 1];
-        float q0[8], q1[8];
-        fq8_vec(v0, fmt, dv, true, false, unused, q0);
-        fq8_vec(v1, fmt, dv, true, false, unused, q1);
         uint4 o8;
-        o8.x = qt_pack_fp8x4<E5M2>(q0[0], q0[1], q0[2], q0[3]);
-        o8.y = qt_pack_fp8x4<E5M2>(q0[4], q0[5], q0[6], q0[7]);
-        o8.z = qt_pack_fp8x4<E5M2>(q1[0], q1[1], q1[2], q1[3]);
-        o8.w = qt_pack_fp8x4<E5M2>(q1[4], q1[5], q1[6], q1[7]);
+        if (__builtin_expect(!fq8_fast16<E5M2>(v0, v1, mag, o8), 0)) o8 = fq8_closed16<E5M2>(v0, v1, fmt);
         y8[i] = o8;
     }
 }
@@ -350,6 +416,15 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
         const long i1 = t % a.d1, i0 = t / a.d1;
         const uint4 in = *(const uint4 *)(a.x + i0 * a.s0 + i1 * a.s1 + i2 * a.s2 + c * 8);
         uint4 r;
+        if constexpr (FP8 != 0 && !OBS) {                // unit scale, exact E4M3 / E5M2 (host-checked): hardware conversion
+            if (unit) {
+                uint32_t o[4] = {in.x, in.y, in.z, in.w};
+                const uint2 codes = fq8_hw_vec8<FP8 == 2>(o, fmt);
+                ((uint4 *)a.y)[v] = uint4{o[0], o[1], o[2], o[3]};
+                y8[v] = codes;
+                continue;
+            }
+        }
         if (unit) r = fq_vec<kIoBf16, KIND, kDivUnit, OBS>(in, dv, rnd, amax);
         else if (dv.safe) r = fq_vec<kIoBf16, KIND, kDivFast, OBS>(in, dv, rnd, amax);
         else r = fq_vec<kIoBf16, KIND, kDivExact, OBS>(in, dv, rnd, amax);
@@ -863,8 +938,9 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     const uint4 *xv = (const uint4 *)x;
     uint4 *yv = (uint4 *)y;
     uint4 *y8v = (uint4 *)y8;
+    static const bool hw = getenv("QT_FQ8_CLOSED_FORM") == nullptr;       // A/B switch for DESIGN.md's measurement
 #define QT_FQ8(OBS, BOTH, E5)                                                                                  \
-    fq8_kernel<OBS, BOTH, E5><<<grid, 256, 0, st>>>(xv, yv, y8v, nvec, *fmt, scale, amax)
+    fq8_kernel<OBS, BOTH, E5><<<grid, 256, 0, st>>>(xv, yv, y8v, nvec, *fmt, scale, amax, hw)
     if (e5m2) {
         if (amax) { if (y) QT_FQ8(true, true, true); else QT_FQ8(true, false, true); }
         else      { if (y) QT_FQ8(false, true, true); else QT_FQ8(false, false, true); }

@@ -67,18 +67,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 const float h0 = rbf(bf_lo(q[j]) * r), h1 = rbf(bf_hi(q[j]) * r);
                 o[j] = pack_bf16x2(bf_lo(g[j]) * h0, bf_hi(g[j]) * h1);
             }
-            if constexpr (FQ != 0) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, fmt.p0, fmt.p1, fmt.fhi);
-                    const uint32_t r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
-                    o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
-                    f[2 * j] = qt_u2f(r0);
-                    f[2 * j + 1] = qt_u2f(r1);
-                }
-                y8[row * (size_t)nvec + c] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
-            }
+            if constexpr (FQ != 0) y8[row * (size_t)nvec + c] = fq8_hw_vec8<FQ == 2>(o, fmt);
             y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
         }
     }
@@ -115,19 +104,15 @@ __global__ __launch_bounds__(256) void silu_mul_fq8_kernel(const uint4 *__restri
         const uint4 a = g[row * rs_g + col], b = u[row * rs_u + col];
         const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
         uint32_t o[4];
-        float r[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
             const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
-            const uint32_t h = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));            // the unquantized product, bf16
-            const uint32_t r0 = qt_fp_sat_u32(h << 16, fmt.p0, fmt.p1, fmt.fhi), r1 = qt_fp_sat_u32(h & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
-            o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
-            r[2 * j] = qt_u2f(r0);
-            r[2 * j + 1] = qt_u2f(r1);
+            o[j] = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));                        // the unquantized product, bf16
         }
+        const uint2 codes = fq8_hw_vec8<E5M2>(o, fmt);
         y[i] = uint4{o[0], o[1], o[2], o[3]};
-        y8[i] = uint2{qt_pack_fp8x4<E5M2>(r[0], r[1], r[2], r[3]), qt_pack_fp8x4<E5M2>(r[4], r[5], r[6], r[7])};
+        y8[i] = codes;
     }
 }
 
@@ -208,19 +193,20 @@ __device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
     for (int j = 0; j < 4; ++j) {
         const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
         const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
-        const uint32_t e = pack_bf16x2(a0 + b0, a1 + b1);            // the rotary output, bf16
-        const uint32_t r0 = qt_fp_sat_u32(e << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-        const uint32_t r1 = qt_fp_sat_u32(e & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-        out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+        out[j] = pack_bf16x2(a0 + b0, a1 + b1);                      // the rotary output, bf16
+    }
+    if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
+        const uint2 codes = a.e5m2 ? fq8_hw_vec8<true>(out, a.fmt) : fq8_hw_vec8<false>(out, a.fmt);
+        *(uint2 *)(a.y8 + o * 8) = codes;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t r0 = qt_fp_sat_u32(out[j] << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+            const uint32_t r1 = qt_fp_sat_u32(out[j] & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+            out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+        }
     }
     *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
-    if (a.y8) {                                          // the values are on the format's grid: their FP8 bytes are exact
-        const float f0 = qt_u2f(out[0] << 16), f1 = qt_u2f(out[0] & 0xFFFF0000u), f2 = qt_u2f(out[1] << 16),
-                    f3 = qt_u2f(out[1] & 0xFFFF0000u), f4 = qt_u2f(out[2] << 16), f5 = qt_u2f(out[2] & 0xFFFF0000u),
-                    f6 = qt_u2f(out[3] << 16), f7 = qt_u2f(out[3] & 0xFFFF0000u);
-        *(uint2 *)(a.y8 + o * 8) = a.e5m2 ? uint2{qt_pack_fp8x4<true>(f0, f1, f2, f3), qt_pack_fp8x4<true>(f4, f5, f6, f7)}
-                                          : uint2{qt_pack_fp8x4<false>(f0, f1, f2, f3), qt_pack_fp8x4<false>(f4, f5, f6, f7)};
-    }
 }
 
 __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k) {
@@ -313,17 +299,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
                                    bf_hi(g[j]) * (rstd * (bf_hi(q[j]) - mean)) + bf_hi(h[j]));
             a.y[base + c] = uint4{o[0], o[1], o[2], o[3]};
             if constexpr (FQ != 0) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-                    const uint32_t r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-                    o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
-                    f[2 * j] = qt_u2f(r0);
-                    f[2 * j + 1] = qt_u2f(r1);
-                }
+                const uint2 codes = fq8_hw_vec8<FQ == 2>(o, a.fmt);
                 a.yq[base + c] = uint4{o[0], o[1], o[2], o[3]};
-                a.y8[base + c] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
+                a.y8[base + c] = codes;
             }
         }
     }
@@ -338,19 +316,10 @@ __global__ __launch_bounds__(256) void gelu_kernel(const uint4 *__restrict__ x, 
         const uint4 a = x[i];
         const uint32_t p[4] = {a.x, a.y, a.z, a.w};
         uint32_t o[4];
-        float f[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            o[j] = pack_bf16x2(gelu_erf(bf_lo(p[j])), gelu_erf(bf_hi(p[j])));
-            if constexpr (FQ != 0) {
-                const uint32_t r0 = qt_fp_sat_u32(o[j] << 16, fmt.p0, fmt.p1, fmt.fhi), r1 = qt_fp_sat_u32(o[j] & 0xFFFF0000u, fmt.p0, fmt.p1, fmt.fhi);
-                o[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
-                f[2 * j] = qt_u2f(r0);
-                f[2 * j + 1] = qt_u2f(r1);
-            }
-        }
+        for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(gelu_erf(bf_lo(p[j])), gelu_erf(bf_hi(p[j])));
+        if constexpr (FQ != 0) y8[i] = fq8_hw_vec8<FQ == 2>(o, fmt);
         y[i] = uint4{o[0], o[1], o[2], o[3]};
-        if constexpr (FQ != 0) y8[i] = uint2{qt_pack_fp8x4<FQ == 2>(f[0], f[1], f[2], f[3]), qt_pack_fp8x4<FQ == 2>(f[4], f[5], f[6], f[7])};
     }
 }
 
