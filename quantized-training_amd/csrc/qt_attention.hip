@@ -46,6 +46,7 @@ struct AttnArgs {
     const uint16_t *lut;
     const float *scale;
     uint32_t *amax;
+    int p8;                   // probabilities' format is exactly E4M3 (1) / E5M2 (2) at unit scale: hardware conversion
 };
 
 __device__ __forceinline__ float bf16_round(float f) { return qt_u2f(pack_bf16x2(f, 0.0f) << 16); }
@@ -190,11 +191,12 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
             const float mv[4] = {qt_u2f(mk[j].x << 16), qt_u2f(mk[j].x & 0xFFFF0000u), qt_u2f(mk[j].y << 16),
                                  qt_u2f(mk[j].y & 0xFFFF0000u)};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = bf16_round(acc[j][r]);               // matmul output, bf16
-                x = bf16_round(x * a.scaling);                 // attn_scaling (MulFunctional), bf16
-                x = bf16_round(x + mv[r]);                     // + mask, bf16 (mask 0 when absent: exact no-op)
-                t[j][r] = (kbase + r < a.Sk) ? x : -INFINITY;  // keys past the end contribute nothing
+            for (int r = 0; r < 4; r += 2) {                   // two scores per packed conversion
+                uint32_t w = pack_bf16x2(acc[j][r], acc[j][r + 1]);                                         // matmul output, bf16
+                w = pack_bf16x2(qt_u2f(w << 16) * a.scaling, qt_u2f(w & 0xFFFF0000u) * a.scaling);          // attn_scaling (MulFunctional), bf16
+                if (a.mask) w = pack_bf16x2(qt_u2f(w << 16) + mv[r], qt_u2f(w & 0xFFFF0000u) + mv[r + 1]);  // + mask, bf16
+                t[j][r] = (kbase + r < a.Sk) ? qt_u2f(w << 16) : -INFINITY;      // keys past the end contribute nothing
+                t[j][r + 1] = (kbase + r + 1 < a.Sk) ? qt_u2f(w & 0xFFFF0000u) : -INFINITY;
             }
         }
     };
@@ -314,6 +316,17 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
                     amax = amax > a1 ? amax : a1;
                 }
                 uint32_t lo = p << 16, hi = p & 0xFFFF0000u;
+                if constexpr (UNIT && KIND == QT_FMT_FP_SAT) {
+                    if (a.p8) {
+                        // a probability is finite-or-NaN and in [0, 1]: no saturation, no sign, so the format's RNE is
+                        // the hardware conversion and the quantized bf16 value is the decode of that byte pair
+                        float2_t d;
+                        if (a.p8 == 2) d = __builtin_amdgcn_cvt_pk_f32_bf8(__builtin_amdgcn_cvt_pk_bf8_f32(qt_u2f(lo), qt_u2f(hi), 0, false), false);
+                        else d = __builtin_amdgcn_cvt_pk_f32_fp8(__builtin_amdgcn_cvt_pk_fp8_f32(qt_u2f(lo), qt_u2f(hi), 0, false), false);
+                        pw[j][hf] = pack_bf16x2(d.x, d.y);
+                        continue;
+                    }
+                }
                 if constexpr (!UNIT) {
                     const uint32_t qd = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
                     lo = qd << 16;
@@ -395,7 +408,12 @@ extern "C" int qt_attention_fq_bf16(const uint16_t *q, const uint16_t *k, const 
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15u) || ((uintptr_t)mask & 7u) ||
         (mask && ((mask_sb | mask_sh | mask_sq) & 3)))
         return QT_ERR_UNALIGNED;
-    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax};
+    int p8 = 0;
+    if (fmt->kind == QT_FMT_FP_SAT && !scale) {
+        if (fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f) p8 = 1;
+        else if (fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f) p8 = 2;
+    }
+    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8};
     hipStream_t st = (hipStream_t)stream;
     return D == 128 ? launch_attn<128>(a, st) : launch_attn<64>(a, st);
 }
