@@ -63,8 +63,14 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qc = lane & 15, g = lane >> 4;      // query column owned by the lane, lane group
-    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int q0 = blockIdx.x * kBQ + wave * 16;
+    // 1-D grid, query blocks ordered so that a causal mask's heavy blocks (late queries: many live key tiles) come first
+    // and the light ones mirror them: with every workgroup resident at once and round-robin placement, the two
+    // workgroups a CU receives (indices c and c + total/2) then hold nq + 1 live tiles between them instead of up to 2 nq
+    const int BH = a.B * a.H, nq = (a.Sq + kBQ - 1) / kBQ;
+    const int kq = blockIdx.x / BH, bh = blockIdx.x % BH;
+    const int qb = kq < nq / 2 ? nq - 1 - kq : kq - nq / 2;
+    const int b = bh / a.H, h = bh % a.H;
+    const int q0 = qb * kBQ + wave * 16;
     const int qrow = q0 + qc;
     const int qload = qrow < a.Sq ? qrow : a.Sq - 1;
     const uint16_t *Qp = a.q + ((long)bh * a.Sq + qload) * D;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     unsigned long long live = ~0ull;
     if (a.mask && ntiles <= 64) {
         live = 0ull;
-        const int qr = blockIdx.x * kBQ + (tid >> 2);
+        const int qr = qb * kBQ + (tid >> 2);
         const uint16_t *mrow = a.mask + b * a.mask_sb + h * a.mask_sh + (long)(qr < a.Sq ? qr : a.Sq - 1) * a.mask_sq;
         // bf16 pattern >= 0xF14A  <=>  value <= -1e30 (negative, magnitude >= 1e30; -inf and NaN-free masks)
         const bool vec_ok = ((a.mask_sb | a.mask_sh | a.mask_sq) % 8 == 0) && (((uintptr_t)a.mask & 15u) == 0) && (a.Sk % 8 == 0);
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
 
 template <int D, int KIND>
 int launch_attn_kind(const AttnArgs &a, hipStream_t st) {
-    dim3 grid((a.Sq + kBQ - 1) / kBQ, a.B * a.H);
+    dim3 grid((unsigned)(((a.Sq + kBQ - 1) / kBQ) * a.B * a.H));
     const bool unit = a.scale == nullptr, obs = a.amax != nullptr;
     if (unit && obs) attention_fq_kernel<D, KIND, true, true><<<grid, 256, 0, st>>>(a);
     else if (unit) attention_fq_kernel<D, KIND, true, false><<<grid, 256, 0, st>>>(a);
