@@ -88,6 +88,36 @@ class XNNPACKQuantizer(Quantizer):
         return self
 
     def transform_for_annotation(self, model):
+        """Python scalars in add / mul / div become 0-d buffers (``_tensor_constant_<i>``) read through get_attr nodes,
+        so that these ops only have tensor operands when they are annotated (upstream xnnpack_quantizer.py:225-229,
+        xnnpack_quantizer_utils.py:506-541)."""
+        targets = (torch.ops.aten.add.Tensor, torch.ops.aten.mul.Tensor, torch.ops.aten.div.Tensor)
+        devices = {t.device for t in list(model.parameters()) + list(model.buffers())}
+        assert len(devices) <= 1, f"expected the model on one device, got {devices}"
+        device = next(iter(devices)) if devices else None
+        counter = 0
+        for node in list(model.graph.nodes):
+            if node.op != "call_function" or node.target not in targets or all(isinstance(a, Node) for a in node.args):
+                continue
+            dtypes = {a.meta["val"].dtype for a in node.all_input_nodes}
+            assert len(dtypes) <= 1
+            dtype = next(iter(dtypes)) if dtypes else None
+            args = []
+            for a in node.args:
+                if isinstance(a, Node):
+                    args.append(a)
+                    continue
+                while hasattr(model, f"_tensor_constant_{counter}"):
+                    counter += 1
+                name = f"_tensor_constant_{counter}"
+                value = torch.tensor(float(a), dtype=dtype, device=device)
+                model.register_buffer(name, value)
+                with model.graph.inserting_before(node):
+                    const = model.graph.create_node("get_attr", name, (), {})
+                const.meta["val"] = node.meta["val"].fake_mode.from_tensor(value, static_shapes=True)
+                args.append(const)
+            node.args = tuple(args)
+        model.recompile()
         return model
 
     def _apply(self, model, config, filter_fn):

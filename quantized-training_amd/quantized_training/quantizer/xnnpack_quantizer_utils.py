@@ -4,7 +4,9 @@ Same roles as upstream src/quantized_training/quantizer/xnnpack_quantizer_utils.
 ``QuantizationConfig`` names the spec of a GEMM's input activation / output / weight / bias, and each
 annotator walks the exported ATen graph and records, on every matching node, which of its input edges (and
 whether its output) receive a fake-quantizer.  torch.ao's ``prepare_pt2e`` then inserts the modules.
-Covered patterns: linear, conv1d/2d, matmul, residual add (the patterns ``get_default_quantizer`` enables).
+Covered patterns: linear, conv1d/2d, matmul, residual add (the ones ``get_default_quantizer`` enables) and the rest of
+upstream's static list -- activation, softmax, layer_norm (:371-503), reached through ``set_global`` /
+``set_module_name`` / ``set_object_type`` -- plus the registered-but-unlisted ``add`` / ``mul`` annotators (:285-368).
 """
 from dataclasses import dataclass, replace
 from typing import Callable, Dict, List, Optional
@@ -113,10 +115,59 @@ def _annotate_residual(gm, cfg: QuantizationConfig, filter_fn=None):
     return done
 
 
+def _unary_or_binary(targets, n_inputs):
+    """Every Node among the first ``n_inputs`` arguments gets the input-activation spec (upstream's add / mul /
+    softmax / activation annotators differ only in the targets they match)."""
+    def annotate(gm, cfg: QuantizationConfig, filter_fn=None):
+        done = []
+        for node in gm.graph.nodes:
+            if node.op != "call_function" or node.target not in targets:
+                continue
+            if _annotated(node) or (filter_fn and not filter_fn(node)):
+                continue
+            inputs = {a: cfg.input_activation for a in node.args[:n_inputs] if isinstance(a, Node)}
+            _set(node, inputs, cfg.output_activation)
+            done.append([node])
+        return done
+    return annotate
+
+
+def _annotate_layer_norm(gm, cfg: QuantizationConfig, filter_fn=None):
+    """aten.layer_norm(x, shape, weight, bias, ...): activation, weight and bias specs on the three tensor inputs
+    (upstream :408-453)."""
+    done = []
+    for node in gm.graph.nodes:
+        if node.op != "call_function" or node.target != torch.ops.aten.layer_norm.default:
+            continue
+        if _annotated(node) or (filter_fn and not filter_fn(node)):
+            continue
+        act, weight = node.args[0], node.args[2]
+        assert isinstance(act, Node) and isinstance(weight, Node)
+        inputs = {act: cfg.input_activation, weight: cfg.weight}
+        bias = node.args[3] if len(node.args) > 3 else None
+        if bias:
+            assert isinstance(bias, Node)
+            inputs[bias] = cfg.bias
+        _set(node, inputs, cfg.output_activation)
+        done.append([node])
+    return done
+
+
+_A = torch.ops.aten
+_ACTIVATIONS = (_A.relu.default, _A.sigmoid.default, _A.tanh.default, _A.hardswish.default, _A.hardtanh.default,
+                _A.silu.default, _A.gelu.default, _A.relu_.default, _A.sigmoid_.default, _A.tanh_.default,
+                _A.hardswish_.default, _A.hardtanh_.default, _A.silu_.default, _A.gelu_.default)
+
 OP_TO_ANNOTATOR = {
     "linear": _gemm_with_weight((torch.ops.aten.linear.default,)),
     "conv": _gemm_with_weight((torch.ops.aten.conv1d.default, torch.ops.aten.conv2d.default)),
     "matmul": _annotate_matmul,
     "residual": _annotate_residual,
+    "add": _unary_or_binary((_A.add.Tensor, _A.add_.Tensor), 2),
+    "mul": _unary_or_binary((_A.mul.Tensor, _A.mul_.Tensor), 2),
+    "softmax": _unary_or_binary((_A.softmax.int,), 1),
+    "layer_norm": _annotate_layer_norm,
+    "activation": _unary_or_binary(_ACTIVATIONS, 1),
 }
-STATIC_OPS = list(OP_TO_ANNOTATOR)
+# the patterns the quantizer applies, in upstream's order (fusions before singular ops; xnnpack_quantizer.py:160-168)
+STATIC_OPS = ["linear", "conv", "matmul", "residual", "activation", "softmax", "layer_norm"]

@@ -503,6 +503,75 @@ def gen_pt2e(ref, out):
         json.dump(meta, f, indent=1)
 
 
+def gen_pt2e_patterns(ref, out):
+    """The remaining static patterns of the reference quantizer (xnnpack_quantizer.py:160-168 STATIC_OPS: activation,
+    softmax, layer_norm next to linear / matmul / residual) reached through set_global and through set_object_type /
+    set_module_name: prepared graph, inserted modules and calibrated output."""
+    import torch.nn as nn
+    qp = ref.quantize_pt2e
+    assert qp is not None, getattr(ref, "pt2e_error", None)
+    from quantized_training.quantizer.xnnpack_quantizer import XNNPACKQuantizer
+    from quantized_training.quantizer.xnnpack_quantizer_utils import QuantizationConfig
+    from quantized_training.quantizer.quantizer import QuantizationSpec
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(16, 32)
+            self.fc2 = nn.Linear(32, 16)
+            self.ln = nn.LayerNorm(16)
+
+        def forward(self, x):
+            h = torch.nn.functional.gelu(self.fc1(x))
+            y = self.fc2(torch.relu(h))
+            y = y + x
+            a = torch.matmul(y, y.transpose(-1, -2)) * 0.25
+            return self.ln(torch.matmul(torch.softmax(a, -1), y))
+
+    def spec(s):
+        q = QuantizationSpec.from_str(s)
+        q.observer_or_fake_quant_ctr = FusedAmaxObsFakeQuantize.with_args(record_histogram=False, force_scale_power_of_two=False)
+        return q
+
+    def quantizer(kind):
+        cfg = QuantizationConfig(spec("int8,qs=per_tensor_symmetric"), None, spec("int8,qs=per_tensor_symmetric"), None)
+        cfg_e = QuantizationConfig(spec("e4m3"), None, spec("e4m3"), None)
+        if kind == "global":
+            return XNNPACKQuantizer().set_global(cfg)
+        if kind == "object_types":
+            return (XNNPACKQuantizer().set_object_type(torch.ops.aten.softmax.int, cfg)
+                    .set_object_type(torch.ops.aten.layer_norm.default, cfg_e)
+                    .set_object_type(torch.ops.aten.gelu.default, cfg_e)
+                    .set_object_type(torch.ops.aten.relu.default, cfg))
+        return XNNPACKQuantizer().set_module_name("fc1", cfg_e).set_global(cfg)     # "module_name_then_global"
+
+    rng = np.random.default_rng(29)
+    arrays, meta = {}, {}
+    xs = [(rng.standard_normal((4, 8, 16)) * (i + 1)).astype(np.float32) for i in range(3)]
+    for i, x in enumerate(xs):
+        arrays[f"x{i}"] = f32_bits(torch.from_numpy(x))
+    for kind in ("global", "object_types", "module_name_then_global"):
+        m = Toy().eval()
+        r = np.random.default_rng(3)
+        with torch.no_grad():
+            for n, p in sorted(m.named_parameters()):
+                p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+        gm = qp.prepare_pt2e(m, quantizer(kind), (torch.from_numpy(xs[0]),))
+        info = {"prepared_graph": _graph_rows(gm),
+                "fq_modules": {n: mod.dtype for n, mod in gm.named_modules() if isinstance(mod, torch.ao.quantization.FakeQuantizeBase)}}
+        with torch.no_grad():
+            gm(torch.from_numpy(xs[0]))
+            gm(torch.from_numpy(xs[1]))
+            y = gm(torch.from_numpy(xs[2]))
+        arrays[f"{kind}/y_prepared"] = tensor_bits(y)
+        info["scales"] = {k: [float(t) for t in v.reshape(-1)] for k, v in gm.state_dict().items() if k.endswith(".scale")}
+        meta[kind] = info
+    np.savez_compressed(os.path.join(out, "pt2e_patterns.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "pt2e_patterns.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_pt2e_mx(ref, out):
     """PT2E flow with block-scaled (microscaling) specs: prepared outputs, the converted graph with
     quantize_mx / linear_mx / matmul_mx nodes, quantized weight + scale buffers and converted outputs
@@ -713,6 +782,7 @@ def main():
         "mx": lambda: gen_mx(ref, a.out),
         "pt2e": lambda: gen_pt2e(ref, a.out),
         "pt2e_mx": lambda: gen_pt2e_mx(ref, a.out),
+        "pt2e_patterns": lambda: gen_pt2e_patterns(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
         "lora": lambda: gen_lora(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),

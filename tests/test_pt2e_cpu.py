@@ -195,3 +195,69 @@ def test_group_wise_affine_weights_convert_to_codes_and_dequantize():
     with torch.no_grad():
         y2 = gc(x)
     assert torch.allclose(y1, y2, atol=1e-5, rtol=1e-5)
+
+
+PATTERNS = json.load(open(os.path.join(G, "pt2e_patterns.json")))
+
+
+class ToyPatterns(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(16, 32)
+        self.fc2 = nn.Linear(32, 16)
+        self.ln = nn.LayerNorm(16)
+
+    def forward(self, x):
+        h = torch.nn.functional.gelu(self.fc1(x))
+        y = self.fc2(torch.relu(h))
+        y = y + x
+        a = torch.matmul(y, y.transpose(-1, -2)) * 0.25
+        return self.ln(torch.matmul(torch.softmax(a, -1), y))
+
+
+def _pattern_quantizer(kind):
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    from quantized_training.quantizer.quantizer import QuantizationSpec
+    from quantized_training.quantizer.xnnpack_quantizer import XNNPACKQuantizer
+    from quantized_training.quantizer.xnnpack_quantizer_utils import QuantizationConfig
+
+    def spec(s):
+        q = QuantizationSpec.from_str(s)
+        q.observer_or_fake_quant_ctr = FusedAmaxObsFakeQuantize.with_args(record_histogram=False, force_scale_power_of_two=False)
+        return q
+    cfg = QuantizationConfig(spec("int8,qs=per_tensor_symmetric"), None, spec("int8,qs=per_tensor_symmetric"), None)
+    cfg_e = QuantizationConfig(spec("e4m3"), None, spec("e4m3"), None)
+    if kind == "global":
+        return XNNPACKQuantizer().set_global(cfg)
+    if kind == "object_types":
+        return (XNNPACKQuantizer().set_object_type(torch.ops.aten.softmax.int, cfg)
+                .set_object_type(torch.ops.aten.layer_norm.default, cfg_e)
+                .set_object_type(torch.ops.aten.gelu.default, cfg_e)
+                .set_object_type(torch.ops.aten.relu.default, cfg))
+    return XNNPACKQuantizer().set_module_name("fc1", cfg_e).set_global(cfg)
+
+
+@pytest.mark.parametrize("kind", sorted(PATTERNS))
+def test_remaining_static_patterns_match_reference(kind):
+    """activation / softmax / layer_norm annotators (upstream xnnpack_quantizer_utils.py:371-503) through set_global,
+    set_object_type and set_module_name: same prepared graph, same inserted modules and formats, same calibrated
+    output and scales as the reference's quantizer on the same model."""
+    arr = np.load(os.path.join(G, "pt2e_patterns.npz"))
+    info = PATTERNS[kind]
+    xs = [torch.from_numpy(arr[f"x{i}"].view(np.float32)).reshape(4, 8, 16) for i in range(3)]
+    m = ToyPatterns().eval()
+    r = np.random.default_rng(3)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+    gm = qp.prepare_pt2e(m, _pattern_quantizer(kind), (xs[0],))
+    assert _rows(gm) == info["prepared_graph"]
+    fq = {n: mod.dtype for n, mod in gm.named_modules() if isinstance(mod, torch.ao.quantization.FakeQuantizeBase)}
+    assert fq == info["fq_modules"]
+    with torch.no_grad():
+        gm(xs[0])
+        gm(xs[1])
+        y = gm(xs[2])
+    assert np.array_equal(_canon32(y).reshape(-1), arr[f"{kind}__y_prepared"].reshape(-1))
+    scales = {k: [float(t) for t in v.reshape(-1)] for k, v in gm.state_dict().items() if k.endswith(".scale")}
+    assert scales == info["scales"]
