@@ -329,6 +329,64 @@ _lib.impl("linear_mx", _linear_mx_impl, "CompositeExplicitAutograd")
 _lib.impl("matmul_mx", _matmul_mx_impl, "CompositeExplicitAutograd")
 
 
+# ---- outlier side path of a block-scaled linear layer (upstream decomposed.py:450-566) ---------------------------
+# filter_outlier splits an activation into its inliers (|x| <= threshold, outliers zeroed) and the outliers as a CSR
+# matrix of the [rows, C] view, padded to int(numel * max_pct) entries; spmm_csr multiplies that sparse matrix by the
+# (dequantized) weight.  Upstream walks both with Python loops over .item(); here they are index arithmetic on the
+# tensor's own device, entries in the same row-major order and, on CPU, accumulated in the same order.
+_lib.define("filter_outlier(Tensor input, float threshold, float max_pct=0.05) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib.define("spmm_csr(Tensor data, Tensor indices, Tensor indptr, Tensor B, Tensor? B_scale=None, "
+            "Tensor? B_code=None, int? block_size=None, bool weight_transposed=False) -> Tensor")
+
+
+def _filter_outlier_impl(input, threshold, max_pct=0.05):
+    is_outlier = torch.abs(input) > threshold
+    inlier = torch.where(is_outlier, 0, input)
+    outliers = torch.where(is_outlier, input, 0).reshape(-1, input.shape[-1])
+    max_nnz = int(input.numel() * max_pct)
+    nz = outliers != 0
+    rows, cols = nz.nonzero(as_tuple=True)                      # row-major, as the reference's nested loops visit them
+    counts = nz.sum(dim=1)
+    indptr = torch.zeros(outliers.shape[0] + 1, dtype=torch.int32, device=input.device)
+    indptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    nnz = int(rows.numel())
+    if nnz > max_nnz:
+        import logging
+        logging.getLogger(__name__).warning(f"Number of non-zero elements {nnz} exceeds max_nnz {max_nnz}, truncating.")
+    keep = min(nnz, max_nnz)
+    data = torch.zeros((max_nnz,), dtype=input.dtype, device=input.device)
+    indices = torch.zeros((max_nnz,), dtype=torch.int32, device=input.device)
+    data[:keep] = outliers[rows[:keep], cols[:keep]]
+    indices[:keep] = cols[:keep].to(torch.int32)
+    return inlier, data, indices, indptr
+
+
+def _spmm_csr_impl(data, indices, indptr, B, B_scale=None, B_code=None, block_size=None, weight_transposed=False):
+    M = indptr.numel() - 1
+    K = B.shape[1] if weight_transposed else B.shape[0]
+    if B_code is not None:
+        B = B_code[B.to(torch.long)]
+    if B_scale is not None:
+        B = B * expand(B_scale, B.shape, block_size)
+    if weight_transposed:
+        B = B.T
+    Y = torch.zeros((M, K), dtype=data.dtype, device=data.device)
+    nnz = int(indptr[-1])
+    if nnz > data.numel():                                        # the truncated case: upstream's loop runs off the arrays
+        raise IndexError(f"index {data.numel()} is out of bounds for dimension 0 with size {data.numel()}")
+    if nnz == 0:
+        return Y
+    counts = (indptr[1:] - indptr[:-1]).to(torch.long)
+    row_of = torch.repeat_interleave(torch.arange(M, device=data.device), counts)
+    cols = indices[:nnz].to(torch.long)
+    Y.index_add_(0, row_of, (data[:nnz].unsqueeze(0) * B[:, cols]).T.contiguous())
+    return Y
+
+
+_lib.impl("filter_outlier", _filter_outlier_impl, "CompositeExplicitAutograd")
+_lib.impl("spmm_csr", _spmm_csr_impl, "CompositeExplicitAutograd")
+
+
 def linear_mx(input, weight, bias=None, **kw):
     return torch.ops.quantized_ops.linear_mx(input, weight, bias, **kw)
 

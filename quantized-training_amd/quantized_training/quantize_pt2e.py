@@ -10,7 +10,7 @@ Same entry points as upstream src/quantized_training/quantize_pt2e.py:
 The fake-quant modules and the quantize / dequantize operators are the same HIP-backed ones as in eager mode.
 Block-scaled fake-quantizers lower to quantize_mx / calculate_mx_qparam + quantize nodes whose consumers become
 linear_mx / matmul_mx / conv2d_mx (:456-700); group-wise affine weights lower to stored codes + dequantize (:754-826).
-Not covered here: outlier splitting into a CSR side path (filter_outlier / spmm_csr) and the dequantize-sinking
+Not covered here: the dequantize-sinking
 clean-up pass, which depends on the accelerator code generator.
 """
 import copy
@@ -257,8 +257,6 @@ def _lower_mx_fake_quant(model: GraphModule, node: Node, fq):
     device = next(iter(fq.buffers())).device
     src = node.args[0]
     src_dtype = fq.dtype
-    if fq.outlier_threshold is not None:
-        raise NotImplementedError("outlier splitting (filter_outlier / spmm_csr) is not part of this engine")
     if isinstance(fq.ch_axis, int):
         fq.ch_axis = (fq.ch_axis,)
     fuse = False
@@ -268,6 +266,15 @@ def _lower_mx_fake_quant(model: GraphModule, node: Node, fq):
             fuse = axis in (1, -3)
         else:
             fuse = axis == -1 or ("val" in src.meta and axis == src.meta["val"].ndim - 1)
+
+    to_quantize = src
+    csr = None
+    if fq.outlier_threshold is not None:                 # outliers leave through a CSR side path (upstream :489-510)
+        assert src.op != "get_attr", "Outlier suppression is not supported for weight quantization."
+        with graph.inserting_before(node):
+            flt = graph.call_function(torch.ops.quantized_ops.filter_outlier.default, (src, fq.outlier_threshold), {})
+            to_quantize = graph.call_function(operator.getitem, (flt, 0), {})
+            csr = tuple(graph.call_function(operator.getitem, (flt, i), {}) for i in (1, 2, 3))
 
     quant_map = get_quantization_map(fq.dtype, device)
     dequant_code = quant_code = None
@@ -296,7 +303,7 @@ def _lower_mx_fake_quant(model: GraphModule, node: Node, fq):
             m_node = _buffer_node(model, graph, "qmap", fq.qmap)
             sm_node = _buffer_node(model, graph, "qmap", fq.scale_qmap) if fq.scale_qmap is not None else None
             mx = graph.call_function(torch.ops.quantized_ops.quantize_mx.default,
-                                     (src, m_node, fq.ch_axis, fq.block_size, fq.quant_max, fq.force_scale_power_of_two,
+                                     (to_quantize, m_node, fq.ch_axis, fq.block_size, fq.quant_max, fq.force_scale_power_of_two,
                                       sm_node, quant_code))
             s_node = graph.call_function(operator.getitem, (mx, 0))
             q_node = graph.call_function(operator.getitem, (mx, 1))
@@ -354,10 +361,28 @@ def _lower_mx_fake_quant(model: GraphModule, node: Node, fq):
             stack = mx_op.meta.setdefault("source_fn_stack", [])
             stack.append((mx_op.name, stack[-1][1] if stack else mx_op.target))
         elif user.target in mapping.values():
+            mx_op = user
             user.kwargs = kwargs
+        elif user.target == torch.ops.quantized_ops.spmm_csr.default:        # the weight of an outlier side path (:705-716)
+            assert src.op == "get_attr", f"Expect input node to be a get_attr, but found {src.op}"
+            user.args = user.args[:-1] + (q_node,)
+            user.kwargs = {"B_scale": kwargs.get("weight_scale"), "B_code": kwargs.get("weight_code"),
+                           "block_size": fq.block_size}
+            continue
         else:
             raise RuntimeError(f"Unsupported user node {user.target} for quantization, expected one of "
                                f"{list(mapping.keys())}")
+        if csr is not None and src.op != "get_attr":     # y = linear_mx(inliers) + outliers_csr @ W^T (:721-750)
+            assert mx_op.target in (torch.ops.aten.linear.default, torch.ops.quantized_ops.linear_mx.default), \
+                f"Only torch.nn.Linear is supported for outlier suppresion, got {user.target}"
+            with graph.inserting_after(mx_op):
+                spmm = graph.call_function(torch.ops.quantized_ops.spmm_csr.default, csr + (mx_op.args[1],),
+                                           {"B_scale": kwargs.get("weight_scale"), "B_code": kwargs.get("weight_code"),
+                                            "block_size": fq.block_size})
+            with graph.inserting_after(spmm):
+                add = graph.call_function(torch.ops.aten.add.Tensor, (spmm, mx_op), {})
+            mx_op.replace_all_uses_with(add)
+            add.replace_input_with(add, mx_op)
 
 
 def _lower_group_wise_affine(model: GraphModule, node: Node, fq):

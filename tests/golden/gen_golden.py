@@ -572,6 +572,68 @@ def gen_pt2e_patterns(ref, out):
         json.dump(meta, f, indent=1)
 
 
+def gen_outlier(ref, out):
+    """Outlier side path of a block-scaled linear layer: the two operators on their own (decomposed.py:450-566) and the
+    converted graph + outputs of a two-layer model whose activation spec carries `outlier=` (quantize_pt2e.py:489-510,
+    705-750).  The reference only handles 2-D activations here (its add of the [rows, N] side product fails on
+    higher ranks), so the model input is [16, 64]."""
+    import torch.nn as nn
+    qp = ref.quantize_pt2e
+    ops = torch.ops.quantized_ops
+    rng = np.random.default_rng(31)
+    arrays, meta = {}, {}
+    x = torch.from_numpy((rng.standard_normal((3, 5, 32)) * 2).astype(np.float32))
+    x[0, 0, 0] = float("nan")
+    inl, data, idx, ptr = ops.filter_outlier(x, 3.5, 0.1)
+    arrays["op/x"] = f32_bits(x)
+    arrays["op/inlier"] = canon_nan32(f32_bits(inl))
+    arrays["op/data"] = f32_bits(data)
+    arrays["op/indices"] = idx.numpy().astype(np.int64)
+    arrays["op/indptr"] = ptr.numpy().astype(np.int64)
+    w = torch.from_numpy(rng.standard_normal((24, 32)).astype(np.float32))
+    ws = torch.from_numpy((2.0 ** rng.integers(-3, 2, (24, 1))).astype(np.float32))
+    arrays["op/w"] = f32_bits(w)
+    arrays["op/ws"] = f32_bits(ws)
+    arrays["op/y_plain"] = f32_bits(ops.spmm_csr(data, idx, ptr, w))
+    arrays["op/y_scaled"] = f32_bits(ops.spmm_csr(data, idx, ptr, w, ws, None, 32))
+    arrays["op/y_transposed"] = f32_bits(ops.spmm_csr(data, idx, ptr, w.T.contiguous(), None, None, None, True))
+    meta["op"] = {"threshold": 3.5, "max_pct": 0.1, "nnz": int(ptr[-1])}
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(64, 128)
+            self.fc2 = nn.Linear(128, 64)
+
+        def forward(self, x):
+            return self.fc2(torch.relu(self.fc1(x)))
+
+    m = Toy().eval()
+    r = np.random.default_rng(3)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.1).astype(np.float32)))
+    xs = [torch.from_numpy((rng.standard_normal((16, 64)) * 2).astype(np.float32)) for _ in range(2)]
+    arrays["x0"], arrays["x1"] = f32_bits(xs[0]), f32_bits(xs[1])
+    kw = dict(input_activation="int8,qs=microscaling,bs=32,ax=-1,outlier=4.5", weight="int8,qs=microscaling,bs=32,ax=-1",
+              force_scale_power_of_two=True)
+    gm = qp.prepare_pt2e(m, qp.get_default_quantizer(**kw), (xs[0],))
+    with torch.no_grad():
+        gm(xs[0])
+        y1 = gm(xs[1])
+    arrays["y_prepared"] = tensor_bits(y1)
+    gc = qp.convert_pt2e(gm)
+    with torch.no_grad():
+        y2 = gc(xs[1])
+    arrays["y_converted"] = tensor_bits(y2)
+    meta["model"] = {"kw": kw, "converted_graph": _graph_rows(gc),
+                     "converted_kwargs": {n.name: {k: (v.name if isinstance(v, torch.fx.Node) else v) for k, v in n.kwargs.items()}
+                                          for n in gc.graph.nodes if n.kwargs}}
+    np.savez_compressed(os.path.join(out, "outlier.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "outlier.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def gen_pt2e_mx(ref, out):
     """PT2E flow with block-scaled (microscaling) specs: prepared outputs, the converted graph with
     quantize_mx / linear_mx / matmul_mx nodes, quantized weight + scale buffers and converted outputs
@@ -783,6 +845,7 @@ def main():
         "pt2e": lambda: gen_pt2e(ref, a.out),
         "pt2e_mx": lambda: gen_pt2e_mx(ref, a.out),
         "pt2e_patterns": lambda: gen_pt2e_patterns(ref, a.out),
+        "outlier": lambda: gen_outlier(ref, a.out),
         "eager": lambda: gen_eager(ref, a.out),
         "lora": lambda: gen_lora(ref, a.out),
         "spec": lambda: gen_spec(ref, a.out),

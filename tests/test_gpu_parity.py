@@ -1177,3 +1177,21 @@ def test_gelu_kernel_vs_torch(nv):
                 assert fq(y) is y
             assert torch.equal(y.view(torch.int16), wq.view(torch.int16))
             assert torch.equal(y._qt_fp8.view(torch.uint8), wq._qt_fp8.view(torch.uint8))
+
+
+def test_outlier_side_path_operators_on_device(nv):
+    """quantized_ops::filter_outlier / spmm_csr on device tensors (index arithmetic, no host loops) against the same
+    operators on CPU tensors, which are pinned to the reference (tests/test_pt2e_cpu.py): identical inliers and CSR
+    arrays; the product up to the accumulation order of the atomics."""
+    ops = torch.ops.quantized_ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(64, 96, generator=g) * 2
+    w = torch.randn(40, 96, generator=g)
+    ws = 2.0 ** torch.randint(-3, 2, (40, 3), generator=g).float()
+    c = ops.filter_outlier(x, 4.0, 0.05)
+    d = ops.filter_outlier(x.cuda(), 4.0, 0.05)
+    for a, b in zip(c, d):
+        assert b.device.type == "cuda" and torch.equal(a, b.cpu())
+    yc = ops.spmm_csr(c[1], c[2], c[3], w, ws, None, 32)
+    yd = ops.spmm_csr(d[1], d[2], d[3], w.cuda(), ws.cuda(), None, 32)
+    assert yd.device.type == "cuda" and float((yc - yd.cpu()).abs().max()) <= 1e-5 * float(yc.abs().max())

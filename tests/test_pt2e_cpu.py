@@ -261,3 +261,73 @@ def test_remaining_static_patterns_match_reference(kind):
     assert np.array_equal(_canon32(y).reshape(-1), arr[f"{kind}__y_prepared"].reshape(-1))
     scales = {k: [float(t) for t in v.reshape(-1)] for k, v in gm.state_dict().items() if k.endswith(".scale")}
     assert scales == info["scales"]
+
+
+# ---- outlier side path (filter_outlier / spmm_csr and their lowering) against the reference ----------------------
+OUTLIER = json.load(open(os.path.join(G, "outlier.json")))
+
+
+def _f32(arr, key, shape):
+    return torch.from_numpy(arr[key].view(np.float32).copy()).reshape(shape)
+
+
+def test_filter_outlier_and_spmm_csr_operators():
+    """quantized_ops::filter_outlier / spmm_csr (upstream decomposed.py:450-566): same inliers, same CSR arrays (row-major
+    entries, padded to int(numel * max_pct)), and bit-identical products -- plain, with block scales, transposed."""
+    arr = np.load(os.path.join(G, "outlier.npz"))
+    ops = torch.ops.quantized_ops
+    x = _f32(arr, "op__x", (3, 5, 32))
+    inl, data, idx, ptr = ops.filter_outlier(x, OUTLIER["op"]["threshold"], OUTLIER["op"]["max_pct"])
+    assert np.array_equal(_canon32(inl).reshape(-1), arr["op__inlier"].reshape(-1))
+    assert np.array_equal(_canon32(data), arr["op__data"].reshape(-1))
+    assert idx.dtype == torch.int32 and ptr.dtype == torch.int32
+    assert np.array_equal(idx.numpy().astype(np.int64), arr["op__indices"]) and np.array_equal(ptr.numpy().astype(np.int64), arr["op__indptr"])
+    assert int(ptr[-1]) == OUTLIER["op"]["nnz"]
+    w, ws = _f32(arr, "op__w", (24, 32)), _f32(arr, "op__ws", (24, 1))
+    assert np.array_equal(_canon32(ops.spmm_csr(data, idx, ptr, w)).reshape(-1), arr["op__y_plain"].reshape(-1))
+    assert np.array_equal(_canon32(ops.spmm_csr(data, idx, ptr, w, ws, None, 32)).reshape(-1), arr["op__y_scaled"].reshape(-1))
+    assert np.array_equal(_canon32(ops.spmm_csr(data, idx, ptr, w.T.contiguous(), None, None, None, True)).reshape(-1),
+                          arr["op__y_transposed"].reshape(-1))
+    # more outliers than the padded arrays hold: truncated with a warning; the product then fails as upstream's loop does
+    _, d2, i2, p2 = ops.filter_outlier(x, 0.5, 0.01)
+    assert d2.numel() == int(x.numel() * 0.01) and int(p2[-1]) > d2.numel()
+    with pytest.raises(IndexError):
+        ops.spmm_csr(d2, i2, p2, w)
+
+
+def test_outlier_spec_lowering_matches_reference():
+    """An activation spec with `outlier=`: convert_pt2e inserts filter_outlier in front of quantize_mx and adds
+    spmm_csr(outliers, quantized weight) to the block-scaled linear (upstream quantize_pt2e.py:489-510, 705-750):
+    identical converted graph, kwargs and outputs."""
+    arr = np.load(os.path.join(G, "outlier.npz"))
+    info = OUTLIER["model"]
+
+    class Two(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(64, 128)
+            self.fc2 = nn.Linear(128, 64)
+
+        def forward(self, x):
+            return self.fc2(torch.relu(self.fc1(x)))
+
+    m = Two().eval()
+    r = np.random.default_rng(3)
+    with torch.no_grad():
+        for n, p in sorted(m.named_parameters()):
+            p.copy_(torch.from_numpy((r.standard_normal(tuple(p.shape)) * 0.1).astype(np.float32)))
+    x0, x1 = _f32(arr, "x0", (16, 64)), _f32(arr, "x1", (16, 64))
+    gm = qp.prepare_pt2e(m, qp.get_default_quantizer(**info["kw"]), (x0,))
+    with torch.no_grad():
+        gm(x0)
+        y1 = gm(x1)
+    assert np.array_equal(_canon32(y1).reshape(-1), arr["y_prepared"].reshape(-1))
+    gc = qp.convert_pt2e(gm)
+    assert _rows(gc) == info["converted_graph"]
+    kwargs = {n.name: {k: (v.name if isinstance(v, torch.fx.Node) else v) for k, v in n.kwargs.items()}
+              for n in gc.graph.nodes if n.kwargs}
+    assert kwargs == info["converted_kwargs"]
+    with torch.no_grad():
+        y2 = gc(x1)
+    assert np.array_equal(_canon32(y2).reshape(-1), arr["y_converted"].reshape(-1))
+    assert float((y1 - y2).abs().max()) <= 1e-5 * float(y1.abs().max())      # the side path restores what the fake-quantizer kept
