@@ -407,18 +407,22 @@ def test_fp8_side_output(nv, dtype, tdtype, scale):
     qmap = o.get_quantization_map(dtype)
     sb = o.f32_to_bf16(np.array([scale], np.float32))
     q_exp = o.canon_nan16(o.quantize_bf16(xb, qmap, sb))
-    for both in (True, False):
+    for both, obs in ((True, True), (False, True), (True, False), (False, False)):
+        # without the observer and at scale 1 both variants take the hardware conversion (finite vectors) or the closed
+        # form (vectors holding a NaN / Inf pattern); the pattern sweep puts both kinds next to each other
         y = torch.zeros_like(x)
         y8 = torch.zeros(x.numel(), dtype=torch.uint8, device="cuda")
         amax = torch.zeros(1, dtype=torch.int32, device="cuda")
         nv.check(L.qt_fake_quant_bf16_fp8(x.data_ptr(), y.data_ptr() if both else None, y8.data_ptr(), x.numel(),
-                                          ctypes.byref(fmt), s.data_ptr(), amax.data_ptr(), stream()), "fq8")
+                                          ctypes.byref(fmt), s.data_ptr() if (obs or scale != 1.0) else None,
+                                          amax.data_ptr() if obs else None, stream()), "fq8")
         torch.cuda.synchronize()
         dec = y8.view(tdtype).float().bfloat16().view(torch.int16)
-        assert np.array_equal(o.canon_nan16(host_u16(dec)), q_exp), (dtype, scale, both)
+        assert np.array_equal(o.canon_nan16(host_u16(dec)), q_exp), (dtype, scale, both, obs)
         if both:
-            assert np.array_equal(o.canon_nan16(host_u16(y)), expect_bf16(xb, dtype, scale))
-        assert (host_u32(amax)[0] & 0x7FFFFFFF) > 0x7F800000      # the pattern sweep contains NaNs
+            assert np.array_equal(o.canon_nan16(host_u16(y)), expect_bf16(xb, dtype, scale)), (dtype, scale, obs)
+        if obs:
+            assert (host_u32(amax)[0] & 0x7FFFFFFF) > 0x7F800000      # the pattern sweep contains NaNs
 
 
 def test_fp8_linear_path(nv):
