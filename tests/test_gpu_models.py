@@ -302,3 +302,29 @@ def test_bert_block_fusions_vs_hf_chains(family):
     assert (n1, c1) == (n0, c0), (n1, c1, n0, c0)
     for a, b in ((s1, s0), (e1, e0)):
         assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01, float((a - b).abs().max())
+
+
+def test_mobilebert_blocks_on_device():
+    """MobileBERT has BertLayer-shaped blocks with NoNorm, ReLU and bottlenecked q / k / v inputs: the BERT block fusions
+    must step aside (different input widths -> no sibling GEMM, NoNorm -> HF's code) and the device path must agree with
+    the CPU path."""
+    import copy
+    from transformers import MobileBertConfig, MobileBertForQuestionAnswering
+    torch.manual_seed(0)
+    cfg = MobileBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, vocab_size=300,
+                           embedding_size=64, intra_bottleneck_size=64, max_position_embeddings=128)
+    base = MobileBertForQuestionAnswering(cfg).eval()
+    ids = torch.randint(3, 300, (4, 64), generator=torch.Generator().manual_seed(1))
+    att = torch.ones_like(ids)
+    att[2, 40:] = 0
+    outs = {}
+    for dev in ("cpu", "cuda"):
+        m = copy.deepcopy(base).to(dev)
+        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+        with torch.no_grad():
+            m(ids.to(dev), attention_mask=att.to(dev))
+            o = m(ids.to(dev), attention_mask=att.to(dev))
+        outs[dev] = (o.start_logits.float().cpu(), o.end_logits.float().cpu())
+    for a, b in zip(outs["cpu"], outs["cuda"]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 0.06 * float(a.abs().max()) + 0.02
