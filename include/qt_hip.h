@@ -127,6 +127,12 @@ int qt_dequantize_f32(const float *x_dev, float *y_dev, size_t n, const float *s
  * Per-channel variants view x as [outer][C][inner] and use scale[c] / amax_bits[c]. */
 int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float quant_max, int force_pow2,
                     void *stream);
+/* qt_scale_update for `count` fake-quantizers in one launch: element i of each device array describes fake-quantizer i
+ * (history_ptrs_dev[i] -> its [L_i, C_i] history, scale_ptrs_dev[i] -> its C_i scales).  A captured training step runs
+ * this once up front instead of one small launch before every fake-quant pass; valid because the scale a call applies
+ * depends only on the amaxes of earlier calls. */
+int qt_scale_update_multi(float *const *history_ptrs_dev, const int *L_dev, const int *C_dev, float *const *scale_ptrs_dev,
+                          const float *quant_max_dev, const int *force_pow2_dev, int count, void *stream);
 int qt_fake_quant_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t n, const qt_format *fmt,
                        const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev,
                        void *stream);

@@ -594,10 +594,8 @@ __global__ __launch_bounds__(256) void fq_pc_last_kernel(const void *__restrict_
 }
 
 // ---- delayed-scaling state machine (fake_quantize.py:230-242), one thread per channel ----------
-__global__ void scale_update_kernel(float *__restrict__ hist, int L, int C, float *__restrict__ scale, float quant_max,
-                                    int pow2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__device__ __forceinline__ void scale_update_channel(float *__restrict__ hist, int L, int C, float *__restrict__ scale,
+                                                     float quant_max, int pow2, int c) {
     // amax = torch.amax(history, dim=0): NaN propagates
     float amax = hist[c];
     bool nan = amax != amax;
@@ -623,6 +621,22 @@ __global__ void scale_update_kernel(float *__restrict__ hist, int L, int C, floa
         sf = (float)exp2((double)ceilf(lg));
     }
     scale[c] = sf;
+}
+
+__global__ void scale_update_kernel(float *__restrict__ hist, int L, int C, float *__restrict__ scale, float quant_max,
+                                    int pow2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) scale_update_channel(hist, L, C, scale, quant_max, pow2, c);
+}
+
+// The same update for MANY fake-quantizers in one launch (workgroup i = fake-quantizer i): a captured training step runs
+// it once up front instead of one 4.7 us launch in front of each of its few hundred fake-quant passes.  Valid because
+// the scale a call applies depends only on amaxes of EARLIER calls (fake_quantize.py:230-242).
+__global__ void scale_update_multi_kernel(float *const *__restrict__ hist, const int *__restrict__ L, const int *__restrict__ C,
+                                          float *const *__restrict__ scale, const float *__restrict__ quant_max,
+                                          const int *__restrict__ pow2) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < C[i]; c += blockDim.x) scale_update_channel(hist[i], L[i], C[i], scale[i], quant_max[i], pow2[i], c);
 }
 
 // ---- generic quantize / dequantize (decomposed.py:166-262); tables read from global memory ------
@@ -904,6 +918,15 @@ int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float qu
     if (!history_dev || !scale_dev || L < 1 || C < 1) return QT_ERR_BAD_ARG;
     unsigned grid = (unsigned)((C + 127) / 128);
     scale_update_kernel<<<grid, 128, 0, (hipStream_t)stream>>>(history_dev, L, C, scale_dev, quant_max, force_pow2);
+    return launch_status();
+}
+
+int qt_scale_update_multi(float *const *history_ptrs_dev, const int *L_dev, const int *C_dev, float *const *scale_ptrs_dev,
+                          const float *quant_max_dev, const int *force_pow2_dev, int count, void *stream) {
+    if (count == 0) return QT_OK;
+    if (!history_ptrs_dev || !L_dev || !C_dev || !scale_ptrs_dev || !quant_max_dev || !force_pow2_dev || count < 0) return QT_ERR_BAD_ARG;
+    scale_update_multi_kernel<<<(unsigned)count, 128, 0, (hipStream_t)stream>>>(history_ptrs_dev, L_dev, C_dev, scale_ptrs_dev,
+                                                                               quant_max_dev, force_pow2_dev);
     return launch_status();
 }
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "qt_dequantize_bf16": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P, _P]),
     "qt_dequantize_f32": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P, _P]),
     "qt_scale_update": (c_int, [_P, c_int, c_int, _P, c_float, c_int, _P]),
+    "qt_scale_update_multi": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P]),
     "qt_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_bf16_fp8": (c_int, [_P, _P, _P, c_size_t, _FMT, _P, _P, _P]),

@@ -138,6 +138,61 @@ def _as_flag(v):
     return bool(v)
 
 
+# ---- batched delayed-scaling update (harness.GraphedTrainStep) --------------------------------------------------------
+_PREUPDATED = set()       # data_ptr of every amax history whose NEXT call's scale update has already been done
+
+
+def _take_preupdate(amax_history) -> bool:
+    p = amax_history.data_ptr()
+    if p in _PREUPDATED:
+        _PREUPDATED.discard(p)
+        return True
+    return False
+
+
+def launch_scale_update(amax_history, scale, quant_max, pow2, stream_ptr):
+    """The delayed-scaling update in front of one observed call -- unless BatchedScaleUpdate already did it."""
+    if _take_preupdate(amax_history):
+        return
+    _native.check(_native.lib().qt_scale_update(amax_history.data_ptr(), int(amax_history.shape[0]), int(scale.numel()),
+                                                scale.data_ptr(), float(quant_max), int(bool(pow2)), stream_ptr),
+                  "qt_scale_update")
+
+
+class BatchedScaleUpdate:
+    """The delayed-scaling update (amax = max(history), roll, scale = amax / quant_max) of many fake-quantizers as ONE
+    launch (qt_scale_update_multi), done before the step that will call each of them; their next call then skips its own
+    update.  Only fake-quantizers that observe, already hold a history and live on `device` take part."""
+
+    def __init__(self, fake_quantizers, device):
+        fqs = [f for f in fake_quantizers
+               if getattr(f, "_observe", False) and f.amax_history.numel() > 0 and f.amax_history.device == device
+               and f.amax_history.dtype == torch.float32 and f.scale.dtype == torch.float32]
+        self.fqs = fqs
+        i64 = dict(dtype=torch.int64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.hist = torch.tensor([f.amax_history.data_ptr() for f in fqs], **i64)
+        self.scale = torch.tensor([f.scale.data_ptr() for f in fqs], **i64)
+        self.L = torch.tensor([int(f.amax_history.shape[0]) for f in fqs], **i32)
+        self.C = torch.tensor([int(f.scale.numel()) for f in fqs], **i32)
+        self.qmax = torch.tensor([float(f.quant_max) for f in fqs], dtype=torch.float32, device=device)
+        self.pow2 = torch.tensor([int(bool(f.force_scale_power_of_two)) for f in fqs], **i32)
+        self.device = device
+
+    def launch(self):
+        if not self.fqs:
+            return
+        _native.check(_native.lib().qt_scale_update_multi(self.hist.data_ptr(), self.L.data_ptr(), self.C.data_ptr(),
+                                                          self.scale.data_ptr(), self.qmax.data_ptr(), self.pow2.data_ptr(),
+                                                          len(self.fqs), _stream_ptr(self.hist)), "qt_scale_update_multi")
+        for f in self.fqs:
+            _PREUPDATED.add(f.amax_history.data_ptr())
+
+    def forget(self):
+        for f in self.fqs:
+            _PREUPDATED.discard(f.amax_history.data_ptr())
+
+
 def _rows_view(t):
     """(view, transposed) when `t` is a non-contiguous bf16 device tensor whose rows are contiguous:
     either its last dim has stride 1, or its last two dims are a transposed pair (K^T)."""
@@ -159,8 +214,7 @@ def _forward_rows(input, rows, observe, qmap, amax_history, scale, quant_max, po
     st = _stream_ptr(v)
     fmt = fmt if fmt is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
     if observe:
-        _native.check(L.qt_scale_update(amax_history.data_ptr(), int(amax_history.shape[0]), int(scale.numel()),
-                                        scale.data_ptr(), float(quant_max), int(bool(pow2)), st), "qt_scale_update")
+        launch_scale_update(amax_history, scale, quant_max, pow2, st)
     y = torch.empty(v.shape, dtype=v.dtype, device=v.device)
     shp = [1] * (4 - v.dim()) + list(v.shape)
     strd = [0] * (4 - v.dim()) + list(v.stride())
@@ -292,10 +346,7 @@ class FusedAmaxObsFakeQuantFunction(torch.autograd.Function):
         L = _native.lib()
         fmt = qt_format if qt_format is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
         if observe:
-            C = scale.numel()
-            _native.check(L.qt_scale_update(amax_history.data_ptr(), int(amax_history.shape[0]), int(C),
-                                            scale.data_ptr(), float(quant_max), int(bool(force_scale_power_of_two)),
-                                            _stream_ptr(x)), "qt_scale_update")
+            launch_scale_update(amax_history, scale, quant_max, force_scale_power_of_two, _stream_ptr(x))
         if (emit_fp8 is not None and quantize and not per_row_fake_quant and x.dtype == torch.bfloat16
                 and x.numel() % 16 == 0 and x.numel() > 0):
             # one pass: bf16 fake-quantized tensor (unless emit_fp8 == "only") + the same values as FP8 bytes
@@ -564,6 +615,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
                 and not self.record_histogram and self.outlier_threshold is None and self.fp8_exact())
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
+        self.__dict__["_qt_calls"] = self.__dict__.get("_qt_calls", 0) + 1      # harness.GraphedTrainStep reads this
         done_by = getattr(X, "_qt_fq_done_by", None)
         if done_by is self:
             # the kernel that produced X already applied this fake-quantizer (and attached X._qt_fp8): the call the

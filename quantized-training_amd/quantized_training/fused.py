@@ -10,7 +10,8 @@ import os
 import torch
 
 from . import _native
-from .fake_quantize import STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr
+from .fake_quantize import (STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr,
+                            launch_scale_update)
 from .quantizer.quantizer import QScheme
 
 _IDENTITY = _native.QtFormat(_native.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
@@ -404,9 +405,7 @@ def fused_linear_or_none(layer, x):
         if fq.amax_history.numel() == 0:
             fq.amax_history.resize_((fq.amax_history_len,)).fill_(0.0)
             fq.scale.resize_(()).fill_(1.0)
-        _native.check(L.qt_scale_update(fq.amax_history.data_ptr(), int(fq.amax_history.shape[0]), 1,
-                                        fq.scale.data_ptr(), float(fq.quant_max),
-                                        int(bool(fq.force_scale_power_of_two)), st), "qt_scale_update")
+        launch_scale_update(fq.amax_history, fq.scale, fq.quant_max, fq.force_scale_power_of_two, st)
     qw = _operand(fq, x.device)
     qx = _native.QtOperandQ()
     qx.fmt = _IDENTITY
@@ -482,9 +481,7 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
             if fq_p.amax_history.numel() == 0:
                 fq_p.amax_history.resize_((fq_p.amax_history_len,)).fill_(0.0)
                 fq_p.scale.resize_(()).fill_(1.0)
-            _native.check(L.qt_scale_update(fq_p.amax_history.data_ptr(), int(fq_p.amax_history.shape[0]), 1,
-                                            fq_p.scale.data_ptr(), float(fq_p.quant_max),
-                                            int(bool(fq_p.force_scale_power_of_two)), st), "qt_scale_update")
+            launch_scale_update(fq_p.amax_history, fq_p.scale, fq_p.quant_max, fq_p.force_scale_power_of_two, st)
         lut = fq_p.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
         scale_ptr = fq_p.scale.data_ptr() if fq_p._quantize else None
         amax_ptr = fq_p.amax_history.data_ptr() if fq_p._observe else None
@@ -618,9 +615,7 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
             if fq_p.amax_history.numel() == 0:
                 fq_p.amax_history.resize_((fq_p.amax_history_len,)).fill_(0.0)
                 fq_p.scale.resize_(()).fill_(1.0)
-            _native.check(L.qt_scale_update(fq_p.amax_history.data_ptr(), int(fq_p.amax_history.shape[0]), 1,
-                                            fq_p.scale.data_ptr(), float(fq_p.quant_max),
-                                            int(bool(fq_p.force_scale_power_of_two)), st), "qt_scale_update")
+            launch_scale_update(fq_p.amax_history, fq_p.scale, fq_p.quant_max, fq_p.force_scale_power_of_two, st)
         lut = fq_p.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
         unit_scale = fq_p.qscheme is None and getattr(fq_p, "_scale_is_one", True)      # no scale tensor at all
         scale_ptr = fq_p.scale.data_ptr() if (fq_p._quantize and not unit_scale) else None

@@ -328,3 +328,48 @@ def test_mobilebert_blocks_on_device():
     for a, b in zip(outs["cpu"], outs["cuda"]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) <= 0.06 * float(a.abs().max()) + 0.02
+
+
+def test_graphed_training_step_equals_eager_steps():
+    """harness.GraphedTrainStep: forward + quantized backward + clip + AdamW captured once and replayed.  Same kernels in
+    the same order as the eager loop, delayed-scaling state advancing inside the graph: losses, the gradient
+    fake-quantizer's scale / amax history and the weights after six steps are identical to the eager run."""
+    import copy
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100,
+                        max_position_embeddings=66, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base = RobertaForSequenceClassification(cfg)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 100, (8, 16), generator=g).cuda(), "labels": torch.randint(0, 2, (8,), generator=g).cuda()}
+               for _ in range(7)]
+    flags = _args("--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
+                  "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10",
+                  "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual")
+    res = {}
+    for mode in ("eager", "graph"):
+        m = copy.deepcopy(base).cuda()
+        qt.quantize(m, flags)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        m.train()
+        losses = []
+        if mode == "eager":
+            for b in [batches[0]] * 3 + batches[1:]:
+                opt.zero_grad(set_to_none=True)
+                loss = m(**b).loss
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0, error_if_nonfinite=False)
+                opt.step()
+                losses.append(float(loss.detach()))
+            losses = losses[3:]
+        else:
+            step = harness.GraphedTrainStep(m, opt)
+            step.capture(batches[0], warmup=3)
+            for b in batches[1:]:
+                losses.append(float(step.replay(b)))
+        fq = dict(m.named_modules())["roberta.encoder.layer.0.attention.self.query.error_pre_process.0"]
+        res[mode] = (losses, fq.scale.clone(), fq.amax_history.clone(), m.classifier.dense.weight.detach().clone())
+    (l0, s0, h0, w0), (l1, s1, h1, w1) = res["eager"], res["graph"]
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(s0, s1) and torch.equal(h0, h1) and torch.equal(w0, w1)
+    assert float(s0) != 1.0
