@@ -207,6 +207,34 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
 }
 
+// Vector-granular variant of the same (aligned tensors too small for the LDS table: a [2048, 768] gradient is 1.5 M
+// elements): 16-B loads and stores, eight gathers per lane from the L2-resident table.  The element-granular kernel
+// above moves 2 B per lane per access -- 12.4 us for such a gradient; this one is bandwidth-shaped again.
+template <int IO, bool OBS>
+__global__ __launch_bounds__(256) void fq_gather_vec_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec,
+                                                           size_t n, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                           const float *__restrict__ scale, uint32_t *amax_out) {
+    Rounder<QT_FMT_LUT> rnd{fmt, lut};
+    float s = scale ? *scale : 1.0f;
+    if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+    const bool unit = (s == 1.0f);
+    uint32_t amax = 0;
+    const uint4 *x = (const uint4 *)xv;
+    uint4 *y = (uint4 *)yv;
+    const UniformDiv dv(s);
+    if (unit)
+        fq_stream<IO, QT_FMT_LUT, kDivUnit, OBS, 256, 1, 0>(x, y, nvec, dv, rnd, amax);
+    else if (dv.safe)
+        fq_stream<IO, QT_FMT_LUT, kDivFast, OBS, 256, 1, 0>(x, y, nvec, dv, rnd, amax);
+    else
+        fq_stream<IO, QT_FMT_LUT, kDivExact, OBS, 256, 1, 0>(x, y, nvec, dv, rnd, amax);
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (size_t i = nvec * kPer + threadIdx.x; i < n; i += 256) fq_one<IO, QT_FMT_LUT, OBS>(xv, yv, i, s, unit, rnd, amax);
+    }
+    if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
 // ---- OCP FP8 side output ------------------------------------------------------------------------
 // For e4m3 / e5m2 every fake-quantized value q = map[x / s] is exactly representable as an OCP FP8
 // byte (gfx950's v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 convert an on-grid value exactly), so the pass
@@ -763,6 +791,15 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     constexpr int kPer = IO == kIoBf16 ? 8 : 4;
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
     const bool gather = !aligned || (KIND == QT_FMT_LUT && (n < kLutLdsMinElems || y == nullptr)) || n < 4096;
+    if constexpr (KIND == QT_FMT_LUT) {
+        if (aligned && y != nullptr && n >= 4096 && n < kLutLdsMinElems) {
+            const size_t nv = n / kPer;
+            unsigned grid = grid_for(nv, 256, 8);
+            if (amax) fq_gather_vec_kernel<IO, true><<<grid, 256, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+            else fq_gather_vec_kernel<IO, false><<<grid, 256, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+            return launch_status();
+        }
+    }
     if (gather) {
         // observe-only never touches the table, so KIND is irrelevant there
         unsigned grid = grid_for(n, 256 * 8, 8);
