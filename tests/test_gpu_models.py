@@ -373,3 +373,25 @@ def test_graphed_training_step_equals_eager_steps():
     assert l0 == l1, (l0, l1)
     assert torch.equal(s0, s1) and torch.equal(h0, h1) and torch.equal(w0, w1)
     assert float(s0) != 1.0
+
+
+def test_collect_qa_logits_graph_replay_equals_eager():
+    """SQuAD-style evaluation with graph=True: same-shaped batches replay one captured forward, the ragged last batch runs
+    eagerly; logits identical to the eager loop (stateless E4M3 spec)."""
+    import copy
+    from transformers import BertConfig, BertForQuestionAnswering
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, vocab_size=300,
+                     max_position_embeddings=96)
+    m = BertForQuestionAnswering(cfg).eval().bfloat16().cuda()
+    qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for n in (8, 8, 8, 5):
+        ids = torch.randint(3, 300, (n, 96), generator=g)
+        att = torch.ones_like(ids)
+        att[0, 70:] = 0
+        batches.append({"input_ids": ids, "attention_mask": att, "token_type_ids": torch.zeros_like(ids)})
+    s0, e0 = harness.collect_qa_logits(m, batches)
+    s1, e1 = harness.collect_qa_logits(m, batches, graph=True)
+    assert s0.shape == (29, 96) and torch.equal(s0, s1) and torch.equal(e0, e1)
