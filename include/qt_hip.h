@@ -306,6 +306,12 @@ int qt_layernorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const
                       uint16_t *y_dev, uint16_t *yq_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt,
                       void *stream);
 int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n, const qt_format *fmt, void *stream);
+/* The residual add of a LLaMA block (modeling_llama.py LlamaDecoderLayer.forward: `hidden = residual + hidden`) absorbed into
+ * the RMSNorm behind it: sum = bf16(x + residual) (written out: it is the next residual), y = RMSNorm(sum) as
+ * qt_rmsnorm_bf16 computes it; with y8 (non-NULL) the first consumer's stateless E4M3 / E5M2 fake-quantizer is applied to y
+ * as in qt_rmsnorm_fq8_bf16. */
+int qt_add_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
+                        uint16_t *y_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt, void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols,
                      size_t gate_row_stride, size_t up_row_stride, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:

@@ -24,10 +24,12 @@ constexpr int kNormMaxVec = 8;        // 16-byte vectors per thread: rows up to 
 
 // FQ: 0 plain; 1 / 2 = the first consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result, which is
 // written as bf16 plus its FP8 code (producer-fused fake-quant, model_fusions.py)
-template <int FQ>
+// ADD: the row is bf16(x + res) (the residual add in front of the norm, torch's rounding), also written to `sum`
+template <int FQ, bool ADD = false>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ w,
                                                                uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
-                                                               uint2 *__restrict__ y8, qt_format fmt) {
+                                                               uint2 *__restrict__ y8, qt_format fmt,
+                                                               const uint4 *__restrict__ res = nullptr, uint4 *__restrict__ sum = nullptr) {
     __shared__ float s_part[kNormThreads / 64];
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
@@ -38,6 +40,14 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
         const int c = threadIdx.x + i * kNormThreads;
         if (c < nvec) {
             v[i] = xr[c];
+            if constexpr (ADD) {
+                const uint4 r = res[row * (size_t)nvec + c];
+                v[i].x = pack_bf16x2(bf_lo(v[i].x) + bf_lo(r.x), bf_hi(v[i].x) + bf_hi(r.x));
+                v[i].y = pack_bf16x2(bf_lo(v[i].y) + bf_lo(r.y), bf_hi(v[i].y) + bf_hi(r.y));
+                v[i].z = pack_bf16x2(bf_lo(v[i].z) + bf_lo(r.z), bf_hi(v[i].z) + bf_hi(r.z));
+                v[i].w = pack_bf16x2(bf_lo(v[i].w) + bf_lo(r.w), bf_hi(v[i].w) + bf_hi(r.w));
+                sum[row * (size_t)nvec + c] = v[i];
+            }
             const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -373,6 +383,25 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, 
     else
         rmsnorm_kernel<1><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
                                                                                     (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
+    return launch_status();
+}
+
+int qt_add_rmsnorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, uint8_t *y8,
+                        long rows, long cols, float eps, const qt_format *fmt, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !residual || !weight || !sum || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
+    const int fq = y8 ? fp8_code_of(fmt) : 0;
+    if (y8 && !fq) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)sum | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u))
+        return QT_ERR_UNALIGNED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (int)(cols / 8);
+    const float inv = 1.0f / (float)cols;
+    const qt_format f = fq ? *fmt : qt_format{};
+    if (fq == 2) rmsnorm_kernel<2, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
+    else if (fq == 1) rmsnorm_kernel<1, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
+    else rmsnorm_kernel<0, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum);
     return launch_status();
 }
 

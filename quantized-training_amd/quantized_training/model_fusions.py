@@ -64,6 +64,35 @@ def rmsnorm_fq(x, weight, eps, fq):
     return y
 
 
+def add_rmsnorm(x, residual, norm, fq=None):
+    """(bf16(x + residual), RMSNorm of that sum) in one launch; with `fq` the norm result carries the first consumer's
+    fake-quant exactly as rmsnorm_fq's does."""
+    cols = x.shape[-1]
+    x2, r2 = x.contiguous(), residual.contiguous()
+    total = torch.empty_like(x2)
+    y = torch.empty_like(x2)
+    y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) if fq is not None else None
+    _native.check(_native.lib().qt_add_rmsnorm_bf16(
+        x2.data_ptr(), r2.data_ptr(), norm.weight.data_ptr(), total.data_ptr(), y.data_ptr(),
+        y8.data_ptr() if y8 is not None else None, x2.numel() // cols, cols, float(norm.variance_epsilon),
+        ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
+    if fq is not None:
+        y._qt_fp8 = _fp8_view(y8, fq)
+        y._qt_fq_done_by = fq
+    return total, y
+
+
+def _add_rmsnorm_or_none(x, residual, norm):
+    """The residual add in front of a LlamaRMSNorm absorbed into its kernel, or None (gradients needed, hooks on the norm,
+    other dtypes / devices, QT_FUSED_MODEL_OPS=0)."""
+    w = getattr(norm, "weight", None)
+    if (norm is None or w is None or norm.__dict__.get("_qt_hf_forward") is None or _hooked(norm) or not _eligible(x, residual, w)
+            or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()
+            or os.environ.get("QT_FUSED_ADD_NORM", "1") == "0"):
+        return None
+    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm))
+
+
 def _norm_consumer_fq(norm):
     """The fake-quantizer the norm kernel may apply: every Linear fed by this norm must quantize its input with the
     same stateless format (then the first one's pass is fused here and the siblings', run on the already quantized
@@ -358,6 +387,9 @@ def _qk_fqs(attn):
 
 # ---- module-level swaps -------------------------------------------------------------------------------------------
 def _rmsnorm_forward(self, hidden_states):
+    pre = getattr(hidden_states, "_qt_prenormed", None)
+    if pre is not None and pre[0] is self and not _hooked(self):
+        return pre[1]                    # the previous block's kernel added its residual and normalised for this norm
     w = self.weight
     if (_eligible(hidden_states, w) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384
             and hidden_states.numel() > 0 and w.is_contiguous()):
@@ -379,6 +411,37 @@ def _mlp_forward(self, x):
             return self.down_proj(silu_mul(gate, up))
         return self.down_proj(self.act_fn(gate) * up)
     return self._qt_hf_forward(x)
+
+
+_LAYER_PARAMS = ["self", "hidden_states", "attention_mask", "position_ids", "past_key_values", "use_cache",
+                 "position_embeddings", "kwargs"]
+
+
+def _decoder_layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                           position_embeddings=None, **kwargs):
+    """transformers' LlamaDecoderLayer.forward, statement for statement, with each `residual + hidden_states` absorbed into
+    the RMSNorm kernel that reads the sum next -- this block's post-attention norm, and the NEXT block's input norm (or the
+    model's final norm), whose result travels with the returned tensor (`_qt_prenormed`) until that norm is called."""
+    residual = hidden_states
+    hidden_states = self.input_layernorm(hidden_states)
+    hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                      past_key_values=past_key_values, use_cache=use_cache,
+                                      position_embeddings=position_embeddings, **kwargs)
+    fused = _add_rmsnorm_or_none(hidden_states, residual, self.post_attention_layernorm)
+    if fused is not None:
+        residual, hidden_states = fused
+    else:
+        hidden_states = residual + hidden_states
+        residual = hidden_states
+        hidden_states = self.post_attention_layernorm(hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    nxt = self.__dict__.get("_qt_next_norm")
+    fused = _add_rmsnorm_or_none(hidden_states, residual, nxt) if nxt is not None else None
+    if fused is None:
+        return residual + hidden_states
+    out, normed = fused
+    out._qt_prenormed = (nxt, normed)
+    return out
 
 
 def _bind(module, fn):
@@ -442,6 +505,18 @@ def apply_llama_fusions(model):
             mod.register_forward_pre_hook(_attn_enter, with_kwargs=True)
             mod.register_forward_hook(_attn_exit, with_kwargs=True, always_call=True)
             mod._qt_ctx_hooks = True
+    # residual adds absorbed into the norm behind them: only if this transformers version's decoder layer is the one
+    # _decoder_layer_forward restates (same parameters) and the model exposes its blocks and final norm the usual way
+    import inspect
+    same_layer = list(inspect.signature(ml.LlamaDecoderLayer.forward).parameters) == _LAYER_PARAMS
+    for mod in model.modules():
+        layers, final = getattr(mod, "layers", None), getattr(mod, "norm", None)
+        if (same_layer and isinstance(mod, ml.LlamaModel) and isinstance(final, ml.LlamaRMSNorm) and layers is not None
+                and all(isinstance(l, ml.LlamaDecoderLayer) for l in layers)):
+            n_used = mod.config.num_hidden_layers
+            for i, layer in enumerate(layers[:n_used]):
+                layer.__dict__["_qt_next_norm"] = layers[i + 1].input_layernorm if i + 1 < n_used else final
+                _bind(layer, _decoder_layer_forward)
     # which Linears consume each norm's output (plain references kept out of the module tree)
     for mod in model.modules():
         if isinstance(mod, ml.LlamaDecoderLayer):

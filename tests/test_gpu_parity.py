@@ -1199,3 +1199,29 @@ def test_outlier_side_path_operators_on_device(nv):
     yc = ops.spmm_csr(c[1], c[2], c[3], w, ws, None, 32)
     yd = ops.spmm_csr(d[1], d[2], d[3], w.cuda(), ws.cuda(), None, 32)
     assert yd.device.type == "cuda" and float((yc - yd.cpu()).abs().max()) <= 1e-5 * float(yc.abs().max())
+
+
+def test_add_rmsnorm_equals_add_then_rmsnorm(nv):
+    """qt_add_rmsnorm_bf16: the sum is torch's bf16 add bit for bit, the norm (and, with a consumer, its fake-quantized
+    image + FP8 code) is exactly what the norm kernel gives on that sum -- the residual add costs no launch of its own."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    from transformers.models.llama import modeling_llama as ml
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for cols in (4096, 5120, 264):
+        x = (torch.randn(517, cols, device="cuda", generator=g) * 3).bfloat16()
+        r = (torch.randn(517, cols, device="cuda", generator=g) * 40).bfloat16()
+        norm = ml.LlamaRMSNorm(cols, eps=1e-5).cuda().bfloat16()
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.1 * torch.randn(cols, device="cuda", generator=g))
+            total, y = mf.add_rmsnorm(x, r, norm)
+            want_sum = x + r
+            assert torch.equal(total.view(torch.int16), want_sum.view(torch.int16))
+            assert torch.equal(y.view(torch.int16), mf.rmsnorm(want_sum, norm.weight, norm.variance_epsilon).view(torch.int16))
+            for dtype in ("e4m3", "e5m2"):
+                fq = FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+                total2, yq = mf.add_rmsnorm(x, r, norm, fq)
+                ref = mf.rmsnorm_fq(want_sum, norm.weight, norm.variance_epsilon, fq)
+                assert torch.equal(total2.view(torch.int16), want_sum.view(torch.int16))
+                assert torch.equal(yq.view(torch.int16), ref.view(torch.int16))
+                assert torch.equal(yq._qt_fp8.view(torch.uint8), ref._qt_fp8.view(torch.uint8)) and fq(yq) is yq
