@@ -37,27 +37,23 @@ class Linear(nn.Linear):
 
     @classmethod
     def from_float(cls, mod):
-        assert type_before_parametrizations(mod) == cls._FLOAT_MODULE, (
-            f" qat.{cls.__name__}.from_float only works for {cls._FLOAT_MODULE.__name__}")
-        assert hasattr(mod, "qconfig"), "Input float module must have qconfig defined"
-        assert mod.qconfig, "Input float module must have a valid qconfig"
-        # build on the meta device: the parameters are replaced by the float module's right below
-        qat = cls(mod.in_features, mod.out_features, bias=mod.bias is not None, qconfig=mod.qconfig,
-                  device="meta")
-        if is_parametrized(mod, "weight"):
-            transfer_parametrizations_and_params(mod, qat, "weight")
-        else:
-            qat.weight = mod.weight
-        if is_parametrized(mod, "bias"):
-            transfer_parametrizations_and_params(mod, qat, "bias")
-        else:
-            qat.bias = mod.bias
-        return qat
+        """The QAT twin of a float ``nn.Linear`` that carries a ``qconfig``; weight and bias stay the SAME Parameter
+        objects (or parametrizations) as the float module's."""
+        kind = type_before_parametrizations(mod)
+        assert kind == cls._FLOAT_MODULE, f" qat.{cls.__name__}.from_float only works for {cls._FLOAT_MODULE.__name__}"
+        assert getattr(mod, "qconfig", None), "Input float module must have a valid qconfig"
+        twin = cls(mod.in_features, mod.out_features, bias=mod.bias is not None, qconfig=mod.qconfig,
+                   device="meta")                      # parameters are adopted from `mod` right below
+        for name in ("weight", "bias"):
+            if is_parametrized(mod, name):
+                transfer_parametrizations_and_params(mod, twin, name)
+            else:
+                setattr(twin, name, getattr(mod, name))
+        return twin
 
     def to_float(self):
-        linear = torch.nn.Linear(self.in_features, self.out_features, self.bias is not None)
-        linear.weight = torch.nn.Parameter(self.weight.detach())
-        if self.bias is not None:
-            linear.bias = torch.nn.Parameter(self.bias.detach())
-        linear.train(self.training)
-        return linear
+        """A plain ``nn.Linear`` holding detached copies of the current parameters."""
+        plain = torch.nn.Linear(self.in_features, self.out_features, bias=self.bias is not None, device="meta")
+        plain.weight = torch.nn.Parameter(self.weight.detach())
+        plain.bias = None if self.bias is None else torch.nn.Parameter(self.bias.detach())
+        return plain.train(self.training)
