@@ -209,6 +209,18 @@ int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev
                    long lda, long sa, long ldb_k, long ldb_n, long sb, const qt_operand_q *qa,
                    const qt_operand_q *qb, void *stream);
 
+/* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
+ * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
+ *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)
+ * x8: the FP8 codes of the already fake-quantized activation ([M][K], what qt_fake_quant_bf16_fp8 and the producer-fused
+ * kernels emit; format 0 = E4M3, 1 = E5M2).  w_devs[i]: the UNQUANTIZED bf16 weight i, [ns[i]][K] row-major; the kernel
+ * applies the e4m3 / e5m2 value map (w_format; unit scale, fp8.py:10-67) to every weight tile on its way from LDS to the
+ * matrix core, so fq(W) is never written to HBM and W is read once.  Up to 4 weights that share the activation (q / k / v
+ * projections) go in one launch, their outputs side by side in y (row stride sum n).  bias_devs (nullable array of
+ * nullable bf16 [ns[i]] vectors).  w_devs / bias_devs / ns are HOST arrays.  K % 128 == 0, ns[i] % 16 == 0. */
+int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
+                       const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream);
+
 /* ---- A10: attention-score path between the two attention GEMMs ------------------------------
  * Replaces, for one attention block, the chain
  *     attn_scaling(scores, scaling) ; + attention_mask ; softmax(fp32) ; .to(bf16) ; fq(probs)

@@ -67,10 +67,10 @@ struct Plan {
     bool tuned = false;
 };
 
-using Key = std::tuple<int, int, int, long, int, int, int, int, int, long, long, long>;
+using Key = std::tuple<int, int, int, long, int, int, int, int, int, long, long, long>;     // [8] = device ordinal
 std::map<Key, Plan> g_plans;
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_handles;       // one library handle per device (created with that device current)
 
 hipDataType fp8_type(int f) { return f == 1 ? HIP_R_8F_E5M2 : HIP_R_8F_E4M3; }
 
@@ -86,9 +86,12 @@ extern "C" int qt_fp8_gemm(const uint8_t *a8, int a_format, const uint8_t *b8, i
     if (!L.ok) return QT_ERR_NO_DEVICE;                      // library not available in this process
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return QT_ERR_NO_DEVICE;
+    hipblasLtHandle_t &g_handle = g_handles[dev];
     if (!g_handle && L.Create(&g_handle) != HIPBLAS_STATUS_SUCCESS) return QT_ERR_NO_DEVICE;
 
-    const Key key{a_format, b_format, b_is_kn, batch, M, N, K, bias_bf16 ? 1 : 0, 0, a_batch_stride, b_batch_stride, c_batch_stride};
+    const Key key{a_format, b_format, b_is_kn, batch, M, N, K, bias_bf16 ? 1 : 0, dev, a_batch_stride, b_batch_stride, c_batch_stride};
     Plan &p = g_plans[key];
     if (!p.desc) {
         // column-major view: C^T [N, M] = op(B-matrix) . A-matrix, with the A-matrix [K, M] (ld K)

@@ -1,0 +1,491 @@
+// Fake-quant Linear with the weight's E4M3 / E5M2 fake-quantizer fused into the GEMM's operand path.
+//
+// Replaces   F.linear(input, self.weight_fake_quant(self.weight), self.bias)       modules/qat/linear.py:40-41
+// for stateless FP8 fake-quantizers (e4m3 / e5m2 specs without `qs`: scale 1, fp8.py:10-67) on both operands:
+//   * the activation arrives as the FP8 codes the producer passes already emit (qt_fake_quant_bf16_fp8 & co.);
+//   * the bf16 weight is read ONCE from HBM, unquantized, straight into LDS (global_load_lds), and each wave converts the
+//     fragments it multiplies on their way from LDS to the matrix core: v_cvt_scalef32_pk_{fp8,bf8}_bf16 at scale 1.0 is
+//     the format's round-to-nearest-even on every bf16 input whose result is finite (tools/exp_cvt_bf16.hip: all 65 536
+//     patterns; subnormals and the flush to zero included; the sign of a zero result differs, which no product sees).
+//     Inputs that overflow the format (|w| > 464 / 61440: the reference saturates) and non-finite ones (the reference
+//     maps +-Inf to NaN) show up as an all-ones exponent in the converted code; a lane that sees one redoes its 32
+//     elements with the closed form (qt_fp_sat_u32) -- so fq(W) never exists in HBM and the codes are bit-exact;
+//   * products of the codes are exactly the reference's bf16 products; v_mfma_scale_f32_16x16x128_f8f6f4 at unit E8M0
+//     scales (the 2x-rate FP8 instruction), fp32 accumulation, bias and the bf16 rounding in the epilogue.
+//
+// Work decomposition (M = rows of x, N = rows of W = output columns).  A workgroup owns 256 rows x (16 nt) columns,
+// nt <= 12; 8 waves = 4 row bands (64 rows) x 2 column halves (ceil(nt/2) and floor(nt/2) 16-column groups: the two
+// waves that share a SIMD are one of each, so an odd nt still balances per SIMD).  The host picks the column widths so
+// that the grid is a whole number of rounds over the CUs -- 1024 x 11008: 4 x 64 tiles of 176 / 160 columns = 256
+// workgroups, not 4 x 43 of 256 (172 workgroups, a third of the chip idle).  Tile ids are dealt so that the row tiles of
+// one column tile run on the same XCD at the same time: a weight tile leaves HBM once and is re-read from that XCD's L2.
+// Up to four weight tensors sharing one activation (q / k / v projections) form the "segments" of one launch.
+//
+// LDS, per stage: 32 KiB activation tile (256 rows x 128 FP8 codes, 16-byte chunks XOR-swizzled by row as in
+// qt_mx_gemm.hip) + NB x 8 KiB weight tile (16 nt rows x 128 bf16 = 256 B per row = exactly one bank row, so the
+// 16-byte chunk index is XORed with the row to spread a fragment's sixteen rows over sixteen slots).  Two stages: the
+// DMA of k-step t+1 is in flight while step t is multiplied (counted vmcnt + raw s_barrier; fragment reads are inline
+// asm so that hipcc does not drain the DMA queue in front of them, see qt_mx_gemm.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "../../include/qt_hip.h"
+#include "qt_device.h"
+#include "qt_formats.h"
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // native vector: usable as a "+v" asm operand
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int kTM = 256, kBK = 128, kMaxSeg = 4, kMaxNT = 12, kMaxNB = 6;
+constexpr int kABytes = kTM * kBK;                  // one activation tile: 32 KiB of FP8 codes
+constexpr int kUnitE8M0 = 127;                      // 2^0
+
+struct Segment {
+    const uint16_t *w;        // [n][K] bf16
+    const uint16_t *bias;     // [n] bf16 or NULL
+    int g0;                   // first 16-column group of this weight in the concatenation of all weights
+};
+
+struct Args {
+    const uint8_t *x8;        // [M][K] FP8 codes
+    uint16_t *y;              // [M][ldc] bf16
+    int M, K, ldc;
+    int tiles_m, tiles_n, nseg;
+    int gbase, gextra;        // column tile j covers gbase + (j < gextra) groups of 16 columns
+    int nb;                   // ceil(4 * widest tile / 8): weight DMA pieces the widest tile needs per wave
+    int dbg;                  // tuning switches (QT_FQ8_DEBUG): 2 = no multiplications, 128 = no issue stagger
+    Segment seg[kMaxSeg];
+};
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// activation tile: row-major 128-byte rows, chunk index XOR ((row >> 1) & 7)
+__device__ __forceinline__ int a_chunk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// two packed bf16 pairs -> four FP8 codes (the first conversion's untouched half is overwritten by the second)
+template <bool E5M2>
+__device__ __forceinline__ uint32_t cvt_bf16x4(uint32_t p0, uint32_t p1) {
+    v2s o = __builtin_bit_cast(v2s, p0);
+    if constexpr (E5M2) {
+        o = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(o, __builtin_bit_cast(v2bf, p0), 1.0f, false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(o, __builtin_bit_cast(v2bf, p1), 1.0f, true);
+    } else {
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(v2bf, p0), 1.0f, false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(v2bf, p1), 1.0f, true);
+    }
+    return __builtin_bit_cast(uint32_t, o);
+}
+
+// 32 bf16 weights of one lane (four 16-byte chunks) -> the lane's 32-byte B fragment of fq(W) codes: the hardware conversion,
+// right for every input whose result is finite.  Overflow and non-finite inputs come out as NaN / Inf codes, which poison
+// the accumulator and are caught after the k loop (slow_tile redoes such a tile with the closed form).
+template <bool E5M2>
+__device__ __forceinline__ v8i convert_frag(const u32x4 (&raw)[4]) {
+    const uint32_t in[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
+                             raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+    v8i f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) f[d] = (int)cvt_bf16x4<E5M2>(in[2 * d], in[2 * d + 1]);
+    return f;
+}
+
+// four bf16 values (two packed words) -> their four exact codes (closed form of the value map, fp8.py:10-67)
+template <bool E5M2>
+__device__ __forceinline__ uint32_t exact_bf16x4(uint32_t p0, uint32_t p1) {
+    constexpr int mb = E5M2 ? 2 : 3, emin = E5M2 ? -14 : -6;
+    constexpr float fmax = E5M2 ? 57344.0f : 448.0f;
+    return qt_pack_fp8x4<E5M2>(qt_u2f(qt_fp_sat_u32(p0 << 16, mb, emin, fmax)), qt_u2f(qt_fp_sat_u32(p0 & 0xFFFF0000u, mb, emin, fmax)),
+                               qt_u2f(qt_fp_sat_u32(p1 << 16, mb, emin, fmax)), qt_u2f(qt_fp_sat_u32(p1 & 0xFFFF0000u, mb, emin, fmax)));
+}
+
+#define QT_LDS_WAIT4(n, v) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
+
+// FX / FW: 0 = E4M3, 1 = E5M2 (the instruction's operand format codes); NB: weight DMA pieces (4 rows x 256 bytes) per wave
+// and stage (2, 4 or 6: tiles of up to 4, 8, 12 column groups)
+template <int FX, int FW, int NB>
+struct LinearFq8 {
+    static constexpr int kStage = kABytes + NB * 8 * 1024;
+    static constexpr int kGroup = 4 + NB;                   // vector-memory instructions of one issue()
+    // One wave's share: rows [wm * 64, +64) x NTW column groups starting at group jbase of the tile whose first group
+    // (in the concatenation of the weights) is tg0.
+    template <int NTW>
+    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
+        const int r = l & 15, g = l >> 4, wm = w & 3, wn = w >> 2;
+        const int nk = a.K / kBK;
+        constexpr int stage_bytes = kStage;
+        auto seg_of = [&](int grp) __attribute__((always_inline)) {       // weight holding column group `grp`
+            int s = 0;
+#pragma unroll
+            for (int i = 1; i < kMaxSeg; ++i)
+                if (i < a.nseg && grp >= a.seg[i].g0) s = i;
+            return s;
+        };
+        // ---- DMA sources (k tile 0); LDS destinations are wave-uniform
+        const uint8_t *ga[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
+            ga[i] = a.x8 + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        // Weight pieces (4 rows x 256 bytes): piece p = w + 8 i, so p & 3 == w & 3 for every piece of this wave and the
+        // swizzled lane offset is the same for all of them; only the (wave-uniform) base differs.  Surplus pieces repeat
+        // piece w & 3 (same bytes, same place).
+        const int npieces = nt * 4;
+        const uint8_t *ub[NB];                                 // wave-uniform: first row of the piece, k tile 0
+        int pb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int p = w + 8 * i;
+            pb[i] = p < npieces ? p : (w & 3);
+            const int grp = tg0 + (pb[i] >> 2), s = seg_of(grp);
+            ub[i] = (const uint8_t *)a.seg[s].w + ((long)((grp - a.seg[s].g0) * 16 + (pb[i] & 3) * 4) * a.K) * 2;
+        }
+        const int row16 = (w & 3) * 4 + (l >> 4);              // row & 15 of this lane's row in any of its pieces
+        const uint32_t b_lane = (uint32_t)(l >> 4) * (uint32_t)a.K * 2u + (((l & 15) ^ row16) << 4);
+        auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * kBK), (lds_void *)(stage + (w * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void *)(ub[i] + (long)kt * (2 * kBK) + b_lane), (lds_void *)(stage + kABytes + pb[i] * 1024), 16, 0, 0);
+        };
+        // Wave half 1 issues its share in the middle of its multiplications instead of in front of them, so that one wave
+        // of every SIMD is on the matrix core while the other one feeds the DMA queue.
+        const int ipos = (wn == 1 && !(a.dbg & 128)) ? (NTW + 1) / 2 : -1;
+
+        v4f acc[4][NTW > 0 ? NTW : 1];
+        // lane-constant parts of the fragment addresses
+        const uint32_t a_lo = a_chunk_off(wm * 64 + r, g), a_hi = a_chunk_off(wm * 64 + r, 4 + g);
+        const uint32_t b_row = kABytes + (jbase * 16 + r) * 256;
+        const uint32_t b0 = b_row + (((2 * g) ^ r) << 4), b1 = b_row + (((2 * g + 1) ^ r) << 4);
+        const uint32_t b2 = b_row + (((8 + 2 * g) ^ r) << 4), b3 = b_row + (((9 + 2 * g) ^ r) << 4);
+
+        auto compute = [&](uint32_t s, int kt_next, uint8_t *next_stage) __attribute__((always_inline)) {
+            if constexpr (NTW > 0) {
+                u32x4 fa_lo[4], fa_hi[4];
+                fa_lo[0] = ds_read128<0 * 2048>(s + a_lo); fa_hi[0] = ds_read128<0 * 2048>(s + a_hi);
+                fa_lo[1] = ds_read128<1 * 2048>(s + a_lo); fa_hi[1] = ds_read128<1 * 2048>(s + a_hi);
+                fa_lo[2] = ds_read128<2 * 2048>(s + a_lo); fa_hi[2] = ds_read128<2 * 2048>(s + a_hi);
+                fa_lo[3] = ds_read128<3 * 2048>(s + a_lo); fa_hi[3] = ds_read128<3 * 2048>(s + a_hi);
+                u32x4 raw[2][4];
+                auto read_b = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    raw[J & 1][0] = ds_read128<J * 4096>(s + b0);
+                    raw[J & 1][1] = ds_read128<J * 4096>(s + b1);
+                    raw[J & 1][2] = ds_read128<J * 4096>(s + b2);
+                    raw[J & 1][3] = ds_read128<J * 4096>(s + b3);
+                };
+                v8i fa[4];
+                auto step = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    if constexpr (J + 1 < NTW) {
+                        read_b(std::integral_constant<int, J + 1>{});
+                        if constexpr (J == 0) {
+                            asm volatile("s_waitcnt lgkmcnt(4)"
+                                         : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]),
+                                           "+v"(fa_lo[3]), "+v"(fa_hi[3]), "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]));
+                        } else {
+                            QT_LDS_WAIT4(4, raw[J & 1]);
+                        }
+                    } else {
+                        if constexpr (J == 0) {
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]),
+                                           "+v"(fa_lo[3]), "+v"(fa_hi[3]), "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]));
+                        } else {
+                            QT_LDS_WAIT4(0, raw[J & 1]);
+                        }
+                    }
+                    if constexpr (J == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            fa[i] = v8i{(int)fa_lo[i].x, (int)fa_lo[i].y, (int)fa_lo[i].z, (int)fa_lo[i].w,
+                                        (int)fa_hi[i].x, (int)fa_hi[i].y, (int)fa_hi[i].z, (int)fa_hi[i].w};
+                    }
+                    const v8i fb = convert_frag<FW == 1>(raw[J & 1]);
+                    // operands swapped: D rows = W rows (output columns), D columns = x rows, so a lane ends up with four
+                    // consecutive output columns of one row -- an 8-byte store in the epilogue
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+                    if (J + 1 == ipos && kt_next >= 0) issue(kt_next, next_stage);
+                };
+                read_b(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 0>{});
+                if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
+                if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
+                if constexpr (NTW > 3) step(std::integral_constant<int, 3>{});
+                if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
+                if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
+            } else {
+                if (ipos >= 0 && kt_next >= 0) issue(kt_next, next_stage);
+            }
+        };
+
+        const uint32_t s_base = lds_addr(lds);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        issue(0, lds);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            uint8_t *next_stage = lds + (cur ^ 1) * stage_bytes;
+            // Vector-memory queue of this wave, oldest first: [pieces of step kt] and, for the half that issues in front of its
+            // multiplications, the pieces of step kt + 1 behind them.
+            if (ipos < 0) {
+                if (more) {
+                    issue(kt + 1, next_stage);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGroup) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                    // every wave's pieces of step kt have landed
+            if (!(a.dbg & 2)) compute(s_base + cur * stage_bytes, (more && ipos >= 0) ? kt + 1 : -1, next_stage);
+            else if (more && ipos >= 0) issue(kt + 1, next_stage);
+            __builtin_amdgcn_s_barrier();                    // this stage may be refilled
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Overflowed or non-finite weights (and NaN activations) leave NaN / Inf in the accumulators: such a tile is redone
+        // by slow_tile.  The workgroup-wide vote goes through LDS (the stages are dead here).
+        bool bad = false;
+        if constexpr (NTW > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
+        }
+        volatile int *flag = (volatile int *)lds;
+        if (w == 0 && l == 0) *flag = 0;
+        __syncthreads();
+        if (bad) *flag = 1;
+        __syncthreads();
+        if (*flag) return true;
+
+        // ---- epilogue: lane (r, g) of tile (i, j) holds y[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]
+        if constexpr (NTW > 0) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int grp = tg0 + jbase + j, s = seg_of(grp);
+                const int col = grp * 16 + 4 * g;                       // output column
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.seg[s].bias) {
+                    const uint2 b = *(const uint2 *)(a.seg[s].bias + (col - a.seg[s].g0 * 16));
+                    bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
+                    bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * 64 + i * 16 + r;
+                    if (row < a.M) {
+                        const uint2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
+                                         pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
+                        *(uint2 *)(a.y + (long)row * a.ldc + col) = o;
+                    }
+                }
+            }
+        }
+        return false;
+    }
+};
+
+// The redo path of a tile whose fast pass saw NaN / Inf: every weight goes through the closed form of the value map.  Plain
+// loops, operands straight from global memory, one 16 x 16 output tile at a time -- only ever taken for weights beyond the
+// format's range or non-finite values.
+template <int FX, int FW>
+__device__ void slow_tile(const Args &a, int m0, int tg0, int jbase, int ntw, int w, int l) {
+    const int r = l & 15, g = l >> 4, wm = w & 3;
+    const int nk = a.K / kBK;
+#pragma unroll 1
+    for (int j = 0; j < ntw; ++j) {
+        const int grp = tg0 + jbase + j;
+        int s = 0;
+#pragma unroll
+        for (int i = 1; i < kMaxSeg; ++i)
+            if (i < a.nseg && grp >= a.seg[i].g0) s = i;
+        const uint16_t *wrow = a.seg[s].w + (long)((grp - a.seg[s].g0) * 16 + r) * a.K;
+        const int col = grp * 16 + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.seg[s].bias) {
+            const uint2 b = *(const uint2 *)(a.seg[s].bias + (col - a.seg[s].g0 * 16));
+            bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
+            bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
+        }
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + wm * 64 + i * 16 + r;
+            const uint8_t *xrow = a.x8 + (long)min(row, a.M - 1) * a.K;
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int kt = 0; kt < nk; ++kt) {
+                const uint4 xl = *(const uint4 *)(xrow + kt * kBK + 16 * g), xh = *(const uint4 *)(xrow + kt * kBK + 64 + 16 * g);
+                const uint4 *wl = (const uint4 *)(wrow + kt * kBK + 16 * g), *wh = (const uint4 *)(wrow + kt * kBK + 64 + 16 * g);
+                const uint4 w0 = wl[0], w1 = wl[1], w2 = wh[0], w3 = wh[1];
+                const v8i fa = {(int)xl.x, (int)xl.y, (int)xl.z, (int)xl.w, (int)xh.x, (int)xh.y, (int)xh.z, (int)xh.w};
+                v8i fb;
+                fb[0] = (int)exact_bf16x4<FW == 1>(w0.x, w0.y); fb[1] = (int)exact_bf16x4<FW == 1>(w0.z, w0.w);
+                fb[2] = (int)exact_bf16x4<FW == 1>(w1.x, w1.y); fb[3] = (int)exact_bf16x4<FW == 1>(w1.z, w1.w);
+                fb[4] = (int)exact_bf16x4<FW == 1>(w2.x, w2.y); fb[5] = (int)exact_bf16x4<FW == 1>(w2.z, w2.w);
+                fb[6] = (int)exact_bf16x4<FW == 1>(w3.x, w3.y); fb[7] = (int)exact_bf16x4<FW == 1>(w3.z, w3.w);
+                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa, acc, FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+            }
+            if (row < a.M) {
+                const uint2 o = {pack_bf16x2(acc[0] + bv[0], acc[1] + bv[1]), pack_bf16x2(acc[2] + bv[2], acc[3] + bv[3])};
+                *(uint2 *)(a.y + (long)row * a.ldc + col) = o;
+            }
+        }
+    }
+}
+
+template <int FX, int FW, int NB>
+__global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    // Workgroup ids go round-robin over the 8 XCDs: give XCD x the contiguous run of tiles [x * per + min(x, rem), ...),
+    // column tile = id / tiles_m, so the row tiles of one column tile (one weight tile) are neighbours on one XCD.
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    const int tn = id / a.tiles_m, tm = id % a.tiles_m;
+    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
+    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    const int m0 = tm * kTM;
+    const int nt0 = (nt + 1) >> 1;
+    const int wn = w >> 2;
+    const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
+    using L = LinearFq8<FX, FW, NB>;
+    bool redo;
+    switch (ntw) {                                          // wave-uniform
+        case 0: redo = L::template run<0>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        case 1: redo = L::template run<1>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        case 2: redo = L::template run<2>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        case 3: redo = L::template run<3>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        case 4: redo = L::template run<4>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        case 5: redo = L::template run<5>(a, lds, m0, tg0, nt, jbase, w, l); break;
+        default: redo = L::template run<6>(a, lds, m0, tg0, nt, jbase, w, l); break;
+    }
+    if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+}
+
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+template <int FX, int FW, int NB>
+int launch_nb(const Args &a, hipStream_t st) {
+    constexpr int kLds = 2 * LinearFq8<FX, FW, NB>::kStage;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8_kernel<FX, FW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    linear_fq8_kernel<FX, FW, NB><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+template <int FX, int FW>
+int launch(const Args &a, hipStream_t st) {
+    if (a.nb <= 2) return launch_nb<FX, FW, 2>(a, st);
+    if (a.nb <= 4) return launch_nb<FX, FW, 4>(a, st);
+    return launch_nb<FX, FW, 6>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
+                       const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream) {
+    if (count < 1 || count > kMaxSeg || !w_devs || !ns) return QT_ERR_BAD_ARG;
+    if (x_format < 0 || x_format > 1 || w_format < 0 || w_format > 1) return QT_ERR_BAD_DTYPE;
+    long ntot = 0, groups = 0;
+    for (int i = 0; i < count; ++i) {
+        if (ns[i] < 0 || ns[i] % 16 != 0) return QT_ERR_BAD_ARG;
+        ntot += ns[i];
+    }
+    if ((long)M * ntot == 0) return QT_OK;
+    if (!x8_dev || !y_dev || M < 0 || K < kBK || K % kBK != 0 || ntot > (1L << 30)) return QT_ERR_BAD_ARG;
+    if (((uintptr_t)x8_dev & 15u) || ((uintptr_t)y_dev & 7u)) return QT_ERR_UNALIGNED;
+    for (int i = 0; i < count; ++i) {
+        if (ns[i] && (!w_devs[i] || ((uintptr_t)w_devs[i] & 15u))) return QT_ERR_UNALIGNED;
+        if (bias_devs && bias_devs[i] && ((uintptr_t)bias_devs[i] & 7u)) return QT_ERR_UNALIGNED;
+    }
+    groups = ntot / 16;
+    Args a{};
+    a.x8 = x8_dev; a.y = y_dev; a.M = M; a.K = K; a.ldc = (int)ntot;
+    a.tiles_m = (M + kTM - 1) / kTM;
+    // Column tiles: as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than kMaxNT groups;
+    // the weights are treated as one concatenated [sum n][K] matrix, a tile may span two of them.
+    const char *e_tn = getenv("QT_FQ8_TILES_N"), *e_nt = getenv("QT_FQ8_MAX_NT"), *e_dbg = getenv("QT_FQ8_DEBUG");   // tuning / A-B switches
+    const int force_tn = e_tn ? atoi(e_tn) : 0;
+    int max_nt = e_nt ? atoi(e_nt) : kMaxNT;
+    if (max_nt < 1 || max_nt > kMaxNT) max_nt = kMaxNT;
+    const int cus = cu_count();
+    const long tn_min = (groups + max_nt - 1) / max_nt;
+    const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
+    long tn = rounds * cus / a.tiles_m;
+    if (force_tn > 0) tn = force_tn;
+    if (tn < tn_min) tn = tn_min;
+    if (tn > groups) tn = groups;
+    a.tiles_n = (int)tn;
+    a.gbase = (int)(groups / tn);
+    a.gextra = (int)(groups % tn);
+    const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
+    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
+    a.nb = (worst_nt * 4 + 7) / 8;
+    a.dbg = e_dbg ? atoi(e_dbg) : 0;
+    int nseg = 0, g0 = 0;
+    for (int i = 0; i < count; ++i) {
+        if (ns[i] == 0) continue;
+        a.seg[nseg].w = w_devs[i];
+        a.seg[nseg].bias = bias_devs ? bias_devs[i] : nullptr;
+        a.seg[nseg].g0 = g0;
+        g0 += ns[i] / 16;
+        ++nseg;
+    }
+    a.nseg = nseg;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_format == 0 && w_format == 0) return launch<0, 0>(a, st);
+    if (x_format == 1 && w_format == 1) return launch<1, 1>(a, st);
+    if (x_format == 0 && w_format == 1) return launch<0, 1>(a, st);
+    if (x_format == 1 && w_format == 0) return launch<1, 0>(a, st);
+    return QT_ERR_BAD_DTYPE;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libqt_hip.so")
 
 QT_MAP_ENTRIES = 65536
 QT_FMT_LUT, QT_FMT_IDENTITY, QT_FMT_FP_SAT, QT_FMT_INT = 0, 1, 2, 3
-QT_ERR_BAD_DTYPE = -1
+QT_ERR_BAD_DTYPE, QT_ERR_BAD_ARG, QT_ERR_UNALIGNED, QT_ERR_NO_DEVICE = -1, -2, -3, -4
 
 
 class QtFormat(ctypes.Structure):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
+    "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
                                _OPQ, _OPQ, _P]),
     "qt_softmax_fq_bf16": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P,
@@ -98,6 +99,40 @@ SIGNATURES = {
 }
 
 _lib = None
+_PENDING = {"device": None, "multi": None}
+
+
+def note_device(index):
+    """Called by the launch helpers with the device ordinal of the tensors about to be handed to a kernel: the next
+    native call runs with that device current (the C ABI takes raw pointers and a stream and launches on the calling
+    thread's current device; hipBLASLt handles are per device as well).  Free when the process sees one GPU."""
+    _PENDING["device"] = index
+
+
+class _GuardedLib:
+    """The ctypes library with every entry point wrapped in a device guard (see note_device)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name in SIGNATURES:
+            setattr(self, name, self._guard(getattr(cdll, name)))
+
+    @staticmethod
+    def _guard(fn):
+        def call(*args):
+            idx = _PENDING["device"]
+            if idx is None:
+                return fn(*args)
+            _PENDING["device"] = None
+            import torch
+            if _PENDING["multi"] is None:
+                _PENDING["multi"] = torch.cuda.device_count() > 1
+            if not _PENDING["multi"] or idx == torch.cuda.current_device():
+                return fn(*args)
+            with torch.cuda.device(idx):
+                return fn(*args)
+        call.__name__ = getattr(fn, "__name__", "native")
+        return call
 
 
 def lib():
@@ -115,7 +150,7 @@ def lib():
             fn.argtypes = args
         if L.qt_abi_version() != 1:
             raise QtError("libqt_hip.so ABI version mismatch")
-        _lib = L
+        _lib = _GuardedLib(L)
     return _lib
 
 

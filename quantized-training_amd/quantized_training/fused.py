@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _native
-from .fake_quantize import (STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr,
+from .fake_quantize import (STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr, handover_valid,
                             launch_scale_update)
 from .quantizer.quantizer import QScheme
 
@@ -23,6 +23,46 @@ def fused_gemm_enabled():
 
 def fp8_gemm_enabled():
     return os.environ.get("QT_FP8_GEMM", "1") != "0"
+
+
+def fq8_gemm_enabled():
+    """Hand-written FP8 GEMM with the weight fake-quantizer fused into its operand path (qt_linear_fq8_bf16) instead of
+    the weight pass + library GEMM pair."""
+    return os.environ.get("QT_FQ8_GEMM", "0") == "1"
+
+
+_F8_CODE = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}
+
+
+def hip_fq8_linear_or_none(x8, layers):
+    """y[.., sum N] = x . [fq(W_0); fq(W_1); ...]^T + bias through qt_linear_fq8_bf16: x8 holds the FP8 codes of the already
+    fake-quantized activation, the bf16 weights of `layers` (QAT Linears that share it, stateless FP8 weight fake-quantizers
+    of one format) are converted inside the kernel.  None when the kernel does not take the problem."""
+    K = x8.shape[-1]
+    if x8.dtype not in _F8_CODE or K % 128 != 0 or not x8.is_contiguous() or x8.data_ptr() % 16 or not 1 <= len(layers) <= 4:
+        return None
+    wf = layers[0].weight_fake_quant._qt_format
+    for l in layers:
+        W, f = l.weight, l.weight_fake_quant._qt_format
+        if (W.dtype != torch.bfloat16 or not W.is_contiguous() or W.shape[1] != K or W.shape[0] % 16 or W.data_ptr() % 16
+                or W.device != x8.device or f.key() != wf.key()):
+            return None
+        if l.bias is not None and (l.bias.dtype != torch.bfloat16 or not l.bias.is_contiguous() or l.bias.data_ptr() % 8
+                                   or l.bias.device != x8.device):
+            return None
+    n = len(layers)
+    M = x8.numel() // K
+    ns = [l.weight.shape[0] for l in layers]
+    y = torch.empty((M, sum(ns)), dtype=torch.bfloat16, device=x8.device)
+    wp = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
+    bp = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
+    nn = (ctypes.c_int * n)(*ns)
+    rc = _native.lib().qt_linear_fq8_bf16(x8.data_ptr(), _F8_CODE[x8.dtype], wp, bp, nn, n, 1 if wf.p0 == 2 else 0, y.data_ptr(),
+                                           M, K, _stream_ptr(x8))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
+        return None
+    _native.check(rc, "qt_linear_fq8_bf16")
+    return y
 
 
 def mark_fp8_producer(consumer, act_fq):
@@ -233,6 +273,14 @@ def _sibling_linear_or_none(layer, x, x8):
     K = layer.weight.shape[1]
     total = sum(Ns)
     dev = x.device
+    n = len(group.layers)
+    if fq8_gemm_enabled():
+        layer.weight_fake_quant._move_to(dev)
+        y = hip_fq8_linear_or_none(x8.reshape(-1, K), group.layers)
+        if y is not None:
+            STATS.add(layer.weight.numel())
+            group.stash = (key, y, [True] + [False] * (n - 1))
+            return y[:, :Ns[0]].reshape(*x.shape[:-1], Ns[0])
     if group.buf is None or group.buf.device != dev or group.buf.shape != (total, K):
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -240,7 +288,6 @@ def _sibling_linear_or_none(layer, x, x8):
     fq = layer.weight_fake_quant
     fq._move_to(dev)
     L = _native.lib()
-    n = len(group.layers)
     xs = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in group.layers])
     ns = (ctypes.c_size_t * n)(*[l.weight.numel() for l in group.layers])
     _native.check(L.qt_fake_quant_bf16_fp8_multi(xs, ns, n, group.buf.data_ptr(), ctypes.byref(fq._qt_format),
@@ -263,7 +310,7 @@ def fp8_linear_or_none(layer, x):
     4 and nothing for the GEMM to re-read in bf16), and the products q_x * q_w are exactly the
     reference's bf16 products; fp32 accumulation, bf16 output.  Library FP8 GEMM (hipBLASLt through
     torch._scaled_mm) -- a plain GEMM on already-quantized operands."""
-    x8 = getattr(x, "_qt_fp8", None)
+    x8 = getattr(x, "_qt_fp8", None) if handover_valid(x) else None
     fq = layer.weight_fake_quant
     if x8 is None or not fp8_gemm_enabled() or not isinstance(fq, FusedAmaxObsFakeQuantize) or not fq.fp8_exact():
         return None
@@ -279,6 +326,11 @@ def fp8_linear_or_none(layer, x):
     shared = _sibling_linear_or_none(layer, x, x8)
     if shared is not None:
         return shared
+    if fq8_gemm_enabled() and not prefetch_enabled() and not _WEIGHT_CACHE["on"]:
+        y = hip_fq8_linear_or_none(x8.reshape(-1, K), [layer])
+        if y is not None:
+            STATS.add(W.numel())                   # the weight's fake-quant call, computed inside the GEMM
+            return y.reshape(*x.shape[:-1], W.shape[0])
     pf = _PREFETCH if prefetch_enabled() else None
     slot = None
     w8 = None
@@ -512,7 +564,7 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
         return None
     if (B * H, Q, C, D) in _LT.setdefault("no_pv", set()):
         return None                            # the library had no kernel for this problem last time
-    done = getattr(value, "_qt_fq_done_by", None)
+    done = getattr(value, "_qt_fq_done_by", None) if handover_valid(value) else None
     v8 = getattr(value, "_qt_fp8", None)
     if not (done is fq_v and v8 is not None and value.is_contiguous()):
         vq = torch.empty((B, H, C, D), dtype=torch.bfloat16, device=value.device)

@@ -61,6 +61,7 @@ def rmsnorm_fq(x, weight, eps, fq):
                                                     _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
     y._qt_fp8 = _fp8_view(y8, fq)
     y._qt_fq_done_by = fq
+    y._qt_ver = y._version
     return y
 
 
@@ -79,6 +80,7 @@ def add_rmsnorm(x, residual, norm, fq=None):
     if fq is not None:
         y._qt_fp8 = _fp8_view(y8, fq)
         y._qt_fq_done_by = fq
+        y._qt_ver = y._version
     return total, y
 
 
@@ -166,6 +168,7 @@ def silu_mul_fq(gate, up, fq):
                   "qt_silu_mul_fq8_bf16")
     y._qt_fp8 = _fp8_view(y8, fq)
     y._qt_fq_done_by = fq
+    y._qt_ver = y._version
     return y
 
 
@@ -234,9 +237,13 @@ def rope_fq(q, k, cos, sin, fq_q, fq_k):
                                                 Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fq_q._qt_format),
                                                 ctypes.byref(fq_k._qt_format), _stream_ptr(q)), "qt_rope_fq_bf16")
     q_out._qt_fq_done_by = fq_q
+    q_out._qt_ver = q_out._version
     k_out._qt_fq_done_by = fq_k
+    k_out._qt_ver = k_out._version
     q_out._qt_fp8 = _fp8_view(q8, fq_q)                 # Q.K^T can then run as an FP8 GEMM (functional_modules.py)
+    q_out._qt_ver = q_out._version
     k_out._qt_fp8 = _fp8_view(k8, fq_k)
+    k_out._qt_ver = k_out._version
     return q_out, k_out
 
 
@@ -273,6 +280,7 @@ def gelu(x, fq=None):
     if fq is not None:
         y._qt_fp8 = _fp8_view(y8, fq)
         y._qt_fq_done_by = fq
+        y._qt_ver = y._version
     return y
 
 

@@ -60,6 +60,25 @@ def _additive_mask(mask, dtype):
     return add
 
 
+_CAUSAL = {}
+
+
+def _causal_mask(q_len, k_len, dtype, device):
+    """Additive causal mask [1, 1, q_len, k_len] (query i sees keys <= i + k_len - q_len).  HF's default (sdpa) mask
+    preparation hands the attention block `attention_mask=None` for unpadded batches and expects the kernel to apply
+    `is_causal` itself (`_ignore_causal_mask_sdpa`); the quantizable path adds masks to the scores like the upstream
+    blocks do (modeling_llama.py:228-246 upstream), so it has to build that mask -- without it a model loaded the
+    usual way would attend bidirectionally."""
+    key = (q_len, k_len, dtype, str(device))
+    m = _CAUSAL.get(key)
+    if m is None:
+        if len(_CAUSAL) > 16:
+            _CAUSAL.clear()
+        m = torch.full((q_len, k_len), torch.finfo(dtype).min, dtype=dtype, device=device).triu(k_len - q_len + 1)[None, None]
+        _CAUSAL[key] = m
+    return m
+
+
 def quantizable_attention_forward(module, query, key, value, attention_mask, scaling=None, dropout=0.0, **kwargs):
     """Drop-in for HF's ``eager_attention_forward`` that goes through the module's hookable ops:
     ``av_matmul(softmax(attn_scaling(qk_matmul(q, k^T), scale) + mask), v)``."""
@@ -69,12 +88,18 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     if scaling is None:
         scaling = query.size(-1) ** -0.5
     attention_mask = _additive_mask(attention_mask, query.dtype)
+    causal = kwargs.get("is_causal")
+    if causal is None:
+        causal = getattr(module, "is_causal", False)
+    if attention_mask is None and query.shape[2] > 1 and causal:
+        attention_mask = _causal_mask(query.shape[2], key.shape[2], query.dtype, query.device)
     from ...fused import fused_attention_or_none, fused_scores_to_probs_or_none
     core = fused_attention_or_none(module, query, key, value, attention_mask, scaling, dropout)
     if core is not None:
         return core, None                      # probabilities are never materialised on this path
     key_t = key.transpose(2, 3)
-    if getattr(key, "_qt_fq_done_by", None) is not None:
+    if getattr(key, "_qt_fq_done_by", None) is not None and getattr(key, "_qt_ver", None) == key._version:
+        key_t._qt_ver = key._qt_ver                          # a view shares the version counter
         key_t._qt_fq_done_by = key._qt_fq_done_by          # fake-quant is elementwise: done for K means done for K^T
         if getattr(key, "_qt_fp8", None) is not None:
             key_t._qt_fp8_of_transpose = key._qt_fp8        # FP8 code of K itself ([B, H, S, D], contiguous)

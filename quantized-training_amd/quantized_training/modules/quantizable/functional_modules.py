@@ -38,7 +38,8 @@ class MatmulFunctional(_BinaryOp):
         # Q . K^T with both operands already fake-quantized to exact FP8 values by the kernel that produced them
         # (model_fusions.rope_fq): the same products on the FP8 matrix cores.  The input hooks have run by now.
         q8, k8 = getattr(lhs, "_qt_fp8", None), getattr(rhs, "_qt_fp8_of_transpose", None)
-        if (q8 is not None and k8 is not None and os.environ.get("QT_FP8_ATTENTION", "1") != "0" and lhs.dim() == 4
+        fresh = getattr(lhs, "_qt_ver", None) == lhs._version and getattr(rhs, "_qt_ver", None) == rhs._version
+        if (q8 is not None and k8 is not None and fresh and os.environ.get("QT_FP8_ATTENTION", "1") != "0" and lhs.dim() == 4
                 and q8.shape == lhs.shape and k8.shape[:2] == lhs.shape[:2] and k8.shape[-1] == lhs.shape[-1]
                 and not (torch.is_grad_enabled() and (lhs.requires_grad or rhs.requires_grad))):
             from ...fused import lt_fp8_gemm

@@ -1225,3 +1225,126 @@ def test_add_rmsnorm_equals_add_then_rmsnorm(nv):
                 assert torch.equal(total2.view(torch.int16), want_sum.view(torch.int16))
                 assert torch.equal(yq.view(torch.int16), ref.view(torch.int16))
                 assert torch.equal(yq._qt_fp8.view(torch.uint8), ref._qt_fp8.view(torch.uint8)) and fq(yq) is yq
+
+
+# ---- qt_linear_fq8_bf16: FP8 GEMM with the weight fake-quantizer fused into its operand path ------------------------
+F8_CODE = {"e4m3": 0, "e5m2": 1}
+F8_TORCH = {"e4m3": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}
+
+
+def _codes_of(nv, t, dtype):
+    """FP8 codes of fq(t) from the (oracle-pinned) elementwise pass, as a uint8 device tensor."""
+    fmt = nv.format_for(dtype)
+    y8 = torch.empty(t.shape, dtype=torch.uint8, device="cuda")
+    one = torch.ones((), dtype=torch.float32, device="cuda")
+    nv.check(nv.lib().qt_fake_quant_bf16_fp8(t.data_ptr(), None, y8.data_ptr(), t.numel(), ctypes.byref(fmt), one.data_ptr(), None,
+                                             stream()), "fq8")
+    return y8
+
+
+def _linear_fq8(nv, x8, xdtype, ws, wdtype, biases=None):
+    M, K = x8.shape
+    n = len(ws)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in (biases or [None] * n)])
+    ns = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
+    y = torch.empty((M, sum(w.shape[0] for w in ws)), dtype=torch.bfloat16, device="cuda")
+    nv.check(nv.lib().qt_linear_fq8_bf16(x8.data_ptr(), F8_CODE[xdtype], wp, bp, ns, n, F8_CODE[wdtype], y.data_ptr(), M, K,
+                                         stream()), "qt_linear_fq8_bf16")
+    return y
+
+
+@pytest.mark.parametrize("xdtype,wdtype", [("e4m3", "e4m3"), ("e5m2", "e5m2"), ("e4m3", "e5m2"), ("e5m2", "e4m3")])
+def test_linear_fq8_weight_codes_are_the_value_map(nv, xdtype, wdtype):
+    """Identity activation: y[m][n] = fq(W)[n][m] -- one product per output, so the kernel's in-flight conversion of W is
+    compared bit for bit with the oracle's value map on ALL 65 536 bf16 patterns (rows 0..127 of W), overflowing values
+    included (the reference saturates, fp8.py:32); rows holding +-Inf / NaN must come out all-NaN (fp8.py:36 and 0 * NaN)."""
+    K = 512
+    torch.manual_seed(1)
+    W = (torch.randn(400, K, device="cuda") * 3).bfloat16()
+    W.view(torch.int16)[:128] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16).view(128, 512)
+    x8 = _codes_of(nv, torch.eye(K, device="cuda").bfloat16(), xdtype)
+    qmap = o.get_quantization_map(wdtype)
+    bias = torch.randn(400, device="cuda").bfloat16()
+    for sanitize in (True, False):
+        Wt = W.clone()
+        if sanitize:
+            Wt[~torch.isfinite(Wt.float())] = 0
+        exp = o.canon_nan16(o.vmap_bf16(host_u16(Wt.view(torch.int16)), qmap)).reshape(400, K)
+        got = o.canon_nan16(host_u16(_linear_fq8(nv, x8, xdtype, [Wt], wdtype).t().contiguous().view(torch.int16)))
+        nan_rows = (exp == 0x7FC0).any(axis=1)
+        assert nan_rows.sum() == (0 if sanitize else 2)
+        same = (got == exp) | (((got | exp) & 0x7FFF) == 0)                 # the sign of a zero is not part of a product
+        assert same[~nan_rows].all()
+        assert (got[nan_rows] == 0x7FC0).all()
+        gotb = _linear_fq8(nv, x8, xdtype, [Wt], wdtype, [bias]).t().contiguous()
+        expb = (torch.from_numpy(o.bf16_to_f32(exp)).cuda() + bias.float()[:, None]).bfloat16()
+        assert torch.equal(gotb[~torch.from_numpy(nan_rows).cuda()].view(torch.int16), expb[~torch.from_numpy(nan_rows).cuda()].view(torch.int16))
+
+
+@pytest.mark.parametrize("M,Ns,K", [(1024, [4096], 1024), (1024, [176], 256), (300, [48, 64, 16], 384), (1, [16], 128),
+                                    (777, [2048, 512, 512], 512), (520, [11008], 256), (257, [208, 4096 - 208], 128)])
+@pytest.mark.parametrize("xdtype,wdtype", [("e4m3", "e4m3"), ("e5m2", "e4m3")])
+def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
+    """Ragged M, column tiles spanning two weights, several weights per launch, bias: against the fp64 product of the
+    oracle-quantized operands.  Tolerance: one bf16 rounding of the result (2^-8 relative) plus the scaled matrix
+    instruction's accumulation error, measured <= 2^-16 sum |a||b| (bound used: 2^-14)."""
+    torch.manual_seed(0)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    ws = [(torch.randn(n, K, device="cuda") * 0.05).bfloat16() for n in Ns]
+    bs = [torch.randn(n, device="cuda").bfloat16() if i % 2 == 0 else None for i, n in enumerate(Ns)]
+    x8 = _codes_of(nv, x, xdtype)
+    y = _linear_fq8(nv, x8, xdtype, ws, wdtype, bs).double()
+    qx, qw = o.get_quantization_map(xdtype), o.get_quantization_map(wdtype)
+    xa = torch.from_numpy(o.bf16_to_f32(o.vmap_bf16(host_u16(x.view(torch.int16)), qx))).cuda().double()
+    wa = torch.cat([torch.from_numpy(o.bf16_to_f32(o.vmap_bf16(host_u16(w.view(torch.int16)), qw))).cuda().double() for w in ws])
+    bias = torch.cat([b.double() if b is not None else torch.zeros(n, device="cuda", dtype=torch.float64) for b, n in zip(bs, Ns)])
+    ref = xa @ wa.t() + bias
+    tol = ref.abs() * 2.0 ** -8 + (xa.abs() @ wa.abs().t()) * 2.0 ** -14 + 1e-30
+    assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
+
+
+def test_linear_fq8_rejects_what_it_does_not_take(nv):
+    x8 = torch.zeros(16, 192, dtype=torch.uint8, device="cuda")
+    w = torch.zeros(32, 192, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty(16, 32, dtype=torch.bfloat16, device="cuda")
+    wp, ns = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_int * 1)(32)
+    L = nv.lib()
+    assert L.qt_linear_fq8_bf16(x8.data_ptr(), 0, wp, None, ns, 1, 0, y.data_ptr(), 16, 192, stream()) == nv.QT_ERR_BAD_ARG   # K % 128
+    ns2 = (ctypes.c_int * 1)(24)
+    assert L.qt_linear_fq8_bf16(x8.data_ptr(), 0, wp, None, ns2, 1, 0, y.data_ptr(), 16, 128, stream()) == nv.QT_ERR_BAD_ARG  # n % 16
+    assert L.qt_linear_fq8_bf16(x8.data_ptr(), 2, wp, None, ns, 1, 0, y.data_ptr(), 16, 128, stream()) == nv.QT_ERR_BAD_DTYPE
+    assert L.qt_linear_fq8_bf16(x8.data_ptr(), 0, wp, None, ns, 1, 0, y.data_ptr(), 0, 128, stream()) == 0                    # empty
+
+
+def test_fq8_route_through_quantize(nv, monkeypatch):
+    """QT_FQ8_GEMM=1: the QAT Linears of a quantize()d model (single layers and a q / k / v sibling group) run the fused
+    kernel; logits equal the default route's within the accumulation bound, element counts are identical."""
+    import quantized_training as qt
+    from quantized_training import fake_quantize
+    torch.manual_seed(0)
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v = (torch.nn.Linear(256, 128, bias=True) for _ in range(3))
+            self.o = torch.nn.Linear(128, 256, bias=False)
+
+        def forward(self, x):
+            return self.o(self.q(x) * self.k(x) + self.v(x))
+
+    model = Block().cuda().bfloat16()
+    args = qt.add_qspec_args().parse_args(["--activation", "e4m3", "--weight", "e4m3", "--bf16"])
+    qt.quantize(model, args)
+    x = torch.randn(3, 70, 256, device="cuda").bfloat16()
+    outs, counts = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QT_FQ8_GEMM", mode)
+        with torch.no_grad():
+            model(x)                                                       # creates the activation fake-quantizers
+            fake_quantize.STATS.reset()
+            outs[mode] = model(x).double()
+            counts[mode] = (fake_quantize.STATS.elements, fake_quantize.STATS.calls)
+    assert counts["0"] == counts["1"]
+    scale = outs["0"].abs().max()
+    assert float((outs["0"] - outs["1"]).abs().max()) <= 2.0 ** -6 * float(scale)

@@ -163,3 +163,27 @@ def test_llama_attention_twin_and_training_backward_hooks():
     g = m.model.layers[0].self_attn.q_proj.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
     assert float(mods["model.layers.0.self_attn.q_proj.error_pre_process.0"].amax_history[0]) > 0
+
+
+def test_llama_default_attention_stays_causal_after_quantize():
+    """A LLaMA built the usual way (HF's default attention implementation, sdpa) hands the attention block
+    `attention_mask=None` for unpadded batches and relies on the kernel's `is_causal`; the quantizable path must apply
+    the causal mask itself.  With nothing quantized the converted model equals the float model, and logits at position
+    t do not move when later tokens change."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=100, max_position_embeddings=64)
+    m = LlamaForCausalLM(cfg).eval()                      # no attn_implementation="eager"
+    ids = torch.randint(3, 100, (2, 12), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = m(ids).logits
+    qt.quantize(m, _args())
+    with torch.no_grad():
+        out = m(ids).logits
+        ids2 = ids.clone()
+        ids2[:, -1] = (ids2[:, -1] + 7) % 97 + 3
+        out2 = m(ids2).logits
+    assert float((out - ref).abs().max()) < 1e-5
+    assert float((out2[:, :-1] - out[:, :-1]).abs().max()) < 1e-6
+    assert float((out2[:, -1] - out[:, -1]).abs().max()) > 1e-4
