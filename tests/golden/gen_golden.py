@@ -24,6 +24,9 @@ Outputs (all data, no reference source text):
                     (quantize.py:52-193)
   wikitext_windows.json
                     sliding-window schedule of examples/language_modeling/wikitext.py:143-165
+  blocks.*, qa_logits.*, fq_extra.*, checkpoint.*
+                    upstream's quantizable BERT / MobileBERT twins, QA-loop logits, histogram / outlier options and a
+                    calibrated state_dict: see gen_golden_blocks.py
 """
 import argparse
 import hashlib
@@ -851,6 +854,13 @@ def main():
         "spec": lambda: gen_spec(ref, a.out),
         "windows": lambda: gen_windows(a.out),
     }
+    import gen_golden_blocks as gb           # upstream's BERT / MobileBERT twins, QA logits, histogram / outlier, checkpoint
+    steps.update({
+        "blocks": lambda: gb.gen_blocks(ref, a.out),
+        "qa_logits": lambda: gb.gen_qa_logits(ref, a.out),
+        "fq_extra": lambda: gb.gen_fq_extra(ref, a.out),
+        "checkpoint": lambda: gb.gen_checkpoint(ref, a.out),
+    })
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):
             continue
