@@ -58,54 +58,97 @@ def parse():
                     help="debug: initialise torch.distributed (nccl) and take the multi-rank code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU: tiny LLaMA on the CPU, gloo instead of RCCL, same sharding / timing / "
+                         "gather code (the line is marked invalid)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py launches its own ranks")
     return ap.parse_args()
 
 
-def roofline_leg(device):
-    """Dominant kernel of the window (top row of profiles/*_bench_kernel_stats.csv): the weight pass of the FP8 GEMM
-    route, `fq8_kernel` with FP8-only output, on a 4096 x 11008 bf16 tensor (LLaMA-2-7B gate/up/down weight).
-    Algorithmic bytes of THIS variant: 3 B/element (2 read as bf16 + 1 written as the FP8 code) -- less than
-    SURVEY 8(d)'s 4 B/element because the bf16 copy of the quantized weight is never needed.  The bf16 -> bf16 pass
-    (4 B/element, every other spec) is timed next to it and reported under "bf16_out"."""
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (nothing
+    in this process has touched the GPU yet -- a process that has must never be replaced by another program) and pass
+    its exit code on.  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    port = a.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def profiled_traffic(key):
+    """HBM bytes per launch of the roofline kernels from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE x 2 on gfx950 as the microarchitecture guide prescribes).  Collected by
+    tools/gpu_session_prof.sh on the same launch, NOT in this run: the JSON names the file next to the number."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                node = json.load(open(path))
+                for part in key:
+                    node = node[part]
+                return node, "profiles/" + name
+            except Exception:  # noqa: BLE001
+                continue
+    return None, None
+
+
+def roofline_leg(device, weight_dtype="e4m3", model_shape=(4096, 11008)):
+    """Dominant kernel of the window (top row of profiles/*_bench_kernel_stats.csv): the weight pass on a gate / up / down
+    weight of the model (bf16 [hidden, intermediate]; 4096 x 11008 for LLaMA-2-7B).
+      * e4m3 / e5m2 without `qs` (the FP8 GEMM route): `fq8_kernel` with FP8-only output; algorithmic bytes 3 B/element
+        (2 read as bf16 + 1 written as the FP8 code) -- less than SURVEY 8(d)'s 4 B/element because the bf16 copy of the
+        quantized weight is never needed.  The bf16 -> bf16 pass (4 B/element) is timed next to it ("bf16_out").
+      * every other dtype (posit(8,2) of BASELINE config 4, ...): the bf16 -> bf16 pass with the value map staged in LDS,
+        4 B/element."""
     from quantized_training import _native as nv
     import quantized_training as qt
     L = nv.lib()
-    rows, cols, pool = 4096, 11008, 8                       # 8 x 90 MB in + 8 x 90 MB out = 1.44 GB
+    rows, cols, pool = model_shape[0], model_shape[1], 8    # 7B: 8 x 90 MB in + 8 x 90 MB out = 1.44 GB, beyond the Infinity Cache
     n = rows * cols
     x = torch.empty(pool, rows, cols, device=device, dtype=torch.bfloat16).normal_(0.0, 0.02)
     y = torch.empty_like(x)
-    y8 = torch.empty(pool, rows, cols, device=device, dtype=torch.uint8)
-    fmt = nv.format_for("e4m3")
-    lut = qt.get_quantization_map("e4m3", device)
+    base = weight_dtype.split(",")[0]
+    fmt = nv.format_for(base)
+    lut = qt.get_quantization_map(base, device)
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    fp8_route = base in ("e4m3", "e5m2") and "qs=" not in weight_dtype
     ms, ms8 = ctypes.c_float(0.0), ctypes.c_float(0.0)
+    y8 = torch.empty(pool, rows, cols, device=device, dtype=torch.uint8) if fp8_route else None
     for iters in (pool, 5 * pool):                           # warm-up pass, then the timed region
         nv.check(L.qt_bench_fake_quant_bf16(x.data_ptr(), y.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(),
                                             None, None, iters, n, pool, st, ctypes.byref(ms)), "bench")
-        nv.check(L.qt_bench_fake_quant_bf16_fp8(x.data_ptr(), None, y8.data_ptr(), n, ctypes.byref(fmt), None, None,
-                                                iters, n, pool, st, ctypes.byref(ms8)), "bench fp8")
-    achieved8 = n * 3 / (ms8.value * 1e-3) / 1e9
+        if fp8_route:
+            nv.check(L.qt_bench_fake_quant_bf16_fp8(x.data_ptr(), None, y8.data_ptr(), n, ctypes.byref(fmt), None, None,
+                                                    iters, n, pool, st, ctypes.byref(ms8)), "bench fp8")
     achieved = n * 4 / (ms.value * 1e-3) / 1e9
-    traffic = traffic_bf16 = None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            pj = json.load(open(prof))
-            traffic = pj.get("fp8_only", {}).get("hbm_bytes_per_launch")
-            traffic_bf16 = pj.get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            pass
+    shape = f"{rows}x{cols}"
     del x, y, y8
     torch.cuda.empty_cache()
-    gemm = gemm_leg(device)
+    is_7b = (rows, cols) == (4096, 11008)
+    t4, src4 = profiled_traffic(("hbm_bytes_per_launch",)) if (is_7b and base == "e4m3") else (None, None)
+    bf16_out = {"kernel": f"fq_kernel<bf16> {base} {shape} ({'closed form' if fmt.kind != nv.QT_FMT_LUT else 'value map in LDS'})",
+                "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4), "ms_per_launch": round(ms.value, 5),
+                "algorithmic_bytes_per_launch": n * 4, "traffic": t4, "traffic_source": src4}
+    if not fp8_route:
+        out = {"bound": "hbm", "achieved": bf16_out["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bf16_out["frac"],
+               "traffic": t4, "traffic_source": src4, "kernel": bf16_out["kernel"] + " (weight pass, bf16 GEMM route)",
+               "ms_per_launch": bf16_out["ms_per_launch"], "algorithmic_bytes_per_launch": n * 4}
+        return out
+    achieved8 = n * 3 / (ms8.value * 1e-3) / 1e9
+    t3, src3 = profiled_traffic(("fp8_only", "hbm_bytes_per_launch")) if (is_7b and base == "e4m3") else (None, None)
     return {"bound": "hbm", "achieved": round(achieved8, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved8 / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "kernel": "fq8_kernel<obs off, fp8 only> e4m3 4096x11008 (weight pass of the FP8 GEMM route)",
+            "frac": round(achieved8 / HBM_PEAK_GBPS, 4), "traffic": t3, "traffic_source": src3,
+            "kernel": f"fq8_kernel<obs off, fp8 only> {base} {shape} (weight pass of the FP8 GEMM route)",
             "ms_per_launch": round(ms8.value, 5), "algorithmic_bytes_per_launch": n * 3,
-            "bf16_out": {"kernel": "fq_kernel<bf16,FP_SAT> e4m3 4096x11008", "achieved": round(achieved, 1),
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "ms_per_launch": round(ms.value, 5),
-                         "algorithmic_bytes_per_launch": n * 4, "traffic": traffic_bf16},
-            "gemm": gemm}
+            "bf16_out": bf16_out, "gemm": gemm_leg(device)}
 
 
 def gemm_leg(device):
@@ -163,24 +206,41 @@ def cpu_baseline_leg():
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:      # decided before anything initialises the GPU
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if a.gpus != world:
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     multi = world > 1 or a.force_dist
-    if multi:
-        dist.init_process_group("nccl", device_id=device)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.dry_run:
+        device = torch.device("cpu")
+        a.model, a.max_length, a.stride, a.no_graph, a.no_roofline, a.no_cpu_baseline = "llama-tiny", 64, 32, True, True, True
+        if multi:
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            print("[bench] no GPU visible (use --dry-run for the CPU plumbing check)", file=sys.stderr)
+            sys.exit(3)
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        if multi:
+            dist.init_process_group("nccl", device_id=device)
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
     import quantized_training as qt
     from quantized_training import harness
     from quantized_training.fake_quantize import STATS
 
-    model = harness.build_causal_lm(a.model, device=device, seed=0, num_layers=a.layers)
-    qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--bf16",
-                                            "--quantize_forward", "gemm"])
+    model = harness.build_causal_lm(a.model, device=device, seed=0, num_layers=a.layers,
+                                    dtype=torch.float32 if a.dry_run else torch.bfloat16)
+    qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--quantize_forward", "gemm"]
+                                           + ([] if a.dry_run else ["--bf16"]))
     qt.quantize(model, qargs)
     if a.cache_eval_weights:
         model.eval()
@@ -202,7 +262,7 @@ def main():
             harness.window_nll(model, *batches[min(i, need - 1)])
         STATS.reset()
         harness.window_nll(model, *batches[0])
-        torch.cuda.synchronize()
+        sync()
         elems_per_step = STATS.elements
         calls_per_step = STATS.calls
         # The whole window forward is launch-bound on the host (~2 500 small launches), and nothing in
@@ -228,14 +288,14 @@ def main():
             run_window(*batches[i])
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for i in range(a.steps):
             nlls.append(run_window(*batches[a.warmup + i]).clone())
-        torch.cuda.synchronize()
+        sync()
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
     t = torch.tensor([el], device=device, dtype=torch.float64)
     if multi:
@@ -248,6 +308,7 @@ def main():
     if rank == 0:
         total_elems = elems_per_step * a.steps * world
         hidden, layers = model.config.hidden_size, model.config.num_hidden_layers
+        model_shape = (model.config.hidden_size, model.config.intermediate_size)
         full = a.layers is None
         out = {
             "metric": "quantized_elements_per_sec",
@@ -256,7 +317,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "f32" if a.dry_run else "bf16", "data": "synthetic",
             "config": {"workload": f"{a.model}-shaped LLaMA ({layers} layers, hidden {hidden}, random init) "
                                    f"WikiText-style window eval B=1 S={a.max_length} stride {a.stride}, "
                                    f"fake-quant activation={a.activation} weight={a.weight}, --quantize_forward gemm "
@@ -265,14 +326,15 @@ def main():
                        "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
                        "launch": "hipGraph replay" if graph_used else "eager",
-                       "valid": bool(full) and not a.cache_eval_weights},
+                       "valid": bool(full) and not a.cache_eval_weights and not a.dry_run},
             "mean_window_nll": float(allnll.double().mean().item()),
         }
     if rank == 0:                                   # outside the timed region; the other ranks wait at the barrier below
         del model
-        torch.cuda.empty_cache()
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
         if not a.no_roofline:
-            out["roofline"] = roofline_leg(device)
+            out["roofline"] = roofline_leg(device, a.weight, model_shape)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
     if multi:

@@ -224,3 +224,27 @@ def test_eval_weight_cache_is_bit_identical_and_skips_the_weight_pass():
             assert STATS.elements == full
         finally:
             harness.cache_quantized_weights(False)
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (child process, before anything touches a GPU);
+    with --dry-run the same sharding / barrier / max-over-ranks timing / metric gather runs on the CPU over gloo and rank 0
+    prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["valid"] is False and out["config"]["parallelism"].startswith("dp2")
+    # a launcher that started a different number of ranks than --gpus says: clean non-zero exit, no traceback
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True, text=True,
+                        timeout=300, env=env2)
+    assert p2.returncode == 2 and "Traceback" not in p2.stderr
