@@ -86,6 +86,15 @@ int qt_round_fp8_f32(const float *x_dev, float *y_dev, size_t n, int mbits, floa
                      void *stream);
 int qt_round_posit_f32(const float *x_dev, float *y_dev, size_t n, int nbits, int es, void *stream);
 
+/* quantize_to_posit(input, nbits, es, round_to_even, return_pbits) with its two options (posit.py:6-67): round_to_even = 0
+ * keeps values below the smallest representable step at minpos instead of flushing them (posit.py:50-53); pbits (nullable,
+ * int32 per element) receives the posit bit pattern times the sign of the input (posit.py:60-65).  The pattern is the
+ * mathematically intended one where upstream's int32 arithmetic overflows (2 + run + es + 23 > 33) and, for regime-dominated
+ * inputs (whose pattern upstream leaves to platform-dependent shift counts), that of the value the input is clamped to. */
+int qt_posit_quantize_host(const float *x, float *y, int32_t *pbits, size_t n, int nbits, int es, int round_to_even);
+int qt_posit_quantize_f32(const float *x_dev, float *y_dev, int32_t *pbits_dev, size_t n, int nbits, int es, int round_to_even,
+                          void *stream);
+
 /* ---- A5: quantized_ops::vmap(Tensor self, Tensor other) -> Tensor   decomposed.py:143-163
  * y[i] = lut[idx(x[i])], idx = bf16 bits, or hi16(f32 bits) | (lo16 != 0) for fp32 / fp16
  * (fp16 goes through its fp32 image; the looked-up bf16 value is cast to the output dtype). */

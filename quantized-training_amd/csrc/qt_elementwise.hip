@@ -742,6 +742,15 @@ __global__ __launch_bounds__(256) void round_posit_kernel(const float *__restric
         y[i] = qt_u2f(qt_posit_u32(qt_f2u(x[i]), nbits, es, thr));
 }
 
+__global__ __launch_bounds__(256) void posit_bits_kernel(const float *__restrict__ x, float *__restrict__ y, int32_t *__restrict__ pbits,
+                                                        size_t n, int nbits, int es, float thr) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int32_t pb;
+        y[i] = qt_u2f(qt_posit_bits_u32(qt_f2u(x[i]), nbits, es, thr, &pb));
+        if (pbits) pbits[i] = pb;
+    }
+}
+
 // ---- launch helpers --------------------------------------------------------------------------
 int num_cus() {
     static int cus = 0;
@@ -1146,6 +1155,15 @@ int qt_round_posit_f32(const float *x, float *y, size_t n, int nbits, int es, vo
     if (!x || !y || nbits < 3 || nbits > 24 || es < 0 || es > 4 || ((nbits - 2) << es) > 126) return QT_ERR_BAD_ARG;
     unsigned grid = grid_for(n, 256 * 4, 8);
     round_posit_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, n, nbits, es, qt_internal_posit_threshold(nbits, es));
+    return launch_status();
+}
+
+int qt_posit_quantize_f32(const float *x, float *y, int32_t *pbits, size_t n, int nbits, int es, int round_to_even, void *stream) {
+    if (n == 0) return QT_OK;
+    if (!x || !y || nbits < 3 || nbits > 24 || es < 0 || es > 4 || ((nbits - 2) << es) > 126) return QT_ERR_BAD_ARG;
+    unsigned grid = grid_for(n, 256 * 4, 8);
+    posit_bits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, pbits, n, nbits, es,
+                                                          round_to_even ? qt_internal_posit_threshold(nbits, es) : 0.0f);
     return launch_status();
 }
 

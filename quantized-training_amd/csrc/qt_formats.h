@@ -102,6 +102,39 @@ QT_HD uint32_t qt_posit_u32(uint32_t raw, int nbits, int es, float thr) {
     return out | (raw & 0x80000000u);                            // :48
 }
 
+// Same rounding with the posit bit pattern next to the value (posit.py:60-65, `return_pbits=True`): the nbits-1 magnitude
+// bits of the encoding (regime | exponent | fraction after rounding) times the sign of the input, as an integer.  Upstream
+// builds the pattern in int32, which overflows once 2 + run + es + 23 > 33 and is shifted by platform-dependent amounts for
+// regime-dominated inputs; here the pattern is computed in 64 bits, regime-dominated magnitudes give the pattern of the
+// value they are clamped to (maxpos = 2^(nbits-1) - 1, minpos = 1, or 0 when flushed), +-Inf the maxpos pattern, NaN 0.
+// thr = 0 reproduces round_to_even=False (no flush of values below the smallest representable step, posit.py:50-53).
+QT_HD uint32_t qt_posit_bits_u32(uint32_t raw, int nbits, int es, float thr, int32_t *pbits) {
+    const uint32_t a = raw & 0x7FFFFFFFu;
+    const int32_t sgn = (raw >> 31) ? -1 : 1;
+    const int32_t maxpat = (int32_t)((1u << (nbits - 1)) - 1u);
+    if (a > 0x7F800000u) { *pbits = 0; return QT_NAN32; }
+    if (a == 0x7F800000u) { *pbits = sgn * maxpat; return QT_NAN32; }
+    if (a == 0u) { *pbits = 0; return 0u; }
+    const uint32_t out = qt_posit_u32(raw, nbits, es, thr);
+    const int scale = (int)(a >> 23) - 127;
+    const int max_scale = (nbits - 2) << es;
+    if (scale > max_scale || scale < -max_scale) {
+        *pbits = (out << 1) == 0u ? 0 : sgn * (scale > 0 ? maxpat : 1);
+        return out;
+    }
+    const bool r = scale >= 0;
+    const int k = scale >> es;
+    const int run = r ? 1 + k : -k;
+    const int sh = 2 + run + es + 23 - nbits;
+    const uint64_t regime = r ? ((((uint64_t)1 << (run + 1)) - 1) ^ 1) : 1;
+    const uint64_t pt = (regime << (23 + es)) | ((uint64_t)(scale & ((1 << es) - 1)) << 23) | (a & 0x7FFFFFu);
+    const uint32_t lb = (uint32_t)(pt >> sh) & 1u, gb = (uint32_t)(pt >> (sh - 1)) & 1u;
+    const uint32_t sb = (pt & (((uint64_t)1 << (sh - 1)) - 1)) != 0;
+    const int32_t body = (int32_t)((pt >> sh) & (uint64_t)maxpat) + (int32_t)((lb & gb) | (gb & sb));
+    *pbits = sgn * body;
+    return out;
+}
+
 QT_HD uint32_t qt_apply_format_img(const qt_format &f, uint32_t u) {
     switch (f.kind) {
         case QT_FMT_FP_SAT: return qt_fp_sat_u32(u, f.p0, f.p1, f.fhi);

@@ -247,6 +247,18 @@ int qt_round_posit_host(const float *x, float *y, size_t n, int nbits, int es) {
     return QT_OK;
 }
 
+int qt_posit_quantize_host(const float *x, float *y, int32_t *pbits, size_t n, int nbits, int es, int round_to_even) {
+    if ((!x || !y) && n) return QT_ERR_BAD_ARG;
+    if (nbits < 3 || nbits > 24 || es < 0 || es > 4 || ((nbits - 2) << es) > 126) return QT_ERR_BAD_ARG;
+    const float thr = round_to_even ? posit_threshold(nbits, es) : 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        int32_t pb;
+        y[i] = qt_u2f(qt_posit_bits_u32(qt_f2u(x[i]), nbits, es, thr, &pb));
+        if (pbits) pbits[i] = pb;
+    }
+    return QT_OK;
+}
+
 // helpers shared with the device half (qt_elementwise.hip)
 float qt_internal_posit_threshold(int nbits, int es) { return posit_threshold(nbits, es); }
 int qt_internal_fp8_emin(float fp8_min) { return fp8_emin(fp8_min); }

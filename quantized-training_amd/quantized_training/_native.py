@@ -47,6 +47,8 @@ SIGNATURES = {
     "qt_round_posit_host": (c_int, [_P, _P, c_size_t, c_int, c_int]),
     "qt_round_fp8_f32": (c_int, [_P, _P, c_size_t, c_int, c_float, c_float, _P]),
     "qt_round_posit_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, _P]),
+    "qt_posit_quantize_host": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int]),
+    "qt_posit_quantize_f32": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "qt_vmap_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),
     "qt_vmap_f32": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),
     "qt_vmap_f16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P]),

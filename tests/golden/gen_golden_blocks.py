@@ -251,3 +251,22 @@ def gen_checkpoint(ref, out):
     np.savez_compressed(os.path.join(out, "checkpoint.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
     with open(os.path.join(out, "checkpoint.json"), "w") as f:
         json.dump(meta, f, indent=1)
+
+
+POSIT_OPTS = [(8, 0), (8, 1), (8, 2), (16, 1), (6, 1), (16, 2)]
+
+
+def gen_posit_opts(ref, out):
+    """quantize_to_posit(x, nbits, es, round_to_even=False) and (..., return_pbits=True) (posit.py:27-35, 50-53, 60-65)."""
+    g = _helpers()
+    rng = np.random.default_rng(31)
+    x = g.sample_f32(rng, 6000)
+    arrays = {"x": g.f32_bits(torch.from_numpy(x))}
+    for nbits, es in POSIT_OPTS:
+        xt = torch.from_numpy(x)
+        y0 = ref.posit.quantize_to_posit(xt, nbits, es, round_to_even=False)
+        y1, pb = ref.posit.quantize_to_posit(xt, nbits, es, return_pbits=True)
+        arrays[f"p{nbits}_{es}/y_no_rte"] = g.canon_nan32(g.f32_bits(y0))
+        arrays[f"p{nbits}_{es}/y"] = g.canon_nan32(g.f32_bits(y1))
+        arrays[f"p{nbits}_{es}/pbits"] = pb.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(out, "posit_opts.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})

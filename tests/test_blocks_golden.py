@@ -296,3 +296,38 @@ def test_quantize_toy_model_on_device(run):
         if k.endswith(".scale") or k.endswith(".amax_history"):
             exp = values(arrays[f"{run}__sd__{k}"])
             assert torch.allclose(torch.nan_to_num(v.float().reshape(-1).cpu()), torch.nan_to_num(exp), rtol=0.05, atol=1e-6), k
+
+
+# ---- quantize_to_posit(..., round_to_even=False) / (..., return_pbits=True)                     posit.py:27-35, 50-53, 60-65
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("nbits,es", [(8, 0), (8, 1), (8, 2), (16, 1), (6, 1), (16, 2)])
+def test_posit_options_match_upstream(nbits, es, device):
+    """Values: bit for bit on every input, in both rounding modes.  Bit patterns: equal wherever upstream's int32 arithmetic
+    defines them -- finite, non-zero, not regime-dominated, pattern length 2 + run + es + 23 <= 33 (beyond that its
+    `regime << (23 + es)` overflows; regime-dominated inputs are shifted by platform-dependent counts) -- and saturated
+    (maxpos / minpos / 0) where it does not."""
+    d = np.load(os.path.join(G, "posit_opts.npz"))
+    xb = d["x"]
+    x = torch.from_numpy(xb.view(np.float32).copy()).to(device)
+    y0 = qt.quantize_to_posit(x, nbits, es, round_to_even=False)
+    y1, pb = qt.quantize_to_posit(x, nbits, es, return_pbits=True)
+    assert pb.dtype == torch.int32 and pb.shape == x.shape
+
+    def canon(t):
+        b = bits(t).copy()
+        b[((b & 0x7F800000) == 0x7F800000) & ((b & 0x7FFFFF) != 0)] = 0x7FC00000
+        return b
+    assert np.array_equal(canon(y0), d[f"p{nbits}_{es}__y_no_rte"])
+    assert np.array_equal(canon(y1), d[f"p{nbits}_{es}__y"])
+    a = xb & 0x7FFFFFFF
+    scale = (a >> 23).astype(np.int64) - 127
+    k = scale >> es
+    run = np.where(scale >= 0, 1 + k, -k)
+    dominated = np.abs(scale) > ((nbits - 2) << es)
+    comparable = (a < 0x7F800000) & (a != 0) & ~dominated & (2 + run + es + 23 <= 33)
+    got = pb.cpu().numpy()
+    assert comparable.sum() > 2000 and np.array_equal(got[comparable], d[f"p{nbits}_{es}__pbits"][comparable])
+    maxpat = (1 << (nbits - 1)) - 1
+    assert (got[a == 0] == 0).all() and (np.abs(got) <= maxpat).all()
+    big = (a < 0x7F800000) & dominated & (scale > 0)
+    assert (np.abs(got[big]) == maxpat).all() and (np.sign(got[big]) == np.where(xb[big] >> 31, -1, 1)).all()
