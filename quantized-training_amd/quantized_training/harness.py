@@ -152,6 +152,7 @@ LLAMA_SHAPES = {
     "llama-2-7b": (4096, 32, 32, 32, 11008, 32000),
     "llama-2-13b": (5120, 40, 40, 40, 13824, 32000),
     "llama-tiny": (128, 2, 4, 4, 352, 512),
+    "llama-mid": (1024, 8, 8, 8, 2816, 2048),          # head_dim 128 like the 7B / 13B shapes; tests of accumulated drift
 }
 
 

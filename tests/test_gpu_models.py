@@ -395,3 +395,44 @@ def test_collect_qa_logits_graph_replay_equals_eager():
     s0, e0 = harness.collect_qa_logits(m, batches)
     s1, e1 = harness.collect_qa_logits(m, batches, graph=True)
     assert s0.shape == (29, 96) and torch.equal(s0, s1) and torch.equal(e0, e1)
+
+
+def test_perplexity_drift_mid_size_model():
+    """8 layers, hidden 1024 (head_dim 128 like LLaMA-2-7B), S = 1024, bf16, E4M3 activations + weights: the error a route
+    adds per layer accumulates over depth and sequence length here, unlike in the 2-layer 128-wide model above.  Mean window
+    NLL of (a) every fast path + hipGraph replay, (b) the same with the hand-written fused FP8 GEMM (QT_FQ8_GEMM=1), (c) the
+    plain bf16 route (all fast paths off, eager) and (d) the CPU formulation, pairwise within the north star's bound:
+    +-0.01 at perplexity 5.36 = 1.87e-3 relative."""
+    tok = torch.randint(0, 2048, (1, 2600), generator=torch.Generator().manual_seed(9))
+    toggles = ("QT_FP8_GEMM", "QT_FUSED_SOFTMAX", "QT_FUSED_MODEL_OPS", "QT_FUSED_PRODUCER_FQ", "QT_FP8_ATTENTION", "QT_LT_GEMM")
+    windows = harness.wikitext_windows(tok.shape[1], 1024, 512)[:3]
+
+    def run(dev, fast, fq8=False):
+        for k in toggles:
+            os.environ[k] = "1" if fast else "0"
+        os.environ["QT_FQ8_GEMM"] = "1" if fq8 else "0"
+        try:
+            m = harness.build_causal_lm("llama-mid", device="cpu", dtype=torch.float32, seed=0).to(device=dev, dtype=torch.bfloat16)
+            qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+            out = []
+            with torch.no_grad():
+                first = tok[:, :1024].to(dev)
+                harness.window_nll(m, first, 1024)
+                g = None
+                if fast and dev == "cuda":
+                    g = harness.GraphedWindow(m, 1024, None, torch.device("cuda"))
+                    g.capture(first)
+                for (b, e, t) in windows:
+                    ids = tok[:, b:e].to(dev)
+                    out.append(float(g.replay(ids, t) if g is not None else harness.window_nll(m, ids, t)))
+            return sum(out) / len(out)
+        finally:
+            for k in toggles + ("QT_FQ8_GEMM",):
+                os.environ.pop(k, None)
+
+    res = {"fast": run("cuda", True), "fast+fq8": run("cuda", True, fq8=True), "plain": run("cuda", False), "cpu": run("cpu", False)}
+    bound = 0.01 / 5.36
+    ref = res["cpu"]
+    for k, v in res.items():
+        assert abs(v - ref) <= bound * ref, res
+    assert abs(res["fast"] - res["plain"]) <= bound * ref and abs(res["fast+fq8"] - res["fast"]) <= bound * ref, res
