@@ -554,3 +554,50 @@ def mx_pack(values, scales, fmt, block_size=32):
         raise ValueError("scale outside E8M0")
     e8 = np.repeat(e8.astype(np.uint8), block_size // 32, axis=1)
     return out, e8
+
+
+# ---- attention-score path with every bf16 rounding point explicit ---------------------------------------------------------
+# modules/quantizable/modeling_bert.py:118, 142-158 (and the HF LLaMA eager path the LLaMA twin follows):
+#     scores = qk_matmul(q, k^T)                     bf16 tensor (fp32-accumulated GEMM, ONE rounding)
+#     t      = attn_scaling(scores, scaling)         bf16 x python float -> bf16 (ONE rounding of the fp32 product)
+#     u      = t + mask                              bf16 + bf16 -> bf16 (ONE rounding)
+#     p      = softmax(u) in fp32, then bf16         (ONE rounding; nn.Softmax on bf16 computes in fp32 as well)
+#     pq     = fake-quant(p)                         value map on the bf16 pattern (av_matmul's input hook, quantize.py:128-140)
+#     out    = av_matmul(pq, v)                      bf16 (fp32-accumulated GEMM, ONE rounding)
+# exp and every sum are evaluated in float64 here, so this is the chain's value with exact transcendental / reduction
+# arithmetic; an implementation in fp32 differs from it only where its ~1e-7 relative error straddles a bf16 rounding
+# boundary -- a few elements in 10^4, each by one bf16 ULP -- whereas a missing or extra rounding point moves a large
+# share of the elements.
+def _rbf64(x):
+    """float64 -> nearest bf16 value (as float64), through fp32 like the hardware path: the fp32 rounding is exact for
+    products / sums of two bf16 values, so double rounding cannot occur for the single-operation steps below."""
+    return bf16_to_f32(f32_to_bf16(np.asarray(x, dtype=np.float64).astype(np.float32))).astype(np.float64)
+
+
+def softmax_fq(scores_bits, mask_bits, scaling, qmap):
+    """scores_bits: uint16 [..., rows, cols] bf16 patterns; mask_bits: broadcastable uint16 array or None; scaling: python
+    float (multiplied as fp32, like torch's bf16-tensor x scalar); qmap: uint16[65536] or None.  Returns (p_bits, pq_bits)."""
+    s = bf16_to_f32(scores_bits).astype(np.float64)
+    t = _rbf64(s.astype(np.float32) * np.float32(scaling))
+    if mask_bits is not None:
+        m = bf16_to_f32(mask_bits).astype(np.float64)
+        with np.errstate(over="ignore"):
+            t = _rbf64(t + m)
+    mx = t.max(axis=-1, keepdims=True)
+    e = np.exp(t - mx)
+    p = e / e.sum(axis=-1, keepdims=True)
+    p_bits = f32_to_bf16(p.astype(np.float32))
+    return p_bits, (vmap_bf16(p_bits, qmap) if qmap is not None else p_bits)
+
+
+def attention_fq(q_bits, k_bits, v_bits, mask_bits, scaling, qmap):
+    """q [B,H,Sq,D], k / v [B,H,Sk,D] as uint16 bf16 patterns (already fake-quantized); returns the attention output
+    [B,H,Sq,D] as bf16 patterns plus the quantized probabilities' patterns."""
+    q = bf16_to_f32(q_bits).astype(np.float64)
+    k = bf16_to_f32(k_bits).astype(np.float64)
+    v = bf16_to_f32(v_bits).astype(np.float64)
+    scores = f32_to_bf16(np.einsum("bhqd,bhkd->bhqk", q, k).astype(np.float32))
+    _, pq_bits = softmax_fq(scores, mask_bits, scaling, qmap)
+    pq = bf16_to_f32(pq_bits).astype(np.float64)
+    out = np.einsum("bhqk,bhkd->bhqd", pq, v)
+    return f32_to_bf16(out.astype(np.float32)), pq_bits
