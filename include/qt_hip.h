@@ -284,6 +284,18 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
                int b_format, void *c_dev, int c_is_f32, const void *bias_dev, long batch, int M, int N, int K,
                long a_batch_stride_rows, long b_batch_stride_rows, void *stream);
 
+/* ---- section 8(f).1: converted per-tensor graphs, quantize -> GEMM -> dequantize(s_x * s_w)     quantize_pt2e.py:323-446
+ * The int8 GEMM of such a graph on v_mfma_i32_16x16x64_i8 with the dequantize node in its epilogue:
+ *     C[b][M][N] = round_C( round_C( A[b][M][K] . B[b][N][K]^T + bias[N] ) * out_scale )
+ * A, B: int8 CODES (what `quantize` produced, narrowed; weights are stored as codes by convert_pt2e), exact int32
+ * accumulation; bias (nullable) and out_scale (nullable; one element, or N elements with out_scale_per_col) in C's dtype
+ * (bf16 / fp32); the two roundings are those of the graph's `aten.linear` output and of its `dequantize` multiply.
+ * fold_f32 (fp32 C only): the dequantize node looks its input up in the identity value map first, which for an fp32 tensor
+ * keeps the high 16 bits with a sticky bit (decomposed.py:151-153); applied to (acc + bias) before the multiply.
+ * Batch strides in rows (0 = shared operand).  K % 16 == 0, code pointers 16-byte aligned. */
+int qt_q8_gemm(const int8_t *a_codes, const int8_t *b_codes, void *c_dev, int c_is_f32, const void *bias_dev, const void *out_scale_dev,
+               int out_scale_per_col, int fold_f32, long batch, int M, int N, int K, long a_batch_stride_rows, long b_batch_stride_rows, void *stream);
+
 /* Fused quantize_mx for blocks along the last axis (decomposed.py:365-448 with axes = [-1]): x [rows][cols] in the
  * tensor dtype -> q (element values map[x / scale], nullable), scales [rows][cols / block_size] (same dtype), and, when
  * codes / e8m0 are given (requires force_pow2, block_size % 32 == 0, pack_format = the QT_MX_* format the map rounds

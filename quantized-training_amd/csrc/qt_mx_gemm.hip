@@ -40,7 +40,52 @@ struct MxGemmArgs {
     int M, N, K;
     long bA, bB, bsA, bsB, bC;   // batch strides: bytes for A / B / scales, elements for C
     int out_f32;
+    const void *out_scale;       // I8 kernels: dequantize factor(s) in C's dtype applied after the rounding of (acc + bias), or NULL
+    int out_scale_per_col;       // 0: one factor, 1: one per output column
+    int out_fold_f32;            // fp32 output: pass (acc + bias) through the identity value map first (hi16 | sticky, decomposed.py:151-153)
 };
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// One 128-deep step of a 16 x 16 output tile.  I8: both operands are int8 codes (same tile layout as the 8-bit float
+// formats: a lane's bytes 0-15 are k = 16 g + [0, 16) of the first 64-deep half, bytes 16-31 the same of the second), two
+// v_mfma_i32_16x16x64_i8 with exact int32 accumulation; otherwise the block-scaled float instruction.
+template <int FA, int FB, bool I8>
+struct Mma {
+    using acc_t = std::conditional_t<I8, v4i, v4f>;
+    static __device__ __forceinline__ acc_t zero() {
+        if constexpr (I8) return v4i{0, 0, 0, 0};
+        else return v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ acc_t run(const v8i &a, const v8i &b, acc_t c, int sa, int sb) {
+        if constexpr (I8) {
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{a[0], a[1], a[2], a[3]}, v4i{b[0], b[1], b[2], b[3]}, c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{a[4], a[5], a[6], a[7]}, v4i{b[4], b[5], b[6], b[7]}, c, 0, 0, 0);
+        } else {
+            return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FA, FB, 0, sa, 0, sb);
+        }
+    }
+};
+
+// (acc + bias) rounded to the output dtype, then -- converted per-tensor graphs, quantize_pt2e.py:323-446: the
+// dequantize(s_x * s_w) node behind the GEMM -- multiplied by the dequantize factor and rounded again.
+__device__ __forceinline__ void emit_out(const MxGemmArgs &a, float accv, float bv, float sv, long idx) {
+    float v = accv + bv;
+    if (a.out_f32) {
+        if (a.out_fold_f32) v = qt_u2f(qt_fold_img(qt_f2u(v)));
+        if (a.out_scale) v = v * sv;
+        ((float *)a.C)[idx] = v;
+    } else {
+        uint16_t b = qt_f2bf(v);
+        if (a.out_scale) b = qt_f2bf(qt_bf2f(b) * sv);
+        ((uint16_t *)a.C)[idx] = b;
+    }
+}
+__device__ __forceinline__ float out_scale_of(const MxGemmArgs &a, int col) {
+    if (!a.out_scale) return 1.0f;
+    const long i = a.out_scale_per_col ? col : 0;
+    return a.out_f32 ? ((const float *)a.out_scale)[i] : qt_bf2f(((const uint16_t *)a.out_scale)[i]);
+}
 
 // LDS image of a 128-row operand tile.  8- and 4-bit tiles are unpadded with the 16-byte chunk index XOR-swizzled by
 // the row so that the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ... : sixteen different rows, half of
@@ -88,8 +133,9 @@ __device__ __forceinline__ v8i read_frag(const uint8_t *tile, int row, int g) {
     return f;
 }
 
-template <int FA, int FB>
+template <int FA, int FB, bool I8 = false>
 __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
+    using M_ = Mma<FA, FB, I8>;
     using TA = Tile<FA>;
     using TB = Tile<FB>;
     constexpr int RA = TA::kRow, RB = TB::kRow;
@@ -185,11 +231,11 @@ __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
         }
     };
 
-    v4f acc[4][4];
+    typename M_::acc_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::zero();
 
     load_tile(0);
     store_tile(0, 0);
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, cs_a[i], 0, cs_b[j]);
+                acc[i][j] = M_::run(fa[i], fb[j], acc[i][j], cs_a[i], cs_b[j]);
     };
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int cur = kt & 1;
@@ -230,16 +276,14 @@ __global__ __launch_bounds__(256) void mx_gemm_kernel(MxGemmArgs a) {
         if (col >= a.N) continue;
         float bv = 0.f;
         if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+        const float sv = out_scale_of(a, col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m0 + wm * 64 + i * 16 + 4 * g + e;
                 if (row >= a.M) continue;
-                const float v = acc[i][j][e] + bv;
-                const long idx = cbase + (long)row * a.N + col;
-                if (a.out_f32) ((float *)a.C)[idx] = v;
-                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+                emit_out(a, (float)acc[i][j][e], bv, sv, cbase + (long)row * a.N + col);
             }
         }
     }
@@ -377,8 +421,9 @@ __device__ __forceinline__ uint8_t *ring_stage_of(int s) {
 // while a tile is multiplied; the wait is a counted s_waitcnt vmcnt(pieces still allowed in flight) followed by a raw
 // s_barrier (a __syncthreads() would drain the prefetch) -- for grids of about one workgroup per CU, where a tile's
 // ~1.5 us load latency is otherwise fully exposed.
-template <int FA, int FB, int STAGES>
+template <int FA, int FB, int STAGES, bool I8 = false>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void mx_gemm_dma_kernel(MxGemmArgs a) {
+    using M_ = Mma<FA, FB, I8>;
     using TA = Tile<FA>;
     using TB = Tile<FB>;
     using DA = DmaTile<FA>;
@@ -423,11 +468,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
     const uint8_t *gs = w < 2 ? a.sA + bz * a.bsA + (long)min(m0 + srow, a.M - 1) * nblk
                               : a.sB + bz * a.bsB + (long)min(n0 + srow, a.N - 1) * nblk;
 
-    v4f acc[4][4];
+    typename M_::acc_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::zero();
 
     auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
         uint8_t *const s_a = stage, *const s_b = s_a + TA::kBytes, *const s_s = s_b + TB::kBytes;
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
+                acc[i][j] = M_::run(fa[i], fb[j], acc[i][j], sa[i], sb[j]);
     };
     auto compute_ring = [&](const uint8_t *stage) __attribute__((always_inline)) {
         const uint32_t s_a = lds_addr(stage), s_b = s_a + TA::kBytes, s_sa = s_b + TB::kBytes, s_sb = s_sa + 512;
@@ -482,7 +527,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
+                acc[i][j] = M_::run(fa[i], fb[j], acc[i][j], sa[i], sb[j]);
     };
     if constexpr (STAGES == 1) {
         for (int kt = 0; kt < nk; ++kt) {
@@ -525,16 +570,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
         if (col >= a.N) continue;
         float bv = 0.f;
         if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+        const float sv = out_scale_of(a, col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m0 + wm * 64 + i * 16 + 4 * g + e;
                 if (row >= a.M) continue;
-                const float v = acc[i][j][e] + bv;
-                const long idx = cbase + (long)row * a.N + col;
-                if (a.out_f32) ((float *)a.C)[idx] = v;
-                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+                emit_out(a, (float)acc[i][j][e], bv, sv, cbase + (long)row * a.N + col);
             }
         }
     }
@@ -544,8 +587,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void 
 // At 128 x 128 the 8192^3 GEMMs are bound by operand re-reads through L2 (~12.5 TB/s); a 256 x 256 tile halves them.
 // 8 waves x (128 x 64): 32 accumulator tiles per wave (128 accumulator registers) leave room for two waves per SIMD,
 // one workgroup per CU, two-stage LDS-DMA ring (2 x 66 KiB), fragment reads as immediate-offset inline asm.
-template <int FA, int FB>
+template <int FA, int FB, bool I8 = false>
 __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
+    using M_ = Mma<FA, FB, I8>;
     using TA = Tile<FA>;
     using TB = Tile<FB>;
     using DA = DmaTile<FA>;
@@ -592,11 +636,11 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
     const uint8_t *gs = w < 4 ? a.sA + bz * a.bsA + (long)min(m0 + srow, a.M - 1) * nblk
                               : a.sB + bz * a.bsB + (long)min(n0 + srow, a.N - 1) * nblk;
 
-    v4f acc[8][4];
+    typename M_::acc_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::zero();
 
     auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
         uint8_t *const s_a = stage, *const s_b = s_a + kABytes, *const s_s = s_b + kBBytes;
@@ -643,7 +687,7 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[i][j], FA, FB, 0, sa[i], 0, sb[j]);
+                acc[i][j] = M_::run(fa[i], fb[j], acc[i][j], sa[i], sb[j]);
         __builtin_amdgcn_sched_barrier(0);
         read_a(s_a, s_sa, QT_I(0), QT_I(1)); read_a(s_a, s_sa, QT_I(1), QT_I(1));
         read_a(s_a, s_sa, QT_I(2), QT_I(1)); read_a(s_a, s_sa, QT_I(3), QT_I(1));
@@ -653,7 +697,7 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[i], fb[j], acc[4 + i][j], FA, FB, 0, sa[i], 0, sb[j]);
+                acc[4 + i][j] = M_::run(fa[i], fb[j], acc[4 + i][j], sa[i], sb[j]);
     };
 #undef QT_I
 
@@ -683,16 +727,14 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
         if (col >= a.N) continue;
         float bv = 0.f;
         if (a.bias) bv = a.out_f32 ? ((const float *)a.bias)[col] : qt_bf2f(((const uint16_t *)a.bias)[col]);
+        const float sv = out_scale_of(a, col);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m0 + wm * 128 + i * 16 + 4 * g + e;
                 if (row >= a.M) continue;
-                const float v = acc[i][j][e] + bv;
-                const long idx = cbase + (long)row * a.N + col;
-                if (a.out_f32) ((float *)a.C)[idx] = v;
-                else ((uint16_t *)a.C)[idx] = qt_f2bf(v);
+                emit_out(a, (float)acc[i][j][e], bv, sv, cbase + (long)row * a.N + col);
             }
         }
     }
@@ -785,7 +827,7 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     if ((kbA & 15) || (kbB & 15) || (((uintptr_t)a_codes | (uintptr_t)b_codes) & 15u)) return QT_ERR_UNALIGNED;
     MxGemmArgs g{a_codes, b_codes, a_e8m0, b_e8m0, c_dev, bias_dev, M, N, K,
                  a_batch_stride_rows * kbA, b_batch_stride_rows * kbB, a_batch_stride_rows * (K / 32), b_batch_stride_rows * (K / 32),
-                 (long)M * N, c_is_f32};
+                 (long)M * N, c_is_f32, nullptr, 0, 0};
     const dim3 grid(((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM), (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     static const bool no_dma = getenv("QT_MX_NO_DMA") != nullptr;        // tuning / A-B switch
@@ -837,6 +879,46 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     QT_MX(0, 0) QT_MX(0, 1) QT_MX(1, 0) QT_MX(1, 1) QT_MX(2, 2) QT_MX(3, 3) QT_MX(4, 4) QT_MX(0, 4) QT_MX(2, 4) QT_MX(3, 4)
 #undef QT_MX
     return QT_ERR_BAD_DTYPE;          // element-format pair without a kernel: caller dequantizes
+}
+
+
+int qt_q8_gemm(const int8_t *a_codes, const int8_t *b_codes, void *c_dev, int c_is_f32, const void *bias_dev, const void *out_scale_dev,
+               int out_scale_per_col, int fold_f32, long batch, int M, int N, int K, long a_batch_stride_rows, long b_batch_stride_rows, void *stream) {
+    if (batch * M * N == 0) return QT_OK;
+    if (!a_codes || !b_codes || !c_dev || batch < 0 || batch > 65535 || M < 0 || N < 0 || K < 16 || K % 16) return QT_ERR_BAD_ARG;
+    if (((uintptr_t)a_codes | (uintptr_t)b_codes) & 15u) return QT_ERR_UNALIGNED;
+    const uint8_t *A = (const uint8_t *)a_codes, *B = (const uint8_t *)b_codes;
+    // the scale-byte pointers of the block-scaled kernels are never used by the int8 instruction; the code buffers stand in
+    // for them (every address those loads form lies inside the buffers)
+    MxGemmArgs g{A, B, A, B, c_dev, bias_dev, M, N, K, a_batch_stride_rows * (long)K, b_batch_stride_rows * (long)K,
+                 a_batch_stride_rows * (long)(K / 32), b_batch_stride_rows * (long)(K / 32), (long)M * N, c_is_f32, out_scale_dev,
+                 out_scale_per_col, fold_f32};
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM), (unsigned)batch);
+    const bool dma_ok = K % kBK == 0;
+    const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    if (dma_ok && M >= 512 && N >= 512 && big_tiles >= 192) {
+        mx_gemm_big_kernel<0, 0, true><<<dim3((unsigned)big_tiles, (unsigned)batch), 512, 0, st>>>(g);
+        return launch_status();
+    }
+    if (dma_ok) {
+        if ((long)grid.x * grid.y <= 2L * 256) {
+            mx_gemm_dma_kernel<0, 0, 2, true><<<grid, 256, 0, st>>>(g);
+        } else {
+            constexpr int kLds = Tile<0>::kBytes + Tile<0>::kBytes + 1024;
+            mx_gemm_dma_kernel<0, 0, 1, true><<<grid, 256, kLds, st>>>(g);
+        }
+        return launch_status();
+    }
+    constexpr int kLds = 4 * Tile<0>::kBytes;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    mx_gemm_kernel<0, 0, true><<<grid, 256, kLds, st>>>(g);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -94,6 +94,7 @@ SIGNATURES = {
     "qt_mx_pack": (c_int, [_P, _P, c_int, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_int,
                           c_int, _P, _P]),
     "qt_mx_gemm": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int, c_long, c_long, _P]),
+    "qt_q8_gemm": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_long, c_int, c_int, c_int, c_long, c_long, _P]),
     "qt_bench_fake_quant_bf16": (c_int, [_P, _P, c_size_t, _FMT, _P, _P, _P, c_int, c_size_t, c_int, _P,
                                         POINTER(c_float)]),
     "qt_bench_fake_quant_bf16_fp8": (c_int, [_P, _P, _P, c_size_t, _FMT, _P, _P, c_int, c_size_t, c_int, _P,

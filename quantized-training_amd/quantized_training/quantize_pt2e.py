@@ -435,7 +435,7 @@ def _eliminate_dequantize_with_no_effect(model: GraphModule):
     return model
 
 
-def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effect: bool = True):
+def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effect: bool = True, native=None):
     """Lower every FusedAmaxObsFakeQuantize `call_module` of a prepared (and calibrated) graph to
     quantized_ops nodes (upstream :975-1002): quantize / dequantize for per-tensor and per-channel specs,
     quantize_mx + *_mx GEMMs for microscaling, stored codes + dequantize for group-wise affine weights."""
@@ -458,4 +458,9 @@ def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effe
     model.graph.eliminate_dead_code(is_impure_node=lambda n: n.op in {"placeholder", "output"})
     model.recompile()
     model.delete_all_unused_submodules()
+    # Device models: the quantize -> GEMM -> dequantize triples of per-tensor int8 / FP8 specs run on the integer / FP8 matrix
+    # cores (pt2e_native.py).  The graph above is upstream's node for node; this pass only runs where it can execute natively.
+    from . import pt2e_native
+    if native or (native is None and pt2e_native.enabled_for(model)):
+        pt2e_native.fuse_native_gemms(model)
     return model

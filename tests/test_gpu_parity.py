@@ -1352,3 +1352,135 @@ def test_fq8_route_through_quantize(nv, monkeypatch):
     assert counts["0"] == counts["1"]
     scale = outs["0"].abs().max()
     assert float((outs["0"] - outs["1"]).abs().max()) <= 2.0 ** -6 * float(scale)
+
+
+# ---- converted per-tensor PT2E graphs on the integer matrix cores (qt_q8_gemm, pt2e_native.py) -----------------------------
+@pytest.mark.parametrize("batch,M,N,K", [(1, 128, 128, 128), (1, 1, 16, 16), (1, 300, 200, 48), (3, 70, 96, 256), (1, 1024, 512, 1024),
+                                         (1, 2048, 3072, 512), (2, 520, 1040, 384)])
+def test_q8_gemm_is_exact(nv, batch, M, N, K):
+    """int8 codes x int8 codes with int32 accumulation: equal to the integer product (computed in int64 on the device by
+    torch) whenever it fits fp32 exactly; bias, the bf16 rounding of the sum and the dequantize multiply keep the rounding
+    points of `aten.linear` -> `dequantize` (quantize_pt2e.py:323-446)."""
+    torch.manual_seed(batch + M + N + K)
+    a = torch.randint(-128, 128, (batch, M, K), device="cuda", dtype=torch.int8)
+    b = torch.randint(-128, 128, (batch, N, K), device="cuda", dtype=torch.int8)
+    L = nv.lib()
+    exact = torch.matmul(a.double(), b.double().transpose(1, 2))        # integers < 2^53: exact in float64
+    y = torch.empty((batch, M, N), dtype=torch.float32, device="cuda")
+    nv.check(L.qt_q8_gemm(a.data_ptr(), b.data_ptr(), y.data_ptr(), 1, None, None, 0, 0, batch, M, N, K, M, N, stream()), "q8")
+    assert torch.equal(y.double(), exact)                          # |sum| <= 128 * 128 * 1024 = 2^24: exact in fp32
+    bias = torch.randint(-2000, 2000, (N,), device="cuda").float()
+    scale = torch.rand(N, device="cuda") * 1e-3 + 1e-4
+    for per_col in (0, 1):
+        s = scale if per_col else scale[:1].clone()
+        nv.check(L.qt_q8_gemm(a.data_ptr(), b.data_ptr(), y.data_ptr(), 1, bias.data_ptr(), s.data_ptr(), per_col, 0, batch, M, N, K, M, N,
+                              stream()), "q8")
+        assert torch.equal(y, (exact.float() + bias) * s)
+        nv.check(L.qt_q8_gemm(a.data_ptr(), b.data_ptr(), y.data_ptr(), 1, bias.data_ptr(), s.data_ptr(), per_col, 1, batch, M, N, K, M, N,
+                              stream()), "q8")
+        pre = (exact.float() + bias).view(torch.int32)
+        folded = ((pre & -65536) | ((pre & 0xFFFF) != 0).int() * 65536).view(torch.float32)     # identity map on an fp32 tensor
+        assert torch.equal(y, folded * s)
+        yb = torch.empty((batch, M, N), dtype=torch.bfloat16, device="cuda")
+        bias16, s16 = bias.bfloat16(), s.bfloat16()
+        nv.check(L.qt_q8_gemm(a.data_ptr(), b.data_ptr(), yb.data_ptr(), 0, bias16.data_ptr(), s16.data_ptr(), per_col, 0,
+                              batch, M, N, K, M, N, stream()), "q8")
+        expb = ((exact.float() + bias16.float()).bfloat16().float() * s16.float()).bfloat16()
+        assert torch.equal(yb, expb)
+
+
+def test_pt2e_converted_graph_runs_natively(nv):
+    """The reference's PT2E toy flow (tests/golden/pt2e.*: prepare, calibrate, convert) with the model on the device: the
+    int8 configuration's two Linears and its y . y^T matmul run through qt_q8_gemm (counted); the FP8 configuration is an
+    fp32 model whose GEMM outputs are re-rounded through a bfloat16 map, which stays on the value-tensor route.  Outputs match
+    upstream's converted-graph output within the accumulation bound."""
+    from test_pt2e_cpu import META, _model
+    from quantized_training import pt2e_native, quantize_pt2e as qp
+    arr = np.load(os.path.join(G, "pt2e.npz"))
+    for name in ("int8", "fp8"):
+        info = META[name]
+        xs = [torch.from_numpy(arr[f"x{i}"].view(np.float32)).reshape(4, 8, 16).cuda() for i in range(4)]
+        gm = qp.prepare_pt2e(_model(arr).cuda(), qp.get_default_quantizer(**info["kw"]), (xs[0],))
+        with torch.no_grad():
+            for i in range(4):
+                gm(xs[i])
+        before = dict(pt2e_native.STATS)
+        gc = qp.convert_pt2e(gm, info["output_dtype"]) if info["output_dtype"] else qp.convert_pt2e(gm)
+        targets = [str(n.target) for n in gc.graph.nodes]
+        if name == "int8":
+            assert any("linear_q" in t for t in targets) and not any(t == "aten.linear.default" for t in targets)
+        with torch.no_grad():
+            y = gc(xs[3]).float().cpu()
+        exp = torch.from_numpy(arr[f"{name}__y_converted"].view(np.float32).copy()).reshape(y.shape)
+        ran = {k: pt2e_native.STATS[k] - before[k] for k in before}
+        if name == "int8":
+            assert ran["linear_int8"] == 2 and ran["matmul_int8"] >= 1, ran
+        g, e = y.reshape(-1, y.shape[-1]), exp.reshape(-1, y.shape[-1])
+        rel = ((g - e).norm(dim=1) / e.norm(dim=1).clamp_min(1e-6)).max()
+        assert float(rel) <= 0.05, (name, float(rel))
+
+
+def test_pt2e_native_matches_value_tensor_route_at_size(nv, monkeypatch):
+    """A wider model (K = 512 / 1024, 1024 rows: the LDS-DMA and 256 x 256 int8 kernels): the natively executed converted
+    graph against the same converted graph run as upstream runs it (bf16 `aten.linear` on the value tensors)."""
+    from quantized_training import pt2e_native, quantize_pt2e as qp
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(512, 1024)
+            self.fc2 = torch.nn.Linear(1024, 512)
+
+        def forward(self, x):
+            return self.fc2(torch.relu(self.fc1(x))) + x
+
+    torch.manual_seed(0)
+    x = torch.randn(4, 256, 512, device="cuda").bfloat16()
+    outs = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("QT_PT2E_NATIVE", native)
+        torch.manual_seed(1)
+        net = Net().cuda().bfloat16().eval()
+        gm = qp.prepare_pt2e(net, qp.get_default_quantizer("int8,qs=per_tensor_symmetric", None, "int8,qs=per_tensor_symmetric", "int24"), (x,))
+        with torch.no_grad():
+            gm(x), gm(x * 0.5)
+        before = pt2e_native.STATS["linear_int8"]
+        gc = qp.convert_pt2e(gm)
+        with torch.no_grad():
+            outs[native] = gc(x).float()
+        assert (pt2e_native.STATS["linear_int8"] - before) == (2 if native == "1" else 0)
+    a, b = outs["1"], outs["0"]
+    rel = ((a - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-6)).max()
+    assert float(rel) <= 0.02, float(rel)
+
+
+def test_pt2e_fp8_linears_run_on_the_fp8_matrix_cores(nv, monkeypatch):
+    """bf16 model, `fp8_e4m3,qs=per_tensor_symmetric` activations and weights: the converted graph's Linears narrow both
+    operands to OCP FP8 codes and run the library FP8 GEMM (counted), against the value-tensor route."""
+    from quantized_training import pt2e_native, quantize_pt2e as qp
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(256, 512)
+            self.fc2 = torch.nn.Linear(512, 256)
+
+        def forward(self, x):
+            return self.fc2(torch.relu(self.fc1(x)))
+
+    x = torch.randn(2, 128, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)).bfloat16()
+    outs = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("QT_PT2E_NATIVE", native)
+        torch.manual_seed(1)
+        gm = qp.prepare_pt2e(Net().cuda().bfloat16().eval(),
+                             qp.get_default_quantizer("fp8_e4m3,qs=per_tensor_symmetric", None, "fp8_e4m3,qs=per_tensor_symmetric", "float32"), (x,))
+        with torch.no_grad():
+            gm(x), gm(x * 0.5)
+        before = pt2e_native.STATS["linear_fp8"]
+        gc = qp.convert_pt2e(gm)
+        with torch.no_grad():
+            outs[native] = gc(x).float()
+        assert (pt2e_native.STATS["linear_fp8"] - before) == (2 if native == "1" else 0)
+    rel = ((outs["1"] - outs["0"]).norm(dim=-1) / outs["0"].norm(dim=-1).clamp_min(1e-6)).max()
+    assert float(rel) <= 0.02, float(rel)
