@@ -117,13 +117,21 @@ struct UniformDiv {
     __device__ __forceinline__ float operator()(float x) const { return x / s; }
 };
 
+// Internal kind (not part of the C ABI): a table format whose map is odd-symmetric (qt_format.p0 == 1, see qt_format_for);
+// only entries 0 .. 0x7FFF are staged and the sign goes back on finite non-zero and infinite results.
+constexpr int kFmtLutHalf = 4;
+
 template <int KIND>
 struct Rounder {
     qt_format fmt;
     const uint16_t *lds;   // KIND == QT_FMT_LUT: table in LDS (or global for the gather kernels)
     // image -> image
     __device__ __forceinline__ uint32_t operator()(uint32_t img) const {
-        if constexpr (KIND == QT_FMT_LUT) {
+        if constexpr (KIND == kFmtLutHalf) {
+            const uint32_t t = lds[(img >> 16) & 0x7FFFu];
+            const uint32_t sign = ((t - 1u) < 0x7F80u) ? (img & 0x80000000u) : 0u;        // zero and NaN results carry no sign
+            return (t << 16) | sign;
+        } else if constexpr (KIND == QT_FMT_LUT) {
             return (uint32_t)lds[img >> 16] << 16;
         } else if constexpr (KIND == QT_FMT_FP_SAT) {
             return qt_fp_sat_u32(img, fmt.p0, fmt.p1, fmt.fhi);

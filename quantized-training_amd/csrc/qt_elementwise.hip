@@ -161,12 +161,13 @@ __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, 
                                                   size_t n, qt_format fmt, const uint16_t *__restrict__ lut,
                                                   const float *__restrict__ scale, uint32_t *amax_out) {
     Rounder<KIND> rnd{fmt, nullptr};
-    if constexpr (KIND == QT_FMT_LUT) {
-        __shared__ uint4 s_lut[QT_MAP_ENTRIES * 2 / 16];
+    if constexpr (KIND == QT_FMT_LUT || KIND == kFmtLutHalf) {
+        constexpr int kVecs = (KIND == kFmtLutHalf ? QT_MAP_ENTRIES / 2 : QT_MAP_ENTRIES) * 2 / 16;   // 64 KiB: two workgroups per CU
+        __shared__ uint4 s_lut[kVecs];
         if (yv) {
             const uint4 *g = (const uint4 *)lut;
 #pragma unroll
-            for (int i = 0; i < QT_MAP_ENTRIES * 2 / 16 / BLOCK; ++i) s_lut[i * BLOCK + threadIdx.x] = g[i * BLOCK + threadIdx.x];
+            for (int i = 0; i < kVecs / BLOCK; ++i) s_lut[i * BLOCK + threadIdx.x] = g[i * BLOCK + threadIdx.x];
         }
         rnd.lds = (const uint16_t *)s_lut;
         __syncthreads();
@@ -601,6 +602,55 @@ __global__ __launch_bounds__(256) void fq_pc_vec_kernel(const uint4 *__restrict_
     }
 }
 
+// Table formats on large per-channel tensors: the value map staged in LDS (the whole 128 KiB, or its non-negative 64 KiB half
+// for odd-symmetric maps: then two workgroups per CU) by a persistent 1024-thread workgroup, ONE WAVE PER ROW -- the row's
+// scale in a register, amax reduced inside the wave, no workgroup barrier in the row loop.  The kernel above gathers from
+// the L2-resident table instead (3.0-3.1 TB/s on a [4096, 11008] weight).
+template <int IO, int KINDL>
+__global__ __launch_bounds__(1024) void fq_pc_vec_lds_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, size_t rows,
+                                                             size_t C, size_t vpr, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                             const float *__restrict__ scale, uint32_t *amax_out) {
+    constexpr int kVecs = (KINDL == kFmtLutHalf ? QT_MAP_ENTRIES / 2 : QT_MAP_ENTRIES) * 2 / 16;
+    __shared__ uint4 s_lut[kVecs];
+    {
+        const uint4 *g = (const uint4 *)lut;
+#pragma unroll
+        for (int i = 0; i < kVecs / 1024; ++i) s_lut[i * 1024 + threadIdx.x] = g[i * 1024 + threadIdx.x];
+    }
+    __syncthreads();
+    Rounder<KINDL> rnd{fmt, (const uint16_t *)s_lut};
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 16 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 16;
+    for (size_t row = wave; row < rows; row += nwaves) {
+        const size_t c = row % C;
+        float s = scale ? scale[c] : 1.0f;
+        if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+        const bool unit = (s == 1.0f);
+        const UniformDiv dv(s);
+        uint32_t amax = 0;
+        const uint4 *xr = x + row * vpr;
+        uint4 *yr = y + row * vpr;
+        for (size_t i = lane; i < vpr; i += 64) {
+            const uint4 in = xr[i];
+            uint4 r;
+            if (amax_out) {
+                if (unit) r = fq_vec<IO, KINDL, kDivUnit, true>(in, dv, rnd, amax);
+                else if (dv.safe) r = fq_vec<IO, KINDL, kDivFast, true>(in, dv, rnd, amax);
+                else r = fq_vec<IO, KINDL, kDivExact, true>(in, dv, rnd, amax);
+            } else {
+                if (unit) r = fq_vec<IO, KINDL, kDivUnit, false>(in, dv, rnd, amax);
+                else if (dv.safe) r = fq_vec<IO, KINDL, kDivFast, false>(in, dv, rnd, amax);
+                else r = fq_vec<IO, KINDL, kDivExact, false>(in, dv, rnd, amax);
+            }
+            yr[i] = r;
+        }
+        if (amax_out) {
+            amax = wave_max_u32(amax);
+            if (lane == 0 && amax) atomicMax(amax_out + c, amax);
+        }
+    }
+}
+
 // inner == 1 (channel is the fastest dim): element i belongs to channel i % C
 template <int IO, int KIND>
 __global__ __launch_bounds__(256) void fq_pc_last_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t n,
@@ -820,6 +870,19 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     }
     const size_t nvec = n / kPer;
     if constexpr (KIND == QT_FMT_LUT) {
+        // Opt-in (QT_LUT_HALF=1): odd-symmetric maps can stage only their non-negative half (64 KiB, two workgroups = 32 waves
+        // per CU).  Measured SLOWER on bf16 [4096, 11008]: posit8_1 41.3 us (4.37 TB/s) against 37.7 us (4.79 TB/s) with the
+        // whole table -- putting the sign back costs three more VALU operations per element than the second workgroup's extra
+        // waves recover (tools/exp_table_formats.py) -- so the whole table stays the default.
+        static const int half_mode = getenv("QT_LUT_HALF") ? atoi(getenv("QT_LUT_HALF")) : 0;      // tuning / A-B switch
+        if (fmt.p0 == 1 && half_mode) {
+            unsigned grid = grid_for(nvec, (size_t)kLutBlock * 4 * 4, 2);
+            if (amax)
+                fq_kernel<IO, kFmtLutHalf, true, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+            else
+                fq_kernel<IO, kFmtLutHalf, false, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+            return launch_status();
+        }
         unsigned grid = grid_for(nvec, (size_t)kLutBlock * 4 * 4, 1);
         if (amax)
             fq_kernel<IO, KIND, true, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
@@ -889,6 +952,23 @@ int launch_pc_kind(const void *x, void *y, size_t outer, size_t C, size_t inner,
         unsigned grid = grid_for(n, 256 * 4, 8);
         fq_pc_last_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, n, C, fmt, lut, scale, amax);
     } else if (inner % kPer == 0 && inner >= 64 * kPer && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0)) {
+        if constexpr (KIND == QT_FMT_LUT) {
+            static const int lds_mode = getenv("QT_PC_LDS") ? atoi(getenv("QT_PC_LDS")) : 1;          // tuning / A-B switch
+            if (lds_mode && y && outer * C * inner >= kLutLdsMinElems) {
+                const size_t rows = outer * C;
+                static const int half_mode = getenv("QT_LUT_HALF") ? atoi(getenv("QT_LUT_HALF")) : 0;  // see launch_fq_kind
+                if (fmt.p0 == 1 && half_mode) {
+                    unsigned grid = grid_for(rows, 16, 2);
+                    fq_pc_vec_lds_kernel<IO, kFmtLutHalf><<<grid, 1024, 0, st>>>((const uint4 *)x, (uint4 *)y, rows, C, inner / kPer, fmt,
+                                                                               lut, scale, amax);
+                } else {
+                    unsigned grid = grid_for(rows, 16, 1);
+                    fq_pc_vec_lds_kernel<IO, QT_FMT_LUT><<<grid, 1024, 0, st>>>((const uint4 *)x, (uint4 *)y, rows, C, inner / kPer, fmt,
+                                                                              lut, scale, amax);
+                }
+                return launch_status();
+            }
+        }
         unsigned grid = grid_for(outer * C, 1, 16);
         fq_pc_vec_kernel<IO, KIND><<<grid, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, outer * C, C, inner / kPer, fmt, lut,
                                                          scale, amax);

@@ -149,7 +149,7 @@ const char *qt_status_string(int code) {
     }
 }
 
-int qt_format_for(const char *dtype, qt_format *out) {
+static int format_basic(const char *dtype, qt_format *out) {
     if (!out) return QT_ERR_BAD_ARG;
     qt_format f = {QT_FMT_LUT, 0, 0, 0.0f, 0.0f};
     ParsedDtype p = parse_dtype(dtype);
@@ -180,6 +180,24 @@ int qt_format_for(const char *dtype, qt_format *out) {
     return QT_OK;
 }
 
+// Table formats whose map is odd-symmetric -- map[-v] = -map[v] for every finite non-zero result, zero results +0 and NaN
+// results canonical on both sides (posit, fpN_eXmY, NormalFloat ...) -- are marked p0 = 1: the device kernels then stage
+// only the non-negative half of the table (64 KiB of LDS instead of 128) and put the sign back on the looked-up value.
+int qt_format_for(const char *dtype, qt_format *out) {
+    const int rc = format_basic(dtype, out);
+    if (rc != QT_OK || out->kind != QT_FMT_LUT) return rc;
+    static thread_local uint16_t map[QT_MAP_ENTRIES];
+    if (qt_build_map(dtype, map) != QT_OK) return QT_OK;
+    bool odd = true;
+    for (uint32_t i = 0; i < 0x8000u && odd; ++i) {
+        const uint16_t t = map[i], n = map[i | 0x8000u];
+        const uint16_t want = (uint16_t)(t - 1u) < 0x7F80u ? (uint16_t)(t | 0x8000u) : t;      // signed unless zero / NaN
+        odd = n == want && (t & 0x8000u) == 0;
+    }
+    out->p0 = odd ? 1 : 0;
+    return QT_OK;
+}
+
 uint16_t qt_format_apply_host(const qt_format *fmt, uint16_t b) {
     return (uint16_t)(qt_apply_format_img(*fmt, (uint32_t)b << 16) >> 16);
 }
@@ -189,7 +207,7 @@ int qt_build_map(const char *dtype, uint16_t *out) {
     ParsedDtype p = parse_dtype(dtype);
     if (p.family == ParsedDtype::BAD) return QT_ERR_BAD_DTYPE;
     qt_format f;
-    qt_format_for(dtype, &f);
+    format_basic(dtype, &f);
     float max_norm = 0.0f, thr = 0.0f;
     int mb = 0;
     if (p.family == ParsedDtype::INT || p.family == ParsedDtype::UINT) {
