@@ -46,7 +46,7 @@ typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-constexpr int kTM = 256, kBK = 128, kMaxSeg = 4, kMaxNT = 12, kMaxNB = 6;
+constexpr int kTM = 256, kBK = 128, kMaxSeg = 4, kMaxNT = 12;
 constexpr int kABytes = kTM * kBK;                  // one activation tile: 32 KiB of FP8 codes
 constexpr int kUnitE8M0 = 127;                      // 2^0
 
@@ -66,6 +66,17 @@ struct Args {
     int dbg;                  // tuning switches (QT_FQ8_DEBUG): 2 = no multiplications, 128 = no issue stagger
     Segment seg[kMaxSeg];
 };
+
+// The weight holding column group `grp`, by compile-time indices only: a run-time index into the kernel-argument struct makes
+// hipcc copy the whole struct to scratch memory and read its fields from there.
+struct SegRef { const uint16_t *w, *bias; int g0; };
+__device__ __forceinline__ SegRef seg_lookup(const Args &a, int grp) {
+    SegRef r{a.seg[0].w, a.seg[0].bias, a.seg[0].g0};
+    if (a.nseg > 1 && grp >= a.seg[1].g0) r = SegRef{a.seg[1].w, a.seg[1].bias, a.seg[1].g0};
+    if (a.nseg > 2 && grp >= a.seg[2].g0) r = SegRef{a.seg[2].w, a.seg[2].bias, a.seg[2].g0};
+    if (a.nseg > 3 && grp >= a.seg[3].g0) r = SegRef{a.seg[3].w, a.seg[3].bias, a.seg[3].g0};
+    return r;
+}
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
@@ -131,13 +142,6 @@ struct LinearFq8 {
         const int r = l & 15, g = l >> 4, wm = w & 3, wn = w >> 2;
         const int nk = a.K / kBK;
         constexpr int stage_bytes = kStage;
-        auto seg_of = [&](int grp) __attribute__((always_inline)) {       // weight holding column group `grp`
-            int s = 0;
-#pragma unroll
-            for (int i = 1; i < kMaxSeg; ++i)
-                if (i < a.nseg && grp >= a.seg[i].g0) s = i;
-            return s;
-        };
         // ---- DMA sources (k tile 0); LDS destinations are wave-uniform
         const uint8_t *ga[4];
 #pragma unroll
@@ -155,8 +159,9 @@ struct LinearFq8 {
         for (int i = 0; i < NB; ++i) {
             const int p = w + 8 * i;
             pb[i] = p < npieces ? p : (w & 3);
-            const int grp = tg0 + (pb[i] >> 2), s = seg_of(grp);
-            ub[i] = (const uint8_t *)a.seg[s].w + ((long)((grp - a.seg[s].g0) * 16 + (pb[i] & 3) * 4) * a.K) * 2;
+            const int grp = tg0 + (pb[i] >> 2);
+            const SegRef sg = seg_lookup(a, grp);
+            ub[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb[i] & 3) * 4) * a.K) * 2;
         }
         const int row16 = (w & 3) * 4 + (l >> 4);              // row & 15 of this lane's row in any of its pieces
         const uint32_t b_lane = (uint32_t)(l >> 4) * (uint32_t)a.K * 2u + (((l & 15) ^ row16) << 4);
@@ -291,11 +296,12 @@ struct LinearFq8 {
         if constexpr (NTW > 0) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const int grp = tg0 + jbase + j, s = seg_of(grp);
+                const int grp = tg0 + jbase + j;
+                const SegRef sg = seg_lookup(a, grp);
                 const int col = grp * 16 + 4 * g;                       // output column
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.seg[s].bias) {
-                    const uint2 b = *(const uint2 *)(a.seg[s].bias + (col - a.seg[s].g0 * 16));
+                if (sg.bias) {
+                    const uint2 b = *(const uint2 *)(sg.bias + (col - sg.g0 * 16));
                     bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
                     bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
                 }
@@ -318,21 +324,18 @@ struct LinearFq8 {
 // loops, operands straight from global memory, one 16 x 16 output tile at a time -- only ever taken for weights beyond the
 // format's range or non-finite values.
 template <int FX, int FW>
-__device__ void slow_tile(const Args &a, int m0, int tg0, int jbase, int ntw, int w, int l) {
+__device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jbase, int ntw, int w, int l) {
     const int r = l & 15, g = l >> 4, wm = w & 3;
     const int nk = a.K / kBK;
 #pragma unroll 1
     for (int j = 0; j < ntw; ++j) {
         const int grp = tg0 + jbase + j;
-        int s = 0;
-#pragma unroll
-        for (int i = 1; i < kMaxSeg; ++i)
-            if (i < a.nseg && grp >= a.seg[i].g0) s = i;
-        const uint16_t *wrow = a.seg[s].w + (long)((grp - a.seg[s].g0) * 16 + r) * a.K;
+        const SegRef sg = seg_lookup(a, grp);
+        const uint16_t *wrow = sg.w + (long)((grp - sg.g0) * 16 + r) * a.K;
         const int col = grp * 16 + 4 * g;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.seg[s].bias) {
-            const uint2 b = *(const uint2 *)(a.seg[s].bias + (col - a.seg[s].g0 * 16));
+        if (sg.bias) {
+            const uint2 b = *(const uint2 *)(sg.bias + (col - sg.g0 * 16));
             bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
             bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
         }
