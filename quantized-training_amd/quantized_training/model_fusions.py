@@ -16,6 +16,7 @@ differs from torch's kernel only through the summation order of its mean / varia
 `QT_FUSED_MODEL_OPS=0` keeps HF's own code everywhere.
 """
 import ctypes
+import logging
 import os
 
 import torch
@@ -24,6 +25,18 @@ from . import _native
 from .fake_quantize import FusedAmaxObsFakeQuantize, _stream_ptr
 
 __all__ = ["apply_llama_fusions", "apply_bert_fusions", "rmsnorm", "silu_mul", "rope", "layernorm", "gelu"]
+
+
+logger = logging.getLogger(__name__)
+_DECLINED = set()
+
+
+def _declined(what, why):
+    """One log line per (rebinding, reason) when a fused forward is NOT installed, so that a slower run is explainable
+    from its log (the model still runs, on Hugging Face's own code for that piece)."""
+    if (what, why) not in _DECLINED:
+        _DECLINED.add((what, why))
+        logger.warning("quantized_training: %s keeps the Hugging Face code path: %s", what, why)
 
 
 def _enabled():
@@ -469,9 +482,10 @@ def _patch_rope():
         return
     try:
         from transformers.models.llama import modeling_llama as ml
-    except Exception:  # noqa: BLE001
+        original = ml.apply_rotary_pos_emb
+    except Exception as e:  # noqa: BLE001
+        _declined("rotary embedding", f"transformers.models.llama.modeling_llama.apply_rotary_pos_emb not found ({e})")
         return
-    original = ml.apply_rotary_pos_emb
 
     def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
         ok = (unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and _eligible(q, k, cos, sin)
@@ -516,9 +530,17 @@ def apply_llama_fusions(model):
     # residual adds absorbed into the norm behind them: only if this transformers version's decoder layer is the one
     # _decoder_layer_forward restates (same parameters) and the model exposes its blocks and final norm the usual way
     import inspect
-    same_layer = list(inspect.signature(ml.LlamaDecoderLayer.forward).parameters) == _LAYER_PARAMS
+    have = list(inspect.signature(ml.LlamaDecoderLayer.forward).parameters)
+    same_layer = have == _LAYER_PARAMS
+    if n and not same_layer:
+        _declined("residual add + RMSNorm (LlamaDecoderLayer.forward)",
+                  f"this transformers version's decoder layer takes {have}, the restated one {_LAYER_PARAMS}")
     for mod in model.modules():
         layers, final = getattr(mod, "layers", None), getattr(mod, "norm", None)
+        if same_layer and isinstance(mod, ml.LlamaModel) and not (
+                isinstance(final, ml.LlamaRMSNorm) and layers is not None and all(isinstance(l, ml.LlamaDecoderLayer) for l in layers)):
+            _declined("residual add + RMSNorm (LlamaDecoderLayer.forward)",
+                      "the LlamaModel's .layers / .norm are not plain LlamaDecoderLayer / LlamaRMSNorm modules")
         if (same_layer and isinstance(mod, ml.LlamaModel) and isinstance(final, ml.LlamaRMSNorm) and layers is not None
                 and all(isinstance(l, ml.LlamaDecoderLayer) for l in layers)):
             n_used = mod.config.num_hidden_layers

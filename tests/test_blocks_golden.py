@@ -127,11 +127,7 @@ def test_blocks_match_upstream_twins(blocks, key, device):
     assert sorted((n, type(m).__name__) for n, m in blk.named_modules()) == sorted(map(tuple, info["modules"]))
 
 
-@pytest.mark.parametrize("device", DEVICES)
-@pytest.mark.parametrize("sname", sorted(QA_META))
-def test_qa_loop_logits_match_upstream(sname, device):
-    """The SQuAD evaluation loop (run_qa_no_trainer.py:914-959) on a seeded tiny BERT with upstream's twins: start / end
-    logits over three padded batches, collected by harness.collect_qa_logits."""
+def _qa_logits(sname, device):
     npz = np.load(os.path.join(G, "qa_logits.npz"))
     info = QA_META[sname]
     dtype = info["dtype"]
@@ -145,24 +141,64 @@ def test_qa_loop_logits_match_upstream(sname, device):
         batches.append({"input_ids": torch.from_numpy(arr(npz, f"batch{i}/input_ids")),
                         "attention_mask": torch.from_numpy(arr(npz, f"batch{i}/attention_mask"))})
     start, end = harness.collect_qa_logits(model, batches, device=torch.device(device))
-    for name, got in (("start_logits", start), ("end_logits", end)):
-        exp = arr(npz, f"{sname}/{name}")
-        if device == "cpu":
-            assert np.array_equal(bits(got.float()), exp), (sname, name)
-        else:
-            # almost every logit is identical; where an intermediate value fell on the other side of a rounding boundary of
-            # the 8-bit format (one step = 6-12 % of that value) a few logits of that token move
+    return npz, info, model, start, end
+
+
+# Routes of the device path for a bf16 FP8 model, from the one that repeats upstream's operations to the default one:
+#   plain   - fake-quantized VALUES through bf16 GEMMs, Hugging Face's LayerNorm / GELU / softmax kernels
+#   fused   - same GEMMs, one-launch LayerNorm / GELU / softmax (summation order of the statistics differs: 1 bf16 ulp)
+#   default - FP8 codes through the FP8 matrix instruction as well (its 128-term dot product is not the CPU's fp32 chain)
+# A last-bit difference in a hidden value flips an 8-bit code (a 6-12 % step) in a few per cent of the cases, and a logit is a
+# 64-term dot product of such values: the plain route must reproduce upstream's logits, the other two are bounded
+# statistically (and by what they do to the answer: the arg max).
+QA_ROUTES = {
+    "plain": {"QT_FP8_GEMM": "0", "QT_FUSED_MODEL_OPS": "0", "QT_FUSED_SOFTMAX": "0", "QT_FUSED_ATTENTION": "0"},
+    "fused": {"QT_FP8_GEMM": "0"},
+    "default": {},
+}
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("sname", sorted(QA_META))
+def test_qa_loop_logits_match_upstream(sname, device, monkeypatch):
+    """The SQuAD evaluation loop (run_qa_no_trainer.py:914-959) on a seeded tiny BERT with upstream's twins: start / end
+    logits over three padded batches, collected by harness.collect_qa_logits."""
+    routes = QA_ROUTES if (device != "cpu" and QA_META[sname]["dtype"] == "bfloat16") else {"default": {}}
+    for route, env in routes.items():
+        for k in ("QT_FP8_GEMM", "QT_FUSED_MODEL_OPS", "QT_FUSED_SOFTMAX", "QT_FUSED_ATTENTION"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        npz, info, model, start, end = _qa_logits(sname, device)
+        dtype = info["dtype"]
+        for name, got in (("start_logits", start), ("end_logits", end)):
+            exp = arr(npz, f"{sname}/{name}")
+            if device == "cpu":
+                assert np.array_equal(bits(got.float()), exp), (sname, name)
+                continue
             e = values(exp).reshape(got.shape)
-            d = (got.float().cpu() - e).abs()
+            g = got.float().cpu()
+            d = (g - e).abs()
             scale = float(e.abs().max())
-            small = 0.02 if dtype == "bfloat16" else 0.01
-            assert float((d > small * scale).float().mean()) <= 0.02, (sname, name, float((d > small * scale).float().mean()))
-            assert float(d.pow(2).mean().sqrt()) <= small * scale and float(d.max()) <= 0.2 * scale, (sname, name, float(d.max()))
-    assert {k: list(v.shape) for k, v in model.state_dict().items()} == info["state_dict"]
-    if device == "cpu":
-        for k, v in model.state_dict().items():
-            if k.endswith(".scale") or k.endswith(".amax_history"):
-                assert np.array_equal(bits(v.reshape(-1)), arr(npz, f"{sname}/sd/{k}")), k
+            rms, worst = float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale
+            share = float((d > 0.01 * scale).float().mean())
+            tag = (sname, route, name, rms, worst, share)
+            if dtype != "bfloat16" or route == "plain":
+                # fp32 models (table formats) and the plain bf16 route: the same operations as upstream's, the logits
+                # agree to accumulation order
+                assert share <= 0.02 and rms <= 0.01 and worst <= 0.2, tag
+            else:
+                corr = float(torch.corrcoef(torch.stack([g.flatten(), e.flatten()]))[0, 1])
+                # the answer: the position we would pick scores, in upstream's logits, within `regret` of upstream's pick
+                # (random-init logits are flat -- ties within the noise are common, so positions themselves may differ)
+                regret = float((e.max(-1).values - e.gather(-1, g.argmax(-1, keepdim=True)).squeeze(-1)).max()) / scale
+                lim = {"fused": (0.03, 0.15, 0.995, 0.1), "default": (0.05, 0.2, 0.99, 0.15)}[route]
+                assert rms <= lim[0] and worst <= lim[1] and corr >= lim[2] and regret <= lim[3], (corr, regret) + tag
+        assert {k: list(v.shape) for k, v in model.state_dict().items()} == info["state_dict"]
+        if device == "cpu":
+            for k, v in model.state_dict().items():
+                if k.endswith(".scale") or k.endswith(".amax_history"):
+                    assert np.array_equal(bits(v.reshape(-1)), arr(npz, f"{sname}/sd/{k}")), k
 
 
 @pytest.mark.parametrize("device", DEVICES)

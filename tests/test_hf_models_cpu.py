@@ -187,3 +187,25 @@ def test_llama_default_attention_stays_causal_after_quantize():
     assert float((out - ref).abs().max()) < 1e-5
     assert float((out2[:, :-1] - out[:, :-1]).abs().max()) < 1e-6
     assert float((out2[:, -1] - out[:, -1]).abs().max()) > 1e-4
+
+
+def test_declined_llama_rebinding_is_logged_once(monkeypatch, caplog):
+    """When this transformers version's decoder layer is not the one model_fusions restates, the residual-add + RMSNorm
+    rebinding is skipped: one warning says so (once per reason), the other rebindings still happen and the model runs."""
+    import logging
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from quantized_training import model_fusions as mf
+    monkeypatch.setattr(mf, "_LAYER_PARAMS", ["self", "hidden_states", "something_else"])
+    mf._DECLINED.clear()
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=100, max_position_embeddings=64)
+    m = LlamaForCausalLM(cfg).eval()
+    with caplog.at_level(logging.WARNING, logger=mf.logger.name):
+        assert mf.apply_llama_fusions(m) > 0
+        assert mf.apply_llama_fusions(m) > 0              # a second conversion does not repeat the line
+    lines = [r.getMessage() for r in caplog.records if "keeps the Hugging Face code path" in r.getMessage()]
+    assert len(lines) == 1 and "LlamaDecoderLayer.forward" in lines[0] and "something_else" in lines[0]
+    assert not hasattr(m.model.layers[0], "_qt_hf_forward")          # decoder layer untouched
+    assert hasattr(m.model.layers[0].mlp, "_qt_hf_forward")          # the MLP rebinding still made
+    with torch.no_grad():
+        assert torch.isfinite(m(torch.randint(3, 100, (1, 8))).logits).all()

@@ -33,9 +33,10 @@ span = (rows[hi][0] - rows[lo][0]) / 1e3 / args.windows
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"(Custom_)?Cijk_\w*?(MT\d+x\d+x\d+)", n)
-    if m:
-        return "hipBLASLt FP8 GEMM " + m.group(2) + (" (custom)" if m.group(1) else "")
+    m = re.match(r"(Custom_)?Cijk_[A-Za-z]+_[A-Za-z]+_([A-Z0-9]+)_\w*?(MT\d+x\d+x\d+)", n)
+    if m:                                               # Tensile name: ..._<types>_..., F8.. = FP8 inputs, BBS / BSS = bf16
+        kind = "FP8" if m.group(2).startswith("F8") else ("bf16" if m.group(2).startswith("B") else m.group(2))
+        return f"hipBLASLt {kind} GEMM {m.group(3)}" + (" (custom)" if m.group(1) else "")
     return re.sub(r"\(.*", "", n)[:72]
 
 
