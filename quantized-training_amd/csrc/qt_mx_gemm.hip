@@ -336,6 +336,13 @@ __device__ __forceinline__ uint4 asm_ds_read_b128_off(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));      // native vector: usable as a "+v" asm operand
+template <int OFF>
+__device__ __forceinline__ u32x4w ds_read128w(uint32_t addr) {
+    u32x4w v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 template <int OFF>
 __device__ __forceinline__ int asm_ds_read_u8_off(uint32_t addr) {
     int v;
@@ -740,6 +747,329 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
     }
 }
 
+// ---- TM x (16 nt) tiles, TM in {256, 128} and nt chosen per launch: M = 1024-class GEMMs --------------------------------
+// The 256 x 256 kernel needs >= 192 tiles, and the 128 x 128 kernels run one 4-wave workgroup per CU on these shapes (256
+// tiles), so every LDS and DMA latency of a step is exposed (1024 x 4096 x 4096: 1.1 us per step).  Here a workgroup is 8
+// waves owning TM rows x 16 nt columns, and the host picks TM and the column widths so that the grid is a whole number of
+// rounds over the CUs with the fewest operand bytes per CU, K (TM + 16 nt): 1024 x 11008 -> 4 x 64 tiles of 256 x
+// (176 | 160), 1024 x 4096 -> 8 x 32 tiles of 128 x 128.  Waves: TM / 64 row bands (64 rows) x 8 / bands column parts
+// (nt split as evenly as 16-column groups allow); the two waves of a SIMD share their A fragments.  8-bit formats only.
+//
+// LDS rings, all filled by LDS-DMA: the A tile (TM x 128 bytes) with both operands' scale bytes (1 + 1 KiB) two deep, the
+// B tile (nt x 2 KiB, rounded up to the wave count) THREE deep -- B streams from HBM (a byte is used by M / TM workgroups
+// only), A from L2 (shared by every column tile), so B gets a step more of latency cover.  A wave issues its pieces of
+// A (k + 1) and B (k + 2) spread over its multiplications of step k (a burst in front of them stalls the wave until the
+// memory pipe has drained it); one counted s_waitcnt vmcnt + ONE raw barrier per step.  B fragments are read two
+// 16-column groups ahead of their multiplications.  The operands are multiplied swapped (B fragment first), so a lane
+// ends up with four consecutive output columns of one row: 8-byte (bf16) or 16-byte (fp32) stores.
+struct WideGeom {
+    int tm;                     // 256 or 128
+    int tiles_m, tiles_n;
+    int gbase, gextra;          // column tile j covers gbase + (j < gextra) groups of 16 columns
+    int dbg;                    // QT_MX_WIDE_DEBUG: 2 = no multiplications (DMA only), 4 = a wave's DMA instructions in one burst,
+                                // 8 = k tile 0 every step (cache-resident operands), 16 = no DMA inside the loop
+};
+
+template <int FA, int FB, int TM, int NBP>         // NBP: B DMA pieces (8 rows x 128 bytes) per wave and stage
+struct MxWide {
+    static constexpr int kBands = TM / 64, kParts = 8 / kBands;
+    static constexpr int kABytes = TM * 128;
+    static constexpr int kAStage = kABytes + 2048;                     // + A scales (TM x 4 <= 1 KiB) + B scales (<= 256 x 4)
+    static constexpr int kBStage = NBP * 8 * 1024;
+    static constexpr int kLds = 2 * kAStage + 3 * kBStage;
+    static constexpr int kItems = kBands + 1 + NBP;                    // DMA instructions of one wave per step
+    static constexpr int kMaxNTW = TM == 256 ? 6 : 4;
+
+    static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+    template <int NTW>
+    static __device__ __forceinline__ void run(const MxGemmArgs &a, const WideGeom &geo, uint8_t *lds, int m0, int tg0, int nt, int jbase,
+                                               int w, int l, long bz) {
+        const int r = l & 15, g = l >> 4, wm = w % kBands;
+        const int nk = a.K / kBK, nblk = a.K / 32;
+        // ---- DMA sources at k tile 0
+        const uint8_t *ga[kBands], *gb[NBP], *gs;
+        int pb[NBP];
+#pragma unroll
+        for (int i = 0; i < kBands; ++i) {
+            const int row = (w * kBands + i) * 8 + (l >> 3), slot = l & 7;
+            ga[i] = a.A + bz * a.bA + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        const int npieces = nt * 2;
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) {
+            const int p = w + 8 * i;
+            pb[i] = p < npieces ? p : p % npieces;                    // surplus pieces repeat one (same bytes, same place)
+            const int row = pb[i] * 8 + (l >> 3), slot = l & 7;
+            gb[i] = a.B + bz * a.bB + (long)(tg0 * 16 + row) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        int s_dst;
+        if (w < kBands) {
+            gs = a.sA + bz * a.bsA + (long)min(m0 + w * 64 + l, a.M - 1) * nblk;
+            s_dst = kABytes + w * 256;
+        } else {
+            const int q = (w - kBands) & 3;                           // 64-row piece of the B scales (surplus waves repeat one)
+            gs = a.sB + bz * a.bsB + (long)(tg0 * 16 + min(q * 64 + l, nt * 16 - 1)) * nblk;
+            s_dst = kABytes + 1024 + q * 256;
+        }
+
+        // item 0 .. kBands-1: A pieces of step ka, kBands: this wave's scale piece of step ka, then the B pieces of step kb
+        auto issue_item = [&](auto ic, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I < kBands) {
+                if (ka >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(ga[I] + (long)ka * kBK), (lds_void *)(as + (w * kBands + I) * 1024), 16, 0, 0);
+            } else if constexpr (I == kBands) {
+                if (ka >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(gs + ka * 4), (lds_void *)(as + s_dst), 4, 0, 0);
+            } else {
+                if (kb >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(gb[I - kBands - 1] + (long)kb * kBK), (lds_void *)(bs + pb[I - kBands - 1] * 1024), 16, 0, 0);
+            }
+        };
+        auto issue_range = [&](auto lo, auto hi, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            static_assert(HI - LO <= 9, "issue_range covers at most nine items");
+            if constexpr (LO + 0 < HI) issue_item(std::integral_constant<int, LO + 0>{}, ka, as, kb, bs);
+            if constexpr (LO + 1 < HI) issue_item(std::integral_constant<int, LO + 1>{}, ka, as, kb, bs);
+            if constexpr (LO + 2 < HI) issue_item(std::integral_constant<int, LO + 2>{}, ka, as, kb, bs);
+            if constexpr (LO + 3 < HI) issue_item(std::integral_constant<int, LO + 3>{}, ka, as, kb, bs);
+            if constexpr (LO + 4 < HI) issue_item(std::integral_constant<int, LO + 4>{}, ka, as, kb, bs);
+            if constexpr (LO + 5 < HI) issue_item(std::integral_constant<int, LO + 5>{}, ka, as, kb, bs);
+            if constexpr (LO + 6 < HI) issue_item(std::integral_constant<int, LO + 6>{}, ka, as, kb, bs);
+            if constexpr (LO + 7 < HI) issue_item(std::integral_constant<int, LO + 7>{}, ka, as, kb, bs);
+            if constexpr (LO + 8 < HI) issue_item(std::integral_constant<int, LO + 8>{}, ka, as, kb, bs);
+        };
+
+        v4f acc[4][NTW > 0 ? NTW : 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        // lane-constant parts of the fragment addresses
+        const uint32_t a_lo = chunk_off(wm * 64 + r, g), a_hi = chunk_off(wm * 64 + r, 4 + g);
+        const uint32_t sa_off = kABytes + (wm * 64 + r) * 4 + g;
+        const uint32_t b_lo = chunk_off(jbase * 16 + r, g), b_hi = chunk_off(jbase * 16 + r, 4 + g);
+        const uint32_t sb_off = kABytes + 1024 + (jbase * 16 + r) * 4 + g;
+
+        // multiplications of one step (A / scales at LDS address sa_, B at sb_) with the DMA of (ka -> as, kb -> bs) spread over them
+        auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
+            if constexpr (NTW > 0) {
+                u32x4w fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
+                int sa[4], sb[3];
+#define QT_RA(i)                                                                                                  \
+    fa_lo[i] = ds_read128w<i * 2048>(sa_ + a_lo); fa_hi[i] = ds_read128w<i * 2048>(sa_ + a_hi);                   \
+    sa[i] = asm_ds_read_u8_off<i * 64>(sa_ + sa_off);
+                QT_RA(0) QT_RA(1) QT_RA(2) QT_RA(3)
+#undef QT_RA
+                auto read_b = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    fb_lo[J % 3] = ds_read128w<J * 2048>(sb_ + b_lo);
+                    fb_hi[J % 3] = ds_read128w<J * 2048>(sb_ + b_hi);
+                    sb[J % 3] = asm_ds_read_u8_off<J * 64>(sa_ + sb_off);
+                };
+                v8i fa[4];
+                auto step = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int P = J % 3;
+                    if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
+                    // LDS reads still allowed in flight: the fragments of the groups behind this one (three reads each)
+                    constexpr int kAhead = (J + 2 < NTW ? 6 : (J + 1 < NTW ? 3 : 0));
+                    if constexpr (J == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(%15)"
+                                     : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]), "+v"(fa_lo[3]),
+                                       "+v"(fa_hi[3]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(fb_lo[0]), "+v"(fb_hi[0]), "+v"(sb[0])
+                                     : "n"(kAhead));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            fa[i] = v8i{(int)fa_lo[i].x, (int)fa_lo[i].y, (int)fa_lo[i].z, (int)fa_lo[i].w,
+                                        (int)fa_hi[i].x, (int)fa_hi[i].y, (int)fa_hi[i].z, (int)fa_hi[i].w};
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fb_lo[P]), "+v"(fb_hi[P]), "+v"(sb[P]) : "n"(kAhead));
+                    }
+                    const v8i fb = v8i{(int)fb_lo[P].x, (int)fb_lo[P].y, (int)fb_lo[P].z, (int)fb_lo[P].w,
+                                       (int)fb_hi[P].x, (int)fb_hi[P].y, (int)fb_hi[P].z, (int)fb_hi[P].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FB, FA, 0, sb[P], 0, sa[i]);
+                    // this group's share of the wave's DMA instructions
+                    if (!(geo.dbg & 4))
+                        issue_range(std::integral_constant<int, J * kItems / NTW>{}, std::integral_constant<int, (J + 1) * kItems / NTW>{}, ka, as, kb, bs);
+                };
+                read_b(std::integral_constant<int, 0>{});
+                if constexpr (NTW > 1) read_b(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 0>{});
+                if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
+                if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
+                if constexpr (NTW > 3) step(std::integral_constant<int, 3>{});
+                if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
+                if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
+            } else {
+                if (!(geo.dbg & 4)) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, as, kb, bs);
+            }
+        };
+
+        uint8_t *const as0 = lds, *const as1 = lds + kAStage, *const bs0 = lds + 2 * kAStage;
+        uint8_t *b_cur = bs0, *b_n1 = bs0 + kBStage, *b_n2 = bs0 + 2 * kBStage;
+        const uint32_t l0 = lds_addr(lds);
+        // queue of this wave, oldest first: B(0) | A(0), scales(0) | B(1)
+        issue_range(std::integral_constant<int, kBands + 1>{}, std::integral_constant<int, kItems>{}, -1, as0, 0, b_cur);
+        issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kBands + 1>{}, 0, as0, -1, b_cur);
+        if (nk > 1) issue_range(std::integral_constant<int, kBands + 1>{}, std::integral_constant<int, kItems>{}, -1, as0, 1, b_n1);
+        for (int kt = 0; kt < nk; ++kt) {
+            // newest in the queue: the B pieces of step kt + 1; everything older (A, scales and B of step kt) must have landed
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(geo.dbg & 32)) __builtin_amdgcn_s_barrier();       // ... for every wave; and every wave is done with step kt - 1: its stages may be refilled
+            uint8_t *const a_next = (kt & 1) ? as0 : as1;
+            int ka = kt + 1 < nk ? kt + 1 : -1, kb = kt + 2 < nk ? kt + 2 : -1;
+            if (geo.dbg & 8) { ka = min(ka, 0); kb = min(kb, 0); }
+            if (geo.dbg & 16) ka = kb = -1;
+            const uint32_t sa_ = l0 + ((kt & 1) ? kAStage : 0), sb_ = l0 + (uint32_t)(b_cur - lds);
+            if (geo.dbg & 4) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, a_next, kb, b_n2);
+            if (!(geo.dbg & 2)) compute(sa_, sb_, ka, a_next, kb, b_n2);
+            else if (!(geo.dbg & 4)) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, a_next, kb, b_n2);
+            uint8_t *const t = b_cur; b_cur = b_n1; b_n1 = b_n2; b_n2 = t;
+        }
+
+        // ---- epilogue: lane (r, g) of tile (i, j) holds C[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]
+        if constexpr (NTW > 0) {
+            const long cbase = bz * a.bC;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int col = (tg0 + jbase + j) * 16 + 4 * g;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+                    if (a.out_f32) {
+                        const float4 b = *(const float4 *)((const float *)a.bias + col);
+                        bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+                    } else {
+                        const uint2 b = *(const uint2 *)((const uint16_t *)a.bias + col);
+                        bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
+                        bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * 64 + i * 16 + r;
+                    if (row >= a.M) continue;
+                    const long idx = cbase + (long)row * a.N + col;
+                    if (a.out_f32) {
+                        *(float4 *)((float *)a.C + idx) = float4{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    } else {
+                        const uint32_t p0 = (uint32_t)qt_f2bf(acc[i][j][0] + bv[0]) | ((uint32_t)qt_f2bf(acc[i][j][1] + bv[1]) << 16);
+                        const uint32_t p1 = (uint32_t)qt_f2bf(acc[i][j][2] + bv[2]) | ((uint32_t)qt_f2bf(acc[i][j][3] + bv[3]) << 16);
+                        *(uint2 *)((uint16_t *)a.C + idx) = uint2{p0, p1};
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int FA, int FB, int TM, int NBP>
+__global__ __launch_bounds__(512, 1) void mx_gemm_wide_kernel(MxGemmArgs a, WideGeom geo) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t wide_lds[];
+    using W_ = MxWide<FA, FB, TM, NBP>;
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    // Workgroup ids go round-robin over the 8 XCDs: XCD x gets a contiguous run of tiles; column tile = id / tiles_m, so the
+    // row tiles of one column tile (one B tile) are neighbours on one XCD and B leaves HBM once.
+    const int ntiles = geo.tiles_m * geo.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    const int tn = id / geo.tiles_m, tm = id % geo.tiles_m;
+    const int nt = geo.gbase + (tn < geo.gextra ? 1 : 0);
+    const int tg0 = tn * geo.gbase + min(tn, geo.gextra);
+    const int m0 = tm * TM;
+    const int part = w / W_::kBands, pbase = nt / W_::kParts, pextra = nt % W_::kParts;
+    const int ntw = pbase + (part < pextra ? 1 : 0), jbase = part * pbase + min(part, pextra);
+    const long bz = blockIdx.y;
+    switch (ntw) {                                          // wave-uniform
+        case 0: W_::template run<0>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        case 1: W_::template run<1>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        case 2: W_::template run<2>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        case 3: W_::template run<3>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        case 4: W_::template run<4>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        case 5: if constexpr (W_::kMaxNTW >= 5) W_::template run<5>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+        default: if constexpr (W_::kMaxNTW >= 6) W_::template run<6>(a, geo, wide_lds, m0, tg0, nt, jbase, w, l, bz); break;
+    }
+}
+
+int wide_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+// Tiling of the wide kernel.  For each row-tile height: as many column tiles as make whole rounds over the CUs (each at most
+// 12 / 16 groups of 16 columns); the height with fewer operand bytes per CU, rounds x (TM + widest tile), wins.
+bool wide_geometry(int M, int N, long batch, WideGeom &geo) {
+    if (N % 16 != 0 || M < 1) return false;
+    const long groups = N / 16;
+    const int cus = wide_cu_count();
+    static const int force_tn = getenv("QT_MX_WIDE_TILES_N") ? atoi(getenv("QT_MX_WIDE_TILES_N")) : 0;       // tuning / A-B switches
+    const char *e_tm = getenv("QT_MX_WIDE_TM");                     // read per call: the parity tests drive both heights
+    const int force_tm = e_tm ? atoi(e_tm) : 0;
+    static const int dbg = getenv("QT_MX_WIDE_DEBUG") ? atoi(getenv("QT_MX_WIDE_DEBUG")) : 0;
+    long best = -1;
+    for (int tm : {256, 128}) {
+        if (force_tm && tm != force_tm) continue;
+        const int max_nt = tm == 256 ? 12 : 16;
+        const long tiles_m = (M + tm - 1) / tm;
+        const long tn_min = (groups + max_nt - 1) / max_nt;
+        const long per_round = tiles_m * batch;
+        const long rounds = (per_round * tn_min + cus - 1) / cus;
+        long tn = rounds * cus / per_round;
+        if (force_tn > 0) tn = force_tn;
+        if (tn < tn_min) tn = tn_min;
+        if (tn > groups) tn = groups;
+        const long gbase = groups / tn, gextra = groups % tn, worst = gbase + (gextra ? 1 : 0);
+        if (worst > max_nt) continue;
+        const long real_rounds = (per_round * tn + cus - 1) / cus;
+        const long cost = real_rounds * (tm + 16 * worst);
+        if (best < 0 || cost < best) {
+            best = cost;
+            geo.tm = tm; geo.tiles_m = (int)tiles_m; geo.tiles_n = (int)tn; geo.gbase = (int)gbase; geo.gextra = (int)gextra;
+        }
+    }
+    geo.dbg = dbg;
+    return best >= 0;
+}
+
+template <int FA, int FB, int TM, int NBP>
+int launch_wide_nbp(const MxGemmArgs &g, const WideGeom &geo, long batch, hipStream_t st) {
+    constexpr int kLds = MxWide<FA, FB, TM, NBP>::kLds;
+    static_assert(kLds <= 160 * 1024, "LDS rings of the wide kernel exceed a CU's 160 KiB");
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_wide_kernel<FA, FB, TM, NBP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    mx_gemm_wide_kernel<FA, FB, TM, NBP><<<dim3((unsigned)(geo.tiles_m * geo.tiles_n), (unsigned)batch), 512, kLds, st>>>(g, geo);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+template <int FA, int FB>
+int launch_wide(const MxGemmArgs &g, const WideGeom &geo, long batch, hipStream_t st) {
+    const int worst = geo.gbase + (geo.gextra ? 1 : 0);
+    const int nbp = (worst * 2 + 7) / 8;
+    if (geo.tm == 256) {
+        if (nbp <= 1) return launch_wide_nbp<FA, FB, 256, 1>(g, geo, batch, st);
+        if (nbp == 2) return launch_wide_nbp<FA, FB, 256, 2>(g, geo, batch, st);
+        return launch_wide_nbp<FA, FB, 256, 3>(g, geo, batch, st);
+    }
+    if (nbp <= 1) return launch_wide_nbp<FA, FB, 128, 1>(g, geo, batch, st);
+    if (nbp == 2) return launch_wide_nbp<FA, FB, 128, 2>(g, geo, batch, st);
+    if (nbp == 3) return launch_wide_nbp<FA, FB, 128, 3>(g, geo, batch, st);
+    return launch_wide_nbp<FA, FB, 128, 4>(g, geo, batch, st);
+}
+
 // ---- packing: (values, block scales) -> element codes + E8M0 ------------------------------------------------
 // A value that the format holds exactly converts exactly; anything else (and a scale that is not a power of
 // two) raises the `bad` flag so the caller can fall back to the dequantize + GEMM path.
@@ -841,6 +1171,17 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
     static const int force_big = getenv("QT_MX_BIG") ? atoi(getenv("QT_MX_BIG")) : -1;                      // tuning / A-B switch
     const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool big = dma_ok && (force_big >= 0 ? force_big == 1 : (M >= 512 && N >= 512 && big_tiles >= 192));
+    // 8-bit formats, at least two 256-row tiles, fewer tiles than the 256 x 256 kernel wants: column widths fitted to the chip
+    const char *e_wide = getenv("QT_MX_WIDE");                                                           // tuning / A-B switch, read per call
+    const int force_wide = e_wide ? atoi(e_wide) : -1;
+    WideGeom geo{};
+    if (dma_ok && a_format < 2 && b_format < 2 && force_wide != 0 && (force_wide == 1 || (!big && M >= 512 && N >= 512))
+        && wide_geometry(M, N, batch, geo)) {
+        if (a_format == 0 && b_format == 0) return launch_wide<0, 0>(g, geo, batch, st);
+        if (a_format == 0 && b_format == 1) return launch_wide<0, 1>(g, geo, batch, st);
+        if (a_format == 1 && b_format == 0) return launch_wide<1, 0>(g, geo, batch, st);
+        return launch_wide<1, 1>(g, geo, batch, st);
+    }
 #define QT_MX_BIG(FA, FB)                                                                                          \
     if (big && a_format == FA && b_format == FB) {                                                                 \
         const dim3 bgrid((unsigned)big_tiles, (unsigned)batch);                                                    \

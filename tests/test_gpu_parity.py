@@ -756,14 +756,17 @@ def test_mx_pack_matches_host_restatement(nv, fmt, dtype):
                                    ("fp8_e5m2", "fp8_e5m2"), ("fp6_e2m3", "fp6_e2m3"), ("fp6_e3m2", "fp6_e3m2"),
                                    ("fp4_e2m1", "fp4_e2m1"), ("fp8_e4m3", "fp4_e2m1"), ("fp6_e2m3", "fp4_e2m1"),
                                    ("fp6_e3m2", "fp4_e2m1")])
-@pytest.mark.parametrize("shape", [(128, 128, 128), (200, 328, 448), (1, 64, 64), (1024, 512, 1024), (3600, 3400, 256)])
+@pytest.mark.parametrize("shape", [(128, 128, 128), (200, 328, 448), (1, 64, 64), (1024, 512, 1024), (3600, 3400, 256),
+                                   (1000, 2768, 384), (520, 11008, 128)])
 def test_mx_gemm_vs_dequantized_reference(nv, fa, fb, shape):
     """C = (a * expand(sa)) @ (b * expand(sb))^T exactly as linear_mx states it.  Products of MX elements and
     power-of-two scales are exact; the instruction adds the 128 products of a step in an aligned fixed-point tree that
     keeps fewer bits than an fp32 chain (measured: up to 2^-16 of sum|a||b|), so the bound is |err| <= 2^-14 * sum|a||b|
     for the fp32 result; the bf16 result adds one rounding (2^-9 relative, 2^-8 allowed).  The shapes reach every
-    kernel variant: register-staged (ragged K), one-stage and two-stage LDS-DMA at 128 x 128, and the 256 x 256 ring
-    kernel with ragged M and N (3600 x 3400: 15 x 14 tiles)."""
+    kernel variant: register-staged (ragged K), one-stage and two-stage LDS-DMA at 128 x 128, the 256 x 256 ring
+    kernel with ragged M and N (3600 x 3400: 15 x 14 tiles), and for the 8-bit pairs the 256 x (16 nt) kernel with one
+    column group per tile (1024 x 512), ragged M with tiles of 2 / 3 groups (1000 x 2768) and of 11 / 10 groups in a single
+    k step (520 x 11008 x 128)."""
     L = nv.lib()
     M, N, K = shape
     sa, qa = _mx_operand(M, K, fa, 32, torch.float32, seed=1, sigma=2.0)
@@ -787,6 +790,38 @@ def test_mx_gemm_vs_dequantized_reference(nv, fa, fb, shape):
             err = (c.double() - want).abs()
             tol = 2.0 ** -14 * mag + (2.0 ** -8 * want.abs() if out_dtype == torch.bfloat16 else 0.0) + 1e-30
             assert bool((err <= tol).all()), float((err / tol).max())
+
+
+@pytest.mark.parametrize("tm", [256, 128])
+@pytest.mark.parametrize("fa,fb", [("fp8_e4m3", "fp8_e4m3"), ("fp8_e5m2", "fp8_e4m3")])
+@pytest.mark.parametrize("shape", [(1024, 512, 1024), (1000, 2768, 384), (520, 11008, 128), (300, 4096, 256), (256, 16, 128)])
+def test_mx_gemm_wide_kernel_both_heights(nv, fa, fb, shape, tm, monkeypatch):
+    """The TM x (16 nt) kernel forced for both row-tile heights (the host otherwise picks one per shape): ragged M, tiles
+    of 1 ... 12 / 16 column groups, a single k step, batch of 2 with operand batch strides, bias, both output dtypes."""
+    monkeypatch.setenv("QT_MX_WIDE", "1")
+    monkeypatch.setenv("QT_MX_WIDE_TM", str(tm))
+    L = nv.lib()
+    M, N, K = shape
+    B = 2
+    sa, qa = _mx_operand(B * M, K, fa, 32, torch.float32, seed=3, sigma=2.0)
+    sb, qb = _mx_operand(B * N, K, fb, 32, torch.float32, seed=4, sigma=0.5)
+    ca, ea, bad_a = _pack(nv, qa, sa, fa, 32)
+    cb, eb, bad_b = _pack(nv, qb, sb, fb, 32)
+    assert bad_a == 0 and bad_b == 0
+    da = (qa * sa.repeat_interleave(32, 1)).double().view(B, M, K)
+    db = (qb * sb.repeat_interleave(32, 1)).double().view(B, N, K)
+    ref = torch.matmul(da, db.transpose(1, 2))
+    mag = torch.matmul(da.abs(), db.abs().transpose(1, 2))
+    bias = torch.randn(N, device="cuda")
+    for out_dtype in (torch.float32, torch.bfloat16):
+        c = torch.full((B, M, N), float("nan"), dtype=out_dtype, device="cuda")
+        b = bias.to(out_dtype)
+        nv.check(L.qt_mx_gemm(ca.data_ptr(), ea.data_ptr(), MX_FMT_ID[fa], cb.data_ptr(), eb.data_ptr(), MX_FMT_ID[fb],
+                              c.data_ptr(), int(out_dtype == torch.float32), b.data_ptr(), B, M, N, K, M, N, stream()), "qt_mx_gemm")
+        want = ref + b.double()
+        err = (c.double() - want).abs()
+        tol = 2.0 ** -14 * mag + (2.0 ** -8 * want.abs() if out_dtype == torch.bfloat16 else 0.0) + 1e-30
+        assert bool((err <= tol).all()), float((err / tol).max())
 
 
 def test_mx_gemm_batched_and_transposed_operand(nv):
