@@ -755,29 +755,37 @@ __global__ __launch_bounds__(512, 1) void mx_gemm_big_kernel(MxGemmArgs a) {
 // (176 | 160), 1024 x 4096 -> 8 x 32 tiles of 128 x 128.  Waves: TM / 64 row bands (64 rows) x 8 / bands column parts
 // (nt split as evenly as 16-column groups allow); the two waves of a SIMD share their A fragments.  8-bit formats only.
 //
-// LDS rings, all filled by LDS-DMA: the A tile (TM x 128 bytes) with both operands' scale bytes (1 + 1 KiB) two deep, the
-// B tile (nt x 2 KiB, rounded up to the wave count) THREE deep -- B streams from HBM (a byte is used by M / TM workgroups
-// only), A from L2 (shared by every column tile), so B gets a step more of latency cover.  A wave issues its pieces of
-// A (k + 1) and B (k + 2) spread over its multiplications of step k (a burst in front of them stalls the wave until the
-// memory pipe has drained it); one counted s_waitcnt vmcnt + ONE raw barrier per step.  B fragments are read two
-// 16-column groups ahead of their multiplications.  The operands are multiplied swapped (B fragment first), so a lane
-// ends up with four consecutive output columns of one row: 8-byte (bf16) or 16-byte (fp32) stores.
+// LDS, all filled by LDS-DMA: rings of A tiles (TM x 128 bytes) and B tiles (nt x 2 KiB, rounded up to the wave count), as
+// deep as 160 KiB allow (a tile's issue-to-landed time under load is about a step and a half), and two buffers of scale
+// bytes.  Scales are fetched per QUAD of four k steps (16 bytes per row): one DMA instruction = 16 rows x 4 dwords, so it
+// touches 16 lines of the [rows][K / 32] scale array -- fetched per step with one row per lane (64 lines for 256 bytes)
+// the scale pieces alone cost as much as the operand tiles (1024 x 4096 x 4096, DMA only: 30 us with them, 18 without).
+// A wave issues its tile pieces for the step (depth - 1) ahead spread over its multiplications of the current step (a burst
+// in front of them stalls the wave until the memory pipe has drained it), with no branch in between -- hipcc sinks the
+// multiplications of a step into its last basic block otherwise; one counted s_waitcnt vmcnt + ONE raw barrier per step.
+// The operands are multiplied swapped (B fragment first), so a lane ends up with four consecutive output columns of one
+// row: 8-byte (bf16) or 16-byte (fp32) stores.
 struct WideGeom {
     int tm;                     // 256 or 128
     int tiles_m, tiles_n;
     int gbase, gextra;          // column tile j covers gbase + (j < gextra) groups of 16 columns
-    int dbg;                    // QT_MX_WIDE_DEBUG: 2 = no multiplications (DMA only), 4 = a wave's DMA instructions in one burst,
-                                // 8 = k tile 0 every step (cache-resident operands), 16 = no DMA inside the loop
+    int dbg;                    // QT_MX_WIDE_DEBUG: 2 = no multiplications (DMA only), 32 = no barriers
 };
 
 template <int FA, int FB, int TM, int NBP>         // NBP: B DMA pieces (8 rows x 128 bytes) per wave and stage
 struct MxWide {
+    // ring depths: 128 rows: four (nt <= 8) or three stages of A and B; 256 rows: three of each up to nt = 8, beyond that two of
+    // A and three of B (A runs one step ahead, B two)
+    static constexpr int kADepth = TM == 128 ? (NBP <= 2 ? 4 : 3) : (NBP <= 2 ? 3 : 2);
+    static constexpr int kBDepth = kADepth == 2 ? 3 : kADepth;
     static constexpr int kBands = TM / 64, kParts = 8 / kBands;
-    static constexpr int kABytes = TM * 128;
-    static constexpr int kAStage = kABytes + 2048;                     // + A scales (TM x 4 <= 1 KiB) + B scales (<= 256 x 4)
+    static constexpr int kAStage = TM * 128;
     static constexpr int kBStage = NBP * 8 * 1024;
-    static constexpr int kLds = 2 * kAStage + 3 * kBStage;
-    static constexpr int kItems = kBands + 1 + NBP;                    // DMA instructions of one wave per step
+    static constexpr int kQRows = TM + NBP * 64;                       // rows of one scale buffer: the A tile's, then the B tile's
+    static constexpr int kQBytes = kQRows * 16;
+    static constexpr int kQBase = kADepth * kAStage + kBDepth * kBStage;
+    static constexpr int kLds = kQBase + 2 * kQBytes;
+    static constexpr int kItems = kBands + NBP;                        // tile DMA instructions of one wave per step
     static constexpr int kMaxNTW = TM == 256 ? 6 : 4;
 
     static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -788,7 +796,7 @@ struct MxWide {
         const int r = l & 15, g = l >> 4, wm = w % kBands;
         const int nk = a.K / kBK, nblk = a.K / 32;
         // ---- DMA sources at k tile 0
-        const uint8_t *ga[kBands], *gb[NBP], *gs;
+        const uint8_t *ga[kBands], *gb[NBP];
         int pb[NBP];
 #pragma unroll
         for (int i = 0; i < kBands; ++i) {
@@ -803,30 +811,40 @@ struct MxWide {
             const int row = pb[i] * 8 + (l >> 3), slot = l & 7;
             gb[i] = a.B + bz * a.bB + (long)(tg0 * 16 + row) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
         }
-        int s_dst;
-        if (w < kBands) {
-            gs = a.sA + bz * a.bsA + (long)min(m0 + w * 64 + l, a.M - 1) * nblk;
-            s_dst = kABytes + w * 256;
-        } else {
-            const int q = (w - kBands) & 3;                           // 64-row piece of the B scales (surplus waves repeat one)
-            gs = a.sB + bz * a.bsB + (long)(tg0 * 16 + min(q * 64 + l, nt * 16 - 1)) * nblk;
-            s_dst = kABytes + 1024 + q * 256;
+        // Scale instructions of a quad: instruction c covers rows 16 c .. 16 c + 15 of the buffer (A rows first), lane = (row, dword
+        // = k step within the quad); wave w issues instructions w, w + 8, ...  Lanes past the last k tile are masked off.
+        constexpr int kQInstrMax = (kQRows / 16 + 7) / 8;
+        const int qinstr = TM / 16 + nt;                              // instructions per quad
+        const uint8_t *gq[kQInstrMax];
+#pragma unroll
+        for (int i = 0; i < kQInstrMax; ++i) {
+            const int c = w + 8 * i, row = (c < qinstr ? c : 0) * 16 + (l >> 2);
+            gq[i] = row < TM ? a.sA + bz * a.bsA + (long)min(m0 + row, a.M - 1) * nblk + (l & 3) * 4
+                             : a.sB + bz * a.bsB + (long)(tg0 * 16 + row - TM) * nblk + (l & 3) * 4;
         }
+        auto issue_quad = [&](int q, uint8_t *qb) __attribute__((always_inline)) {
+            const bool live = 4 * q + (l & 3) < nk;
+#pragma unroll
+            for (int i = 0; i < kQInstrMax; ++i) {
+                const int c = w + 8 * i;
+                if (c < qinstr && live) __builtin_amdgcn_global_load_lds((glb_void *)(gq[i] + q * 16), (lds_void *)(qb + c * 256), 4, 0, 0);
+            }
+        };
 
-        // item 0 .. kBands-1: A pieces of step ka, kBands: this wave's scale piece of step ka, then the B pieces of step kb
+        // item 0 .. kBands-1: A pieces of step ka, then the B pieces of step kb.  No conditions in here: a branch would split the
+        // step into basic blocks, and hipcc then sinks every multiplication of the step into the last one.  Past the last k tile the
+        // callers repeat it instead (into a slot nobody reads any more).
         auto issue_item = [&](auto ic, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < kBands) {
-                if (ka >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(ga[I] + (long)ka * kBK), (lds_void *)(as + (w * kBands + I) * 1024), 16, 0, 0);
-            } else if constexpr (I == kBands) {
-                if (ka >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(gs + ka * 4), (lds_void *)(as + s_dst), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(ga[I] + (long)ka * kBK), (lds_void *)(as + (w * kBands + I) * 1024), 16, 0, 0);
             } else {
-                if (kb >= 0) __builtin_amdgcn_global_load_lds((glb_void *)(gb[I - kBands - 1] + (long)kb * kBK), (lds_void *)(bs + pb[I - kBands - 1] * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(gb[I - kBands] + (long)kb * kBK), (lds_void *)(bs + pb[I - kBands] * 1024), 16, 0, 0);
             }
         };
         auto issue_range = [&](auto lo, auto hi, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
             constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
-            static_assert(HI - LO <= 9, "issue_range covers at most nine items");
+            static_assert(HI - LO <= 8, "issue_range covers at most eight items");
             if constexpr (LO + 0 < HI) issue_item(std::integral_constant<int, LO + 0>{}, ka, as, kb, bs);
             if constexpr (LO + 1 < HI) issue_item(std::integral_constant<int, LO + 1>{}, ka, as, kb, bs);
             if constexpr (LO + 2 < HI) issue_item(std::integral_constant<int, LO + 2>{}, ka, as, kb, bs);
@@ -835,40 +853,43 @@ struct MxWide {
             if constexpr (LO + 5 < HI) issue_item(std::integral_constant<int, LO + 5>{}, ka, as, kb, bs);
             if constexpr (LO + 6 < HI) issue_item(std::integral_constant<int, LO + 6>{}, ka, as, kb, bs);
             if constexpr (LO + 7 < HI) issue_item(std::integral_constant<int, LO + 7>{}, ka, as, kb, bs);
-            if constexpr (LO + 8 < HI) issue_item(std::integral_constant<int, LO + 8>{}, ka, as, kb, bs);
         };
+        constexpr auto kI0 = std::integral_constant<int, 0>{};
+        constexpr auto kIA = std::integral_constant<int, kBands>{};
+        constexpr auto kIN = std::integral_constant<int, kItems>{};
 
         v4f acc[4][NTW > 0 ? NTW : 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-        // lane-constant parts of the fragment addresses
+        // lane-constant parts of the fragment addresses: tiles relative to their ring slot, scale bytes to (buffer + 4 (k & 3))
         const uint32_t a_lo = chunk_off(wm * 64 + r, g), a_hi = chunk_off(wm * 64 + r, 4 + g);
-        const uint32_t sa_off = kABytes + (wm * 64 + r) * 4 + g;
         const uint32_t b_lo = chunk_off(jbase * 16 + r, g), b_hi = chunk_off(jbase * 16 + r, 4 + g);
-        const uint32_t sb_off = kABytes + 1024 + (jbase * 16 + r) * 4 + g;
+        const uint32_t qa_off = (wm * 64 + r) * 16 + g, qb_off = (TM + jbase * 16 + r) * 16 + g;
 
-        // multiplications of one step (A / scales at LDS address sa_, B at sb_) with the DMA of (ka -> as, kb -> bs) spread over them
-        auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
+        // multiplications of one step (A at LDS address sa_, B at sb_, scale bytes at sq_) with the DMA of (ka -> as, kb -> bs)
+        // spread over them
+        auto compute = [&](uint32_t sa_, uint32_t sb_, uint32_t sq_, int ka, uint8_t *as, int kb, uint8_t *bs) __attribute__((always_inline)) {
             if constexpr (NTW > 0) {
                 u32x4w fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
                 int sa[4], sb[3];
 #define QT_RA(i)                                                                                                  \
     fa_lo[i] = ds_read128w<i * 2048>(sa_ + a_lo); fa_hi[i] = ds_read128w<i * 2048>(sa_ + a_hi);                   \
-    sa[i] = asm_ds_read_u8_off<i * 64>(sa_ + sa_off);
+    sa[i] = asm_ds_read_u8_off<i * 256>(sq_ + qa_off);
                 QT_RA(0) QT_RA(1) QT_RA(2) QT_RA(3)
 #undef QT_RA
                 auto read_b = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
                     fb_lo[J % 3] = ds_read128w<J * 2048>(sb_ + b_lo);
                     fb_hi[J % 3] = ds_read128w<J * 2048>(sb_ + b_hi);
-                    sb[J % 3] = asm_ds_read_u8_off<J * 64>(sa_ + sb_off);
+                    sb[J % 3] = asm_ds_read_u8_off<J * 256>(sq_ + qb_off);
                 };
                 v8i fa[4];
                 auto step = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
                     constexpr int P = J % 3;
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
                     // LDS reads still allowed in flight: the fragments of the groups behind this one (three reads each)
                     constexpr int kAhead = (J + 2 < NTW ? 6 : (J + 1 < NTW ? 3 : 0));
@@ -890,8 +911,8 @@ struct MxWide {
                     for (int i = 0; i < 4; ++i)
                         acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FB, FA, 0, sb[P], 0, sa[i]);
                     // this group's share of the wave's DMA instructions
-                    if (!(geo.dbg & 4))
-                        issue_range(std::integral_constant<int, J * kItems / NTW>{}, std::integral_constant<int, (J + 1) * kItems / NTW>{}, ka, as, kb, bs);
+                    issue_range(std::integral_constant<int, J * kItems / NTW>{}, std::integral_constant<int, (J + 1) * kItems / NTW>{}, ka, as, kb, bs);
+                    __builtin_amdgcn_sched_barrier(0);
                 };
                 read_b(std::integral_constant<int, 0>{});
                 if constexpr (NTW > 1) read_b(std::integral_constant<int, 1>{});
@@ -902,32 +923,43 @@ struct MxWide {
                 if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
                 if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
             } else {
-                if (!(geo.dbg & 4)) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, as, kb, bs);
+                issue_range(kI0, kIN, ka, as, kb, bs);
             }
         };
 
-        uint8_t *const as0 = lds, *const as1 = lds + kAStage, *const bs0 = lds + 2 * kAStage;
-        uint8_t *b_cur = bs0, *b_n1 = bs0 + kBStage, *b_n2 = bs0 + 2 * kBStage;
+        uint8_t *const bs0 = lds + kADepth * kAStage, *const q0 = lds + kQBase;
         const uint32_t l0 = lds_addr(lds);
-        // queue of this wave, oldest first: B(0) | A(0), scales(0) | B(1)
-        issue_range(std::integral_constant<int, kBands + 1>{}, std::integral_constant<int, kItems>{}, -1, as0, 0, b_cur);
-        issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kBands + 1>{}, 0, as0, -1, b_cur);
-        if (nk > 1) issue_range(std::integral_constant<int, kBands + 1>{}, std::integral_constant<int, kItems>{}, -1, as0, 1, b_n1);
-        for (int kt = 0; kt < nk; ++kt) {
-            // newest in the queue: the B pieces of step kt + 1; everything older (A, scales and B of step kt) must have landed
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(geo.dbg & 32)) __builtin_amdgcn_s_barrier();       // ... for every wave; and every wave is done with step kt - 1: its stages may be refilled
-            uint8_t *const a_next = (kt & 1) ? as0 : as1;
-            int ka = kt + 1 < nk ? kt + 1 : -1, kb = kt + 2 < nk ? kt + 2 : -1;
-            if (geo.dbg & 8) { ka = min(ka, 0); kb = min(kb, 0); }
-            if (geo.dbg & 16) ka = kb = -1;
-            const uint32_t sa_ = l0 + ((kt & 1) ? kAStage : 0), sb_ = l0 + (uint32_t)(b_cur - lds);
-            if (geo.dbg & 4) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, a_next, kb, b_n2);
-            if (!(geo.dbg & 2)) compute(sa_, sb_, ka, a_next, kb, b_n2);
-            else if (!(geo.dbg & 4)) issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kItems>{}, ka, a_next, kb, b_n2);
-            uint8_t *const t = b_cur; b_cur = b_n1; b_n1 = b_n2; b_n2 = t;
+        const int klast = nk - 1;
+        // Ring positions: step kt is multiplied from slot kt % depth while step kt + depth - 1 is requested into the slot step
+        // kt - 1 left.  Queue of a wave, oldest first -- quad 0 of the scales, then for equal depths: group(0) .. group(depth - 2);
+        // A two deep: B(0) | A(0) | B(1).
+        int a_slot = 0, a_tgt = kADepth - 1, b_slot = 0, b_tgt = kBDepth - 1;
+        issue_quad(0, q0);
+        if constexpr (kADepth == kBDepth) {
+#pragma unroll
+            for (int d = 0; d < kADepth - 1; ++d) issue_range(kI0, kIN, min(d, klast), lds + d * kAStage, min(d, klast), bs0 + d * kBStage);
+        } else {
+            issue_range(kIA, kIN, 0, lds, 0, bs0);
+            issue_range(kI0, kIA, 0, lds, 0, bs0);
+            issue_range(kIA, kIN, 0, lds, min(1, klast), bs0 + kBStage);
         }
+        for (int kt = 0; kt < nk; ++kt) {
+            // still allowed in flight: what was requested for the steps behind kt; everything older must have landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kADepth == kBDepth ? (kADepth - 2) * kItems : NBP) : "memory");
+            if (!(geo.dbg & 32)) __builtin_amdgcn_s_barrier();       // ... for every wave; and every wave is done with step kt - 1: its slots may be refilled
+            // the next quad of scale bytes, into the buffer quad (kt / 4) - 1 was read from: older than everything this wave will
+            // request before the quad is needed, so the counted waits above cover it (they may wait for one tile piece more)
+            if ((kt & 3) == 0 && kt + 4 < nk) issue_quad((kt >> 2) + 1, q0 + (((kt >> 2) + 1) & 1) * kQBytes);
+            const int ka = min(kt + kADepth - 1, klast), kb = min(kt + kBDepth - 1, klast);
+            uint8_t *const a_dst = lds + a_tgt * kAStage, *const b_dst = bs0 + b_tgt * kBStage;
+            const uint32_t sa_ = l0 + a_slot * kAStage, sb_ = l0 + kADepth * kAStage + b_slot * kBStage;
+            const uint32_t sq_ = l0 + kQBase + ((kt >> 2) & 1) * kQBytes + (kt & 3) * 4;
+            if (!(geo.dbg & 2)) compute(sa_, sb_, sq_, ka, a_dst, kb, b_dst);
+            else issue_range(kI0, kIN, ka, a_dst, kb, b_dst);
+            a_tgt = a_slot; a_slot = a_slot + 1 == kADepth ? 0 : a_slot + 1;
+            b_tgt = b_slot; b_slot = b_slot + 1 == kBDepth ? 0 : b_slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the repeats of the last k tile
 
         // ---- epilogue: lane (r, g) of tile (i, j) holds C[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]
         if constexpr (NTW > 0) {
