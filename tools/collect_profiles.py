@@ -61,3 +61,25 @@ res.update({
 })
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
+
+
+def clean(src, dst):
+    """Experiment logs without the profiler's own chatter."""
+    if not os.path.exists(src):
+        return
+    keep = [ln for ln in open(src, errors="replace") if not any(t in ln for t in ("amdgpu.ids", "rocprofv3", "output_stream.cpp", "simple_timer.cpp", "tool.cpp"))]
+    open(dst, "w").writelines(keep)
+
+
+# per-window breakdown of the headline run, the LLaMA-2-13B posit(8,2) leg, block-scaled path, kernel experiments
+G = os.path.join(ROOT, "gpurun_out")
+for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_breakdown_13b_posit.txt", "13b_posit8_2_window_breakdown.txt"),
+                 ("bench_13b_posit8_2.json", "13b_posit8_2_bench.json"), ("mx_gemm.log", "mx_gemm.txt"), ("mx_linear.log", "mx_linear.txt"),
+                 ("mx_quant.log", "mx_quant.txt"), ("mx_wide.log", "mx_wide_ablation.txt"), ("tile_fetch.log", "tile_fetch_probe.txt"),
+                 ("fq8_session.txt", "linear_fq8_gemm.txt"), ("table_formats.txt", "table_formats.txt"), ("oracle_attention.txt", "oracle_attention.txt")):
+    clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
+for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
+                     ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv")):
+    f = one(pattern)
+    if f:
+        shutil.copy(f, os.path.join(out, f"{tag}_{dst}"))
