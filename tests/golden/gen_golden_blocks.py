@@ -152,9 +152,12 @@ def gen_qa_logits(ref, out):
     for i, (ids, keep) in enumerate(batches):
         arrays[f"batch{i}/input_ids"] = ids
         arrays[f"batch{i}/attention_mask"] = keep
-    for sname in ("posit8_1_act", "e4m3_act_weight", "int8_qs_all"):
+    # (fixture name, spec, model): the BERT loop under three specs, and BASELINE.json's configs[0] at toy size -- MobileBERT with
+    # posit(8,1) activations only, on the CPU
+    for fname, sname, kind in (("posit8_1_act", "posit8_1_act", "bert"), ("e4m3_act_weight", "e4m3_act_weight", "bert"),
+                               ("int8_qs_all", "int8_qs_all", "bert"), ("mobilebert_posit8_1_act", "posit8_1_act", "mobilebert")):
         kw, dtype, _ = SPECS[sname]
-        model = mm.seeded_init_(mm.TinyBertQA(mm.tiny_bert_config()), 3, std=0.2).eval()
+        model = mm.qa_model(kind)
         if dtype == torch.bfloat16:
             model = model.bfloat16()
         ref.quantize.quantize(model, make_args(ref, **kw, bf16=dtype == torch.bfloat16))
@@ -164,12 +167,13 @@ def gen_qa_logits(ref, out):
                 o = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(keep))
                 starts.append(o.start_logits.float())
                 ends.append(o.end_logits.float())
-        arrays[f"{sname}/start_logits"] = g.f32_bits(torch.cat(starts))
-        arrays[f"{sname}/end_logits"] = g.f32_bits(torch.cat(ends))
-        meta[sname] = {"dtype": str(dtype).replace("torch.", ""), "args": kw,
+        arrays[f"{fname}/start_logits"] = g.f32_bits(torch.cat(starts))
+        arrays[f"{fname}/end_logits"] = g.f32_bits(torch.cat(ends))
+        meta[fname] = {"dtype": str(dtype).replace("torch.", ""), "args": kw, "model": kind,
+                       "fake_quantizers": sorted(n for n, m in model.named_modules() if type(m).__name__ == "FusedAmaxObsFakeQuantize"),
                        "state_dict": {k: list(v.shape) for k, v in model.state_dict().items()}}
         for k, v in _state(model, g).items():
-            arrays[f"{sname}/sd/{k}"] = v
+            arrays[f"{fname}/sd/{k}"] = v
     np.savez_compressed(os.path.join(out, "qa_logits.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
     with open(os.path.join(out, "qa_logits.json"), "w") as f:
         json.dump(meta, f, indent=1)

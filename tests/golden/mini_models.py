@@ -120,6 +120,34 @@ class MobileBertBlock(nn.Module):
         return out
 
 
+class TinyMobileBertQA(nn.Module):
+    """MobileBERT embeddings -> n x MobileBertBlock -> qa_outputs: the shape of BASELINE.json's configs[0] (MobileBERT SQuAD
+    evaluation, posit(8,1) activations, CPU), at toy size."""
+
+    def __init__(self, config, layers=2):
+        super().__init__()
+        from transformers.models.mobilebert import modeling_mobilebert as hm
+        self.config = config
+        self.embeddings = hm.MobileBertEmbeddings(config)
+        self.layer = nn.ModuleList([MobileBertBlock(config) for _ in range(layers)])
+        self.qa_outputs = nn.Linear(config.hidden_size, 2)
+
+    def forward(self, input_ids=None, attention_mask=None, **kwargs):
+        h = self.embeddings(input_ids=input_ids)
+        mask = additive_mask(attention_mask, h.dtype) if attention_mask is not None else None
+        for blk in self.layer:
+            h = blk(h, mask)
+        logits = self.qa_outputs(h)
+        return QAOutput(logits[..., 0].contiguous(), logits[..., 1].contiguous())
+
+
+def qa_model(kind):
+    """The seeded QA model of a qa_logits fixture: kind "bert" or "mobilebert"."""
+    if kind == "mobilebert":
+        return seeded_init_(TinyMobileBertQA(tiny_mobilebert_config()), 5, std=0.2).eval()
+    return seeded_init_(TinyBertQA(tiny_bert_config()), 3, std=0.2).eval()
+
+
 def tiny_bert_config():
     from transformers import BertConfig
     return BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=120,

@@ -131,7 +131,7 @@ def _qa_logits(sname, device):
     npz = np.load(os.path.join(G, "qa_logits.npz"))
     info = QA_META[sname]
     dtype = info["dtype"]
-    model = mm.seeded_init_(mm.TinyBertQA(mm.tiny_bert_config()), 3, std=0.2).eval()
+    model = mm.qa_model(info.get("model", "bert"))
     if dtype == "bfloat16":
         model = model.bfloat16()
     model = model.to(device)
@@ -195,6 +195,8 @@ def test_qa_loop_logits_match_upstream(sname, device, monkeypatch):
                 lim = {"fused": (0.03, 0.15, 0.995, 0.1), "default": (0.05, 0.2, 0.99, 0.15)}[route]
                 assert rms <= lim[0] and worst <= lim[1] and corr >= lim[2] and regret <= lim[3], (corr, regret) + tag
         assert {k: list(v.shape) for k, v in model.state_dict().items()} == info["state_dict"]
+        if "fake_quantizers" in info:                     # where upstream's quantize() put fake-quantizers, by module name
+            assert sorted(n for n, m in model.named_modules() if type(m).__name__ == "FusedAmaxObsFakeQuantize") == info["fake_quantizers"]
         if device == "cpu":
             for k, v in model.state_dict().items():
                 if k.endswith(".scale") or k.endswith(".amax_history"):

@@ -75,9 +75,43 @@ def test_perplexity_parity_bf16_fast_paths():
     assert abs(math.exp(ma) / math.exp(mb) - 1) <= 3e-3 * mb
 
 
-def test_bert_squad_style_batch_parity():
+
+# Device routes of a bf16 FP8 model, from the one that repeats the CPU path's operations to the default one (see
+# tests/test_blocks_golden.py::QA_ROUTES): the plain route must reproduce the CPU logits up to accumulation order, the default
+# route (one-launch LayerNorm / GELU / softmax, FP8 codes through the FP8 matrix instruction) is bounded statistically -- a
+# last-bit difference in a hidden value flips an 8-bit code in a few per cent of the cases.
+_PLAIN = {"QT_FP8_GEMM": "0", "QT_FUSED_MODEL_OPS": "0", "QT_FUSED_SOFTMAX": "0", "QT_FUSED_ATTENTION": "0"}
+
+
+def _logits_by_route(build, monkeypatch):
+    outs = {}
+    for name, dev, env in (("cpu", "cpu", {}), ("plain", "cuda", _PLAIN), ("default", "cuda", {})):
+        for k in _PLAIN:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = build(dev)
+    for k in _PLAIN:
+        monkeypatch.delenv(k, raising=False)
+    return outs
+
+
+def _assert_logits(outs):
+    for ref, plain, dflt in zip(outs["cpu"], outs["plain"], outs["default"]):
+        scale = float(ref.abs().max())
+        d = (plain - ref).abs()
+        assert float((d > 0.01 * scale).float().mean()) <= 0.02 and float(d.pow(2).mean().sqrt()) <= 0.01 * scale \
+            and float(d.max()) <= 0.2 * scale, ("plain", float(d.max()) / scale, float((d > 0.01 * scale).float().mean()))
+        d = (dflt - ref).abs()
+        corr = float(torch.corrcoef(torch.stack([dflt.flatten(), ref.flatten()]))[0, 1])
+        assert torch.isfinite(dflt).all()
+        assert float(d.pow(2).mean().sqrt()) <= 0.05 * scale and float(d.max()) <= 0.25 * scale and corr >= 0.99, \
+            ("default", float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale, corr)
+
+
+def test_bert_squad_style_batch_parity(monkeypatch):
     """BERT-base-style QA head (tiny config), bf16, E4M3 act+weight + all op groups: start/end logits of a
-    [16, 384]-shaped batch agree between CPU tensors and the HIP path (bf16 GEMM accumulation tolerance)."""
+    [16, 384]-shaped batch: CPU tensors against the device's plain route (same operations: tight) and its default route."""
     from transformers import BertConfig, BertForQuestionAnswering
     torch.manual_seed(0)
     cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, vocab_size=300,
@@ -85,18 +119,17 @@ def test_bert_squad_style_batch_parity():
     base = BertForQuestionAnswering(cfg).eval()
     ids = torch.randint(3, 300, (4, 384), generator=torch.Generator().manual_seed(1))
     att = torch.ones_like(ids); att[:, 300:] = 0
-    outs = {}
-    for dev in ("cpu", "cuda"):
-        import copy
+    import copy
+
+    def build(dev):
         m = copy.deepcopy(base).to(dev)
         qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16",
                              "--quantize_forward", "gemm,residual,activation,layernorm,scaling"))
         with torch.no_grad():
             m(ids.to(dev), attention_mask=att.to(dev))
             o = m(ids.to(dev), attention_mask=att.to(dev))
-        outs[dev] = (o.start_logits.float().cpu(), o.end_logits.float().cpu())
-    for a, b in zip(outs["cpu"], outs["cuda"]):
-        assert float((a - b).abs().max()) <= 0.06 * float(a.abs().max()) + 0.02
+        return o.start_logits.float().cpu(), o.end_logits.float().cpu()
+    _assert_logits(_logits_by_route(build, monkeypatch))
 
 
 def test_pt2e_llama_on_device():
@@ -304,7 +337,7 @@ def test_bert_block_fusions_vs_hf_chains(family):
         assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01, float((a - b).abs().max())
 
 
-def test_mobilebert_blocks_on_device():
+def test_mobilebert_blocks_on_device(monkeypatch):
     """MobileBERT has BertLayer-shaped blocks with NoNorm, ReLU and bottlenecked q / k / v inputs: the BERT block fusions
     must step aside (different input widths -> no sibling GEMM, NoNorm -> HF's code) and the device path must agree with
     the CPU path."""
@@ -317,17 +350,15 @@ def test_mobilebert_blocks_on_device():
     ids = torch.randint(3, 300, (4, 64), generator=torch.Generator().manual_seed(1))
     att = torch.ones_like(ids)
     att[2, 40:] = 0
-    outs = {}
-    for dev in ("cpu", "cuda"):
+
+    def build(dev):
         m = copy.deepcopy(base).to(dev)
         qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
         with torch.no_grad():
             m(ids.to(dev), attention_mask=att.to(dev))
             o = m(ids.to(dev), attention_mask=att.to(dev))
-        outs[dev] = (o.start_logits.float().cpu(), o.end_logits.float().cpu())
-    for a, b in zip(outs["cpu"], outs["cuda"]):
-        assert torch.isfinite(b).all()
-        assert float((a - b).abs().max()) <= 0.06 * float(a.abs().max()) + 0.02
+        return o.start_logits.float().cpu(), o.end_logits.float().cpu()
+    _assert_logits(_logits_by_route(build, monkeypatch))
 
 
 def test_graphed_training_step_equals_eager_steps():
