@@ -326,6 +326,250 @@ struct LinearFq8 {
     }
 };
 
+// ---- variant R: weights converted in registers on the way in ------------------------------------------------------------
+// The raw bf16 weight tile is what keeps the ring above two deep (76 KiB per stage).  Here a lane loads 8 bf16 weights (16 bytes)
+// into registers with an ordinary global load -- hipcc places the vmcnt waits of those itself, copies of the registers included,
+// which is what makes loop-carried loads safe (an inline-asm load in flight is not) -- converts them a step later and writes the
+// 8 FP8 codes into a two-deep LDS ring of FP8 weight tiles (nt x 2 KiB); the activations keep coming by LDS-DMA into a ring
+// three deep.  So every weight is converted once per workgroup (not once per row band), the fragments of both operands are two
+// ds_read_b128 each, and a step's loads have a whole step to land.  No branch inside a step (hipcc would sink the
+// multiplications behind it); past the last k tile the last one is requested again.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int FX, int FW, int NB>
+struct LinearFq8R {
+    static constexpr int kADepth = 3;
+    static constexpr int kWBytes = NB * 4 * 1024;           // FP8 weight tile: up to 8 NB pieces of 4 rows x 128 bytes
+    static constexpr int kLds = kADepth * kABytes + 2 * kWBytes;
+    static constexpr int kItems = 4 + NB;
+    // Which items column group J of NTW carries: the four activation DMA pieces ride on the first half of the groups, the weight
+    // items (convert + ds_write + reload) on the second half -- a weight register is then reloaded about one step before its
+    // next conversion, and the waits hipcc puts in front of the conversions do not catch this step's DMA pieces young.
+    static constexpr int item_lo(int J, int NTW) {
+        const int h = NTW / 2;
+        if (h == 0) return 0;
+        return J < h ? J * 4 / h : 4 + (J - h) * NB / (NTW - h);
+    }
+    static constexpr int item_hi(int J, int NTW) {
+        const int h = NTW / 2;
+        if (h == 0) return kItems;
+        return J < h ? (J + 1) * 4 / h : 4 + (J - h + 1) * NB / (NTW - h);
+    }
+    static constexpr int writes_in(int J, int NTW) {        // weight items (one ds_write each) among them
+        const int lo = item_lo(J, NTW), hi = item_hi(J, NTW);
+        return (hi > 4 ? hi : 4) - (lo > 4 ? lo : 4);
+    }
+
+    template <int NTW>
+    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
+        const int r = l & 15, g = l >> 4, wm = w & 3;
+        const int nk = a.K / kBK, klast = nk - 1;
+        // ---- activation DMA sources (k tile 0); LDS destinations are wave-uniform
+        const uint8_t *ga[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
+            ga[i] = a.x8 + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        // ---- weight pieces (4 rows x 256 bytes of bf16): piece p = w + 8 i; lane = (row l >> 4, 16-byte chunk l & 15 = k 8c .. 8c+7)
+        const int npieces = nt * 4;
+        const uint8_t *gw[NB];
+        uint32_t wdst[NB];                                     // where the lane's 8 codes go inside an FP8 weight tile
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int p = w + 8 * i, pb = p < npieces ? p : (w & 3);          // surplus pieces repeat one (same bytes, same place)
+            const int grp = tg0 + (pb >> 2);
+            const SegRef sg = seg_lookup(a, grp);
+            const int row = pb * 4 + (l >> 4), c = l & 15;
+            gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
+        }
+        u32x4 wr[NB];
+        auto load_w = [&](auto ic, int kt) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            wr[I] = *(const u32x4 *)(gw[I] + (long)kt * (2 * kBK));
+        };
+        // The activation DMA as inline asm: with the builtin, hipcc's wait-count model sees a pending "flat" access to LDS and turns
+        // every wait for a weight register into vmcnt(0), which also waits for the step's own DMA pieces.  Hidden from the model the
+        // waits become counted ones that are at most four entries too strict (never too lax: uncounted entries only make the real
+        // queue longer than the one hipcc waits on).
+        // (asm statements sit in non-generic lambdas: inside a generic one clang rejects operands captured by reference)
+        auto dma16 = [](const uint8_t *src, uint32_t dst) __attribute__((always_inline)) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        auto ds_write64 = [](uint32_t addr, u32x2 v) __attribute__((always_inline)) {
+            asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        };
+        auto store_w = [&](auto ic, uint32_t wbase) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[I].x, wr[I].y), cvt_bf16x4<FW == 1>(wr[I].z, wr[I].w)};
+            const uint32_t addr = wbase + wdst[I];
+            ds_write64(addr, codes);
+        };
+        // item 0-3: activation pieces of k tile ka into `as`; item 4 + i: weight piece i -- its registers (k tile kb - 1) are
+        // converted and written to the FP8 tile at LDS address `ws`, then reloaded with k tile kb
+        auto item = [&](auto ic, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I < 4) {
+                dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
+            } else {
+                store_w(std::integral_constant<int, I - 4>{}, ws);
+                load_w(std::integral_constant<int, I - 4>{}, kb);
+            }
+        };
+        auto items = [&](auto lo, auto hi, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            static_assert(HI - LO <= 10, "at most ten items");
+            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, ka, as, ws, kb);
+            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, ka, as, ws, kb);
+            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, ka, as, ws, kb);
+            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, ka, as, ws, kb);
+            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, ka, as, ws, kb);
+            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, ka, as, ws, kb);
+            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, ka, as, ws, kb);
+            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, ka, as, ws, kb);
+            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, ka, as, ws, kb);
+            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, ka, as, ws, kb);
+        };
+        constexpr auto kI0 = std::integral_constant<int, 0>{};
+        constexpr auto kIA = std::integral_constant<int, 4>{};
+        constexpr auto kIN = std::integral_constant<int, kItems>{};
+
+        v4f acc[4][NTW > 0 ? NTW : 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        // lane-constant parts of the fragment addresses (both operands are FP8 tiles of 128-byte rows, same swizzle)
+        const uint32_t a_lo = a_chunk_off(wm * 64 + r, g), a_hi = a_chunk_off(wm * 64 + r, 4 + g);
+        const uint32_t b_lo = a_chunk_off(jbase * 16 + r, g), b_hi = a_chunk_off(jbase * 16 + r, 4 + g);
+
+        auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+            if constexpr (NTW > 0) {
+                u32x4 fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
+                fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
+                fa_lo[1] = ds_read128<1 * 2048>(sa_ + a_lo); fa_hi[1] = ds_read128<1 * 2048>(sa_ + a_hi);
+                fa_lo[2] = ds_read128<2 * 2048>(sa_ + a_lo); fa_hi[2] = ds_read128<2 * 2048>(sa_ + a_hi);
+                fa_lo[3] = ds_read128<3 * 2048>(sa_ + a_lo); fa_hi[3] = ds_read128<3 * 2048>(sa_ + a_hi);
+                auto read_b = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    fb_lo[J % 3] = ds_read128<J * 2048>(sb_ + b_lo);
+                    fb_hi[J % 3] = ds_read128<J * 2048>(sb_ + b_hi);
+                };
+                v8i fa[4];
+                auto step = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int P = J % 3;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
+                    // LDS operations still allowed in flight (they return in order): everything issued behind this group's fragment
+                    // reads -- the reads of the next two groups (two each) and the ds_writes of the weight items that the two
+                    // groups in front of this one carried
+                    constexpr int kAhead = (J + 1 < NTW ? 2 : 0) + (J + 2 < NTW ? 2 : 0) + (J >= 2 ? writes_in(J - 2, NTW) : 0) +
+                                           (J >= 1 ? writes_in(J - 1, NTW) : 0);
+                    if constexpr (J == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(%10)"
+                                     : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]), "+v"(fa_lo[3]),
+                                       "+v"(fa_hi[3]), "+v"(fb_lo[0]), "+v"(fb_hi[0])
+                                     : "n"(kAhead));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            fa[i] = v8i{(int)fa_lo[i].x, (int)fa_lo[i].y, (int)fa_lo[i].z, (int)fa_lo[i].w,
+                                        (int)fa_hi[i].x, (int)fa_hi[i].y, (int)fa_hi[i].z, (int)fa_hi[i].w};
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb_lo[P]), "+v"(fb_hi[P]) : "n"(kAhead));
+                    }
+                    const v8i fb = v8i{(int)fb_lo[P].x, (int)fb_lo[P].y, (int)fb_lo[P].z, (int)fb_lo[P].w,
+                                       (int)fb_hi[P].x, (int)fb_hi[P].y, (int)fb_hi[P].z, (int)fb_hi[P].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+                    items(std::integral_constant<int, item_lo(J, NTW)>{}, std::integral_constant<int, item_hi(J, NTW)>{}, ka, as, ws, kb);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                read_b(std::integral_constant<int, 0>{});
+                if constexpr (NTW > 1) read_b(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 0>{});
+                if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
+                if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
+                if constexpr (NTW > 3) step(std::integral_constant<int, 3>{});
+                if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
+                if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
+            } else {
+                items(kI0, kIN, ka, as, ws, kb);
+            }
+        };
+
+        const uint32_t l0 = lds_addr(lds), w0 = l0 + kADepth * kABytes;
+        // prologue: activations of k tiles 0 and 1 on their way; weights of k tile 0 converted into FP8 tile 0, those of k tile 1
+        // in registers
+        items(kI0, kIA, 0, l0, w0, 0);
+        items(kI0, kIA, min(1, klast), l0 + kABytes, w0, 0);
+        load_w(std::integral_constant<int, 0>{}, 0);
+        if constexpr (NB > 1) load_w(std::integral_constant<int, 1>{}, 0);
+        if constexpr (NB > 2) load_w(std::integral_constant<int, 2>{}, 0);
+        if constexpr (NB > 3) load_w(std::integral_constant<int, 3>{}, 0);
+        if constexpr (NB > 4) load_w(std::integral_constant<int, 4>{}, 0);
+        if constexpr (NB > 5) load_w(std::integral_constant<int, 5>{}, 0);
+        items(kIA, kIN, 0, l0, w0, min(1, klast));
+        int a_slot = 0, a_tgt = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's FP8 codes of step kt are written (lgkmcnt) and its activation pieces have landed: they are older in the
+            // vector-memory queue than the weight loads of step kt, which the conversions of the previous step waited for
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NB) : "memory");
+            __builtin_amdgcn_s_barrier();                    // ... every wave's; and every wave is done with step kt - 1
+            const int ka = min(kt + 2, klast), kb = min(kt + 2, klast);
+            const uint32_t sa_ = l0 + a_slot * kABytes, sb_ = w0 + (kt & 1) * kWBytes, ws = w0 + ((kt + 1) & 1) * kWBytes;
+            compute(sa_, sb_, ka, l0 + a_tgt * kABytes, ws, kb);
+            a_tgt = a_slot; a_slot = a_slot == 2 ? 0 : a_slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // Overflowed or non-finite weights (and NaN activations) leave NaN / Inf in the accumulators: such a tile is redone
+        // by slow_tile.  The workgroup-wide vote goes through LDS (the rings are dead here).
+        bool bad = false;
+        if constexpr (NTW > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
+        }
+        __syncthreads();
+        volatile int *flag = (volatile int *)lds;
+        if (w == 0 && l == 0) *flag = 0;
+        __syncthreads();
+        if (bad) *flag = 1;
+        __syncthreads();
+        if (*flag) return true;
+
+        if constexpr (NTW > 0) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int grp = tg0 + jbase + j;
+                const SegRef sg = seg_lookup(a, grp);
+                const int col = grp * 16 + 4 * g;                       // output column
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (sg.bias) {
+                    const uint2 b = *(const uint2 *)(sg.bias + (col - sg.g0 * 16));
+                    bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
+                    bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * 64 + i * 16 + r;
+                    if (row < a.M) {
+                        const uint2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
+                                         pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
+                        *(uint2 *)(a.y + (long)row * a.ldc + col) = o;
+                    }
+                }
+            }
+        }
+        return false;
+    }
+};
+
 // The redo path of a tile whose fast pass saw NaN / Inf: every weight goes through the closed form of the value map.  Plain
 // loops, operands straight from global memory, one 16 x 16 output tile at a time -- only ever taken for weights beyond the
 // format's range or non-finite values.
@@ -404,6 +648,37 @@ __global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
     if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
 }
 
+template <int FX, int FW, int NB>
+__global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_r[];
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    const int tn = id / a.tiles_m, tm = id % a.tiles_m;
+    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
+    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    const int m0 = tm * kTM;
+    const int nt0 = (nt + 1) >> 1;
+    const int wn = w >> 2;
+    const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
+    using L = LinearFq8R<FX, FW, NB>;
+    bool redo;
+    switch (ntw) {                                          // wave-uniform
+        case 0: redo = L::template run<0>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 1: redo = L::template run<1>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 2: redo = L::template run<2>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 3: redo = L::template run<3>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 4: redo = L::template run<4>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 5: redo = L::template run<5>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        default: redo = L::template run<6>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+    }
+    if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+}
+
 int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -428,8 +703,29 @@ int launch_nb(const Args &a, hipStream_t st) {
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
+template <int FX, int FW, int NB>
+int launch_r_nb(const Args &a, hipStream_t st) {
+    constexpr int kLds = LinearFq8R<FX, FW, NB>::kLds;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r_kernel<FX, FW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    linear_fq8r_kernel<FX, FW, NB><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
 template <int FX, int FW>
 int launch(const Args &a, hipStream_t st) {
+    const char *e_var = getenv("QT_FQ8_VARIANT");            // 1: raw bf16 weight tiles by LDS-DMA, 2: weights converted in registers
+    const int variant = e_var ? atoi(e_var) : 2;
+    if (variant == 2) {
+        if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
+        if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
+        return launch_r_nb<FX, FW, 6>(a, st);
+    }
     if (a.nb <= 2) return launch_nb<FX, FW, 2>(a, st);
     if (a.nb <= 4) return launch_nb<FX, FW, 4>(a, st);
     return launch_nb<FX, FW, 6>(a, st);
