@@ -25,10 +25,89 @@ def fp8_gemm_enabled():
     return os.environ.get("QT_FP8_GEMM", "1") != "0"
 
 
+def fq8_gemm_mode():
+    """QT_FQ8_GEMM: "auto" (default) -- per problem shape, whichever of the two routes measured faster on its first call;
+    "1" -- always the hand-written FP8 GEMM with the weight fake-quantizer in its operand path (qt_linear_fq8_bf16);
+    "0" -- always the weight pass + library GEMM pair."""
+    v = os.environ.get("QT_FQ8_GEMM", "auto")
+    return v if v in ("0", "1") else "auto"
+
+
 def fq8_gemm_enabled():
-    """Hand-written FP8 GEMM with the weight fake-quantizer fused into its operand path (qt_linear_fq8_bf16) instead of
-    the weight pass + library GEMM pair."""
-    return os.environ.get("QT_FQ8_GEMM", "0") == "1"
+    return fq8_gemm_mode() != "0"
+
+
+_FQ8_CHOICE = {}          # (M, Ns, K, activation dtype, weight format, device) -> True: fused kernel, False: pass + library GEMM
+
+
+def _fq8_heuristic(M, ns, K, device):
+    """Without a measurement (first call inside a stream capture, or QT_FQ8_TUNE=0): the fused kernel where it filled the chip
+    in one round of 256-row tiles at least five column groups wide -- what the sweep in DESIGN.md 6b showed for M <= 1024."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    tiles_m = (M + 255) // 256
+    groups = sum(ns) // 16
+    tn_min = (groups + 11) // 12
+    if tiles_m * tn_min > cus or tiles_m > cus:
+        return False
+    nt = groups / max(1, cus // tiles_m)
+    return M <= 1024 and nt >= 5.0 and K <= 8192
+
+
+def _fq8_measure(x8, layers):
+    """Times both routes on this very problem (three launches each after two warm-up ones, device events) and returns True when
+    the fused kernel is faster.  Outputs are discarded; no fake-quant call is counted."""
+    dev = x8.device
+    K = x8.shape[-1]
+    n = len(layers)
+    fq = layers[0].weight_fake_quant
+    total = sum(l.weight.shape[0] for l in layers)
+    buf = torch.empty((total, K), dtype=torch.uint8, device=dev)
+    L = _native.lib()
+    xs = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
+    ns = (ctypes.c_size_t * n)(*[l.weight.numel() for l in layers])
+    w8 = buf.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn)
+
+    def pair():
+        _native.check(L.qt_fake_quant_bf16_fp8_multi(xs, ns, n, buf.data_ptr(), ctypes.byref(fq._qt_format), _stream_ptr(x8)),
+                      "qt_fake_quant_bf16_fp8_multi")
+        return lt_fp8_gemm(x8, w8, None)
+
+    def fused():
+        return hip_fq8_linear_or_none(x8, layers)
+
+    if fused() is None:
+        return False
+    if pair() is None:
+        return True
+    times = []
+    for fn in (fused, pair):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+        for _ in range(3):
+            fn()
+        e1.record(torch.cuda.current_stream(dev))
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    return times[0] < times[1]
+
+
+def fq8_route_is_fused(x8, layers):
+    """Route of one fake-quant Linear problem (x8 [M, K] FP8 codes x the bf16 weights of `layers`)."""
+    mode = fq8_gemm_mode()
+    if mode != "auto":
+        return mode == "1"
+    K = x8.shape[-1]
+    M = x8.numel() // K
+    ns = tuple(l.weight.shape[0] for l in layers)
+    key = (M, ns, K, x8.dtype, layers[0].weight_fake_quant._qt_format.key(), x8.device.index)
+    hit = _FQ8_CHOICE.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("QT_FQ8_TUNE", "1") == "0":
+            return _fq8_heuristic(M, ns, K, x8.device)       # not remembered: a later call outside capture may measure
+        hit = _FQ8_CHOICE[key] = bool(_fq8_measure(x8, layers))
+    return hit
 
 
 _F8_CODE = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}
@@ -274,7 +353,7 @@ def _sibling_linear_or_none(layer, x, x8):
     total = sum(Ns)
     dev = x.device
     n = len(group.layers)
-    if fq8_gemm_enabled():
+    if fq8_gemm_enabled() and fq8_route_is_fused(x8.reshape(-1, K), group.layers):
         layer.weight_fake_quant._move_to(dev)
         y = hip_fq8_linear_or_none(x8.reshape(-1, K), group.layers)
         if y is not None:
@@ -326,7 +405,7 @@ def fp8_linear_or_none(layer, x):
     shared = _sibling_linear_or_none(layer, x, x8)
     if shared is not None:
         return shared
-    if fq8_gemm_enabled() and not prefetch_enabled() and not _WEIGHT_CACHE["on"]:
+    if fq8_gemm_enabled() and not prefetch_enabled() and not _WEIGHT_CACHE["on"] and fq8_route_is_fused(x8.reshape(-1, K), [layer]):
         y = hip_fq8_linear_or_none(x8.reshape(-1, K), [layer])
         if y is not None:
             STATS.add(W.numel())                   # the weight's fake-quant call, computed inside the GEMM

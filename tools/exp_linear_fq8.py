@@ -165,7 +165,10 @@ def main():
     llama = [(1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096], 4096), (1024, [4096, 4096, 4096], 4096), (1024, [32000], 4096)]
     bert = [(6144, [768], 768), (6144, [3072], 768), (6144, [768], 3072), (6144, [768, 768, 768], 768)]
     probe = [(1024, [11008], 4096), (1024, [11008], 4224), (1024, [4096], 11008)]
-    shapes = {"llama": llama, "bert": bert, "all": llama + bert, "probe": probe}[args.shapes]
+    # other window lengths and the 13B widths: where does the fused kernel beat the pair?
+    sweep = [(512, [11008], 4096), (2048, [11008], 4096), (2048, [4096], 4096), (4096, [4096], 4096), (1024, [13824], 5120), (1024, [5120], 13824),
+             (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120), (1024, [8192], 4096), (1024, [6144], 4096), (256, [11008], 4096)]
+    shapes = {"llama": llama, "bert": bert, "all": llama + bert, "probe": probe, "sweep": sweep}[args.shapes]
     for (M, Ns, K) in shapes:
         bench(M, Ns, K, args.iters)
     print("ALL CHECKS", "PASSED" if ok else "FAILED")
