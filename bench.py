@@ -101,12 +101,14 @@ def profiled_traffic(key):
 
 
 def roofline_leg(device, weight_dtype="e4m3", model_shape=(4096, 11008)):
-    """Dominant kernel of the window (top row of profiles/*_bench_kernel_stats.csv): the weight pass on a gate / up / down
-    weight of the model (bf16 [hidden, intermediate]; 4096 x 11008 for LLaMA-2-7B).
+    """The fake-quant pass over a weight of the model (bf16 [hidden, intermediate]; 4096 x 11008 for LLaMA-2-7B) -- the dominant
+    elementwise kernel of the window, HBM-bound.  Since round 2 the q / k / v, gate and up projections run the weight's
+    fake-quantizer inside their GEMM ("fused_gemm" below, the window's largest kernel by time, MFMA / L2-bound); the separate pass
+    still serves the o and down projections and every spec whose values are not FP8 codes.
       * e4m3 / e5m2 without `qs` (the FP8 GEMM route): `fq8_kernel` with FP8-only output; algorithmic bytes 3 B/element
         (2 read as bf16 + 1 written as the FP8 code) -- less than SURVEY 8(d)'s 4 B/element because the bf16 copy of the
         quantized weight is never needed.  The bf16 -> bf16 pass (4 B/element) is timed next to it ("bf16_out").
-      * every other dtype (posit(8,2) of BASELINE config 4, ...): the bf16 -> bf16 pass with the value map staged in LDS,
+      * every other dtype (posit(8,2) of BASELINE configs[3], ...): the bf16 -> bf16 pass with the value map staged in LDS,
         4 B/element."""
     from quantized_training import _native as nv
     import quantized_training as qt
@@ -148,7 +150,7 @@ def roofline_leg(device, weight_dtype="e4m3", model_shape=(4096, 11008)):
             "frac": round(achieved8 / HBM_PEAK_GBPS, 4), "traffic": t3, "traffic_source": src3,
             "kernel": f"fq8_kernel<obs off, fp8 only> {base} {shape} (weight pass of the FP8 GEMM route)",
             "ms_per_launch": round(ms8.value, 5), "algorithmic_bytes_per_launch": n * 3,
-            "bf16_out": bf16_out, "gemm": gemm_leg(device)}
+            "bf16_out": bf16_out, "gemm": gemm_leg(device), "fused_gemm": fused_gemm_leg(device)}
 
 
 def gemm_leg(device):
@@ -177,6 +179,46 @@ def gemm_leg(device):
             "frac": round(tf / FP8_PEAK_TFLOPS, 4), "ms_per_launch": round(ms, 5),
             "kernel": "FP8 E4M3 GEMM 1024x11008x4096 (gate/up projection), fp32 accumulate, bf16 out",
             "flops_per_launch": 2 * M * N * K}
+
+
+def fused_gemm_leg(device):
+    """The kernel most of the window's Linears run on (QT_FQ8_GEMM=auto picks it for the q / k / v, gate and up projections):
+    qt_linear_fq8_bf16 -- FP8 GEMM with the weight's E4M3 fake-quantizer in its operand path -- at 1024 x 11008 x 4096, rotating
+    over 8 bf16 weights (8 x 90 MB, more than the Infinity Cache), HIP events on the launch stream.  Two views of the same launch:
+    matrix-core rate (2 M N K flops against the dense FP8 peak) and the bytes it has to move at least (weights 2 B/element once,
+    FP8 activations once, bf16 output once) against the HBM peak."""
+    import ctypes
+    from quantized_training import _native
+    L = _native.lib()
+    M, N, K, pool = 1024, 11008, 4096, 8
+    x8 = torch.randn(M, K, device=device).to(torch.float8_e4m3fn)
+    w = (torch.randn(pool, N, K, device=device) * 0.02).bfloat16()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def run(i):
+        wp = (ctypes.c_void_p * 1)(w[i % pool].data_ptr())
+        return L.qt_linear_fq8_bf16(x8.data_ptr(), 0, wp, None, (ctypes.c_int * 1)(N), 1, 0, y.data_ptr(), M, K, st)
+    if run(0) != 0:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for iters in (pool, 5 * pool):
+        e0.record()
+        for i in range(iters):
+            run(i)
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    nbytes = N * K * 2 + M * K + M * N * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    del x8, w, y
+    torch.cuda.empty_cache()
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_PEAK_TFLOPS, 4),
+            "ms_per_launch": round(ms, 5), "flops_per_launch": 2 * M * N * K,
+            "kernel": "linear_fq8r_kernel: FP8 E4M3 GEMM 1024x11008x4096 with the bf16 weight fake-quantized in its operand path",
+            "hbm_view": {"algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBPS, 4)}}
 
 
 def cpu_baseline_leg():

@@ -536,34 +536,47 @@ struct LinearFq8R {
                     for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
         }
         __syncthreads();
-        volatile int *flag = (volatile int *)lds;
+        volatile int *flag = (volatile int *)(lds + 8 * 64 * (6 * 32 + 8));     // past the eight waves' epilogue tiles
         if (w == 0 && l == 0) *flag = 0;
         __syncthreads();
         if (bad) *flag = 1;
         __syncthreads();
         if (*flag) return true;
 
+        // ---- epilogue.  Lane (r, g) of tile (i, j) holds y[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]: stored
+        // straight from the registers that is 32 contiguous bytes per row and instruction.  The rings are dead, so every wave
+        // turns its 64 x 16 NTW tile around in its own 13 KiB of LDS (no barrier: wave-private) and stores whole rows of it,
+        // 32 NTW contiguous bytes each, 16 bytes per lane.
         if constexpr (NTW > 0) {
+            constexpr int kRowB = NTW * 32 + 8;                        // + 8: rows 16 apart would otherwise share banks
+            const uint32_t tbase = l0 + w * (64 * (6 * 32 + 8));
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int grp = tg0 + jbase + j;
                 const SegRef sg = seg_lookup(a, grp);
-                const int col = grp * 16 + 4 * g;                       // output column
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (sg.bias) {
-                    const uint2 b = *(const uint2 *)(sg.bias + (col - sg.g0 * 16));
+                    const uint2 b = *(const uint2 *)(sg.bias + (grp * 16 + 4 * g - sg.g0 * 16));
                     bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
                     bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * 64 + i * 16 + r;
-                    if (row < a.M) {
-                        const uint2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
-                                         pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
-                        *(uint2 *)(a.y + (long)row * a.ldc + col) = o;
-                    }
+                    const u32x2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
+                    ds_write64(tbase + (i * 16 + r) * kRowB + j * 32 + g * 8, o);
                 }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int kChunksPerRow = NTW * 2, kChunks = 64 * kChunksPerRow;
+            const long col0 = (long)(tg0 + jbase) * 16;
+#pragma unroll
+            for (int it = 0; it < (kChunks + 63) / 64; ++it) {
+                const int c = it * 64 + l, row = c / kChunksPerRow, ch = c % kChunksPerRow;
+                uint2 lo_, hi_;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo_), "=&v"(hi_) : "v"(tbase + row * kRowB + ch * 16) : "memory");
+                const int grow = m0 + wm * 64 + row;
+                if (c < kChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
             }
         }
         return false;

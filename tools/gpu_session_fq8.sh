@@ -6,6 +6,5 @@ run() { echo "== $1"; shift; env "$@" timeout 300 python tools/exp_linear_fq8.py
 echo "== checks (variant 2: weights converted in registers)"; QT_FQ8_VARIANT=2 timeout 600 python -u tools/exp_linear_fq8.py --shapes probe
 run "variant 2" QT_FQ8_VARIANT=2
 run "variant 1 (raw bf16 weight tiles by LDS-DMA)" QT_FQ8_VARIANT=1
-run "variant 1, no compute" QT_FQ8_VARIANT=1 QT_FQ8_DEBUG=2
 } > gpurun_out/fq8_session.txt 2>&1
 grep -E "^==|bench|exact|accuracy|CHECKS|rror|fault" gpurun_out/fq8_session.txt | cut -c1-118
