@@ -230,6 +230,18 @@ int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev
 int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
                        const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream);
 
+/* ---- The gated MLP front half as ONE launch (LLaMA: modeling_llama.LlamaMLP.forward, act_fn(gate_proj(x)) * up_proj(x), whose
+ * result is the down projection's fake-quantized input): both fake-quant Linears of A9 (modules/qat/linear.py:40-41, stateless
+ * E4M3 / E5M2 weight specs) on the same FP8-coded activation, then, per output element, in the module chain's arithmetic:
+ *     g = bf16(acc_gate + bias_gate), u = bf16(acc_up + bias_up), p = bf16(bf16(g / (1 + exp(-g))) * u)   -- SiLU * up
+ *     h = fq_out(p)                                              -- the consumer's input fake-quantizer (fake_quantize.py:217-248)
+ * written as bf16 values (h_dev [M][N]) AND as FP8 codes (h8_dev [M][N]); out_format: an e4m3 / e5m2 closed-form format with unit
+ * scale (qt_format_for).  w_gate_dev / w_up_dev: UNQUANTIZED bf16 [N][K]; the weight value map (w_format) is applied inside the
+ * GEMM as in qt_linear_fq8_bf16.  K % 128 == 0, N % 16 == 0; pointers 16-byte aligned. */
+int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_dev, const uint16_t *w_up_dev,
+                    const uint16_t *bias_gate_dev, const uint16_t *bias_up_dev, int N, int w_format, uint16_t *h_dev, uint8_t *h8_dev,
+                    const qt_format *out_format, int M, int K, void *stream);
+
 /* ---- A10: attention-score path between the two attention GEMMs ------------------------------
  * Replaces, for one attention block, the chain
  *     attn_scaling(scores, scaling) ; + attention_mask ; softmax(fp32) ; .to(bf16) ; fq(probs)

@@ -71,6 +71,12 @@ struct Args {
     int nb;                   // ceil(4 * widest tile / 8): weight DMA pieces the widest tile needs per wave
     int dbg;                  // tuning switches (QT_FQ8_DEBUG): 2 = no multiplications, 128 = no issue stagger
     Segment seg[kMaxSeg];
+    // pair mode (qt_mlp_fq8_bf16): seg[0] = gate, seg[1] = up weights [N][K]; the virtual column groups alternate gate / up
+    // (group 2 P: gate rows 16 P .., group 2 P + 1: the same rows of up), gbase / gextra count PAIRS, and the epilogue writes
+    // h = fq(silu(bf16(gate)) * bf16(up)) as bf16 values (y, [M][ldc]) and FP8 codes (y8, [M][ldc])
+    int pair;
+    uint8_t *y8;
+    qt_format out_fmt;        // the output fake-quantizer (E4M3 / E5M2 closed form, unit scale)
 };
 
 // The weight holding column group `grp`, by compile-time indices only: a run-time index into the kernel-argument struct makes
@@ -336,7 +342,21 @@ struct LinearFq8 {
 // multiplications behind it); past the last k tile the last one is requested again.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int FX, int FW, int NB>
+__device__ __forceinline__ float bf_round(float f) { return qt_u2f(pack_bf16x2(f, 0.0f) << 16); }      // round to bf16, keep as float
+// silu(g) * u on four (gate, up) pairs, with the roundings of the module chain (LlamaMLP: bf16 GEMM outputs, SiLU in fp32 rounded
+// to bf16, product rounded to bf16 -- the arithmetic of silu_mul_kernel, csrc/qt_model_ops.hip): two packed bf16 words
+__device__ __forceinline__ void silu_mul4(const float (&gt)[4], const float (&up)[4], uint32_t &w0, uint32_t &w1) {
+    float p[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g = bf_round(gt[e]), u = bf_round(up[e]);
+        p[e] = bf_round(g / (1.0f + expf(-g))) * u;
+    }
+    w0 = pack_bf16x2(p[0], p[1]);
+    w1 = pack_bf16x2(p[2], p[3]);
+}
+
+template <int FX, int FW, int NB, bool PAIR = false>
 struct LinearFq8R {
     static constexpr int kADepth = 3;
     static constexpr int kWBytes = NB * 4 * 1024;           // FP8 weight tile: up to 8 NB pieces of 4 rows x 128 bytes
@@ -379,9 +399,14 @@ struct LinearFq8R {
         for (int i = 0; i < NB; ++i) {
             const int p = w + 8 * i, pb = p < npieces ? p : (w & 3);          // surplus pieces repeat one (same bytes, same place)
             const int grp = tg0 + (pb >> 2);
-            const SegRef sg = seg_lookup(a, grp);
             const int row = pb * 4 + (l >> 4), c = l & 15;
-            gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            if constexpr (PAIR) {
+                const uint16_t *wb = (grp & 1) ? a.seg[1].w : a.seg[0].w;
+                gw[i] = (const uint8_t *)wb + ((long)((grp >> 1) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            } else {
+                const SegRef sg = seg_lookup(a, grp);
+                gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            }
             wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
         }
         u32x4 wr[NB];
@@ -399,6 +424,9 @@ struct LinearFq8R {
         };
         auto ds_write64 = [](uint32_t addr, u32x2 v) __attribute__((always_inline)) {
             asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        };
+        auto ds_write32 = [](uint32_t addr, uint32_t v) __attribute__((always_inline)) {
+            asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
         };
         auto store_w = [&](auto ic, uint32_t wbase) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
@@ -547,7 +575,65 @@ struct LinearFq8R {
         // straight from the registers that is 32 contiguous bytes per row and instruction.  The rings are dead, so every wave
         // turns its 64 x 16 NTW tile around in its own 13 KiB of LDS (no barrier: wave-private) and stores whole rows of it,
         // 32 NTW contiguous bytes each, 16 bytes per lane.
-        if constexpr (NTW > 0) {
+        if constexpr (PAIR && NTW > 0) {
+            // gate / up pairs: column group 2 jp holds gate, 2 jp + 1 up, both for output columns 16 P .. 16 P + 15
+            static_assert(!PAIR || NTW % 2 == 0, "pair mode gives every wave whole pairs");
+            constexpr int kRowV = NTW * 16 + 8, kRowC = NTW * 8 + 8;   // bytes per tile row: bf16 values, FP8 codes
+            const uint32_t tv = l0 + w * (64 * (6 * 32 + 8)), tc = tv + 64 * kRowV;
+            const bool oe5 = a.out_fmt.p0 == 2;
+#pragma unroll
+            for (int jp = 0; jp < NTW / 2; ++jp) {
+                const int col = ((tg0 + jbase) / 2 + jp) * 16 + 4 * g;
+                float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.seg[0].bias) {
+                    const uint2 b = *(const uint2 *)(a.seg[0].bias + col);
+                    bg[0] = qt_u2f(b.x << 16); bg[1] = qt_u2f(b.x & 0xFFFF0000u); bg[2] = qt_u2f(b.y << 16); bg[3] = qt_u2f(b.y & 0xFFFF0000u);
+                }
+                if (a.seg[1].bias) {
+                    const uint2 b = *(const uint2 *)(a.seg[1].bias + col);
+                    bu[0] = qt_u2f(b.x << 16); bu[1] = qt_u2f(b.x & 0xFFFF0000u); bu[2] = qt_u2f(b.y << 16); bu[3] = qt_u2f(b.y & 0xFFFF0000u);
+                }
+#pragma unroll
+                for (int ih = 0; ih < 2; ++ih) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * ih + ii;
+                        const float gt[4] = {acc[i][2 * jp][0] + bg[0], acc[i][2 * jp][1] + bg[1], acc[i][2 * jp][2] + bg[2], acc[i][2 * jp][3] + bg[3]};
+                        const float up[4] = {acc[i][2 * jp + 1][0] + bu[0], acc[i][2 * jp + 1][1] + bu[1], acc[i][2 * jp + 1][2] + bu[2],
+                                             acc[i][2 * jp + 1][3] + bu[3]};
+                        silu_mul4(gt, up, o[2 * ii], o[2 * ii + 1]);
+                    }
+                    const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);   // o: now fq(product)
+                    ds_write64(tv + ((2 * ih) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[0], o[1]});
+                    ds_write64(tv + ((2 * ih + 1) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[2], o[3]});
+                    ds_write32(tc + ((2 * ih) * 16 + r) * kRowC + jp * 16 + g * 4, codes.x);
+                    ds_write32(tc + ((2 * ih + 1) * 16 + r) * kRowC + jp * 16 + g * 4, codes.y);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long col0 = (long)((tg0 + jbase) / 2) * 16;
+            constexpr int kVChunks = 64 * NTW, kCChunks = 64 * (NTW / 2);       // 16-byte chunks of the values / of the codes
+#pragma unroll
+            for (int it = 0; it < (kVChunks + 63) / 64; ++it) {
+                const int c = it * 64 + l, row = c / NTW, ch = c % NTW;
+                uint2 lo_, hi_;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo_), "=&v"(hi_) : "v"(tv + row * kRowV + ch * 16) : "memory");
+                const int grow = m0 + wm * 64 + row;
+                if (c < kVChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+            }
+#pragma unroll
+            for (int it = 0; it < (kCChunks + 63) / 64; ++it) {
+                const int c = it * 64 + l, row = c / (NTW / 2), ch = c % (NTW / 2);
+                uint2 lo_, hi_;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo_), "=&v"(hi_) : "v"(tc + row * kRowC + ch * 16) : "memory");
+                const int grow = m0 + wm * 64 + row;
+                if (c < kCChunks && grow < a.M) *(uint4 *)(a.y8 + (long)grow * a.ldc + col0 + ch * 16) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+            }
+        }
+        if constexpr (!PAIR && NTW > 0) {
             constexpr int kRowB = NTW * 32 + 8;                        // + 8: rows 16 apart would otherwise share banks
             const uint32_t tbase = l0 + w * (64 * (6 * 32 + 8));
 #pragma unroll
@@ -628,6 +714,69 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
     }
 }
 
+// Pair mode's redo path: gate and up tiles with exactly fake-quantized weights, then the same epilogue arithmetic, straight stores.
+template <int FX, int FW>
+__device__ __forceinline__ void slow_tile_pair(const Args &a, int m0, int tg0, int jbase, int ntw, int w, int l) {
+    const int r = l & 15, g = l >> 4, wm = w & 3;
+    const int nk = a.K / kBK;
+    const bool oe5 = a.out_fmt.p0 == 2;
+#pragma unroll 1
+    for (int jp = 0; jp < ntw / 2; ++jp) {
+        const int P = (tg0 + jbase) / 2 + jp, col = P * 16 + 4 * g;
+        const uint16_t *grow_ = a.seg[0].w + (long)(P * 16 + r) * a.K, *urow_ = a.seg[1].w + (long)(P * 16 + r) * a.K;
+        float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.seg[0].bias) {
+            const uint2 b = *(const uint2 *)(a.seg[0].bias + col);
+            bg[0] = qt_u2f(b.x << 16); bg[1] = qt_u2f(b.x & 0xFFFF0000u); bg[2] = qt_u2f(b.y << 16); bg[3] = qt_u2f(b.y & 0xFFFF0000u);
+        }
+        if (a.seg[1].bias) {
+            const uint2 b = *(const uint2 *)(a.seg[1].bias + col);
+            bu[0] = qt_u2f(b.x << 16); bu[1] = qt_u2f(b.x & 0xFFFF0000u); bu[2] = qt_u2f(b.y << 16); bu[3] = qt_u2f(b.y & 0xFFFF0000u);
+        }
+#pragma unroll 1
+        for (int ih = 0; ih < 2; ++ih) {
+            uint32_t o[4];
+#pragma unroll 1
+            for (int ii = 0; ii < 2; ++ii) {
+                const int row = m0 + wm * 64 + (2 * ih + ii) * 16 + r;
+                const uint8_t *xrow = a.x8 + (long)min(row, a.M - 1) * a.K;
+                v4f ag = {0.f, 0.f, 0.f, 0.f}, au = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int kt = 0; kt < nk; ++kt) {
+                    const uint4 xl = *(const uint4 *)(xrow + kt * kBK + 16 * g), xh = *(const uint4 *)(xrow + kt * kBK + 64 + 16 * g);
+                    const v8i fa = {(int)xl.x, (int)xl.y, (int)xl.z, (int)xl.w, (int)xh.x, (int)xh.y, (int)xh.z, (int)xh.w};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const uint16_t *wrow = m ? urow_ : grow_;
+                        const uint4 *wl = (const uint4 *)(wrow + kt * kBK + 16 * g), *wh = (const uint4 *)(wrow + kt * kBK + 64 + 16 * g);
+                        const uint4 w0 = wl[0], w1 = wl[1], w2 = wh[0], w3 = wh[1];
+                        v8i fb;
+                        fb[0] = (int)exact_bf16x4<FW == 1>(w0.x, w0.y); fb[1] = (int)exact_bf16x4<FW == 1>(w0.z, w0.w);
+                        fb[2] = (int)exact_bf16x4<FW == 1>(w1.x, w1.y); fb[3] = (int)exact_bf16x4<FW == 1>(w1.z, w1.w);
+                        fb[4] = (int)exact_bf16x4<FW == 1>(w2.x, w2.y); fb[5] = (int)exact_bf16x4<FW == 1>(w2.z, w2.w);
+                        fb[6] = (int)exact_bf16x4<FW == 1>(w3.x, w3.y); fb[7] = (int)exact_bf16x4<FW == 1>(w3.z, w3.w);
+                        if (m) au = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa, au, FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+                        else ag = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa, ag, FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+                    }
+                }
+                const float gt[4] = {ag[0] + bg[0], ag[1] + bg[1], ag[2] + bg[2], ag[3] + bg[3]};
+                const float up[4] = {au[0] + bu[0], au[1] + bu[1], au[2] + bu[2], au[3] + bu[3]};
+                if (ii == 0) silu_mul4(gt, up, o[0], o[1]);
+                else silu_mul4(gt, up, o[2], o[3]);
+            }
+            const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int row = m0 + wm * 64 + (2 * ih + ii) * 16 + r;
+                if (row < a.M) {
+                    *(uint2 *)(a.y + (long)row * a.ldc + col) = uint2{o[2 * ii], o[2 * ii + 1]};
+                    *(uint32_t *)(a.y8 + (long)row * a.ldc + col) = ii ? codes.y : codes.x;
+                }
+            }
+        }
+    }
+}
+
 template <int FX, int FW, int NB>
 __global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -661,7 +810,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
     if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
 }
 
-template <int FX, int FW, int NB>
+template <int FX, int FW, int NB, bool PAIR>
 __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_r[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -672,24 +821,30 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
         id = x * per + (x < rem ? x : rem) + q;
     }
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
-    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
-    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    // column groups of this tile; in pair mode gbase / gextra count gate / up pairs and each wave half gets whole pairs
+    const int unit = PAIR ? 2 : 1;
+    const int nu = a.gbase + (tn < a.gextra ? 1 : 0);
+    const int nt = unit * nu;
+    const int tg0 = unit * (tn * a.gbase + min(tn, a.gextra));
     const int m0 = tm * kTM;
-    const int nt0 = (nt + 1) >> 1;
+    const int nt0 = unit * ((nu + 1) >> 1);
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFq8R<FX, FW, NB>;
+    using L = LinearFq8R<FX, FW, NB, PAIR>;
     bool redo;
     switch (ntw) {                                          // wave-uniform
         case 0: redo = L::template run<0>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
-        case 1: redo = L::template run<1>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 1: if constexpr (!PAIR) { redo = L::template run<1>(a, lds_r, m0, tg0, nt, jbase, w, l); break; }
         case 2: redo = L::template run<2>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
-        case 3: redo = L::template run<3>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 3: if constexpr (!PAIR) { redo = L::template run<3>(a, lds_r, m0, tg0, nt, jbase, w, l); break; }
         case 4: redo = L::template run<4>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
-        case 5: redo = L::template run<5>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
+        case 5: if constexpr (!PAIR) { redo = L::template run<5>(a, lds_r, m0, tg0, nt, jbase, w, l); break; }
         default: redo = L::template run<6>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
     }
-    if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+    if (redo) {
+        if constexpr (PAIR) slow_tile_pair<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+        else slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+    }
 }
 
 int cu_count() {
@@ -716,16 +871,16 @@ int launch_nb(const Args &a, hipStream_t st) {
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
-template <int FX, int FW, int NB>
+template <int FX, int FW, int NB, bool PAIR = false>
 int launch_r_nb(const Args &a, hipStream_t st) {
-    constexpr int kLds = LinearFq8R<FX, FW, NB>::kLds;
+    constexpr int kLds = LinearFq8R<FX, FW, NB, PAIR>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r_kernel<FX, FW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r_kernel<FX, FW, NB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fq8r_kernel<FX, FW, NB><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fq8r_kernel<FX, FW, NB, PAIR><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -734,6 +889,11 @@ template <int FX, int FW>
 int launch(const Args &a, hipStream_t st) {
     const char *e_var = getenv("QT_FQ8_VARIANT");            // 1: raw bf16 weight tiles by LDS-DMA, 2: weights converted in registers
     const int variant = e_var ? atoi(e_var) : 2;
+    if (a.pair) {
+        if (a.nb <= 2) return launch_r_nb<FX, FW, 2, true>(a, st);
+        if (a.nb <= 4) return launch_r_nb<FX, FW, 4, true>(a, st);
+        return launch_r_nb<FX, FW, 6, true>(a, st);
+    }
     if (variant == 2) {
         if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
         if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
@@ -804,6 +964,45 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
     if (x_format == 0 && w_format == 1) return launch<0, 1>(a, st);
     if (x_format == 1 && w_format == 0) return launch<1, 0>(a, st);
     return QT_ERR_BAD_DTYPE;
+}
+
+int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_dev, const uint16_t *w_up_dev, const uint16_t *bias_gate_dev,
+                    const uint16_t *bias_up_dev, int N, int w_format, uint16_t *h_dev, uint8_t *h8_dev, const qt_format *out_format, int M, int K,
+                    void *stream) {
+    if (x_format < 0 || x_format > 1 || w_format < 0 || w_format > 1) return QT_ERR_BAD_DTYPE;
+    if (!out_format || out_format->kind != QT_FMT_FP_SAT || !(out_format->p0 == 2 || out_format->p0 == 3)) return QT_ERR_BAD_DTYPE;
+    if (N < 0 || N % 16 != 0) return QT_ERR_BAD_ARG;
+    if ((long)M * N == 0) return QT_OK;
+    if (!x8_dev || !w_gate_dev || !w_up_dev || !h_dev || !h8_dev || M < 0 || K < kBK || K % kBK != 0) return QT_ERR_BAD_ARG;
+    if (((uintptr_t)x8_dev | (uintptr_t)w_gate_dev | (uintptr_t)w_up_dev | (uintptr_t)h_dev | (uintptr_t)h8_dev) & 15u) return QT_ERR_UNALIGNED;
+    if ((bias_gate_dev && ((uintptr_t)bias_gate_dev & 7u)) || (bias_up_dev && ((uintptr_t)bias_up_dev & 7u))) return QT_ERR_UNALIGNED;
+    Args a{};
+    a.x8 = x8_dev; a.y = h_dev; a.y8 = h8_dev; a.M = M; a.K = K; a.ldc = N; a.pair = 1; a.out_fmt = *out_format;
+    a.tiles_m = (M + kTM - 1) / kTM;
+    // column tiles in gate / up pairs: at most six pairs (twelve column groups) each, whole rounds over the CUs
+    const long pairs = N / 16;
+    const int cus = cu_count();
+    const long tn_min = (pairs + 5) / 6;
+    const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
+    long tn = rounds * cus / a.tiles_m;
+    if (tn < tn_min) tn = tn_min;
+    if (tn > pairs) tn = pairs;
+    a.tiles_n = (int)tn;
+    a.gbase = (int)(pairs / tn);
+    a.gextra = (int)(pairs % tn);
+    const int worst_nt = 2 * (a.gbase + (a.gextra ? 1 : 0));
+    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
+    a.nb = (worst_nt * 4 + 7) / 8;
+    const char *e_dbg = getenv("QT_FQ8_DEBUG");
+    a.dbg = e_dbg ? atoi(e_dbg) : 0;
+    a.seg[0].w = w_gate_dev; a.seg[0].bias = bias_gate_dev; a.seg[0].g0 = 0;
+    a.seg[1].w = w_up_dev; a.seg[1].bias = bias_up_dev; a.seg[1].g0 = 0;
+    a.nseg = 2;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_format == 0 && w_format == 0) return launch<0, 0>(a, st);
+    if (x_format == 1 && w_format == 1) return launch<1, 1>(a, st);
+    if (x_format == 0 && w_format == 1) return launch<0, 1>(a, st);
+    return launch<1, 0>(a, st);
 }
 
 }  // extern "C"

@@ -68,6 +68,7 @@ SIGNATURES = {
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "qt_mlp_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, _P]),
     "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
                                _OPQ, _OPQ, _P]),
     "qt_softmax_fq_bf16": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P,

@@ -331,6 +331,74 @@ def _origin_key(x):
     return (x.data_ptr(), x._version, tuple(x.shape))         # the leader's input was handed through by its hook
 
 
+def hip_mlp_fq8_or_none(x8, gate, up, out_fq):
+    """(h, h8) = the gated MLP's front half in one launch (qt_mlp_fq8_bf16): fq_out(silu(gate(x)) * up(x)) as bf16 values and FP8
+    codes from the FP8 codes of x and the UNQUANTIZED bf16 weights of the QAT Linears `gate` / `up`.  None when the kernel does
+    not take the problem."""
+    K = x8.shape[-1]
+    Wg, Wu = gate.weight, up.weight
+    fg, fu = gate.weight_fake_quant._qt_format, up.weight_fake_quant._qt_format
+    if (x8.dtype not in _F8_CODE or K % 128 != 0 or not x8.is_contiguous() or x8.data_ptr() % 16 or Wg.shape != Wu.shape or fg.key() != fu.key()
+            or Wg.shape[1] != K or Wg.shape[0] % 16):
+        return None
+    for W in (Wg, Wu):
+        if W.dtype != torch.bfloat16 or not W.is_contiguous() or W.data_ptr() % 16 or W.device != x8.device:
+            return None
+    for l in (gate, up):
+        if l.bias is not None and (l.bias.dtype != torch.bfloat16 or not l.bias.is_contiguous() or l.bias.data_ptr() % 8 or l.bias.device != x8.device):
+            return None
+    N = Wg.shape[0]
+    M = x8.numel() // K
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=x8.device)
+    h8 = torch.empty((M, N), dtype=torch.uint8, device=x8.device)
+    rc = _native.lib().qt_mlp_fq8_bf16(x8.data_ptr(), _F8_CODE[x8.dtype], Wg.data_ptr(), Wu.data_ptr(),
+                                        gate.bias.data_ptr() if gate.bias is not None else None, up.bias.data_ptr() if up.bias is not None else None,
+                                        N, 1 if fg.p0 == 2 else 0, h.data_ptr(), h8.data_ptr(), ctypes.byref(out_fq._qt_format), M, K,
+                                        _stream_ptr(x8))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
+        return None
+    _native.check(rc, "qt_mlp_fq8_bf16")
+    return h, h8
+
+
+_MLP_CHOICE = {}          # (M, N, K, activation dtype, formats, device) -> True: one launch, False: two fused GEMMs + SiLU * up
+
+
+def mlp_route_is_one_launch(x8, gate, up, out_fq, three_launches):
+    """Whether qt_mlp_fq8_bf16 beats the launches it would replace on this problem: measured on the first call outside a stream
+    capture (`three_launches()` runs the two fused GEMMs and the SiLU * up pass on the same inputs); inside a capture, without a
+    measurement: one launch where it fills the chip in a single round (512 x 11008 x 4096: 67 against 97 us; at 1024 rows it needs two
+    rounds of uneven tiles and loses, 141 against 132 us)."""
+    if os.environ.get("QT_FQ8_MLP", "1") == "2":              # always (tests, ablations)
+        return True
+    K = x8.shape[-1]
+    M = x8.numel() // K
+    N = gate.weight.shape[0]
+    key = (M, N, K, x8.dtype, gate.weight_fake_quant._qt_format.key(), out_fq._qt_format.key(), x8.device.index)
+    hit = _MLP_CHOICE.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("QT_FQ8_TUNE", "1") == "0":
+            cus = torch.cuda.get_device_properties(x8.device).multi_processor_count
+            return ((M + 255) // 256) * ((N // 16 + 5) // 6) <= cus
+        if hip_mlp_fq8_or_none(x8, gate, up, out_fq) is None:
+            hit = False
+        else:
+            times = []
+            for fn in (lambda: hip_mlp_fq8_or_none(x8, gate, up, out_fq), three_launches):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(x8.device))
+                for _ in range(3):
+                    fn()
+                e1.record(torch.cuda.current_stream(x8.device))
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1))
+            hit = times[0] < times[1]
+        _MLP_CHOICE[key] = hit
+    return hit
+
+
 def _sibling_linear_or_none(layer, x, x8):
     group = layer.__dict__.get("_qt_sibling_group")
     if group is None or os.environ.get("QT_SIBLING_GEMM", "1") == "0" or prefetch_enabled() or _WEIGHT_CACHE["on"]:

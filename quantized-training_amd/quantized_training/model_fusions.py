@@ -421,8 +421,97 @@ def _rmsnorm_forward(self, hidden_states):
     return self._qt_hf_forward(hidden_states)
 
 
+def _only_pre_hooks(mod):
+    return not (mod._forward_hooks or mod._backward_hooks or mod._backward_pre_hooks)
+
+
+def _run_pre_hooks(mod, x):
+    """What Module.__call__ does with the forward pre-hooks quantize() registered (quantize.py:128-140: the input fake-quantizers):
+    the possibly replaced positional input."""
+    args = (x,)
+    for hook_id, hook in mod._forward_pre_hooks.items():
+        if hook_id in mod._forward_pre_hooks_with_kwargs:
+            res = hook(mod, args, {})
+            if res is not None:
+                args = res[0]
+        else:
+            res = hook(mod, args)
+            if res is not None:
+                args = res if isinstance(res, tuple) else (res,)
+    return args[0]
+
+
+def _fused_mlp_or_none(self, x):
+    """gate_proj, up_proj, SiLU * up and the down projection's input fake-quantizer as ONE launch (qt_mlp_fq8_bf16) when both
+    projections are QAT Linears on the FP8 route whose fused GEMM is the measured choice for this shape.  Every fake-quant call of
+    the module chain still happens and is counted once: the two input fake-quantizers run as hooks (the second one on the already
+    quantized tensor, as before), the two weight fake-quantizers and the consumer's inside the kernel."""
+    from . import fused
+    from .fake_quantize import STATS, handover_valid
+    from .modules.qat.linear import Linear as QATLinear
+    gate, up, down = self.gate_proj, self.up_proj, self.down_proj
+    if os.environ.get("QT_FQ8_MLP", "1") == "0" or not fused.fq8_gemm_enabled() or fused.prefetch_enabled() or fused._WEIGHT_CACHE["on"]:
+        return None
+    if not (isinstance(gate, QATLinear) and isinstance(up, QATLinear) and _eligible(x) and _only_pre_hooks(gate) and _only_pre_hooks(up)):
+        return None
+    if os.environ.get("QT_FUSED_PRODUCER_FQ", "1") == "0":
+        return None
+    fq_out = consumer_fq(down)
+    for l in (gate, up):
+        f = l.weight_fake_quant
+        if not (isinstance(f, FusedAmaxObsFakeQuantize) and f.fp8_exact()):
+            return None
+    if fq_out is None or gate.weight.shape != up.weight.shape or x.shape[-1] != gate.weight.shape[1]:
+        return None
+    # The route is decided before any hook runs (a hook must not run twice): x has to arrive with the FP8 code its producer
+    # (the RMSNorm kernel, for its first consumer) attached.
+    x8 = getattr(x, "_qt_fp8", None) if handover_valid(x) else None
+    if x8 is None or getattr(x, "_qt_fq_done_by", None) is None or not fused.fq8_route_is_fused(x8.reshape(-1, x8.shape[-1]), [gate]):
+        return None
+    x8f = x8.reshape(-1, x8.shape[-1])
+
+    def three_launches():                                       # what the one launch replaces, for the measurement only
+        g = fused.hip_fq8_linear_or_none(x8f, [gate])
+        u = fused.hip_fq8_linear_or_none(x8f, [up])
+        return silu_mul_fq(g, u, fq_out)
+    for l in (gate, up):
+        l.weight_fake_quant._move_to(x.device)
+    if not fused.mlp_route_is_one_launch(x8f, gate, up, fq_out, three_launches):
+        return None
+    xg = _run_pre_hooks(gate, x)                               # gate's input fake-quantizer: hands the producer's result through, counted
+    x8 = getattr(xg, "_qt_fp8", None) if handover_valid(xg) else None
+    xu = _run_pre_hooks(up, x)                                 # up's own input fake-quantizer: same values, still computed and counted
+    if x8 is None:
+        return _after_hooks_unfused(self, xg, xu)
+    for l in (gate, up):
+        l.weight_fake_quant._move_to(x.device)
+    got = fused.hip_mlp_fq8_or_none(x8.reshape(-1, x8.shape[-1]), gate, up, fq_out)
+    if got is None:
+        return _after_hooks_unfused(self, xg, xu)
+    STATS.add(gate.weight.numel())
+    STATS.add(up.weight.numel())
+    h, h8 = got
+    y = h.reshape(*x.shape[:-1], gate.weight.shape[0])
+    y._qt_fp8 = _fp8_view(h8.reshape(y.shape), fq_out)
+    y._qt_fq_done_by = fq_out
+    y._qt_ver = y._version
+    return y
+
+
+def _after_hooks_unfused(self, xg, xu):
+    """Both projections' input hooks have run but the fused kernel cannot be used after all: finish with the Linears' own forwards
+    (no hooks again) and the one-launch SiLU * up."""
+    gate = self.gate_proj.forward(xg)
+    up = self.up_proj.forward(xu)
+    fq = consumer_fq(self.down_proj)
+    return silu_mul_fq(gate, up, fq) if fq is not None else silu_mul(gate, up)
+
+
 def _mlp_forward(self, x):
     if not _hooked(self.act_fn) and getattr(self.act_fn, "__class__", None).__name__ in ("SiLU", "SiLUActivation"):
+        y = _fused_mlp_or_none(self, x)
+        if y is not None:
+            return self.down_proj(y)
         gate = self.gate_proj(x)
         up = self.up_proj(x)
         if _eligible(gate, up) and gate.shape == up.shape and gate.shape[-1] % 8 == 0 and gate.numel() > 0:

@@ -109,6 +109,40 @@ def _assert_logits(outs):
             ("default", float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale, corr)
 
 
+def test_llama_mlp_front_half_as_one_launch(monkeypatch):
+    """QT_FQ8_MLP=2 forces qt_mlp_fq8_bf16 (gate GEMM + up GEMM + SiLU * up + the down projection's input fake-quantizer in one
+    launch) wherever the fused FP8 GEMM runs: logits bit-identical to the same model with the three launches it replaces (same
+    matrix-instruction tiles in the same k order), identical fake-quant call and element counts."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from quantized_training import fake_quantize, fused
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=320, max_position_embeddings=256)
+    m = LlamaForCausalLM(cfg).eval().bfloat16().cuda()
+    qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16"))
+    ids = torch.randint(3, 320, (2, 96), generator=torch.Generator().manual_seed(2)).cuda()
+    monkeypatch.setenv("QT_FQ8_GEMM", "1")
+    calls = {"n": 0}
+    real = fused.hip_mlp_fq8_or_none
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(fused, "hip_mlp_fq8_or_none", counted)
+    outs, counts = {}, {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("QT_FQ8_MLP", mode)
+        with torch.no_grad():
+            m(ids)
+            fake_quantize.STATS.reset()
+            calls["n"] = 0
+            outs[mode] = m(ids).logits.float()
+            counts[mode] = (fake_quantize.STATS.elements, fake_quantize.STATS.calls, calls["n"])
+    assert counts["0"][:2] == counts["2"][:2]
+    assert counts["0"][2] == 0 and counts["2"][2] == cfg.num_hidden_layers
+    assert torch.equal(outs["0"], outs["2"])
+
+
 def test_bert_squad_style_batch_parity(monkeypatch):
     """BERT-base-style QA head (tiny config), bf16, E4M3 act+weight + all op groups: start/end logits of a
     [16, 384]-shaped batch: CPU tensors against the device's plain route (same operations: tight) and its default route."""

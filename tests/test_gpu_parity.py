@@ -1343,6 +1343,40 @@ def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 11008, 512), (300, 96, 256), (520, 2064, 384), (1, 16, 128), (64, 4096, 1024)])
+@pytest.mark.parametrize("xdtype,wdtype,odtype", [("e4m3", "e4m3", "e4m3"), ("e4m3", "e5m2", "e5m2")])
+def test_mlp_fq8_equals_two_gemms_and_silu_mul(nv, M, N, K, xdtype, wdtype, odtype):
+    """qt_mlp_fq8_bf16 = gate GEMM, up GEMM (qt_linear_fq8_bf16: same tiles of the matrix instruction in the same k order, so the
+    same fp32 sums), SiLU * up and the consumer's fake-quantizer (qt_silu_mul_fq8_bf16) -- values and FP8 codes bit for bit, with
+    bias, ragged M, and weights beyond the format's range / non-finite ones (the kernel's redo path)."""
+    L = nv.lib()
+    torch.manual_seed(3)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    wg = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    wu = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    bg, bu = torch.randn(N, device="cuda").bfloat16(), None
+    x8 = _codes_of(nv, x, xdtype)
+    fo = nv.format_for(odtype)
+    for poison in (False, True):
+        if poison:                                   # a tile with an overflowing and an infinite weight: the exact redo path
+            wg[min(3, N - 1), 5] = 30000.0 if wdtype == "e4m3" else 1e30
+            wu[N // 2, 7] = float("inf")
+        yg = _linear_fq8(nv, x8, xdtype, [wg], wdtype, [bg])
+        yu = _linear_fq8(nv, x8, xdtype, [wu], wdtype, [bu])
+        want = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        want8 = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+        nv.check(L.qt_silu_mul_fq8_bf16(yg.data_ptr(), yu.data_ptr(), want.data_ptr(), want8.data_ptr(), M, N, N, N, ctypes.byref(fo),
+                                        stream()), "qt_silu_mul_fq8_bf16")
+        h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        h8 = torch.full((M, N), 0x55, dtype=torch.uint8, device="cuda")
+        nv.check(L.qt_mlp_fq8_bf16(x8.data_ptr(), 0 if xdtype == "e4m3" else 1, wg.data_ptr(), wu.data_ptr(), bg.data_ptr(), None, N,
+                                   0 if wdtype == "e4m3" else 1, h.data_ptr(), h8.data_ptr(), ctypes.byref(fo), M, K, stream()), "qt_mlp_fq8_bf16")
+        a, b = o.canon_nan16(host_u16(h.view(torch.int16))), o.canon_nan16(host_u16(want.view(torch.int16)))
+        assert np.array_equal(a, b), (poison, int((a != b).sum()))
+        nan = (b == 0x7FC0)
+        assert np.array_equal(h8.cpu().numpy()[~nan.reshape(M, N)], want8.cpu().numpy()[~nan.reshape(M, N)]), poison
+
+
 def test_linear_fq8_rejects_what_it_does_not_take(nv):
     x8 = torch.zeros(16, 192, dtype=torch.uint8, device="cuda")
     w = torch.zeros(32, 192, dtype=torch.bfloat16, device="cuda")
