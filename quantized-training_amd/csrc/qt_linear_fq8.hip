@@ -777,6 +777,238 @@ __device__ __forceinline__ void slow_tile_pair(const Args &a, int m0, int tg0, i
     }
 }
 
+// ---- variant R2: variant R with TWO k tiles per step, for narrow tiles (at most four column groups) -----------------------
+// A 256 x 64 tile multiplies 8 times per wave and k tile; the step's fixed costs -- barrier, the waits for the DMA pieces and
+// the weight registers, the LDS latency in front of the first multiplication -- are then ~0.7 of a 1.0 us step (1024 x 4096 x
+// 11008: 85 us for 86 steps).  Here a step is 256 deep: half as many of those, twice the work to cover them.  Activations two
+// steps of 64 KiB (the DMA of step s + 1 lands during step s), FP8 weight tiles 2 x 2 x 8 KiB: 160 KiB of LDS.
+template <int FX, int FW>
+struct LinearFq8R2 {
+    static constexpr int NB = 2;                            // weight pieces per wave and k tile
+    static constexpr int kAStage = 2 * kABytes, kWTile = NB * 4 * 1024, kWStage = 2 * kWTile;
+    static constexpr int kLds = 2 * kAStage + 2 * kWStage;
+    static constexpr int kItems = 8 + 2 * NB;               // per step and wave: 8 activation DMA pieces, 4 weight items
+    // items of group gi (k half h = gi / NTW, column group J = gi % NTW) out of G = 2 NTW: DMA pieces on the first half of the
+    // groups, weight items (convert + ds_write + reload) on the second half
+    static constexpr int item_lo(int gi, int G) { return gi < G / 2 ? gi * 8 / (G / 2) : 8 + (gi - G / 2) * (2 * NB) / (G - G / 2); }
+    static constexpr int item_hi(int gi, int G) { return gi < G / 2 ? (gi + 1) * 8 / (G / 2) : 8 + (gi - G / 2 + 1) * (2 * NB) / (G - G / 2); }
+    static constexpr int writes_in(int gi, int G) {
+        const int lo = item_lo(gi, G), hi = item_hi(gi, G);
+        return (hi > 8 ? hi : 8) - (lo > 8 ? lo : 8);
+    }
+
+    template <int NTW>
+    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
+        static_assert(NTW <= 2, "narrow tiles only");
+        const int r = l & 15, g = l >> 4, wm = w & 3;
+        const int ns = a.K / (2 * kBK), slast = ns - 1;       // steps of two k tiles
+        const uint8_t *ga[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
+            ga[i] = a.x8 + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        const int npieces = nt * 4;
+        const uint8_t *gw[NB];
+        uint32_t wdst[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int p = w + 8 * i, pb = p < npieces ? p : (w & 3);
+            const int grp = tg0 + (pb >> 2);
+            const int row = pb * 4 + (l >> 4), c = l & 15;
+            const SegRef sg = seg_lookup(a, grp);
+            gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
+        }
+        u32x4 wr[2 * NB];                                      // [k half][piece]
+        auto dma16 = [](const uint8_t *src, uint32_t dst) __attribute__((always_inline)) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        auto ds_write64 = [](uint32_t addr, u32x2 v) __attribute__((always_inline)) {
+            asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        };
+        // item 0-7: activation piece (k half I / 4, piece I % 4) of step sa into `as`; item 8 + i: weight registers i (k half i / NB,
+        // piece i % NB, holding step sb - 1) converted into the FP8 tiles at `ws`, then reloaded with step sb
+        auto item = [&](auto ic, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I < 8) {
+                dma16(ga[I & 3] + (long)(2 * sa + (I >> 2)) * kBK, as + (I >> 2) * kABytes + (w * 4 + (I & 3)) * 1024);
+            } else {
+                constexpr int Wi = I - 8, H = Wi / NB, P = Wi % NB;
+                const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[Wi].x, wr[Wi].y), cvt_bf16x4<FW == 1>(wr[Wi].z, wr[Wi].w)};
+                const uint32_t addr = ws + H * kWTile + wdst[P];
+                ds_write64(addr, codes);
+                wr[Wi] = *(const u32x4 *)(gw[P] + (long)(2 * sb + H) * (2 * kBK));
+            }
+        };
+        auto items = [&](auto lo, auto hi, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            static_assert(HI - LO <= 12, "at most twelve items");
+            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, sa, as, ws, sb);
+            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, sa, as, ws, sb);
+            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, sa, as, ws, sb);
+            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, sa, as, ws, sb);
+            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, sa, as, ws, sb);
+            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, sa, as, ws, sb);
+            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, sa, as, ws, sb);
+            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, sa, as, ws, sb);
+            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, sa, as, ws, sb);
+            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, sa, as, ws, sb);
+            if constexpr (LO + 10 < HI) item(std::integral_constant<int, LO + 10>{}, sa, as, ws, sb);
+            if constexpr (LO + 11 < HI) item(std::integral_constant<int, LO + 11>{}, sa, as, ws, sb);
+        };
+        constexpr auto kI0 = std::integral_constant<int, 0>{};
+        constexpr auto kIA = std::integral_constant<int, 8>{};
+        constexpr auto kIN = std::integral_constant<int, kItems>{};
+
+        v4f acc[4][NTW > 0 ? NTW : 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        const uint32_t a_lo = a_chunk_off(wm * 64 + r, g), a_hi = a_chunk_off(wm * 64 + r, 4 + g);
+        const uint32_t b_lo = a_chunk_off(jbase * 16 + r, g), b_hi = a_chunk_off(jbase * 16 + r, 4 + g);
+
+        // one k half (activations at sa_, FP8 weights at sb_) of a step, carrying the step's items of its groups
+        auto half = [&](auto hc, uint32_t sa_, uint32_t sb_, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+            constexpr int H = decltype(hc)::value, G = 2 * NTW;
+            u32x4 fa_lo[4], fa_hi[4], fb_lo[2], fb_hi[2];
+            fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
+            fa_lo[1] = ds_read128<1 * 2048>(sa_ + a_lo); fa_hi[1] = ds_read128<1 * 2048>(sa_ + a_hi);
+            fa_lo[2] = ds_read128<2 * 2048>(sa_ + a_lo); fa_hi[2] = ds_read128<2 * 2048>(sa_ + a_hi);
+            fa_lo[3] = ds_read128<3 * 2048>(sa_ + a_lo); fa_hi[3] = ds_read128<3 * 2048>(sa_ + a_hi);
+            fb_lo[0] = ds_read128<0>(sb_ + b_lo); fb_hi[0] = ds_read128<0>(sb_ + b_hi);
+            if constexpr (NTW > 1) { fb_lo[1] = ds_read128<2048>(sb_ + b_lo); fb_hi[1] = ds_read128<2048>(sb_ + b_hi); }
+            v8i fa[4];
+            auto step = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(jc)::value, gi = H * NTW + J;
+                __builtin_amdgcn_sched_barrier(0);
+                // LDS operations issued behind this group's fragment reads: the next group's reads and the ds_writes of the group in front
+                constexpr int kAhead = (J + 1 < NTW ? 2 : 0) + (J >= 1 ? writes_in(gi - 1, G) : 0);
+                if constexpr (J == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(%10)"
+                                 : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]), "+v"(fa_lo[3]),
+                                   "+v"(fa_hi[3]), "+v"(fb_lo[0]), "+v"(fb_hi[0])
+                                 : "n"(kAhead));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        fa[i] = v8i{(int)fa_lo[i].x, (int)fa_lo[i].y, (int)fa_lo[i].z, (int)fa_lo[i].w,
+                                    (int)fa_hi[i].x, (int)fa_hi[i].y, (int)fa_hi[i].z, (int)fa_hi[i].w};
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb_lo[J]), "+v"(fb_hi[J]) : "n"(kAhead));
+                }
+                const v8i fb = v8i{(int)fb_lo[J].x, (int)fb_lo[J].y, (int)fb_lo[J].z, (int)fb_lo[J].w,
+                                   (int)fb_hi[J].x, (int)fb_hi[J].y, (int)fb_hi[J].z, (int)fb_hi[J].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
+                items(std::integral_constant<int, item_lo(gi, G)>{}, std::integral_constant<int, item_hi(gi, G)>{}, sa, as, ws, sb);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});
+            if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
+        };
+
+        const uint32_t l0 = lds_addr(lds), w0 = l0 + 2 * kAStage;
+        // prologue: activations of step 0 on their way; weights of step 0 converted into FP8 stage 0, those of step 1 in registers
+        items(kI0, kIA, 0, l0, w0, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) wr[i] = *(const u32x4 *)(gw[i % NB] + (long)(i / NB) * (2 * kBK));
+        items(kIA, kIN, 0, l0, w0, min(1, slast));
+        for (int s = 0; s < ns; ++s) {
+            // the weight loads of step s + 1 are the newest entries of this wave's queue; its DMA pieces of step s are older
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int sa = min(s + 1, slast), sb = min(s + 2, slast);
+            const uint32_t sa_ = l0 + (s & 1) * kAStage, sb_ = w0 + (s & 1) * kWStage;
+            const uint32_t as = l0 + ((s + 1) & 1) * kAStage, ws = w0 + ((s + 1) & 1) * kWStage;
+            if constexpr (NTW > 0) {
+                half(std::integral_constant<int, 0>{}, sa_, sb_, sa, as, ws, sb);
+                half(std::integral_constant<int, 1>{}, sa_ + kABytes, sb_ + kWTile, sa, as, ws, sb);
+            } else {
+                items(kI0, kIN, sa, as, ws, sb);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        bool bad = false;
+        if constexpr (NTW > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
+        }
+        __syncthreads();
+        volatile int *flag = (volatile int *)(lds + 8 * 64 * (6 * 32 + 8));
+        if (w == 0 && l == 0) *flag = 0;
+        __syncthreads();
+        if (bad) *flag = 1;
+        __syncthreads();
+        if (*flag) return true;
+        if constexpr (NTW > 0) {
+            constexpr int kRowB = NTW * 32 + 8;
+            const uint32_t tbase = l0 + w * (64 * (6 * 32 + 8));
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int grp = tg0 + jbase + j;
+                const SegRef sg = seg_lookup(a, grp);
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (sg.bias) {
+                    const uint2 b = *(const uint2 *)(sg.bias + (grp * 16 + 4 * g - sg.g0 * 16));
+                    bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
+                    bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
+                    ds_write64(tbase + (i * 16 + r) * kRowB + j * 32 + g * 8, o);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int kChunksPerRow = NTW * 2, kChunks = 64 * kChunksPerRow;
+            const long col0 = (long)(tg0 + jbase) * 16;
+#pragma unroll
+            for (int it = 0; it < (kChunks + 63) / 64; ++it) {
+                const int c = it * 64 + l, row = c / kChunksPerRow, ch = c % kChunksPerRow;
+                uint2 lo_, hi_;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo_), "=&v"(hi_) : "v"(tbase + row * kRowB + ch * 16) : "memory");
+                const int grow = m0 + wm * 64 + row;
+                if (c < kChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+            }
+        }
+        return false;
+    }
+};
+
+template <int FX, int FW>
+__global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_r2[];
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        id = x * per + (x < rem ? x : rem) + q;
+    }
+    const int tn = id / a.tiles_m, tm = id % a.tiles_m;
+    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
+    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    const int m0 = tm * kTM;
+    const int nt0 = (nt + 1) >> 1;
+    const int wn = w >> 2;
+    const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
+    using L = LinearFq8R2<FX, FW>;
+    bool redo;
+    switch (ntw) {                                          // wave-uniform
+        case 0: redo = L::template run<0>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
+        case 1: redo = L::template run<1>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
+        default: redo = L::template run<2>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
+    }
+    if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+}
+
 template <int FX, int FW, int NB>
 __global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -886,6 +1118,20 @@ int launch_r_nb(const Args &a, hipStream_t st) {
 }
 
 template <int FX, int FW>
+int launch_r2(const Args &a, hipStream_t st) {
+    constexpr int kLds = LinearFq8R2<FX, FW>::kLds;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r2_kernel<FX, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    linear_fq8r2_kernel<FX, FW><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+template <int FX, int FW>
 int launch(const Args &a, hipStream_t st) {
     const char *e_var = getenv("QT_FQ8_VARIANT");            // 1: raw bf16 weight tiles by LDS-DMA, 2: weights converted in registers
     const int variant = e_var ? atoi(e_var) : 2;
@@ -895,6 +1141,8 @@ int launch(const Args &a, hipStream_t st) {
         return launch_r_nb<FX, FW, 6, true>(a, st);
     }
     if (variant == 2) {
+        const char *e_r2 = getenv("QT_FQ8_R2");              // 0: narrow tiles keep one k tile per step
+        if (a.nb <= 2 && a.K % (2 * kBK) == 0 && !(e_r2 && atoi(e_r2) == 0)) return launch_r2<FX, FW>(a, st);
         if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
         if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
         return launch_r_nb<FX, FW, 6>(a, st);
