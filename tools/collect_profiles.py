@@ -52,13 +52,31 @@ def traffic_of(kernel, bytes_per_elem, bench_ms):
     }
 
 
-res = traffic_of("fq_kernel", 4, bench["roofline"]["bf16_out"]["ms_per_launch"])
+roof = bench["roofline"].get("elementwise_pass", bench["roofline"])      # round 2: the pass sits beside the fused GEMM
+res = traffic_of("fq_kernel", 4, roof["bf16_out"]["ms_per_launch"])
 res.update({
     "tensor": "bf16[4096,11008], 8-tensor rotating pool (1.44 GB in + out)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/roofline_only.py",
     "FETCH_SIZE_correction": "x2 on gfx950 (16 B/lane coalesced streaming reads are tallied at half)",
-    "fp8_only": traffic_of("fq8_kernel", 3, bench["roofline"]["ms_per_launch"]),
+    "fp8_only": traffic_of("fq8_kernel", 3, roof["ms_per_launch"]),
 })
+try:                                                     # the fused FP8 GEMM leg (round 2): same passes, its own kernel rows
+    fetch, nf = pmc(one("pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE", "linear_fq8r_kernel")
+    write, nw = pmc(one("pmc_write/*/*counter_collection.csv"), "WRITE_SIZE", "linear_fq8r_kernel")
+    k = [r for r in rows if "linear_fq8r_kernel" in r["Name"]][0]
+    M_, N_, K_ = 1024, 11008, 4096
+    alg = N_ * K_ * 2 + M_ * K_ + M_ * N_ * 2
+    res["fused_gemm"] = {
+        "kernel": k["Name"][:120], "launches_sampled": [nf, nw], "FETCH_SIZE_KB_raw_per_launch": fetch,
+        "fetch_bytes_per_launch": int(fetch * 1024 * 2), "WRITE_SIZE_KB_per_launch": write, "write_bytes_per_launch": int(write * 1024),
+        "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "algorithmic_bytes_per_launch": alg,
+        "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / alg,
+        "kernel_avg_duration_us_rocprof": float(k["AverageNs"]) / 1e3,
+        "note": "1024 x 11008 x 4096: weights 2 B/element once + FP8 activations once + bf16 output once; fetches beyond that are the "
+                "activation tile re-read by the 64 column tiles through L2 misses",
+    }
+except Exception as e:  # noqa: BLE001
+    print("no fused GEMM rows in the PMC passes:", e)
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 
