@@ -28,10 +28,13 @@
 // asm so that hipcc does not drain the DMA queue in front of them, see qt_mx_gemm.hip).  The two waves of a SIMD issue their
 // DMA half a step apart (column half 0 in front of its multiplications, half 1 in the middle of them).
 //
-// Measured on MI355X (tools/exp_linear_fq8.py): 1024 x 11008 x 4096 in 78 us against 65 us for the weight pass
-// + library GEMM pair, so the host side keeps this entry opt-in (QT_FQ8_GEMM=1).  The raw bf16 weight tile makes a stage
-// 76 KiB: the ring cannot be deeper than two, and a two-deep ring pays the tiles' issue-to-landed time on every step (DMA alone:
-// 54 us; multiplications alone: 44 us).
+// The text above describes variant 1 (LinearFq8: raw bf16 weight tiles by LDS-DMA, converted by every wave that multiplies them),
+// kept for the ablation.  What the host launches by default is variant R / R2 further down (LinearFq8R, LinearFq8R2: weights
+// converted in registers on the way in, FP8 weight tiles in LDS) and its pair mode (qt_mlp_fq8_bf16).
+//
+// Measured on MI355X (tools/exp_linear_fq8.py): 1024 x 11008 x 4096 in 56 us (variant R) against 66-70 us for the
+// weight pass + library GEMM pair and 78 us for variant 1, whose 76 KiB stages allow a ring of two only -- a two-deep ring pays the
+// tiles' issue-to-landed time on every step (DMA alone: 54 us; multiplications alone: 44 us).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
