@@ -82,6 +82,11 @@ struct Args {
     qt_format out_fmt;        // the output fake-quantizer (E4M3 / E5M2 closed form, unit scale)
 };
 
+// Column tile tn of tiles_n: first unit (16-column group, or gate / up pair) and unit count.  The gextra tiles that are one unit wider
+// are spread evenly over the tile index (tile tn starts at floor(tn * units / tiles_n)): with all of them in front, the XCDs that own
+// the first tiles (tile ids are contiguous per XCD) carry up to a fifth more work than the others and the launch waits for them.
+__device__ __forceinline__ void tile_span(const Args &a, int tn, int &first, int &count);
+
 // The weight holding column group `grp`, by compile-time indices only: a run-time index into the kernel-argument struct makes
 // hipcc copy the whole struct to scratch memory and read its fields from there.
 struct SegRef { const uint16_t *w, *bias; int g0; };
@@ -91,6 +96,12 @@ __device__ __forceinline__ SegRef seg_lookup(const Args &a, int grp) {
     if (a.nseg > 2 && grp >= a.seg[2].g0) r = SegRef{a.seg[2].w, a.seg[2].bias, a.seg[2].g0};
     if (a.nseg > 3 && grp >= a.seg[3].g0) r = SegRef{a.seg[3].w, a.seg[3].bias, a.seg[3].g0};
     return r;
+}
+
+__device__ __forceinline__ void tile_span(const Args &a, int tn, int &first, int &count) {
+    const long units = (long)a.gbase * a.tiles_n + a.gextra;
+    first = (int)(tn * units / a.tiles_n);
+    count = (int)((tn + 1) * units / a.tiles_n) - first;
 }
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
@@ -996,8 +1007,8 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
         id = x * per + (x < rem ? x : rem) + q;
     }
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
-    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
-    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    int tg0, nt;
+    tile_span(a, tn, tg0, nt);
     const int m0 = tm * kTM;
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
@@ -1025,8 +1036,8 @@ __global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
         id = x * per + (x < rem ? x : rem) + q;
     }
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
-    const int nt = a.gbase + (tn < a.gextra ? 1 : 0);
-    const int tg0 = tn * a.gbase + min(tn, a.gextra);
+    int tg0, nt;
+    tile_span(a, tn, tg0, nt);
     const int m0 = tm * kTM;
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
@@ -1058,9 +1069,10 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
     // column groups of this tile; in pair mode gbase / gextra count gate / up pairs and each wave half gets whole pairs
     const int unit = PAIR ? 2 : 1;
-    const int nu = a.gbase + (tn < a.gextra ? 1 : 0);
+    int u0, nu;
+    tile_span(a, tn, u0, nu);
     const int nt = unit * nu;
-    const int tg0 = unit * (tn * a.gbase + min(tn, a.gextra));
+    const int tg0 = unit * u0;
     const int m0 = tm * kTM;
     const int nt0 = unit * ((nu + 1) >> 1);
     const int wn = w >> 2;
