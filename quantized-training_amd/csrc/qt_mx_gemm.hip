@@ -337,6 +337,7 @@ __device__ __forceinline__ uint4 asm_ds_read_b128_off(uint32_t addr) {
     return v;
 }
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));      // native vector: usable as a "+v" asm operand
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ u32x4w ds_read128w(uint32_t addr) {
     u32x4w v;
@@ -961,37 +962,66 @@ struct MxWide {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the repeats of the last k tile
 
-        // ---- epilogue: lane (r, g) of tile (i, j) holds C[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]
+        // ---- epilogue: lane (r, g) of tile (i, j) holds C[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3].  bf16 output: every
+        // wave turns its 64 x 16 NTW tile around in its own 13 KiB of the (now dead) rings and stores whole rows, 32 NTW contiguous
+        // bytes each instead of 32; fp32 output: 16-byte stores straight from the registers.
         if constexpr (NTW > 0) {
             const long cbase = bz * a.bC;
+            float bvs[NTW][4];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int col = (tg0 + jbase + j) * 16 + 4 * g;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                bvs[j][0] = bvs[j][1] = bvs[j][2] = bvs[j][3] = 0.f;
                 if (a.bias) {
                     if (a.out_f32) {
                         const float4 b = *(const float4 *)((const float *)a.bias + col);
-                        bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+                        bvs[j][0] = b.x; bvs[j][1] = b.y; bvs[j][2] = b.z; bvs[j][3] = b.w;
                     } else {
                         const uint2 b = *(const uint2 *)((const uint16_t *)a.bias + col);
-                        bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
-                        bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * 64 + i * 16 + r;
-                    if (row >= a.M) continue;
-                    const long idx = cbase + (long)row * a.N + col;
-                    if (a.out_f32) {
-                        *(float4 *)((float *)a.C + idx) = float4{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
-                    } else {
-                        const uint32_t p0 = (uint32_t)qt_f2bf(acc[i][j][0] + bv[0]) | ((uint32_t)qt_f2bf(acc[i][j][1] + bv[1]) << 16);
-                        const uint32_t p1 = (uint32_t)qt_f2bf(acc[i][j][2] + bv[2]) | ((uint32_t)qt_f2bf(acc[i][j][3] + bv[3]) << 16);
-                        *(uint2 *)((uint16_t *)a.C + idx) = uint2{p0, p1};
+                        bvs[j][0] = qt_u2f(b.x << 16); bvs[j][1] = qt_u2f(b.x & 0xFFFF0000u);
+                        bvs[j][2] = qt_u2f(b.y << 16); bvs[j][3] = qt_u2f(b.y & 0xFFFF0000u);
                     }
                 }
             }
+            if (a.out_f32) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int col = (tg0 + jbase + j) * 16 + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + wm * 64 + i * 16 + r;
+                        if (row >= a.M) continue;
+                        *(float4 *)((float *)a.C + cbase + (long)row * a.N + col) =
+                            float4{acc[i][j][0] + bvs[j][0], acc[i][j][1] + bvs[j][1], acc[i][j][2] + bvs[j][2], acc[i][j][3] + bvs[j][3]};
+                    }
+                }
+            } else {
+                constexpr int kRowB = NTW * 32 + 8;                    // + 8: rows 16 apart would otherwise share banks
+                const uint32_t tbase = l0 + w * (64 * (6 * 32 + 8));
+                __syncthreads();                                       // every wave is out of the k loop: the rings are free
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t p0 = (uint32_t)qt_f2bf(acc[i][j][0] + bvs[j][0]) | ((uint32_t)qt_f2bf(acc[i][j][1] + bvs[j][1]) << 16);
+                        const uint32_t p1 = (uint32_t)qt_f2bf(acc[i][j][2] + bvs[j][2]) | ((uint32_t)qt_f2bf(acc[i][j][3] + bvs[j][3]) << 16);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(tbase + (i * 16 + r) * kRowB + j * 32 + g * 8), "v"(u32x2w{p0, p1}) : "memory");
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                constexpr int kChunksPerRow = NTW * 2, kChunks = 64 * kChunksPerRow;
+                const long col0 = (long)(tg0 + jbase) * 16;
+#pragma unroll
+                for (int it = 0; it < (kChunks + 63) / 64; ++it) {
+                    const int c = it * 64 + l, row = c / kChunksPerRow, ch = c % kChunksPerRow;
+                    uint2 lo_, hi_;
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo_), "=&v"(hi_) : "v"(tbase + row * kRowB + ch * 16) : "memory");
+                    const int grow = m0 + wm * 64 + row;
+                    if (c < kChunks && grow < a.M) *(uint4 *)((uint16_t *)a.C + cbase + (long)grow * a.N + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+                }
+            }
+        } else {
+            if (!a.out_f32) __syncthreads();                           // the barrier of the bf16 epilogue above
         }
     }
 };
