@@ -12,3 +12,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 python tools/window_breakdown.py gpurun_out/prof_13b_posit --windows 3 --layers 40 --anchor softmax > gpurun_out/window_breakdown_13b_posit.txt 2>&1
 head -25 gpurun_out/window_breakdown_13b_posit.txt
 find gpurun_out/prof_13b_posit -name "*kernel_trace.csv" -delete
+# the fused FP8 GEMM against the pair it replaces (both variants) and the one-launch MLP front half
+bash tools/gpu_session_fq8.sh > /dev/null 2>&1
+timeout 600 python tools/exp_mlp_fq8.py > gpurun_out/mlp_fq8.txt 2>&1
+grep -E "^bench" gpurun_out/fq8_session.txt | head -8 | cut -c1-120
