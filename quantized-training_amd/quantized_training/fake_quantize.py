@@ -18,6 +18,7 @@ What is different underneath:
 """
 import ctypes
 import logging
+import os
 from typing import Optional
 
 import torch
@@ -632,6 +633,23 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             # reference issues here is satisfied by that fused computation, counted once
             _Stats.add(X.numel())
             return X
+        if (done_by is not None and self._emit_fp8 and isinstance(done_by, FusedAmaxObsFakeQuantize) and handover_valid(X)
+                and getattr(X, "_qt_fp8", None) is not None and X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous()
+                and not (torch.is_grad_enabled() and X.requires_grad) and self.producer_fusable() and done_by.producer_fusable()
+                and done_by._qt_format.key() == self._qt_format.key() and os.environ.get("QT_FQ_IDEMPOTENT", "1") != "0"):
+            # X was produced by an identical stateless fake-quantizer (a sibling's: q beside k, v; gate beside up), so it lies on
+            # this format's grid, where the fake-quantizer is the identity: the result of this call is X, value for value.  The call
+            # is still evaluated -- the pass below computes the FP8 code of every element of X -- but the bf16 tensor it would
+            # write is a copy of X and is not written: the result is a view of X carrying the codes just computed.
+            self._move_to(X.device)
+            _Stats.add(X.numel())
+            x8 = FusedAmaxObsFakeQuantFunction.apply(X, False, True, self.qmap, self.amax_history, self.scale, self.amax_history_len,
+                                                      self.quant_max, None, False, False, self._qt_format, "only")
+            out = X.view(X.shape)
+            out._qt_fp8 = x8
+            out._qt_ver = out._version
+            out._qt_origin = (X.data_ptr(), X._version, tuple(X.shape))
+            return out
         expect = self.__dict__.get("_qt_expected")
         if expect is not None:
             # same hand-over when the producer's tensor reaches the hook as a view (a reshape in between drops Python
