@@ -169,7 +169,8 @@ int qt_fake_quant_rows_bf16(const uint16_t *x_dev, uint16_t *y_dev, long d0, lon
                             long s0, long s1, long s2, const qt_format *fmt, const uint16_t *lut_dev,
                             const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
 /* Same layout change with a stateless E4M3 / E5M2 fake-quantizer (unit scale, no observer) that also emits the FP8
- * code of every element (y8 contiguous like y): one pass replaces ".contiguous()" + the consumer Linear's input pass. */
+ * code of every element (y8 contiguous like y): one pass replaces ".contiguous()" + the consumer Linear's input pass.  y_dev may be
+ * NULL when only the codes are wanted (the value operand of P.V as an FP8 GEMM). */
 int qt_fake_quant_rows_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, long d0, long d1, long d2,
                                 long inner, long s0, long s1, long s2, const qt_format *fmt, void *stream);
 int qt_fake_quant_pc_bf16(const uint16_t *x_dev, uint16_t *y_dev, size_t outer, size_t C, size_t inner,

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
             if (unit) {
                 uint32_t o[4] = {in.x, in.y, in.z, in.w};
                 const uint2 codes = fq8_hw_vec8<FP8 == 2>(o, fmt);
-                ((uint4 *)a.y)[v] = uint4{o[0], o[1], o[2], o[3]};
+                if (a.y) ((uint4 *)a.y)[v] = uint4{o[0], o[1], o[2], o[3]};       // NULL: only the codes are wanted
                 y8[v] = codes;
                 continue;
             }
@@ -1158,12 +1158,12 @@ int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs, const size_t *ns, in
 int qt_fake_quant_rows_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, long d0, long d1, long d2, long inner, long s0,
                                 long s1, long s2, const qt_format *fmt, void *stream) {
     if (d0 * d1 * d2 * inner == 0) return QT_OK;
-    if (!x || !y || !y8 || !fmt || d0 < 0 || d1 < 0 || d2 < 0 || inner < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    if (!x || !y8 || !fmt || d0 < 0 || d1 < 0 || d2 < 0 || inner < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
     const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
     const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
     if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
     if ((inner & 7) || ((s0 | s1 | s2) & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;
-    RowsArgs a{x, y, d1, d2, inner / 8, s0, s1, s2, (size_t)(d0 * d1 * d2 * (inner / 8))};
+    RowsArgs a{x, y, d1, d2, inner / 8, s0, s1, s2, (size_t)(d0 * d1 * d2 * (inner / 8))};          // y may be NULL: FP8 codes only
     const unsigned grid = grid_for(a.nvec, 256, 32);
     hipStream_t st = (hipStream_t)stream;
     if (e5m2) fq_rows_kernel<QT_FMT_FP_SAT, false, 2><<<grid, 256, 0, st>>>(a, *fmt, nullptr, nullptr, nullptr, (uint2 *)y8);

@@ -714,9 +714,8 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
     done = getattr(value, "_qt_fq_done_by", None) if handover_valid(value) else None
     v8 = getattr(value, "_qt_fp8", None)
     if not (done is fq_v and v8 is not None and value.is_contiguous()):
-        vq = torch.empty((B, H, C, D), dtype=torch.bfloat16, device=value.device)
-        v8u = torch.empty((B, H, C, D), dtype=torch.uint8, device=value.device)
-        _native.check(L.qt_fake_quant_rows_bf16_fp8(value.data_ptr(), vq.data_ptr(), v8u.data_ptr(), B, H, C, D,
+        v8u = torch.empty((B, H, C, D), dtype=torch.uint8, device=value.device)     # only the codes feed the FP8 P.V GEMM
+        _native.check(L.qt_fake_quant_rows_bf16_fp8(value.data_ptr(), None, v8u.data_ptr(), B, H, C, D,
                                                     value.stride(0), value.stride(1), value.stride(2),
                                                     ctypes.byref(fq_v._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
         v8 = v8u.view(torch.float8_e5m2 if fq_v._qt_format.p0 == 2 else torch.float8_e4m3fn)
