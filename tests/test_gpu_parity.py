@@ -1322,7 +1322,9 @@ def test_linear_fq8_weight_codes_are_the_value_map(nv, xdtype, wdtype):
 
 
 @pytest.mark.parametrize("M,Ns,K", [(1024, [4096], 1024), (1024, [176], 256), (300, [48, 64, 16], 384), (1, [16], 128),
-                                    (777, [2048, 512, 512], 512), (520, [11008], 256), (257, [208, 4096 - 208], 128)])
+                                    (777, [2048, 512, 512], 512), (520, [11008], 256), (257, [208, 4096 - 208], 128),
+                                    # BASELINE.json's full LLaMA-2-7B sizes: gate / up, down (two k tiles per step), q / k / v
+                                    (1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096, 4096, 4096], 4096)])
 @pytest.mark.parametrize("xdtype,wdtype", [("e4m3", "e4m3"), ("e5m2", "e4m3")])
 def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     """Ragged M, column tiles spanning two weights, several weights per launch, bias: against the fp64 product of the
@@ -1343,7 +1345,8 @@ def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 11008, 512), (300, 96, 256), (520, 2064, 384), (1, 16, 128), (64, 4096, 1024)])
+@pytest.mark.parametrize("M,N,K", [(1024, 11008, 512), (300, 96, 256), (520, 2064, 384), (1, 16, 128), (64, 4096, 1024),
+                                   (1024, 11008, 4096)])
 @pytest.mark.parametrize("xdtype,wdtype,odtype", [("e4m3", "e4m3", "e4m3"), ("e4m3", "e5m2", "e5m2")])
 def test_mlp_fq8_equals_two_gemms_and_silu_mul(nv, M, N, K, xdtype, wdtype, odtype):
     """qt_mlp_fq8_bf16 = gate GEMM, up GEMM (qt_linear_fq8_bf16: same tiles of the matrix instruction in the same k order, so the
