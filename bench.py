@@ -382,6 +382,9 @@ def main():
                        "launch": "hipGraph replay" if graph_used else "eager",
                        "valid": bool(full) and not a.cache_eval_weights and not a.dry_run},
             "mean_window_nll": float(allnll.double().mean().item()),
+            # north_star: elements/s "as absolute and as fraction of HBM roofline" -- SURVEY 8(d)'s 4 B per quantized element
+            # (bf16 in + bf16 out) against the HBM peak of the GPUs used
+            "fraction_of_hbm_roofline": None if a.dry_run else round(total_elems / el * 4.0 / (HBM_PEAK_GBPS * 1e9 * world), 4),
         }
     if rank == 0:                                   # outside the timed region; the other ranks wait at the barrier below
         del model
