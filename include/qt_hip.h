@@ -261,6 +261,15 @@ int qt_softmax_fq_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uin
 int qt_softmax_fq_bf16_fp8(const uint16_t *scores_dev, const uint16_t *mask_dev, uint16_t *out_dev, uint8_t *out8_dev,
                            long batch, int heads, int q_len, long cols, long mask_sb, long mask_sh, long mask_sq,
                            float scaling, const qt_format *fmt, void *stream);
+/* The FP8-only variant with a per-row shortcut for masks that end in a masked run (causal, right padding): row_live_dev[r] = one
+ * past the last column of mask row r whose entry is above -1e30 (qt_mask_row_live; r = b * live_sb + h * live_sh + q * live_sq, in rows
+ * of the mask's own [b][h][q] extent, 0 strides for broadcast dimensions).  512-column pieces that lie entirely beyond it are
+ * neither loaded nor evaluated -- their probabilities are exactly 0 -- unless the row has no unmasked column at all (then it is a
+ * uniform distribution and is evaluated in full).  Same results as qt_softmax_fq_bf16_fp8, bit for bit. */
+int qt_mask_row_live(const uint16_t *mask_dev, long rows, long cols, long row_stride, int *row_live_dev, void *stream);
+int qt_softmax_fq_bf16_fp8_live(const uint16_t *scores_dev, const uint16_t *mask_dev, uint8_t *out8_dev, long batch, int heads, int q_len,
+                                long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
+                                const int *row_live_dev, long live_sb, long live_sh, long live_sq, void *stream);
 
 /* Whole attention core for already fake-quantized q, k, v (bf16 [B, H, S, D] contiguous, D = 64 or 128):
  *     O = av_matmul( fq_P( softmax( attn_scaling(qk_matmul(q, k^T), scaling) + mask ) ), v )

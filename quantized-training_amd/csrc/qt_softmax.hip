@@ -38,6 +38,9 @@ struct SoftmaxArgs {
     uint32_t *amax;
     uint8_t *out8;            // optional FP8 code of the quantized probabilities (E4M3 / E5M2 spec, unit scale)
     int out8_e5m2;
+    const int *row_live;      // optional, per mask row (same (b, h, q) strides / 8-column granularity as the mask rows, in ROWS): one past
+                              // the last column whose mask entry is above -1e30 (qt_mask_row_live); columns from there on are masked
+    long live_sb, live_sh, live_sq;
 };
 
 __device__ __forceinline__ float wave_max_f32(float v) {
@@ -68,12 +71,22 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
             const long h = bh % a.heads, b = bh / a.heads;
             msk = (const uint4 *)(a.mask + b * a.mask_sb + h * a.mask_sh + q * a.mask_sq);
         }
+        // Columns at or beyond `live` are masked (mask <= -1e30): whatever the score, bf16(bf16(score * scaling) + mask) is
+        // about -3.4e38 and its exponential 0 -- as long as the row has one unmasked column to carry the maximum (live > 0).
+        // A 512-column piece that lies entirely beyond `live` is then not even loaded (under a causal mask: the second piece
+        // of the first 512 rows).
+        long live = 0x7FFFFFFF;
+        if (a.row_live) {
+            const long q = row % a.q_len, bh = row / a.q_len;
+            live = a.row_live[(bh / a.heads) * a.live_sb + (bh % a.heads) * a.live_sh + q * a.live_sq];
+            if (live <= 0) live = 0x7FFFFFFF;                  // a fully masked row is a uniform distribution over ALL columns
+        }
         float t[NV][8];
         float mx = -INFINITY;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int iv = v * 64 + lane;
-            if (iv < nvec_row) {
+            if (iv < nvec_row && (long)v * 512 < live) {
                 const uint4 x = src[iv];
                 uint4 m = {0u, 0u, 0u, 0u};
                 if (msk) m = msk[iv];
@@ -224,6 +237,48 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
         case QT_FMT_IDENTITY: return launch_softmax<QT_FMT_IDENTITY>(a, st);
         default: return QT_ERR_BAD_ARG;
     }
+}
+
+namespace {
+// one wave per mask row: one past the last column whose entry is above -1e30
+__global__ __launch_bounds__(256) void mask_row_live_kernel(const uint16_t *mask, long rows, long cols, long row_stride, int *out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t *m = mask + row * row_stride;
+    int last = 0;
+    for (long c = lane; c < cols; c += 64)
+        if (qt_bf2f(m[c]) > -1e30f) last = (int)c + 1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+    if (lane == 0) out[row] = last;
+}
+}  // namespace
+
+extern "C" int qt_mask_row_live(const uint16_t *mask, long rows, long cols, long row_stride, int *out, void *stream) {
+    if (rows == 0) return QT_OK;
+    if (!mask || !out || rows < 0 || cols < 0 || row_stride < cols) return QT_ERR_BAD_ARG;
+    mask_row_live_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, rows, cols, row_stride, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+extern "C" int qt_softmax_fq_bf16_fp8_live(const uint16_t *scores, const uint16_t *mask, uint8_t *out8, long batch, int heads, int q_len,
+                                           long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
+                                           const int *row_live, long live_sb, long live_sh, long live_sq, void *stream) {
+    const long rows = batch * heads * q_len;
+    if (rows == 0 || cols == 0) return QT_OK;
+    if (!scores || !out8 || !fmt || !mask || !row_live || batch < 0 || heads < 1 || q_len < 1 || cols < 0 || fmt->kind != QT_FMT_FP_SAT)
+        return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if (cols > 64L * 8 * kMaxVec) return QT_ERR_BAD_ARG;
+    if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)mask) & 15u) || ((uintptr_t)out8 & 7u) || ((mask_sb | mask_sh | mask_sq) & 7))
+        return QT_ERR_UNALIGNED;
+    SoftmaxArgs a{scores, mask, nullptr, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, nullptr, nullptr, nullptr,
+                  out8, e5m2 ? 1 : 0, row_live, live_sb, live_sh, live_sq};
+    return launch_softmax<QT_FMT_FP_SAT>(a, (hipStream_t)stream);
 }
 
 extern "C" int qt_softmax_fq_bf16_fp8(const uint16_t *scores, const uint16_t *mask, uint16_t *out, uint8_t *out8, long batch,

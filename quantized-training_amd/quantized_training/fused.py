@@ -670,7 +670,7 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
         mask = m
     L = _native.lib()
     st = _stream_ptr(scores)
-    fp8_out = _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value)
+    fp8_out = _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value, mask_owner=attention_mask)
     if fp8_out is not None:
         return None, fp8_out                  # the probabilities exist only as FP8 codes on this path
     out = torch.empty_like(scores)
@@ -695,7 +695,33 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
     return out, torch.matmul(out, v)
 
 
-def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value):
+def _mask_row_live(mask, owner, B, H, Q, C, st):
+    """Per-row extent of the unmasked part of an additive mask (qt_mask_row_live), or None when the mask's rows are not evenly
+    spaced.  Kept as an attribute of `owner` -- the tensor object the attention block was handed, of which `mask` is a view: the
+    cached causal mask of a window evaluation is the same object for every layer and window, a mask Hugging Face builds per
+    forward is the same object for every layer of that forward; a new object (or a new version of it) is scanned again.  Returns
+    (row_live, stride_b, stride_h, stride_q) in rows."""
+    # Opt-in: bit-identical, but not faster inside the window (12.97 against 12.88 ms on one box) -- there the scores the Q.K^T GEMM
+    # just wrote are cache-resident and the pieces it skips cost little; alone on cold buffers the pass gains about a tenth.
+    if os.environ.get("QT_SOFTMAX_ROW_LIVE", "0") != "1" or mask.dim() != 4 or C <= 512:
+        return None
+    mb, mh, mq, _ = mask.shape
+    rs = mask.stride(2) if mq > 1 else C
+    if (mh > 1 and mask.stride(1) != mq * rs) or (mb > 1 and mask.stride(0) != mh * mq * rs) or rs < C:
+        return None
+    key = (mask.data_ptr(), owner._version, tuple(mask.shape), mask.stride())
+    hit = getattr(owner, "_qt_row_live", None)
+    if hit is not None and hit[0] == key:
+        rl = hit[1]
+    else:
+        rows = mb * mh * mq
+        rl = torch.empty(rows, dtype=torch.int32, device=mask.device)
+        _native.check(_native.lib().qt_mask_row_live(mask.data_ptr(), rows, C, rs, rl.data_ptr(), st), "qt_mask_row_live")
+        owner._qt_row_live = (key, rl)
+    return rl, (mh * mq if mb == B and B > 1 else 0), (mq if mh == H and H > 1 else 0), (1 if mq == Q and Q > 1 else 0)
+
+
+def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value, mask_owner=None):
     """When the probabilities' and the values' fake-quantizers are stateless E4M3 / E5M2 ones, both tensors are exactly
     FP8: the score pass writes the probabilities' FP8 code only (1 B/element instead of 2), the value pass writes FP8
     next to bf16, and P.V runs as a batched FP8 GEMM (qt_fp8_gemm).  Same products, fp32 accumulation."""
@@ -721,9 +747,16 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
                                                     ctypes.byref(fq_v._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
         v8 = v8u.view(torch.float8_e5m2 if fq_v._qt_format.p0 == 2 else torch.float8_e4m3fn)
     p8u = torch.empty((B, H, Q, C), dtype=torch.uint8, device=scores.device)
-    _native.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr() if mask is not None else None, None,
-                                           p8u.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling),
-                                           ctypes.byref(fq_p._qt_format), st), "qt_softmax_fq_bf16_fp8")
+    live = _mask_row_live(mask, mask_owner, B, H, Q, C, st) if (mask is not None and mask_owner is not None) else None
+    if live is not None:
+        rl, lsb, lsh, lsq = live
+        _native.check(L.qt_softmax_fq_bf16_fp8_live(scores.data_ptr(), mask.data_ptr(), p8u.data_ptr(), B, H, Q, C, msb, msh, msq,
+                                                    float(scaling), ctypes.byref(fq_p._qt_format), rl.data_ptr(), lsb, lsh, lsq, st),
+                      "qt_softmax_fq_bf16_fp8_live")
+    else:
+        _native.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr() if mask is not None else None, None,
+                                               p8u.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling),
+                                               ctypes.byref(fq_p._qt_format), st), "qt_softmax_fq_bf16_fp8")
     p8 = p8u.view(torch.float8_e5m2 if fq_p._qt_format.p0 == 2 else torch.float8_e4m3fn)
     out = lt_fp8_gemm(p8.view(B * H, Q, C), v8.view(B * H, C, D), None, b_is_kn=True)
     if out is None:

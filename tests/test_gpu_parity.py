@@ -1380,6 +1380,46 @@ def test_mlp_fq8_equals_two_gemms_and_silu_mul(nv, M, N, K, xdtype, wdtype, odty
         assert np.array_equal(h8.cpu().numpy()[~nan.reshape(M, N)], want8.cpu().numpy()[~nan.reshape(M, N)]), poison
 
 
+@pytest.mark.parametrize("kind", ["causal", "padding", "one_row_fully_masked", "scattered"])
+def test_softmax_row_live_shortcut_changes_nothing(nv, kind):
+    """qt_softmax_fq_bf16_fp8_live (pieces of 512 columns beyond a row's last unmasked column are not loaded) writes the same FP8
+    codes as qt_softmax_fq_bf16_fp8 for causal and padding masks, a fully masked row (uniform distribution over all columns) and a
+    mask with holes; scores beyond the unmasked part hold NaN / Inf patterns to prove they are not read."""
+    L = nv.lib()
+    B, H, Q, C = 2, 3, 1024, 1024
+    torch.manual_seed(0)
+    scores = (torch.randn(B, H, Q, C, device="cuda") * 3).bfloat16()
+    neg = torch.finfo(torch.bfloat16).min
+    mask = torch.zeros(B, 1, Q, C, device="cuda", dtype=torch.bfloat16)
+    if kind == "causal":
+        mask[:] = torch.full((Q, C), neg, device="cuda", dtype=torch.bfloat16).triu(1)
+    elif kind == "padding":
+        mask[0, :, :, 700:] = neg
+        mask[1, :, :, 130:] = neg
+    elif kind == "one_row_fully_masked":
+        mask[:] = torch.full((Q, C), neg, device="cuda", dtype=torch.bfloat16).triu(1)
+        mask[1, 0, 5, :] = neg
+    else:
+        mask[:, :, :, 5::7] = neg
+        mask[0, :, :300, 600:] = neg
+    rows = B * Q
+    live = torch.empty(rows, dtype=torch.int32, device="cuda")
+    nv.check(L.qt_mask_row_live(mask.data_ptr(), rows, C, C, live.data_ptr(), stream()), "qt_mask_row_live")
+    want_live = ((mask.view(rows, C).float() > -1e30) * torch.arange(1, C + 1, device="cuda")).amax(dim=1).int()
+    assert torch.equal(live, want_live)
+    fmt = nv.format_for("e4m3")
+    ref = torch.empty(B, H, Q, C, dtype=torch.uint8, device="cuda")
+    nv.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr(), None, ref.data_ptr(), B, H, Q, C, Q * C, 0, C, 0.125,
+                                      ctypes.byref(fmt), stream()), "qt_softmax_fq_bf16_fp8")
+    poisoned = scores.clone()
+    beyond = (torch.arange(C, device="cuda")[None, :] >= ((live.view(B, 1, Q, 1) + 511) // 512 * 512)) & (live.view(B, 1, Q, 1) > 0)
+    poisoned.view(torch.int16)[beyond.expand(B, H, Q, C)] = 0x7FC0          # NaN wherever the shortcut promises not to look
+    got = torch.full((B, H, Q, C), 0x55, dtype=torch.uint8, device="cuda")
+    nv.check(L.qt_softmax_fq_bf16_fp8_live(poisoned.data_ptr(), mask.data_ptr(), got.data_ptr(), B, H, Q, C, Q * C, 0, C, 0.125,
+                                           ctypes.byref(fmt), live.data_ptr(), Q, 0, 1, stream()), "qt_softmax_fq_bf16_fp8_live")
+    assert torch.equal(got, ref)
+
+
 def test_linear_fq8_rejects_what_it_does_not_take(nv):
     x8 = torch.zeros(16, 192, dtype=torch.uint8, device="cuda")
     w = torch.zeros(32, 192, dtype=torch.bfloat16, device="cuda")
