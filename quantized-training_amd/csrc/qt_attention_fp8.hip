@@ -1,0 +1,301 @@
+// qt_attention_fp8.hip -- the attention core on FP8 codes for head_dim 128: Q.K^T, scaling, mask, softmax, fake-quant of the
+// probabilities and P.V in ONE launch, the S x S tensors never written.
+//
+// Replaces, when all four fake-quantizers around the two matmuls are stateless E4M3 / E5M2 ones (unit scale),
+//     av_matmul(fq_p(softmax(attn_scaling(qk_matmul(fq_q(q), fq_k(k)^T), scale) + mask)), fq_v(v))
+//                                                     modules/quantizable/modeling_llama.py:228-246, modeling_bert.py:118-158
+// with the module chain's rounding points kept: scores rounded to bf16 (the matmul's output dtype), bf16(score * scaling),
+// bf16(. + mask), softmax in fp32 over the WHOLE row (no running rescale), probabilities rounded to bf16, their fake-quantizer
+// (for a value in [0, 1] the format's round-to-nearest-even is the hardware conversion), P.V accumulated in fp32, output bf16.
+//
+// A workgroup = 4 waves owns 64 query rows of one (batch, head); a wave owns 16 of them and keeps ITS WHOLE score strip
+// (16 x Sk, Sk <= 1024) in registers as packed bf16 -- Q.K^T is one v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile because
+// head_dim = 128 is the instruction's depth.  The operands are multiplied swapped (K fragment first), so lane (r, g) ends up with
+// the scores of query r against keys 16 t + 4 g + {0..3} of every tile t: the row statistics are lane-local plus two shuffles.
+// Sweep 1 walks the keys in blocks of 128 (K block by LDS-DMA, double buffered) and fills the strip; the maximum and the sum of
+// exponentials follow; sweep 2 walks the same blocks with V: the lane's 32 probability codes of a block ARE the B operand of the
+// P.V instruction if the keys of a block are assigned to its k slots as slot 16 g + 4 t + e <-> key 16 t + 4 g + e -- so V arrives
+// transposed ([128 d][Sk]) with that permutation inside every 128-key block (qt_value_codes_t writes it while fake-quantizing V),
+// and its fragments are read exactly like K's.  Key blocks beyond every row's last unmasked column (qt_mask_row_live) are
+// skipped in both sweeps: their probabilities are exactly 0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qt_hip.h"
+#include "qt_device.h"
+#include "qt_formats.h"
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 128, kBlock = 128, kMaxBlocks = 8, kBuf = kBlock * kD;       // one K / V^T block: 16 KiB of codes
+constexpr int kUnit = 127;                                                        // E8M0 2^0
+
+struct AttnArgs {
+    const uint8_t *q8, *k8, *vt8;       // [B][H][Sq][128], [B][H][Sk][128], [B][H][128][Sk] (keys permuted inside 128-blocks)
+    const uint16_t *mask;               // additive bf16 or NULL; element strides for (b, h, q), columns contiguous
+    long msb, msh, msq;
+    const int *row_live;                // optional: one past the last unmasked column per mask row; row strides for (b, h, q)
+    long lsb, lsh, lsq;
+    int mask_simple;                    // the caller vouches: every mask row is exactly 0 up to its row_live entry and the bf16 minimum from
+                                        // there on (causal, right padding) -- the mask is then not read at all
+    uint16_t *out;                      // [B][Sq][H][128] bf16
+    int H, Sq, Sk;
+    float scaling;
+};
+
+__device__ __forceinline__ float blo(uint32_t w) { return qt_u2f(w << 16); }
+__device__ __forceinline__ float bhi(uint32_t w) { return qt_u2f(w & 0xFFFF0000u); }
+__device__ __forceinline__ int chunk_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// LDS-DMA as inline asm (16 bytes per lane, 1 KiB per wave): hipcc's wait-count model then does not see a pending LDS access
+// and keeps counted waits for the ordinary loads (mask, fragments); the DMA is waited for explicitly (vmcnt(0) + barrier)
+__device__ __forceinline__ void dma16(const uint8_t *src, uint32_t dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+}
+
+// F: operand format of q, k, v and p (0 = E4M3, 1 = E5M2)
+//
+// A workgroup = 8 waves takes TWO blocks of 64 query rows of one (batch, head): waves 0-3 the x-th block from the end, waves 4-7 the
+// x-th from the start.  Both walk the same K / V blocks, so each block is fetched once for the two; under a causal mask the second
+// group simply has fewer live key blocks and sits out the rest (it still joins the barriers).  Every workgroup then carries about the
+// same work -- all workgroups of a launch are resident at once, so the launch lasts as long as its heaviest one -- and every SIMD has
+// one wave of each group.
+template <int F>
+__global__ __launch_bounds__(512, 1) void attention_fp8_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = l & 15, g = l >> 4, grp = w >> 2, wq = w & 3;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int nkb = a.Sk / kBlock, nqb = (a.Sq + 63) / 64;
+    const int qb_heavy = nqb - 1 - (int)blockIdx.x, qb_light = (int)blockIdx.x;
+    const int qb = grp == 0 ? qb_heavy : qb_light;
+    const bool idle = grp == 1 && qb_light >= qb_heavy;                    // odd count: the middle block belongs to group 0 alone
+    const int q0 = qb * 64;
+    const int qrow = q0 + wq * 16 + r, qc = min(qrow, a.Sq - 1);
+    // key blocks that hold an unmasked column for at least one of a group's 64 rows (a fully masked row counts as all)
+    auto live_blocks = [&](int qblock) {
+        if (!a.row_live) return nkb;
+        const int qq = min(qblock * 64 + l, a.Sq - 1);
+        int lv = a.row_live[b * a.lsb + h * a.lsh + qq * a.lsq];
+        if (lv <= 0) lv = a.Sk;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lv = max(lv, __shfl_xor(lv, off, 64));
+        return min(nkb, (lv + kBlock - 1) / kBlock);
+    };
+    const int nl_heavy = live_blocks(qb_heavy), nl_light = qb_light >= qb_heavy ? 0 : live_blocks(qb_light);
+    const int nmax = max(nl_heavy, nl_light);                              // blocks the workgroup walks
+    const int nlive = idle ? 0 : (grp == 0 ? nl_heavy : nl_light);         // blocks this wave multiplies
+    const uint32_t l0 = lds_addr(lds);
+    // DMA pieces of this wave: 8 rows x 128 bytes each, rows 16 w + 8 i + (l >> 3), 16-byte slot l & 7 (swizzled by the row)
+    const uint8_t *kp[2], *vp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (w * 2 + i) * 8 + (l >> 3), slot = l & 7, sw = ((slot ^ ((row >> 1) & 7)) << 4);
+        kp[i] = a.k8 + ((long)bh * a.Sk + row) * kD + sw;                   // + block * 128 * 128
+        vp[i] = a.vt8 + ((long)bh * kD + row) * a.Sk + sw;                  // + block * 128
+    }
+    auto issue_k = [&](int kb, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(kp[i] + (long)kb * kBuf, l0 + buf * kBuf + (w * 2 + i) * 1024);
+    };
+    auto issue_v = [&](int kb, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(vp[i] + (long)kb * kBlock, l0 + buf * kBuf + (w * 2 + i) * 1024);
+    };
+    // the query fragment: row r, bytes 16 g .. and 64 + 16 g ..
+    const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * kD;
+    const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = *(const u32x4 *)(qp + 64 + 16 * g);
+    const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
+    const bool simple = a.mask && a.row_live && a.mask_simple;
+    const uint16_t *mrow = (a.mask && !simple) ? a.mask + b * a.msb + h * a.msh + (long)qc * a.msq + 4 * g : nullptr;
+    const int my_live = simple ? a.row_live[b * a.lsb + h * a.lsh + qc * a.lsq] : 0;      // this lane's row: keys >= my_live are masked
+    const int f_lo = chunk_off(r, g), f_hi = chunk_off(r, 4 + g);          // fragment of tile 0: tile i is 2048 bytes further
+
+    uint32_t sc[kMaxBlocks][8][2];                                          // the strip: bf16(bf16(score * scaling) + mask), packed pairs
+    float mx = -INFINITY;
+    // ---- sweep 1: scores
+    issue_k(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < kMaxBlocks; ++kb) {
+        if (kb < nmax) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // block kb has landed; everyone is done with block kb - 1
+            if (kb + 1 < nmax) issue_k(kb + 1, (kb + 1) & 1);
+            if (kb < nlive) {
+                const uint8_t *blk = lds + (kb & 1) * kBuf;
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) {
+                    const u32x4 klo = *(const u32x4 *)(blk + ti * 2048 + f_lo), khi = *(const u32x4 *)(blk + ti * 2048 + f_hi);
+                    const v8i kf = {(int)klo.x, (int)klo.y, (int)klo.z, (int)klo.w, (int)khi.x, (int)khi.y, (int)khi.z, (int)khi.w};
+                    const v4f s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf, qf, v4f{0.f, 0.f, 0.f, 0.f}, F, F, 0, kUnit, 0, kUnit);
+                    uint32_t w0 = pack_bf16x2(s[0], s[1]), w1 = pack_bf16x2(s[2], s[3]);                 // the matmul's bf16 output
+                    w0 = pack_bf16x2(blo(w0) * a.scaling, bhi(w0) * a.scaling);
+                    w1 = pack_bf16x2(blo(w1) * a.scaling, bhi(w1) * a.scaling);
+                    if (mrow) {
+                        const uint2 m = *(const uint2 *)(mrow + kb * kBlock + ti * 16);
+                        w0 = pack_bf16x2(blo(w0) + blo(m.x), bhi(w0) + bhi(m.x));
+                        w1 = pack_bf16x2(blo(w1) + blo(m.y), bhi(w1) + bhi(m.y));
+                    } else if (simple) {
+                        // x + 0 = x; bf16(x + min) = min for every finite x (NaN stays NaN): the mask's effect without reading it
+                        const int key = kb * kBlock + ti * 16 + 4 * g;
+                        if (key + 3 >= my_live) {
+                            const uint32_t lo0 = w0 & 0xFFFFu, hi0 = w0 >> 16, lo1 = w1 & 0xFFFFu, hi1 = w1 >> 16;
+                            auto sel = [&](uint32_t bits, int kk) { return (kk < my_live || (bits & 0x7FFFu) > 0x7F80u) ? bits : 0xFF7Fu; };
+                            w0 = sel(lo0, key) | (sel(hi0, key + 1) << 16);
+                            w1 = sel(lo1, key + 2) | (sel(hi1, key + 3) << 16);
+                        }
+                    }
+                    sc[kb][ti][0] = w0;
+                    sc[kb][ti][1] = w1;
+                    mx = fmaxf(mx, fmaxf(fmaxf(blo(w0), bhi(w0)), fmaxf(blo(w1), bhi(w1))));
+                }
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- row sum of exp(t - max); a tile whose four logits all lie more than 110 below the maximum contributes exactly 0
+    const float cut = mx - 110.0f;
+    float sum = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < kMaxBlocks; ++kb) {
+        if (kb < nlive) {
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti) {
+                const float v0 = blo(sc[kb][ti][0]), v1 = bhi(sc[kb][ti][0]), v2 = blo(sc[kb][ti][1]), v3 = bhi(sc[kb][ti][1]);
+                if (!((v0 < cut) & (v1 < cut) & (v2 < cut) & (v3 < cut)))
+                    sum += __expf(v0 - mx) + __expf(v1 - mx) + __expf(v2 - mx) + __expf(v3 - mx);
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // ---- sweep 2: probabilities -> codes -> P.V
+    v4f acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();                                          // every wave is out of sweep 1: the buffers are free
+    issue_v(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < kMaxBlocks; ++kb) {
+        if (kb < nmax) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kb + 1 < nmax) issue_v(kb + 1, (kb + 1) & 1);
+            if (kb < nlive) {
+                uint32_t pd[8];
+                uint32_t nz = 0;
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) {
+                    const float v0 = blo(sc[kb][ti][0]), v1 = bhi(sc[kb][ti][0]), v2 = blo(sc[kb][ti][1]), v3 = bhi(sc[kb][ti][1]);
+                    uint32_t code = 0;
+                    if (!((v0 < cut) & (v1 < cut) & (v2 < cut) & (v3 < cut))) {
+                        const uint32_t p0 = pack_bf16x2(__expf(v0 - mx) * inv, __expf(v1 - mx) * inv);   // probabilities, bf16
+                        const uint32_t p1 = pack_bf16x2(__expf(v2 - mx) * inv, __expf(v3 - mx) * inv);
+                        code = qt_pack_fp8x4<F == 1>(blo(p0), bhi(p0), blo(p1), bhi(p1));                // fq_p: exact for a value in [0, 1]
+                    }
+                    pd[ti] = code;
+                    nz |= code;
+                }
+                if (__any(nz != 0)) {
+                    const v8i pf = {(int)pd[0], (int)pd[1], (int)pd[2], (int)pd[3], (int)pd[4], (int)pd[5], (int)pd[6], (int)pd[7]};
+                    const uint8_t *blk = lds + (kb & 1) * kBuf;
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        const u32x4 vlo = *(const u32x4 *)(blk + dt * 2048 + f_lo), vhi = *(const u32x4 *)(blk + dt * 2048 + f_hi);
+                        const v8i vf = {(int)vlo.x, (int)vlo.y, (int)vlo.z, (int)vlo.w, (int)vhi.x, (int)vhi.y, (int)vhi.z, (int)vhi.w};
+                        acc[dt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, pf, acc[dt], F, F, 0, kUnit, 0, kUnit);
+                    }
+                }
+            }
+        }
+    }
+    // ---- output: lane (r, g) of d tile dt holds out[query r][d = 16 dt + 4 g .. + 3]
+    if (!idle && qrow < a.Sq) {
+        uint16_t *orow = a.out + (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+            *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+    }
+}
+
+// fq_v(V) as FP8 codes, transposed to [d][key] with the keys of every 128-block permuted into the k-slot order of the P.V instruction
+// (slot 16 g + 4 t + e <-> key 16 t + 4 g + e inside each half of 64).  One workgroup per (batch * head, key block).
+template <bool E5M2>
+__global__ __launch_bounds__(256) void value_codes_t_kernel(const uint16_t *v, uint8_t *vt8, int H, long Sk, long sb, long sh, long sk,
+                                                            qt_format fmt) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kD * kBlock];
+    const int t = threadIdx.x, kb = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int vi = it * 256 + t, key = vi >> 4, dv = vi & 15;
+        const uint4 in = *(const uint4 *)(v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8);
+        uint32_t o[4] = {in.x, in.y, in.z, in.w};
+        const uint2 codes = fq8_hw_vec8<E5M2>(o, fmt);
+        const int p = (key & 64) | (((key >> 2) & 3) << 4) | (((key >> 4) & 3) << 2) | (key & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[(dv * 8 + j) * kBlock + p] = (uint8_t)((j < 4 ? codes.x >> (8 * j) : codes.y >> (8 * (j - 4))) & 0xFFu);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ci = it * 256 + t, d = ci >> 3, ch = ci & 7;
+        *(uint4 *)(vt8 + ((long)bh * kD + d) * Sk + (long)kb * kBlock + ch * 16) = *(const uint4 *)(tile + d * kBlock + ch * 16);
+    }
+}
+
+int status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+bool fp8_closed_form(const qt_format *f, bool &e5m2) {
+    if (!f || f->kind != QT_FMT_FP_SAT) return false;
+    e5m2 = f->p0 == 2 && f->p1 == -14 && f->fhi == 57344.0f;
+    return e5m2 || (f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, long Sk, long stride_b, long stride_h, long stride_k,
+                     const qt_format *fmt, void *stream) {
+    if (B * H * Sk == 0) return QT_OK;
+    bool e5m2 = false;
+    if (!v_dev || !vt8_dev || B < 0 || H < 1 || Sk < 0 || Sk % kBlock != 0 || B * H > 65535 || !fp8_closed_form(fmt, e5m2)) return QT_ERR_BAD_ARG;
+    if ((((uintptr_t)v_dev | (uintptr_t)vt8_dev) & 15u) || ((stride_b | stride_h | stride_k) & 7)) return QT_ERR_UNALIGNED;
+    const dim3 grid((unsigned)(Sk / kBlock), (unsigned)(B * H));
+    if (e5m2) value_codes_t_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+    else value_codes_t_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+    return status();
+}
+
+int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t *vt8_dev, int operand_format, const uint16_t *mask_dev,
+                     long mask_sb, long mask_sh, long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
+                     int mask_is_simple, uint16_t *out_dev, long B, int H, int Sq, int Sk, float scaling, void *stream) {
+    if (B * H * Sq == 0) return QT_OK;
+    if (!q8_dev || !k8_dev || !vt8_dev || !out_dev || B < 0 || H < 1 || Sq < 1 || Sk < kBlock || Sk % kBlock != 0 || Sk > kBlock * kMaxBlocks ||
+        B * H > 65535 || operand_format < 0 || operand_format > 1)
+        return QT_ERR_BAD_ARG;
+    if ((((uintptr_t)q8_dev | (uintptr_t)k8_dev | (uintptr_t)vt8_dev) & 15u) || ((uintptr_t)out_dev & 7u) ||
+        (mask_dev && ((((uintptr_t)mask_dev) & 7u) || ((mask_sb | mask_sh | mask_sq) & 3))))
+        return QT_ERR_UNALIGNED;
+    AttnArgs a{q8_dev, k8_dev, vt8_dev, mask_dev, mask_sb, mask_sh, mask_sq, row_live_dev, live_sb, live_sh, live_sq, mask_is_simple ? 1 : 0,
+               out_dev, H, Sq, Sk, scaling};
+    const int nqb = (Sq + 63) / 64;
+    const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));          // two blocks of 64 rows per workgroup (see the kernel)
+    hipStream_t st = (hipStream_t)stream;
+    if (operand_format == 0) attention_fp8_kernel<0><<<grid, 512, 2 * kBuf, st>>>(a);
+    else attention_fp8_kernel<1><<<grid, 512, 2 * kBuf, st>>>(a);
+    return status();
+}
+
+}  // extern "C"

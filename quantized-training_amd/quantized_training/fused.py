@@ -701,9 +701,7 @@ def _mask_row_live(mask, owner, B, H, Q, C, st):
     cached causal mask of a window evaluation is the same object for every layer and window, a mask Hugging Face builds per
     forward is the same object for every layer of that forward; a new object (or a new version of it) is scanned again.  Returns
     (row_live, stride_b, stride_h, stride_q) in rows."""
-    # Opt-in: bit-identical, but not faster inside the window (12.97 against 12.88 ms on one box) -- there the scores the Q.K^T GEMM
-    # just wrote are cache-resident and the pieces it skips cost little; alone on cold buffers the pass gains about a tenth.
-    if os.environ.get("QT_SOFTMAX_ROW_LIVE", "0") != "1" or mask.dim() != 4 or C <= 512:
+    if mask.dim() != 4:
         return None
     mb, mh, mq, _ = mask.shape
     rs = mask.stride(2) if mq > 1 else C
@@ -719,6 +717,27 @@ def _mask_row_live(mask, owner, B, H, Q, C, st):
         _native.check(_native.lib().qt_mask_row_live(mask.data_ptr(), rows, C, rs, rl.data_ptr(), st), "qt_mask_row_live")
         owner._qt_row_live = (key, rl)
     return rl, (mh * mq if mb == B and B > 1 else 0), (mq if mh == H and H > 1 else 0), (1 if mq == Q and Q > 1 else 0)
+
+
+def _mask_is_simple(mask, owner, rl):
+    """True when every row of the additive mask is exactly 0 up to its last unmasked column and the dtype's minimum from there on
+    (causal masks, right padding): the FP8 attention kernel then applies the mask from the per-row extents without reading it.  One
+    comparison on the device and one host read per mask object, outside stream capture only (inside a capture: what is cached, else
+    False)."""
+    key = (mask.data_ptr(), owner._version, tuple(mask.shape), mask.stride())
+    hit = getattr(owner, "_qt_mask_simple", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    C = mask.shape[-1]
+    rows = rl.numel()
+    cols = torch.arange(C, device=mask.device, dtype=torch.int32)
+    want = torch.where(cols[None, :] < rl[:, None], torch.zeros((), dtype=mask.dtype, device=mask.device),
+                       torch.full((), torch.finfo(mask.dtype).min, dtype=mask.dtype, device=mask.device))
+    simple = bool(torch.equal(mask.reshape(rows, C), want))
+    owner._qt_mask_simple = (key, simple)
+    return simple
 
 
 def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value, mask_owner=None):
@@ -747,7 +766,10 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
                                                     ctypes.byref(fq_v._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
         v8 = v8u.view(torch.float8_e5m2 if fq_v._qt_format.p0 == 2 else torch.float8_e4m3fn)
     p8u = torch.empty((B, H, Q, C), dtype=torch.uint8, device=scores.device)
-    live = _mask_row_live(mask, mask_owner, B, H, Q, C, st) if (mask is not None and mask_owner is not None) else None
+    # Opt-in for the score pass: bit-identical, but not faster inside the window (12.97 against 12.88 ms on one box) -- there the scores the
+    # Q.K^T GEMM just wrote are cache-resident and the pieces it skips cost little; alone on cold buffers the pass gains about a tenth.
+    live = (_mask_row_live(mask, mask_owner, B, H, Q, C, st)
+            if (mask is not None and mask_owner is not None and C > 512 and os.environ.get("QT_SOFTMAX_ROW_LIVE", "0") == "1") else None)
     if live is not None:
         rl, lsb, lsh, lsq = live
         _native.check(L.qt_softmax_fq_bf16_fp8_live(scores.data_ptr(), mask.data_ptr(), p8u.data_ptr(), B, H, Q, C, msb, msh, msq,
@@ -785,6 +807,53 @@ def _mask_strides(attention_mask, B, H, Q, C, device, align):
     return m, sb, sh, sq
 
 
+def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs):
+    """qt_attention_fp8: the attention core in one launch on FP8 codes (head_dim 128, keys in blocks of 128 up to 1024) when the four
+    fake-quantizers around the two matmuls are stateless E4M3 / E5M2 ones of one format and q / k arrive with their codes (the rotary
+    kernel attaches them).  Counts the four fake-quant calls the reference issues: q and k handed through by their hooks' modules, the
+    value pass (qt_value_codes_t) and the probabilities inside the kernel.  Returns [B, Sq, H, D] or None."""
+    fq_q, fq_k, fq_p, fq_v = fqs
+    B, H, Q, D = query.shape
+    C = key.shape[2]
+    if D != 128 or C % 128 != 0 or C > 1024 or B * H > 65535 or value.dtype != torch.bfloat16 or value.stride(-1) != 1:
+        return None
+    if not all(isinstance(f, FusedAmaxObsFakeQuantize) and f.producer_fusable() for f in fqs):
+        return None
+    if len({f._qt_format.key() for f in fqs}) != 1 or any(s % 8 for s in value.stride()[:3]) or value.data_ptr() % 16:
+        return None
+    q8, k8 = getattr(query, "_qt_fp8", None), getattr(key, "_qt_fp8", None)
+    if (q8 is None or k8 is None or not handover_valid(query) or not handover_valid(key) or query._qt_fq_done_by is not fq_q
+            or key._qt_fq_done_by is not fq_k or not q8.is_contiguous() or not k8.is_contiguous()
+            or tuple(q8.shape) != (B, H, Q, D) or tuple(k8.shape) != (B, H, C, D)):
+        return None
+    mk = _mask_strides(attention_mask, B, H, Q, C, query.device, 4)
+    if mk is False:
+        return None
+    mask, msb, msh, msq = mk
+    L = _native.lib()
+    st = _stream_ptr(query)
+    rl_ptr, lsb, lsh, lsq, simple = None, 0, 0, 0, False
+    if mask is not None:
+        live = _mask_row_live(mask, attention_mask, B, H, Q, C, st)
+        if live is not None:
+            rl, lsb, lsh, lsq = live
+            rl_ptr = rl.data_ptr()
+            simple = _mask_is_simple(mask, attention_mask, rl)
+    fq_q(query)                                              # hand-overs: counted by the fake-quantizers themselves
+    fq_k(key)
+    fmt = fq_v._qt_format
+    vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)
+    _native.check(L.qt_value_codes_t(value.data_ptr(), vt8.data_ptr(), B, H, C, value.stride(0), value.stride(1), value.stride(2),
+                                     ctypes.byref(fmt), st), "qt_value_codes_t")
+    STATS.add(value.numel())                                 # fq_v, evaluated by the pass above
+    STATS.add(B * H * Q * C)                                 # fq_p, evaluated inside the kernel
+    out = torch.empty((B, Q, H, D), dtype=torch.bfloat16, device=query.device)
+    _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 1 if fmt.p0 == 2 else 0,
+                                     mask.data_ptr() if mask is not None else None, msb, msh, msq, rl_ptr, lsb, lsh, lsq, int(simple),
+                                     out.data_ptr(), B, H, Q, C, float(scaling), st), "qt_attention_fp8")
+    return out
+
+
 def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dropout):
     """The whole attention core in ONE HIP launch (qt_attention_fq_bf16): QK^T, scaling, mask, softmax,
     fake-quant of the probabilities and P.V on the matrix cores, the S x S tensor never written.  q, k, v go
@@ -796,7 +865,8 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
     faster than the library-GEMM chain (B16 H12 S384: 85 vs 113 us); at head_dim 128 the chain wins (92 vs 122 us at
     B1 H32 S1024), so the chain stays the default there."""
     mode = os.environ.get("QT_FUSED_ATTENTION", "auto")
-    if mode == "0" or (mode != "1" and query.shape[-1] != 64):
+    fp8_kernel = query.dim() == 4 and query.shape[-1] == 128 and os.environ.get("QT_FP8_ATTENTION_KERNEL", "1") != "0"
+    if mode == "0" or (mode != "1" and query.shape[-1] != 64 and not fp8_kernel):
         return None
     if not (query.device.type == "cuda" and query.dtype == torch.bfloat16 and query.dim() == 4):
         return None
@@ -830,6 +900,12 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
             return None
     elif attn.qk_matmul._forward_pre_hooks or attn.av_matmul._forward_pre_hooks:
         return None
+    if fp8_kernel and fq_q is not None and os.environ.get("QT_FP8_ATTENTION", "1") != "0":
+        out = _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, (fq_q, fq_k, fq_p, fq_v))
+        if out is not None:
+            return out
+    if mode != "1" and query.shape[-1] != 64:
+        return None                                          # head_dim 128 without the FP8 kernel: the library-GEMM chain (see above)
     mk = _mask_strides(attention_mask, B, H, Q, C, query.device, 4)
     if mk is False:
         return None

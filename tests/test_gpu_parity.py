@@ -1420,6 +1420,69 @@ def test_softmax_row_live_shortcut_changes_nothing(nv, kind):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,mask_kind,live", [(1, 4, 128, 128, "causal", True), (2, 3, 200, 256, "padding", True), (1, 2, 64, 384, None, False),
+                                                      (1, 8, 1024, 1024, "causal", True), (1, 2, 256, 256, "causal", False)])
+@pytest.mark.parametrize("fmt_name", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("simple", [False, True])
+def test_attention_fp8_kernel(nv, B, H, Sq, Sk, mask_kind, live, fmt_name, simple):
+    """qt_attention_fp8 (+ qt_value_codes_t) against oracle.attention_fq, head_dim 128, all four matmul inputs in one stateless FP8
+    format: the module chain with every rounding point explicit and exp / sums in float64.  Almost every output element is
+    identical (measured <= 6e-3 differ: the FP8 matrix instruction adds the 128 products of a score in an aligned fixed-point tree
+    that keeps fewer bits than the oracle's exact sum, so a few more scores than in the bf16 kernel's test straddle a bf16 rounding
+    boundary); where a probability lands on the other side of a boundary of its 8-bit format one output row moves by at most that
+    probability's step.  Also: the permuted transposed value codes against a torch restatement."""
+    L = nv.lib()
+    D = 128
+    torch.manual_seed(B * 7 + H + Sk)
+    qmap_in = torch.from_numpy(o.get_quantization_map(fmt_name).view(np.int16)).cuda().view(torch.bfloat16)
+    fqin = lambda t: qmap_in[(t.view(torch.int16).to(torch.int32) & 0xFFFF).long()]  # noqa: E731
+    q = fqin((torch.randn(B, H, Sq, D, device="cuda")).bfloat16())
+    k = fqin((torch.randn(B, H, Sk, D, device="cuda")).bfloat16())
+    v_raw = torch.randn(B, Sk, H, D, device="cuda").bfloat16().transpose(1, 2)        # [B, H, Sk, D] view of a [B, S, H, D] buffer, unquantized
+    v = fqin(v_raw.contiguous())
+    scaling = D ** -0.5
+    minv = torch.finfo(torch.bfloat16).min
+    mask, msb, msq = None, 0, 0
+    if mask_kind == "causal":
+        mask = torch.full((Sq, Sk), minv, device="cuda").triu(1 + Sk - Sq).bfloat16()[None, None]
+        msq = mask.stride(2)
+    elif mask_kind == "padding":
+        mask = torch.zeros(B, 1, 1, Sk, device="cuda", dtype=torch.bfloat16)
+        mask[:, :, :, Sk - 29:] = minv
+        mask[0, :, :, Sk - 150:] = minv
+        msb = mask.stride(0)
+    fmt = nv.format_for(fmt_name)
+    fcode = 0 if fmt_name == "e4m3" else 1
+    q8, k8 = _codes_of(nv, q, fmt_name), _codes_of(nv, k, fmt_name)
+    vt8 = torch.empty(B, H, D, Sk, dtype=torch.uint8, device="cuda")
+    nv.check(L.qt_value_codes_t(v_raw.data_ptr(), vt8.data_ptr(), B, H, Sk, v_raw.stride(0), v_raw.stride(1), v_raw.stride(2), ctypes.byref(fmt),
+                                stream()), "qt_value_codes_t")
+    # the permutation: position p of a 128-block holds key ((p >> 2) & 3) * 16 + ((p >> 4) & 3) * 4 + (p & 3) (+ 64 for the upper half)
+    pos = torch.arange(128, device="cuda")
+    key_of = (pos & 64) | (((pos >> 2) & 3) << 4) | (((pos >> 4) & 3) << 2) | (pos & 3)
+    want_vt = _codes_of(nv, v, fmt_name).view(B, H, Sk // 128, 128, D)[:, :, :, key_of, :].permute(0, 1, 4, 2, 3).reshape(B, H, D, Sk)
+    assert torch.equal(vt8, want_vt)
+    simple = simple and live and mask is not None              # both test masks are "zeros, then the minimum" row by row
+    rl, lsb, lsq = None, 0, 0
+    if live and mask is not None:
+        mrows = mask.shape[0] * mask.shape[2]
+        rl = torch.empty(mrows, dtype=torch.int32, device="cuda")
+        nv.check(L.qt_mask_row_live(mask.data_ptr(), mrows, Sk, Sk, rl.data_ptr(), stream()), "qt_mask_row_live")
+        lsb, lsq = (mask.shape[2] if mask.shape[0] > 1 else 0), (1 if mask.shape[2] > 1 else 0)
+    out = torch.full((B, Sq, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    nv.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), fcode, mask.data_ptr() if mask is not None else None, msb, 0, msq,
+                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), out.data_ptr(), B, H, Sq, Sk, scaling, stream()),
+             "qt_attention_fp8")
+    torch.cuda.synchronize()
+    u16 = lambda t: host_u16(t.contiguous().view(torch.int16))  # noqa: E731
+    exp, _ = o.attention_fq(u16(q), u16(k), u16(v), u16(mask) if mask is not None else None, scaling, o.get_quantization_map(fmt_name))
+    got = u16(out.permute(0, 2, 1, 3))
+    assert float((got != exp).mean()) <= (1.2e-2 if fmt_name == "e4m3" else 3e-2), float((got != exp).mean())      # e5m2: two mantissa bits
+    ev = o.bf16_to_f32(exp)
+    err = np.abs(o.bf16_to_f32(got) - ev) / (np.abs(ev).max(axis=-1, keepdims=True) + 1e-30)
+    assert float(err.max()) <= 0.08, float(err.max())
+
+
 def test_linear_fq8_rejects_what_it_does_not_take(nv):
     x8 = torch.zeros(16, 192, dtype=torch.uint8, device="cuda")
     w = torch.zeros(32, 192, dtype=torch.bfloat16, device="cuda")
