@@ -45,6 +45,8 @@ struct AttnArgs {
     uint16_t *out;                      // [B][Sq][H][128] bf16
     int H, Sq, Sk;
     float scaling;
+    uint8_t *out8;                      // optional: the consumer's (output projection's input) stateless FP8 fake-quantizer applied on the way
+    qt_format out_fmt;                  // out: `out` then holds fq(result), out8 its codes, same layout
 };
 
 __device__ __forceinline__ float blo(uint32_t w) { return qt_u2f(w << 16); }
@@ -219,10 +221,25 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_kernel(AttnArgs a) {
     }
     // ---- output: lane (r, g) of d tile dt holds out[query r][d = 16 dt + 4 g .. + 3]
     if (!idle && qrow < a.Sq) {
-        uint16_t *orow = a.out + (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
+        const long o0 = (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
+        uint16_t *orow = a.out + o0;
+        if (a.out8) {
+            const bool oe5 = a.out_fmt.p0 == 2;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-            *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+            for (int dt = 0; dt < 8; dt += 2) {
+                uint32_t o[4] = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3]),
+                                 pack_bf16x2(acc[dt + 1][0], acc[dt + 1][1]), pack_bf16x2(acc[dt + 1][2], acc[dt + 1][3])};
+                const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);     // o: now fq(values)
+                *(uint2 *)(orow + dt * 16) = uint2{o[0], o[1]};
+                *(uint2 *)(orow + dt * 16 + 16) = uint2{o[2], o[3]};
+                *(uint32_t *)(a.out8 + o0 + dt * 16) = codes.x;
+                *(uint32_t *)(a.out8 + o0 + dt * 16 + 16) = codes.y;
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+                *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+        }
     }
 }
 
@@ -280,7 +297,8 @@ int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, lo
 
 int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t *vt8_dev, int operand_format, const uint16_t *mask_dev,
                      long mask_sb, long mask_sh, long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
-                     int mask_is_simple, uint16_t *out_dev, long B, int H, int Sq, int Sk, float scaling, void *stream) {
+                     int mask_is_simple, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B, int H, int Sq, int Sk,
+                     float scaling, void *stream) {
     if (B * H * Sq == 0) return QT_OK;
     if (!q8_dev || !k8_dev || !vt8_dev || !out_dev || B < 0 || H < 1 || Sq < 1 || Sk < kBlock || Sk % kBlock != 0 || Sk > kBlock * kMaxBlocks ||
         B * H > 65535 || operand_format < 0 || operand_format > 1)
@@ -288,8 +306,10 @@ int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t
     if ((((uintptr_t)q8_dev | (uintptr_t)k8_dev | (uintptr_t)vt8_dev) & 15u) || ((uintptr_t)out_dev & 7u) ||
         (mask_dev && ((((uintptr_t)mask_dev) & 7u) || ((mask_sb | mask_sh | mask_sq) & 3))))
         return QT_ERR_UNALIGNED;
+    bool oe5 = false;
+    if (out8_dev && (!fp8_closed_form(out_format, oe5) || ((uintptr_t)out8_dev & 3u))) return QT_ERR_BAD_ARG;
     AttnArgs a{q8_dev, k8_dev, vt8_dev, mask_dev, mask_sb, mask_sh, mask_sq, row_live_dev, live_sb, live_sh, live_sq, mask_is_simple ? 1 : 0,
-               out_dev, H, Sq, Sk, scaling};
+               out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}};
     const int nqb = (Sq + 63) / 64;
     const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));          // two blocks of 64 rows per workgroup (see the kernel)
     hipStream_t st = (hipStream_t)stream;

@@ -848,9 +848,19 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
     STATS.add(value.numel())                                 # fq_v, evaluated by the pass above
     STATS.add(B * H * Q * C)                                 # fq_p, evaluated inside the kernel
     out = torch.empty((B, Q, H, D), dtype=torch.bfloat16, device=query.device)
+    # the output projection's stateless FP8 input fake-quantizer rides on the epilogue (as model_fusions.attention_output does for the
+    # library-GEMM chain): HF reshapes the result before the projection's hook sees it, so the hand-over is an expectation
+    from .model_fusions import consumer_fq
+    proj = getattr(attn, "o_proj", None)
+    fq_o = consumer_fq(proj) if (proj is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0") else None
+    out8 = torch.empty((B, Q, H, D), dtype=torch.uint8, device=query.device) if fq_o is not None else None
     _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 1 if fmt.p0 == 2 else 0,
                                      mask.data_ptr() if mask is not None else None, msb, msh, msq, rl_ptr, lsb, lsh, lsq, int(simple),
-                                     out.data_ptr(), B, H, Q, C, float(scaling), st), "qt_attention_fp8")
+                                     out.data_ptr(), out8.data_ptr() if out8 is not None else None,
+                                     ctypes.byref(fq_o._qt_format) if fq_o is not None else None, B, H, Q, C, float(scaling), st),
+                  "qt_attention_fp8")
+    if fq_o is not None:
+        fq_o.expect_prequantized(out, out8.view(torch.float8_e5m2 if fq_o._qt_format.p0 == 2 else torch.float8_e4m3fn))
     return out
 
 

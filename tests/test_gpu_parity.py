@@ -1471,7 +1471,7 @@ def test_attention_fp8_kernel(nv, B, H, Sq, Sk, mask_kind, live, fmt_name, simpl
         lsb, lsq = (mask.shape[2] if mask.shape[0] > 1 else 0), (1 if mask.shape[2] > 1 else 0)
     out = torch.full((B, Sq, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
     nv.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), fcode, mask.data_ptr() if mask is not None else None, msb, 0, msq,
-                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), out.data_ptr(), B, H, Sq, Sk, scaling, stream()),
+                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), out.data_ptr(), None, None, B, H, Sq, Sk, scaling, stream()),
              "qt_attention_fp8")
     torch.cuda.synchronize()
     u16 = lambda t: host_u16(t.contiguous().view(torch.int16))  # noqa: E731
@@ -1481,6 +1481,17 @@ def test_attention_fp8_kernel(nv, B, H, Sq, Sk, mask_kind, live, fmt_name, simpl
     ev = o.bf16_to_f32(exp)
     err = np.abs(o.bf16_to_f32(got) - ev) / (np.abs(ev).max(axis=-1, keepdims=True) + 1e-30)
     assert float(err.max()) <= 0.08, float(err.max())
+    # with the consumer's fake-quantizer on the epilogue: fq(out) and its codes, from the very same result
+    fo = nv.format_for("e4m3")
+    outq = torch.empty_like(out)
+    out8 = torch.empty(B, Sq, H, D, dtype=torch.uint8, device="cuda")
+    nv.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), fcode, mask.data_ptr() if mask is not None else None, msb, 0, msq,
+                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), outq.data_ptr(), out8.data_ptr(), ctypes.byref(fo),
+                                B, H, Sq, Sk, scaling, stream()), "qt_attention_fp8")
+    want8 = _codes_of(nv, out, "e4m3")
+    assert torch.equal(out8, want8)
+    qm = torch.from_numpy(o.get_quantization_map("e4m3").view(np.int16)).cuda()
+    assert torch.equal(outq.view(torch.int16), qm[(out.view(torch.int16).to(torch.int32) & 0xFFFF).long()])
 
 
 def test_linear_fq8_rejects_what_it_does_not_take(nv):
