@@ -16,3 +16,4 @@ find gpurun_out/prof_13b_posit -name "*kernel_trace.csv" -delete
 bash tools/gpu_session_fq8.sh > /dev/null 2>&1
 timeout 600 python tools/exp_mlp_fq8.py > gpurun_out/mlp_fq8.txt 2>&1
 grep -E "^bench" gpurun_out/fq8_session.txt | head -8 | cut -c1-120
+timeout 600 python tools/exp_attention_fp8.py > gpurun_out/attention_fp8.txt 2>&1

@@ -15,13 +15,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("dir")
 ap.add_argument("--windows", type=int, default=5)
 ap.add_argument("--layers", type=int, default=32)
-ap.add_argument("--anchor", default="softmax_fq_kernel")
+ap.add_argument("--anchor", default="attention_fp8_kernel,softmax_fq_kernel",
+                help="kernel(s) launched once per layer, comma separated: the first one present in the trace marks the windows")
 args = ap.parse_args()
 
 path = max(glob.glob(os.path.join(args.dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
 rows.sort()
-anchors = [i for i, r in enumerate(rows) if args.anchor in r[2]]
+anchors = []
+for name in args.anchor.split(","):
+    anchors = [i for i, r in enumerate(rows) if name in r[2]]
+    if anchors:
+        break
 need = args.windows * args.layers
 assert len(anchors) >= need + args.layers, "trace holds fewer windows than asked for"
 # a window starts at the first kernel after the previous window's last anchor launch + everything behind it in that layer:
