@@ -20,6 +20,7 @@
 // skipped in both sweeps: their probabilities are exactly 0.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/qt_hip.h"
 #include "qt_device.h"
@@ -32,6 +33,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 128, kBlock = 128, kMaxBlocks = 8, kBuf = kBlock * kD;       // one K / V^T block: 16 KiB of codes
+constexpr int kSplitLds = kMaxBlocks * kBuf + 2 * 2 * 64 * 4;                   // variant 2: every block of a sweep + the row statistics
 constexpr int kUnit = 127;                                                        // E8M0 2^0
 
 struct AttnArgs {
@@ -243,6 +245,323 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_kernel(AttnArgs a) {
     }
 }
 
+// ---- variant 2: the two wave groups split the KEYS of one block of 64 query rows ---------------------------------------------
+// Of every 128-key block group 0 takes tiles 0-3 (keys 0 .. 63) and group 1 tiles 4-7, so the two always carry the same work; an
+// iteration walks a PAIR of blocks, which gives each wave 8 score tiles = the 128 probabilities one P.V instruction contracts (its
+// low half from the first block, its high half from the second: with the slot <-> key permutation of the V^T blocks the group's tiles
+// are exactly the low (group 0) or high (group 1) 16-byte chunks of a lane's fragment).  A wave's strip is at most 4 x 8 tiles, which
+// leaves room to keep it in fp32: each exponential is evaluated once (variant 1 keeps bf16 logits and evaluates exp twice).  The row
+// maximum and sum and the partial P.V sums of the two groups meet in LDS.
+//
+// Control flow is wave-uniform throughout (extents are scalars), so the four tiles of a half-block form one basic block the
+// scheduler can overlap: fragment reads, MFMA and the rounding chain of neighbouring tiles.  Under a row-extent mask a wave skips
+// the tiles beyond the extents of its own 16 rows, and tiles wholly inside them take the path without mask arithmetic.
+//
+// Workgroups are ordered heaviest first over the whole launch (one per CU at a time: longest-first keeps the CUs evenly loaded).
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+// two packed bf16 pairs of probabilities -> four FP8 codes with the hardware conversion (non-saturating: right for values in [0, 1])
+template <bool E5M2>
+__device__ __forceinline__ uint32_t prob_codes(uint32_t p0, uint32_t p1) {
+    v2s o = __builtin_bit_cast(v2s, p0);
+    if constexpr (E5M2) {
+        o = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(o, __builtin_bit_cast(v2bf, p0), 1.0f, false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(o, __builtin_bit_cast(v2bf, p1), 1.0f, true);
+    } else {
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(v2bf, p0), 1.0f, false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(v2bf, p1), 1.0f, true);
+    }
+    return __builtin_bit_cast(uint32_t, o);
+}
+
+__device__ __forceinline__ float max3(float x, float y, float z) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+
+// scores of the four tiles t0 .. t0 + 3 of one K block.  MODE 0: no mask arithmetic; 1: row-extent mask applied from my_live
+// (tiles from `tiles` on lie beyond every row of the wave); 2: additive mask read from mrow
+template <int F, int MODE>
+__device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8i &qf, int f_lo, int f_hi, float scaling, float (*ev)[4], float &mx,
+                                           const uint16_t *mrow, int key0, int my_live, int tiles) {
+    // staged by hand -- all fragment reads, then the MFMAs back to back, then the rounding chains -- because the compiler keeps
+    // source order and a read -> MFMA -> chain sequence per tile exposes the LDS and MFMA latencies four times over
+    uint2 m[4];
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = *(const uint2 *)(mrow + key0 + j * 16);
+    }
+    u32x4 klo[4], khi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == 1 && j >= tiles) continue;
+        klo[j] = *(const u32x4 *)(blk + (t0 + j) * 2048 + f_lo);
+        khi[j] = *(const u32x4 *)(blk + (t0 + j) * 2048 + f_hi);
+    }
+    v4f s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == 1 && j >= tiles) continue;
+        const v8i kf = {(int)klo[j].x, (int)klo[j].y, (int)klo[j].z, (int)klo[j].w, (int)khi[j].x, (int)khi[j].y, (int)khi[j].z, (int)khi[j].w};
+        s[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf, qf, v4f{0.f, 0.f, 0.f, 0.f}, F, F, 0, kUnit, 0, kUnit);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == 1 && j >= tiles) {
+            ev[j][0] = ev[j][1] = ev[j][2] = ev[j][3] = -INFINITY;
+            continue;
+        }
+        uint32_t w0 = pack_bf16x2(s[j][0], s[j][1]), w1 = pack_bf16x2(s[j][2], s[j][3]);     // the matmul's bf16 output
+        w0 = pack_bf16x2(blo(w0) * scaling, bhi(w0) * scaling);
+        w1 = pack_bf16x2(blo(w1) * scaling, bhi(w1) * scaling);
+        if (MODE == 2) {
+            w0 = pack_bf16x2(blo(w0) + blo(m[j].x), bhi(w0) + bhi(m[j].x));
+            w1 = pack_bf16x2(blo(w1) + blo(m[j].y), bhi(w1) + bhi(m[j].y));
+        }
+        float v[4] = {blo(w0), bhi(w0), blo(w1), bhi(w1)};
+        if (MODE == 1) {
+            // x + 0 = x; bf16(x + min) = min for every finite x (NaN stays NaN): the mask's effect without reading it
+            const int left = my_live - (key0 + j * 16);                    // columns of this lane's four still inside its row's extent
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (e < left || v[e] != v[e]) ? v[e] : -3.3895313892515355e38f;
+        }
+        ev[j][0] = v[0]; ev[j][1] = v[1]; ev[j][2] = v[2]; ev[j][3] = v[3];
+        mx = max3(mx, v[0], v[1]);
+        mx = max3(mx, v[2], v[3]);
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // 8 x 16 KiB of K, then V^T, blocks (later the partial sums) + the row statistics
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = l & 15, g = l >> 4, grp = w >> 2, wq = w & 3;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;                 // a head's blocks of rows are 8 apart in launch order: one XCD, one L2
+    const int nkb = a.Sk / kBlock, nqb = (a.Sq + 63) / 64;
+    const int qb = nqb - 1 - (int)blockIdx.y;                              // the heaviest blocks of rows of every head first under a causal mask
+    const int q0 = qb * 64;
+    const int qrow = q0 + wq * 16 + r, qc = min(qrow, a.Sq - 1);
+    // extents: nlive = key blocks holding an unmasked column of one of the 64 rows; wmax / wmin = the largest / smallest extent among
+    // this wave's 16 rows; my_live = this lane's row (0: a fully masked row, which attends to every key alike)
+    int nlive = nkb, wmax = a.Sk, wmin = a.Sk, my_live = a.Sk;
+    if (a.row_live) {
+        const int qq = min(q0 + l, a.Sq - 1);
+        int lv = a.row_live[b * a.lsb + h * a.lsh + qq * a.lsq];
+        my_live = a.row_live[b * a.lsb + h * a.lsh + qc * a.lsq];
+        if (lv <= 0) lv = a.Sk;
+        int hi = my_live <= 0 ? a.Sk : my_live, lo = max(my_live, 0);       // a fully masked row is walked to the end and masked from column 0
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lv = max(lv, __shfl_xor(lv, off, 64));
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            hi = max(hi, __shfl_xor(hi, off, 64));
+            lo = min(lo, __shfl_xor(lo, off, 64));
+        }
+        nlive = __builtin_amdgcn_readfirstlane(min(nkb, (lv + kBlock - 1) / kBlock));
+        wmax = __builtin_amdgcn_readfirstlane(hi);
+        wmin = __builtin_amdgcn_readfirstlane(lo);
+    }
+    const int niter = (nlive + 1) / 2;                                     // iteration i: blocks 2 i and 2 i + 1
+    const bool simple = a.mask && a.row_live && a.mask_simple, full = a.mask && !simple;
+    if (!simple) wmin = a.Sk;                                              // extents then only bound the walk; inside them the mask is read
+    if (!simple && !a.row_live) wmax = a.Sk;
+    const uint32_t l0 = lds_addr(lds);
+    // DMA: an iteration brings two blocks (32 pieces of 8 rows x 128 bytes): this wave's pieces are 4 w .. 4 w + 3 of those 32
+    const uint8_t *kp[4], *vp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = ((w * 4 + i) & 15) * 8 + (l >> 3), slot = l & 7, sw = ((slot ^ ((row >> 1) & 7)) << 4);
+        kp[i] = a.k8 + ((long)bh * a.Sk + row) * kD + sw;                   // + block * 128 * 128
+        vp[i] = a.vt8 + ((long)bh * kD + row) * a.Sk + sw;                  // + block * 128
+    }
+    // the second block of the last pair may lie beyond the live blocks: it is then fetched from the last one and never multiplied
+    auto issue_k = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = w * 4 + i, kb = min(2 * it + (piece >> 4), nkb - 1);
+            dma16(kp[i] + (long)kb * kBuf, l0 + (2 * it) * kBuf + piece * 1024);
+        }
+    };
+    auto issue_v = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = w * 4 + i, kb = min(2 * it + (piece >> 4), nkb - 1);
+            dma16(vp[i] + (long)kb * kBlock, l0 + (2 * it) * kBuf + piece * 1024);
+        }
+    };
+    // every pair has its own buffers; requests run two pairs ahead of the arithmetic (a wave that requested a whole sweep at once
+    // would sit in the request queue -- 64 bytes per clock per CU -- before its first multiplication)
+    auto wait_pair = [&](int it) {
+        if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next pair (4 requests of this wave) may still be under way
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * kD;
+    const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = *(const u32x4 *)(qp + 64 + 16 * g);
+    const uint16_t *mrow = full ? a.mask + b * a.msb + h * a.msh + (long)qc * a.msq + 4 * g : nullptr;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the compiler's waits for these must not meet the block requests
+    const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
+    const int f_lo = chunk_off(r, g), f_hi = chunk_off(r, 4 + g);
+    const int f_v = chunk_off(r, 4 * grp + g);                             // V^T: this group's tiles are one 16-byte chunk per block
+    constexpr int kIter = kMaxBlocks / 2;
+    // this wave's four tiles of block kb start at key kb * 128 + 64 grp; how many of them does one of its rows reach?
+    auto tiles_of = [&](int kb) { return kb < nlive ? min(4, max(0, (wmax - (kb * kBlock + 64 * grp) + 15) >> 4)) : 0; };
+
+    float e[kIter][8][4];                                                  // this wave's part of the strip: logits, then their exponentials
+    float mx = -INFINITY;
+    // ---- sweep 1: scores
+    issue_k(0);
+    if (niter > 1) issue_k(1);
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        if (it < niter) {
+            wait_pair(it);
+            if (it + 2 < niter) issue_k(it + 2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int kb = 2 * it + c, key0 = kb * kBlock + 64 * grp, nt = tiles_of(kb);
+                const uint8_t *blk = lds + kb * kBuf;
+                float (*ev)[4] = &e[it][4 * c];
+                if (nt == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ev[j][0] = ev[j][1] = ev[j][2] = ev[j][3] = -INFINITY;
+                } else if (full) {
+                    score_half<F, 2>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, mrow, key0, 0, 4);
+                } else if (!simple || key0 + 64 <= wmin) {
+                    score_half<F, 0>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0, 0, 4);
+                } else {
+                    score_half<F, 1>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0 + 4 * g, my_live, nt);
+                }
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // everyone is through sweep 1: the V^T blocks replace the K blocks while the exponentials are evaluated
+    __builtin_amdgcn_s_barrier();
+    issue_v(0);
+    if (niter > 1) issue_v(1);
+    // the two groups' maxima meet in LDS
+    float *stat = (float *)(lds + kMaxBlocks * kBuf);                      // [max, sum][2 groups][64 rows]
+    if (g == 0) stat[grp * 64 + wq * 16 + r] = mx;
+    __syncthreads();
+    mx = fmaxf(stat[wq * 16 + r], stat[64 + wq * 16 + r]);
+    // ---- exponentials, once (a column at the bf16 minimum, or beyond the extents, gives exactly 0)
+    const float kLog2e = 1.4426950408889634f;                              // (v - max) first: a fully masked row has max = the bf16 minimum
+    float2_t sum2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        if (it < niter) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (tiles_of(2 * it + c) != 0) {
+#pragma unroll
+                    for (int j = 4 * c; j < 4 * c + 4; ++j) {
+                        float *v = e[it][j];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) v[x] = (v[x] - mx) * kLog2e;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) v[x] = __builtin_amdgcn_exp2f(v[x]);
+                        sum2 += float2_t{v[0], v[1]};
+                        sum2 += float2_t{v[2], v[3]};
+                    }
+                }
+            }
+        }
+    }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0) stat[128 + grp * 64 + wq * 16 + r] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (stat[128 + wq * 16 + r] + stat[128 + 64 + wq * 16 + r]);
+    v4f acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        if (it < niter) {
+            wait_pair(it);
+            if (it + 2 < niter) issue_v(it + 2);
+            const bool live0 = tiles_of(2 * it) != 0, live1 = tiles_of(2 * it + 1) != 0;
+            if (live0 | live1) {
+                // staged as in sweep 1: half of the V^T fragments are requested before the codes are formed, the rest before the MFMAs
+                const uint8_t *blk = lds + (2 * it) * kBuf + f_v;
+                u32x4 vlo[8], vhi[8];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    vlo[dt] = *(const u32x4 *)(blk + dt * 2048);
+                    vhi[dt] = *(const u32x4 *)(blk + kBuf + dt * 2048);
+                }
+                uint32_t pd[8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c == 0 ? live0 : live1) {
+#pragma unroll
+                        for (int j = 4 * c; j < 4 * c + 4; ++j) {
+                            const float *v = e[it][j];
+                            const uint32_t p0 = pack_bf16x2(v[0] * inv, v[1] * inv), p1 = pack_bf16x2(v[2] * inv, v[3] * inv);   // probabilities, bf16
+                            pd[j] = prob_codes<F == 1>(p0, p1);                                                               // fq_p
+                        }
+                    } else {
+                        pd[4 * c] = pd[4 * c + 1] = pd[4 * c + 2] = pd[4 * c + 3] = 0;
+                    }
+                }
+                const v8i pf = {(int)pd[0], (int)pd[1], (int)pd[2], (int)pd[3], (int)pd[4], (int)pd[5], (int)pd[6], (int)pd[7]};
+#pragma unroll
+                for (int dt = 4; dt < 8; ++dt) {
+                    vlo[dt] = *(const u32x4 *)(blk + dt * 2048);
+                    vhi[dt] = *(const u32x4 *)(blk + kBuf + dt * 2048);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const v8i vf = {(int)vlo[dt].x, (int)vlo[dt].y, (int)vlo[dt].z, (int)vlo[dt].w, (int)vhi[dt].x, (int)vhi[dt].y, (int)vhi[dt].z, (int)vhi[dt].w};
+                    acc[dt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, pf, acc[dt], F, F, 0, kUnit, 0, kUnit);
+                }
+            }
+        }
+    }
+    // ---- the two partial sums meet in LDS: group 1 parks its accumulators ([64 rows][128 d] fp32), group 0 adds and stores
+    __syncthreads();
+    float *part = (float *)lds;
+    constexpr int kPartRow = kD + 4;                                       // floats per row: the pad spreads the 16 rows of a store over the banks
+    const int prow = wq * 16 + r;
+    if (grp == 1) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) *(float4 *)(part + prow * kPartRow + dt * 16 + 4 * g) = float4{acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]};
+    }
+    __syncthreads();
+    if (grp == 0 && qrow < a.Sq) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const float4 o = *(const float4 *)(part + prow * kPartRow + dt * 16 + 4 * g);
+            acc[dt][0] += o.x; acc[dt][1] += o.y; acc[dt][2] += o.z; acc[dt][3] += o.w;
+        }
+        const long o0 = (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
+        uint16_t *orow = a.out + o0;
+        if (a.out8) {
+            const bool oe5 = a.out_fmt.p0 == 2;
+#pragma unroll
+            for (int dt = 0; dt < 8; dt += 2) {
+                uint32_t o[4] = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3]),
+                                 pack_bf16x2(acc[dt + 1][0], acc[dt + 1][1]), pack_bf16x2(acc[dt + 1][2], acc[dt + 1][3])};
+                const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);
+                *(uint2 *)(orow + dt * 16) = uint2{o[0], o[1]};
+                *(uint2 *)(orow + dt * 16 + 16) = uint2{o[2], o[3]};
+                *(uint32_t *)(a.out8 + o0 + dt * 16) = codes.x;
+                *(uint32_t *)(a.out8 + o0 + dt * 16 + 16) = codes.y;
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+                *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
+        }
+    }
+}
+
 // fq_v(V) as FP8 codes, transposed to [d][key] with the keys of every 128-block permuted into the k-slot order of the P.V instruction
 // (slot 16 g + 4 t + e <-> key 16 t + 4 g + e inside each half of 64).  One workgroup per (batch * head, key block).
 template <bool E5M2>
@@ -311,10 +630,24 @@ int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t
     AttnArgs a{q8_dev, k8_dev, vt8_dev, mask_dev, mask_sb, mask_sh, mask_sq, row_live_dev, live_sb, live_sh, live_sq, mask_is_simple ? 1 : 0,
                out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}};
     const int nqb = (Sq + 63) / 64;
-    const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));          // two blocks of 64 rows per workgroup (see the kernel)
     hipStream_t st = (hipStream_t)stream;
-    if (operand_format == 0) attention_fp8_kernel<0><<<grid, 512, 2 * kBuf, st>>>(a);
-    else attention_fp8_kernel<1><<<grid, 512, 2 * kBuf, st>>>(a);
+    const char *e_var = getenv("QT_FP8_ATTENTION_VARIANT");               // 1: two blocks of rows per workgroup; 2 (default): keys split over the groups
+    if (e_var && atoi(e_var) == 1) {
+        const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));
+        if (operand_format == 0) attention_fp8_kernel<0><<<grid, 512, 2 * kBuf, st>>>(a);
+        else attention_fp8_kernel<1><<<grid, 512, 2 * kBuf, st>>>(a);
+        return status();
+    }
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)attention_fp8_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) != hipSuccess)
+            return QT_ERR_BAD_ARG;
+        configured = true;
+    }
+    const dim3 grid((unsigned)(B * H), (unsigned)nqb);
+    if (operand_format == 0) attention_fp8_split_kernel<0><<<grid, 512, kSplitLds, st>>>(a);
+    else attention_fp8_split_kernel<1><<<grid, 512, kSplitLds, st>>>(a);
     return status();
 }
 

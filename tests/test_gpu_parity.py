@@ -1421,16 +1421,23 @@ def test_softmax_row_live_shortcut_changes_nothing(nv, kind):
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,mask_kind,live", [(1, 4, 128, 128, "causal", True), (2, 3, 200, 256, "padding", True), (1, 2, 64, 384, None, False),
-                                                      (1, 8, 1024, 1024, "causal", True), (1, 2, 256, 256, "causal", False)])
+                                                      (1, 8, 1024, 1024, "causal", True), (1, 2, 256, 256, "causal", False),
+                                                      (1, 2, 1000, 640, "causal", True),     # ragged rows, an odd block count, rows 0 .. 359 fully masked
+                                                      (2, 2, 1, 256, "padding", True)])      # one query row
 @pytest.mark.parametrize("fmt_name", ["e4m3", "e5m2"])
 @pytest.mark.parametrize("simple", [False, True])
-def test_attention_fp8_kernel(nv, B, H, Sq, Sk, mask_kind, live, fmt_name, simple):
+@pytest.mark.parametrize("variant", [2, 1])
+def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, fmt_name, simple, variant):
     """qt_attention_fp8 (+ qt_value_codes_t) against oracle.attention_fq, head_dim 128, all four matmul inputs in one stateless FP8
     format: the module chain with every rounding point explicit and exp / sums in float64.  Almost every output element is
     identical (measured <= 6e-3 differ: the FP8 matrix instruction adds the 128 products of a score in an aligned fixed-point tree
     that keeps fewer bits than the oracle's exact sum, so a few more scores than in the bf16 kernel's test straddle a bf16 rounding
     boundary); where a probability lands on the other side of a boundary of its 8-bit format one output row moves by at most that
-    probability's step.  Also: the permuted transposed value codes against a torch restatement."""
+    probability's step.  Also: the permuted transposed value codes against a torch restatement.  Both kernels: variant 2 (the
+    default: the two wave groups split the keys of one block of rows) and variant 1 (two blocks of rows per workgroup)."""
+    if variant == 1 and (fmt_name == "e5m2" or Sk == 384):
+        pytest.skip("variant 1 is the fallback: covered on the e4m3 cases")
+    monkeypatch.setenv("QT_FP8_ATTENTION_VARIANT", str(variant))
     L = nv.lib()
     D = 128
     torch.manual_seed(B * 7 + H + Sk)

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("dir")
 ap.add_argument("--windows", type=int, default=5)
 ap.add_argument("--layers", type=int, default=32)
-ap.add_argument("--anchor", default="attention_fp8_kernel,softmax_fq_kernel",
+ap.add_argument("--anchor", default="attention_fp8_split_kernel,attention_fp8_kernel,softmax_fq_kernel",
                 help="kernel(s) launched once per layer, comma separated: the first one present in the trace marks the windows")
 args = ap.parse_args()
 
