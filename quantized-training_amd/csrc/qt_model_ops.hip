@@ -179,51 +179,51 @@ struct RopeFqArgs {
     int e5m2;
 };
 
-__device__ __forceinline__ void rope_fq_one(const RopeFqArgs &a, size_t o) {
-    const long dv = a.r.D / 8;
-    const long d8 = (long)(o % dv);
-    const size_t bhs = o / dv;
-    const long s = (long)(bhs % (size_t)a.r.S);
-    const size_t bh = bhs / (size_t)a.r.S;
-    const long h = (long)(bh % (size_t)a.r.H);
-    const size_t b = bh / (size_t)a.r.H;
-    const size_t bs = b * a.r.S + s;
-    const size_t in_row = bs * (size_t)a.r.rsv + h * dv;         // vector index of x[b][s][h][0]
-    const long half = dv / 2;
-    const bool low = d8 < half;
-    const uint4 xv = *(const uint4 *)(a.r.x + (in_row + d8) * 8);
-    const uint4 pv = *(const uint4 *)(a.r.x + (in_row + (low ? d8 + half : d8 - half)) * 8);
-    const uint4 cv = *(const uint4 *)(a.r.cos + (bs * dv + d8) * 8);
-    const uint4 sv = *(const uint4 *)(a.r.sin + (bs * dv + d8) * 8);
-    const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
-    const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
-    const float sgn = low ? -1.0f : 1.0f;
-    uint32_t out[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
-        const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
-        out[j] = pack_bf16x2(a0 + b0, a1 + b1);                      // the rotary output, bf16
-    }
-    if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
-        const uint2 codes = a.e5m2 ? fq8_hw_vec8<true>(out, a.fmt) : fq8_hw_vec8<false>(out, a.fmt);
-        *(uint2 *)(a.y8 + o * 8) = codes;
-    } else {
+// One workgroup per token (b, s): its vectors are the H * D / 8 of a row of x, so the only divisions left are one per token
+// (scalar) and one 32-bit division per vector (64-bit index arithmetic per vector cost more than the rotation itself).
+__device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, uint32_t b, uint32_t s, size_t bs) {
+    const uint32_t dv = (uint32_t)a.r.D / 8, half = dv / 2, nv = (uint32_t)a.r.H * dv;
+    const uint16_t *xrow = a.r.x + bs * (size_t)a.r.rsv * 8;
+    const uint16_t *crow = a.r.cos + bs * dv * 8, *srow = a.r.sin + bs * dv * 8;
+    for (uint32_t v = threadIdx.x; v < nv; v += 256) {
+        const uint32_t h = v / dv, d8 = v - h * dv;
+        const bool low = d8 < half;
+        const uint4 xv = *(const uint4 *)(xrow + (size_t)v * 8);
+        const uint4 pv = *(const uint4 *)(xrow + (size_t)(low ? v + half : v - half) * 8);      // rotate_half partner
+        const uint4 cv = *(const uint4 *)(crow + d8 * 8);
+        const uint4 sv = *(const uint4 *)(srow + d8 * 8);
+        const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
+        const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
+        const float sgn = low ? -1.0f : 1.0f;
+        uint32_t out[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t r0 = qt_fp_sat_u32(out[j] << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-            const uint32_t r1 = qt_fp_sat_u32(out[j] & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
-            out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+            const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+            const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
+            out[j] = pack_bf16x2(a0 + b0, a1 + b1);                      // the rotary output, bf16
         }
+        const size_t o = (((size_t)b * (size_t)a.r.H + h) * (size_t)a.r.S + s) * dv + d8;     // [B][H][S][D] order
+        if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
+            const uint2 codes = a.e5m2 ? fq8_hw_vec8<true>(out, a.fmt) : fq8_hw_vec8<false>(out, a.fmt);
+            *(uint2 *)(a.y8 + o * 8) = codes;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r0 = qt_fp_sat_u32(out[j] << 16, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+                const uint32_t r1 = qt_fp_sat_u32(out[j] & 0xFFFF0000u, a.fmt.p0, a.fmt.p1, a.fmt.fhi);
+                out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+            }
+        }
+        *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
     }
-    *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
 }
 
 __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k) {
-    const size_t total = q.r.nvec + k.r.nvec;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        if (i < q.r.nvec) rope_fq_one(q, i);
-        else rope_fq_one(k, i - q.r.nvec);
+    const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;                 // q and k hold the same tokens
+    for (size_t bs = blockIdx.x; bs < tokens; bs += gridDim.x) {
+        const uint32_t b = (uint32_t)(bs / (size_t)q.r.S), s = (uint32_t)(bs - (size_t)b * (size_t)q.r.S);
+        rope_fq_token(q, b, s, bs);
+        rope_fq_token(k, b, s, bs);
     }
 }
 
@@ -513,8 +513,9 @@ int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, c
     if ((q_out8 && !is_e5m2(fmt_q) && !is_e4m3(fmt_q)) || (k_out8 && !is_e5m2(fmt_k) && !is_e4m3(fmt_k))) return QT_ERR_BAD_ARG;
     RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0};
     RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0};
-    size_t blocks = (aq.r.nvec + ak.r.nvec + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
+    size_t blocks = (size_t)B * (size_t)S;                                // one workgroup per token
+    if (blocks > 256 * 64) blocks = 256 * 64;
     rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
     return launch_status();
 }
