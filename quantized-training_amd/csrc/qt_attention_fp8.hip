@@ -33,7 +33,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 128, kBlock = 128, kMaxBlocks = 8, kBuf = kBlock * kD;       // one K / V^T block: 16 KiB of codes
-constexpr int kSplitLds = kMaxBlocks * kBuf + 2 * 2 * 64 * 4;                   // variant 2: every block of a sweep + the row statistics
 constexpr int kUnit = 127;                                                        // E8M0 2^0
 
 struct AttnArgs {
@@ -282,7 +281,7 @@ __device__ __forceinline__ float max3(float x, float y, float z) {
 
 // scores of the four tiles t0 .. t0 + 3 of one K block.  MODE 0: no mask arithmetic; 1: row-extent mask applied from my_live
 // (tiles from `tiles` on lie beyond every row of the wave); 2: additive mask read from mrow
-template <int F, int MODE>
+template <int F, int D, int MODE>
 __device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8i &qf, int f_lo, int f_hi, float scaling, float (*ev)[4], float &mx,
                                            const uint16_t *mrow, int key0, int my_live, int tiles) {
     // staged by hand -- all fragment reads, then the MFMAs back to back, then the rounding chains -- because the compiler keeps
@@ -296,8 +295,9 @@ __device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8i
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (MODE == 1 && j >= tiles) continue;
-        klo[j] = *(const u32x4 *)(blk + (t0 + j) * 2048 + f_lo);
-        khi[j] = *(const u32x4 *)(blk + (t0 + j) * 2048 + f_hi);
+        klo[j] = *(const u32x4 *)(blk + (t0 + j) * (16 * D) + f_lo);
+        if (D == 128) khi[j] = *(const u32x4 *)(blk + (t0 + j) * (16 * D) + f_hi);
+        else khi[j] = u32x4{0u, 0u, 0u, 0u};                             // head_dim 64: the upper half of the 128-deep product is 0 x 0
     }
     v4f s[4];
 #pragma unroll
@@ -333,8 +333,10 @@ __device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8i
     }
 }
 
-template <int F>
+template <int F, int D>
 __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a) {
+    constexpr int kBuf = kBlock * D;                                       // one K / V^T block of codes: 16 KiB at head_dim 128, 8 KiB at 64
+    constexpr int kPieces = D / 32;                                        // 1 KiB request pieces per wave and pair of blocks
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // 8 x 16 KiB of K, then V^T, blocks (later the partial sums) + the row statistics
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = l & 15, g = l >> 4, grp = w >> 2, wq = w & 3;
@@ -368,42 +370,52 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     if (!simple) wmin = a.Sk;                                              // extents then only bound the walk; inside them the mask is read
     if (!simple && !a.row_live) wmax = a.Sk;
     const uint32_t l0 = lds_addr(lds);
-    // DMA: an iteration brings two blocks (32 pieces of 8 rows x 128 bytes): this wave's pieces are 4 w .. 4 w + 3 of those 32
-    const uint8_t *kp[4], *vp[4];
+    // DMA: an iteration brings two blocks (2 x D / 16 pieces of 1 KiB): this wave's pieces are kPieces w .. of those.  K block, head_dim
+    // 128: a piece = 8 key rows x 128 bytes, 16-byte chunks XOR-swizzled by the row (chunk_off); head_dim 64: 16 key rows x 64 bytes,
+    // chunk c of row r in slot c ^ 2 (r >> 3 & 1) -- with ds_read_b128's lane groups that makes the 16 fragment reads of a tile
+    // conflict-free.  V^T block: D rows (d) x 128 bytes (keys), pieces of 8 rows, the same swizzle as the 128-byte K rows.
+    const uint8_t *kp[kPieces], *vp[kPieces];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = ((w * 4 + i) & 15) * 8 + (l >> 3), slot = l & 7, sw = ((slot ^ ((row >> 1) & 7)) << 4);
-        kp[i] = a.k8 + ((long)bh * a.Sk + row) * kD + sw;                   // + block * 128 * 128
-        vp[i] = a.vt8 + ((long)bh * kD + row) * a.Sk + sw;                  // + block * 128
+    for (int i = 0; i < kPieces; ++i) {
+        const int piece = (w * kPieces + i) % (D / 8);                    // within its block (D / 8 pieces of 1 KiB)
+        if (D == 128) {
+            const int row = piece * 8 + (l >> 3), slot = l & 7, sw = ((slot ^ ((row >> 1) & 7)) << 4);
+            kp[i] = a.k8 + ((long)bh * a.Sk + row) * D + sw;                // + block * 128 * D
+        } else {
+            const int r16 = l >> 2, row = piece * 16 + r16, sw = (((l & 3) ^ (((r16 >> 3) & 1) << 1)) << 4);
+            kp[i] = a.k8 + ((long)bh * a.Sk + row) * D + sw;
+        }
+        const int vrow = piece * 8 + (l >> 3), vslot = l & 7, vsw = ((vslot ^ ((vrow >> 1) & 7)) << 4);
+        vp[i] = a.vt8 + ((long)bh * D + vrow) * a.Sk + vsw;                 // + block * 128
     }
     // the second block of the last pair may lie beyond the live blocks: it is then fetched from the last one and never multiplied
     auto issue_k = [&](int it) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = w * 4 + i, kb = min(2 * it + (piece >> 4), nkb - 1);
+        for (int i = 0; i < kPieces; ++i) {
+            const int piece = w * kPieces + i, kb = min(2 * it + piece / (D / 8), nkb - 1);
             dma16(kp[i] + (long)kb * kBuf, l0 + (2 * it) * kBuf + piece * 1024);
         }
     };
     auto issue_v = [&](int it) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = w * 4 + i, kb = min(2 * it + (piece >> 4), nkb - 1);
+        for (int i = 0; i < kPieces; ++i) {
+            const int piece = w * kPieces + i, kb = min(2 * it + piece / (D / 8), nkb - 1);
             dma16(vp[i] + (long)kb * kBlock, l0 + (2 * it) * kBuf + piece * 1024);
         }
     };
     // every pair has its own buffers; requests run two pairs ahead of the arithmetic (a wave that requested a whole sweep at once
     // would sit in the request queue -- 64 bytes per clock per CU -- before its first multiplication)
     auto wait_pair = [&](int it) {
-        if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next pair (4 requests of this wave) may still be under way
+        if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");   // the next pair (this wave's requests of it) may still be under way
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * kD;
-    const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = *(const u32x4 *)(qp + 64 + 16 * g);
+    const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * D;
+    const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = D == 128 ? *(const u32x4 *)(qp + 64 + 16 * g) : u32x4{0u, 0u, 0u, 0u};
     const uint16_t *mrow = full ? a.mask + b * a.msb + h * a.msh + (long)qc * a.msq + 4 * g : nullptr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the compiler's waits for these must not meet the block requests
     const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
-    const int f_lo = chunk_off(r, g), f_hi = chunk_off(r, 4 + g);
+    const int f_lo = D == 128 ? chunk_off(r, g) : r * 64 + ((g ^ (((r >> 3) & 1) << 1)) << 4), f_hi = chunk_off(r, 4 + g);
     const int f_v = chunk_off(r, 4 * grp + g);                             // V^T: this group's tiles are one 16-byte chunk per block
     constexpr int kIter = kMaxBlocks / 2;
     // this wave's four tiles of block kb start at key kb * 128 + 64 grp; how many of them does one of its rows reach?
@@ -428,11 +440,11 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ev[j][0] = ev[j][1] = ev[j][2] = ev[j][3] = -INFINITY;
                 } else if (full) {
-                    score_half<F, 2>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, mrow, key0, 0, 4);
+                    score_half<F, D, 2>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, mrow, key0, 0, 4);
                 } else if (!simple || key0 + 64 <= wmin) {
-                    score_half<F, 0>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0, 0, 4);
+                    score_half<F, D, 0>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0, 0, 4);
                 } else {
-                    score_half<F, 1>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0 + 4 * g, my_live, nt);
+                    score_half<F, D, 1>(blk, 4 * grp, qf, f_lo, f_hi, a.scaling, ev, mx, nullptr, key0 + 4 * g, my_live, nt);
                 }
             }
         }
@@ -477,9 +489,10 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     if (g == 0) stat[128 + grp * 64 + wq * 16 + r] = sum;
     __syncthreads();
     const float inv = 1.0f / (stat[128 + wq * 16 + r] + stat[128 + 64 + wq * 16 + r]);
-    v4f acc[8];
+    constexpr int kDT = D / 16;                                            // output tiles of 16 d
+    v4f acc[kDT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < kDT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         if (it < niter) {
@@ -489,9 +502,9 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
             if (live0 | live1) {
                 // staged as in sweep 1: half of the V^T fragments are requested before the codes are formed, the rest before the MFMAs
                 const uint8_t *blk = lds + (2 * it) * kBuf + f_v;
-                u32x4 vlo[8], vhi[8];
+                u32x4 vlo[kDT], vhi[kDT];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < kDT / 2; ++dt) {
                     vlo[dt] = *(const u32x4 *)(blk + dt * 2048);
                     vhi[dt] = *(const u32x4 *)(blk + kBuf + dt * 2048);
                 }
@@ -511,13 +524,13 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
                 }
                 const v8i pf = {(int)pd[0], (int)pd[1], (int)pd[2], (int)pd[3], (int)pd[4], (int)pd[5], (int)pd[6], (int)pd[7]};
 #pragma unroll
-                for (int dt = 4; dt < 8; ++dt) {
+                for (int dt = kDT / 2; dt < kDT; ++dt) {
                     vlo[dt] = *(const u32x4 *)(blk + dt * 2048);
                     vhi[dt] = *(const u32x4 *)(blk + kBuf + dt * 2048);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
+                for (int dt = 0; dt < kDT; ++dt) {
                     const v8i vf = {(int)vlo[dt].x, (int)vlo[dt].y, (int)vlo[dt].z, (int)vlo[dt].w, (int)vhi[dt].x, (int)vhi[dt].y, (int)vhi[dt].z, (int)vhi[dt].w};
                     acc[dt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, pf, acc[dt], F, F, 0, kUnit, 0, kUnit);
                 }
@@ -527,25 +540,25 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     // ---- the two partial sums meet in LDS: group 1 parks its accumulators ([64 rows][128 d] fp32), group 0 adds and stores
     __syncthreads();
     float *part = (float *)lds;
-    constexpr int kPartRow = kD + 4;                                       // floats per row: the pad spreads the 16 rows of a store over the banks
+    constexpr int kPartRow = D + 4;                                       // floats per row: the pad spreads the 16 rows of a store over the banks
     const int prow = wq * 16 + r;
     if (grp == 1) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) *(float4 *)(part + prow * kPartRow + dt * 16 + 4 * g) = float4{acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]};
+        for (int dt = 0; dt < kDT; ++dt) *(float4 *)(part + prow * kPartRow + dt * 16 + 4 * g) = float4{acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]};
     }
     __syncthreads();
     if (grp == 0 && qrow < a.Sq) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
+        for (int dt = 0; dt < kDT; ++dt) {
             const float4 o = *(const float4 *)(part + prow * kPartRow + dt * 16 + 4 * g);
             acc[dt][0] += o.x; acc[dt][1] += o.y; acc[dt][2] += o.z; acc[dt][3] += o.w;
         }
-        const long o0 = (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
+        const long o0 = (((long)b * a.Sq + qrow) * a.H + h) * D + 4 * g;
         uint16_t *orow = a.out + o0;
         if (a.out8) {
             const bool oe5 = a.out_fmt.p0 == 2;
 #pragma unroll
-            for (int dt = 0; dt < 8; dt += 2) {
+            for (int dt = 0; dt < kDT; dt += 2) {
                 uint32_t o[4] = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3]),
                                  pack_bf16x2(acc[dt + 1][0], acc[dt + 1][1]), pack_bf16x2(acc[dt + 1][2], acc[dt + 1][3])};
                 const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
             }
         } else {
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
+            for (int dt = 0; dt < kDT; ++dt)
                 *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
         }
     }
@@ -564,14 +577,14 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
 
 // fq_v(V) as FP8 codes, transposed to [d][key] with the keys of every 128-block permuted into the k-slot order of the P.V instruction
 // (slot 16 g + 4 t + e <-> key 16 t + 4 g + e inside each half of 64).  One workgroup per (batch * head, key block).
-template <bool E5M2>
+template <bool E5M2, int D>
 __global__ __launch_bounds__(256) void value_codes_t_kernel(const uint16_t *v, uint8_t *vt8, int H, long Sk, long sb, long sh, long sk,
                                                             qt_format fmt) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kD * kBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[D * kBlock];
     const int t = threadIdx.x, kb = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int vi = it * 256 + t, key = vi >> 4, dv = vi & 15;
+    for (int it = 0; it < D / 16; ++it) {
+        const int vi = it * 256 + t, key = vi / (D / 8), dv = vi % (D / 8);
         const uint4 in = *(const uint4 *)(v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8);
         uint32_t o[4] = {in.x, in.y, in.z, in.w};
         const uint2 codes = fq8_hw_vec8<E5M2>(o, fmt);
@@ -581,9 +594,9 @@ __global__ __launch_bounds__(256) void value_codes_t_kernel(const uint16_t *v, u
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < D / 32; ++it) {
         const int ci = it * 256 + t, d = ci >> 3, ch = ci & 7;
-        *(uint4 *)(vt8 + ((long)bh * kD + d) * Sk + (long)kb * kBlock + ch * 16) = *(const uint4 *)(tile + d * kBlock + ch * 16);
+        *(uint4 *)(vt8 + ((long)bh * D + d) * Sk + (long)kb * kBlock + ch * 16) = *(const uint4 *)(tile + d * kBlock + ch * 16);
     }
 }
 
@@ -598,29 +611,50 @@ bool fp8_closed_form(const qt_format *f, bool &e5m2) {
     return e5m2 || (f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f);
 }
 
+template <int F, int D>
+int launch_split(const AttnArgs &a, long BH, int nqb, hipStream_t st) {
+    constexpr int kLds = kMaxBlocks * kBlock * D + 2 * 2 * 64 * 4;       // every block of a sweep + the row statistics
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+            return QT_ERR_BAD_ARG;
+        configured = true;
+    }
+    attention_fp8_split_kernel<F, D><<<dim3((unsigned)BH, (unsigned)nqb), 512, kLds, st>>>(a);
+    return status();
+}
+
 }  // namespace
 
 extern "C" {
 
-int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, long Sk, long stride_b, long stride_h, long stride_k,
+int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, long Sk, int head_dim, long stride_b, long stride_h, long stride_k,
                      const qt_format *fmt, void *stream) {
     if (B * H * Sk == 0) return QT_OK;
     bool e5m2 = false;
-    if (!v_dev || !vt8_dev || B < 0 || H < 1 || Sk < 0 || Sk % kBlock != 0 || B * H > 65535 || !fp8_closed_form(fmt, e5m2)) return QT_ERR_BAD_ARG;
+    if (!v_dev || !vt8_dev || B < 0 || H < 1 || Sk < 0 || Sk % kBlock != 0 || B * H > 65535 || (head_dim != 64 && head_dim != 128) ||
+        !fp8_closed_form(fmt, e5m2))
+        return QT_ERR_BAD_ARG;
     if ((((uintptr_t)v_dev | (uintptr_t)vt8_dev) & 15u) || ((stride_b | stride_h | stride_k) & 7)) return QT_ERR_UNALIGNED;
     const dim3 grid((unsigned)(Sk / kBlock), (unsigned)(B * H));
-    if (e5m2) value_codes_t_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
-    else value_codes_t_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 128) {
+        if (e5m2) value_codes_t_kernel<true, 128><<<grid, 256, 0, st>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+        else value_codes_t_kernel<false, 128><<<grid, 256, 0, st>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+    } else {
+        if (e5m2) value_codes_t_kernel<true, 64><<<grid, 256, 0, st>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+        else value_codes_t_kernel<false, 64><<<grid, 256, 0, st>>>(v_dev, vt8_dev, (int)H, Sk, stride_b, stride_h, stride_k, *fmt);
+    }
     return status();
 }
 
 int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t *vt8_dev, int operand_format, const uint16_t *mask_dev,
                      long mask_sb, long mask_sh, long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
                      int mask_is_simple, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B, int H, int Sq, int Sk,
-                     float scaling, void *stream) {
+                     int head_dim, float scaling, void *stream) {
     if (B * H * Sq == 0) return QT_OK;
     if (!q8_dev || !k8_dev || !vt8_dev || !out_dev || B < 0 || H < 1 || Sq < 1 || Sk < kBlock || Sk % kBlock != 0 || Sk > kBlock * kMaxBlocks ||
-        B * H > 65535 || operand_format < 0 || operand_format > 1)
+        B * H > 65535 || operand_format < 0 || operand_format > 1 || (head_dim != 64 && head_dim != 128))
         return QT_ERR_BAD_ARG;
     if ((((uintptr_t)q8_dev | (uintptr_t)k8_dev | (uintptr_t)vt8_dev) & 15u) || ((uintptr_t)out_dev & 7u) ||
         (mask_dev && ((((uintptr_t)mask_dev) & 7u) || ((mask_sb | mask_sh | mask_sq) & 3))))
@@ -631,24 +665,15 @@ int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t
                out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}};
     const int nqb = (Sq + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    const char *e_var = getenv("QT_FP8_ATTENTION_VARIANT");               // 1: two blocks of rows per workgroup; 2 (default): keys split over the groups
-    if (e_var && atoi(e_var) == 1) {
+    const char *e_var = getenv("QT_FP8_ATTENTION_VARIANT");               // 1: two blocks of rows per workgroup (head_dim 128 only); 2 (default): keys split over the groups
+    if (e_var && atoi(e_var) == 1 && head_dim == 128) {
         const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));
         if (operand_format == 0) attention_fp8_kernel<0><<<grid, 512, 2 * kBuf, st>>>(a);
         else attention_fp8_kernel<1><<<grid, 512, 2 * kBuf, st>>>(a);
         return status();
     }
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)attention_fp8_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds) != hipSuccess)
-            return QT_ERR_BAD_ARG;
-        configured = true;
-    }
-    const dim3 grid((unsigned)(B * H), (unsigned)nqb);
-    if (operand_format == 0) attention_fp8_split_kernel<0><<<grid, 512, kSplitLds, st>>>(a);
-    else attention_fp8_split_kernel<1><<<grid, 512, kSplitLds, st>>>(a);
-    return status();
+    if (head_dim == 128) return operand_format == 0 ? launch_split<0, 128>(a, B * H, nqb, st) : launch_split<1, 128>(a, B * H, nqb, st);
+    return operand_format == 0 ? launch_split<0, 64>(a, B * H, nqb, st) : launch_split<1, 64>(a, B * H, nqb, st);
 }
 
 }  // extern "C"

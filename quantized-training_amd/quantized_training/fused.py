@@ -808,23 +808,33 @@ def _mask_strides(attention_mask, B, H, Q, C, device, align):
 
 
 def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs):
-    """qt_attention_fp8: the attention core in one launch on FP8 codes (head_dim 128, keys in blocks of 128 up to 1024) when the four
-    fake-quantizers around the two matmuls are stateless E4M3 / E5M2 ones of one format and q / k arrive with their codes (the rotary
-    kernel attaches them).  Counts the four fake-quant calls the reference issues: q and k handed through by their hooks' modules, the
-    value pass (qt_value_codes_t) and the probabilities inside the kernel.  Returns [B, Sq, H, D] or None."""
+    """qt_attention_fp8: the attention core in one launch on FP8 codes (head_dim 128 or 64, keys in blocks of 128 up to 1024) when the
+    four fake-quantizers around the two matmuls are stateless E4M3 / E5M2 ones of one format.  q / k either arrive with their codes (the
+    rotary kernel attaches them) or are [B, H, S, D] views of the projections' outputs (BERT's transpose_for_scores), whose codes a
+    codes-only pass over the view writes here -- that pass IS the fq_q / fq_k call.  Counts the four fake-quant calls the reference
+    issues: q and k (handed through by their modules, or the passes just named), the value pass (qt_value_codes_t) and the
+    probabilities inside the kernel.  Returns [B, Sq, H, D] or None."""
     fq_q, fq_k, fq_p, fq_v = fqs
     B, H, Q, D = query.shape
     C = key.shape[2]
-    if D != 128 or C % 128 != 0 or C > 1024 or B * H > 65535 or value.dtype != torch.bfloat16 or value.stride(-1) != 1:
+    if D not in (64, 128) or C % 128 != 0 or C > 1024 or B * H > 65535 or value.dtype != torch.bfloat16 or value.stride(-1) != 1:
         return None
     if not all(isinstance(f, FusedAmaxObsFakeQuantize) and f.producer_fusable() for f in fqs):
         return None
     if len({f._qt_format.key() for f in fqs}) != 1 or any(s % 8 for s in value.stride()[:3]) or value.data_ptr() % 16:
         return None
-    q8, k8 = getattr(query, "_qt_fp8", None), getattr(key, "_qt_fp8", None)
-    if (q8 is None or k8 is None or not handover_valid(query) or not handover_valid(key) or query._qt_fq_done_by is not fq_q
-            or key._qt_fq_done_by is not fq_k or not q8.is_contiguous() or not k8.is_contiguous()
-            or tuple(q8.shape) != (B, H, Q, D) or tuple(k8.shape) != (B, H, C, D)):
+
+    def handed(t, fq, rows):
+        t8 = getattr(t, "_qt_fp8", None)
+        if t8 is None or not handover_valid(t) or t._qt_fq_done_by is not fq or not t8.is_contiguous() or tuple(t8.shape) != (B, H, rows, D):
+            return None
+        return t8
+
+    def view_ok(t):
+        return t.dtype == torch.bfloat16 and t.stride(-1) == 1 and not any(s % 8 for s in t.stride()[:3]) and t.data_ptr() % 16 == 0
+
+    q8, k8 = handed(query, fq_q, Q), handed(key, fq_k, C)
+    if (q8 is None and not view_ok(query)) or (k8 is None and not view_ok(key)):
         return None
     mk = _mask_strides(attention_mask, B, H, Q, C, query.device, 4)
     if mk is False:
@@ -839,11 +849,21 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
             rl, lsb, lsh, lsq = live
             rl_ptr = rl.data_ptr()
             simple = _mask_is_simple(mask, attention_mask, rl)
-    fq_q(query)                                              # hand-overs: counted by the fake-quantizers themselves
-    fq_k(key)
+
+    def codes(t, fq, t8, rows):
+        if t8 is not None:
+            fq(t)                                            # hand-over: counted by the fake-quantizer itself
+            return t8
+        t8 = torch.empty((B, H, rows, D), dtype=torch.uint8, device=t.device)
+        _native.check(L.qt_fake_quant_rows_bf16_fp8(t.data_ptr(), None, t8.data_ptr(), B, H, rows, D, t.stride(0), t.stride(1), t.stride(2),
+                                                    ctypes.byref(fq._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
+        STATS.add(t.numel())
+        return t8
+
+    q8, k8 = codes(query, fq_q, q8, Q), codes(key, fq_k, k8, C)
     fmt = fq_v._qt_format
     vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)
-    _native.check(L.qt_value_codes_t(value.data_ptr(), vt8.data_ptr(), B, H, C, value.stride(0), value.stride(1), value.stride(2),
+    _native.check(L.qt_value_codes_t(value.data_ptr(), vt8.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2),
                                      ctypes.byref(fmt), st), "qt_value_codes_t")
     STATS.add(value.numel())                                 # fq_v, evaluated by the pass above
     STATS.add(B * H * Q * C)                                 # fq_p, evaluated inside the kernel
@@ -857,7 +877,7 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
     _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 1 if fmt.p0 == 2 else 0,
                                      mask.data_ptr() if mask is not None else None, msb, msh, msq, rl_ptr, lsb, lsh, lsq, int(simple),
                                      out.data_ptr(), out8.data_ptr() if out8 is not None else None,
-                                     ctypes.byref(fq_o._qt_format) if fq_o is not None else None, B, H, Q, C, float(scaling), st),
+                                     ctypes.byref(fq_o._qt_format) if fq_o is not None else None, B, H, Q, C, D, float(scaling), st),
                   "qt_attention_fp8")
     if fq_o is not None:
         fq_o.expect_prequantized(out, out8.view(torch.float8_e5m2 if fq_o._qt_format.p0 == 2 else torch.float8_e4m3fn))
@@ -875,7 +895,7 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
     faster than the library-GEMM chain (B16 H12 S384: 85 vs 113 us); at head_dim 128 the chain wins (92 vs 122 us at
     B1 H32 S1024), so the chain stays the default there."""
     mode = os.environ.get("QT_FUSED_ATTENTION", "auto")
-    fp8_kernel = query.dim() == 4 and query.shape[-1] == 128 and os.environ.get("QT_FP8_ATTENTION_KERNEL", "1") != "0"
+    fp8_kernel = query.dim() == 4 and query.shape[-1] in (64, 128) and os.environ.get("QT_FP8_ATTENTION_KERNEL", "1") != "0"
     if mode == "0" or (mode != "1" and query.shape[-1] != 64 and not fp8_kernel):
         return None
     if not (query.device.type == "cuda" and query.dtype == torch.bfloat16 and query.dim() == 4):

@@ -144,175 +144,47 @@ def test_llama_mlp_front_half_as_one_launch(monkeypatch):
 
 
 def test_bert_squad_style_batch_parity(monkeypatch):
-    """BERT-base-style QA head (tiny config), bf16, E4M3 act+weight + all op groups: start/end logits of a
-    [16, 384]-shaped batch: CPU tensors against the device's plain route (same operations: tight) and its default route."""
+    """BERT-base-style QA head (tiny config, head_dim 64 as in BERT-base), bf16, E4M3 act+weight + all op groups: start/end logits of a
+    [16, 384]-shaped batch: CPU tensors against the device's plain route (same operations: tight) and its default route.  The default
+    route runs the attention core as qt_attention_fp8 (head_dim 64, right-padded rows): checked to be the kernel that ran, with the
+    same fake-quant call and element counts as the bf16 attention kernel it replaces."""
     from transformers import BertConfig, BertForQuestionAnswering
+    from quantized_training import fused
+    from quantized_training.fake_quantize import STATS
     torch.manual_seed(0)
-    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, vocab_size=300,
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=300,
                      max_position_embeddings=384)
     base = BertForQuestionAnswering(cfg).eval()
     ids = torch.randint(3, 300, (4, 384), generator=torch.Generator().manual_seed(1))
     att = torch.ones_like(ids); att[:, 300:] = 0
     import copy
+    ran = {"n": 0}
+    real = fused._attention_fp8_or_none
 
-    def build(dev):
+    def counted(*a, **k):
+        out = real(*a, **k)
+        ran["n"] += out is not None
+        return out
+    monkeypatch.setattr(fused, "_attention_fp8_or_none", counted)
+    counts = {}
+
+    def build(dev, groups="gemm,residual,activation,layernorm,scaling"):
         m = copy.deepcopy(base).to(dev)
-        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16",
-                             "--quantize_forward", "gemm,residual,activation,layernorm,scaling"))
+        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", groups))
         with torch.no_grad():
             m(ids.to(dev), attention_mask=att.to(dev))
+            STATS.reset()
             o = m(ids.to(dev), attention_mask=att.to(dev))
+            counts[len(counts)] = (STATS.elements, STATS.calls)
         return o.start_logits.float().cpu(), o.end_logits.float().cpu()
-    _assert_logits(_logits_by_route(build, monkeypatch))
-
-
-def test_pt2e_llama_on_device():
-    """The reference's current LLaMA driver flow (wikitext.py:68-136) on a tiny LLaMA: get_default_quantizer,
-    rotary matmul excluded, torch.export with a dynamic sequence length, prepare_pt2e, calibration, observers
-    frozen, evaluation -- device tensors (HIP fake-quant modules inside the exported graph) vs CPU tensors."""
-    from quantized_training import quantize_pt2e as qp
-    res = {}
-    for dev in ("cpu", "cuda"):
-        m = _llama(dev, torch.float32)
-        q = qp.get_default_quantizer("int8,qs=per_tensor_symmetric", None, "int8,qs=per_tensor_symmetric", "int24")
-        q.set_module_name_object_type_order(r"model\.rotary_emb", torch.ops.aten.matmul.default, 0, None)
-        ids = TOK[:, :64].to(dev)
-        seq = torch.export.Dim("seq_length", min=3, max=256)
-        with torch.no_grad():
-            gm = qp.prepare_pt2e(m, q, (ids,), {"labels": ids.clone(), "use_cache": False},
-                                 {"input_ids": {1: seq}, "labels": {1: seq}, "use_cache": None})
-        n_fq = sum(isinstance(mod, torch.ao.quantization.FakeQuantizeBase) for mod in gm.modules())
-        with torch.no_grad():
-            for i in range(3):                                        # calibration
-                w = TOK[:, i * 32: i * 32 + 96].to(dev)
-                gm(w, labels=w.clone(), use_cache=False)
-            for mod in gm.modules():
-                if isinstance(mod, torch.ao.quantization.FakeQuantizeBase):
-                    mod.disable_observer()
-            w = TOK[:, 200:328].to(dev)
-            res[dev] = (float(gm(w, labels=w.clone(), use_cache=False).loss), n_fq)
-    assert res["cpu"][1] == res["cuda"][1] and res["cpu"][1] > 20
-    assert abs(res["cpu"][0] - res["cuda"][0]) <= 0.01 / 5.36 * res["cpu"][0]
-
-
-@pytest.mark.parametrize("name", ["mxfp8", "mxfp4_bf16", "mxfp6_w_int", "nvfp4_like", "nf4_weight"])
-def test_pt2e_microscaling_converted_graph_on_device(name):
-    """The converted block-scaled graphs of tests/golden/pt2e_mx.* on the GPU.  MXFP8 / MXFP4 run their four GEMMs on the
-    scaled matrix instruction (asserted through mx_gemm.STATS); formats the instruction does not take (int elements, fp8
-    scales, codebooks) must take the reference formulation.  Outputs against the reference's CPU result: the quantize
-    steps are bit-exact, the GEMMs differ in accumulation order only, and a one-ulp difference before a later quantize
-    step can move single elements to the neighbouring code -- so the bound is on the error norm, 2 % of the output norm
-    (4-bit formats: 8 %), with the tight element-wise GEMM bound tested in test_gpu_parity.py."""
-    import json
-    import numpy as np
-    from quantized_training import quantize_pt2e as qp
-    from quantized_training import mx_gemm
-    from test_pt2e_cpu import mx_setup, META_MX, G
-    arr = np.load(os.path.join(G, "pt2e_mx.npz"))
-    info, m, xs = mx_setup(name, arr, device="cuda")
-    gm = qp.prepare_pt2e(m, qp.get_default_quantizer(**info["kw"]), (xs[0],))
-    with torch.no_grad():
-        gm(xs[0])
-        gm(xs[1])
-    gc = qp.convert_pt2e(gm)
-    assert [str(n.target) for n in gc.graph.nodes] == [r[2] for r in info["converted_graph"]]
-    mx_gemm.STATS.reset()
-    with torch.no_grad():
-        y = gc(xs[1])
-    # mxfp6_w_int: int4 weight values with power-of-two scales are exactly fp6_e3m2 codes, so those GEMMs are native
-    # too; its P.V matmul has K = 32, whose 24-byte fp6 rows are not 16-byte aligned -> reference formulation
-    native_expected = {"mxfp8": 4, "mxfp4_bf16": 4, "mxfp6_w_int": 3}.get(name, 0)
-    assert mx_gemm.STATS.native == native_expected, (mx_gemm.STATS.native, mx_gemm.STATS.fallback)
-    want = arr[f"{name}__y_converted"]
-    if y.dtype == torch.bfloat16:
-        ref = torch.from_numpy(want.view(np.int16).copy()).view(torch.bfloat16).float()
-    else:
-        ref = torch.from_numpy(want.view(np.float32).copy())
-    ref = ref.reshape(y.shape)
-    err = (y.float().cpu() - ref).norm() / ref.norm()
-    assert float(err) <= (0.08 if "fp4" in name or "nf4" in name else 0.02), float(err)
-
-
-def test_roberta_mrpc_style_training_on_device_matches_cpu():
-    """BASELINE config 5 in miniature: RoBERTa sequence classifier, int8 activations + weights with delayed scaling,
-    E5M2 gradients (quantized backward, gemm + residual), AdamW, clip 1.0 -- six steps with CPU tensors and with device
-    tensors from the same initial weights and batches.  fp32 model: the fake-quant passes are bit-exact on both sides,
-    the GEMMs and reductions differ in accumulation order, and int8 rounding amplifies a last-bit difference into one
-    quantization step on isolated elements; the loss curves must agree to 2 % per step and the delayed-scaling state
-    (scale of the first gradient fake-quantizer) to 2 %."""
-    import copy
-    from transformers import RobertaConfig, RobertaForSequenceClassification
-    torch.manual_seed(0)
-    cfg = RobertaConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=100,
-                        max_position_embeddings=66, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    base = RobertaForSequenceClassification(cfg)
-    g = torch.Generator().manual_seed(1)
-    batches = [{"input_ids": torch.randint(3, 100, (8, 16), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)}
-               for _ in range(6)]
-    res = {}
-    for dev in ("cpu", "cuda"):
-        m = copy.deepcopy(base).to(dev)
-        qt.quantize(m, _args("--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
-                             "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10",
-                             "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual"))
-        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
-        losses = harness.train_steps(m, batches, opt)
-        fq = dict(m.named_modules())["roberta.encoder.layer.0.attention.self.query.error_pre_process.0"]
-        res[dev] = (losses, float(fq.scale), float(fq.amax_history.max()))
-    (l0, s0, a0), (l1, s1, a1) = res["cpu"], res["cuda"]
-    assert all(abs(x - y) <= 0.02 * abs(x) for x, y in zip(l0, l1)), (l0, l1)
-    assert abs(s0 - s1) <= 0.02 * s0 and abs(a0 - a1) <= 0.02 * a0, (s0, s1, a0, a1)
-    assert s0 != 1.0
-
-
-def test_llama_model_fusions_vs_hf_chains():
-    """quantize() routes LlamaRMSNorm / rotary / SiLU*up through one-launch kernels under no_grad; with
-    QT_FUSED_MODEL_OPS=0 HF's own torch chains run.  Same quantized-element count, window NLLs within 1e-3 relative
-    (the only non-bit-identical piece is the RMSNorm mean's summation order)."""
-    from quantized_training.fake_quantize import STATS
-    res = {}
-    for flag in ("1", "0"):
-        os.environ["QT_FUSED_MODEL_OPS"] = flag
-        try:
-            m = _llama("cuda", torch.bfloat16)
-            qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
-            with torch.no_grad():
-                harness.window_nll(m, TOK[:, :256].cuda(), 256)
-                STATS.reset()
-                nll = [float(harness.window_nll(m, TOK[:, b:e].cuda(), t)) for (b, e, t) in harness.wikitext_windows(TOK.shape[1], 256, 128)]
-            res[flag] = (nll, STATS.elements)
-        finally:
-            os.environ.pop("QT_FUSED_MODEL_OPS", None)
-    (a, na), (b, nb) = res["1"], res["0"]
-    assert na == nb
-    assert all(abs(x - y) <= 1e-3 * abs(y) for x, y in zip(a, b)), (a, b)
-
-
-def test_lora_qat_linear_on_device_matches_golden_forward():
-    """The LoRA QAT layer on device tensors: the three weight fake-quant calls run through the HIP kernels; the
-    first forward of each golden case (reference run, tests/golden/gen_golden.py gen_lora) is reproduced up to the
-    accumulation order of the two bf16 matmuls (|dy| <= 2^-6 (|y| + 1))."""
-    from test_surface_cpu import LORA, LORA_NPZ, _PeftStyleLoraLinear, _from_bits16
-    from quantized_training.modules.qat import LoraLinear
-    for case in LORA:
-        n, fin, fout, r = case["name"], case["in"], case["out"], case["r"]
-        key = lambda k: LORA_NPZ[(n + "/" + k).replace("/", "__")]
-        flt = _PeftStyleLoraLinear(fin, fout, r, case["fan_in_fan_out"])
-        with torch.no_grad():
-            flt.base_layer.weight.copy_(_from_bits16(key("w"), flt.base_layer.weight.shape))
-            flt.base_layer.bias.copy_(_from_bits16(key("b"), (fout,)))
-            flt.lora_A["default"].weight.copy_(_from_bits16(key("A"), (r, fin)))
-            flt.lora_B["default"].weight.copy_(_from_bits16(key("B"), (fout, r)))
-        flt.qconfig = qt.get_qconfig(None, qt.QuantizationSpec.from_str(case["spec"]), None)
-        layer = LoraLinear.from_float(flt).cuda()
-        x = _from_bits16(key("0/x"), (5, fin)).cuda()
-        y = layer(x)
-        y.float().square().mean().backward()
-        ref = _from_bits16(key("0/y"), (5, fout)).float()
-        assert ((y.detach().float().cpu() - ref).abs() <= 2.0 ** -6 * (ref.abs() + 1)).all(), n
-        g = flt.lora_B["default"].weight.grad
-        gref = _from_bits16(key("0/gB"), (fout, r)).float()
-        assert g is not None and ((g.float().cpu() - gref).abs() <= 2.0 ** -5 * (gref.abs() + gref.abs().max())).all(), n
+    _assert_logits(_logits_by_route(build, monkeypatch))                        # (the scaling group's hooks keep the chain unfused)
+    ran["n"] = 0
+    _assert_logits(_logits_by_route(lambda dev: build(dev, "gemm"), monkeypatch))
+    assert ran["n"] == cfg.num_hidden_layers, ran                              # the default route's second forward, every layer (the first creates the hooks' modules)
+    monkeypatch.setenv("QT_FP8_ATTENTION_KERNEL", "0")
+    build("cuda", "gemm")
+    assert ran["n"] == cfg.num_hidden_layers
+    assert counts[5] == counts[6], counts                                       # default route with / without the FP8 attention kernel
 
 
 @pytest.mark.parametrize("family", ["bert", "roberta"])

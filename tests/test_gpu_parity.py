@@ -1420,26 +1420,28 @@ def test_softmax_row_live_shortcut_changes_nothing(nv, kind):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,mask_kind,live", [(1, 4, 128, 128, "causal", True), (2, 3, 200, 256, "padding", True), (1, 2, 64, 384, None, False),
-                                                      (1, 8, 1024, 1024, "causal", True), (1, 2, 256, 256, "causal", False),
-                                                      (1, 2, 1000, 640, "causal", True),     # ragged rows, an odd block count, rows 0 .. 359 fully masked
-                                                      (2, 2, 1, 256, "padding", True)])      # one query row
+@pytest.mark.parametrize("B,H,Sq,Sk,mask_kind,live,D", [
+    (1, 4, 128, 128, "causal", True, 128), (2, 3, 200, 256, "padding", True, 128), (1, 2, 64, 384, None, False, 128),
+    (1, 8, 1024, 1024, "causal", True, 128), (1, 2, 256, 256, "causal", False, 128),
+    (1, 2, 1000, 640, "causal", True, 128),      # ragged rows, an odd block count, rows 0 .. 359 fully masked
+    (2, 2, 1, 256, "padding", True, 128),        # one query row
+    (2, 12, 384, 384, "padding", True, 64),      # the BERT-base head shape
+    (1, 3, 200, 256, "causal", True, 64), (1, 2, 64, 128, None, False, 64), (1, 2, 1000, 640, "causal", True, 64)])
 @pytest.mark.parametrize("fmt_name", ["e4m3", "e5m2"])
 @pytest.mark.parametrize("simple", [False, True])
 @pytest.mark.parametrize("variant", [2, 1])
-def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, fmt_name, simple, variant):
-    """qt_attention_fp8 (+ qt_value_codes_t) against oracle.attention_fq, head_dim 128, all four matmul inputs in one stateless FP8
+def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, D, fmt_name, simple, variant):
+    """qt_attention_fp8 (+ qt_value_codes_t) against oracle.attention_fq, head_dim 128 and 64, all four matmul inputs in one stateless FP8
     format: the module chain with every rounding point explicit and exp / sums in float64.  Almost every output element is
     identical (measured <= 6e-3 differ: the FP8 matrix instruction adds the 128 products of a score in an aligned fixed-point tree
     that keeps fewer bits than the oracle's exact sum, so a few more scores than in the bf16 kernel's test straddle a bf16 rounding
     boundary); where a probability lands on the other side of a boundary of its 8-bit format one output row moves by at most that
     probability's step.  Also: the permuted transposed value codes against a torch restatement.  Both kernels: variant 2 (the
     default: the two wave groups split the keys of one block of rows) and variant 1 (two blocks of rows per workgroup)."""
-    if variant == 1 and (fmt_name == "e5m2" or Sk == 384):
-        pytest.skip("variant 1 is the fallback: covered on the e4m3 cases")
+    if variant == 1 and (fmt_name == "e5m2" or Sk == 384 or D != 128):
+        pytest.skip("variant 1 is the fallback (head_dim 128 only): covered on the e4m3 cases")
     monkeypatch.setenv("QT_FP8_ATTENTION_VARIANT", str(variant))
     L = nv.lib()
-    D = 128
     torch.manual_seed(B * 7 + H + Sk)
     qmap_in = torch.from_numpy(o.get_quantization_map(fmt_name).view(np.int16)).cuda().view(torch.bfloat16)
     fqin = lambda t: qmap_in[(t.view(torch.int16).to(torch.int32) & 0xFFFF).long()]  # noqa: E731
@@ -1462,7 +1464,7 @@ def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, fm
     fcode = 0 if fmt_name == "e4m3" else 1
     q8, k8 = _codes_of(nv, q, fmt_name), _codes_of(nv, k, fmt_name)
     vt8 = torch.empty(B, H, D, Sk, dtype=torch.uint8, device="cuda")
-    nv.check(L.qt_value_codes_t(v_raw.data_ptr(), vt8.data_ptr(), B, H, Sk, v_raw.stride(0), v_raw.stride(1), v_raw.stride(2), ctypes.byref(fmt),
+    nv.check(L.qt_value_codes_t(v_raw.data_ptr(), vt8.data_ptr(), B, H, Sk, D, v_raw.stride(0), v_raw.stride(1), v_raw.stride(2), ctypes.byref(fmt),
                                 stream()), "qt_value_codes_t")
     # the permutation: position p of a 128-block holds key ((p >> 2) & 3) * 16 + ((p >> 4) & 3) * 4 + (p & 3) (+ 64 for the upper half)
     pos = torch.arange(128, device="cuda")
@@ -1478,7 +1480,7 @@ def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, fm
         lsb, lsq = (mask.shape[2] if mask.shape[0] > 1 else 0), (1 if mask.shape[2] > 1 else 0)
     out = torch.full((B, Sq, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
     nv.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), fcode, mask.data_ptr() if mask is not None else None, msb, 0, msq,
-                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), out.data_ptr(), None, None, B, H, Sq, Sk, scaling, stream()),
+                                rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), out.data_ptr(), None, None, B, H, Sq, Sk, D, scaling, stream()),
              "qt_attention_fp8")
     torch.cuda.synchronize()
     u16 = lambda t: host_u16(t.contiguous().view(torch.int16))  # noqa: E731
@@ -1494,7 +1496,7 @@ def test_attention_fp8_kernel(nv, monkeypatch, B, H, Sq, Sk, mask_kind, live, fm
     out8 = torch.empty(B, Sq, H, D, dtype=torch.uint8, device="cuda")
     nv.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), fcode, mask.data_ptr() if mask is not None else None, msb, 0, msq,
                                 rl.data_ptr() if rl is not None else None, lsb, 0, lsq, int(simple), outq.data_ptr(), out8.data_ptr(), ctypes.byref(fo),
-                                B, H, Sq, Sk, scaling, stream()), "qt_attention_fp8")
+                                B, H, Sq, Sk, D, scaling, stream()), "qt_attention_fp8")
     want8 = _codes_of(nv, out, "e4m3")
     assert torch.equal(out8, want8)
     qm = torch.from_numpy(o.get_quantization_map("e4m3").view(np.int16)).cuda()

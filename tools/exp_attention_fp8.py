@@ -52,14 +52,14 @@ def main():
         mp = mask.data_ptr() if mask is not None else None
 
         def vpass_t():
-            _native.check(L.qt_value_codes_t(v.data_ptr(), vt8.data_ptr(), B, H, S, v.stride(0), v.stride(1), v.stride(2), ctypes.byref(fmt), st()), "vt")
+            _native.check(L.qt_value_codes_t(v.data_ptr(), vt8.data_ptr(), B, H, S, D, v.stride(0), v.stride(1), v.stride(2), ctypes.byref(fmt), st()), "vt")
 
         simple = True
 
         def core(with_live=True):
             _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 0, mp, 0, 0, S if mask is not None else 0,
                                              live.data_ptr() if (live is not None and with_live) else None, 0, 0, 1, int(simple and with_live), out.data_ptr(), None, None, B, H, S, S,
-                                             scaling, st()), "attn")
+                                             D, scaling, st()), "attn")
 
         def one_launch():
             vpass_t(); core()
