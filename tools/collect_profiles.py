@@ -94,10 +94,12 @@ G = os.path.join(ROOT, "gpurun_out")
 for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_breakdown_13b_posit.txt", "13b_posit8_2_window_breakdown.txt"),
                  ("bench_13b_posit8_2.json", "13b_posit8_2_bench.json"), ("mx_gemm.log", "mx_gemm.txt"), ("mx_linear.log", "mx_linear.txt"),
                  ("mx_quant.log", "mx_quant.txt"), ("mx_wide.log", "mx_wide_ablation.txt"), ("tile_fetch.log", "tile_fetch_probe.txt"),
-                 ("fq8_session.txt", "linear_fq8_gemm.txt"), ("mlp_fq8.txt", "mlp_fq8.txt"), ("attention_fp8.txt", "attention_fp8.txt"), ("table_formats.txt", "table_formats.txt"), ("oracle_attention.txt", "oracle_attention.txt")):
+                 ("fq8_session.txt", "linear_fq8_gemm.txt"), ("mlp_fq8.txt", "mlp_fq8.txt"), ("attention_fp8.txt", "attention_fp8.txt"), ("table_formats.txt", "table_formats.txt"), ("oracle_attention.txt", "oracle_attention.txt"),
+                 ("bert_batch.txt", "bert_batch.txt"), ("train_step.txt", "train_step.txt")):
     clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
 for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
-                     ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv")):
+                     ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv"),
+                     ("prof_bert_stats/*/*kernel_stats.csv", "bert_kernel_stats.csv"), ("prof_train_stats/*/*kernel_stats.csv", "train_kernel_stats.csv")):
     f = one(pattern)
     if f:
         shutil.copy(f, os.path.join(out, f"{tag}_{dst}"))

@@ -34,8 +34,8 @@ def timeit(fn, iters=30):
 
 def main():
     fmt = _native.format_for("e4m3")
-    for (B, H, S, causal) in ((1, 32, 1024, True), (1, 32, 1024, False), (1, 32, 512, True), (4, 32, 256, True)):
-        D = 128
+    for (B, H, S, causal, D) in ((1, 32, 1024, True, 128), (1, 32, 1024, False, 128), (1, 32, 512, True, 128), (4, 32, 256, True, 128),
+                                 (16, 12, 384, False, 64), (16, 12, 128, False, 64)):
         q8 = torch.randn(B, H, S, D, device=DEV).to(torch.float8_e4m3fn)
         k8 = torch.randn(B, H, S, D, device=DEV).to(torch.float8_e4m3fn)
         v = torch.randn(B, S, H, D, device=DEV).bfloat16().transpose(1, 2)           # as the v projection leaves it
@@ -76,7 +76,7 @@ def main():
             print("library route unavailable"); continue
         t1, tc = timeit(one_launch), timeit(chain)
         tv, ta, tn = timeit(vpass_t), timeit(core), timeit(lambda: core(False))
-        print(f"B{B} H{H} S{S} {'causal' if causal else 'no mask'}: one launch {t1:6.1f} us (value codes {tv:5.1f} + core {ta:6.1f}; core without row extents {tn:6.1f})"
+        print(f"B{B} H{H} S{S} D{D} {'causal' if causal else 'no mask'}: one launch {t1:6.1f} us (value codes {tv:5.1f} + core {ta:6.1f}; core without row extents {tn:6.1f})"
               f" | chain {tc:6.1f} us", flush=True)
 
 

@@ -17,3 +17,5 @@ bash tools/gpu_session_fq8.sh > /dev/null 2>&1
 timeout 600 python tools/exp_mlp_fq8.py > gpurun_out/mlp_fq8.txt 2>&1
 grep -E "^bench" gpurun_out/fq8_session.txt | head -8 | cut -c1-120
 timeout 600 python tools/exp_attention_fp8.py > gpurun_out/attention_fp8.txt 2>&1
+# the two secondary configurations: BERT-base QA batch and the RoBERTa-base training step
+bash tools/gpu_session_aux.sh
