@@ -267,6 +267,11 @@ int qt_softmax_fq_bf16_fp8(const uint16_t *scores_dev, const uint16_t *mask_dev,
  * neither loaded nor evaluated -- their probabilities are exactly 0 -- unless the row has no unmasked column at all (then it is a
  * uniform distribution and is evaluated in full).  Same results as qt_softmax_fq_bf16_fp8, bit for bit. */
 int qt_mask_row_live(const uint16_t *mask_dev, long rows, long cols, long row_stride, int *row_live_dev, void *stream);
+/* The same, and *irregular_dev (device) = 0 when every row is exactly "zeros up to its extent, the bf16 minimum from there on" (causal
+ * masks, right padding), else 1: qt_attention_fp8 then decides on the device whether it has to read the mask (no host read-back, so it
+ * works inside a stream capture). */
+int qt_mask_row_live_checked(const uint16_t *mask_dev, long rows, long cols, long row_stride, int *row_live_dev, int *irregular_dev,
+                             void *stream);
 /* ---- The attention core on FP8 codes, head_dim D = 128 or 64, ONE launch (modules/quantizable/modeling_llama.py:228-246, modeling_bert.py:118-158):
  *     out = av_matmul(fq_p(softmax(attn_scaling(qk_matmul(fq_q(q), fq_k(k)^T), scale) + mask)), fq_v(v))
  * for stateless E4M3 / E5M2 fake-quantizers (unit scale) of one format on all four matmul inputs, with the module chain's rounding
@@ -276,15 +281,16 @@ int qt_mask_row_live(const uint16_t *mask_dev, long rows, long cols, long row_st
  * strides for batch, head, key; head_dim contiguous), which IS the fq_v call.  mask: additive bf16 or NULL (element strides, columns
  * contiguous); row_live (optional, qt_mask_row_live): key blocks beyond every row's last unmasked column are skipped; mask_is_simple: the
  * caller has checked that every mask row is exactly 0 up to its row_live entry and the bf16 minimum from there on (causal, right padding),
- * and the kernel applies that without reading the mask (x + 0 = x; bf16(x + min) = min for finite x).  out: [B][Sq][H][D] bf16;
+ * and the kernel applies that without reading the mask (x + 0 = x; bf16(x + min) = min for finite x); mask_irregular_dev (optional): the
+ * device-side verdict of qt_mask_row_live_checked, 0 meaning the same.  out: [B][Sq][H][D] bf16;
  * with out8 (+ out_format, an e4m3 / e5m2 closed-form format) the consumer's stateless input fake-quantizer -- the output projection's --
  * is applied on the way out: out = fq(result), out8 its FP8 codes.  Sk % 128 == 0, Sk <= 1024. */
 int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, long Sk, int head_dim, long stride_b, long stride_h, long stride_k,
                      const qt_format *fmt, void *stream);
 int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t *vt8_dev, int operand_format, const uint16_t *mask_dev,
                      long mask_sb, long mask_sh, long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
-                     int mask_is_simple, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B, int H, int Sq, int Sk,
-                     int head_dim, float scaling, void *stream);
+                     int mask_is_simple, const int *mask_irregular_dev, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B,
+                     int H, int Sq, int Sk, int head_dim, float scaling, void *stream);
 int qt_softmax_fq_bf16_fp8_live(const uint16_t *scores_dev, const uint16_t *mask_dev, uint8_t *out8_dev, long batch, int heads, int q_len,
                                 long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
                                 const int *row_live_dev, long live_sb, long live_sh, long live_sq, void *stream);

@@ -48,6 +48,7 @@ struct AttnArgs {
     float scaling;
     uint8_t *out8;                      // optional: the consumer's (output projection's input) stateless FP8 fake-quantizer applied on the way
     qt_format out_fmt;                  // out: `out` then holds fq(result), out8 its codes, same layout
+    const int *mask_irregular;          // optional, device: 0 = qt_mask_row_live_checked found every row "zeros, then the minimum" (as mask_simple)
 };
 
 __device__ __forceinline__ float blo(uint32_t w) { return qt_u2f(w << 16); }
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_kernel(AttnArgs a) {
     const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * kD;
     const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = *(const u32x4 *)(qp + 64 + 16 * g);
     const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
-    const bool simple = a.mask && a.row_live && a.mask_simple;
+    const bool simple = a.mask && a.row_live && (a.mask_simple || (a.mask_irregular && *a.mask_irregular == 0));
     const uint16_t *mrow = (a.mask && !simple) ? a.mask + b * a.msb + h * a.msh + (long)qc * a.msq + 4 * g : nullptr;
     const int my_live = simple ? a.row_live[b * a.lsb + h * a.lsh + qc * a.lsq] : 0;      // this lane's row: keys >= my_live are masked
     const int f_lo = chunk_off(r, g), f_hi = chunk_off(r, 4 + g);          // fragment of tile 0: tile i is 2048 bytes further
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
         wmin = __builtin_amdgcn_readfirstlane(lo);
     }
     const int niter = (nlive + 1) / 2;                                     // iteration i: blocks 2 i and 2 i + 1
-    const bool simple = a.mask && a.row_live && a.mask_simple, full = a.mask && !simple;
+    const bool simple = a.mask && a.row_live && (a.mask_simple || (a.mask_irregular && *a.mask_irregular == 0)), full = a.mask && !simple;
     if (!simple) wmin = a.Sk;                                              // extents then only bound the walk; inside them the mask is read
     if (!simple && !a.row_live) wmax = a.Sk;
     const uint32_t l0 = lds_addr(lds);
@@ -650,8 +651,8 @@ int qt_value_codes_t(const uint16_t *v_dev, uint8_t *vt8_dev, long B, long H, lo
 
 int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t *vt8_dev, int operand_format, const uint16_t *mask_dev,
                      long mask_sb, long mask_sh, long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
-                     int mask_is_simple, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B, int H, int Sq, int Sk,
-                     int head_dim, float scaling, void *stream) {
+                     int mask_is_simple, const int *mask_irregular_dev, uint16_t *out_dev, uint8_t *out8_dev, const qt_format *out_format, long B,
+                     int H, int Sq, int Sk, int head_dim, float scaling, void *stream) {
     if (B * H * Sq == 0) return QT_OK;
     if (!q8_dev || !k8_dev || !vt8_dev || !out_dev || B < 0 || H < 1 || Sq < 1 || Sk < kBlock || Sk % kBlock != 0 || Sk > kBlock * kMaxBlocks ||
         B * H > 65535 || operand_format < 0 || operand_format > 1 || (head_dim != 64 && head_dim != 128))
@@ -662,7 +663,7 @@ int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t
     bool oe5 = false;
     if (out8_dev && (!fp8_closed_form(out_format, oe5) || ((uintptr_t)out8_dev & 3u))) return QT_ERR_BAD_ARG;
     AttnArgs a{q8_dev, k8_dev, vt8_dev, mask_dev, mask_sb, mask_sh, mask_sq, row_live_dev, live_sb, live_sh, live_sq, mask_is_simple ? 1 : 0,
-               out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}};
+               out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}, mask_irregular_dev};
     const int nqb = (Sq + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
     const char *e_var = getenv("QT_FP8_ATTENTION_VARIANT");               // 1: two blocks of rows per workgroup (head_dim 128 only); 2 (default): keys split over the groups

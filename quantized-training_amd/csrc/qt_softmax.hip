@@ -240,8 +240,9 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
 }
 
 namespace {
-// one wave per mask row: one past the last column whose entry is above -1e30
-__global__ __launch_bounds__(256) void mask_row_live_kernel(const uint16_t *mask, long rows, long cols, long row_stride, int *out) {
+// one wave per mask row: one past the last column whose entry is above -1e30.  With `irregular`: rows that are not exactly "zeros up
+// to that column, the bf16 minimum from there on" (causal masks and right padding are) set it to 1
+__global__ __launch_bounds__(256) void mask_row_live_kernel(const uint16_t *mask, long rows, long cols, long row_stride, int *out, int *irregular) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -252,13 +253,28 @@ __global__ __launch_bounds__(256) void mask_row_live_kernel(const uint16_t *mask
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
     if (lane == 0) out[row] = last;
+    if (irregular) {
+        bool bad = false;
+        for (long c = lane; c < cols; c += 64) bad |= c < last ? (m[c] & 0x7FFFu) != 0 : m[c] != 0xFF7Fu;
+        if (__any(bad) && lane == 0) atomicOr(irregular, 1);
+    }
 }
 }  // namespace
 
 extern "C" int qt_mask_row_live(const uint16_t *mask, long rows, long cols, long row_stride, int *out, void *stream) {
     if (rows == 0) return QT_OK;
     if (!mask || !out || rows < 0 || cols < 0 || row_stride < cols) return QT_ERR_BAD_ARG;
-    mask_row_live_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, rows, cols, row_stride, out);
+    mask_row_live_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, rows, cols, row_stride, out, nullptr);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
+extern "C" int qt_mask_row_live_checked(const uint16_t *mask, long rows, long cols, long row_stride, int *out, int *irregular_dev, void *stream) {
+    if (!irregular_dev) return QT_ERR_BAD_ARG;
+    if (hipMemsetAsync(irregular_dev, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return QT_ERR_BAD_ARG;
+    if (rows == 0) return QT_OK;
+    if (!mask || !out || rows < 0 || cols < 0 || row_stride < cols) return QT_ERR_BAD_ARG;
+    mask_row_live_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, rows, cols, row_stride, out, irregular_dev);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }

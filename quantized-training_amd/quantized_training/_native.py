@@ -75,8 +75,9 @@ SIGNATURES = {
                                   _P, _P]),
     "qt_softmax_fq_bf16_fp8": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P]),
     "qt_mask_row_live": (c_int, [_P, c_long, c_long, c_long, _P, _P]),
+    "qt_mask_row_live_checked": (c_int, [_P, c_long, c_long, c_long, _P, _P, _P]),
     "qt_value_codes_t": (c_int, [_P, _P, c_long, c_long, c_long, c_int, c_long, c_long, c_long, _FMT, _P]),
-    "qt_attention_fp8": (c_int, [_P, _P, _P, c_int, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, c_int, _P, _P, _P, c_long, c_int,
+    "qt_attention_fp8": (c_int, [_P, _P, _P, c_int, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, c_int, _P, _P, _P, _P, c_long, c_int,
                                  c_int, c_int, c_int, c_float, _P]),
     "qt_softmax_fq_bf16_fp8_live": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, c_long, c_long,
                                             c_long, _P]),

@@ -699,7 +699,9 @@ def _mask_row_live(mask, owner, B, H, Q, C, st):
     """Per-row extent of the unmasked part of an additive mask (qt_mask_row_live), or None when the mask's rows are not evenly
     spaced.  Kept as an attribute of `owner` -- the tensor object the attention block was handed, of which `mask` is a view: the
     cached causal mask of a window evaluation is the same object for every layer and window, a mask Hugging Face builds per
-    forward is the same object for every layer of that forward; a new object (or a new version of it) is scanned again.  Returns
+    forward is the same object for every layer of that forward; a new object (or a new version of it) is scanned again.  The scan
+    also leaves, behind the extents (element `rows` of the buffer), whether any row is NOT exactly "zeros, then the dtype's minimum":
+    qt_attention_fp8 reads that on the device (no host read-back: also inside a stream capture).  Returns
     (row_live, stride_b, stride_h, stride_q) in rows."""
     if mask.dim() != 4:
         return None
@@ -713,31 +715,11 @@ def _mask_row_live(mask, owner, B, H, Q, C, st):
         rl = hit[1]
     else:
         rows = mb * mh * mq
-        rl = torch.empty(rows, dtype=torch.int32, device=mask.device)
-        _native.check(_native.lib().qt_mask_row_live(mask.data_ptr(), rows, C, rs, rl.data_ptr(), st), "qt_mask_row_live")
+        rl = torch.empty(rows + 1, dtype=torch.int32, device=mask.device)
+        _native.check(_native.lib().qt_mask_row_live_checked(mask.data_ptr(), rows, C, rs, rl.data_ptr(), rl.data_ptr() + 4 * rows, st),
+                      "qt_mask_row_live_checked")
         owner._qt_row_live = (key, rl)
     return rl, (mh * mq if mb == B and B > 1 else 0), (mq if mh == H and H > 1 else 0), (1 if mq == Q and Q > 1 else 0)
-
-
-def _mask_is_simple(mask, owner, rl):
-    """True when every row of the additive mask is exactly 0 up to its last unmasked column and the dtype's minimum from there on
-    (causal masks, right padding): the FP8 attention kernel then applies the mask from the per-row extents without reading it.  One
-    comparison on the device and one host read per mask object, outside stream capture only (inside a capture: what is cached, else
-    False)."""
-    key = (mask.data_ptr(), owner._version, tuple(mask.shape), mask.stride())
-    hit = getattr(owner, "_qt_mask_simple", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    if torch.cuda.is_current_stream_capturing():
-        return False
-    C = mask.shape[-1]
-    rows = rl.numel()
-    cols = torch.arange(C, device=mask.device, dtype=torch.int32)
-    want = torch.where(cols[None, :] < rl[:, None], torch.zeros((), dtype=mask.dtype, device=mask.device),
-                       torch.full((), torch.finfo(mask.dtype).min, dtype=mask.dtype, device=mask.device))
-    simple = bool(torch.equal(mask.reshape(rows, C), want))
-    owner._qt_mask_simple = (key, simple)
-    return simple
 
 
 def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p, fq_v, value, mask_owner=None):
@@ -842,13 +824,13 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
     mask, msb, msh, msq = mk
     L = _native.lib()
     st = _stream_ptr(query)
-    rl_ptr, lsb, lsh, lsq, simple = None, 0, 0, 0, False
+    rl_ptr, lsb, lsh, lsq, irregular_ptr = None, 0, 0, 0, None
     if mask is not None:
         live = _mask_row_live(mask, attention_mask, B, H, Q, C, st)
         if live is not None:
             rl, lsb, lsh, lsq = live
             rl_ptr = rl.data_ptr()
-            simple = _mask_is_simple(mask, attention_mask, rl)
+            irregular_ptr = rl_ptr + 4 * (rl.numel() - 1)    # 0: every row is "zeros, then the minimum" and the mask is not read
 
     def codes(t, fq, t8, rows):
         if t8 is not None:
@@ -875,7 +857,7 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
     fq_o = consumer_fq(proj) if (proj is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0") else None
     out8 = torch.empty((B, Q, H, D), dtype=torch.uint8, device=query.device) if fq_o is not None else None
     _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 1 if fmt.p0 == 2 else 0,
-                                     mask.data_ptr() if mask is not None else None, msb, msh, msq, rl_ptr, lsb, lsh, lsq, int(simple),
+                                     mask.data_ptr() if mask is not None else None, msb, msh, msq, rl_ptr, lsb, lsh, lsq, 0, irregular_ptr,
                                      out.data_ptr(), out8.data_ptr() if out8 is not None else None,
                                      ctypes.byref(fq_o._qt_format) if fq_o is not None else None, B, H, Q, C, D, float(scaling), st),
                   "qt_attention_fp8")

@@ -58,7 +58,7 @@ def main():
 
         def core(with_live=True):
             _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 0, mp, 0, 0, S if mask is not None else 0,
-                                             live.data_ptr() if (live is not None and with_live) else None, 0, 0, 1, int(simple and with_live), out.data_ptr(), None, None, B, H, S, S,
+                                             live.data_ptr() if (live is not None and with_live) else None, 0, 0, 1, int(simple and with_live), None, out.data_ptr(), None, None, B, H, S, S,
                                              D, scaling, st()), "attn")
 
         def one_launch():
