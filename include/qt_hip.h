@@ -408,6 +408,14 @@ int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t
                     uint16_t *q_out_dev, uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S,
                     long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt_q,
                     const qt_format *fmt_k, void *stream);
+/* The same with the codes mandatory and the bf16 outputs optional (both or neither: the codes decode to exactly those values, so a
+ * consumer that multiplies codes needs nothing else), and -- v_dev non-NULL -- qt_value_codes_t (below: the attention kernel's fq_v
+ * call on the value projection, [B][Hk][S][D] by element strides, D = 64 or 128 contiguous, S % 128 == 0) in the SAME launch: the two
+ * jobs are independent and each alone is too small to fill the chip. */
+int qt_rope_fq_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
+                     uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S, long Hq, long Hk, long D,
+                     long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, const uint16_t *v_dev,
+                     uint8_t *vt8_dev, long v_stride_b, long v_stride_h, long v_stride_k, const qt_format *fmt_v, void *stream);
 
 /* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
  * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose

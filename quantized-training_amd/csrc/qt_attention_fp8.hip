@@ -24,6 +24,7 @@
 
 #include "../../include/qt_hip.h"
 #include "qt_device.h"
+#include "qt_value_codes.h"
 #include "qt_formats.h"
 
 namespace {
@@ -576,29 +577,12 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     }
 }
 
-// fq_v(V) as FP8 codes, transposed to [d][key] with the keys of every 128-block permuted into the k-slot order of the P.V instruction
-// (slot 16 g + 4 t + e <-> key 16 t + 4 g + e inside each half of 64).  One workgroup per (batch * head, key block).
+// fq_v(V) as FP8 codes in the layout the P.V instruction wants: qt_value_codes.h.  One workgroup per (batch * head, key block).
 template <bool E5M2, int D>
 __global__ __launch_bounds__(256) void value_codes_t_kernel(const uint16_t *v, uint8_t *vt8, int H, long Sk, long sb, long sh, long sk,
                                                             qt_format fmt) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[D * kBlock];
-    const int t = threadIdx.x, kb = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
-#pragma unroll
-    for (int it = 0; it < D / 16; ++it) {
-        const int vi = it * 256 + t, key = vi / (D / 8), dv = vi % (D / 8);
-        const uint4 in = *(const uint4 *)(v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8);
-        uint32_t o[4] = {in.x, in.y, in.z, in.w};
-        const uint2 codes = fq8_hw_vec8<E5M2>(o, fmt);
-        const int p = (key & 64) | (((key >> 2) & 3) << 4) | (((key >> 4) & 3) << 2) | (key & 3);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tile[(dv * 8 + j) * kBlock + p] = (uint8_t)((j < 4 ? codes.x >> (8 * j) : codes.y >> (8 * (j - 4))) & 0xFFu);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < D / 32; ++it) {
-        const int ci = it * 256 + t, d = ci >> 3, ch = ci & 7;
-        *(uint4 *)(vt8 + ((long)bh * D + d) * Sk + (long)kb * kBlock + ch * 16) = *(const uint4 *)(tile + d * kBlock + ch * 16);
-    }
+    value_codes_block<E5M2, D>(tile, v, vt8, (int)blockIdx.x, (long)blockIdx.y, H, Sk, sb, sh, sk, fmt);
 }
 
 int status() {

@@ -12,6 +12,7 @@
 #include "../../include/qt_hip.h"
 #include "qt_device.h"
 #include "qt_formats.h"
+#include "qt_value_codes.h"
 
 namespace {
 
@@ -214,7 +215,7 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, uint32_t b, u
                 out[j] = (r0 >> 16) | (r1 & 0xFFFF0000u);
             }
         }
-        *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};
+        if (a.r.y) *(uint4 *)(a.r.y + o * 8) = uint4{out[0], out[1], out[2], out[3]};     // NULL: codes only (they decode to these values)
     }
 }
 
@@ -224,6 +225,33 @@ __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k
         const uint32_t b = (uint32_t)(bs / (size_t)q.r.S), s = (uint32_t)(bs - (size_t)b * (size_t)q.r.S);
         rope_fq_token(q, b, s, bs);
         rope_fq_token(k, b, s, bs);
+    }
+}
+
+// The rotary kernel and the attention kernel's value-code pass (qt_value_codes.h) in ONE launch: both read slices of the q / k / v
+// projections' product, neither depends on the other, and each alone is too small to fill the chip (11 us + 8 us back to back).
+// Workgroups [0, rope_blocks) walk the tokens, the rest take one (batch * head, block of 128 keys) each.
+struct ValueArgs {
+    const uint16_t *v;
+    uint8_t *vt8;
+    long sb, sh, sk, Sk;
+    int H, nkb;
+    qt_format fmt;
+};
+
+template <bool VE5M2, int VD>
+__global__ __launch_bounds__(256) void rope_fq_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueArgs v, unsigned rope_blocks) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[VD * 128];
+    if (blockIdx.x < rope_blocks) {
+        const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;
+        for (size_t bs = blockIdx.x; bs < tokens; bs += rope_blocks) {
+            const uint32_t b = (uint32_t)(bs / (size_t)q.r.S), s = (uint32_t)(bs - (size_t)b * (size_t)q.r.S);
+            rope_fq_token(q, b, s, bs);
+            rope_fq_token(k, b, s, bs);
+        }
+    } else {
+        const unsigned vb = blockIdx.x - rope_blocks;
+        value_codes_block<VE5M2, VD>(tile, v.v, v.vt8, (int)(vb % (unsigned)v.nkb), (long)(vb / (unsigned)v.nkb), v.H, v.Sk, v.sb, v.sh, v.sk, v.fmt);
     }
 }
 
@@ -498,11 +526,13 @@ int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, cons
     return launch_status();
 }
 
-int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
-                    uint16_t *k_out, uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D,
-                    long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, void *stream) {
+static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,
+                          uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                          const qt_format *fmt_q, const qt_format *fmt_k, bool need_values, const uint16_t *v, uint8_t *vt8, long v_sb, long v_sh,
+                          long v_sk, const qt_format *fmt_v, void *stream) {
     if (B * S * D == 0) return QT_OK;
-    if (!q || !k || !cos || !sin || !q_out || !k_out || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
+    if (!q || !k || !cos || !sin || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
+    if (need_values ? (!q_out || !k_out) : (!q_out8 || !k_out8 || (q_out == nullptr) != (k_out == nullptr))) return QT_ERR_BAD_ARG;
     if (fmt_q->kind != QT_FMT_FP_SAT || fmt_k->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
         return QT_ERR_UNALIGNED;
@@ -516,8 +546,42 @@ int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, c
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
     size_t blocks = (size_t)B * (size_t)S;                                // one workgroup per token
     if (blocks > 256 * 64) blocks = 256 * 64;
-    rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak);
+    hipStream_t st = (hipStream_t)stream;
+    if (!v) {
+        rope_fq_kernel<<<(unsigned)blocks, 256, 0, st>>>(aq, ak);
+        return launch_status();
+    }
+    // the value job: v is [B][Hk][S][D] by strides, D contiguous; vt8 [B][Hk][D][S]
+    if (!vt8 || !fmt_v || fmt_v->kind != QT_FMT_FP_SAT || (!is_e5m2(fmt_v) && !is_e4m3(fmt_v)) || (D != 64 && D != 128) || S % 128 != 0 ||
+        B * Hk > 65535)
+        return QT_ERR_BAD_ARG;
+    if ((((uintptr_t)v | (uintptr_t)vt8) & 15u) || ((v_sb | v_sh | v_sk) & 7)) return QT_ERR_UNALIGNED;
+    ValueArgs av{v, vt8, v_sb, v_sh, v_sk, S, (int)Hk, (int)(S / 128), *fmt_v};
+    const unsigned total = (unsigned)blocks + (unsigned)(B * Hk * (S / 128));
+    const bool ve5 = is_e5m2(fmt_v);
+    if (D == 128) {
+        if (ve5) rope_fq_value_kernel<true, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+        else rope_fq_value_kernel<false, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+    } else {
+        if (ve5) rope_fq_value_kernel<true, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+        else rope_fq_value_kernel<false, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+    }
     return launch_status();
+}
+
+int qt_rope_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out,
+                    uint16_t *k_out, uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D,
+                    long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, void *stream) {
+    return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, true, nullptr,
+                          nullptr, 0, 0, 0, nullptr, stream);
+}
+
+int qt_rope_fq_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,
+                     uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                     const qt_format *fmt_q, const qt_format *fmt_k, const uint16_t *v, uint8_t *vt8, long v_stride_b, long v_stride_h,
+                     long v_stride_k, const qt_format *fmt_v, void *stream) {
+    return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, false, v, vt8,
+                          v_stride_b, v_stride_h, v_stride_k, fmt_v, stream);
 }
 
 }  // extern "C"

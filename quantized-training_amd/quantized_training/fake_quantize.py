@@ -130,6 +130,15 @@ def handover_valid(t):
     return getattr(t, "_qt_ver", None) == t._version
 
 
+def materialize_lazy(t):
+    """A producer that knew its consumer multiplies FP8 codes wrote ONLY the codes of fq(t) (t._qt_lazy; model_fusions.rope_fq).  The
+    fake-quantized values are exactly what the codes decode to, so whoever asks for them after all gets them here."""
+    if t.__dict__.get("_qt_lazy", False):
+        t.copy_(t._qt_fp8.to(t.dtype))
+        t._qt_lazy = False
+        t._qt_ver = t._version
+
+
 def _stream_ptr(t):
     """Current stream of the tensor's device for the native call that follows; that call runs with the tensor's device
     current (`_native.note_device`), so `model.to("cuda:1")` or a `dispatch_model` placement needs no `set_device`."""
@@ -632,6 +641,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             # the kernel that produced X already applied this fake-quantizer (and attached X._qt_fp8): the call the
             # reference issues here is satisfied by that fused computation, counted once
             _Stats.add(X.numel())
+            materialize_lazy(X)
             return X
         if (done_by is not None and self._emit_fp8 and isinstance(done_by, FusedAmaxObsFakeQuantize) and handover_valid(X)
                 and getattr(X, "_qt_fp8", None) is not None and X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous()

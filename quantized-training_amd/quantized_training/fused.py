@@ -325,6 +325,10 @@ class SiblingGroup:
         return self.bias[1]
 
 
+def value_key(value):
+    return (value.data_ptr(), value._version, tuple(value.shape), value.stride())
+
+
 def _origin_key(x):
     o = getattr(x, "_qt_origin", None)
     if o is not None:
@@ -834,7 +838,10 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
 
     def codes(t, fq, t8, rows):
         if t8 is not None:
-            fq(t)                                            # hand-over: counted by the fake-quantizer itself
+            # hand-over, counted as the fake-quantizer's own forward would (calling it would also decode codes-only tensors, see
+            # model_fusions.rope_fq: nothing here reads the bf16 values)
+            fq.__dict__["_qt_calls"] = fq.__dict__.get("_qt_calls", 0) + 1
+            STATS.add(t.numel())
             return t8
         t8 = torch.empty((B, H, rows, D), dtype=torch.uint8, device=t.device)
         _native.check(L.qt_fake_quant_rows_bf16_fp8(t.data_ptr(), None, t8.data_ptr(), B, H, rows, D, t.stride(0), t.stride(1), t.stride(2),
@@ -844,10 +851,14 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
 
     q8, k8 = codes(query, fq_q, q8, Q), codes(key, fq_k, k8, C)
     fmt = fq_v._qt_format
-    vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)
-    _native.check(L.qt_value_codes_t(value.data_ptr(), vt8.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2),
-                                     ctypes.byref(fmt), st), "qt_value_codes_t")
-    STATS.add(value.numel())                                 # fq_v, evaluated by the pass above
+    early = attn.__dict__.pop("_qt_vt8", None)
+    if early is not None and early[0] == value_key(value) and early[1] is fq_v:
+        vt8 = early[2]                                       # written by the launch that carried the rotary kernel (model_fusions.rope_fq)
+    else:
+        vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)
+        _native.check(L.qt_value_codes_t(value.data_ptr(), vt8.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2),
+                                         ctypes.byref(fmt), st), "qt_value_codes_t")
+    STATS.add(value.numel())                                 # fq_v, evaluated by that pass
     STATS.add(B * H * Q * C)                                 # fq_p, evaluated inside the kernel
     out = torch.empty((B, Q, H, D), dtype=torch.bfloat16, device=query.device)
     # the output projection's stateless FP8 input fake-quantizer rides on the epilogue (as model_fusions.attention_output does for the

@@ -236,19 +236,36 @@ def rope(q, k, cos, sin):
     return q_out.transpose(1, 2), k_out.transpose(1, 2)
 
 
-def rope_fq(q, k, cos, sin, fq_q, fq_k):
+def rope_fq(q, k, cos, sin, fq_q, fq_k, value_job=None):
     """Rotary embedding with qk_matmul's two input fake-quantizers applied in the same pass; outputs are contiguous
-    [B, H, S, D] (the layout those hooks write) and marked as done for fq_q / fq_k."""
+    [B, H, S, D] (the layout those hooks write) and marked as done for fq_q / fq_k.
+
+    value_job = (attn, value, fq_v), set when the FP8 attention kernel is what will consume these tensors (_fp8_attention_plan): the
+    launch then also carries that kernel's value-code pass (qt_rope_fq_value), and writes the FP8 codes ONLY -- the kernel multiplies
+    codes; should anything else ask for the bf16 values after all (the fake-quantizers' hand-over is the one door to them), they are
+    decoded from the codes then, exactly (fake_quantize.materialize_lazy)."""
     B, Hq, S, D = q.shape
     Hk = k.shape[1]
     q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
     k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
     q8 = torch.empty((B, Hq, S, D), dtype=torch.uint8, device=q.device)
     k8 = torch.empty((B, Hk, S, D), dtype=torch.uint8, device=k.device)
-    _native.check(_native.lib().qt_rope_fq_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                q_out.data_ptr(), k_out.data_ptr(), q8.data_ptr(), k8.data_ptr(), B, S, Hq,
-                                                Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fq_q._qt_format),
-                                                ctypes.byref(fq_k._qt_format), _stream_ptr(q)), "qt_rope_fq_bf16")
+    if value_job is None:
+        _native.check(_native.lib().qt_rope_fq_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                    q_out.data_ptr(), k_out.data_ptr(), q8.data_ptr(), k8.data_ptr(), B, S, Hq,
+                                                    Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fq_q._qt_format),
+                                                    ctypes.byref(fq_k._qt_format), _stream_ptr(q)), "qt_rope_fq_bf16")
+    else:
+        from . import fused
+        attn, value, fq_v = value_job
+        vt8 = torch.empty((B, Hk, D, S), dtype=torch.uint8, device=q.device)
+        _native.check(_native.lib().qt_rope_fq_value(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), None, None, q8.data_ptr(),
+                                                     k8.data_ptr(), B, S, Hq, Hk, D, _row_stride(q), _row_stride(k),
+                                                     ctypes.byref(fq_q._qt_format), ctypes.byref(fq_k._qt_format), value.data_ptr(),
+                                                     vt8.data_ptr(), value.stride(0), value.stride(1), value.stride(2),
+                                                     ctypes.byref(fq_v._qt_format), _stream_ptr(q)), "qt_rope_fq_value")
+        attn.__dict__["_qt_vt8"] = (fused.value_key(value), fq_v, vt8)
+        q_out._qt_lazy = k_out._qt_lazy = True               # bf16 values not written: see the docstring
     q_out._qt_fq_done_by = fq_q
     q_out._qt_ver = q_out._version
     k_out._qt_fq_done_by = fq_k
@@ -384,6 +401,7 @@ _CURRENT_ATTN = []
 
 def _attn_enter(module, args, kwargs):
     _CURRENT_ATTN.append(module)
+    module.__dict__["_qt_cacheless"] = kwargs.get("past_key_values") is None and kwargs.get("past_key_value") is None
 
 
 def _attn_exit(module, args, kwargs, output):
@@ -564,6 +582,37 @@ def _bind(module, fn):
 _ROPE_PATCHED = {"done": False}
 
 
+def _fp8_attention_plan(attn, q, qk_fqs):
+    """(attn, value, fq_v) when the attention core of this call will be qt_attention_fp8 as far as can be told here -- the rotary
+    kernel's outputs go nowhere else (no KV cache), the four fake-quantizers are stateless FP8 ones of one format, the shapes are the
+    kernel's, and the value projection is the q / k / v sibling group's slice (so it exists already) -- else None."""
+    if (os.environ.get("QT_ROPE_VALUE_LAUNCH", "1") == "0" or os.environ.get("QT_FP8_ATTENTION_KERNEL", "1") == "0"
+            or os.environ.get("QT_FP8_ATTENTION", "1") == "0" or os.environ.get("QT_FUSED_ATTENTION", "auto") == "0"
+            or not attn.__dict__.get("_qt_cacheless", False)):
+        return None
+    vproj = getattr(attn, "v_proj", None)
+    group = vproj.__dict__.get("_qt_sibling_group") if vproj is not None else None
+    av = getattr(attn, "av_matmul", None)
+    holder = getattr(av, "activation_pre_process", None) if av is not None else None
+    if (group is None or group.stash is None or holder is None or set(holder.keys()) != {"0", "1"} or vproj not in group.layers
+            or len(av._forward_pre_hooks) != 1 or av._forward_hooks):
+        return None
+    fqs = (*qk_fqs, holder["0"], holder["1"])
+    if not all(isinstance(f, FusedAmaxObsFakeQuantize) and f.producer_fusable() for f in fqs) or len({f._qt_format.key() for f in fqs}) != 1:
+        return None
+    B, H, S, D = q.shape
+    Ns = [l.weight.shape[0] for l in group.layers]
+    idx = group.layers.index(vproj)
+    y = group.stash[1]
+    if D not in (64, 128) or S % 128 != 0 or S > 1024 or B * H > 65535 or Ns[idx] != H * D or y.shape[0] != B * S or not group.stash[2][idx]:
+        return None                                            # (grouped-query heads, other lengths: the ordinary order)
+    off = sum(Ns[:idx])
+    value = y[:, off:off + Ns[idx]].view(B, S, H, D).transpose(1, 2)
+    if value.dtype != torch.bfloat16 or any(st % 8 for st in value.stride()[:3]) or value.data_ptr() % 16:
+        return None
+    return attn, value, holder["1"]
+
+
 def _patch_rope():
     """HF's LlamaAttention.forward calls the module-level apply_rotary_pos_emb; route it through the fused kernel when
     the tensors are the layout it produces ([B, S, H, D] buffers seen as [B, H, S, D], cos / sin [B, S, D])."""
@@ -588,7 +637,7 @@ def _patch_rope():
             if _CURRENT_ATTN and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0":
                 fqs = _qk_fqs(_CURRENT_ATTN[-1])
                 if fqs is not None:
-                    return rope_fq(q, k, cos, sin, *fqs)
+                    return rope_fq(q, k, cos, sin, *fqs, value_job=_fp8_attention_plan(_CURRENT_ATTN[-1], q, fqs))
             return rope(q, k, cos, sin)
         return original(q, k, cos, sin, unsqueeze_dim)
 

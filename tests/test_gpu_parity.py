@@ -1071,6 +1071,47 @@ def test_rotary_fused_with_qk_fake_quant(nv):
         assert torch.equal(got_q._qt_fp8.float(), got_q.float()) and torch.equal(got_k._qt_fp8.float(), got_k.float())
 
 
+def test_rotary_and_value_codes_in_one_launch(nv):
+    """qt_rope_fq_value (rotary + qk fake-quant, codes only, and the attention kernel's value-code pass in one launch) == qt_rope_fq_bf16's
+    codes and qt_value_codes_t's output, bit for bit; the bf16 tensors it leaves unwritten decode from the codes exactly when a
+    fake-quantizer's hand-over is asked for them."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    L = nv.lib()
+    g = torch.Generator(device="cuda").manual_seed(13)
+    for (B, H, S, D, dt) in ((1, 32, 1024, 128, "e4m3"), (2, 4, 256, 64, "e5m2")):
+        qkv = (torch.randn(B * S, 3 * H * D, device="cuda", generator=g) * 3).bfloat16()
+        qkv.view(torch.int16)[5, :7] = torch.tensor([0x7F80, -128, 0x7FC0, 0, -32768, 0x7F7F, 1], dtype=torch.int16, device="cuda")   # inf, -inf, nan, 0, -0, max, tiny
+        qkv.view(torch.int16)[6, 2 * H * D:2 * H * D + 4] = torch.tensor([0x7F80, 0x7FC0, -32768, 0x7F7F], dtype=torch.int16, device="cuda")
+        q = qkv[:, :H * D].view(B, S, H, D).transpose(1, 2)
+        k = qkv[:, H * D:2 * H * D].view(B, S, H, D).transpose(1, 2)
+        v = qkv[:, 2 * H * D:].view(B, S, H, D).transpose(1, 2)
+        ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+        cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+        fq_q, fq_k, fq_v = (FusedAmaxObsFakeQuantize(dtype=dt).cuda() for _ in range(3))
+
+        class Holder:                                            # stands in for the attention module the codes are left on
+            pass
+        attn = Holder()
+        with torch.no_grad():
+            want_q, want_k = mf.rope_fq(q, k, cos, sin, fq_q, fq_k)
+            got_q, got_k = mf.rope_fq(q, k, cos, sin, fq_q, fq_k, value_job=(attn, v, fq_v))
+        want_vt = torch.empty(B, H, D, S, dtype=torch.uint8, device="cuda")
+        nv.check(L.qt_value_codes_t(v.data_ptr(), want_vt.data_ptr(), B, H, S, D, v.stride(0), v.stride(1), v.stride(2),
+                                    ctypes.byref(fq_v._qt_format), stream()), "qt_value_codes_t")
+        assert torch.equal(attn._qt_vt8[2], want_vt)
+        assert torch.equal(got_q._qt_fp8.view(torch.uint8), want_q._qt_fp8.view(torch.uint8))
+        assert torch.equal(got_k._qt_fp8.view(torch.uint8), want_k._qt_fp8.view(torch.uint8))
+        assert got_q._qt_lazy and got_k._qt_lazy
+        with torch.no_grad():
+            assert fq_q(got_q) is got_q and fq_k(got_k) is got_k     # the hand-over decodes the codes
+        assert not got_q._qt_lazy and fq_q(got_q) is got_q
+        for got, want in ((got_q, want_q), (got_k, want_k)):
+            a, b = got.view(torch.int16), want.view(torch.int16)
+            nan = torch.isnan(want)
+            assert torch.equal(a[~nan], b[~nan]) and bool(torch.isnan(got)[nan].all())
+
+
 def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
     """rmsnorm_fq == the norm kernel followed by the consumer's pass, and a sibling consumer's pass over the already
     quantized tensor reproduces it (the stateless formats are idempotent), FP8 bytes included."""
