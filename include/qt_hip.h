@@ -391,6 +391,13 @@ int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t
  * as in qt_rmsnorm_fq8_bf16. */
 int qt_add_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
                         uint16_t *y_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt, void *stream);
+/* RMSNorm (residual_dev / sum_dev both NULL) or residual add + RMSNorm with the stateless E4M3 / E5M2 input fake-quantizers of ALL the
+ * Linears that consume the result (2 or 3: q, k, v -- gate, up) evaluated on it in the same launch: y = fq_0(result) as bf16, y8[i] =
+ * the FP8 codes of fq_i(result).  Each consumer's hook then hands its codes through instead of launching its own pass over the tensor
+ * (quantize.py:128-140 issues one call per consumer; this evaluates each of them where the tensor is in registers). */
+int qt_rmsnorm_consumers_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
+                              uint16_t *y_dev, long rows, long cols, float eps, int consumers, uint8_t *const *y8_dev,
+                              const qt_format *const *fmt, void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols,
                      size_t gate_row_stride, size_t up_row_stride, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:

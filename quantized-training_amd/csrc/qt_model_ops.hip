@@ -26,11 +26,21 @@ constexpr int kNormMaxVec = 8;        // 16-byte vectors per thread: rows up to 
 // FQ: 0 plain; 1 / 2 = the first consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result, which is
 // written as bf16 plus its FP8 code (producer-fused fake-quant, model_fusions.py)
 // ADD: the row is bf16(x + res) (the residual add in front of the norm, torch's rounding), also written to `sum`
-template <int FQ, bool ADD = false>
+// EXTRA: 1 or 2 further consumers of the result (k, v beside q; up beside gate): each one's own stateless E4M3 / E5M2 fake-quantizer is
+// evaluated on the unquantized result too and its FP8 codes written to its own buffer -- the calls their hooks would otherwise make
+// as separate launches over the tensor this kernel has in registers
+struct NormExtra {
+    uint2 *y8[2];
+    qt_format fmt[2];
+    int e5m2[2];
+};
+
+template <int FQ, bool ADD = false, int EXTRA = 0>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ w,
                                                                uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
                                                                uint2 *__restrict__ y8, qt_format fmt,
-                                                               const uint4 *__restrict__ res = nullptr, uint4 *__restrict__ sum = nullptr) {
+                                                               const uint4 *__restrict__ res = nullptr, uint4 *__restrict__ sum = nullptr,
+                                                               NormExtra extra = NormExtra{}) {
     __shared__ float s_part[kNormThreads / 64];
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
@@ -77,6 +87,11 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
             for (int j = 0; j < 4; ++j) {
                 const float h0 = rbf(bf_lo(q[j]) * r), h1 = rbf(bf_hi(q[j]) * r);
                 o[j] = pack_bf16x2(bf_lo(g[j]) * h0, bf_hi(g[j]) * h1);
+            }
+#pragma unroll
+            for (int e = 0; e < EXTRA; ++e) {
+                uint32_t t[4] = {o[0], o[1], o[2], o[3]};
+                extra.y8[e][row * (size_t)nvec + c] = extra.e5m2[e] ? fq8_hw_vec8<true>(t, extra.fmt[e]) : fq8_hw_vec8<false>(t, extra.fmt[e]);
             }
             if constexpr (FQ != 0) y8[row * (size_t)nvec + c] = fq8_hw_vec8<FQ == 2>(o, fmt);
             y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
@@ -380,6 +395,13 @@ int launch_status() {
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
+template <int FQ, bool ADD, int EXTRA>
+void launch_norm_consumers(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, uint8_t *y8,
+                                  long rows, int nvec, float inv, float eps, const qt_format &f, const NormExtra &ex, hipStream_t st) {
+    rmsnorm_kernel<FQ, ADD, EXTRA><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps,
+                                                                           (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, ex);
+}
+
 }  // namespace
 
 extern "C" {
@@ -430,6 +452,43 @@ int qt_add_rmsnorm_bf16(const uint16_t *x, const uint16_t *residual, const uint1
     if (fq == 2) rmsnorm_kernel<2, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
     else if (fq == 1) rmsnorm_kernel<1, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
     else rmsnorm_kernel<0, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum);
+    return launch_status();
+}
+
+int qt_rmsnorm_consumers_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, long rows,
+                              long cols, float eps, int consumers, uint8_t *const *y8, const qt_format *const *fmt, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !y || rows < 0 || cols < 0 || consumers < 2 || consumers > 3 || !y8 || !fmt || (residual != nullptr) != (sum != nullptr))
+        return QT_ERR_BAD_ARG;
+    int code[3] = {0, 0, 0};
+    for (int i = 0; i < consumers; ++i) {
+        if (!y8[i] || !fmt[i] || ((uintptr_t)y8[i] & 7u)) return QT_ERR_BAD_ARG;
+        code[i] = fp8_code_of(fmt[i]);
+        if (!code[i]) return QT_ERR_BAD_ARG;
+    }
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)sum | (uintptr_t)y) & 15u))
+        return QT_ERR_UNALIGNED;
+    NormExtra ex{};
+    for (int i = 1; i < consumers; ++i) {
+        ex.y8[i - 1] = (uint2 *)y8[i];
+        ex.fmt[i - 1] = *fmt[i];
+        ex.e5m2[i - 1] = code[i] == 2;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (int)(cols / 8);
+    const float inv = 1.0f / (float)cols;
+    const int key = (code[0] == 2 ? 4 : 0) | (residual ? 2 : 0) | (consumers == 3 ? 1 : 0);
+    switch (key) {
+        case 0: launch_norm_consumers<1, false, 1>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 1: launch_norm_consumers<1, false, 2>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 2: launch_norm_consumers<1, true, 1>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 3: launch_norm_consumers<1, true, 2>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 4: launch_norm_consumers<2, false, 1>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 5: launch_norm_consumers<2, false, 2>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        case 6: launch_norm_consumers<2, true, 1>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+        default: launch_norm_consumers<2, true, 2>(x, residual, weight, sum, y, y8[0], rows, nvec, inv, eps, *fmt[0], ex, st); break;
+    }
     return launch_status();
 }
 

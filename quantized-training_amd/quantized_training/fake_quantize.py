@@ -643,6 +643,19 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             _Stats.add(X.numel())
             materialize_lazy(X)
             return X
+        also = getattr(X, "_qt_also_done", None)
+        if also is not None and handover_valid(X):
+            # the producing kernel evaluated this fake-quantizer on its result as well (a norm with several consuming Linears,
+            # model_fusions._norm_with_consumers): X holds the fake-quantized values (one format for all the consumers), these are this
+            # call's own codes
+            for fq, x8 in also:
+                if fq is self:
+                    _Stats.add(X.numel())
+                    out = X.view(X.shape)
+                    out._qt_fp8 = x8
+                    out._qt_ver = out._version
+                    out._qt_origin = (X.data_ptr(), X._version, tuple(X.shape))
+                    return out
         if (done_by is not None and self._emit_fp8 and isinstance(done_by, FusedAmaxObsFakeQuantize) and handover_valid(X)
                 and getattr(X, "_qt_fp8", None) is not None and X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous()
                 and not (torch.is_grad_enabled() and X.requires_grad) and self.producer_fusable() and done_by.producer_fusable()

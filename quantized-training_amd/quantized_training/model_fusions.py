@@ -63,10 +63,36 @@ def rmsnorm(x, weight, eps):
     return y
 
 
+def _norm_with_consumers(x2, r2, weight, eps, fqs):
+    """One launch for (residual add +) RMSNorm and the input fake-quantizers of ALL the Linears consuming it (qt_rmsnorm_consumers_bf16):
+    returns (sum or None, y) where y = fq_0(result) carries the first consumer's codes as before and, for the others, their own codes
+    (`_qt_also_done`): their hooks hand those through (fake_quantize.py) instead of launching a pass each over the tensor."""
+    cols = x2.shape[-1]
+    n = len(fqs)
+    total = torch.empty_like(x2) if r2 is not None else None
+    y = torch.empty_like(x2)
+    y8 = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in y8])
+    fmts = (ctypes.c_void_p * n)(*[ctypes.addressof(f._qt_format) for f in fqs])
+    _native.check(_native.lib().qt_rmsnorm_consumers_bf16(
+        x2.data_ptr(), r2.data_ptr() if r2 is not None else None, weight.data_ptr(), total.data_ptr() if total is not None else None,
+        y.data_ptr(), x2.numel() // cols, cols, float(eps), n, ptrs, fmts, _stream_ptr(x2)), "qt_rmsnorm_consumers_bf16")
+    y._qt_fp8 = _fp8_view(y8[0], fqs[0])
+    y._qt_fq_done_by = fqs[0]
+    y._qt_also_done = [(f, _fp8_view(t, f)) for f, t in zip(fqs[1:], y8[1:])]
+    y._qt_ver = y._version
+    return total, y
+
+
 def rmsnorm_fq(x, weight, eps, fq):
-    """RMSNorm with `fq` (the first consumer's input fake-quantizer) applied to the result."""
+    """RMSNorm with `fq` applied to the result: the first consumer's input fake-quantizer, or the list of all consumers' (then one
+    launch evaluates them all, _norm_with_consumers)."""
     cols = x.shape[-1]
     x2 = x.contiguous()
+    if isinstance(fq, (list, tuple)):
+        if len(fq) > 1:
+            return _norm_with_consumers(x2, None, weight, eps, fq)[1]
+        fq = fq[0]
     y = torch.empty_like(x2)
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
     _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(),
@@ -80,9 +106,13 @@ def rmsnorm_fq(x, weight, eps, fq):
 
 def add_rmsnorm(x, residual, norm, fq=None):
     """(bf16(x + residual), RMSNorm of that sum) in one launch; with `fq` the norm result carries the first consumer's
-    fake-quant exactly as rmsnorm_fq's does."""
+    fake-quant exactly as rmsnorm_fq's does (a list: all consumers', as there)."""
     cols = x.shape[-1]
     x2, r2 = x.contiguous(), residual.contiguous()
+    if isinstance(fq, (list, tuple)):
+        if len(fq) > 1:
+            return _norm_with_consumers(x2, r2, norm.weight, norm.variance_epsilon, fq)
+        fq = fq[0]
     total = torch.empty_like(x2)
     y = torch.empty_like(x2)
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) if fq is not None else None
@@ -105,10 +135,10 @@ def _add_rmsnorm_or_none(x, residual, norm):
             or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()
             or os.environ.get("QT_FUSED_ADD_NORM", "1") == "0"):
         return None
-    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm))
+    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm, allow_all=True))
 
 
-def _norm_consumer_fq(norm):
+def _norm_consumer_fq(norm, allow_all=False):
     """The fake-quantizer the norm kernel may apply: every Linear fed by this norm must quantize its input with the
     same stateless format (then the first one's pass is fused here and the siblings', run on the already quantized
     tensor, reproduce it -- the formats are idempotent)."""
@@ -123,6 +153,8 @@ def _norm_consumer_fq(norm):
         g = f._qt_format
         if (g.kind, g.p0, g.p1, g.flo, g.fhi) != (f0.kind, f0.p0, f0.p1, f0.flo, f0.fhi):
             return None
+    if allow_all and 2 <= len(fqs) <= 3 and len({id(f) for f in fqs}) == len(fqs) and os.environ.get("QT_NORM_ALL_CONSUMERS", "1") != "0":
+        return fqs                                   # all of them in the norm's launch (_norm_with_consumers)
     return fqs[0]
 
 
@@ -432,7 +464,7 @@ def _rmsnorm_forward(self, hidden_states):
     w = self.weight
     if (_eligible(hidden_states, w) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384
             and hidden_states.numel() > 0 and w.is_contiguous()):
-        fq = _norm_consumer_fq(self)
+        fq = _norm_consumer_fq(self, allow_all=True)
         if fq is not None:
             return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq)
         return rmsnorm(hidden_states, w, self.variance_epsilon)

@@ -1136,6 +1136,46 @@ def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
             assert torch.equal(sib_from_plain._qt_fp8.view(torch.uint8), sib_from_q._qt_fp8.view(torch.uint8))
 
 
+def test_rmsnorm_with_all_consumers_fake_quant(nv):
+    """One launch for the norm and the input fake-quantizers of all its consuming Linears (qt_rmsnorm_consumers_bf16), plain and with
+    the residual add: values and the first consumer's codes as rmsnorm_fq / add_rmsnorm with one fake-quantizer; every further
+    consumer's hand-over returns the codes its own pass over the tensor computes, counted once per call."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize, STATS
+    g = torch.Generator(device="cuda").manual_seed(22)
+    x = (torch.randn(1024, 4096, device="cuda", generator=g) * 50).bfloat16()
+    res = (torch.randn(1024, 4096, device="cuda", generator=g) * 50).bfloat16()
+    x.view(torch.int16)[3, :4] = torch.tensor([0x7F80, 0x7FC0, -32768, 0x7F7F], dtype=torch.int16, device="cuda")
+    w = (1 + 0.2 * torch.randn(4096, device="cuda", generator=g)).bfloat16()
+
+    class Norm:
+        weight, variance_epsilon = w, 1e-5
+    for dtype in ("e4m3", "e5m2"):
+        for n in (2, 3):
+            fqs = [FusedAmaxObsFakeQuantize(dtype=dtype).cuda() for _ in range(n)]
+            loners = [FusedAmaxObsFakeQuantize(dtype=dtype).cuda() for _ in range(n)]
+            for f in fqs + loners:
+                f._emit_fp8 = "both"
+            with torch.no_grad():
+                for with_res in (False, True):
+                    if with_res:
+                        want_sum, want = mf.add_rmsnorm(x, res, Norm, loners[0])
+                        got_sum, got = mf.add_rmsnorm(x, res, Norm, fqs)
+                        assert torch.equal(want_sum.view(torch.int16), got_sum.view(torch.int16))
+                    else:
+                        want, got = mf.rmsnorm_fq(x, w, 1e-5, loners[0]), mf.rmsnorm_fq(x, w, 1e-5, fqs)
+                    ok = ~torch.isnan(want)
+                    assert torch.equal(want.view(torch.int16)[ok], got.view(torch.int16)[ok]) and bool(torch.isnan(got)[~ok].all())
+                    assert torch.equal(want._qt_fp8.view(torch.uint8), got._qt_fp8.view(torch.uint8))
+                    STATS.reset()
+                    assert fqs[0](got) is got
+                    for f, lone in zip(fqs[1:], loners[1:]):
+                        mine, theirs = f(got), lone(want)                     # theirs: the separate pass over the quantized tensor
+                        assert mine is not got and mine.data_ptr() == got.data_ptr()
+                        assert torch.equal(mine._qt_fp8.view(torch.uint8), theirs._qt_fp8.view(torch.uint8))
+                    assert (STATS.calls, STATS.elements) == (2 * n - 1, (2 * n - 1) * x.numel())
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(1024, 4096, 4096, False), (256, 768, 3072, True), (1000, 1008, 512, True)])
 def test_lt_fp8_gemm_matches_scaled_mm(nv, M, N, K, bias):
     """qt_fp8_gemm (hipBLASLt, measured algorithm choice) against the exact product of the FP8 operands; bf16 output.
