@@ -384,6 +384,11 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint1
 int qt_layernorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, const uint16_t *bias_dev,
                       uint16_t *y_dev, uint16_t *yq_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt,
                       void *stream);
+/* qt_layernorm_bf16 with the stateless E4M3 / E5M2 input fake-quantizers of ALL the Linears consuming the result (2 or 3: q, k, v)
+ * evaluated in the same launch: yq = fq_0(y) as bf16, y8[i] = the FP8 codes of fq_i(y) (as qt_rmsnorm_consumers_bf16). */
+int qt_layernorm_consumers_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, const uint16_t *bias_dev,
+                                uint16_t *y_dev, uint16_t *yq_dev, long rows, long cols, float eps, int consumers, uint8_t *const *y8_dev,
+                                const qt_format *const *fmt, void *stream);
 int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t n, const qt_format *fmt, void *stream);
 /* The residual add of a LLaMA block (modeling_llama.py LlamaDecoderLayer.forward: `hidden = residual + hidden`) absorbed into
  * the RMSNorm behind it: sum = bf16(x + residual) (written out: it is the next residual), y = RMSNorm(sum) as

@@ -284,6 +284,8 @@ struct LnArgs {
     int nvec;
     float inv_cols, eps;
     qt_format fmt;
+    int n_extra;             // further consumers of the result (k, v beside q): each one's own fake-quantizer is evaluated too,
+    NormExtra extra;         // its FP8 codes written to its own buffer (as rmsnorm_kernel's EXTRA)
 };
 
 // G threads per row (64: one wavefront, rows up to 1024 elements keep <= 2 vectors per lane; 256: the whole workgroup)
@@ -352,6 +354,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
                                    bf_hi(g[j]) * (rstd * (bf_hi(q[j]) - mean)) + bf_hi(h[j]));
             a.y[base + c] = uint4{o[0], o[1], o[2], o[3]};
             if constexpr (FQ != 0) {
+                for (int e = 0; e < a.n_extra; ++e) {
+                    uint32_t t[4] = {o[0], o[1], o[2], o[3]};
+                    a.extra.y8[e][base + c] = a.extra.e5m2[e] ? fq8_hw_vec8<true>(t, a.extra.fmt[e]) : fq8_hw_vec8<false>(t, a.extra.fmt[e]);
+                }
                 const uint2 codes = fq8_hw_vec8<FQ == 2>(o, a.fmt);
                 a.yq[base + c] = uint4{o[0], o[1], o[2], o[3]};
                 a.y8[base + c] = codes;
@@ -492,6 +498,8 @@ int qt_rmsnorm_consumers_bf16(const uint16_t *x, const uint16_t *residual, const
     return launch_status();
 }
 
+static int launch_layernorm_any(const LnArgs &a, int fq, bool with_residual, void *stream);
+
 int qt_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, const uint16_t *bias, uint16_t *y,
                       uint16_t *yq, uint8_t *y8, long rows, long cols, float eps, const qt_format *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
@@ -502,8 +510,38 @@ int qt_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_
         (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)yq) & 15u) || ((uintptr_t)y8 & 7u))
         return QT_ERR_UNALIGNED;
     LnArgs a{(const uint4 *)x, (const uint4 *)residual, (const uint4 *)weight, (const uint4 *)bias, (uint4 *)y, (uint4 *)yq, (uint2 *)y8,
-             rows, (int)(cols / 8), 1.0f / (float)cols, eps, fmt && fq ? *fmt : qt_format{}};
+             rows, (int)(cols / 8), 1.0f / (float)cols, eps, fmt && fq ? *fmt : qt_format{}, 0, NormExtra{}};
+    return launch_layernorm_any(a, fq, residual != nullptr, stream);
+}
+
+int qt_layernorm_consumers_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, const uint16_t *bias, uint16_t *y,
+                                uint16_t *yq, long rows, long cols, float eps, int consumers, uint8_t *const *y8,
+                                const qt_format *const *fmt, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !bias || !y || !yq || rows < 0 || cols < 0 || consumers < 2 || consumers > 3 || !y8 || !fmt) return QT_ERR_BAD_ARG;
+    int code[3] = {0, 0, 0};
+    for (int i = 0; i < consumers; ++i) {
+        if (!y8[i] || !fmt[i] || ((uintptr_t)y8[i] & 7u)) return QT_ERR_BAD_ARG;
+        code[i] = fp8_code_of(fmt[i]);
+        if (!code[i]) return QT_ERR_BAD_ARG;
+    }
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)yq) & 15u))
+        return QT_ERR_UNALIGNED;
+    LnArgs a{(const uint4 *)x, (const uint4 *)residual, (const uint4 *)weight, (const uint4 *)bias, (uint4 *)y, (uint4 *)yq, (uint2 *)y8[0],
+             rows, (int)(cols / 8), 1.0f / (float)cols, eps, *fmt[0], consumers - 1, NormExtra{}};
+    for (int i = 1; i < consumers; ++i) {
+        a.extra.y8[i - 1] = (uint2 *)y8[i];
+        a.extra.fmt[i - 1] = *fmt[i];
+        a.extra.e5m2[i - 1] = code[i] == 2;
+    }
+    return launch_layernorm_any(a, code[0], residual != nullptr, stream);
+}
+
+static int launch_layernorm_any(const LnArgs &a, int fq, bool with_residual, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    const long rows = a.rows;
+    const bool residual = with_residual;
     if (a.nvec <= 128) {
         const unsigned blocks = (unsigned)((rows + 3) / 4);
         if (residual) launch_layernorm<64, true>(a, fq, blocks, st);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "qt_rmsnorm_consumers_bf16": (c_int, [_P, _P, _P, _P, _P, c_long, c_long, c_float, c_int, _P, _P, _P]),
     "qt_add_rmsnorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, _FMT, _P]),
     "qt_layernorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_long, c_long, c_float, _FMT, _P]),
+    "qt_layernorm_consumers_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, c_int, _P, _P, _P]),
     "qt_gelu_bf16": (c_int, [_P, _P, _P, c_size_t, _FMT, _P]),
     "qt_silu_mul_bf16": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_size_t, c_size_t, _P]),
     "qt_fake_quant_bf16_fp8_multi": (c_int, [_P, _P, c_int, _P, _FMT, _P]),

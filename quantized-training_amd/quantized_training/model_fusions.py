@@ -318,6 +318,22 @@ def layernorm(x, norm, residual=None, fq=None):
     x2 = x.contiguous()
     r2 = residual.contiguous() if residual is not None else None
     y = torch.empty_like(x2)
+    if isinstance(fq, (list, tuple)):
+        if len(fq) > 1:
+            # every consuming Linear's input fake-quantizer in this launch (qt_layernorm_consumers_bf16): each then finds its own codes
+            # (and the shared fake-quantized values) waiting for its next call
+            fqs, n = fq, len(fq)
+            yq = torch.empty_like(x2)
+            y8s = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
+            ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in y8s])
+            fmts = (ctypes.c_void_p * n)(*[ctypes.addressof(f._qt_format) for f in fqs])
+            _native.check(_native.lib().qt_layernorm_consumers_bf16(
+                x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
+                yq.data_ptr(), x2.numel() // cols, cols, float(norm.eps), n, ptrs, fmts, _stream_ptr(x2)), "qt_layernorm_consumers_bf16")
+            for f, t in zip(fqs, y8s):
+                f.expect_prequantized(y, _fp8_view(t, f), replacement=yq)
+            return y
+        fq = fq[0]
     yq = y8 = None
     if fq is not None:
         yq = torch.empty_like(x2)
@@ -363,12 +379,12 @@ def add_layernorm_or_none(block, hidden, residual):
     norm = getattr(block, "LayerNorm", None)
     if norm is None or add is None or _hooked(add) or not _layernorm_ok(norm, hidden, residual):
         return None
-    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm))
+    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm, allow_all=True))
 
 
 def _layernorm_forward(self, x):
     if _layernorm_ok(self, x):
-        return layernorm(x, self, None, _norm_consumer_fq(self))
+        return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True))
     return self._qt_hf_forward(x)
 
 

@@ -1176,6 +1176,37 @@ def test_rmsnorm_with_all_consumers_fake_quant(nv):
                     assert (STATS.calls, STATS.elements) == (2 * n - 1, (2 * n - 1) * x.numel())
 
 
+def test_layernorm_with_all_consumers_fake_quant(nv):
+    """qt_layernorm_consumers_bf16: y, fq(y) and the first consumer's codes as the one-consumer kernel writes them; every consumer's next
+    call on y hands the shared fake-quantized values and ITS codes through (the codes a pass of its own over y computes)."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize, STATS
+    g = torch.Generator(device="cuda").manual_seed(23)
+    for cols in (768, 4096):
+        x = (torch.randn(512, cols, device="cuda", generator=g) * 5).bfloat16()
+        res = (torch.randn(512, cols, device="cuda", generator=g) * 5).bfloat16()
+        norm = torch.nn.LayerNorm(cols).cuda().bfloat16()
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.2 * torch.randn(cols, device="cuda", generator=g))
+            norm.bias.copy_(0.1 * torch.randn(cols, device="cuda", generator=g))
+        for dtype in ("e4m3", "e5m2"):
+            fqs = [FusedAmaxObsFakeQuantize(dtype=dtype).cuda() for _ in range(3)]
+            lone = FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+            for f in fqs + [lone]:
+                f._emit_fp8 = "both"
+            with torch.no_grad():
+                want_y = mf.layernorm(x, norm, res, lone)
+                want_q = lone(want_y)
+                got_y = mf.layernorm(x, norm, res, fqs)
+                assert torch.equal(want_y.view(torch.int16), got_y.view(torch.int16))
+                STATS.reset()
+                for f in fqs:
+                    out = f(got_y)
+                    assert torch.equal(out.view(torch.int16), want_q.view(torch.int16))
+                    assert torch.equal(out._qt_fp8.view(torch.uint8), want_q._qt_fp8.view(torch.uint8))
+                assert (STATS.calls, STATS.elements) == (3, 3 * x.numel())
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(1024, 4096, 4096, False), (256, 768, 3072, True), (1000, 1008, 512, True)])
 def test_lt_fp8_gemm_matches_scaled_mm(nv, M, N, K, bias):
     """qt_fp8_gemm (hipBLASLt, measured algorithm choice) against the exact product of the FP8 operands; bf16 output.
