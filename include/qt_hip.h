@@ -403,6 +403,12 @@ int qt_add_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, con
 int qt_rmsnorm_consumers_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
                               uint16_t *y_dev, long rows, long cols, float eps, int consumers, uint8_t *const *y8_dev,
                               const qt_format *const *fmt, void *stream);
+/* The window loss of the WikiText loop (examples/language_modeling/wikitext.py:146-158; transformers' ForCausalLMLoss) from the lm head's
+ * bf16 logits [batch][seq_len][vocab] (row_stride elements between positions): label of position s = labels[b][s + 1] (int64; none
+ * for the last position), cross entropy in fp32 with ignore_index, mean over the scored positions -> *loss_out (fp32, device).
+ * row_loss_scratch: batch * seq_len floats.  Deterministic (fixed summation order, no atomics). */
+int qt_causal_lm_loss_bf16(const uint16_t *logits_dev, const long long *labels_dev, long batch, long seq_len, long vocab, long row_stride,
+                           long long ignore_index, float *row_loss_scratch_dev, float *loss_out_dev, void *stream);
 int qt_silu_mul_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols,
                      size_t gate_row_stride, size_t up_row_stride, void *stream);
 /* qt_silu_mul_bf16 with the consumer's stateless E4M3 / E5M2 fake-quantizer (unit scale) applied on the way out:

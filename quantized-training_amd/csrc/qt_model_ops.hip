@@ -408,6 +408,99 @@ void launch_norm_consumers(const uint16_t *x, const uint16_t *residual, const ui
                                                                            (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, ex);
 }
 
+// ---- causal-LM loss of a window: logits -> mean NLL -------------------------------------------------------------------------
+// What the caller of the hot path computes from the lm head's bf16 logits (examples/language_modeling/wikitext.py:146-158 through
+// transformers' ForCausalLMLoss): logits.float(); label of position s = labels[s + 1] (the last position has none); cross entropy in
+// fp32 with ignore_index, mean over the scored positions.  torch runs that as a bf16 -> fp32 copy of the [S, V] logits, a softmax
+// kernel and a reduction (60 + 35 + 12 us at S 1024, V 32000); here one workgroup per position reads its row once (online maximum /
+// sum of exponentials per lane, combined across the workgroup), and a second one-workgroup kernel sums the rows in a fixed order --
+// deterministic, no atomics.
+__global__ __launch_bounds__(256) void nll_rows_kernel(const uint16_t *__restrict__ logits, const long long *__restrict__ labels, long S, long V,
+                                                       long row_stride, long long ignore_index, float *__restrict__ row_loss) {
+    __shared__ float s_m[4], s_s[4];
+    const long row = blockIdx.x, s_pos = row % S;
+    const long long lab = (s_pos + 1 < S) ? labels[row + 1] : ignore_index;
+    if (lab == ignore_index || lab < 0 || lab >= V) {                    // (uniform per workgroup)
+        if (threadIdx.x == 0) row_loss[row] = -1.0f;                     // marks "not scored": a loss is never negative
+        return;
+    }
+    const uint16_t *x = logits + row * row_stride;
+    float m = -INFINITY, sum = 0.0f;
+    const long nvec = V / 8;
+    for (long i = threadIdx.x; i < nvec; i += 256) {
+        const uint4 v = *(const uint4 *)(x + i * 8);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = bf_lo(q[j]);
+            f[2 * j + 1] = bf_hi(q[j]);
+        }
+        float vm = f[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) vm = fmaxf(vm, f[j]);
+        if (vm > m) {
+            sum *= __expf(m - vm);
+            m = vm;
+        }
+        if (m != -INFINITY) {                                            // (eight -inf logits in front of everything else add nothing)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += __expf(f[j] - m);
+        }
+    }
+    for (long c = nvec * 8 + threadIdx.x; c < V; c += 256) {             // a vocabulary that is not a multiple of 8
+        const float f = qt_bf2f(x[c]);
+        if (f > m) {
+            sum *= __expf(m - f);
+            m = f;
+        }
+        if (m != -INFINITY) sum += __expf(f - m);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float om = __shfl_xor(m, off, 64), os = __shfl_xor(sum, off, 64);
+        const float nm = fmaxf(m, om);
+        sum = (m == -INFINITY ? 0.0f : sum * __expf(m - nm)) + (om == -INFINITY ? 0.0f : os * __expf(om - nm));
+        m = nm;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_m[threadIdx.x >> 6] = m;
+        s_s[threadIdx.x >> 6] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), Ssum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ssum += s_m[i] == -INFINITY ? 0.0f : s_s[i] * __expf(s_m[i] - M);
+        row_loss[row] = (M + logf(Ssum)) - qt_bf2f(x[lab]);             // -log softmax(x)[label]
+    }
+}
+
+__global__ __launch_bounds__(256) void nll_mean_kernel(const float *__restrict__ row_loss, long rows, float *__restrict__ out) {
+    __shared__ float s_sum[256];
+    __shared__ int s_cnt[256];
+    float acc = 0.0f;
+    int cnt = 0;
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        const float v = row_loss[r];
+        if (v >= 0.0f || v != v) {                                        // scored (a NaN loss stays a NaN mean)
+            acc += v;
+            ++cnt;
+        }
+    }
+    s_sum[threadIdx.x] = acc;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s_sum[0] / (float)s_cnt[0];             // 0 / 0 = NaN when nothing is scored, as torch
+}
+
 }  // namespace
 
 extern "C" {
@@ -679,6 +772,18 @@ int qt_rope_fq_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, 
                      long v_stride_k, const qt_format *fmt_v, void *stream) {
     return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, false, v, vt8,
                           v_stride_b, v_stride_h, v_stride_k, fmt_v, stream);
+}
+
+int qt_causal_lm_loss_bf16(const uint16_t *logits, const long long *labels, long batch, long seq_len, long vocab, long row_stride,
+                           long long ignore_index, float *row_loss_scratch, float *loss_out, void *stream) {
+    if (!logits || !labels || !row_loss_scratch || !loss_out || batch < 1 || seq_len < 1 || vocab < 1 || row_stride < vocab) return QT_ERR_BAD_ARG;
+    if (((uintptr_t)logits & 15u) || (row_stride & 7)) return QT_ERR_UNALIGNED;
+    const long rows = batch * seq_len;
+    if (rows > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    nll_rows_kernel<<<(unsigned)rows, 256, 0, st>>>(logits, labels, seq_len, vocab, row_stride, ignore_index, row_loss_scratch);
+    nll_mean_kernel<<<1, 256, 0, st>>>(row_loss_scratch, rows, loss_out);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -85,6 +85,7 @@ SIGNATURES = {
                                     _FMT, _P, _P, _P, _P]),
     "qt_quantize_mx_bf16": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, c_int, _P, c_int, _P]),
     "qt_quantize_mx_f32": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_size_t, c_int, _FMT, _P, c_float, c_int, _P, c_int, _P]),
+    "qt_causal_lm_loss_bf16": (c_int, [_P, _P, c_long, c_long, c_long, c_long, ctypes.c_longlong, _P, _P, _P]),
     "qt_rmsnorm_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_float, _P]),
     "qt_rmsnorm_fq8_bf16": (c_int, [_P, _P, _P, _P, c_long, c_long, c_float, _FMT, _P]),
     "qt_rmsnorm_consumers_bf16": (c_int, [_P, _P, _P, _P, _P, c_long, c_long, c_float, c_int, _P, _P, _P]),

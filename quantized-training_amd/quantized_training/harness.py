@@ -38,14 +38,39 @@ def shard_round_robin(items: Sequence, rank: int, world: int) -> List:
     return [it for i, it in enumerate(items) if i % world == rank]
 
 
+def _window_loss(model, input_ids, labels, **kwargs):
+    """`model(input_ids, labels=labels).loss` of a causal LM.  On the device with bf16 logits the loss comes from ONE pass over the
+    logits (qt_causal_lm_loss_bf16: the same shifted-label fp32 cross entropy, mean over the scored positions) instead of the bf16 ->
+    fp32 copy + softmax + reduction transformers runs (QT_FUSED_LOSS=0 keeps those); anything else takes the model's own loss."""
+    import ctypes
+    import os
+    if os.environ.get("QT_FUSED_LOSS", "1") != "0" and input_ids.is_cuda and not torch.is_grad_enabled():
+        from . import _native
+        out = model(input_ids, use_cache=False, **kwargs)
+        logits = getattr(out, "logits", None)
+        if (logits is not None and logits.dim() == 3 and logits.dtype == torch.bfloat16 and logits.is_cuda and logits.stride(2) == 1
+                and logits.stride(0) == logits.shape[1] * logits.stride(1) and logits.stride(1) % 8 == 0 and logits.data_ptr() % 16 == 0
+                and labels.dtype == torch.long and labels.is_contiguous() and labels.shape == logits.shape[:2]):
+            B, S, V = logits.shape
+            scratch = torch.empty(B * S + 1, dtype=torch.float32, device=logits.device)
+            with torch.cuda.device(logits.device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+                _native.check(_native.lib().qt_causal_lm_loss_bf16(logits.data_ptr(), labels.data_ptr(), B, S, V, logits.stride(1), -100,
+                                                                   scratch.data_ptr(), scratch.data_ptr() + 4 * B * S, stream),
+                              "qt_causal_lm_loss_bf16")
+            return scratch[B * S]
+        from transformers.loss.loss_utils import ForCausalLMLoss
+        return ForCausalLMLoss(logits, labels, vocab_size=logits.shape[-1]).float()
+    return model(input_ids, labels=labels, use_cache=False, **kwargs).loss.float()
+
+
 @torch.no_grad()
 def window_nll(model, input_ids: torch.Tensor, trg_len: int) -> torch.Tensor:
     """Mean NLL over the scored labels of one window (labels masked to -100 outside the last
     trg_len positions; the model shifts labels internally), wikitext.py:146-158."""
     target = input_ids.clone()
     target[:, :-trg_len] = -100
-    out = model(input_ids, labels=target, use_cache=False)
-    return out.loss.float()
+    return _window_loss(model, input_ids, target)
 
 
 class GraphedWindow:
@@ -69,8 +94,7 @@ class GraphedWindow:
 
     @torch.no_grad()
     def _forward(self):
-        out = self.model(self.ids, attention_mask=self.mask, labels=self.labels, use_cache=False)
-        return out.loss.float()
+        return _window_loss(self.model, self.ids, self.labels, attention_mask=self.mask)
 
     @torch.no_grad()
     def capture(self, example_ids):

@@ -1136,6 +1136,31 @@ def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
             assert torch.equal(sib_from_plain._qt_fp8.view(torch.uint8), sib_from_q._qt_fp8.view(torch.uint8))
 
 
+@pytest.mark.parametrize("B,S,V,stride", [(1, 1024, 32000, 32000), (3, 37, 1003, 1008), (2, 5, 8, 8)])
+def test_causal_lm_loss_from_bf16_logits(nv, B, S, V, stride):
+    """qt_causal_lm_loss_bf16 == cross_entropy(logits.float()[:, :-1], labels[:, 1:], ignore_index=-100) (transformers' ForCausalLMLoss):
+    fp32 arithmetic in another summation order (1e-6 relative), deterministic; nothing scored -> NaN like torch."""
+    L = nv.lib()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    buf = (torch.randn(B, S, stride, device="cuda", generator=g) * 4).bfloat16()
+    logits = buf[:, :, :V]
+    labels = torch.randint(0, V, (B, S), device="cuda", generator=g)
+    labels[:, : S // 2] = -100
+    labels[0, -1] = -100
+    scratch = torch.empty(B * S + 1, dtype=torch.float32, device="cuda")
+
+    def run(lab):
+        nv.check(L.qt_causal_lm_loss_bf16(logits.data_ptr(), lab.data_ptr(), B, S, V, stride, -100, scratch.data_ptr(),
+                                          scratch.data_ptr() + 4 * B * S, stream()), "qt_causal_lm_loss_bf16")
+        torch.cuda.synchronize()
+        return float(scratch[B * S])
+    got = run(labels)
+    want = float(torch.nn.functional.cross_entropy(logits.float()[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100))
+    assert abs(got - want) <= 2e-6 * abs(want) + 1e-6, (got, want)
+    assert run(labels) == got
+    assert np.isnan(run(torch.full_like(labels, -100)))
+
+
 def test_rmsnorm_with_all_consumers_fake_quant(nv):
     """One launch for the norm and the input fake-quantizers of all its consuming Linears (qt_rmsnorm_consumers_bf16), plain and with
     the residual add: values and the first consumer's codes as rmsnorm_fq / add_rmsnorm with one fake-quantizer; every further
