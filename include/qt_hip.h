@@ -429,7 +429,8 @@ int qt_rope_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t
 /* The same with the codes mandatory and the bf16 outputs optional (both or neither: the codes decode to exactly those values, so a
  * consumer that multiplies codes needs nothing else), and -- v_dev non-NULL -- qt_value_codes_t (below: the attention kernel's fq_v
  * call on the value projection, [B][Hk][S][D] by element strides, D = 64 or 128 contiguous, S % 128 == 0) in the SAME launch: the two
- * jobs are independent and each alone is too small to fill the chip. */
+ * jobs are independent and each alone is too small to fill the chip.  cos_dev = sin_dev = NULL: no rotation -- q and k are only moved
+ * to [B][H][S][D] order and fake-quantized (BERT's transpose_for_scores + qk_matmul's input hooks). */
 int qt_rope_fq_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
                      uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S, long Hq, long Hk, long D,
                      long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, const uint16_t *v_dev,

@@ -205,18 +205,20 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, uint32_t b, u
         const uint32_t h = v / dv, d8 = v - h * dv;
         const bool low = d8 < half;
         const uint4 xv = *(const uint4 *)(xrow + (size_t)v * 8);
-        const uint4 pv = *(const uint4 *)(xrow + (size_t)(low ? v + half : v - half) * 8);      // rotate_half partner
-        const uint4 cv = *(const uint4 *)(crow + d8 * 8);
-        const uint4 sv = *(const uint4 *)(srow + d8 * 8);
-        const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
-        const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
-        const float sgn = low ? -1.0f : 1.0f;
-        uint32_t out[4];
+        uint32_t out[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (a.r.cos) {                                       // NULL: no rotation (BERT's transpose_for_scores + the two fake-quantizers)
+            const uint4 pv = *(const uint4 *)(xrow + (size_t)(low ? v + half : v - half) * 8);      // rotate_half partner
+            const uint4 cv = *(const uint4 *)(crow + d8 * 8);
+            const uint4 sv = *(const uint4 *)(srow + d8 * 8);
+            const uint32_t X[4] = {xv.x, xv.y, xv.z, xv.w}, P[4] = {pv.x, pv.y, pv.z, pv.w};
+            const uint32_t C[4] = {cv.x, cv.y, cv.z, cv.w}, S[4] = {sv.x, sv.y, sv.z, sv.w};
+            const float sgn = low ? -1.0f : 1.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
-            const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
-            out[j] = pack_bf16x2(a0 + b0, a1 + b1);                      // the rotary output, bf16
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+                const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
+                out[j] = pack_bf16x2(a0 + b0, a1 + b1);                  // the rotary output, bf16
+            }
         }
         const size_t o = (((size_t)b * (size_t)a.r.H + h) * (size_t)a.r.S + s) * dv + d8;     // [B][H][S][D] order
         if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
@@ -721,7 +723,8 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
                           const qt_format *fmt_q, const qt_format *fmt_k, bool need_values, const uint16_t *v, uint8_t *vt8, long v_sb, long v_sh,
                           long v_sk, const qt_format *fmt_v, void *stream) {
     if (B * S * D == 0) return QT_OK;
-    if (!q || !k || !cos || !sin || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0) return QT_ERR_BAD_ARG;
+    if (!q || !k || (need_values && !cos) || (cos == nullptr) != (sin == nullptr) || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0)
+        return QT_ERR_BAD_ARG;
     if (need_values ? (!q_out || !k_out) : (!q_out8 || !k_out8 || (q_out == nullptr) != (k_out == nullptr))) return QT_ERR_BAD_ARG;
     if (fmt_q->kind != QT_FMT_FP_SAT || fmt_k->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))

@@ -849,10 +849,32 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
         STATS.add(t.numel())
         return t8
 
-    q8, k8 = codes(query, fq_q, q8, Q), codes(key, fq_k, k8, C)
+    def token_rows(t):
+        """Row stride when `t` is the [B, H, S, D] view of a [B, S, H, D]-ordered buffer (transpose_for_scores of a projection), else None."""
+        b_, h_, s_, d_ = t.shape
+        rs = t.stride(2)
+        return rs if (t.stride(3) == 1 and t.stride(1) == d_ and t.stride(0) == s_ * rs and rs % 8 == 0 and rs >= h_ * d_) else None
+
+    vt8 = None
+    if (q8 is None and k8 is None and Q == C and key.shape[1] == H and value.shape[1] == H and token_rows(query) is not None
+            and token_rows(key) is not None and os.environ.get("QT_ROPE_VALUE_LAUNCH", "1") != "0"):
+        # q and k codes and the value codes in ONE launch (qt_rope_fq_value without a rotation): the three calls fq_q, fq_k, fq_v
+        q8 = torch.empty((B, H, Q, D), dtype=torch.uint8, device=query.device)
+        k8 = torch.empty((B, H, C, D), dtype=torch.uint8, device=query.device)
+        vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)
+        _native.check(L.qt_rope_fq_value(query.data_ptr(), key.data_ptr(), None, None, None, None, q8.data_ptr(), k8.data_ptr(), B, Q, H, H, D,
+                                         token_rows(query), token_rows(key), ctypes.byref(fq_q._qt_format), ctypes.byref(fq_k._qt_format),
+                                         value.data_ptr(), vt8.data_ptr(), value.stride(0), value.stride(1), value.stride(2),
+                                         ctypes.byref(fq_v._qt_format), st), "qt_rope_fq_value")
+        STATS.add(query.numel())
+        STATS.add(key.numel())
+    else:
+        q8, k8 = codes(query, fq_q, q8, Q), codes(key, fq_k, k8, C)
     fmt = fq_v._qt_format
     early = attn.__dict__.pop("_qt_vt8", None)
-    if early is not None and early[0] == value_key(value) and early[1] is fq_v:
+    if vt8 is not None:
+        pass                                                 # written by the launch above
+    elif early is not None and early[0] == value_key(value) and early[1] is fq_v:
         vt8 = early[2]                                       # written by the launch that carried the rotary kernel (model_fusions.rope_fq)
     else:
         vt8 = torch.empty((B, H, D, C), dtype=torch.uint8, device=query.device)

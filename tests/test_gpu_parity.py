@@ -1110,6 +1110,19 @@ def test_rotary_and_value_codes_in_one_launch(nv):
             a, b = got.view(torch.int16), want.view(torch.int16)
             nan = torch.isnan(want)
             assert torch.equal(a[~nan], b[~nan]) and bool(torch.isnan(got)[nan].all())
+        # without a rotation (cos = sin = NULL): the permuted-view codes-only passes of q and k (+ the value codes) in one launch
+        q8, k8 = (torch.empty(B, H, S, D, dtype=torch.uint8, device="cuda") for _ in range(2))
+        vt8 = torch.empty(B, H, D, S, dtype=torch.uint8, device="cuda")
+        fmt = fq_q._qt_format
+        nv.check(L.qt_rope_fq_value(q.data_ptr(), k.data_ptr(), None, None, None, None, q8.data_ptr(), k8.data_ptr(), B, S, H, H, D,
+                                    3 * H * D, 3 * H * D, ctypes.byref(fmt), ctypes.byref(fmt), v.data_ptr(), vt8.data_ptr(), v.stride(0),
+                                    v.stride(1), v.stride(2), ctypes.byref(fmt), stream()), "qt_rope_fq_value")
+        for t, t8 in ((q, q8), (k, k8)):
+            want8 = torch.empty_like(t8)
+            nv.check(L.qt_fake_quant_rows_bf16_fp8(t.data_ptr(), None, want8.data_ptr(), B, H, S, D, t.stride(0), t.stride(1), t.stride(2),
+                                                   ctypes.byref(fmt), stream()), "qt_fake_quant_rows_bf16_fp8")
+            assert torch.equal(t8, want8)
+        assert torch.equal(vt8, want_vt)
 
 
 def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
