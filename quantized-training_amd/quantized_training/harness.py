@@ -89,12 +89,18 @@ class GraphedWindow:
         dtype = next(model.parameters()).dtype
         self.mask = torch.full((max_length, max_length), torch.finfo(dtype).min, dtype=torch.float32,
                                device=self.device).triu(1).to(dtype)[None, None]
+        # the positions of a window are always 0 .. max_length - 1: one static tensor, so that what the model derives from them
+        # (rotary tables) can be kept from forward to forward (model_fusions._rotary_table_forward)
+        import inspect
+        takes_positions = "position_ids" in inspect.signature(model.forward).parameters
+        self.positions = torch.arange(max_length, device=self.device).unsqueeze(0) if takes_positions else None
         self.graph = None
         self.loss = None
 
     @torch.no_grad()
     def _forward(self):
-        return _window_loss(self.model, self.ids, self.labels, attention_mask=self.mask)
+        extra = {"position_ids": self.positions} if self.positions is not None else {}
+        return _window_loss(self.model, self.ids, self.labels, attention_mask=self.mask, **extra)
 
     @torch.no_grad()
     def capture(self, example_ids):

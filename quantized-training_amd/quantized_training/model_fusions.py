@@ -627,6 +627,23 @@ def _bind(module, fn):
         module.forward = fn.__get__(module, type(module))
 
 
+def _rotary_table_forward(self, x, position_ids):
+    """LlamaRotaryEmbedding.forward builds cos / sin from the positions with about a dozen small torch kernels on every forward.  A
+    caller that passes the SAME position tensor again (same storage, same version -- the window harness's static arange) gets the
+    tensors computed for it the first time; the cached entry keeps that position tensor alive, so its address cannot come back as
+    another tensor's.  Anything else (a fresh tensor per forward, as transformers builds by default) is computed as before."""
+    if torch.is_grad_enabled() or not _enabled() or os.environ.get("QT_ROTARY_TABLE_CACHE", "1") == "0":
+        return self._qt_hf_forward(x, position_ids)
+    key = (position_ids.data_ptr(), position_ids._version, tuple(position_ids.shape), position_ids.dtype, x.dtype, x.device)
+    hit = self.__dict__.get("_qt_table")
+    if hit is not None and hit[0] == key and hit[2] is position_ids:
+        return hit[1]
+    out = self._qt_hf_forward(x, position_ids)
+    if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):     # (tensors made inside a capture belong to the graph's pool)
+        self.__dict__["_qt_table"] = (key, out, position_ids)
+    return out
+
+
 _ROPE_PATCHED = {"done": False}
 
 
@@ -709,6 +726,8 @@ def apply_llama_fusions(model):
         elif isinstance(mod, ml.LlamaMLP):
             _bind(mod, _mlp_forward)
             n += 1
+        elif isinstance(mod, ml.LlamaRotaryEmbedding):
+            _bind(mod, _rotary_table_forward)
         elif isinstance(mod, ml.LlamaAttention) and not getattr(mod, "_qt_ctx_hooks", False):
             mod.register_forward_pre_hook(_attn_enter, with_kwargs=True)
             mod.register_forward_hook(_attn_exit, with_kwargs=True, always_call=True)
