@@ -886,7 +886,7 @@ def _attention_fp8_or_none(attn, query, key, value, attention_mask, scaling, fqs
     # the output projection's stateless FP8 input fake-quantizer rides on the epilogue (as model_fusions.attention_output does for the
     # library-GEMM chain): HF reshapes the result before the projection's hook sees it, so the hand-over is an expectation
     from .model_fusions import consumer_fq
-    proj = getattr(attn, "o_proj", None)
+    proj = getattr(attn, "o_proj", None) or attn.__dict__.get("_qt_out_proj")       # LLaMA's own / BERT's BertSelfOutput.dense
     fq_o = consumer_fq(proj) if (proj is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0") else None
     out8 = torch.empty((B, Q, H, D), dtype=torch.uint8, device=query.device) if fq_o is not None else None
     _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 1 if fmt.p0 == 2 else 0,

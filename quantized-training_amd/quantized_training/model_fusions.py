@@ -429,6 +429,7 @@ def apply_bert_fusions(model):
             group = SiblingGroup(qkv)
             for lin in qkv:
                 lin.__dict__["_qt_sibling_group"] = group
+        inner.__dict__["_qt_out_proj"] = mod.attention.output.dense   # consumes the attention core's result (fused._attention_fp8_or_none)
         if prev_norm is not None:
             prev_norm.__dict__["_qt_consumers"] = qkv
         mod.attention.output.LayerNorm.__dict__["_qt_consumers"] = [mod.intermediate.dense]
