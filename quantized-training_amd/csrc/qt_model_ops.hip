@@ -197,11 +197,18 @@ struct RopeFqArgs {
 
 // One workgroup per token (b, s): its vectors are the H * D / 8 of a row of x, so the only divisions left are one per token
 // (scalar) and one 32-bit division per vector (64-bit index arithmetic per vector cost more than the rotation itself).
-__device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, uint32_t b, uint32_t s, size_t bs) {
+// A token with fewer than 256 vectors (BERT-base: 96) would leave most of the workgroup idle: a workgroup then takes `tpb` consecutive
+// tokens and spreads their vectors over its threads (two more 32-bit divisions per vector).
+__device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, uint32_t tpb, size_t tokens) {
     const uint32_t dv = (uint32_t)a.r.D / 8, half = dv / 2, nv = (uint32_t)a.r.H * dv;
-    const uint16_t *xrow = a.r.x + bs * (size_t)a.r.rsv * 8;
-    const uint16_t *crow = a.r.cos + bs * dv * 8, *srow = a.r.sin + bs * dv * 8;
-    for (uint32_t v = threadIdx.x; v < nv; v += 256) {
+    const uint32_t S = (uint32_t)a.r.S;
+    for (uint32_t i = threadIdx.x; i < tpb * nv; i += 256) {
+        const uint32_t lt = tpb == 1 ? 0u : i / nv, v = i - lt * nv;
+        const size_t bs = bs0 + lt;
+        if (bs >= tokens) break;
+        const uint32_t b = (uint32_t)(bs / S), s = (uint32_t)(bs - (size_t)b * S);
+        const uint16_t *xrow = a.r.x + bs * (size_t)a.r.rsv * 8;
+        const uint16_t *crow = a.r.cos + bs * dv * 8, *srow = a.r.sin + bs * dv * 8;
         const uint32_t h = v / dv, d8 = v - h * dv;
         const bool low = d8 < half;
         const uint4 xv = *(const uint4 *)(xrow + (size_t)v * 8);
@@ -236,12 +243,11 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, uint32_t b, u
     }
 }
 
-__global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k) {
+__global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k, unsigned tpb) {
     const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;                 // q and k hold the same tokens
-    for (size_t bs = blockIdx.x; bs < tokens; bs += gridDim.x) {
-        const uint32_t b = (uint32_t)(bs / (size_t)q.r.S), s = (uint32_t)(bs - (size_t)b * (size_t)q.r.S);
-        rope_fq_token(q, b, s, bs);
-        rope_fq_token(k, b, s, bs);
+    for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)gridDim.x * tpb) {
+        rope_fq_token(q, bs, tpb, tokens);
+        rope_fq_token(k, bs, tpb, tokens);
     }
 }
 
@@ -257,14 +263,13 @@ struct ValueArgs {
 };
 
 template <bool VE5M2, int VD>
-__global__ __launch_bounds__(256) void rope_fq_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueArgs v, unsigned rope_blocks) {
+__global__ __launch_bounds__(256) void rope_fq_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueArgs v, unsigned rope_blocks, unsigned tpb) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[VD * 128];
     if (blockIdx.x < rope_blocks) {
         const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;
-        for (size_t bs = blockIdx.x; bs < tokens; bs += rope_blocks) {
-            const uint32_t b = (uint32_t)(bs / (size_t)q.r.S), s = (uint32_t)(bs - (size_t)b * (size_t)q.r.S);
-            rope_fq_token(q, b, s, bs);
-            rope_fq_token(k, b, s, bs);
+        for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)rope_blocks * tpb) {
+            rope_fq_token(q, bs, tpb, tokens);
+            rope_fq_token(k, bs, tpb, tokens);
         }
     } else {
         const unsigned vb = blockIdx.x - rope_blocks;
@@ -737,11 +742,13 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
     RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0};
     RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0};
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
-    size_t blocks = (size_t)B * (size_t)S;                                // one workgroup per token
+    const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;                      // vectors of a token: a workgroup takes 256 / that many tokens
+    const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
+    size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipStream_t st = (hipStream_t)stream;
     if (!v) {
-        rope_fq_kernel<<<(unsigned)blocks, 256, 0, st>>>(aq, ak);
+        rope_fq_kernel<<<(unsigned)blocks, 256, 0, st>>>(aq, ak, tpb);
         return launch_status();
     }
     // the value job: v is [B][Hk][S][D] by strides, D contiguous; vt8 [B][Hk][D][S]
@@ -753,11 +760,11 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
     const unsigned total = (unsigned)blocks + (unsigned)(B * Hk * (S / 128));
     const bool ve5 = is_e5m2(fmt_v);
     if (D == 128) {
-        if (ve5) rope_fq_value_kernel<true, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
-        else rope_fq_value_kernel<false, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+        if (ve5) rope_fq_value_kernel<true, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        else rope_fq_value_kernel<false, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
     } else {
-        if (ve5) rope_fq_value_kernel<true, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
-        else rope_fq_value_kernel<false, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks);
+        if (ve5) rope_fq_value_kernel<true, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        else rope_fq_value_kernel<false, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
     }
     return launch_status();
 }
