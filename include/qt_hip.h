@@ -243,6 +243,39 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
                     const uint16_t *bias_gate_dev, const uint16_t *bias_up_dev, int N, int w_format, uint16_t *h_dev, uint8_t *h8_dev,
                     const qt_format *out_format, int M, int K, void *stream);
 
+/* ---- A9 for every other value map (posit, intN, fp6 / fp4, ...): the weight fake-quantizer inside a bf16 GEMM ------------
+ *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)
+ *     fake_quantize.py:31-95        the 65 536-entry value map the weight fake-quantizer applies (stateless specs: scale 1)
+ * qt_build_rowparams (host) turns a value map (qt_build_map) into 512 rows of four words, one row per (sign, exponent) of a
+ * bf16 input: within a row the map is   t = f32(|x| bits + D);  y = clamp((t + C) - C, lo, hi)   -- a round-to-nearest-even
+ * onto a power-of-two grid done by the fp32 adder.  Every row is verified against the map on all of its 128 inputs; rows
+ * that cannot be written this way (non-finite inputs, a few rows at the far ends of some formats) are `flagged`.
+ *   row[r] = {D (int32), C (fp32 bits; bit 0 set = flagged), lo, hi (fp32 bits)};  r = bits >> 7 (rows 256.. = negative inputs)
+ *   signed_rows 0: rows 256..511 equal rows 0..255 (|map(-x)| == |map(x)|), the kernel indexes by exponent only
+ *   sign_mask 0x80008000: the result takes the input's sign; 0: it stays positive (unsigned formats such as fp8_e5m3) */
+typedef struct qt_rowparams {
+    uint32_t row[512][4];
+    int32_t signed_rows;
+    uint32_t sign_mask;
+    int32_t n_flagged;
+    uint8_t flagged[512];
+} qt_rowparams;
+int qt_build_rowparams(const uint16_t *map_host, qt_rowparams *out_host);
+/* Host evaluation of the row form on one bf16 pattern (tests: rows that are not flagged reproduce the map bit for bit). */
+uint16_t qt_rowparams_apply_host(const qt_rowparams *rp, uint16_t bf16_bits, int *flagged);
+
+/* y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 in / out, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * x_dev: the bf16 VALUES of the already fake-quantized activation [M][K].  w_devs[i]: the UNQUANTIZED bf16 weight i [ns[i]][K];
+ * every weight tile goes through the row form of its value map on its way to LDS (rows_dev: the 512 x 4 words of
+ * qt_build_rowparams in device memory), so fq(W) never exists in HBM and W is read once.  A tile that meets a flagged row is
+ * redone with map_dev (the 65 536-entry map in device memory) -- results are exact for every bf16 weight.  Products of
+ * quantized values are the reference's bf16 products.  K % 64 == 0, ns[i] % 16 == 0, up to 4 weights per launch; w_devs /
+ * bias_devs / ns are HOST arrays. */
+int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
+                       int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
+                       uint16_t *y_dev, int M, int K, void *stream);
+
+
 /* ---- A10: attention-score path between the two attention GEMMs ------------------------------
  * Replaces, for one attention block, the chain
  *     attn_scaling(scores, scaling) ; + attention_mask ; softmax(fp32) ; .to(bf16) ; fq(probs)

@@ -277,6 +277,112 @@ int qt_posit_quantize_host(const float *x, float *y, int32_t *pbits, size_t n, i
     return QT_OK;
 }
 
+}  // extern "C"
+
+// ---- row parameters of a value map (qt_linear_fqt_bf16: the weight fake-quantizer inside the bf16 GEMM) -----------------
+// A "row" is the 128 bf16 patterns that share sign and exponent (index = bits >> 7).  Within a row almost every value map of
+// the reference is a round-to-nearest-even onto a power-of-two grid followed by a clamp -- which the fp32 adder evaluates as
+//     t = float_from_bits(|x| bits + D);   z = (t + C) - C;   y = min(max(z, lo), hi)            (C = 1.5 * 2^T, or 0)
+// with a tiny integer nudge D of the pattern for the rows whose tie goes the other way (a posit's last bit may be an exponent
+// bit: posit.py:45-60) or whose threshold is an artefact of bf16 arithmetic (fp8.py:147-203).  The fit is found by search and
+// accepted only if it reproduces the map on all 128 patterns of the row, so the table is exact by construction; rows that do
+// not fit (the non-finite inputs, and a few rows at the far ends of some formats) are flagged -- C's lowest bit -- and a
+// kernel that meets one redoes its tile with the map itself.
+namespace {
+
+inline float rp_eval(uint32_t mag_img, int32_t d, float c, float lo, float hi) {
+    volatile float t = qt_u2f(mag_img + (uint32_t)d);      // volatile: the two roundings must stay two roundings
+    volatile float s = t + c;
+    float z = s - c;
+    z = z < lo ? lo : z;
+    z = z > hi ? hi : z;
+    return z;
+}
+
+// fits one row: `expect[m]` = |map value| as fp32 for mantissa m (any NaN: no fit)
+bool rp_fit_row(uint32_t exp8, const float *expect, uint32_t out[4]) {
+    float lo = expect[0], hi = expect[0];
+    for (int m = 0; m < 128; ++m) {
+        if (expect[m] != expect[m]) return false;
+        lo = expect[m] < lo ? expect[m] : lo;
+        hi = expect[m] > hi ? expect[m] : hi;
+    }
+    if (hi > 3.0e38f) return false;
+    static const int kD[17] = {0, 0x4000, -0x4000, 0x8000, -0x8000, 0xC000, -0xC000, 0x10000, -0x10000, 0x14000, -0x14000,
+                               0x18000, -0x18000, 0x1C000, -0x1C000, 0x20000, -0x20000};
+    for (int di = 0; di < 17; ++di) {
+        for (int T = -62; T <= 70; ++T) {                  // T == -62: no rounding step (C = 0)
+            const float c = T == -62 ? 0.0f : (float)ldexp(1.5, T);
+            bool ok = true;
+            for (int m = 0; m < 128 && ok; ++m) {
+                const uint32_t img = ((exp8 << 7) | (uint32_t)m) << 16;
+                ok = rp_eval(img, kD[di], c, lo, hi) == expect[m];
+            }
+            if (ok) {
+                out[0] = (uint32_t)kD[di]; out[1] = qt_f2u(c); out[2] = qt_f2u(lo); out[3] = qt_f2u(hi);
+                return (out[1] & 1u) == 0u;
+            }
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_build_rowparams(const uint16_t *map, qt_rowparams *out) {
+    if (!map || !out) return QT_ERR_BAD_ARG;
+    memset(out, 0, sizeof(*out));
+    // sign rule for negative inputs: every non-zero finite result negative (the input's sign is copied) or every one positive
+    int neg = 0, pos = 0;
+    for (uint32_t i = 0x8000; i < 0x10000; ++i) {
+        const uint16_t r = map[i];
+        if ((r & 0x7FFF) == 0 || (r & 0x7FFF) > 0x7F80) continue;
+        (r & 0x8000) ? ++neg : ++pos;
+    }
+    for (uint32_t i = 0; i < 0x8000; ++i) {                // a positive input must not produce a negative value
+        const uint16_t r = map[i];
+        if ((r & 0x7FFF) != 0 && (r & 0x7FFF) <= 0x7F80 && (r & 0x8000)) { neg = pos = 1; break; }
+    }
+    const bool sign_ok = !(neg && pos);
+    out->sign_mask = neg ? 0x80008000u : 0u;
+    bool same = true;                                       // |map(-x)| == |map(x)| everywhere: index rows by exponent only
+    for (uint32_t i = 0; i < 0x8000 && same; ++i) {
+        const uint16_t a = map[i] & 0x7FFF, b = map[i | 0x8000] & 0x7FFF;
+        same = a == b || (a > 0x7F80 && b > 0x7F80);
+    }
+    out->signed_rows = same ? 0 : 1;
+    for (uint32_t row = 0; row < 512; ++row) {
+        float expect[128];
+        for (int m = 0; m < 128; ++m) {
+            const uint16_t r = map[(row << 7) | (uint32_t)m];
+            expect[m] = qt_bf2f((uint16_t)(r & 0x7FFF));
+            if ((r & 0x7FFF) > 0x7F80) expect[m] = qt_u2f(QT_NAN32);
+        }
+        uint32_t *p = out->row[row];
+        const bool fit = sign_ok && (row & 0xFF) != 0xFF && rp_fit_row(row & 0xFF, expect, p);
+        if (!fit) {
+            p[0] = 0; p[1] = 1u; p[2] = 0; p[3] = 0;
+            out->flagged[row] = 1;
+            out->n_flagged += 1;
+        }
+    }
+    return QT_OK;
+}
+
+uint16_t qt_rowparams_apply_host(const qt_rowparams *rp, uint16_t b, int *flagged) {
+    const uint32_t row = rp->signed_rows ? (uint32_t)(b >> 7) : (uint32_t)((b >> 7) & 0xFF);
+    const uint32_t *p = rp->row[row];
+    if (flagged) *flagged = (int)(p[1] & 1u);
+    const float z = rp_eval((uint32_t)(b & 0x7FFF) << 16, (int32_t)p[0], qt_u2f(p[1]), qt_u2f(p[2]), qt_u2f(p[3]));
+    return (uint16_t)((qt_f2u(z) >> 16) | (b & (uint16_t)(rp->sign_mask & 0x8000u)));
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // helpers shared with the device half (qt_elementwise.hip)
 float qt_internal_posit_threshold(int nbits, int es) { return posit_threshold(nbits, es); }
 int qt_internal_fp8_emin(float fp8_min) { return fp8_emin(fp8_min); }

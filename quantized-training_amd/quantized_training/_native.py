@@ -28,6 +28,12 @@ class QtOperandQ(ctypes.Structure):
     _fields_ = [("fmt", QtFormat), ("lut_dev", c_void_p), ("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p)]
 
 
+class QtRowParams(ctypes.Structure):
+    """Row form of a value map (qt_build_rowparams): 512 rows {D, C | flagged bit, lo, hi}, see include/qt_hip.h."""
+    _fields_ = [("row", (c_uint32 * 4) * 512), ("signed_rows", ctypes.c_int32), ("sign_mask", c_uint32),
+                ("n_flagged", ctypes.c_int32), ("flagged", ctypes.c_uint8 * 512)]
+
+
 class QtError(RuntimeError):
     pass
 
@@ -68,6 +74,9 @@ SIGNATURES = {
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "qt_build_rowparams": (c_int, [_P, POINTER(QtRowParams)]),
+    "qt_rowparams_apply_host": (c_uint16, [POINTER(QtRowParams), c_uint16, POINTER(c_int)]),
+    "qt_linear_fqt_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P]),
     "qt_mlp_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, _P]),
     "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
                                _OPQ, _OPQ, _P]),
@@ -188,6 +197,15 @@ def build_map_u16(dtype):
         raise ValueError(f"Unsupported dtype: {dtype}")
     check(code, "qt_build_map")
     return out
+
+
+def build_rowparams(map_u16):
+    """QtRowParams of a uint16[65536] value map (host)."""
+    import numpy as np
+    m = np.ascontiguousarray(map_u16, dtype=np.uint16)
+    rp = QtRowParams()
+    check(lib().qt_build_rowparams(m.ctypes.data, ctypes.byref(rp)), "qt_build_rowparams")
+    return rp
 
 
 def format_for(dtype):
