@@ -89,60 +89,107 @@ __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// a table row, as an ordinary LDS load: hipcc schedules these and places their waits itself
-__device__ __forceinline__ u32x4 lds_row(uint32_t addr) {
-    return *(const __attribute__((address_space(3))) u32x4 *)(uintptr_t)addr;
-}
 
 // both operand tiles: row-major 128-byte rows (64 bf16), 16-byte chunk index XOR ((row >> 1) & 7)
 __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// Two packed bf16 weights -> the two packed values of the map, through the row form.  ROWMASK: 0xFF0 = rows by exponent,
-// 0x1FF0 = rows by sign and exponent (maps whose negative half is not the mirror image: intN, uintN).
+// ---- the row form on registers ---------------------------------------------------------------------------------------------
+// A table row is {D, C (bit 0: flagged), lo, hi}; the table sits at LDS address 0, so a row's address is (bits >> 7) << 4.
+// ROWMASK: 0xFF0 = rows by exponent, 0x1FF0 = rows by sign and exponent (maps whose negative half is not the mirror image).
 template <uint32_t ROWMASK>
-__device__ __forceinline__ uint32_t quant_pair(uint32_t x, uint32_t tbl, uint32_t sign_mask, uint32_t &flags) {
-    const uint32_t s = x >> 3;                                // (bits >> 7) << 4 of both halves
-    const u32x4 p0 = lds_row(tbl + (s & ROWMASK));
-    const u32x4 p1 = lds_row(tbl + ((s >> 16) & ROWMASK));
-    const float t0 = qt_u2f(((x & 0x7FFFu) << 16) + p0.x);
-    const float t1 = qt_u2f((x & 0x7FFF0000u) + p1.x);
+__device__ __forceinline__ void row_addrs(uint32_t x, uint32_t &a0, uint32_t &a1) {
+    const uint32_t s = x >> 3;
+    a0 = s & ROWMASK;
+    a1 = (s >> 16) & ROWMASK;
+}
+__device__ __forceinline__ u32x4 ds_gather128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// two packed bf16 weights and their rows -> the two packed values of the map
+__device__ __forceinline__ uint32_t quant_pair(uint32_t x, const u32x4 &p0, const u32x4 &p1, uint32_t sign_mask) {
+    const float t0 = qt_u2f((x << 16) + p0.x);                // the sign bit rides along; |t| below
+    const float t1 = qt_u2f((x & 0xFFFF0000u) + p1.x);
     const float c0 = qt_u2f(p0.y), c1 = qt_u2f(p1.y);
-    const float z0 = __builtin_amdgcn_fmed3f((t0 + c0) - c0, qt_u2f(p0.z), qt_u2f(p0.w));
-    const float z1 = __builtin_amdgcn_fmed3f((t1 + c1) - c1, qt_u2f(p1.z), qt_u2f(p1.w));
-    flags |= p0.y | p1.y;
+    const float z0 = __builtin_amdgcn_fmed3f((__builtin_fabsf(t0) + c0) - c0, qt_u2f(p0.z), qt_u2f(p0.w));
+    const float z1 = __builtin_amdgcn_fmed3f((__builtin_fabsf(t1) + c1) - c1, qt_u2f(p1.z), qt_u2f(p1.w));
     // results are exact bf16 values: the high halves are the answer
     return __builtin_amdgcn_perm(qt_f2u(z1), qt_f2u(z0), 0x07060302u) | (x & sign_mask);
 }
 
-// NB: weight pieces (8 rows x 128 bytes of bf16) per wave and k step (2, 3 or 4: tiles of up to 8, 12, 15 column groups);
-// SROWS: the table has 512 rows (sign and exponent)
-template <int NB, bool SROWS>
+// The LDS operations of one wave and k step, in issue order (they complete in that order, which is what makes counted waits
+// possible).  A "unit" is half a weight piece of the lane: 4 weights = 2 packed words = 4 table rows.
+//     RAW x NB                  the lane's 16 raw bytes of each of its pieces (weight tile t+1)
+//     FA x 8, RB(0) x 2, RB(1) x 2     activation fragments of the step, weight fragments of column groups 0 and 1
+//     [wait RAW(0)]  G(0) x 4   table rows of unit 0
+//     per column group J:  RB(J+2) x 2;  [wait FA / RB(J)];  then per unit u the group carries:
+//                          G(u+1) x 4;  [wait G(u)];  (arithmetic of unit u);  WR(u) x 1      -- and the group's 8 multiplications
+// walk() replays that order and returns how many operations were issued after the last one of (from_kind, from_idx) when the
+// wait (to_kind, to_idx) is reached: the lgkmcnt that wait may leave outstanding.
+enum { kOpRaw = 0, kOpFA = 1, kOpRB = 2, kOpG = 3, kOpWR = 4, kWaitRaw = 10, kWaitF = 11, kWaitG = 12 };
+constexpr int unit_group(int u, int NTW, int U) { return NTW > 0 ? u * NTW / U : 0; }
+constexpr int walk(int NTW, int NB, int from_kind, int from_idx, int to_kind, int to_idx) {
+    const int U = 2 * NB;
+    int n = -1;
+    bool done = false;
+    int result = -1;
+    auto op = [&](int kind, int idx, int count) {
+        if (n >= 0) n += count;
+        if (kind == from_kind && idx == from_idx) n = 0;
+    };
+    auto wait = [&](int kind, int idx) {
+        if (!done && kind == to_kind && idx == to_idx) { result = n; done = true; }
+    };
+    for (int i = 0; i < NB; ++i) op(kOpRaw, i, 1);
+    if (NTW > 0) {
+        op(kOpFA, 0, 8);
+        op(kOpRB, 0, 2);
+        if (NTW > 1) op(kOpRB, 1, 2);
+    }
+    wait(kWaitRaw, 0);
+    op(kOpG, 0, 4);
+    for (int J = 0; J < (NTW > 0 ? NTW : 1); ++J) {
+        if (NTW > 0) {
+            if (J + 2 < NTW) op(kOpRB, J + 2, 2);
+            wait(kWaitF, J);
+        }
+        for (int u = 0; u < U; ++u) {
+            if (unit_group(u, NTW, U) != J) continue;
+            if (u + 1 < U) op(kOpG, u + 1, 4);
+            wait(kWaitG, u);
+            op(kOpWR, u, 1);
+        }
+    }
+    // the counter has four bits: the 16th operation issued behind one cannot issue before that one has completed
+    return result > 15 ? 15 : result;
+}
+
+// ABL (timing experiments only, QT_FQT_ABLATE; results are garbage): 1 no multiplications, 2 no weight items at all, 3 no
+// activation DMA, 5 weight items without the conversion (DMA, LDS round trip), 6 conversion without the table gathers
+//
+// NB: weight pieces (8 rows x 128 bytes of bf16) per wave and k step (1-4: tiles of up to 4, 8, 12, 15 column groups);
+// SROWS: the table has 512 rows (sign and exponent).
+//
+// k step t of a wave (every LDS / DMA operation is inline asm, every wait a computed count):
+//   top      s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      everything requested during step t-1 has landed, every wave's converted
+//                                                          weights of step t are written, every wave is done with step t-1
+//   first    request the activation tile of step t+1 (ring of 2) and the RAW weight tile of step t+2 (ring of 3): 4 + NB DMA
+//            pieces, all in front, so that they have the whole step to land
+//   then     the LDS stream above: 8 multiplications per column group on tile t, and 2 NB units of weight tile t+1 converted IN
+//            PLACE, spread evenly over the groups; the rows of unit u+1 are in flight while unit u is computed
+template <int NB, bool SROWS, int ABL = 0>
 struct LinearFqt {
-    static constexpr int kADepth = 3;
+    static constexpr int kADepth = 2, kWDepth = 3, kU = 2 * NB;
     static constexpr int kMaxNT = NB * 4 < 15 ? NB * 4 : (SROWS ? 14 : 15);
     static constexpr int kTbl = SROWS ? 8192 : 4096;
     static constexpr int kWBytes = kMaxNT * kGroupBytes;
-    static constexpr int kLds = kTbl + kADepth * kABytes + 2 * kWBytes;
+    static constexpr int kDummy = 1024;                     // where surplus pieces go (a tile of 15 groups has 30, the waves request 32)
+    static constexpr int kLds = kTbl + kADepth * kABytes + kWDepth * kWBytes + kDummy;
     static_assert(kLds <= 160 * 1024, "LDS budget");
     static constexpr uint32_t kRowMask = SROWS ? 0x1FF0u : 0xFF0u;
-    static constexpr int kItems = 4 + NB;
     static constexpr int kEpiStride = 64 * ((2 * NB < 8 ? 2 * NB : 8) * 32 + 8);      // a wave's epilogue tile in LDS
-    // items of column group J of NTW: the four activation DMA pieces ride on the first half of the groups, the weight items
-    // (quantize + ds_write + reload) on the second half
-    static constexpr int item_lo(int J, int NTW) {
-        const int h = NTW / 2;
-        if (h == 0) return 0;
-        return J < h ? J * 4 / h : 4 + (J - h) * NB / (NTW - h);
-    }
-    static constexpr int item_hi(int J, int NTW) {
-        const int h = NTW / 2;
-        if (h == 0) return kItems;
-        return J < h ? (J + 1) * 4 / h : 4 + (J - h + 1) * NB / (NTW - h);
-    }
-    static constexpr int writes_in(int J, int NTW) {
-        const int lo = item_lo(J, NTW), hi = item_hi(J, NTW);
-        return (hi > 4 ? hi : 4) - (lo > 4 ? lo : 4);
-    }
+    static_assert(8 * kEpiStride + 16 <= kADepth * kABytes + kWDepth * kWBytes, "epilogue tiles fit in the dead rings");
 
     // One wave's share: rows [wm * 64, +64) x NTW column groups starting at group jbase of the tile whose first group is tg0.
     // Returns true when a flagged row was met (the caller redoes the tile).
@@ -151,88 +198,150 @@ struct LinearFqt {
         const int r = l & 15, g = l >> 4, wm = w & 3;
         const int nk = a.K / kBK, klast = nk - 1;
         const long krow = (long)a.K * 2;                        // bytes per row of x and W
-        const uint32_t l0 = lds_addr(lds);
-        const uint32_t tbl = l0, a0 = l0 + kTbl, w0 = a0 + kADepth * kABytes;
+        // LDS map (the dynamic segment starts at address 0: the kernel has no static LDS)
+        constexpr uint32_t a0 = kTbl, w0 = a0 + kADepth * kABytes, dummy = w0 + kWDepth * kWBytes;
         // ---- the row table into LDS (every thread one 16-byte row)
         {
             const int t = w * 64 + l;
             if (t < (SROWS ? 512 : 256)) {
                 const u32x4 v = *(const u32x4 *)(a.rows + t * 4);
-                asm volatile("ds_write_b128 %0, %1" ::"v"(tbl + t * 16), "v"(v) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(t * 16), "v"(v) : "memory");
             }
         }
-        // ---- activation DMA sources (k tile 0); LDS destinations are wave-uniform
-        const uint8_t *ga[4];
+        // ---- DMA sources: a scalar base (advanced by 128 bytes per k tile) + a 32-bit lane offset; LDS destinations are
+        // wave-uniform.  Activations: 32 pieces of 8 rows x 128 bytes, four per wave.
+        uint32_t ga[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
-            ga[i] = (const uint8_t *)a.x + (long)min(m0 + row, a.M - 1) * krow + ((slot ^ ((row >> 1) & 7)) << 4);
+            ga[i] = (uint32_t)((long)min(m0 + row, a.M - 1) * krow) + ((slot ^ ((row >> 1) & 7)) << 4);
         }
-        // ---- weight pieces (8 rows x 128 bytes): piece p = w + 8 i; lane = (row l >> 3, 16-byte chunk l & 7 = k 8c .. 8c+7)
+        // Weight pieces: piece p = w + 8 i covers rows 8 p .. 8 p + 7 of the tile; the lane's 16 bytes land at piece base + 16 l and
+        // are converted there.  Surplus pieces (p >= 2 nt) re-request piece w & 1 into the dummy kilobyte.
         const int npieces = nt * 2;
-        const uint8_t *gw[NB];
-        uint32_t wdst[NB];
+        uint32_t gw[NB];
+        const uint16_t *wbase[NB];                             // wave-uniform
+        uint32_t wofs[NB];                                     // piece base inside a weight stage (or the dummy), wave-uniform
+        bool real[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int p = w + 8 * i, pb = p < npieces ? p : (w & 1);          // surplus pieces repeat one (same bytes, same place)
+            const int p = w + 8 * i;
+            real[i] = p < npieces;
+            const int pb = real[i] ? p : (w & 1);
             const int grp = tg0 + (pb >> 1);
-            const int row = pb * 8 + (l >> 3), c = l & 7;
+            const int row = pb * 8 + (l >> 3), slot = l & 7;
             const SegRef sg = seg_lookup(a, grp);
-            gw[i] = (const uint8_t *)sg.w + (long)((grp - sg.g0) * 16 + (pb & 1) * 8 + (l >> 3)) * krow + c * 16;
-            wdst[i] = chunk_off(row, c);
+            wbase[i] = sg.w;
+            gw[i] = (uint32_t)((long)((grp - sg.g0) * 16 + (pb & 1) * 8 + (l >> 3)) * krow) + ((slot ^ ((row >> 1) & 7)) << 4);
+            wofs[i] = real[i] ? (uint32_t)pb * 1024u : 0xFFFFFFFFu;
         }
-        u32x4 wr[NB];
         uint32_t flags = 0;
-        auto load_w = [&](auto ic, int kt) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            wr[I] = *(const u32x4 *)(gw[I] + (long)kt * kRowBytes);
-        };
-        // the activation DMA as inline asm, hidden from hipcc's wait-count model (qt_linear_fq8.hip, variant R)
-        auto dma16 = [](const uint8_t *src, uint32_t dst) __attribute__((always_inline)) {
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
-        };
-        auto ds_write128 = [](uint32_t addr, u32x4 v) __attribute__((always_inline)) {
-            asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        const uint32_t sign_mask = a.sign_mask;
+        auto dma16 = [](const void *base, uint32_t off, uint32_t dst) __attribute__((always_inline)) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
         };
         auto ds_write64 = [](uint32_t addr, u32x2 v) __attribute__((always_inline)) {
             asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
         };
-        const uint32_t sign_mask = a.sign_mask;
-        auto store_w = [&](auto ic, uint32_t wbase) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            u32x4 q;
-            q.x = quant_pair<kRowMask>(wr[I].x, tbl, sign_mask, flags);
-            q.y = quant_pair<kRowMask>(wr[I].y, tbl, sign_mask, flags);
-            q.z = quant_pair<kRowMask>(wr[I].z, tbl, sign_mask, flags);
-            q.w = quant_pair<kRowMask>(wr[I].w, tbl, sign_mask, flags);
-            ds_write128(wbase + wdst[I], q);
-        };
-        // item 0-3: activation pieces of k tile ka into `as`; item 4 + i: weight piece i -- its registers (k tile kb - 1) are
-        // quantized and written to the weight tile at LDS address `ws`, then reloaded with k tile kb
-        auto item = [&](auto ic, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            if constexpr (I < 4) {
-                dma16(ga[I] + (long)ka * kRowBytes, as + (w * 4 + I) * 1024);
-            } else {
-                store_w(std::integral_constant<int, I - 4>{}, ws);
-                load_w(std::integral_constant<int, I - 4>{}, kb);
+        // all of a step's requests: activation tile ka into stage `as`, raw weight tile kb into stage `ws`
+        auto request = [&](int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
+            if constexpr (ABL != 3) {
+                const uint8_t *xb = (const uint8_t *)a.x + (long)ka * kRowBytes;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16(xb, ga[i], as + (w * 4 + i) * 1024);
+            }
+            if constexpr (ABL != 2) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) dma16((const uint8_t *)wbase[i] + (long)kb * kRowBytes, gw[i], real[i] ? ws + wofs[i] : dummy);
             }
         };
-        auto items = [&](auto lo, auto hi, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
-            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
-            static_assert(HI - LO <= 8, "at most eight items");
-            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, ka, as, ws, kb);
-            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, ka, as, ws, kb);
-            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, ka, as, ws, kb);
-            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, ka, as, ws, kb);
-            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, ka, as, ws, kb);
-            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, ka, as, ws, kb);
-            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, ka, as, ws, kb);
-            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, ka, as, ws, kb);
+        // the lane's 16 bytes of piece i, relative to a weight stage (surplus pieces: relative address of the dummy from stage 0;
+        // they are only ever read and written by this lane, whatever the stage)
+        uint32_t pofs[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) pofs[i] = (real[i] ? wofs[i] : dummy - w0) + (uint32_t)l * 16u;
+        u32x4 raw[NB];
+        u32x4 rows[2][4];                                        // table rows of the unit being computed / of the next one
+        // ---- the unit stream
+        auto raw_word = [&](auto uc, int k) __attribute__((always_inline)) -> uint32_t {       // packed word k (0, 1) of unit U
+            constexpr int U = decltype(uc)::value;
+            return (U & 1) ? (k ? raw[U >> 1].w : raw[U >> 1].z) : (k ? raw[U >> 1].y : raw[U >> 1].x);
         };
-        constexpr auto kI0 = std::integral_constant<int, 0>{};
-        constexpr auto kIA = std::integral_constant<int, 4>{};
-        constexpr auto kIN = std::integral_constant<int, kItems>{};
+        auto unit_gather = [&](auto uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value;
+            if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
+                uint32_t ad[4];
+                row_addrs<kRowMask>(raw_word(uc, 0), ad[0], ad[1]);
+                row_addrs<kRowMask>(raw_word(uc, 1), ad[2], ad[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rows[U & 1][e] = ds_gather128(ad[e]);
+            }
+        };
+        auto unit_finish = [&](auto uc, uint32_t wc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value, I = U >> 1;
+            if constexpr (ABL != 2) {
+                u32x4(&rp)[4] = rows[U & 1];
+                if constexpr (ABL == 6) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rp[e] = u32x4{0u, 0x4B400000u, 0u, 0x7F000000u};
+                }
+                u32x2 q = {raw_word(uc, 0), raw_word(uc, 1)};
+                if constexpr (ABL != 5) {
+                    q.x = quant_pair(raw_word(uc, 0), rp[0], rp[1], sign_mask);
+                    q.y = quant_pair(raw_word(uc, 1), rp[2], rp[3], sign_mask);
+                    const uint32_t f = (rp[0].y | rp[1].y) | (rp[2].y | rp[3].y);
+                    flags |= real[I] ? f : 0u;
+                }
+                ds_write64((real[I] ? wc : w0) + pofs[I] + (U & 1) * 8, q);
+            }
+        };
+        // unit slot: the next unit's rows requested, this unit's rows waited for, computed, written back
+        auto unit_slot = [&](auto uc, uint32_t wc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value;
+            if constexpr (U + 1 < kU) unit_gather(std::integral_constant<int, U + 1>{});
+            if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
+                constexpr int n = walk(NTW, NB, kOpG, U, kWaitG, U);
+                static_assert(n >= 0, "schedule");
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rows[U & 1][0]), "+v"(rows[U & 1][1]), "+v"(rows[U & 1][2]), "+v"(rows[U & 1][3]) : "n"(n));
+            }
+            unit_finish(uc, wc);
+        };
+        // the units column group J carries
+        auto units_of = [&](auto jc, uint32_t wc) __attribute__((always_inline)) {
+            constexpr int J = decltype(jc)::value;      // (+ 0 * J below: the calls must depend on J, or every one is instantiated)
+            if constexpr (0 < kU && unit_group(0, NTW, kU) == J) unit_slot(std::integral_constant<int, 0 + 0 * J>{}, wc);
+            if constexpr (1 < kU && unit_group(1, NTW, kU) == J) unit_slot(std::integral_constant<int, 1 + 0 * J>{}, wc);
+            if constexpr (2 < kU && unit_group(2, NTW, kU) == J) unit_slot(std::integral_constant<int, 2 + 0 * J>{}, wc);
+            if constexpr (3 < kU && unit_group(3, NTW, kU) == J) unit_slot(std::integral_constant<int, 3 + 0 * J>{}, wc);
+            if constexpr (4 < kU && unit_group(4, NTW, kU) == J) unit_slot(std::integral_constant<int, 4 + 0 * J>{}, wc);
+            if constexpr (5 < kU && unit_group(5, NTW, kU) == J) unit_slot(std::integral_constant<int, 5 + 0 * J>{}, wc);
+            if constexpr (6 < kU && unit_group(6, NTW, kU) == J) unit_slot(std::integral_constant<int, 6 + 0 * J>{}, wc);
+            if constexpr (7 < kU && unit_group(7, NTW, kU) == J) unit_slot(std::integral_constant<int, 7 + 0 * J>{}, wc);
+        };
+        // the step's first LDS operations: raw pieces of the tile to convert (stage wc)
+        auto read_raw = [&](uint32_t wc) __attribute__((always_inline)) {
+            if constexpr (ABL != 2) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) raw[i] = ds_gather128((real[i] ? wc : w0) + pofs[i]);
+            }
+        };
+        // wait for raw[0] (and hand every raw register to the compiler as defined), then the first unit's rows
+        auto first_rows = [&]() __attribute__((always_inline)) {
+            if constexpr (ABL != 2) {
+                constexpr int n = walk(NTW, NB, kOpRaw, 0, kWaitRaw, 0);
+                static_assert(n >= 0, "schedule");
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[0]) : "n"(n));
+                unit_gather(std::integral_constant<int, 0>{});
+            }
+        };
+        // the other raw registers are older than the activation fragments: valid once those are (group 0's wait)
+        auto raws_defined = [&]() __attribute__((always_inline)) {
+            if constexpr (ABL != 2) {
+                if constexpr (NB == 2) asm volatile("" : "+v"(raw[1]));
+                if constexpr (NB == 3) asm volatile("" : "+v"(raw[1]), "+v"(raw[2]));
+                if constexpr (NB == 4) asm volatile("" : "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+            }
+        };
 
         v4f acc[4][NTW > 0 ? NTW : 1];
 #pragma unroll
@@ -243,7 +352,9 @@ struct LinearFqt {
         const uint32_t a_lo = chunk_off(wm * 64 + r, g), a_hi = chunk_off(wm * 64 + r, 4 + g);
         const uint32_t b_lo = chunk_off(jbase * 16 + r, g), b_hi = chunk_off(jbase * 16 + r, 4 + g);
 
-        auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+        // multiplications of step t on (sa_, sb_); conversion of the raw weight tile in stage wc
+        auto compute = [&](uint32_t sa_, uint32_t sb_, uint32_t wc) __attribute__((always_inline)) {
+            read_raw(wc);
             if constexpr (NTW > 0) {
                 u32x4 fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
                 fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
@@ -260,33 +371,32 @@ struct LinearFqt {
                     constexpr int P = J % 3;
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
-                    // LDS operations that may stay in flight (they return in order): the reads of the next two groups and the
-                    // ds_writes of the weight items the two groups in front of this one carried; the table reads of those items
-                    // only add to what is younger than this group's fragments, so the count stays a lower bound
-                    constexpr int kAhead = (J + 1 < NTW ? 2 : 0) + (J + 2 < NTW ? 2 : 0) + (J >= 2 ? writes_in(J - 2, NTW) : 0) +
-                                           (J >= 1 ? writes_in(J - 1, NTW) : 0);
+                    constexpr int kAhead = walk(NTW, NB, kOpRB, J, kWaitF, J);
+                    static_assert(kAhead >= 0, "schedule");
                     if constexpr (J == 0) {
                         asm volatile("s_waitcnt lgkmcnt(%10)"
                                      : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]), "+v"(fa_lo[3]),
                                        "+v"(fa_hi[3]), "+v"(fb_lo[0]), "+v"(fb_hi[0])
                                      : "n"(kAhead));
+                        raws_defined();
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb_lo[P]), "+v"(fb_hi[P]) : "n"(kAhead));
                     }
-                    // operands swapped: D rows = W rows (output columns), D columns = x rows -- a lane ends up with four
-                    // consecutive output columns of one row
+                    units_of(jc, wc);
                     const v8s bl = __builtin_bit_cast(v8s, fb_lo[P]), bh = __builtin_bit_cast(v8s, fb_hi[P]);
+                    if constexpr (ABL != 1) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, __builtin_bit_cast(v8s, fa_lo[i]), acc[i][J], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, __builtin_bit_cast(v8s, fa_lo[i]), acc[i][J], 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, __builtin_bit_cast(v8s, fa_hi[i]), acc[i][J], 0, 0, 0);
-                    items(std::integral_constant<int, item_lo(J, NTW)>{}, std::integral_constant<int, item_hi(J, NTW)>{}, ka, as, ws, kb);
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, __builtin_bit_cast(v8s, fa_hi[i]), acc[i][J], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 read_b(std::integral_constant<int, 0>{});
                 if constexpr (NTW > 1) read_b(std::integral_constant<int, 1>{});
+                first_rows();
                 step(std::integral_constant<int, 0>{});
                 if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
                 if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
@@ -296,38 +406,59 @@ struct LinearFqt {
                 if constexpr (NTW > 6) step(std::integral_constant<int, 6>{});
                 if constexpr (NTW > 7) step(std::integral_constant<int, 7>{});
             } else {
-                items(kI0, kIN, ka, as, ws, kb);
+                first_rows();
+                raws_defined();                                   // (only raw[0] was waited for: the unit waits below cover the rest,
+                units_of(std::integral_constant<int, 0>{}, wc);   //  every raw read being older than every gather)
             }
         };
 
-        // prologue: the table is in place for every wave (barrier); activations of k tiles 0 and 1 on their way; weights of k tile
-        // 0 quantized into weight tile 0, those of k tile 1 in registers
+        // prologue: table in place (barrier); activations of k tile 0, raw weights of k tiles 0 and 1 requested; this wave's pieces
+        // of weight tile 0 converted as soon as they are here (only the wave that requested a piece touches it before a barrier)
         __syncthreads();
-        items(kI0, kIA, 0, a0, w0, 0);
-        items(kI0, kIA, min(1, klast), a0 + kABytes, w0, 0);
-        load_w(std::integral_constant<int, 0>{}, 0);
-        if constexpr (NB > 1) load_w(std::integral_constant<int, 1>{}, 0);
-        if constexpr (NB > 2) load_w(std::integral_constant<int, 2>{}, 0);
-        if constexpr (NB > 3) load_w(std::integral_constant<int, 3>{}, 0);
-        items(kIA, kIN, 0, a0, w0, min(1, klast));
-        int a_slot = 0, a_tgt = 2;
+        request(0, a0, 0, w0);
+        if constexpr (ABL != 2) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dma16((const uint8_t *)wbase[i] + (long)min(1, klast) * kRowBytes, gw[i], real[i] ? w0 + kWBytes + wofs[i] : dummy);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+        if constexpr (ABL != 2) {
+            // plain and serial: read, gather, compute, write, one piece at a time
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                u32x4 v = ds_gather128((real[i] ? w0 : w0) + pofs[i]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+                uint32_t ad[8];
+                row_addrs<kRowMask>(v.x, ad[0], ad[1]); row_addrs<kRowMask>(v.y, ad[2], ad[3]);
+                row_addrs<kRowMask>(v.z, ad[4], ad[5]); row_addrs<kRowMask>(v.w, ad[6], ad[7]);
+                u32x4 p[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p[e] = ds_gather128(ad[e]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+                u32x4 q;
+                q.x = quant_pair(v.x, p[0], p[1], sign_mask); q.y = quant_pair(v.y, p[2], p[3], sign_mask);
+                q.z = quant_pair(v.z, p[4], p[5], sign_mask); q.w = quant_pair(v.w, p[6], p[7], sign_mask);
+                const uint32_t f = (p[0].y | p[1].y | p[2].y) | (p[3].y | p[4].y | p[5].y) | (p[6].y | p[7].y);
+                if constexpr (ABL == 0) flags |= real[i] ? f : 0u;
+                if constexpr (ABL != 0) q = v;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(w0 + pofs[i]), "v"(q) : "memory");
+            }
+        }
+        int wmul = 0;                                              // weight stage multiplied in this step; +1: converted; +2: requested
         for (int kt = 0; kt < nk; ++kt) {
-            // this wave's weight values of step kt are written (lgkmcnt) and its activation pieces have landed: they are older in
-            // the vector-memory queue than the weight loads of step kt, which the conversions of the previous step waited for
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NB) : "memory");
-            __builtin_amdgcn_s_barrier();                    // ... every wave's; and every wave is done with step kt - 1
-            const int ka = min(kt + 2, klast), kb = min(kt + 2, klast);
-            const uint32_t sa_ = a0 + a_slot * kABytes, sb_ = w0 + (kt & 1) * kWBytes, ws = w0 + ((kt + 1) & 1) * kWBytes;
-            compute(sa_, sb_, ka, a0 + a_tgt * kABytes, ws, kb);
-            a_tgt = a_slot; a_slot = a_slot == 2 ? 0 : a_slot + 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int wcv = wmul == 2 ? 0 : wmul + 1, wrq = wcv == 2 ? 0 : wcv + 1;
+            request(min(kt + 1, klast), a0 + ((kt + 1) & 1) * kABytes, min(kt + 2, klast), w0 + wrq * kWBytes);
+            compute(a0 + (kt & 1) * kABytes, w0 + wmul * kWBytes, w0 + wcv * kWBytes);
+            wmul = wcv;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         // A lane that read a flagged row raises the workgroup's flag (through LDS: the rings are dead here).
         __syncthreads();
-        volatile int *flag = (volatile int *)(lds + kTbl + 8 * kEpiStride);     // past the eight waves' epilogue tiles
+        volatile int *flag = (volatile int *)(lds + a0 + 8 * kEpiStride);     // past the eight waves' epilogue tiles
         if (w == 0 && l == 0) *flag = 0;
         __syncthreads();
-        if (flags & 1u) *flag = 1;
+        if ((flags & 1u) && ABL == 0) *flag = 1;
         __syncthreads();
         if (*flag) return true;
 
@@ -368,6 +499,7 @@ struct LinearFqt {
         return false;
     }
 };
+
 
 // The redo path of a tile that met a flagged row: every weight goes through the value map itself.  Plain loops, operands
 // straight from global memory, one 16 x 16 output tile at a time -- only ever taken for weights outside the rows the table
@@ -410,7 +542,7 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
     }
 }
 
-template <int NB, bool SROWS>
+template <int NB, bool SROWS, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_t[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -429,24 +561,27 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFqt<NB, SROWS>;
+    using L = LinearFqt<NB, SROWS, ABL>;
+    if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map below is written in absolute addresses
     bool redo;
+#define QT_RUN(N) L::template run<N>(a, lds_t, m0, tg0, nt, jbase, w, l)
     switch (ntw) {                                          // wave-uniform
-        case 0: redo = L::template run<0>(a, lds_t, m0, tg0, nt, jbase, w, l); break;
-        case 1: redo = L::template run<1>(a, lds_t, m0, tg0, nt, jbase, w, l); break;
-        case 2: redo = L::template run<2>(a, lds_t, m0, tg0, nt, jbase, w, l); break;
-        case 3: if constexpr (NB >= 2) { redo = L::template run<3>(a, lds_t, m0, tg0, nt, jbase, w, l); break; }
-        case 4: if constexpr (NB >= 2) { redo = L::template run<4>(a, lds_t, m0, tg0, nt, jbase, w, l); break; }
-        case 5: if constexpr (NB >= 3) { redo = L::template run<5>(a, lds_t, m0, tg0, nt, jbase, w, l); break; }
-        case 6: if constexpr (NB >= 3) { redo = L::template run<6>(a, lds_t, m0, tg0, nt, jbase, w, l); break; }
-        case 7: if constexpr (NB >= 4) { redo = L::template run<7>(a, lds_t, m0, tg0, nt, jbase, w, l); break; }
+        case 0: redo = QT_RUN(0); break;
+        case 1: redo = QT_RUN(1); break;
+        case 2: redo = QT_RUN(2); break;
+        case 3: if constexpr (NB >= 2) { redo = QT_RUN(3); break; }
+        case 4: if constexpr (NB >= 2) { redo = QT_RUN(4); break; }
+        case 5: if constexpr (NB >= 3) { redo = QT_RUN(5); break; }
+        case 6: if constexpr (NB >= 3) { redo = QT_RUN(6); break; }
+        case 7: if constexpr (NB >= 4) { redo = QT_RUN(7); break; }
         default:
-            if constexpr (NB >= 4) redo = L::template run<8>(a, lds_t, m0, tg0, nt, jbase, w, l);
-            else if constexpr (NB >= 3) redo = L::template run<6>(a, lds_t, m0, tg0, nt, jbase, w, l);
-            else if constexpr (NB >= 2) redo = L::template run<4>(a, lds_t, m0, tg0, nt, jbase, w, l);
-            else redo = L::template run<2>(a, lds_t, m0, tg0, nt, jbase, w, l);
+            if constexpr (NB >= 4) redo = QT_RUN(8);
+            else if constexpr (NB >= 3) redo = QT_RUN(6);
+            else if constexpr (NB >= 2) redo = QT_RUN(4);
+            else redo = QT_RUN(2);
             break;
     }
+#undef QT_RUN
     if (redo) slow_tile(a, m0, tg0, jbase, ntw, w, l);
 }
 
@@ -460,16 +595,16 @@ int cu_count() {
     return n;
 }
 
-template <int NB, bool SROWS>
+template <int NB, bool SROWS, int ABL = 0>
 int launch_nb(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFqt<NB, SROWS>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<NB, SROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fqt_kernel<NB, SROWS><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fqt_kernel<NB, SROWS, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -479,6 +614,17 @@ int launch(const Args &a, hipStream_t st) {
     if (a.nb <= 1) return launch_nb<1, SROWS>(a, st);
     if (a.nb <= 2) return launch_nb<2, SROWS>(a, st);
     if (a.nb <= 3) return launch_nb<3, SROWS>(a, st);
+    if constexpr (!SROWS) {
+        const char *e_abl = getenv("QT_FQT_ABLATE");       // timing experiments (tools/exp_linear_fqt.py --skip-checks): results are garbage
+        switch (e_abl ? atoi(e_abl) : 0) {
+            case 1: return launch_nb<4, false, 1>(a, st);
+            case 2: return launch_nb<4, false, 2>(a, st);
+            case 3: return launch_nb<4, false, 3>(a, st);
+            case 5: return launch_nb<4, false, 5>(a, st);
+            case 6: return launch_nb<4, false, 6>(a, st);
+            default: break;
+        }
+    }
     return launch_nb<4, SROWS>(a, st);
 }
 
@@ -510,7 +656,7 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     // column tiles: as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than max_nt groups
     const char *e_tn = getenv("QT_FQT_TILES_N"), *e_nt = getenv("QT_FQT_MAX_NT");       // tuning / A-B switches
     const int force_tn = e_tn ? atoi(e_tn) : 0;
-    const int hard_nt = signed_rows ? 14 : 15;
+    const int hard_nt = signed_rows ? 14 : 15;      // LDS: table + 2 activation stages + 3 weight stages of hard_nt groups
     int max_nt = e_nt ? atoi(e_nt) : hard_nt;
     if (max_nt < 1 || max_nt > hard_nt) max_nt = hard_nt;
     const int cus = cu_count();
