@@ -3,25 +3,30 @@
 // Replaces   F.linear(input, self.weight_fake_quant(self.weight), self.bias)       modules/qat/linear.py:40-41
 // for stateless weight fake-quantizers whose format is not FP8-exact (posit(n, es), intN, fp6 / fp4, ...: fake_quantize.py:31-95):
 //   * the activation arrives as the bf16 VALUES of fq(x) (the elementwise pass or a producer kernel wrote them);
-//   * the bf16 weight is read ONCE from HBM, unquantized; a lane loads 8 weights, sends each through the ROW FORM of the value
-//     map (below) and writes the 8 quantized bf16 values into an LDS tile -- fq(W) never exists in HBM;
+//   * the bf16 weight is read ONCE from HBM, unquantized, straight into LDS (global_load_lds); the wave that requested a piece
+//     sends its 16 bytes per lane through the ROW FORM of the value map (below) and writes the quantized bf16 values back IN
+//     PLACE, one k step before the tile is multiplied -- fq(W) never exists in HBM;
 //   * v_mfma_f32_16x16x32_bf16 on the quantized operands: products of quantized values are exactly the reference's bf16
 //     products, fp32 accumulation, bias and the bf16 rounding in the epilogue.
 //
 // Row form (qt_build_rowparams, csrc/qt_host.cpp): the 128 bf16 patterns that share an exponent are one row of the map, and
 // within a row the map is a round-to-nearest-even onto a power-of-two grid plus a clamp,
 //     t = f32(|x| bits + D);   y = med3((t + C) - C, lo, hi);   sign of x copied back            D, C, lo, hi: 16 bytes per row
-// i.e. 8.5 vector instructions and one 16-byte LDS read (256 rows = 4 KiB, mostly broadcast: the weights of a tile live in a
+// i.e. 8 vector instructions and one 16-byte LDS read (256 rows = 4 KiB, mostly broadcast: the weights of a tile live in a
 // dozen exponents) per weight instead of a gather from the 128 KiB map, which would not fit beside the operand rings.  The
 // builder verifies each row against the map on all of its inputs; rows that do not fit are flagged (bit 0 of C), lanes OR the
 // C words they read, and a workgroup that met a flagged row redoes its tile with the map itself (slow_tile) -- bit-exact for
 // every bf16 weight.  Flagged in practice: non-finite inputs and a few rows beyond 2^22 / below 2^-38 of some posits.
 //
-// Work decomposition as in qt_linear_fq8.hip (variant R): a workgroup owns 256 rows x (16 nt) columns, nt <= 15, chosen so
-// that the grid is a whole number of rounds over the CUs; 8 waves = 4 row bands x 2 column halves; up to four weights sharing
-// one activation are the segments of one launch; tile ids dealt so that the row tiles of a column tile share an XCD.
-// LDS: row table 4 / 8 KiB | activation ring (3 x 32 KiB: 256 rows x 64 bf16, 16-byte chunks XOR-swizzled by row, filled by
-// LDS-DMA) | quantized weight ring (2 x nt x 2 KiB, same layout, filled by ds_write_b128).  One raw barrier per k step.
+// Work decomposition.  A workgroup owns TM rows x (16 nt) columns, TM = 512 (nt <= 8) where that fills the chip, else 256
+// (nt <= 16): every weight is converted once per ROW TILE, so tall tiles halve the conversion work, and with k steps of 32 a
+// stage is small (activations TM x 64 bytes, weights nt KiB), which buys rings deep enough to cover the memory latency -- three
+// activation stages, five weight stages (multiplied | converted | three landing).  8 waves = 4 row bands x 2 column halves; the
+// host picks the column widths so that the grid is a whole number of rounds over the CUs; up to four weights sharing one
+// activation are the segments of one launch; tile ids are dealt so that the row tiles of a column tile share an XCD.
+// LDS: row table 4 / 8 KiB | activation ring | weight ring | 1 KiB dummy; rows of 64 bytes (32 bf16), 16-byte chunk p of row R
+// holds k chunk p ^ pi((R >> 2) & 3) so that a fragment's sixteen rows x one chunk spread over all 64 banks.  One raw barrier per
+// k step; every global access in the loop is an LDS-DMA and every wait a counted one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,11 +43,9 @@ typedef short v8s __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int kTM = 256, kBK = 64, kRowBytes = 128, kMaxSeg = 4;
-constexpr int kABytes = kTM * kRowBytes;            // one activation tile: 32 KiB of bf16
-constexpr int kGroupBytes = 16 * kRowBytes;         // one 16-row column group of a weight tile: 2 KiB
+constexpr int kBK = 32, kRowBytes = 64, kMaxSeg = 4;
+constexpr int kGroupBytes = 16 * kRowBytes;         // one 16-row group of a tile = one DMA piece: 1 KiB
 
 struct Segment {
     const uint16_t *w;        // [n][K] bf16
@@ -56,10 +59,10 @@ struct Args {
     const uint32_t *rows;     // [512][4] row parameters (device)
     const uint16_t *map;      // [65536] value map (device): the redo path
     uint32_t sign_mask;
+    unsigned long long *dbg; // ABL 9 (QT_FQT_STAMPS = device address): s_memtime stamps of workgroup 0, waves 0 and 4, k step 40
     int M, K, ldc;
     int tiles_m, tiles_n, nseg;
     int gbase, gextra;        // column tile j covers gbase (+1 for gextra of them) groups of 16 columns
-    int nb;                   // weight pieces (8 rows x 128 bytes) per wave and k step the widest tile needs
     Segment seg[kMaxSeg];
 };
 
@@ -90,8 +93,11 @@ __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
     return v;
 }
 
-// both operand tiles: row-major 128-byte rows (64 bf16), 16-byte chunk index XOR ((row >> 1) & 7)
-__device__ __forceinline__ int chunk_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Both operand tiles: row-major 64-byte rows (32 bf16 = four 16-byte k chunks).  A fragment read is sixteen rows x one chunk per
+// 16-lane group of ds_read_b128; rows four apart share a bank row, so chunk c of row R sits at position c ^ pi((R >> 2) & 3),
+// pi = (0, 2, 3, 1): the four (row quad, chunk) combinations a lane group reads land on four different positions.
+__device__ __forceinline__ int chunk_pos(int row, int chunk) { return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
+__device__ __forceinline__ int chunk_off(int row, int chunk) { return row * kRowBytes + (chunk_pos(row, chunk) << 4); }
 
 // ---- the row form on registers ---------------------------------------------------------------------------------------------
 // A table row is {D, C (bit 0: flagged), lo, hi}; the table sits at LDS address 0, so a row's address is (bits >> 7) << 4.
@@ -119,17 +125,19 @@ __device__ __forceinline__ uint32_t quant_pair(uint32_t x, const u32x4 &p0, cons
 }
 
 // The LDS operations of one wave and k step, in issue order (they complete in that order, which is what makes counted waits
-// possible).  A "unit" is half a weight piece of the lane: 4 weights = 2 packed words = 4 table rows.
+// possible).  A "unit" is half a weight piece of the lane: 4 weights = 2 packed words = 4 table rows.  RT = row tiles of a wave.
+//     FA x RT, RB(0), RB(1)     activation fragments of the step, weight fragments of column groups 0 and 1
 //     RAW x NB                  the lane's 16 raw bytes of each of its pieces (weight tile t+1)
-//     FA x 8, RB(0) x 2, RB(1) x 2     activation fragments of the step, weight fragments of column groups 0 and 1
-//     [wait RAW(0)]  G(0) x 4   table rows of unit 0
-//     per column group J:  RB(J+2) x 2;  [wait FA / RB(J)];  then per unit u the group carries:
-//                          G(u+1) x 4;  [wait G(u)];  (arithmetic of unit u);  WR(u) x 1      -- and the group's 8 multiplications
+//     per column group J:  RB(J+2);  [wait FA / RB(J)];  the group's RT multiplications;  in group 0: [wait RAW] G(0) x 4, the table
+//                          rows of unit 0;  then per unit u whose slot the group carries:
+//                          G(u+1) x 4;  [wait G(u)];  (arithmetic of unit u, under the multiplications);  WR(u) x 1
 // walk() replays that order and returns how many operations were issued after the last one of (from_kind, from_idx) when the
 // wait (to_kind, to_idx) is reached: the lgkmcnt that wait may leave outstanding.
 enum { kOpRaw = 0, kOpFA = 1, kOpRB = 2, kOpG = 3, kOpWR = 4, kWaitRaw = 10, kWaitF = 11, kWaitG = 12 };
 constexpr int unit_group(int u, int NTW, int U) { return NTW > 0 ? u * NTW / U : 0; }
-constexpr int walk(int NTW, int NB, int from_kind, int from_idx, int to_kind, int to_idx) {
+// the column group whose multiplications cover unit u's arithmetic: one behind the group that requested its rows
+constexpr int slot_group(int u, int NTW, int U) { return NTW > 0 ? (unit_group(u, NTW, U) + 1 < NTW ? unit_group(u, NTW, U) + 1 : NTW - 1) : 0; }
+constexpr int walk(int RT, int NTW, int NB, int from_kind, int from_idx, int to_kind, int to_idx) {
     const int U = 2 * NB;
     int n = -1;
     bool done = false;
@@ -141,21 +149,23 @@ constexpr int walk(int NTW, int NB, int from_kind, int from_idx, int to_kind, in
     auto wait = [&](int kind, int idx) {
         if (!done && kind == to_kind && idx == to_idx) { result = n; done = true; }
     };
-    for (int i = 0; i < NB; ++i) op(kOpRaw, i, 1);
     if (NTW > 0) {
-        op(kOpFA, 0, 8);
-        op(kOpRB, 0, 2);
-        if (NTW > 1) op(kOpRB, 1, 2);
+        op(kOpFA, 0, RT);
+        op(kOpRB, 0, 1);
+        if (NTW > 1) op(kOpRB, 1, 1);
     }
-    wait(kWaitRaw, 0);
-    op(kOpG, 0, 4);
+    for (int i = 0; i < NB; ++i) op(kOpRaw, i, 1);
     for (int J = 0; J < (NTW > 0 ? NTW : 1); ++J) {
         if (NTW > 0) {
-            if (J + 2 < NTW) op(kOpRB, J + 2, 2);
+            if (J + 2 < NTW) op(kOpRB, J + 2, 1);
             wait(kWaitF, J);
         }
+        if (J == 0) {
+            wait(kWaitRaw, 0);
+            op(kOpG, 0, 4);
+        }
         for (int u = 0; u < U; ++u) {
-            if (unit_group(u, NTW, U) != J) continue;
+            if (slot_group(u, NTW, U) != J) continue;
             if (u + 1 < U) op(kOpG, u + 1, 4);
             wait(kWaitG, u);
             op(kOpWR, u, 1);
@@ -168,38 +178,47 @@ constexpr int walk(int NTW, int NB, int from_kind, int from_idx, int to_kind, in
 // ABL (timing experiments only, QT_FQT_ABLATE; results are garbage): 1 no multiplications, 2 no weight items at all, 3 no
 // activation DMA, 5 weight items without the conversion (DMA, LDS round trip), 6 conversion without the table gathers
 //
-// NB: weight pieces (8 rows x 128 bytes of bf16) per wave and k step (1-4: tiles of up to 4, 8, 12, 15 column groups);
-// SROWS: the table has 512 rows (sign and exponent).
+// TM: rows of a workgroup's tile (512 or 256); NB: weight pieces (16 rows x 64 bytes = one column group) per wave and k step
+// (1: tiles of up to 8 groups, 2: up to 16); SROWS: the table has 512 rows (sign and exponent).
 //
 // k step t of a wave (every LDS / DMA operation is inline asm, every wait a computed count):
-//   top      s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      everything requested during step t-1 has landed, every wave's converted
+//   top      s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier      the activation tile of step t and this wave's raw pieces of weight tile
+//                                                          t+1 have landed (requested two / three steps ago), every wave's converted
 //                                                          weights of step t are written, every wave is done with step t-1
-//   first    request the activation tile of step t+1 (ring of 2) and the RAW weight tile of step t+2 (ring of 3): 4 + NB DMA
-//            pieces, all in front, so that they have the whole step to land
-//   then     the LDS stream above: 8 multiplications per column group on tile t, and 2 NB units of weight tile t+1 converted IN
+//   first    request activation tile t+2 and RAW weight tile t+4
+//   then     the LDS stream above: RT multiplications per column group on tile t, and 2 NB units of weight tile t+1 converted IN
 //            PLACE, spread evenly over the groups; the rows of unit u+1 are in flight while unit u is computed
-template <int NB, bool SROWS, int ABL = 0>
+template <int TM, int NB, bool SROWS, int ABL = 0>
 struct LinearFqt {
-    static constexpr int kADepth = 2, kWDepth = 3, kU = 2 * NB;
-    static constexpr int kMaxNT = NB * 4 < 15 ? NB * 4 : (SROWS ? 14 : 15);
+    static constexpr int kDA = 3, kDW = 5, kU = 2 * NB;
+    static constexpr int kRT = TM / 64;                     // 16-row tiles of a wave's row band (TM / 4 rows)
+    static constexpr int kPA = TM / 128;                    // activation DMA pieces (16 rows) per wave and step
+    static constexpr int kMaxNT = 8 * NB, kMaxNTW = 4 * NB;
+    static constexpr int kABytes = TM * kRowBytes, kWBytes = kMaxNT * kGroupBytes;
     static constexpr int kTbl = SROWS ? 8192 : 4096;
-    static constexpr int kWBytes = kMaxNT * kGroupBytes;
-    static constexpr int kDummy = 1024;                     // where surplus pieces go (a tile of 15 groups has 30, the waves request 32)
-    static constexpr int kLds = kTbl + kADepth * kABytes + kWDepth * kWBytes + kDummy;
+    static constexpr int kDummy = 1024;                     // where surplus pieces go
+    static constexpr int kRings = kDA * kABytes + kDW * kWBytes;
+    static constexpr int kEpiStride = 64 * (kMaxNTW * 32 + 8);           // a wave's epilogue tile (64 rows at a time) in LDS
+    static constexpr int kLds = kTbl + (kRings + kDummy > 8 * kEpiStride ? kRings + kDummy : 8 * kEpiStride);
     static_assert(kLds <= 160 * 1024, "LDS budget");
+    static_assert(kRT * kMaxNTW * 4 <= 128, "accumulators");
     static constexpr uint32_t kRowMask = SROWS ? 0x1FF0u : 0xFF0u;
-    static constexpr int kEpiStride = 64 * ((2 * NB < 8 ? 2 * NB : 8) * 32 + 8);      // a wave's epilogue tile in LDS
-    static_assert(8 * kEpiStride + 16 <= kADepth * kABytes + kWDepth * kWBytes, "epilogue tiles fit in the dead rings");
+    // What the top-of-step wait may leave in flight.  A step issues kPA activation pieces, then NB weight pieces; the activation
+    // tile of step t was requested kDA - 1 steps earlier (younger: that step's weight pieces and kDA - 2 whole steps), the raw
+    // weight tile t+1 kDW - 2 steps earlier (younger: kDW - 3 whole steps).
+    static constexpr int kVmA = NB + (kDA - 2) * (kPA + NB), kVmW = (kDW - 3) * (kPA + NB);
+    static constexpr int kVmTop = kVmA < kVmW ? kVmA : kVmW;
+    static constexpr int kWeave = 5;                         // vector instructions the scheduler is asked to put behind each multiplication
 
-    // One wave's share: rows [wm * 64, +64) x NTW column groups starting at group jbase of the tile whose first group is tg0.
-    // Returns true when a flagged row was met (the caller redoes the tile).
+    // One wave's share: rows [wm * TM / 4, + TM / 4) x NTW column groups starting at group jbase of the tile whose first group is
+    // tg0.  Returns true when a flagged row was met (the caller redoes the tile).
     template <int NTW>
     static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
         const int r = l & 15, g = l >> 4, wm = w & 3;
         const int nk = a.K / kBK, klast = nk - 1;
         const long krow = (long)a.K * 2;                        // bytes per row of x and W
         // LDS map (the dynamic segment starts at address 0: the kernel has no static LDS)
-        constexpr uint32_t a0 = kTbl, w0 = a0 + kADepth * kABytes, dummy = w0 + kWDepth * kWBytes;
+        constexpr uint32_t a0 = kTbl, w0 = a0 + kDA * kABytes, dummy = w0 + kDW * kWBytes;
         // ---- the row table into LDS (every thread one 16-byte row)
         {
             const int t = w * 64 + l;
@@ -208,58 +227,80 @@ struct LinearFqt {
                 asm volatile("ds_write_b128 %0, %1" ::"v"(t * 16), "v"(v) : "memory");
             }
         }
-        // ---- DMA sources: a scalar base (advanced by 128 bytes per k tile) + a 32-bit lane offset; LDS destinations are
-        // wave-uniform.  Activations: 32 pieces of 8 rows x 128 bytes, four per wave.
-        uint32_t ga[4];
+        // ---- DMA sources: a scalar base (advanced by 64 bytes per k tile) + a 32-bit lane offset; LDS destinations are
+        // wave-uniform.  A piece is 16 rows x 64 bytes: lane = (row l >> 2, position l & 3).
+        uint32_t ga[kPA];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
-            ga[i] = (uint32_t)((long)min(m0 + row, a.M - 1) * krow) + ((slot ^ ((row >> 1) & 7)) << 4);
+        for (int i = 0; i < kPA; ++i) {
+            const int row = (w * kPA + i) * 16 + (l >> 2);
+            ga[i] = (uint32_t)((long)min(m0 + row, a.M - 1) * krow) + (chunk_pos(row, l & 3) << 4);
         }
-        // Weight pieces: piece p = w + 8 i covers rows 8 p .. 8 p + 7 of the tile; the lane's 16 bytes land at piece base + 16 l and
-        // are converted there.  Surplus pieces (p >= 2 nt) re-request piece w & 1 into the dummy kilobyte.
-        const int npieces = nt * 2;
+        // Weight pieces: piece p = w + 8 i is column group p of the tile; the lane's 16 bytes land at piece base + 16 l and are
+        // converted there.  Surplus pieces (p >= nt) re-request piece 0 into the dummy kilobyte.
         uint32_t gw[NB];
         const uint16_t *wbase[NB];                             // wave-uniform
-        uint32_t wofs[NB];                                     // piece base inside a weight stage (or the dummy), wave-uniform
+        uint32_t wofs[NB];
         bool real[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int p = w + 8 * i;
-            real[i] = p < npieces;
-            const int pb = real[i] ? p : (w & 1);
-            const int grp = tg0 + (pb >> 1);
-            const int row = pb * 8 + (l >> 3), slot = l & 7;
+            real[i] = p < nt;
+            const int pb = real[i] ? p : 0;
+            const int grp = tg0 + pb;
+            const int row = pb * 16 + (l >> 2);
             const SegRef sg = seg_lookup(a, grp);
             wbase[i] = sg.w;
-            gw[i] = (uint32_t)((long)((grp - sg.g0) * 16 + (pb & 1) * 8 + (l >> 3)) * krow) + ((slot ^ ((row >> 1) & 7)) << 4);
-            wofs[i] = real[i] ? (uint32_t)pb * 1024u : 0xFFFFFFFFu;
+            gw[i] = (uint32_t)((long)((grp - sg.g0) * 16 + (l >> 2)) * krow) + (chunk_pos(row, l & 3) << 4);
+            wofs[i] = (uint32_t)pb * 1024u;
         }
         uint32_t flags = 0;
         const uint32_t sign_mask = a.sign_mask;
+        int stamp_kt = -1;
+        auto stamp = [&](int slot) __attribute__((always_inline)) {
+            if constexpr (ABL == 9) {
+                if (stamp_kt == 40 && blockIdx.x == 0 && (w == 0 || w == 4) && l == 0) a.dbg[(w >> 2) * 32 + slot] = __builtin_amdgcn_s_memtime();
+            }
+        };
         auto dma16 = [](const void *base, uint32_t off, uint32_t dst) __attribute__((always_inline)) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
         };
         auto ds_write64 = [](uint32_t addr, u32x2 v) __attribute__((always_inline)) {
             asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
         };
-        // all of a step's requests: activation tile ka into stage `as`, raw weight tile kb into stage `ws`
-        auto request = [&](int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
-            if constexpr (ABL != 3) {
+        // a step's requests: activation tile ka into stage `as`, raw weight tile kb into stage `ws` -- kPA + NB DMA instructions,
+        // always in this order (the counted waits rely on it)
+        auto req_piece = [&](auto ic, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I < kPA) {
                 const uint8_t *xb = (const uint8_t *)a.x + (long)ka * kRowBytes;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dma16(xb, ga[i], as + (w * 4 + i) * 1024);
-            }
-            if constexpr (ABL != 2) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) dma16((const uint8_t *)wbase[i] + (long)kb * kRowBytes, gw[i], real[i] ? ws + wofs[i] : dummy);
+                if constexpr (ABL != 3) dma16(xb, ga[I], as + (w * kPA + I) * 1024);
+                else dma16(xb, ga[I], dummy);
+            } else {
+                constexpr int i = I - kPA;
+                dma16((const uint8_t *)wbase[i] + (long)kb * kRowBytes, gw[i], (real[i] && ABL != 2) ? ws + wofs[i] : dummy);
             }
         };
-        // the lane's 16 bytes of piece i, relative to a weight stage (surplus pieces: relative address of the dummy from stage 0;
-        // they are only ever read and written by this lane, whatever the stage)
+        auto req_range = [&](auto lo, auto hi, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            static_assert(HI - LO <= 6, "at most six pieces");
+            if constexpr (LO + 0 < HI) req_piece(std::integral_constant<int, LO + 0>{}, ka, as, kb, ws);
+            if constexpr (LO + 1 < HI) req_piece(std::integral_constant<int, LO + 1>{}, ka, as, kb, ws);
+            if constexpr (LO + 2 < HI) req_piece(std::integral_constant<int, LO + 2>{}, ka, as, kb, ws);
+            if constexpr (LO + 3 < HI) req_piece(std::integral_constant<int, LO + 3>{}, ka, as, kb, ws);
+            if constexpr (LO + 4 < HI) req_piece(std::integral_constant<int, LO + 4>{}, ka, as, kb, ws);
+            if constexpr (LO + 5 < HI) req_piece(std::integral_constant<int, LO + 5>{}, ka, as, kb, ws);
+        };
+        constexpr int kReq = kPA + NB;
+        auto request = [&](int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
+            req_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kReq>{}, ka, as, kb, ws);
+        };
+        // the lane's 16 bytes of piece i, relative to a weight stage (surplus pieces: the dummy, whatever the stage)
         uint32_t pofs[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pofs[i] = (real[i] ? wofs[i] : dummy - w0) + (uint32_t)l * 16u;
+        for (int i = 0; i < NB; ++i) pofs[i] = wofs[i] + (uint32_t)l * 16u;
+        auto piece_addr = [&](int i, uint32_t ws) __attribute__((always_inline)) -> uint32_t {
+            return real[i] ? ws + pofs[i] : dummy + (uint32_t)l * 16u;
+        };
         u32x4 raw[NB];
         u32x4 rows[2][4];                                        // table rows of the unit being computed / of the next one
         // ---- the unit stream
@@ -292,7 +333,7 @@ struct LinearFqt {
                     const uint32_t f = (rp[0].y | rp[1].y) | (rp[2].y | rp[3].y);
                     flags |= real[I] ? f : 0u;
                 }
-                ds_write64((real[I] ? wc : w0) + pofs[I] + (U & 1) * 8, q);
+                ds_write64(piece_addr(I, wc) + (U & 1) * 8, q);
             }
         };
         // unit slot: the next unit's rows requested, this unit's rows waited for, computed, written back
@@ -300,7 +341,7 @@ struct LinearFqt {
             constexpr int U = decltype(uc)::value;
             if constexpr (U + 1 < kU) unit_gather(std::integral_constant<int, U + 1>{});
             if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
-                constexpr int n = walk(NTW, NB, kOpG, U, kWaitG, U);
+                constexpr int n = walk(kRT, NTW, NB, kOpG, U, kWaitG, U);
                 static_assert(n >= 0, "schedule");
                 asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rows[U & 1][0]), "+v"(rows[U & 1][1]), "+v"(rows[U & 1][2]), "+v"(rows[U & 1][3]) : "n"(n));
             }
@@ -309,94 +350,105 @@ struct LinearFqt {
         // the units column group J carries
         auto units_of = [&](auto jc, uint32_t wc) __attribute__((always_inline)) {
             constexpr int J = decltype(jc)::value;      // (+ 0 * J below: the calls must depend on J, or every one is instantiated)
-            if constexpr (0 < kU && unit_group(0, NTW, kU) == J) unit_slot(std::integral_constant<int, 0 + 0 * J>{}, wc);
-            if constexpr (1 < kU && unit_group(1, NTW, kU) == J) unit_slot(std::integral_constant<int, 1 + 0 * J>{}, wc);
-            if constexpr (2 < kU && unit_group(2, NTW, kU) == J) unit_slot(std::integral_constant<int, 2 + 0 * J>{}, wc);
-            if constexpr (3 < kU && unit_group(3, NTW, kU) == J) unit_slot(std::integral_constant<int, 3 + 0 * J>{}, wc);
-            if constexpr (4 < kU && unit_group(4, NTW, kU) == J) unit_slot(std::integral_constant<int, 4 + 0 * J>{}, wc);
-            if constexpr (5 < kU && unit_group(5, NTW, kU) == J) unit_slot(std::integral_constant<int, 5 + 0 * J>{}, wc);
-            if constexpr (6 < kU && unit_group(6, NTW, kU) == J) unit_slot(std::integral_constant<int, 6 + 0 * J>{}, wc);
-            if constexpr (7 < kU && unit_group(7, NTW, kU) == J) unit_slot(std::integral_constant<int, 7 + 0 * J>{}, wc);
+            if constexpr (0 < kU && slot_group(0, NTW, kU) == J) unit_slot(std::integral_constant<int, 0 + 0 * J>{}, wc);
+            if constexpr (1 < kU && slot_group(1, NTW, kU) == J) unit_slot(std::integral_constant<int, 1 + 0 * J>{}, wc);
+            if constexpr (2 < kU && slot_group(2, NTW, kU) == J) unit_slot(std::integral_constant<int, 2 + 0 * J>{}, wc);
+            if constexpr (3 < kU && slot_group(3, NTW, kU) == J) unit_slot(std::integral_constant<int, 3 + 0 * J>{}, wc);
         };
+        static_assert(kU <= 4, "units_of lists four units");
         // the step's first LDS operations: raw pieces of the tile to convert (stage wc)
         auto read_raw = [&](uint32_t wc) __attribute__((always_inline)) {
             if constexpr (ABL != 2) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) raw[i] = ds_gather128((real[i] ? wc : w0) + pofs[i]);
+                for (int i = 0; i < NB; ++i) raw[i] = ds_gather128(piece_addr(i, wc));
             }
         };
-        // wait for raw[0] (and hand every raw register to the compiler as defined), then the first unit's rows
+        // wait for raw[0], then the first unit's rows
         auto first_rows = [&]() __attribute__((always_inline)) {
             if constexpr (ABL != 2) {
-                constexpr int n = walk(NTW, NB, kOpRaw, 0, kWaitRaw, 0);
+                constexpr int n = walk(kRT, NTW, NB, kOpRaw, NB - 1, kWaitRaw, 0);
                 static_assert(n >= 0, "schedule");
-                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[0]) : "n"(n));
+                if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(raw[0]), "+v"(raw[1]) : "n"(n));
+                else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[0]) : "n"(n));
                 unit_gather(std::integral_constant<int, 0>{});
             }
         };
-        // the other raw registers are older than the activation fragments: valid once those are (group 0's wait)
-        auto raws_defined = [&]() __attribute__((always_inline)) {
-            if constexpr (ABL != 2) {
-                if constexpr (NB == 2) asm volatile("" : "+v"(raw[1]));
-                if constexpr (NB == 3) asm volatile("" : "+v"(raw[1]), "+v"(raw[2]));
-                if constexpr (NB == 4) asm volatile("" : "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
-            }
-        };
+        static_assert(NB <= 2, "first_rows lists two pieces");
 
-        v4f acc[4][NTW > 0 ? NTW : 1];
+        v4f acc[kRT][NTW > 0 ? NTW : 1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < kRT; ++i)
 #pragma unroll
             for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-        // lane-constant parts of the fragment addresses: k sub-step 0 = chunks 0..3, sub-step 1 = chunks 4..7
-        const uint32_t a_lo = chunk_off(wm * 64 + r, g), a_hi = chunk_off(wm * 64 + r, 4 + g);
-        const uint32_t b_lo = chunk_off(jbase * 16 + r, g), b_hi = chunk_off(jbase * 16 + r, 4 + g);
+        // lane-constant parts of the fragment addresses (row tiles and column groups are 16 rows = 1 KiB apart)
+        const uint32_t a_frag = chunk_off(wm * (TM / 4) + r, g), b_frag = chunk_off(jbase * 16 + r, g);
 
         // multiplications of step t on (sa_, sb_); conversion of the raw weight tile in stage wc
-        auto compute = [&](uint32_t sa_, uint32_t sb_, uint32_t wc) __attribute__((always_inline)) {
-            read_raw(wc);
+        auto compute = [&](uint32_t sa_, uint32_t sb_, uint32_t wc, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
+            stamp(1);
             if constexpr (NTW > 0) {
-                u32x4 fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
-                fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
-                fa_lo[1] = ds_read128<1 * 2048>(sa_ + a_lo); fa_hi[1] = ds_read128<1 * 2048>(sa_ + a_hi);
-                fa_lo[2] = ds_read128<2 * 2048>(sa_ + a_lo); fa_hi[2] = ds_read128<2 * 2048>(sa_ + a_hi);
-                fa_lo[3] = ds_read128<3 * 2048>(sa_ + a_lo); fa_hi[3] = ds_read128<3 * 2048>(sa_ + a_hi);
+                u32x4 fa[kRT], fb[3];
+                fa[0] = ds_read128<0 * 1024>(sa_ + a_frag);
+                fa[1] = ds_read128<1 * 1024>(sa_ + a_frag);
+                fa[2] = ds_read128<2 * 1024>(sa_ + a_frag);
+                fa[3] = ds_read128<3 * 1024>(sa_ + a_frag);
+                if constexpr (kRT > 4) {
+                    fa[4] = ds_read128<4 * 1024>(sa_ + a_frag);
+                    fa[5] = ds_read128<5 * 1024>(sa_ + a_frag);
+                    fa[6] = ds_read128<6 * 1024>(sa_ + a_frag);
+                    fa[7] = ds_read128<7 * 1024>(sa_ + a_frag);
+                }
                 auto read_b = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
-                    fb_lo[J % 3] = ds_read128<J * 2048>(sb_ + b_lo);
-                    fb_hi[J % 3] = ds_read128<J * 2048>(sb_ + b_hi);
+                    fb[J % 3] = ds_read128<J * 1024>(sb_ + b_frag);
                 };
                 auto step = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
                     constexpr int P = J % 3;
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
-                    constexpr int kAhead = walk(NTW, NB, kOpRB, J, kWaitF, J);
+                    constexpr int kAhead = walk(kRT, NTW, NB, kOpRB, J, kWaitF, J);
                     static_assert(kAhead >= 0, "schedule");
                     if constexpr (J == 0) {
-                        asm volatile("s_waitcnt lgkmcnt(%10)"
-                                     : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]), "+v"(fa_lo[3]),
-                                       "+v"(fa_hi[3]), "+v"(fb_lo[0]), "+v"(fb_hi[0])
-                                     : "n"(kAhead));
-                        raws_defined();
+                        if constexpr (kRT > 4) {
+                            asm volatile("s_waitcnt lgkmcnt(%9)"
+                                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]), "+v"(fb[0])
+                                         : "n"(kAhead));
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]) : "n"(kAhead));
+                        }
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb_lo[P]), "+v"(fb_hi[P]) : "n"(kAhead));
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[P]) : "n"(kAhead));
                     }
-                    units_of(jc, wc);
-                    const v8s bl = __builtin_bit_cast(v8s, fb_lo[P]), bh = __builtin_bit_cast(v8s, fb_hi[P]);
+                    stamp(4 + 3 * J);
+                    // operands swapped: D rows = W rows (output columns), D columns = x rows -- a lane ends up with four
+                    // consecutive output columns of one row.  The multiplications come first in program order; the vector work
+                    // of the group (a unit's arithmetic, the next unit's row addresses) is woven between them below.
+                    const v8s bf = __builtin_bit_cast(v8s, fb[P]);
                     if constexpr (ABL != 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, __builtin_bit_cast(v8s, fa_lo[i]), acc[i][J], 0, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, __builtin_bit_cast(v8s, fa_hi[i]), acc[i][J], 0, 0, 0);
+                        for (int i = 0; i < kRT; ++i)
+                            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(v8s, fa[i]), acc[i][J], 0, 0, 0);
                     }
+                    stamp(5 + 3 * J);
+                    if constexpr (J == 0) first_rows();
+                    units_of(jc, wc);
+                    // this group's share of the step's requests
+                    req_range(std::integral_constant<int, J * kReq / NTW>{}, std::integral_constant<int, (J + 1) * kReq / NTW>{}, ka, as, kb, ws);
+                    if constexpr (ABL != 1 && kWeave > 0) {
+#pragma unroll
+                        for (int i = 0; i < kRT; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one multiplication
+                            __builtin_amdgcn_sched_group_barrier(0x002, kWeave, 0);     // kWeave vector instructions
+                        }
+                    }
+                    stamp(6 + 3 * J);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 read_b(std::integral_constant<int, 0>{});
                 if constexpr (NTW > 1) read_b(std::integral_constant<int, 1>{});
-                first_rows();
+                read_raw(wc);
+                stamp(2);
                 step(std::integral_constant<int, 0>{});
                 if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
                 if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
@@ -406,26 +458,25 @@ struct LinearFqt {
                 if constexpr (NTW > 6) step(std::integral_constant<int, 6>{});
                 if constexpr (NTW > 7) step(std::integral_constant<int, 7>{});
             } else {
+                request(ka, as, kb, ws);
+                read_raw(wc);
                 first_rows();
-                raws_defined();                                   // (only raw[0] was waited for: the unit waits below cover the rest,
-                units_of(std::integral_constant<int, 0>{}, wc);   //  every raw read being older than every gather)
+                units_of(std::integral_constant<int, 0>{}, wc);
             }
         };
 
-        // prologue: table in place (barrier); activations of k tile 0, raw weights of k tiles 0 and 1 requested; this wave's pieces
-        // of weight tile 0 converted as soon as they are here (only the wave that requested a piece touches it before a barrier)
+        // prologue: table in place (barrier); activation tiles 0 .. kDA-2 and raw weight tiles 0 .. kDW-2 requested and landed; this
+        // wave's pieces of weight tile 0 converted (only the wave that requested a piece touches it before a barrier)
         __syncthreads();
-        request(0, a0, 0, w0);
-        if constexpr (ABL != 2) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) dma16((const uint8_t *)wbase[i] + (long)min(1, klast) * kRowBytes, gw[i], real[i] ? w0 + kWBytes + wofs[i] : dummy);
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+        for (int s = 0; s < kDW - 1; ++s)
+            request(min(s < kDA - 1 ? s : kDA - 2, klast), a0 + (s < kDA - 1 ? s : kDA - 2) * kABytes, min(s, klast), w0 + s * kWBytes);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (ABL != 2) {
             // plain and serial: read, gather, compute, write, one piece at a time
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                u32x4 v = ds_gather128((real[i] ? w0 : w0) + pofs[i]);
+                u32x4 v = ds_gather128(piece_addr(i, w0));
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
                 uint32_t ad[8];
                 row_addrs<kRowMask>(v.x, ad[0], ad[1]); row_addrs<kRowMask>(v.y, ad[2], ad[3]);
@@ -438,68 +489,82 @@ struct LinearFqt {
                 q.x = quant_pair(v.x, p[0], p[1], sign_mask); q.y = quant_pair(v.y, p[2], p[3], sign_mask);
                 q.z = quant_pair(v.z, p[4], p[5], sign_mask); q.w = quant_pair(v.w, p[6], p[7], sign_mask);
                 const uint32_t f = (p[0].y | p[1].y | p[2].y) | (p[3].y | p[4].y | p[5].y) | (p[6].y | p[7].y);
-                if constexpr (ABL == 0) flags |= real[i] ? f : 0u;
-                if constexpr (ABL != 0) q = v;
-                asm volatile("ds_write_b128 %0, %1" ::"v"(w0 + pofs[i]), "v"(q) : "memory");
+                if constexpr (ABL == 0 || ABL == 9) flags |= real[i] ? f : 0u;
+                if constexpr (ABL != 0 && ABL != 9) q = v;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(piece_addr(i, w0)), "v"(q) : "memory");
             }
         }
-        int wmul = 0;                                              // weight stage multiplied in this step; +1: converted; +2: requested
+        int sa = 0, sw = 0;                                        // stages multiplied in this step (activations, weights)
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp_kt = kt; stamp(29);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
+            stamp(31);
             __builtin_amdgcn_s_barrier();
-            const int wcv = wmul == 2 ? 0 : wmul + 1, wrq = wcv == 2 ? 0 : wcv + 1;
-            request(min(kt + 1, klast), a0 + ((kt + 1) & 1) * kABytes, min(kt + 2, klast), w0 + wrq * kWBytes);
-            compute(a0 + (kt & 1) * kABytes, w0 + wmul * kWBytes, w0 + wcv * kWBytes);
-            wmul = wcv;
+            stamp_kt = kt;
+            stamp(0);
+            // the stages requested now are the ones multiplied in step t - 1
+            const int sa_req = sa == 0 ? kDA - 1 : sa - 1, sw_req = sw == 0 ? kDW - 1 : sw - 1, sw_cv = sw == kDW - 1 ? 0 : sw + 1;
+            compute(a0 + sa * kABytes, w0 + sw * kWBytes, w0 + sw_cv * kWBytes, min(kt + kDA - 1, klast), a0 + sa_req * kABytes,
+                    min(kt + kDW - 1, klast), w0 + sw_req * kWBytes);
+            stamp(30);
+            sa = sa == kDA - 1 ? 0 : sa + 1;
+            sw = sw_cv;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        // A lane that read a flagged row raises the workgroup's flag (through LDS: the rings are dead here).
+        // A lane that read a flagged row raises the workgroup's flag (through LDS: the table is dead here).
         __syncthreads();
-        volatile int *flag = (volatile int *)(lds + a0 + 8 * kEpiStride);     // past the eight waves' epilogue tiles
+        volatile int *flag = (volatile int *)lds;
         if (w == 0 && l == 0) *flag = 0;
         __syncthreads();
-        if ((flags & 1u) && ABL == 0) *flag = 1;
+        if ((flags & 1u) && (ABL == 0 || ABL == 9)) *flag = 1;
         __syncthreads();
         if (*flag) return true;
 
-        // ---- epilogue.  Lane (r, g) of tile (i, j) holds y[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]; every wave
-        // turns its 64 x 16 NTW tile around in its own LDS (no barrier: wave-private) and stores whole rows, 16 bytes per lane.
+        // ---- epilogue.  Lane (r, g) of tile (i, j) holds y[row wm*TM/4 + i*16 + r][column group j, columns 4g .. 4g+3]; every wave
+        // turns its tile around in its own LDS, 64 rows at a time (no barrier: wave-private), and stores whole rows, 16 bytes per lane.
         if constexpr (NTW > 0) {
             constexpr int kRowB = NTW * 32 + 8;                        // + 8: rows 16 apart would otherwise share banks
             const uint32_t tbase = a0 + w * kEpiStride;
+            float bv[NTW][4];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int grp = tg0 + jbase + j;
                 const SegRef sg = seg_lookup(a, grp);
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
                 if (sg.bias) {
                     const uint2 b = *(const uint2 *)(sg.bias + (grp * 16 + 4 * g - sg.g0 * 16));
-                    bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
-                    bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32x2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
-                    ds_write64(tbase + (i * 16 + r) * kRowB + j * 32 + g * 8, o);
+                    bv[j][0] = qt_u2f(b.x << 16); bv[j][1] = qt_u2f(b.x & 0xFFFF0000u);
+                    bv[j][2] = qt_u2f(b.y << 16); bv[j][3] = qt_u2f(b.y & 0xFFFF0000u);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             constexpr int kChunksPerRow = NTW * 2, kChunks = 64 * kChunksPerRow;
             const long col0 = (long)(tg0 + jbase) * 16;
 #pragma unroll
-            for (int it = 0; it < (kChunks + 63) / 64; ++it) {
-                const int c = it * 64 + l, row = c / kChunksPerRow, ch = c % kChunksPerRow;
-                uint2 lo_, hi_;
-                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(lo_), "=&v"(hi_) : "v"(tbase + row * kRowB + ch * 16) : "memory");
-                const int grow = m0 + wm * 64 + row;
-                if (c < kChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+            for (int h = 0; h < kRT / 4; ++h) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = h * 4 + ii;
+                        const u32x2 o = {pack_bf16x2(acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]),
+                                         pack_bf16x2(acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3])};
+                        ds_write64(tbase + (ii * 16 + r) * kRowB + j * 32 + g * 8, o);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < (kChunks + 63) / 64; ++it) {
+                    const int c = it * 64 + l, row = c / kChunksPerRow, ch = c % kChunksPerRow;
+                    uint2 lo_, hi_;
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo_), "=&v"(hi_) : "v"(tbase + row * kRowB + ch * 16) : "memory");
+                    const int grow = m0 + wm * (TM / 4) + h * 64 + row;
+                    if (c < kChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+                }
             }
         }
         return false;
     }
 };
-
 
 // The redo path of a tile that met a flagged row: every weight goes through the value map itself.  Plain loops, operands
 // straight from global memory, one 16 x 16 output tile at a time -- only ever taken for weights outside the rows the table
@@ -507,6 +572,7 @@ struct LinearFqt {
 __device__ __forceinline__ uint32_t map_pair(const uint16_t *map, uint32_t x) {
     return (uint32_t)map[x & 0xFFFFu] | ((uint32_t)map[x >> 16] << 16);
 }
+template <int TM>
 __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jbase, int ntw, int w, int l) {
     const int r = l & 15, g = l >> 4, wm = w & 3;
     const int nk = a.K / 32;
@@ -523,8 +589,8 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
             bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
         }
 #pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + r;
+        for (int i = 0; i < TM / 64; ++i) {
+            const int row = m0 + wm * (TM / 4) + i * 16 + r;
             const uint16_t *xrow = a.x + (long)min(row, a.M - 1) * a.K;
             v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -542,7 +608,7 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
     }
 }
 
-template <int NB, bool SROWS, int ABL = 0>
+template <int TM, int NB, bool SROWS, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_t[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -557,32 +623,30 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
     int tg0, nt;
     tile_span(a, tn, tg0, nt);
-    const int m0 = tm * kTM;
+    const int m0 = tm * TM;
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFqt<NB, SROWS, ABL>;
-    if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map below is written in absolute addresses
+    using L = LinearFqt<TM, NB, SROWS, ABL>;
+    if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map is written in absolute addresses
     bool redo;
 #define QT_RUN(N) L::template run<N>(a, lds_t, m0, tg0, nt, jbase, w, l)
     switch (ntw) {                                          // wave-uniform
         case 0: redo = QT_RUN(0); break;
         case 1: redo = QT_RUN(1); break;
         case 2: redo = QT_RUN(2); break;
-        case 3: if constexpr (NB >= 2) { redo = QT_RUN(3); break; }
-        case 4: if constexpr (NB >= 2) { redo = QT_RUN(4); break; }
-        case 5: if constexpr (NB >= 3) { redo = QT_RUN(5); break; }
-        case 6: if constexpr (NB >= 3) { redo = QT_RUN(6); break; }
-        case 7: if constexpr (NB >= 4) { redo = QT_RUN(7); break; }
+        case 3: redo = QT_RUN(3); break;
+        case 4: redo = QT_RUN(4); break;
+        case 5: if constexpr (NB >= 2) { redo = QT_RUN(5); break; }
+        case 6: if constexpr (NB >= 2) { redo = QT_RUN(6); break; }
+        case 7: if constexpr (NB >= 2) { redo = QT_RUN(7); break; }
         default:
-            if constexpr (NB >= 4) redo = QT_RUN(8);
-            else if constexpr (NB >= 3) redo = QT_RUN(6);
-            else if constexpr (NB >= 2) redo = QT_RUN(4);
-            else redo = QT_RUN(2);
+            if constexpr (NB >= 2) redo = QT_RUN(8);
+            else redo = QT_RUN(4);
             break;
     }
 #undef QT_RUN
-    if (redo) slow_tile(a, m0, tg0, jbase, ntw, w, l);
+    if (redo) slow_tile<TM>(a, m0, tg0, jbase, ntw, w, l);
 }
 
 int cu_count() {
@@ -595,37 +659,49 @@ int cu_count() {
     return n;
 }
 
-template <int NB, bool SROWS, int ABL = 0>
-int launch_nb(const Args &a, hipStream_t st) {
-    constexpr int kLds = LinearFqt<NB, SROWS>::kLds;
+template <int TM, int NB, bool SROWS, int ABL = 0>
+int launch_one(const Args &a, hipStream_t st) {
+    constexpr int kLds = LinearFqt<TM, NB, SROWS>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fqt_kernel<NB, SROWS, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fqt_kernel<TM, NB, SROWS, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
 template <bool SROWS>
-int launch(const Args &a, hipStream_t st) {
-    if (a.nb <= 1) return launch_nb<1, SROWS>(a, st);
-    if (a.nb <= 2) return launch_nb<2, SROWS>(a, st);
-    if (a.nb <= 3) return launch_nb<3, SROWS>(a, st);
-    if constexpr (!SROWS) {
-        const char *e_abl = getenv("QT_FQT_ABLATE");       // timing experiments (tools/exp_linear_fqt.py --skip-checks): results are garbage
-        switch (e_abl ? atoi(e_abl) : 0) {
-            case 1: return launch_nb<4, false, 1>(a, st);
-            case 2: return launch_nb<4, false, 2>(a, st);
-            case 3: return launch_nb<4, false, 3>(a, st);
-            case 5: return launch_nb<4, false, 5>(a, st);
-            case 6: return launch_nb<4, false, 6>(a, st);
-            default: break;
+int launch(const Args &a, hipStream_t st, int tm) {
+    if (tm == 512) {
+        if constexpr (!SROWS) {
+            const char *e_abl = getenv("QT_FQT_ABLATE");       // timing experiments (tools/exp_linear_fqt.py --skip-checks): results are garbage
+            switch (e_abl ? atoi(e_abl) : 0) {
+                case 1: return launch_one<512, 1, false, 1>(a, st);
+                case 2: return launch_one<512, 1, false, 2>(a, st);
+                case 3: return launch_one<512, 1, false, 3>(a, st);
+                case 5: return launch_one<512, 1, false, 5>(a, st);
+                case 6: return launch_one<512, 1, false, 6>(a, st);
+                case 9: return launch_one<512, 1, false, 9>(a, st);
+                default: break;
+            }
         }
+        return launch_one<512, 1, SROWS>(a, st);
     }
-    return launch_nb<4, SROWS>(a, st);
+    const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
+    if (worst_nt <= 8) return launch_one<256, 1, SROWS>(a, st);
+    return launch_one<256, 2, SROWS>(a, st);
+}
+
+// column tiles for `tiles_m` row tiles: as many as make whole rounds over the CUs, no wider than max_nt groups
+void plan(long groups, int tiles_m, int max_nt, int cus, long &tn, long &rounds) {
+    const long tn_min = (groups + max_nt - 1) / max_nt;
+    rounds = (tiles_m * tn_min + cus - 1) / cus;
+    tn = rounds * cus / tiles_m;
+    if (tn < tn_min) tn = tn_min;
+    if (tn > groups) tn = groups;
 }
 
 }  // namespace
@@ -643,6 +719,10 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     }
     if ((long)M * ntot == 0) return QT_OK;
     if (!x_dev || !y_dev || !rows_dev || !map_dev || M < 0 || K < kBK || K % kBK != 0 || ntot > (1L << 30)) return QT_ERR_BAD_ARG;
+    // DMA sources are a 64-bit base + a 32-bit byte offset
+    if ((long)M * K * 2 >= (1L << 32)) return QT_ERR_BAD_ARG;
+    for (int i = 0; i < count; ++i)
+        if ((long)ns[i] * K * 2 >= (1L << 32)) return QT_ERR_BAD_ARG;
     if (((uintptr_t)x_dev & 15u) || ((uintptr_t)y_dev & 7u) || ((uintptr_t)rows_dev & 15u) || (ntot & 3)) return QT_ERR_UNALIGNED;
     for (int i = 0; i < count; ++i) {
         if (ns[i] && (!w_devs[i] || ((uintptr_t)w_devs[i] & 15u))) return QT_ERR_UNALIGNED;
@@ -652,26 +732,37 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     Args a{};
     a.x = x_dev; a.y = y_dev; a.rows = rows_dev; a.map = map_dev; a.sign_mask = sign_mask;
     a.M = M; a.K = K; a.ldc = (int)ntot;
-    a.tiles_m = (M + kTM - 1) / kTM;
-    // column tiles: as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than max_nt groups
-    const char *e_tn = getenv("QT_FQT_TILES_N"), *e_nt = getenv("QT_FQT_MAX_NT");       // tuning / A-B switches
-    const int force_tn = e_tn ? atoi(e_tn) : 0;
-    const int hard_nt = signed_rows ? 14 : 15;      // LDS: table + 2 activation stages + 3 weight stages of hard_nt groups
-    int max_nt = e_nt ? atoi(e_nt) : hard_nt;
-    if (max_nt < 1 || max_nt > hard_nt) max_nt = hard_nt;
+    {
+        const char *e_st = getenv("QT_FQT_STAMPS");
+        a.dbg = e_st ? (unsigned long long *)strtoull(e_st, nullptr, 0) : nullptr;
+    }
+    const char *e_tn = getenv("QT_FQT_TILES_N"), *e_tm = getenv("QT_FQT_TM");          // tuning / A-B switches
+    const int force_tn = e_tn ? atoi(e_tn) : 0, force_tm = e_tm ? atoi(e_tm) : 0;
     const int cus = cu_count();
-    const long tn_min = (groups + max_nt - 1) / max_nt;
-    const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
-    long tn = rounds * cus / a.tiles_m;
-    if (force_tn > 0) tn = force_tn;
-    if (tn < tn_min) tn = tn_min;
-    if (tn > groups) tn = groups;
+    // 512-row tiles (half the conversion work per multiplication) where they fill the chip with tiles at least five groups wide;
+    // else 256-row tiles
+    long tn5, r5, tn2, r2;
+    plan(groups, (M + 511) / 512, 8, cus, tn5, r5);
+    plan(groups, (M + 255) / 256, 16, cus, tn2, r2);
+    int tm = 256;
+    if (M > 256) {
+        const double width5 = (double)groups / (double)tn5, fill5 = (double)((M + 511) / 512) * tn5 / ((double)r5 * cus);
+        const double fill2 = (double)((M + 255) / 256) * tn2 / ((double)r2 * cus);
+        if (width5 >= 5.0 && fill5 >= 0.9 * fill2) tm = 512;
+    }
+    if (force_tm == 256 || force_tm == 512) tm = force_tm;
+    a.tiles_m = (M + tm - 1) / tm;
+    long tn = tm == 512 ? tn5 : tn2;
+    {
+        const int max_nt = tm == 512 ? 8 : 16;
+        const long tn_min = (groups + max_nt - 1) / max_nt;
+        if (force_tn > 0) tn = force_tn;
+        if (tn < tn_min) tn = tn_min;
+        if (tn > groups) tn = groups;
+    }
     a.tiles_n = (int)tn;
     a.gbase = (int)(groups / tn);
     a.gextra = (int)(groups % tn);
-    const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
-    if (worst_nt > hard_nt) return QT_ERR_BAD_ARG;
-    a.nb = (worst_nt * 2 + 7) / 8;
     int nseg = 0, g0 = 0;
     for (int i = 0; i < count; ++i) {
         if (ns[i] == 0) continue;
@@ -683,7 +774,7 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     }
     a.nseg = nseg;
     hipStream_t st = (hipStream_t)stream;
-    return signed_rows ? launch<true>(a, st) : launch<false>(a, st);
+    return signed_rows ? launch<true>(a, st, tm) : launch<false>(a, st, tm);
 }
 
 }  // extern "C"
