@@ -590,6 +590,12 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
                 and self.outlier_threshold is None and not self._observe and self._quantize
                 and getattr(self, "_scale_is_one", True))
 
+    def stateless_map(self):
+        """True when this fake-quantizer is a pure function of its input: the value map of `dtype` at scale 1 (specs without
+        `qs`), quantize on, observer off -- what a GEMM may apply to its weight operand on the fly (fused.fqt_linear_or_none)."""
+        return (self._quantize and not self._observe and self.qscheme is None and not self.is_per_channel
+                and not self.record_histogram and self.outlier_threshold is None and getattr(self, "_scale_is_one", True))
+
     def sync_flags_from_buffers(self):
         """Re-read the enable buffers (one host sync); call after writing them directly."""
         self._observe = bool(self.observer_enabled[0].item())
@@ -735,6 +741,9 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             X._qt_fp8 = x8
             X._qt_ver = X._version
             X._qt_origin = (src.data_ptr(), src._version, tuple(src.shape))    # which tensor this is fq(.) of (sibling GEMMs)
+        elif X is not orig_in and self.qscheme is None and not self._observe:
+            X._qt_origin = (orig_in.data_ptr(), orig_in._version, tuple(orig_in.shape))
+            X._qt_ver = X._version
 
         if self.outlier_threshold is not None:                              # upstream :401-402
             X = torch.where(mask, X, orig_X)

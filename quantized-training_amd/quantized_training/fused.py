@@ -580,6 +580,9 @@ def fused_linear_or_none(layer, x):
     out = fp8_linear_or_none(layer, x)
     if out is not None:
         return out
+    out = fqt_linear_or_none(layer, x)
+    if out is not None:
+        return out
     fq = layer.weight_fake_quant
     W = layer.weight
     if not (fused_gemm_enabled() and isinstance(fq, FusedAmaxObsFakeQuantize)):
@@ -619,6 +622,144 @@ def fused_linear_or_none(layer, x):
     _native.check(code, "qt_linear_fq_bf16")
     STATS.add(W.numel())
     return y.reshape(*x.shape[:-1], N)
+
+
+# ---- any stateless value map on the weight: bf16 GEMM with the map applied in its operand path (qt_linear_fqt_bf16) --------
+_FQT_TABLES = {}          # (dtype, device) -> dict: rows / map device tensors, signed_rows, sign_mask, usable
+
+
+def fqt_gemm_mode():
+    """QT_FQT_GEMM: "auto" (default) -- the fused kernel for the problem shapes where it measured faster than the weight pass +
+    library GEMM pair (a fixed rule, `fqt_route_is_fused`: no timing at run time, every rank and every run takes the same route);
+    "1" -- wherever the kernel takes the problem; "0" -- never."""
+    v = os.environ.get("QT_FQT_GEMM", "auto")
+    return v if v in ("0", "1") else "auto"
+
+
+def fqt_tables(fq, device):
+    """Row form of `fq`'s value map on `device` (built once per dtype and device): None when the map has flagged rows inside
+    the range weights live in (2^-40 .. 2^15), where the kernel would keep falling back to its slow path."""
+    key = (str(fq.dtype), str(device))
+    hit = _FQT_TABLES.get(key)
+    if hit is None:
+        import numpy as np
+        m = _native.build_map_u16(fq.dtype)
+        rp = _native.build_rowparams(m)
+        rows = np.ctypeslib.as_array(rp.row).reshape(2048).astype(np.uint32)
+        flagged = np.ctypeslib.as_array(rp.flagged)
+        lo, hi = 127 - 40, 127 + 15
+        usable = not flagged[lo:hi].any() and not (rp.signed_rows and flagged[256 + lo:256 + hi].any())
+        hit = {"rows": torch.from_numpy(rows.view(np.int32).copy()).to(device), "map": torch.from_numpy(m.view(np.int16).copy()).to(device),
+               "signed": int(rp.signed_rows), "mask": int(rp.sign_mask), "usable": bool(usable)}
+        _FQT_TABLES[key] = hit
+    return hit if hit["usable"] else None
+
+
+def fqt_route_is_fused(M, ns, K, device):
+    """Fixed routing rule for qt_linear_fqt_bf16, from the measurements in DESIGN.md 6c (MI355X, posit(8,2)): the kernel wins where
+    512-row tiles at least seven column groups wide fill the chip (1024 x 15360 x 5120: 169 against 199 us; 1024 x 32000 x 5120: 350
+    against 397) and loses on narrower tiles (1024 x 13824 x 5120: 191 against 179; N = 5120: 113 against 71)."""
+    mode = fqt_gemm_mode()
+    if mode != "auto":
+        return mode == "1"
+    if M <= 256 or K % 32:
+        return False
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    groups = sum(ns) // 16
+    tiles_m = (M + 511) // 512
+    tn_min = (groups + 7) // 8
+    rounds = (tiles_m * tn_min + cus - 1) // cus
+    tn = max(tn_min, rounds * cus // tiles_m)
+    return groups / tn >= 7.0 and tiles_m * tn >= 0.9 * rounds * cus
+
+
+def hip_fqt_linear_or_none(x2, layers, tables):
+    """y[M, sum N] = x2 . [fq(W_0); fq(W_1); ...]^T + bias through qt_linear_fqt_bf16: x2 [M, K] holds the bf16 VALUES of the already
+    fake-quantized activation, the bf16 weights of `layers` go through the row form of their value map inside the kernel."""
+    M, K = x2.shape
+    if x2.dtype != torch.bfloat16 or K % 32 or not x2.is_contiguous() or x2.data_ptr() % 16 or not 1 <= len(layers) <= 4:
+        return None
+    for l in layers:
+        W = l.weight
+        if (W.dtype != torch.bfloat16 or not W.is_contiguous() or W.shape[1] != K or W.shape[0] % 16 or W.data_ptr() % 16 or W.device != x2.device):
+            return None
+        if l.bias is not None and (l.bias.dtype != torch.bfloat16 or not l.bias.is_contiguous() or l.bias.data_ptr() % 8 or l.bias.device != x2.device):
+            return None
+    n = len(layers)
+    ns = [l.weight.shape[0] for l in layers]
+    y = torch.empty((M, sum(ns)), dtype=torch.bfloat16, device=x2.device)
+    wp = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
+    bp = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
+    nn = (ctypes.c_int * n)(*ns)
+    rc = _native.lib().qt_linear_fqt_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
+                                           tables["map"].data_ptr(), y.data_ptr(), M, K, _stream_ptr(x2))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
+        return None
+    _native.check(rc, "qt_linear_fqt_bf16")
+    return y
+
+
+def _fqt_weight_ok(layer):
+    fq = layer.weight_fake_quant
+    return (isinstance(fq, FusedAmaxObsFakeQuantize) and fq.stateless_map() and fq._qt_format.kind != _native.QT_FMT_IDENTITY
+            and not fq.fp8_exact())
+
+
+def fqt_linear_or_none(layer, x):
+    """The fake-quant Linear of a stateless non-FP8 weight spec (posit, intN, fp6 / fp4 without `qs`) as ONE launch: the weight's
+    value map is applied inside the bf16 GEMM, fq(W) is never written.  q / k / v projections that read the same fake-quantized
+    tensor (same stateless input format) share a launch through their SiblingGroup.  None when the rule above prefers the weight
+    pass + library GEMM, or the kernel does not take the problem."""
+    if fqt_gemm_mode() == "0" or not _fqt_weight_ok(layer):
+        return None
+    W = layer.weight
+    if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad):
+        return None
+    if not (x.device.type == "cuda" and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16) or _WEIGHT_CACHE["on"]:
+        return None
+    K = W.shape[1]
+    fq = layer.weight_fake_quant
+    tables = fqt_tables(fq, x.device)
+    if tables is None:
+        return None
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    group = layer.__dict__.get("_qt_sibling_group")
+    if group is not None and os.environ.get("QT_SIBLING_GEMM", "1") != "0":
+        idx = group.layers.index(layer)
+        Ns = [l.weight.shape[0] for l in group.layers]
+        key = _origin_key(x)
+        if idx > 0:
+            st = group.stash
+            if st is not None and st[0] == ("fqt",) + tuple(key) and not st[2][idx]:
+                st[2][idx] = True
+                STATS.add(W.numel())
+                off = sum(Ns[:idx])
+                return st[1][:, off:off + Ns[idx]].reshape(*x.shape[:-1], Ns[idx])
+        else:
+            group.stash = None
+            same = all(_fqt_weight_ok(l) and str(l.weight_fake_quant.dtype) == str(fq.dtype) and l.weight.shape[1] == K
+                       and (l.bias is None) == (layer.bias is None) for l in group.layers)
+            afq = [getattr(l, "activation_pre_process", None) for l in group.layers]
+            afq = [h["0"] if h is not None and "0" in h else None for h in afq]
+            same = same and all(isinstance(f, FusedAmaxObsFakeQuantize) and f.stateless_map() and str(f.dtype) == str(afq[0].dtype) for f in afq)
+            if same and getattr(x, "_qt_origin", None) is not None and fqt_route_is_fused(M, Ns, K, x.device):
+                if not x2.is_contiguous():
+                    x2 = x2.contiguous()
+                y = hip_fqt_linear_or_none(x2, group.layers, tables)
+                if y is not None:
+                    STATS.add(W.numel())
+                    group.stash = (("fqt",) + tuple(key), y, [True] + [False] * (len(Ns) - 1))
+                    return y[:, :Ns[0]].reshape(*x.shape[:-1], Ns[0])
+    if not fqt_route_is_fused(M, [W.shape[0]], K, x.device):
+        return None
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = hip_fqt_linear_or_none(x2, [layer], tables)
+    if y is None:
+        return None
+    STATS.add(W.numel())
+    return y.reshape(*x.shape[:-1], W.shape[0])
 
 
 def _has_hooks(mod, name):

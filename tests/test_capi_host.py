@@ -102,3 +102,47 @@ def test_bad_arguments_are_reported_not_thrown():
     assert L.qt_scale_update(None, 1, 1, None, 1.0, 0, None) == -2
     assert L.qt_linear_fq_bf16(None, None, None, None, 0, 0, 8, None, None, None) == 0
     assert L.qt_linear_fq_bf16(None, None, None, None, 4, 4, 8, None, None, None) == -2
+
+
+# ---- row form of a value map (qt_build_rowparams): what qt_linear_fqt_bf16 applies to its weight operand ------------------
+_ROW_KEYS = [k for k in _C_KEYS if k not in ("none", "float32")]
+
+
+@pytest.mark.parametrize("key", _ROW_KEYS)
+def test_row_form_reproduces_the_value_map(key):
+    """Every row the builder does not flag reproduces the oracle-pinned map (tests/golden/maps.npz = upstream's
+    get_quantization_map, fake_quantize.py:31-95) on all of its 128 inputs, bit for bit up to the sign of a zero (which no product
+    sees); the flagged rows are exactly the ones the kernel redoes with the map itself, and there are few of them."""
+    m = MAPS[key].astype(np.uint16)
+    rp = _native.build_rowparams(m)
+    L = _native.lib()
+    f = ctypes.c_int(0)
+    flagged = np.ctypeslib.as_array(rp.flagged).astype(bool)
+    assert flagged.sum() == rp.n_flagged
+    assert flagged[255] and flagged[511]                      # non-finite inputs never take the row form
+    got = np.empty(65536, dtype=np.uint16)
+    fl = np.empty(65536, dtype=bool)
+    for b in range(65536):
+        got[b] = L.qt_rowparams_apply_host(ctypes.byref(rp), b, ctypes.byref(f))
+        fl[b] = bool(f.value)
+    row = np.arange(65536) >> 7
+    expect_flag = flagged[row] if rp.signed_rows else flagged[row & 0xFF]
+    assert np.array_equal(fl, expect_flag)
+    same = (got == m) | (((got | m) & 0x7FFF) == 0)
+    assert same[~fl].all(), np.flatnonzero(~same & ~fl)[:8]
+    # the rows weights live in (2^-40 .. 2^15) are all covered for the formats of BASELINE.json and the README tables
+    if key in ("posit8_0", "posit8_1", "posit8_2", "int8", "int4", "e4m3", "e5m2", "fp8_e4m3", "fp6_e3m2", "fp6_e2m3", "fp4_e2m1"):
+        assert not flagged[127 - 40:127 + 15].any()
+        assert rp.n_flagged <= 8
+
+
+def test_row_form_sign_rules():
+    """Odd maps copy the input's sign, unsigned formats (fp8_e5m3, uintN) keep results positive, intN needs rows by sign."""
+    rp = _native.build_rowparams(MAPS["posit8_1"].astype(np.uint16))
+    assert rp.sign_mask == 0x80008000 and rp.signed_rows == 0
+    rp = _native.build_rowparams(MAPS["int8"].astype(np.uint16))
+    assert rp.sign_mask == 0x80008000 and rp.signed_rows == 1     # -128 has no positive twin
+    rp = _native.build_rowparams(MAPS["uint8"].astype(np.uint16))
+    assert rp.sign_mask == 0 and rp.signed_rows == 1
+    rp = _native.build_rowparams(MAPS["fp8_e5m3"].astype(np.uint16))
+    assert rp.sign_mask == 0 and rp.signed_rows == 0

@@ -1495,6 +1495,142 @@ def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
 
 
+# ---- qt_linear_fqt_bf16: bf16 GEMM with ANY value map applied to the weights in its operand path --------------------------
+class _Fqt:
+    """Device-side tables of one dtype: the value map, its row form (qt_build_rowparams) and the elementwise format."""
+    _cache = {}
+
+    def __new__(cls, nv, dtype):
+        hit = cls._cache.get(dtype)
+        if hit is None:
+            hit = object.__new__(cls)
+            hit.map_host = nv.build_map_u16(dtype)
+            hit.rp = nv.build_rowparams(hit.map_host)
+            rows = np.ctypeslib.as_array(hit.rp.row).reshape(2048).astype(np.uint32)
+            hit.rows = torch.from_numpy(rows.view(np.int32).copy()).cuda()
+            hit.map = torch.from_numpy(hit.map_host.view(np.int16).copy()).cuda()
+            cls._cache[dtype] = hit
+        return hit
+
+
+def _linear_fqt(nv, x, ws, dtype, biases=None):
+    f = _Fqt(nv, dtype)
+    M, K = x.shape
+    n = len(ws)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in (biases or [None] * n)])
+    ns = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
+    y = torch.empty((M, sum(w.shape[0] for w in ws)), dtype=torch.bfloat16, device="cuda")
+    nv.check(nv.lib().qt_linear_fqt_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
+                                         y.data_ptr(), M, K, stream()), "qt_linear_fqt_bf16")
+    return y
+
+
+@pytest.mark.parametrize("wdtype", ["posit8_1", "posit8_2", "int8", "fp6_e3m2", "fp4_e2m1", "posit8_0", "uint8", "fp8_e5m3", "e4m3"])
+@pytest.mark.parametrize("M", [512, 300])
+def test_linear_fqt_weight_values_are_the_value_map(nv, wdtype, M):
+    """Identity activation: y[m][n] = fq(W)[n][m] -- one product per output, so the kernel's in-flight conversion of W (the row form
+    of the map, and the redo path for the rows it flags) is compared bit for bit with the oracle's value map on ALL 65 536 bf16
+    patterns (rows 0..127 of W); rows holding +-Inf / NaN must come out all-NaN (0 * NaN).  M = 512 takes the 512-row tiles,
+    M = 300 (ragged) the 256-row ones."""
+    K = 512
+    torch.manual_seed(1)
+    W = (torch.randn(400, K, device="cuda") * 3).bfloat16()
+    W.view(torch.int16)[:128] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16).view(128, 512)
+    eye = torch.eye(K, device="cuda").bfloat16()[:M] if M <= K else None
+    qmap = o.get_quantization_map(wdtype)
+    bias = torch.randn(400, device="cuda").bfloat16()
+    for sanitize in (True, False):
+        Wt = W.clone()
+        if sanitize:
+            Wt[~torch.isfinite(Wt.float())] = 0
+        exp = o.canon_nan16(o.vmap_bf16(host_u16(Wt.view(torch.int16)), qmap)).reshape(400, K)[:, :M]
+        got = o.canon_nan16(host_u16(_linear_fqt(nv, eye, [Wt], wdtype).t().contiguous().view(torch.int16)))
+        nan_rows = (o.canon_nan16(o.vmap_bf16(host_u16(Wt.view(torch.int16)), qmap)).reshape(400, K) == 0x7FC0).any(axis=1)
+        same = (got == exp) | (((got | exp) & 0x7FFF) == 0)                 # the sign of a zero is not part of a product
+        assert same[~nan_rows].all(), (wdtype, int((~same[~nan_rows]).sum()))
+        assert (got[nan_rows] == 0x7FC0).all()
+        gotb = _linear_fqt(nv, eye, [Wt], wdtype, [bias]).t().contiguous()
+        expb = (torch.from_numpy(o.bf16_to_f32(exp)).cuda() + bias.float()[:, None]).bfloat16()
+        keep = ~torch.from_numpy(nan_rows).cuda()
+        assert torch.equal(gotb[keep].view(torch.int16), expb[keep].view(torch.int16))
+
+
+@pytest.mark.parametrize("M,Ns,K", [(1024, [4096], 1024), (1024, [176], 256), (300, [48, 64, 16], 384), (1, [16], 32), (777, [2048, 512, 512], 512),
+                                    (257, [208, 4096 - 208], 128), (512, [128], 96),
+                                    # BASELINE.json configs[3], full LLaMA-2-13B sizes: gate / up, down, o, q / k / v, lm head
+                                    (1024, [13824], 5120), (1024, [5120], 13824), (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120),
+                                    (1024, [32000], 5120),
+                                    # BERT-base (configs[0] / [1] shapes)
+                                    (6144, [768], 768), (6144, [3072], 768), (6144, [768], 3072)])
+@pytest.mark.parametrize("dtype", ["posit8_2", "int8"])
+def test_linear_fqt_vs_fp64_product_of_the_quantized_operands(nv, M, Ns, K, dtype):
+    """Ragged M, both tile heights, column tiles spanning two weights, several weights per launch, bias: against the fp64 product of
+    the oracle-quantized operands.  Tolerance: one bf16 rounding of the result (2^-8 relative) plus fp32 accumulation of exact
+    products (measured <= 2^-20 sum |a||b|; bound used: 2^-18)."""
+    torch.manual_seed(0)
+    qm = o.get_quantization_map(dtype)
+
+    def fq(t):
+        return torch.from_numpy(o.vmap_bf16(host_u16(t.view(torch.int16)), qm).view(np.int16)).cuda().view(torch.bfloat16)
+
+    x = fq((torch.randn(M, K, device="cuda") * (1.0 if dtype != "int8" else 20.0)).bfloat16())
+    ws = [(torch.randn(n, K, device="cuda") * (0.05 if dtype != "int8" else 3.0)).bfloat16() for n in Ns]
+    bs = [torch.randn(n, device="cuda").bfloat16() if i % 2 == 0 else None for i, n in enumerate(Ns)]
+    y = _linear_fqt(nv, x, ws, dtype, bs).double()
+    xa = x.double()
+    wa = torch.cat([fq(w).double() for w in ws])
+    bias = torch.cat([b.double() if b is not None else torch.zeros(n, device="cuda", dtype=torch.float64) for b, n in zip(bs, Ns)])
+    ref = xa @ wa.t() + bias
+    tol = ref.abs() * 2.0 ** -8 + (xa.abs() @ wa.abs().t()) * 2.0 ** -18 + 1e-30
+    assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
+
+
+def test_linear_fqt_rejects_what_it_does_not_take(nv):
+    f = _Fqt(nv, "posit8_1")
+    x = torch.zeros(64, 48, device="cuda", dtype=torch.bfloat16)        # K % 32 != 0
+    W = torch.zeros(32, 48, device="cuda", dtype=torch.bfloat16)
+    wp = (ctypes.c_void_p * 1)(W.data_ptr())
+    ns = (ctypes.c_int * 1)(32)
+    y = torch.empty(64, 32, device="cuda", dtype=torch.bfloat16)
+    rc = nv.lib().qt_linear_fqt_bf16(x.data_ptr(), wp, None, ns, 1, f.rows.data_ptr(), 0, f.rp.sign_mask, f.map.data_ptr(), y.data_ptr(), 64, 48, stream())
+    assert rc == nv.QT_ERR_BAD_ARG
+    ns = (ctypes.c_int * 1)(24)                                          # N % 16 != 0
+    rc = nv.lib().qt_linear_fqt_bf16(x.data_ptr(), wp, None, ns, 1, f.rows.data_ptr(), 0, f.rp.sign_mask, f.map.data_ptr(), y.data_ptr(), 64, 64, stream())
+    assert rc == nv.QT_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("dtype", ["posit8_2", "fp4_e2m1"])
+def test_qat_linear_takes_the_fused_value_map_gemm(nv, dtype, monkeypatch):
+    """modules/qat/linear.py:40-41 through fused.fqt_linear_or_none: same result as the weight pass + library GEMM up to the
+    accumulation order (both are fp32 sums of the same exact products), one fake-quant call counted for the weight, and the fixed
+    routing rule is what QT_FQT_GEMM=auto follows."""
+    import quantized_training as qt
+    from quantized_training import fused
+    from quantized_training.fake_quantize import STATS
+    from quantized_training.modules.qat.linear import Linear as QATLinear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 1024, bias=True).cuda().bfloat16()
+    lin.qconfig = qt.QConfig(activation=None, weight=lambda **kw: qt.FusedAmaxObsFakeQuantize(dtype=dtype, **{k: v for k, v in kw.items() if k == "device"}),
+                             error=None)
+    q = QATLinear.from_float(lin).cuda()
+    x = (torch.randn(4, 128, 512, device="cuda")).bfloat16()
+    with torch.no_grad():
+        monkeypatch.setenv("QT_FQT_GEMM", "0")
+        ref = q(x)
+        monkeypatch.setenv("QT_FQT_GEMM", "1")
+        before = STATS.elements
+        got = q(x)
+        assert STATS.elements - before == q.weight.numel()
+    assert got.shape == ref.shape
+    err = (got.float() - ref.float()).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.float().abs().max()) + 1e-6
+    assert fused.fqt_route_is_fused(1024, [15360], 5120, x.device) is False or True      # rule evaluates without timing anything
+    monkeypatch.setenv("QT_FQT_GEMM", "auto")
+    assert fused.fqt_route_is_fused(1024, [5120], 5120, x.device) is False
+    assert fused.fqt_route_is_fused(1024, [5120, 5120, 5120], 5120, x.device) is True
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 11008, 512), (300, 96, 256), (520, 2064, 384), (1, 16, 128), (64, 4096, 1024),
                                    (1024, 11008, 4096)])
 @pytest.mark.parametrize("xdtype,wdtype,odtype", [("e4m3", "e4m3", "e4m3"), ("e4m3", "e5m2", "e5m2")])
