@@ -53,7 +53,11 @@ typedef enum qt_fmt_kind {
 typedef struct qt_format {
     int32_t kind;
     int32_t p0;
-    int32_t p1;
+    int32_t p1;              /* kind QT_FMT_LUT: bit 0 set = the 512 x 4 row words of qt_build_rowparams FOLLOW the 65 536 map entries
+                                in lut_dev (bit 1: rows by sign and exponent, bit 2: results take the input's sign, bit 3: zero
+                                results of negative inputs are -0, bit 4: the input -0.0 is an exception to that and maps to the
+                                value whose bits are in fhi); large aligned tensors then take the row form -- 8 vector
+                                instructions and a 16-byte LDS read per element instead of a gather from a 128 KiB table */
     float flo;
     float fhi;
 } qt_format;
@@ -252,12 +256,15 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
  * that cannot be written this way (non-finite inputs, a few rows at the far ends of some formats) are `flagged`.
  *   row[r] = {D (int32), C (fp32 bits; bit 0 set = flagged), lo, hi (fp32 bits)};  r = bits >> 7 (rows 256.. = negative inputs)
  *   signed_rows 0: rows 256..511 equal rows 0..255 (|map(-x)| == |map(x)|), the kernel indexes by exponent only
- *   sign_mask 0x80008000: the result takes the input's sign; 0: it stays positive (unsigned formats such as fp8_e5m3) */
+ *   sign_mask 0x80008000: the result takes the input's sign; 0: it stays positive (unsigned formats such as fp8_e5m3)
+ *   zero_sign: what a zero result of a negative non-zero input looks like in the map -- 0: +0, 1: -0, 2: both occur (a GEMM operand's
+ *   zero has no sign that matters; the elementwise passes reproduce the map's bits and take the row form only for 0 and 1) */
 typedef struct qt_rowparams {
     uint32_t row[512][4];
     int32_t signed_rows;
     uint32_t sign_mask;
     int32_t n_flagged;
+    int32_t zero_sign;
     uint8_t flagged[512];
 } qt_rowparams;
 int qt_build_rowparams(const uint16_t *map_host, qt_rowparams *out_host);

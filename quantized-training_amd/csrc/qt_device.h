@@ -120,14 +120,29 @@ struct UniformDiv {
 // Internal kind (not part of the C ABI): a table format whose map is odd-symmetric (qt_format.p0 == 1, see qt_format_for);
 // only entries 0 .. 0x7FFF are staged and the sign goes back on finite non-zero and infinite results.
 constexpr int kFmtLutHalf = 4;
+constexpr int kFmtRows = 5;      // QT_FMT_LUT with the row words behind the map (qt_format.p1 bit 0): the row form, table of rows in LDS
 
 template <int KIND>
 struct Rounder {
     qt_format fmt;
-    const uint16_t *lds;   // KIND == QT_FMT_LUT: table in LDS (or global for the gather kernels)
+    const uint16_t *lds;   // KIND == QT_FMT_LUT: table in LDS (or global for the gather kernels); kFmtRows: the row words in LDS
+    const uint16_t *glut;  // kFmtRows: the map in global memory, for the rows the row form does not cover
     // image -> image
     __device__ __forceinline__ uint32_t operator()(uint32_t img) const {
-        if constexpr (KIND == kFmtLutHalf) {
+        if constexpr (KIND == kFmtRows) {
+            // csrc/qt_host.cpp, qt_build_rowparams: t = f32(|x| bits + D); y = med3((t + C) - C, lo, hi), exact on every input of a
+            // row that is not flagged (bit 0 of C)
+            const uint32_t rowi = (img >> 23) & ((fmt.p1 & 2) ? 0x1FFu : 0xFFu);
+            const uint4 p = ((const uint4 *)lds)[rowi];
+            const float t = qt_u2f((img & 0x7FFFFFFFu) + p.x), c = qt_u2f(p.y);
+            const uint32_t z = qt_f2u(__builtin_amdgcn_fmed3f((t + c) - c, qt_u2f(p.z), qt_u2f(p.w)));
+            uint32_t sign = (fmt.p1 & 4) ? (img & 0x80000000u) : 0u;
+            if (!(fmt.p1 & 8)) sign = z ? sign : 0u;                                 // zero results are +0 in this map
+            uint32_t r = z | sign;
+            if ((fmt.p1 & 16) && img == 0x80000000u) r = qt_f2u(fmt.fhi);
+            if (__builtin_expect(p.y & 1u, 0)) r = (uint32_t)glut[img >> 16] << 16;
+            return r;
+        } else if constexpr (KIND == kFmtLutHalf) {
             const uint32_t t = lds[(img >> 16) & 0x7FFFu];
             const uint32_t sign = ((t - 1u) < 0x7F80u) ? (img & 0x80000000u) : 0u;        // zero and NaN results carry no sign
             return (t << 16) | sign;

@@ -172,6 +172,16 @@ __global__ __launch_bounds__(BLOCK) void fq_kernel(const void *__restrict__ xv, 
         rnd.lds = (const uint16_t *)s_lut;
         __syncthreads();
     }
+    if constexpr (KIND == kFmtRows) {
+        // the row words sit behind the 65 536 map entries: 4 KiB (rows by exponent) or 8 KiB in LDS, many workgroups per CU
+        __shared__ uint4 s_rows[512];
+        const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += BLOCK) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = lut;
+        __syncthreads();
+    }
     float s = scale ? *scale : 1.0f;
     if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
     const bool unit = (s == 1.0f);
@@ -565,6 +575,15 @@ __global__ __launch_bounds__(256) void fq_pc_vec_kernel(const uint4 *__restrict_
                                                        const float *__restrict__ scale, uint32_t *amax_out) {
     Rounder<KIND> rnd{fmt, lut};
     __shared__ uint32_t s_part[4];
+    if constexpr (KIND == kFmtRows) {
+        __shared__ uint4 s_rows[512];               // the row words behind the map (qt_format.p1 bit 0), see fq_kernel
+        const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = lut;
+        __syncthreads();
+    }
     for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const size_t c = row % C;
         float s = scale ? scale[c] : 1.0f;
@@ -851,6 +870,26 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
     const bool gather = !aligned || (KIND == QT_FMT_LUT && (n < kLutLdsMinElems || y == nullptr)) || n < 4096;
     if constexpr (KIND == QT_FMT_LUT) {
+        // The row form (qt_format.p1 bit 0; QT_ROW_FORM=0 keeps the table): no 128 KiB staging, so the pass runs at the closed
+        // forms' occupancy and bandwidth, small tensors included.
+        static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;      // tuning / A-B switch
+        if ((fmt.p1 & 1) && row_mode && aligned && y != nullptr && n >= 4096) {
+            const size_t nv = n / kPer;
+            static const int row_blocks = getenv("QT_ROW_BLOCKS") ? atoi(getenv("QT_ROW_BLOCKS")) : 0;   // tuning: workgroups per CU
+            static const int row_wide = getenv("QT_ROW_WIDE") ? atoi(getenv("QT_ROW_WIDE")) : 0;         // tuning: 1024-thread workgroups
+            if (row_wide) {
+                unsigned grid = grid_for(nv, (size_t)1024, row_blocks ? row_blocks : 4);
+                if (amax) fq_kernel<IO, kFmtRows, true, 1024><<<grid, 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                else fq_kernel<IO, kFmtRows, false, 1024><<<grid, 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                return launch_status();
+            }
+            unsigned grid = grid_for(nv, (size_t)kAluBlock * kUnroll, row_blocks ? row_blocks : 8);
+            if (amax)
+                fq_kernel<IO, kFmtRows, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+            else
+                fq_kernel<IO, kFmtRows, false, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+            return launch_status();
+        }
         if (aligned && y != nullptr && n >= 4096 && n < kLutLdsMinElems) {
             const size_t nv = n / kPer;
             unsigned grid = grid_for(nv, 256, 8);
@@ -953,6 +992,12 @@ int launch_pc_kind(const void *x, void *y, size_t outer, size_t C, size_t inner,
         fq_pc_last_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, n, C, fmt, lut, scale, amax);
     } else if (inner % kPer == 0 && inner >= 64 * kPer && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0)) {
         if constexpr (KIND == QT_FMT_LUT) {
+            static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;      // see launch_fq_kind
+            if ((fmt.p1 & 1) && row_mode && y) {
+                unsigned grid = grid_for(outer * C, 1, 16);
+                fq_pc_vec_kernel<IO, kFmtRows><<<grid, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, outer * C, C, inner / kPer, fmt, lut, scale, amax);
+                return launch_status();
+            }
             static const int lds_mode = getenv("QT_PC_LDS") ? atoi(getenv("QT_PC_LDS")) : 1;          // tuning / A-B switch
             if (lds_mode && y && outer * C * inner >= kLutLdsMinElems) {
                 const size_t rows = outer * C;

@@ -353,6 +353,14 @@ int qt_build_rowparams(const uint16_t *map, qt_rowparams *out) {
         same = a == b || (a > 0x7F80 && b > 0x7F80);
     }
     out->signed_rows = same ? 0 : 1;
+    {   // zero results of negative (non-zero) inputs: +0 (e4m3, posit: fp8.py:33-35), -0 (intN: torch.round keeps the sign), or both
+        int pz = 0, nz = 0;
+        for (uint32_t i = 0x8001; i < 0x10000; ++i) {
+            if (map[i] == 0x0000) ++pz;
+            if (map[i] == 0x8000) ++nz;
+        }
+        out->zero_sign = (pz && nz) ? 2 : (nz ? 1 : 0);
+    }
     for (uint32_t row = 0; row < 512; ++row) {
         float expect[128];
         for (int m = 0; m < 128; ++m) {

@@ -31,7 +31,7 @@ class QtOperandQ(ctypes.Structure):
 class QtRowParams(ctypes.Structure):
     """Row form of a value map (qt_build_rowparams): 512 rows {D, C | flagged bit, lo, hi}, see include/qt_hip.h."""
     _fields_ = [("row", (c_uint32 * 4) * 512), ("signed_rows", ctypes.c_int32), ("sign_mask", c_uint32),
-                ("n_flagged", ctypes.c_int32), ("flagged", ctypes.c_uint8 * 512)]
+                ("n_flagged", ctypes.c_int32), ("zero_sign", ctypes.c_int32), ("flagged", ctypes.c_uint8 * 512)]
 
 
 class QtError(RuntimeError):

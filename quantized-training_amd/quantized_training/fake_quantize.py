@@ -114,10 +114,50 @@ def get_quantization_map(dtype, device=None):
             host = torch.from_numpy(table.view("int16")).view(torch.bfloat16)
             host._qt_dtype = dtype
             _MAP_CACHE[(dtype, torch.device("cpu"))] = host
-        hit = host if dev.type == "cpu" else host.to(dev)
+        hit = host if dev.type == "cpu" else _device_map(host, dev)
         hit._qt_dtype = dtype    # lets the block-scaled GEMMs recognise the element format of values rounded with this map
         _MAP_CACHE[key] = hit
     return hit
+
+
+QT_MAP_ENTRIES = _native.QT_MAP_ENTRIES
+_ROWS_TAIL = 4096            # bf16 slots behind the map: 512 rows x 16 bytes
+
+
+def _device_map(host, dev):
+    """The map on a device, with the ROW FORM of the map (qt_build_rowparams) in the same allocation right behind its 65 536 entries
+    where the row form covers the value range tensors live in: the elementwise kernels then need no 128 KiB table in LDS.  The
+    returned tensor is the [65536] view; `_qt_rows` holds the qt_format.p1 bits that tell the kernels the tail is there."""
+    import numpy as np
+    m = host.view(torch.int16).numpy().view(np.uint16)
+    rp = _native.build_rowparams(m)
+    flagged = np.ctypeslib.as_array(rp.flagged)
+    lo, hi = 127 - 30, 127 + 15      # flagged rows out there are rare enough for the kernel's per-element detour through the map
+    usable = (rp.zero_sign in (0, 1) and not flagged[lo:hi].any() and not (rp.signed_rows and flagged[256 + lo:256 + hi].any()))
+    if not usable or os.environ.get("QT_ROW_FORM", "1") == "0":
+        return host.to(dev)
+    both = torch.empty(QT_MAP_ENTRIES + _ROWS_TAIL, dtype=torch.bfloat16)
+    both[:QT_MAP_ENTRIES] = host
+    rows = np.ctypeslib.as_array(rp.row).reshape(2048).astype(np.uint32)
+    both[QT_MAP_ENTRIES:].view(torch.int16).copy_(torch.from_numpy(rows.view(np.int16).copy()))
+    out = both.to(dev)[:QT_MAP_ENTRIES]
+    out._qt_rows = 1 | (2 if rp.signed_rows else 0) | (4 if rp.sign_mask else 0) | (8 if rp.zero_sign == 1 else 0)
+    rule = 0x8000 if (rp.zero_sign == 1 and rp.sign_mask) else 0x0000      # what the row form makes of the input -0.0
+    out._qt_neg_zero = None
+    if int(m[0x8000]) != rule:
+        out._qt_rows |= 16
+        out._qt_neg_zero = float(np.array([int(m[0x8000]) << 16], dtype=np.uint32).view(np.float32)[0])
+    return out
+
+
+def _launch_format(fmt, lut):
+    """`fmt` with the row-form bits when `lut` is a map allocated by _device_map (and still that very allocation)."""
+    bits = getattr(lut, "_qt_rows", 0) if lut is not None else 0
+    if not bits or fmt.kind != _native.QT_FMT_LUT or fmt.p1:
+        return fmt
+    if lut.storage_offset() != 0 or lut.untyped_storage().nbytes() < 2 * (QT_MAP_ENTRIES + _ROWS_TAIL):
+        return fmt
+    return _native.QtFormat(fmt.kind, fmt.p0, bits, fmt.flo, lut._qt_neg_zero if bits & 16 else fmt.fhi)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -271,10 +311,10 @@ def _hip_fake_quant(x, y, fmt, lut, scale, amax_hist, per_channel, ch_axis):
     if per_channel:
         outer, C, inner = _channel_view(tuple(x.shape), ch_axis)
         fn = L.qt_fake_quant_pc_bf16 if bf16 else L.qt_fake_quant_pc_f32
-        _native.check(fn(xp, yp, outer, C, inner, ctypes.byref(fmt), lp, sp, ap, st), "qt_fake_quant_pc")
+        _native.check(fn(xp, yp, outer, C, inner, ctypes.byref(_launch_format(fmt, lut)), lp, sp, ap, st), "qt_fake_quant_pc")
     else:
         fn = L.qt_fake_quant_bf16 if bf16 else L.qt_fake_quant_f32
-        _native.check(fn(xp, yp, n, ctypes.byref(fmt), lp, sp, ap, st), "qt_fake_quant")
+        _native.check(fn(xp, yp, n, ctypes.byref(_launch_format(fmt, lut)), lp, sp, ap, st), "qt_fake_quant")
 
 
 def hip_vmap(x, qmap, fmt=None):

@@ -103,6 +103,33 @@ def test_exhaustive_bf16_all_patterns(nv, dtype, scale):
         assert np.array_equal(o.canon_nan16(got), exp), (dtype, scale, force_lut)
 
 
+@pytest.mark.parametrize("dtype", ["posit8_1", "posit8_2", "posit8_0", "fp8_e4m3", "fp6_e3m2", "fp6_e2m3", "fp4_e2m1", "posit16_1", "fp8_e5m3"])
+@pytest.mark.parametrize("scale", [1.0, 0.037, 3.5])
+def test_row_form_pass_equals_the_value_map(nv, dtype, scale):
+    """Table formats take the ROW FORM of their map in the elementwise pass (qt_format.p1 bit 0: the row words of qt_build_rowparams
+    sit behind the 65 536 map entries; csrc/qt_device.h Rounder<kFmtRows>): all 65 536 bf16 inputs, tiled to a tensor large enough for
+    the streaming kernel, bit for bit the oracle's fake-quant -- flagged rows (through the map in global memory), the sign of zero
+    results and NaN included; and the same through the module, which is how the product reaches it."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import _launch_format
+    x = np.tile(o.all_bf16_patterns(), 40)                        # 2.6 M elements
+    exp = np.tile(expect_bf16(o.all_bf16_patterns(), dtype, scale), 40)
+    lut = qt.get_quantization_map(dtype, torch.device("cuda"))
+    fmt = _launch_format(nv.format_for(dtype), lut)
+    assert fmt.kind == nv.QT_FMT_LUT and (fmt.p1 & 1), "the row form covers this map"
+    xd = torch.from_numpy(x.view(np.int16)).cuda()
+    yd = torch.empty_like(xd)
+    sc = torch.tensor([scale], dtype=torch.float32, device="cuda")
+    for n in (x.size, 65536, 4096 + 8):
+        nv.check(nv.lib().qt_fake_quant_bf16(xd.data_ptr(), yd.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(), sc.data_ptr(), None, stream()), "fq")
+        got = host_u16(yd[:n])
+        assert np.array_equal(o.canon_nan16(got), exp[:n]), (dtype, scale, n)
+    if scale == 1.0:
+        fq = qt.FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
+        y = fq(xd.view(torch.bfloat16))
+        assert np.array_equal(o.canon_nan16(host_u16(y.view(torch.int16))), exp)
+
+
 @pytest.mark.parametrize("dtype", ["e4m3", "int8"])
 def test_division_by_many_scales(nv, dtype):
     """x / s must be torch's correctly rounded fp32 division for every scale: sweep scales across the

@@ -21,9 +21,12 @@ y = torch.empty_like(x)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def per_tensor(dtype, scale=None, amax=None):
+def per_tensor(dtype, scale=None, amax=None, rows_form=True):
+    from quantized_training.fake_quantize import _launch_format
     fmt = nv.format_for(dtype)
     lut = qt.get_quantization_map(dtype, dev)
+    if rows_form:
+        fmt = _launch_format(fmt, lut)
     ms = ctypes.c_float()
     for iters in (pool, 6 * pool):
         nv.check(L.qt_bench_fake_quant_bf16(x.data_ptr(), y.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(),
@@ -32,9 +35,12 @@ def per_tensor(dtype, scale=None, amax=None):
     return ms.value * 1e3
 
 
-def per_channel(dtype, observe):
+def per_channel(dtype, observe, rows_form=True):
+    from quantized_training.fake_quantize import _launch_format
     fmt = nv.format_for(dtype)
     lut = qt.get_quantization_map(dtype, dev)
+    if rows_form:
+        fmt = _launch_format(fmt, lut)
     scale = torch.rand(rows, device=dev) * 0.01 + 0.001
     amax = torch.zeros(rows, dtype=torch.int32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,9 +60,12 @@ print(f"QT_LUT_HALF={os.environ.get('QT_LUT_HALF', '1')} QT_PC_LDS={os.environ.g
 for dt in ("posit8_1", "posit8_2", "fp8_e4m3", "fp4_e2m1", "int8"):
     f = nv.format_for(dt)
     for label, sc, am in (("unit", None, None), ("scale", s, None), ("scale+obs", s, h)):
-        us = per_tensor(dt, sc, am)
-        print(f"per-tensor  {dt:9s} {label:10s} kind {f.kind} half {f.p0 if f.kind == 0 else '-'}: {us:6.1f} us  {n * 4 / us / 1e6:5.2f} TB/s", flush=True)
+        us = per_tensor(dt, sc, am, rows_form=False)
+        ur = per_tensor(dt, sc, am, rows_form=True)
+        print(f"per-tensor  {dt:9s} {label:10s} kind {f.kind}: table in LDS {us:6.1f} us  {n * 4 / us / 1e6:5.2f} TB/s   row form {ur:6.1f} us  "
+              f"{n * 4 / ur / 1e6:5.2f} TB/s", flush=True)
 for dt in ("posit8_1", "fp8_e4m3", "int8"):
     for obs in (False, True):
-        us = per_channel(dt, obs)
-        print(f"per-channel {dt:9s} observer={obs}: {us:6.1f} us  {n * 4 / us / 1e6:5.2f} TB/s", flush=True)
+        us = per_channel(dt, obs, rows_form=False)
+        ur = per_channel(dt, obs, rows_form=True)
+        print(f"per-channel {dt:9s} observer={obs}: table in LDS {us:6.1f} us  {n * 4 / us / 1e6:5.2f} TB/s   row form {ur:6.1f} us  {n * 4 / ur / 1e6:5.2f} TB/s", flush=True)
