@@ -58,6 +58,17 @@ template <int KIND, int NV>
 __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Rounder<KIND> rnd{a.fmt, a.lut};
+    if constexpr (KIND == kFmtRows) {
+        // table formats whose map came with its row form (qt_format.p1 bit 0): the row words in LDS instead of a gather from the
+        // 128 KiB map in L2 per probability (csrc/qt_device.h, Rounder<kFmtRows>)
+        __shared__ uint4 s_rows[512];
+        const uint4 *g = (const uint4 *)(a.lut + QT_MAP_ENTRIES);
+        const int nrows = (a.fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = a.lut;
+        __syncthreads();
+    }
     const float s = a.scale ? qt_bf2f(qt_f2bf(*a.scale)) : 1.0f;
     const bool unit = s == 1.0f;
     const UniformDiv dv(s);
@@ -231,7 +242,7 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
     SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     switch (fmt->kind) {
-        case QT_FMT_LUT: return launch_softmax<QT_FMT_LUT>(a, st);
+        case QT_FMT_LUT: return (fmt->p1 & 1) ? launch_softmax<kFmtRows>(a, st) : launch_softmax<QT_FMT_LUT>(a, st);
         case QT_FMT_FP_SAT: return launch_softmax<QT_FMT_FP_SAT>(a, st);
         case QT_FMT_INT: return launch_softmax<QT_FMT_INT>(a, st);
         case QT_FMT_IDENTITY: return launch_softmax<QT_FMT_IDENTITY>(a, st);

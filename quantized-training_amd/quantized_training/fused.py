@@ -827,6 +827,9 @@ def fused_scores_to_probs_or_none(attn, scores, attention_mask, scaling, dropout
                 fq_p.amax_history.resize_((fq_p.amax_history_len,)).fill_(0.0)
                 fq_p.scale.resize_(()).fill_(1.0)
             launch_scale_update(fq_p.amax_history, fq_p.scale, fq_p.quant_max, fq_p.force_scale_power_of_two, st)
+        if fmt.kind == _native.QT_FMT_LUT:
+            from .fake_quantize import _launch_format
+            fmt = _launch_format(fmt, fq_p.qmap)             # the row form of the map where the allocation carries it
         lut = fq_p.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
         scale_ptr = fq_p.scale.data_ptr() if fq_p._quantize else None
         amax_ptr = fq_p.amax_history.data_ptr() if fq_p._observe else None
