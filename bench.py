@@ -39,17 +39,29 @@ FP8_PEAK_TFLOPS = 5000.0        # MI355X_MICROARCH.md: FP8 MFMA ~5 PF dense (spa
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
+# BASELINE.json `configs` the driver can time: name -> (kind, model shape, activation spec, weight spec)
+WORKLOADS = {
+    "llama-7b-e4m3": ("llama", "llama-2-7b", "e4m3", "e4m3"),
+    "llama-13b-posit8_2": ("llama", "llama-2-13b", "posit8_2", "posit8_2"),
+    "bert-base-squad-e4m3": ("bert", "bert-base", "e4m3", "e4m3"),
+    "roberta-mrpc-int8-e5m2-train": ("roberta", "roberta-base", "int8,qs=per_tensor_symmetric", "int8,qs=per_tensor_symmetric"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="llama-2-7b")
+    ap.add_argument("--workload", default="llama-7b-e4m3", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configs: llama-7b-e4m3 = configs[2] (the headline, default), bert-base-squad-e4m3 = configs[1], "
+                         "llama-13b-posit8_2 = configs[3] on the GPUs given, roberta-mrpc-int8-e5m2-train = configs[4]")
+    ap.add_argument("--model", default=None, help="(llama workloads) override the model shape")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the line is then marked invalid)")
     ap.add_argument("--max_length", type=int, default=1024)
     ap.add_argument("--stride", type=int, default=512)
-    ap.add_argument("--activation", default="e4m3")
-    ap.add_argument("--weight", default="e4m3")
+    ap.add_argument("--activation", default=None)
+    ap.add_argument("--weight", default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--cache-eval-weights", action="store_true",
                     help="side experiment (line marked invalid): keep fq(W) across windows instead of re-quantizing, "
@@ -62,7 +74,16 @@ def parse():
                     help="plumbing check without a GPU: tiny LLaMA on the CPU, gloo instead of RCCL, same sharding / timing / "
                          "gather code (the line is marked invalid)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py launches its own ranks")
-    return ap.parse_args()
+    a = ap.parse_args()
+    kind, model, act, wgt = WORKLOADS[a.workload]
+    if a.model is not None and a.model != model and a.workload == "llama-7b-e4m3":
+        # the pre-workload spelling: --model llama-2-13b --activation posit8_2 --weight posit8_2
+        pass
+    a.kind = kind
+    a.model = a.model or model
+    a.activation = a.activation or act
+    a.weight = a.weight or wgt
+    return a
 
 
 def launch_ranks(a):
@@ -233,17 +254,23 @@ def fused_gemm_leg(device):
                          "frac": round(gbs / HBM_PEAK_GBPS, 4)}}
 
 
-def cpu_baseline_leg():
+def fused_routes():
+    from quantized_training import fused
+    return fused.routes_report()
+
+
+def cpu_baseline_leg(dtype="e4m3", shape=(4096, 11008)):
     """The reference-semantics path (C restatement, oracle/qt_oracle.c, validated against the
     reference's golden vectors) on this host's cores, bounded sample of the same workload:
-    the bf16 4096 x 11008 E4M3 tensor quantized repeatedly for about 10-20 s."""
+    a bf16 weight-shaped tensor of the workload fake-quantized with its dtype's map repeatedly for about 10-20 s."""
     import numpy as np
     from oracle import c_oracle, qt_oracle
     rng = np.random.default_rng(0)
-    n = 4096 * 11008
+    n = shape[0] * shape[1]
+    dtype = dtype.split(",")[0]
     x = qt_oracle.f32_to_bf16((rng.standard_normal(n) * 0.02).astype(np.float32))
     y = np.empty_like(x)
-    qmap = qt_oracle.get_quantization_map("e4m3")
+    qmap = qt_oracle.get_quantization_map(dtype)
     one = int(qt_oracle.f32_to_bf16(np.array([1.0], np.float32))[0])
     c_oracle.fake_quant_bf16(x[: 1 << 20], qmap, one)
     t0 = time.perf_counter()
@@ -255,7 +282,175 @@ def cpu_baseline_leg():
         if el > 12.0:
             break
     return {"value": reps * n / el, "unit": "elements/s", "cores": c_oracle.num_threads(), "kind": "port",
-            "sample": f"{reps} x bf16[4096,11008] E4M3 fake-quant passes (scale 1), {el:.1f} s, OpenMP static"}
+            "sample": f"{reps} x bf16[{shape[0]},{shape[1]}] {dtype} fake-quant passes (scale 1), {el:.1f} s, OpenMP static"}
+
+
+def fqt_gemm_leg(device, dtype, M, Ns, K):
+    """qt_linear_fqt_bf16 -- bf16 GEMM with the weight's value map (`dtype`) applied in its operand path -- at one problem shape,
+    rotating over weights beyond the Infinity Cache, HIP events on the launch stream; against the dense bf16 matrix-core peak."""
+    from quantized_training import fused
+    import quantized_training as qt
+
+    class _L:                                              # what hip_fqt_linear_or_none reads of a layer
+        def __init__(self, w):
+            self.weight, self.bias = w, None
+    fq = qt.FusedAmaxObsFakeQuantize(dtype=dtype).to(device)
+    tables = fused.fqt_tables(fq, device)
+    if tables is None:
+        return None
+    N = sum(Ns)
+    pool = max(2, min(8, int(600e6 // (N * K * 2)) + 1))
+    x = fq((torch.randn(M, K, device=device)).bfloat16())
+    ws = [[_L((torch.randn(n, K, device=device) * 0.02).bfloat16()) for n in Ns] for _ in range(pool)]
+    if fused.hip_fqt_linear_or_none(x, ws[0], tables) is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for iters in (pool, 5 * pool):
+        e0.record()
+        for i in range(iters):
+            fused.hip_fqt_linear_or_none(x, ws[i % pool], tables)
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    nbytes = N * K * 2 + M * K * 2 + M * N * 2
+    del x, ws
+    torch.cuda.empty_cache()
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "ms_per_launch": round(ms, 5), "flops_per_launch": 2 * M * N * K, "traffic": None,
+            "kernel": f"linear_fqt_kernel: bf16 GEMM {M}x{N}x{K} with the {dtype} value map applied to the bf16 weight in its operand path",
+            "hbm_view": {"algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+
+
+def lib_fp8_gemm_leg(device, M, N, K):
+    """Library FP8 GEMM (qt_fp8_gemm, hipBLASLt) at one shape: the route the committed table keeps for the BERT-base widths."""
+    from quantized_training.fused import lt_fp8_gemm
+    pool = 8
+    a8 = torch.randn(M, K, device=device).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(pool, N, K, device=device) * 0.02).to(torch.float8_e4m3fn)
+    if lt_fp8_gemm(a8, b8[0]) is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for iters in (pool, 5 * pool):
+        e0.record()
+        for i in range(iters):
+            lt_fp8_gemm(a8, b8[i % pool])
+        e1.record()
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_PEAK_TFLOPS, 4),
+            "ms_per_launch": round(ms, 5), "flops_per_launch": 2 * M * N * K, "traffic": None,
+            "kernel": f"FP8 E4M3 GEMM {M}x{N}x{K} (BERT-base intermediate dense), fp32 accumulate, bf16 out"}
+
+
+def encoder_workload(a, device, world, rank, multi, sync):
+    """BASELINE.json configs[1] and configs[4] as bench workloads (one step = one batch; every rank its own batches, no data-path
+    collective).  configs[1]: BERT-base QA model, SQuAD-style eval batches [16, 384] (run_squad.py:29-47 -> run_qa_no_trainer.py:914-959),
+    E4M3 activations + weights, forward replayed from a hipGraph.  configs[4]: RoBERTa-base classifier, MRPC-style batches [16, 128]
+    (run_glue_no_trainer.py:647-700), int8 activations + weights with delayed scaling, E5M2 gradients through the backward hooks,
+    clip 1.0 + AdamW, the whole step replayed from a hipGraph.  Returns the JSON dict on rank 0 (None elsewhere)."""
+    import quantized_training as qt
+    from quantized_training import fused, harness
+    from quantized_training.fake_quantize import STATS
+    torch.manual_seed(0)
+    need = a.warmup + a.steps
+    g = torch.Generator().manual_seed(1 + rank)
+    if a.kind == "bert":
+        from transformers import BertConfig, BertForQuestionAnswering
+        model = BertForQuestionAnswering(BertConfig()).to(device).eval()
+        qt.quantize(model, qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--bf16", "--quantize_forward", "gemm"]))
+        B, S = 16, 384
+        batches = [{"input_ids": torch.randint(1000, 30000, (B, S), generator=g).to(device), "attention_mask": torch.ones(B, S, dtype=torch.long, device=device),
+                    "token_type_ids": torch.zeros(B, S, dtype=torch.long, device=device)} for _ in range(need)]
+        with torch.no_grad():
+            for _ in range(2):
+                model(**batches[0])
+            STATS.reset()
+            model(**batches[0])
+            sync()
+            elems, calls = STATS.elements, STATS.calls
+            step = harness.GraphedBatch(model, batches[0])
+            run = lambda b: step.replay(b)                      # noqa: E731
+            for i in range(a.warmup):
+                run(batches[i])
+            if multi:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                run(batches[a.warmup + i])
+            sync()
+            if multi:
+                dist.barrier()
+            sync()
+            el = time.perf_counter() - t0
+        what = (f"BERT-base QA model (12 layers, hidden 768, random init) SQuAD-style eval batch [{B}, {S}], fake-quant activation={a.activation} "
+                f"weight={a.weight}, --quantize_forward gemm (weights re-quantized every forward)")
+        launch = "hipGraph replay"
+        shape_w = (768, 3072)
+    else:
+        from transformers import RobertaConfig, RobertaForSequenceClassification
+        model = RobertaForSequenceClassification(RobertaConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(device).bfloat16()
+        qt.quantize(model, qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--error",
+                                                           "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm",
+                                                           "--quantize_backprop", "gemm,residual", "--bf16"]))
+        B, S = 16, 128
+        batches = [{"input_ids": torch.randint(3, 50000, (B, S), generator=g).to(device), "labels": torch.randint(0, 2, (B,), generator=g).to(device)}
+                   for _ in range(need + 3)]
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, capturable=True)
+        harness.train_steps(model, batches[:2], torch.optim.AdamW(model.parameters(), lr=2e-5))
+        STATS.reset()
+        harness.train_steps(model, batches[2:3], torch.optim.AdamW(model.parameters(), lr=2e-5))
+        sync()
+        elems, calls = STATS.elements, STATS.calls
+        step = harness.GraphedTrainStep(model, opt)
+        step.capture(batches[0], warmup=3)
+        for i in range(a.warmup):
+            step.replay(batches[3 + i])
+        if multi:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step.replay(batches[3 + a.warmup + i])
+        sync()
+        if multi:
+            dist.barrier()
+        sync()
+        el = time.perf_counter() - t0
+        what = (f"RoBERTa-base classifier (12 layers, hidden 768, random init) MRPC-style TRAINING step [{B}, {S}]: fake-quant activation={a.activation} "
+                f"weight={a.weight}, E5M2 gradients (--quantize_backprop gemm,residual), clip 1.0, AdamW")
+        launch = "hipGraph replay (forward + backward + optimizer)"
+        shape_w = (768, 3072)
+    t = torch.tensor([el], device=device, dtype=torch.float64)
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    if rank != 0:
+        return None
+    total = elems * a.steps * world
+    out = {"metric": "quantized_elements_per_sec", "value": total / el, "unit": "elements/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": what, "elements_per_step": elems, "fake_quant_calls_per_step": calls,
+                      "parallelism": f"dp{world} (one batch per rank and step, no data-path collective)", "launch": launch, "valid": True,
+                      "routes": fused.routes_report()},
+           "fraction_of_hbm_roofline": round(total / el * 4.0 / (HBM_PEAK_GBPS * 1e9 * world), 4)}
+    del model
+    torch.cuda.empty_cache()
+    if not a.no_roofline:
+        if a.kind == "bert":
+            leg = lib_fp8_gemm_leg(device, 6144, 3072, 768)
+            ew = roofline_leg(device, a.weight, shape_w)
+            if leg is not None:
+                leg["elementwise_pass"] = ew
+            out["roofline"] = leg if leg is not None else ew
+        else:
+            out["roofline"] = roofline_leg(device, a.weight, shape_w)
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(a.weight, shape_w)
+    return out
 
 
 def main():
@@ -290,6 +485,15 @@ def main():
     import quantized_training as qt
     from quantized_training import harness
     from quantized_training.fake_quantize import STATS
+
+    if a.kind != "llama" and not a.dry_run:
+        out = encoder_workload(a, device, world, rank, multi, sync)
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
     model = harness.build_causal_lm(a.model, device=device, seed=0, num_layers=a.layers,
                                     dtype=torch.float32 if a.dry_run else torch.bfloat16)
@@ -380,7 +584,8 @@ def main():
                        "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
                        "launch": "hipGraph replay" if graph_used else "eager",
-                       "valid": bool(full) and not a.cache_eval_weights and not a.dry_run},
+                       "valid": bool(full) and not a.cache_eval_weights and not a.dry_run,
+                       "routes": fused_routes()},
             "mean_window_nll": float(allnll.double().mean().item()),
             # north_star: elements/s "as absolute and as fraction of HBM roofline" -- SURVEY 8(d)'s 4 B per quantized element
             # (bf16 in + bf16 out) against the HBM peak of the GPUs used
@@ -392,8 +597,14 @@ def main():
             torch.cuda.empty_cache()
         if not a.no_roofline:
             out["roofline"] = roofline_leg(device, a.weight, model_shape)
+            if a.weight.split(",")[0] not in ("e4m3", "e5m2") and "qs=" not in a.weight:
+                # every other stateless spec: the widest Linears (q / k / v as one launch, the lm head) run the value map inside a bf16 GEMM
+                leg = fqt_gemm_leg(device, a.weight, a.max_length, [hidden, hidden, hidden], hidden)
+                if leg is not None:
+                    leg["elementwise_pass"] = out["roofline"]
+                    out["roofline"] = leg
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg()
+            out["cpu_baseline"] = cpu_baseline_leg(a.weight, model_shape)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

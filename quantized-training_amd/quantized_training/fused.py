@@ -38,11 +38,47 @@ def fq8_gemm_enabled():
 
 
 _FQ8_CHOICE = {}          # (M, Ns, K, activation dtype, weight format, device) -> True: fused kernel, False: pass + library GEMM
+ROUTES = {}               # what ran, for the bench line: "MxNxK" -> route name (first decision per shape)
+
+# Measured on MI355X (tools/exp_linear_fq8.py, gpurun_out/fq8_routes.log -> profiles/r03_fq8_routes.txt): microseconds of the fused
+# kernel against the weight pass + library GEMM, weights rotating beyond the Infinity Cache.  (M, sum N, K) -> fused kernel wins.
+# The default route of a shape is this table, then the rule below: the same on every box, rank and run.
+_FQ8_TABLE = {
+    (1024, 11008, 4096): True,    # 54.7 / 69.1
+    (1024, 4096, 11008): True,    # 68.0 / 72.8
+    (1024, 4096, 4096): True,     # 27.9 / 32.9
+    (1024, 12288, 4096): True,    # 54.7 / 70.5  (q / k / v)
+    (1024, 32000, 4096): True,    # 159.8 / 169.8
+    (1024, 8192, 4096): True,     # 44.9 / 50.2
+    (1024, 6144, 4096): True,     # 40.7 / 43.1
+    (512, 11008, 4096): True,     # 43.3 / 56.0
+    (256, 11008, 4096): True,     # 30.0 / 43.2
+    (2048, 11008, 4096): True,    # 102.5 / 105.3
+    (2048, 4096, 4096): False,    # 45.5 / 45.0
+    (4096, 4096, 4096): False,    # 87.6 / 57.6
+    (6144, 768, 768): True,       # 16.7 / 27.2
+    (6144, 2304, 768): False,     # 29.6 / 27.6  (q / k / v)
+    (6144, 3072, 768): False,     # 35.2 / 30.1
+    (6144, 768, 3072): False,     # 34.4 / 27.6
+    (1024, 13824, 5120): False,   # 99.1 / 88.2
+    (1024, 5120, 13824): False,   # 111.5 / 107.2
+    (1024, 5120, 5120): True,     # 46.3 / 47.1
+    (1024, 15360, 5120): False,   # 105.9 / 96.7 (q / k / v)
+}
+
+
+def _note_route(kind, M, ns, K, route):
+    ROUTES.setdefault(f"{kind}:{M}x{sum(ns)}x{K}", route)
+
+
+def routes_report():
+    """The GEMM routes taken so far, per problem shape (bench.py puts them into its JSON line)."""
+    return dict(sorted(ROUTES.items()))
 
 
 def _fq8_heuristic(M, ns, K, device):
-    """Without a measurement (first call inside a stream capture, or QT_FQ8_TUNE=0): the fused kernel where it filled the chip
-    in one round of 256-row tiles at least five column groups wide -- what the sweep in DESIGN.md 6b showed for M <= 1024."""
+    """Shapes the table does not list: the fused kernel where it fills the chip in one round of 256-row tiles at least five column
+    groups wide -- what the sweep in DESIGN.md 6b showed for M <= 1024."""
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     tiles_m = (M + 255) // 256
     groups = sum(ns) // 16
@@ -54,8 +90,9 @@ def _fq8_heuristic(M, ns, K, device):
 
 
 def _fq8_measure(x8, layers):
-    """Times both routes on this very problem (device events around four launches after two warm-up ones, twice, alternating) and
-    returns True when the fused kernel is faster.  Outputs are discarded; no fake-quant call is counted."""
+    """QT_FQ8_TUNE=1 only: times both routes on this very problem (device events around four launches after two warm-up ones, twice,
+    alternating) and returns True when the fused kernel is faster.  Outputs are discarded; no fake-quant call is counted.  Under
+    torch.distributed rank 0's verdict is broadcast, so every rank takes the same route."""
     dev = x8.device
     K = x8.shape[-1]
     n = len(layers)
@@ -76,38 +113,63 @@ def _fq8_measure(x8, layers):
         return hip_fq8_linear_or_none(x8, layers)
 
     if fused() is None:
-        return False
-    if pair() is None:
-        return True
-    best = [float("inf"), float("inf")]
-    for _ in range(2):                                     # two alternating rounds, the better one of each route counts
-        for i, fn in enumerate((fused, pair)):
-            for _ in range(2):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(dev))
-            for _ in range(4):
-                fn()
-            e1.record(torch.cuda.current_stream(dev))
-            e1.synchronize()
-            best[i] = min(best[i], e0.elapsed_time(e1))
-    return best[0] < best[1]
+        verdict = False
+    elif pair() is None:
+        verdict = True
+    else:
+        best = [float("inf"), float("inf")]
+        for _ in range(2):                                     # two alternating rounds, the better one of each route counts
+            for i, fn in enumerate((fused, pair)):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(dev))
+                for _ in range(4):
+                    fn()
+                e1.record(torch.cuda.current_stream(dev))
+                e1.synchronize()
+                best[i] = min(best[i], e0.elapsed_time(e1))
+        verdict = best[0] < best[1]
+    return _agree_across_ranks(verdict, dev)
+
+
+def _agree_across_ranks(flag, device):
+    """rank 0's value of a measured choice, on every rank (no-op without an initialised process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else "cpu")
+    dist.broadcast(t, src=0)
+    return bool(int(t.item()))
+
+
+def fq8_tune_enabled():
+    """QT_FQ8_TUNE=1: decide unknown shapes by timing both routes on the first call (outside stream capture).  Off by default: the
+    two routes sum in different orders, so a timing race would make logits depend on the box, the run and the rank."""
+    return os.environ.get("QT_FQ8_TUNE", "0") == "1"
 
 
 def fq8_route_is_fused(x8, layers):
-    """Route of one fake-quant Linear problem (x8 [M, K] FP8 codes x the bf16 weights of `layers`)."""
-    mode = fq8_gemm_mode()
-    if mode != "auto":
-        return mode == "1"
+    """Route of one fake-quant Linear problem (x8 [M, K] FP8 codes x the bf16 weights of `layers`): QT_FQ8_GEMM=0 / 1 forces it; else
+    the committed table, else (QT_FQ8_TUNE=1, outside a capture) a measurement agreed across ranks, else the rule."""
     K = x8.shape[-1]
     M = x8.numel() // K
     ns = tuple(l.weight.shape[0] for l in layers)
-    key = (M, ns, K, x8.dtype, layers[0].weight_fake_quant._qt_format.key(), x8.device.index)
-    hit = _FQ8_CHOICE.get(key)
-    if hit is None:
-        if torch.cuda.is_current_stream_capturing() or os.environ.get("QT_FQ8_TUNE", "1") == "0":
-            return _fq8_heuristic(M, ns, K, x8.device)       # not remembered: a later call outside capture may measure
-        hit = _FQ8_CHOICE[key] = bool(_fq8_measure(x8, layers))
+    mode = fq8_gemm_mode()
+    if mode != "auto":
+        hit = mode == "1"
+    else:
+        hit = _FQ8_TABLE.get((M, sum(ns), K))
+        if hit is None:
+            key = (M, ns, K, x8.dtype, layers[0].weight_fake_quant._qt_format.key(), x8.device.index)
+            hit = _FQ8_CHOICE.get(key)
+            if hit is None:
+                if fq8_tune_enabled() and not torch.cuda.is_current_stream_capturing():
+                    hit = bool(_fq8_measure(x8, layers))
+                else:
+                    hit = _fq8_heuristic(M, ns, K, x8.device)
+                _FQ8_CHOICE[key] = hit
+    _note_route("fq8", M, ns, K, "fused_fp8_gemm" if hit else "weight_pass+library_fp8_gemm")
     return hit
 
 
@@ -369,38 +431,50 @@ def hip_mlp_fq8_or_none(x8, gate, up, out_fq):
 _MLP_CHOICE = {}          # (M, N, K, activation dtype, formats, device) -> True: one launch, False: two fused GEMMs + SiLU * up
 
 
+# (M, N, K) -> the gated MLP's front half as ONE launch (qt_mlp_fq8_bf16) beats two fused GEMMs + SiLU * up; measured on MI355X
+# (profiles/r02_mlp_fq8.txt and the window profiles: 114 us inside the LLaMA-2-7B window against 132 us for the three launches)
+_MLP_TABLE = {
+    (1024, 11008, 4096): True,
+    (512, 11008, 4096): True,     # 67.3 / 96.5
+}
+
+
 def mlp_route_is_one_launch(x8, gate, up, out_fq, three_launches):
-    """Whether qt_mlp_fq8_bf16 beats the launches it would replace on this problem: measured on the first call outside a stream
-    capture (`three_launches()` runs the two fused GEMMs and the SiLU * up pass on the same inputs); inside a capture, without a
-    measurement: one launch where it fills the chip in a single round (512 x 11008 x 4096: 67 against 97 us; at 1024 rows it needs two
-    rounds of uneven tiles and loses, 141 against 132 us)."""
+    """Whether qt_mlp_fq8_bf16 runs the gated MLP's front half on this problem: QT_FQ8_MLP=2 forces it; else the committed table;
+    else (QT_FQ8_TUNE=1, outside a capture) a measurement against `three_launches()` agreed across ranks; else one launch where
+    it fills the chip in a single round."""
     if os.environ.get("QT_FQ8_MLP", "1") == "2":              # always (tests, ablations)
         return True
     K = x8.shape[-1]
     M = x8.numel() // K
     N = gate.weight.shape[0]
-    key = (M, N, K, x8.dtype, gate.weight_fake_quant._qt_format.key(), out_fq._qt_format.key(), x8.device.index)
-    hit = _MLP_CHOICE.get(key)
+    hit = _MLP_TABLE.get((M, N, K))
     if hit is None:
-        if torch.cuda.is_current_stream_capturing() or os.environ.get("QT_FQ8_TUNE", "1") == "0":
-            cus = torch.cuda.get_device_properties(x8.device).multi_processor_count
-            return ((M + 255) // 256) * ((N // 16 + 5) // 6) <= cus
-        if hip_mlp_fq8_or_none(x8, gate, up, out_fq) is None:
-            hit = False
-        else:
-            times = []
-            for fn in (lambda: hip_mlp_fq8_or_none(x8, gate, up, out_fq), three_launches):
-                for _ in range(2):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(torch.cuda.current_stream(x8.device))
-                for _ in range(3):
-                    fn()
-                e1.record(torch.cuda.current_stream(x8.device))
-                e1.synchronize()
-                times.append(e0.elapsed_time(e1))
-            hit = times[0] < times[1]
-        _MLP_CHOICE[key] = hit
+        key = (M, N, K, x8.dtype, gate.weight_fake_quant._qt_format.key(), out_fq._qt_format.key(), x8.device.index)
+        hit = _MLP_CHOICE.get(key)
+        if hit is None:
+            if fq8_tune_enabled() and not torch.cuda.is_current_stream_capturing():
+                if hip_mlp_fq8_or_none(x8, gate, up, out_fq) is None:
+                    hit = False
+                else:
+                    times = []
+                    for fn in (lambda: hip_mlp_fq8_or_none(x8, gate, up, out_fq), three_launches):
+                        for _ in range(2):
+                            fn()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(torch.cuda.current_stream(x8.device))
+                        for _ in range(3):
+                            fn()
+                        e1.record(torch.cuda.current_stream(x8.device))
+                        e1.synchronize()
+                        times.append(e0.elapsed_time(e1))
+                    hit = times[0] < times[1]
+                hit = _agree_across_ranks(hit, x8.device)
+            else:
+                cus = torch.cuda.get_device_properties(x8.device).multi_processor_count
+                hit = ((M + 255) // 256) * ((N // 16 + 5) // 6) <= cus
+            _MLP_CHOICE[key] = hit
+    _note_route("mlp", M, [N, N], K, "one_launch_gate_up_silu" if hit else "two_gemms+silu_mul")
     return hit
 
 
@@ -673,6 +747,12 @@ def fqt_route_is_fused(M, ns, K, device):
     return groups / tn >= 7.0 and tiles_m * tn >= 0.9 * rounds * cus
 
 
+def _fqt_route(M, ns, K, device):
+    hit = fqt_route_is_fused(M, ns, K, device)
+    _note_route("fqt", M, ns, K, "fused_value_map_gemm" if hit else "weight_pass+library_bf16_gemm")
+    return hit
+
+
 def hip_fqt_linear_or_none(x2, layers, tables):
     """y[M, sum N] = x2 . [fq(W_0); fq(W_1); ...]^T + bias through qt_linear_fqt_bf16: x2 [M, K] holds the bf16 VALUES of the already
     fake-quantized activation, the bf16 weights of `layers` go through the row form of their value map inside the kernel."""
@@ -743,7 +823,7 @@ def fqt_linear_or_none(layer, x):
             afq = [getattr(l, "activation_pre_process", None) for l in group.layers]
             afq = [h["0"] if h is not None and "0" in h else None for h in afq]
             same = same and all(isinstance(f, FusedAmaxObsFakeQuantize) and f.stateless_map() and str(f.dtype) == str(afq[0].dtype) for f in afq)
-            if same and getattr(x, "_qt_origin", None) is not None and fqt_route_is_fused(M, Ns, K, x.device):
+            if same and getattr(x, "_qt_origin", None) is not None and _fqt_route(M, Ns, K, x.device):
                 if not x2.is_contiguous():
                     x2 = x2.contiguous()
                 y = hip_fqt_linear_or_none(x2, group.layers, tables)
@@ -751,7 +831,7 @@ def fqt_linear_or_none(layer, x):
                     STATS.add(W.numel())
                     group.stash = (("fqt",) + tuple(key), y, [True] + [False] * (len(Ns) - 1))
                     return y[:, :Ns[0]].reshape(*x.shape[:-1], Ns[0])
-    if not fqt_route_is_fused(M, [W.shape[0]], K, x.device):
+    if not _fqt_route(M, [W.shape[0]], K, x.device):
         return None
     if not x2.is_contiguous():
         x2 = x2.contiguous()

@@ -97,6 +97,12 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     core = fused_attention_or_none(module, query, key, value, attention_mask, scaling, dropout)
     if core is not None:
         return core, None                      # probabilities are never materialised on this path
+    # The fused core declined (a hooked sub-module, dropout while training, a mask it cannot address, ...).  A producer that
+    # expected it may have written only the FP8 codes of q / k (model_fusions.rope_fq, `_qt_lazy`): give the tensors their
+    # values BEFORE any view is taken -- a view does not carry the lazy state, and the matmul below would read unwritten memory.
+    from ...fake_quantize import materialize_lazy
+    materialize_lazy(query)
+    materialize_lazy(key)
     key_t = key.transpose(2, 3)
     if getattr(key, "_qt_fq_done_by", None) is not None and getattr(key, "_qt_ver", None) == key._version:
         key_t._qt_ver = key._qt_ver                          # a view shares the version counter

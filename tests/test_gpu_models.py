@@ -143,6 +143,64 @@ def test_llama_mlp_front_half_as_one_launch(monkeypatch):
     assert torch.equal(outs["0"], outs["2"])
 
 
+def test_declined_attention_core_materializes_code_only_rotary_outputs(monkeypatch):
+    """with the FP8 attention kernel planned, the rotary kernel writes only the FP8 codes of q / k (`_qt_lazy`).  When the
+    fused core then declines -- here: a forward hook on the softmax module, and the library FP8 GEMM switched off -- the module chain
+    must see the VALUES of q and k (attention.py materializes them before K is transposed), not unwritten memory: logits equal to the
+    same model evaluated with the code-only launch switched off."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from quantized_training import fake_quantize
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=320, max_position_embeddings=256)
+    m = LlamaForCausalLM(cfg).eval().bfloat16().cuda()
+    qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16"))
+    ids = torch.randint(3, 320, (1, 128), generator=torch.Generator().manual_seed(2)).cuda()
+    seen = {"n": 0}
+
+    def hook(mod, args, out):
+        seen["n"] += 1
+    handles = [mod.register_forward_hook(hook) for name, mod in m.named_modules() if name.endswith("self_attn.softmax")]
+    assert handles, "the quantizable attention block has a softmax sub-module"
+    monkeypatch.setenv("QT_LT_GEMM", "0")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QT_ROPE_VALUE_LAUNCH", mode)
+        with torch.no_grad():
+            m(ids)
+            outs[mode] = m(ids).logits.float()
+    for h in handles:
+        h.remove()
+    assert seen["n"] > 0, "the module chain ran (the fused core declined)"
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"])
+
+
+def test_gemm_routes_are_fixed_and_reported(monkeypatch):
+    """the route of a problem shape comes from the committed tables / rules in fused.py, never from a timing race
+    (QT_FQ8_TUNE is opt-in), so two evaluations of the same model give bit-identical logits and `fused.routes_report()` names the
+    route of every GEMM shape."""
+    from quantized_training import fused
+    monkeypatch.delenv("QT_FQ8_TUNE", raising=False)
+    assert not fused.fq8_tune_enabled()
+
+    def run():
+        fused._FQ8_CHOICE.clear(); fused._MLP_CHOICE.clear(); fused.ROUTES.clear()
+        m = harness.build_causal_lm("llama-tiny", device="cuda", dtype=torch.bfloat16, seed=0)
+        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16"))
+        ids = torch.randint(3, 500, (1, 256), generator=torch.Generator().manual_seed(2)).cuda()
+        with torch.no_grad():
+            m(ids)
+            return m(ids).logits.float(), fused.routes_report()
+    a, ra = run()
+    b, rb = run()
+    assert torch.equal(a, b) and ra == rb and len(ra) >= 1
+    assert all(v in ("fused_fp8_gemm", "weight_pass+library_fp8_gemm", "one_launch_gate_up_silu", "two_gemms+silu_mul",
+                     "fused_value_map_gemm", "weight_pass+library_bf16_gemm") for v in ra.values())
+    # the committed table, not a measurement: BASELINE.json's LLaMA-2-7B shapes
+    assert fused._FQ8_TABLE[(1024, 11008, 4096)] is True and fused._FQ8_TABLE[(4096, 4096, 4096)] is False
+
+
 def test_bert_squad_style_batch_parity(monkeypatch):
     """BERT-base-style QA head (tiny config, head_dim 64 as in BERT-base), bf16, E4M3 act+weight + all op groups: start/end logits of a
     [16, 384]-shaped batch: CPU tensors against the device's plain route (same operations: tight) and its default route.  The default
