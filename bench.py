@@ -399,7 +399,7 @@ def encoder_workload(a, device, world, rank, multi, sync):
         B, S = 16, 128
         batches = [{"input_ids": torch.randint(3, 50000, (B, S), generator=g).to(device), "labels": torch.randint(0, 2, (B,), generator=g).to(device)}
                    for _ in range(need + 3)]
-        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, fused=True, capturable=True)
         harness.train_steps(model, batches[:2], torch.optim.AdamW(model.parameters(), lr=2e-5))
         STATS.reset()
         harness.train_steps(model, batches[2:3], torch.optim.AdamW(model.parameters(), lr=2e-5))
