@@ -574,20 +574,43 @@ def _rbf64(x):
     return bf16_to_f32(f32_to_bf16(np.asarray(x, dtype=np.float64).astype(np.float32))).astype(np.float64)
 
 
-def softmax_fq(scores_bits, mask_bits, scaling, qmap):
-    """scores_bits: uint16 [..., rows, cols] bf16 patterns; mask_bits: broadcastable uint16 array or None; scaling: python
-    float (multiplied as fp32, like torch's bf16-tensor x scalar); qmap: uint16[65536] or None.  Returns (p_bits, pq_bits)."""
+def scale_and_mask(scores_bits, mask_bits, scaling):
+    """The softmax's input in bf16: bf16(bf16(score x scaling) + mask), each step ONE rounding of an exactly representable fp32
+    result (modeling_bert.py:142-146: MulFunctional with a python float, then `+ attention_mask`).  Returns float64 values."""
     s = bf16_to_f32(scores_bits).astype(np.float64)
     t = _rbf64(s.astype(np.float32) * np.float32(scaling))
     if mask_bits is not None:
         m = bf16_to_f32(mask_bits).astype(np.float64)
         with np.errstate(over="ignore"):
             t = _rbf64(t + m)
+    return t
+
+
+def softmax_fq(scores_bits, mask_bits, scaling, qmap):
+    """scores_bits: uint16 [..., rows, cols] bf16 patterns; mask_bits: broadcastable uint16 array or None; scaling: python
+    float (multiplied as fp32, like torch's bf16-tensor x scalar); qmap: uint16[65536] or None.  Returns (p_bits, pq_bits).
+    Pinned to upstream's BertSelfAttention twin by tests/test_oracle_golden.py::test_attention_chain (tests/golden/attn_chain.*)."""
+    t = scale_and_mask(scores_bits, mask_bits, scaling)
     mx = t.max(axis=-1, keepdims=True)
     e = np.exp(t - mx)
     p = e / e.sum(axis=-1, keepdims=True)
     p_bits = f32_to_bf16(p.astype(np.float32))
     return p_bits, (vmap_bf16(p_bits, qmap) if qmap is not None else p_bits)
+
+
+def softmax_fq_f32(scores, mask, scaling, qmap):
+    """The same chain on an fp32 model (no bf16 rounding points; the probabilities' fake-quantizer indexes the map with
+    hi16 | sticky, decomposed.py:151-153): scores / mask float32 arrays.  exp and the sums in float64, ONE rounding to fp32.
+    Returns (p float32, pq float32)."""
+    t = (scores.astype(np.float32) * np.float32(scaling)).astype(np.float32)
+    if mask is not None:
+        with np.errstate(over="ignore"):
+            t = (t + mask.astype(np.float32)).astype(np.float32)
+    t = t.astype(np.float64)
+    mx = t.max(axis=-1, keepdims=True)
+    e = np.exp(t - mx)
+    p = (e / e.sum(axis=-1, keepdims=True)).astype(np.float32)
+    return p, (vmap_f32(p, qmap) if qmap is not None else p)
 
 
 def attention_fq(q_bits, k_bits, v_bits, mask_bits, scaling, qmap):

@@ -861,6 +861,7 @@ def main():
         "fq_extra": lambda: gb.gen_fq_extra(ref, a.out),
         "checkpoint": lambda: gb.gen_checkpoint(ref, a.out),
         "posit_opts": lambda: gb.gen_posit_opts(ref, a.out),
+        "attn_chain": lambda: gb.gen_attn_chain(ref, a.out),
     })
     for k, fn in steps.items():
         if a.only and k not in a.only.split(","):

@@ -13,6 +13,11 @@ container only -- imports /root/reference through _ref_import).
   fq_extra.npz + fq_extra.json
         FusedAmaxObsFakeQuantize with record_histogram / outlier_threshold (fake_quantize.py:348-359, 401-402): outputs,
         histogram buffer, max_outlier_pct, per call.
+  attn_chain.npz + attn_chain.json
+        the attention chain of upstream's BertSelfAttention twin (modeling_bert.py:118-158) tapped with forward (pre-)hooks
+        registered AFTER upstream's quantize(): the fake-quantized q / k^T / probabilities / v as the matmuls receive them, the
+        raw scores, the scaled scores, the softmax output and the context -- at fp32 and bf16, e4m3 and posit8_1, head_dim 64
+        and 128.  Pins oracle.softmax_fq / attention_fq (tests/test_oracle_golden.py::test_attention_chain).
   checkpoint.npz + checkpoint.json
         a state_dict produced by upstream after calibration forwards (lazily sized amax_history / scale buffers,
         fake_quantize.py:406-435), the inputs of the next forward and upstream's outputs for it.
@@ -274,3 +279,66 @@ def gen_posit_opts(ref, out):
         arrays[f"p{nbits}_{es}/y"] = g.canon_nan32(g.f32_bits(y1))
         arrays[f"p{nbits}_{es}/pbits"] = pb.numpy().astype(np.int32)
     np.savez_compressed(os.path.join(out, "posit_opts.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+
+
+# ---- the attention chain of upstream's BertSelfAttention twin, tapped -------------------------------------------------------
+ATTN_CASES = {
+    # name: (activation spec, dtype, heads, head_dim, B, S)
+    "e4m3_bf16_hd64": ("e4m3", torch.bfloat16, 2, 64, 2, 40),
+    "e4m3_bf16_hd128": ("e4m3", torch.bfloat16, 2, 128, 2, 40),
+    "posit8_1_bf16_hd64": ("posit8_1", torch.bfloat16, 2, 64, 2, 40),
+    "posit8_1_bf16_hd128": ("posit8_1", torch.bfloat16, 2, 128, 1, 40),
+    "e4m3_f32_hd64": ("e4m3", torch.float32, 2, 64, 2, 40),
+    "posit8_1_f32_hd128": ("posit8_1", torch.float32, 2, 128, 1, 40),
+}
+
+
+def gen_attn_chain(ref, out):
+    g = _helpers()
+    _ref_twin_mappings(ref)
+    from transformers import BertConfig
+    arrays, meta = {}, {}
+    for name, (spec, dtype, heads, hd, B, S) in ATTN_CASES.items():
+        cfg = BertConfig(hidden_size=heads * hd, num_hidden_layers=1, num_attention_heads=heads, intermediate_size=2 * heads * hd, vocab_size=120,
+                         max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        blk = mm.seeded_init_(mm.BertBlock(cfg), 21, std=0.9 / np.sqrt(heads * hd)).eval()
+        if dtype == torch.bfloat16:
+            blk = blk.bfloat16()
+        ref.quantize.quantize(blk, make_args(ref, activation=spec, weight=None, quantize_forward="gemm", bf16=dtype == torch.bfloat16))
+        att = blk.attention.self
+        taps = {}
+
+        def pre(tag):
+            def hook(mod, args):
+                for i, t in enumerate(args):
+                    if torch.is_tensor(t):
+                        taps[f"{tag}.in{i}"] = t.detach().clone()
+            return hook
+
+        def post(tag):
+            def hook(mod, args, outp):
+                taps[f"{tag}.out"] = outp.detach().clone()
+            return hook
+        hs = []
+        for tag in ("qk_matmul", "attn_scaling", "softmax", "av_matmul"):
+            m = getattr(att, tag)
+            hs.append(m.register_forward_pre_hook(pre(tag)))          # registered after upstream's hooks: sees what the op receives
+            hs.append(m.register_forward_hook(post(tag)))
+        r = np.random.default_rng(300 + hd)
+        h = torch.from_numpy((r.standard_normal((B, S, heads * hd)) * 1.5).astype(np.float32)).to(dtype)
+        keep = torch.ones(B, S)
+        keep[B - 1, S - 7:] = 0
+        mask = mm.additive_mask(keep, dtype)
+        with torch.no_grad():
+            ctx = att(h, mask)[0]
+        for hk in hs:
+            hk.remove()
+        taps["mask"] = mask
+        taps["context"] = ctx
+        for k, v in taps.items():
+            arrays[f"{name}/{k}"] = g.tensor_bits(v)
+        meta[name] = {"spec": spec, "dtype": str(dtype).replace("torch.", ""), "heads": heads, "head_dim": hd, "B": B, "S": S,
+                      "scaling": 1.0 / float(np.sqrt(hd)), "taps": {k: list(v.shape) for k, v in taps.items()}}
+    np.savez_compressed(os.path.join(out, "attn_chain.npz"), **{k.replace("/", "__"): v for k, v in arrays.items()})
+    with open(os.path.join(out, "attn_chain.json"), "w") as f:
+        json.dump(meta, f, indent=1)
