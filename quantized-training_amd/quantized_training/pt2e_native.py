@@ -13,8 +13,8 @@ cores:
   * int8 x int8: both operands narrowed to int8 codes (weights once, at fusion time), `qt_q8_gemm` -- v_mfma_i32_16x16x64_i8,
     exact int32 accumulation -- with bias, the rounding of the GEMM output to the model dtype, the dequantize multiply and its
     rounding in the epilogue (the rounding points of the three-node sequence are kept);
-  * fp8_e4m3 / fp8_e5m2 (per-tensor scaled): operands narrowed to OCP FP8 codes, FP8 GEMM (`qt_fp8_gemm`), then the
-    dequantize kernel.
+  * fp8_e4m3 / fp8_e5m2 (per-tensor scaled): operands narrowed to OCP FP8 codes, the in-tree scaled-MFMA GEMM at unit block
+    scales (`qt_mx_gemm`; the library GEMM `qt_fp8_gemm` only where that kernel does not take the shape), then the dequantize kernel.
 
 The graph `convert_pt2e` returns is untouched on the CPU (it is pinned node for node to upstream's); fusion is a separate,
 idempotent pass that convert_pt2e applies to device models (`native=None` -> automatic, `QT_PT2E_NATIVE=0` turns it off).
@@ -69,6 +69,35 @@ def _q8(a, b, bias, out_scale, out_map, out_shape, batch, M, N, K, a_bs, b_bs, d
     return y
 
 
+_UNIT_E8M0 = {}          # device -> uint8 tensor of 127s (scale 2^0): the block scales of a per-tensor FP8 operand
+_MX_FMT = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}
+
+
+def _fp8_codes_gemm(a, w, bias):
+    """C = a . w^T (+ bias) on FP8 CODES through the in-tree scaled-MFMA GEMM (qt_mx_gemm, v_mfma_scale_f32_16x16x128_f8f6f4) at unit
+    block scales: per-tensor FP8 operands are a block-scaled operand whose every scale is 2^0.  None when the kernel does not take
+    the problem (the caller then keeps the library GEMM)."""
+    if os.environ.get("QT_PT2E_FP8_NATIVE", "1") == "0":
+        return None
+    M, K = a.shape
+    N = w.shape[0]
+    if K % 32 or a.dtype not in _MX_FMT or w.dtype not in _MX_FMT or not a.is_contiguous() or not w.is_contiguous() or a.data_ptr() % 16 or w.data_ptr() % 16:
+        return None
+    need = max(M, N) * (K // 32)
+    ones = _UNIT_E8M0.get(a.device)
+    if ones is None or ones.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ones = torch.full((need,), 127, dtype=torch.uint8, device=a.device)
+        _UNIT_E8M0[a.device] = ones
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    rc = _native.lib().qt_mx_gemm(a.data_ptr(), ones.data_ptr(), _MX_FMT[a.dtype], w.data_ptr(), ones.data_ptr(), _MX_FMT[w.dtype], y.data_ptr(), 0,
+                                  bias.data_ptr() if bias is not None else None, 1, M, N, K, 0, 0, _stream_ptr(a))
+    if rc != 0:
+        return None
+    return y
+
+
 def _linear_q(input, scale, qmap, weight_codes, bias, out_scale, out_map, kind):
     if input.device.type != "cuda" or input.dtype not in (torch.bfloat16, torch.float32):
         w = weight_codes.to(input.dtype)
@@ -81,8 +110,13 @@ def _linear_q(input, scale, qmap, weight_codes, bias, out_scale, out_map, kind):
         STATS["linear_int8"] += 1
         return _q8(a, weight_codes, bias, out_scale, out_map, (*input.shape[:-1], N), 1, M, N, K, 0, 0, input.dtype)
     if kind in _FP8 and input.dtype == torch.bfloat16:
-        from .fused import lt_fp8_gemm
-        y = lt_fp8_gemm(a, weight_codes, bias.to(torch.bfloat16) if bias is not None else None)
+        b16 = bias.to(torch.bfloat16).contiguous() if bias is not None else None
+        y = _fp8_codes_gemm(a.contiguous(), weight_codes, b16)
+        if y is not None:
+            STATS["linear_fp8_native"] = STATS.get("linear_fp8_native", 0) + 1
+        else:
+            from .fused import lt_fp8_gemm
+            y = lt_fp8_gemm(a, weight_codes, b16)
         if y is not None:
             STATS["linear_fp8"] += 1
             y = y.reshape(*input.shape[:-1], N)

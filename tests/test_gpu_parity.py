@@ -2061,7 +2061,7 @@ def test_pt2e_native_matches_value_tensor_route_at_size(nv, monkeypatch):
 
 def test_pt2e_fp8_linears_run_on_the_fp8_matrix_cores(nv, monkeypatch):
     """bf16 model, `fp8_e4m3,qs=per_tensor_symmetric` activations and weights: the converted graph's Linears narrow both
-    operands to OCP FP8 codes and run the library FP8 GEMM (counted), against the value-tensor route."""
+    operands to OCP FP8 codes and run the in-tree FP8 GEMM (qt_mx_gemm at unit block scales; counted), against the value-tensor route."""
     from quantized_training import pt2e_native, quantize_pt2e as qp
 
     class Net(torch.nn.Module):
@@ -2083,9 +2083,12 @@ def test_pt2e_fp8_linears_run_on_the_fp8_matrix_cores(nv, monkeypatch):
         with torch.no_grad():
             gm(x), gm(x * 0.5)
         before = pt2e_native.STATS["linear_fp8"]
+        before_native = pt2e_native.STATS.get("linear_fp8_native", 0)
         gc = qp.convert_pt2e(gm)
         with torch.no_grad():
             outs[native] = gc(x).float()
         assert (pt2e_native.STATS["linear_fp8"] - before) == (2 if native == "1" else 0)
+        # ... and on the in-tree scaled-MFMA kernel (qt_mx_gemm at unit block scales), not the library GEMM
+        assert (pt2e_native.STATS.get("linear_fp8_native", 0) - before_native) == (2 if native == "1" else 0)
     rel = ((outs["1"] - outs["0"]).norm(dim=-1) / outs["0"].norm(dim=-1).clamp_min(1e-6)).max()
     assert float(rel) <= 0.02, float(rel)
