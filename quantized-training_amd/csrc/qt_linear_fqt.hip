@@ -188,7 +188,7 @@ constexpr int walk(int RT, int NTW, int NB, int from_kind, int from_idx, int to_
 //   first    request activation tile t+2 and RAW weight tile t+4
 //   then     the LDS stream above: RT multiplications per column group on tile t, and 2 NB units of weight tile t+1 converted IN
 //            PLACE, spread evenly over the groups; the rows of unit u+1 are in flight while unit u is computed
-template <int TM, int NB, bool SROWS, int ABL = 0>
+template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
 struct LinearFqt {
     static constexpr int kDA = 3, kDW = 5, kU = 2 * NB;
     static constexpr int kRT = TM / 64;                     // 16-row tiles of a wave's row band (TM / 4 rows)
@@ -212,7 +212,7 @@ struct LinearFqt {
 
     // One wave's share: rows [wm * TM / 4, + TM / 4) x NTW column groups starting at group jbase of the tile whose first group is
     // tg0.  Returns true when a flagged row was met (the caller redoes the tile).
-    template <int NTW>
+    template <int NTW, int PH = 0>
     static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
         const int r = l & 15, g = l >> 4, wm = w & 3;
         const int nk = a.K / kBK, klast = nk - 1;
@@ -495,20 +495,129 @@ struct LinearFqt {
             }
         }
         int sa = 0, sw = 0;                                        // stages multiplied in this step (activations, weights)
-        for (int kt = 0; kt < nk; ++kt) {
-            stamp_kt = kt; stamp(29);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
-            stamp(31);
-            __builtin_amdgcn_s_barrier();
-            stamp_kt = kt;
-            stamp(0);
-            // the stages requested now are the ones multiplied in step t - 1
-            const int sa_req = sa == 0 ? kDA - 1 : sa - 1, sw_req = sw == 0 ? kDW - 1 : sw - 1, sw_cv = sw == kDW - 1 ? 0 : sw + 1;
-            compute(a0 + sa * kABytes, w0 + sw * kWBytes, w0 + sw_cv * kWBytes, min(kt + kDA - 1, klast), a0 + sa_req * kABytes,
-                    min(kt + kDW - 1, klast), w0 + sw_req * kWBytes);
-            stamp(30);
-            sa = sa == kDA - 1 ? 0 : sa + 1;
-            sw = sw_cv;
+        if constexpr (PP) {
+            // ---- ping-pong: the two waves of a SIMD (column halves PH = 0 / 1) run half a step apart.  A step is two phases with a
+            // barrier behind each: LOAD (fragments of the step into registers, the step's conversion units, the step's requests: LDS,
+            // vector and DMA-issue work) and COMPUTE (the step's multiplications, from registers only).  Half 0 loads while half 1
+            // multiplies the previous step, then the roles swap: the matrix pipe of a SIMD is fed by one wave while the other one
+            // does everything else (MI355X_MICROARCH.md, "Two waves per SIMD").
+            //   barrier 2t+1 | half 0: LOAD(t)     half 1: COMPUTE(t-1)
+            //   barrier 2t+2 | half 0: COMPUTE(t)  half 1: LOAD(t)
+            // LDS hazards: a stage is read only in LOAD phases (into registers), so it may be requested again two barriers later; the
+            // counted vmcnt sits at the end of every LOAD, in front of its barrier (same count as the lockstep loop's).
+            u32x4 pfa[kRT], pfb[NTW > 0 ? NTW : 1];
+            auto pp_load = [&](int kt) __attribute__((always_inline)) {
+                const int sa_req = sa == 0 ? kDA - 1 : sa - 1, sw_req = sw == 0 ? kDW - 1 : sw - 1, sw_cv = sw == kDW - 1 ? 0 : sw + 1;
+                const uint32_t sa_ = a0 + sa * kABytes, sb_ = w0 + sw * kWBytes, wc = w0 + sw_cv * kWBytes;
+                read_raw(wc);
+                if constexpr (NTW > 0) {
+                    pfa[0] = ds_read128<0 * 1024>(sa_ + a_frag); pfa[1] = ds_read128<1 * 1024>(sa_ + a_frag);
+                    pfa[2] = ds_read128<2 * 1024>(sa_ + a_frag); pfa[3] = ds_read128<3 * 1024>(sa_ + a_frag);
+                    if constexpr (kRT > 4) {
+                        pfa[4] = ds_read128<4 * 1024>(sa_ + a_frag); pfa[5] = ds_read128<5 * 1024>(sa_ + a_frag);
+                        pfa[6] = ds_read128<6 * 1024>(sa_ + a_frag); pfa[7] = ds_read128<7 * 1024>(sa_ + a_frag);
+                    }
+                    pfb[0] = ds_read128<0 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 1) pfb[1] = ds_read128<1 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 2) pfb[2] = ds_read128<2 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 3) pfb[3] = ds_read128<3 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 4) pfb[4] = ds_read128<4 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 5) pfb[5] = ds_read128<5 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 6) pfb[6] = ds_read128<6 * 1024>(sb_ + b_frag);
+                    if constexpr (NTW > 7) pfb[7] = ds_read128<7 * 1024>(sb_ + b_frag);
+                }
+                if constexpr (ABL != 2) {
+                    // the raw pieces were requested first: younger are the fragment reads
+                    constexpr int nraw = (NTW > 0 ? kRT + NTW : 0) > 15 ? 15 : (NTW > 0 ? kRT + NTW : 0);
+                    if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(raw[0]), "+v"(raw[1]) : "n"(nraw));
+                    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[0]) : "n"(nraw));
+                    unit_gather(std::integral_constant<int, 0>{});
+                    auto slot = [&](auto uc) __attribute__((always_inline)) {
+                        constexpr int U = decltype(uc)::value;
+                        if constexpr (U + 1 < kU) unit_gather(std::integral_constant<int, U + 1>{});
+                        if constexpr (ABL != 5 && ABL != 6) {
+                            // younger than G(U): the previous unit's write and the next unit's rows
+                            constexpr int n = (U + 1 < kU ? 4 : 0) + (U > 0 ? 1 : 0);
+                            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rows[U & 1][0]), "+v"(rows[U & 1][1]), "+v"(rows[U & 1][2]), "+v"(rows[U & 1][3]) : "n"(n));
+                        }
+                        unit_finish(uc, wc);
+                    };
+                    slot(std::integral_constant<int, 0>{});
+                    if constexpr (kU > 1) slot(std::integral_constant<int, 1>{});
+                    if constexpr (kU > 2) slot(std::integral_constant<int, 2>{});
+                    if constexpr (kU > 3) slot(std::integral_constant<int, 3>{});
+                }
+                request(min(kt + kDA - 1, klast), a0 + sa_req * kABytes, min(kt + kDW - 1, klast), w0 + sw_req * kWBytes);
+                if constexpr (NTW > 0) {
+                    if constexpr (kRT > 4) {
+                        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
+                                     : "+v"(pfa[0]), "+v"(pfa[1]), "+v"(pfa[2]), "+v"(pfa[3]), "+v"(pfa[4]), "+v"(pfa[5]), "+v"(pfa[6]), "+v"(pfa[7])
+                                     : "n"(kVmTop) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : "+v"(pfa[0]), "+v"(pfa[1]), "+v"(pfa[2]), "+v"(pfa[3]) : "n"(kVmTop) : "memory");
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(pfb[j]));
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
+                }
+                sa = sa == kDA - 1 ? 0 : sa + 1;
+                sw = sw_cv;
+            };
+            auto pp_compute = [&]() __attribute__((always_inline)) {
+                if constexpr (NTW > 0 && ABL != 1) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const v8s bf = __builtin_bit_cast(v8s, pfb[j]);
+#pragma unroll
+                        for (int i = 0; i < kRT; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(v8s, pfa[i]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the prologue's conversions are written
+            if constexpr (PH == 0) {
+                for (int kt = 0; kt < nk; ++kt) {
+                    __builtin_amdgcn_s_barrier();
+                    pp_load(kt);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    pp_compute();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            } else {
+                for (int kt = 0; kt < nk; ++kt) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt > 0) pp_compute();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    pp_load(kt);
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                pp_compute();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                stamp_kt = kt; stamp(29);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
+                stamp(31);
+                __builtin_amdgcn_s_barrier();
+                stamp_kt = kt;
+                stamp(0);
+                // the stages requested now are the ones multiplied in step t - 1
+                const int sa_req = sa == 0 ? kDA - 1 : sa - 1, sw_req = sw == 0 ? kDW - 1 : sw - 1, sw_cv = sw == kDW - 1 ? 0 : sw + 1;
+                compute(a0 + sa * kABytes, w0 + sw * kWBytes, w0 + sw_cv * kWBytes, min(kt + kDA - 1, klast), a0 + sa_req * kABytes,
+                        min(kt + kDW - 1, klast), w0 + sw_req * kWBytes);
+                stamp(30);
+                sa = sa == kDA - 1 ? 0 : sa + 1;
+                sw = sw_cv;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         // A lane that read a flagged row raises the workgroup's flag (through LDS: the table is dead here).
@@ -608,7 +717,7 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
     }
 }
 
-template <int TM, int NB, bool SROWS, int ABL = 0>
+template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
 __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_t[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -627,10 +736,10 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFqt<TM, NB, SROWS, ABL>;
+    using L = LinearFqt<TM, NB, SROWS, ABL, PP>;
     if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map is written in absolute addresses
     bool redo;
-#define QT_RUN(N) L::template run<N>(a, lds_t, m0, tg0, nt, jbase, w, l)
+#define QT_RUN(N) (PP && wn == 1 ? L::template run<N, 1>(a, lds_t, m0, tg0, nt, jbase, w, l) : L::template run<N, 0>(a, lds_t, m0, tg0, nt, jbase, w, l))
     switch (ntw) {                                          // wave-uniform
         case 0: redo = QT_RUN(0); break;
         case 1: redo = QT_RUN(1); break;
@@ -659,16 +768,16 @@ int cu_count() {
     return n;
 }
 
-template <int TM, int NB, bool SROWS, int ABL = 0>
+template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
 int launch_one(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFqt<TM, NB, SROWS>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fqt_kernel<TM, NB, SROWS, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fqt_kernel<TM, NB, SROWS, ABL, PP><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -688,6 +797,8 @@ int launch(const Args &a, hipStream_t st, int tm) {
                 default: break;
             }
         }
+        static const int pp = getenv("QT_FQT_PP") ? atoi(getenv("QT_FQT_PP")) : 0;      // A-B switch: the ping-pong loop
+        if (pp) return launch_one<512, 1, SROWS, 0, true>(a, st);
         return launch_one<512, 1, SROWS>(a, st);
     }
     const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
