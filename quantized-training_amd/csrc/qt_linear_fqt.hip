@@ -41,6 +41,7 @@ namespace {
 
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -59,6 +60,7 @@ struct Args {
     const uint32_t *rows;     // [512][4] row parameters (device)
     const uint16_t *map;      // [65536] value map (device): the redo path
     uint32_t sign_mask;
+    int prio;                // static issue priority of waves 4-7 (QT_FQT_PRIO)
     unsigned long long *dbg; // ABL 9 (QT_FQT_STAMPS = device address): s_memtime stamps of workgroup 0, waves 0 and 4, k step 40
     int M, K, ldc;
     int tiles_m, tiles_n, nseg;
@@ -234,6 +236,10 @@ struct LinearFqt {
         for (int i = 0; i < kPA; ++i) {
             const int row = (w * kPA + i) * 16 + (l >> 2);
             ga[i] = (uint32_t)((long)min(m0 + row, a.M - 1) * krow) + (chunk_pos(row, l & 3) << 4);
+            if constexpr (ABL == 7) {        // timing probe: whole 128-byte lines (8 rows per piece) instead of half lines
+                const int row8 = (w * kPA + i) * 8 + (l >> 3);
+                ga[i] = (uint32_t)((long)min(m0 + row8, a.M - 1) * krow) + ((l & 7) << 4);
+            }
         }
         // Weight pieces: piece p = w + 8 i is column group p of the tile; the lane's 16 bytes land at piece base + 16 l and are
         // converted there.  Surplus pieces (p >= nt) re-request piece 0 into the dummy kilobyte.
@@ -257,8 +263,9 @@ struct LinearFqt {
         const uint32_t sign_mask = a.sign_mask;
         int stamp_kt = -1;
         auto stamp = [&](int slot) __attribute__((always_inline)) {
-            if constexpr (ABL == 9) {
-                if (stamp_kt == 40 && blockIdx.x == 0 && (w == 0 || w == 4) && l == 0) a.dbg[(w >> 2) * 32 + slot] = __builtin_amdgcn_s_memtime();
+            if constexpr (ABL == 9 || ABL == 8) {
+                if (ABL == 8 && !(slot == 29 || slot == 31 || slot == 0 || slot == 30)) return;     // light: four stamps per step
+                if (stamp_kt >= 40 && stamp_kt < 44 && blockIdx.x == 0 && l == 0) a.dbg[(w * 4 + (stamp_kt - 40)) * 32 + slot] = __builtin_amdgcn_s_memtime();
             }
         };
         auto dma16 = [](const void *base, uint32_t off, uint32_t dst) __attribute__((always_inline)) {
@@ -272,7 +279,7 @@ struct LinearFqt {
         auto req_piece = [&](auto ic, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < kPA) {
-                const uint8_t *xb = (const uint8_t *)a.x + (long)ka * kRowBytes;
+                const uint8_t *xb = (const uint8_t *)a.x + (ABL == 7 ? (long)(ka >> 1) * 128 : (long)ka * kRowBytes);
                 if constexpr (ABL != 3) dma16(xb, ga[I], as + (w * kPA + I) * 1024);
                 else dma16(xb, ga[I], dummy);
             } else {
@@ -375,6 +382,15 @@ struct LinearFqt {
         };
         static_assert(NB <= 2, "first_rows lists two pieces");
 
+        v16f acc32[4][2];                                         // ABL 10 only
+        if constexpr (ABL == 10) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+        }
         v4f acc[kRT][NTW > 0 ? NTW : 1];
 #pragma unroll
         for (int i = 0; i < kRT; ++i)
@@ -406,6 +422,14 @@ struct LinearFqt {
                     constexpr int J = decltype(jc)::value;
                     constexpr int P = J % 3;
                     __builtin_amdgcn_sched_barrier(0);
+                    // the younger wave of a SIMD (column half 1) loses the issue arbitration to the older one and would set the pace of
+                    // the step; it runs the first part of the step at priority 1 and the rest at 0, so that both finish together
+                    if constexpr (PH == 1 && !PP) {
+                        if (a.prio == 4) {
+                            if constexpr (J == 0) __builtin_amdgcn_s_setprio(1);
+                            if constexpr (J == (NTW + 1) / 2) __builtin_amdgcn_s_setprio(0);
+                        }
+                    }
                     if constexpr (J + 2 < NTW) read_b(std::integral_constant<int, J + 2>{});
                     constexpr int kAhead = walk(kRT, NTW, NB, kOpRB, J, kWaitF, J);
                     static_assert(kAhead >= 0, "schedule");
@@ -425,7 +449,15 @@ struct LinearFqt {
                     // consecutive output columns of one row.  The multiplications come first in program order; the vector work
                     // of the group (a unit's arithmetic, the next unit's row addresses) is woven between them below.
                     const v8s bf = __builtin_bit_cast(v8s, fb[P]);
-                    if constexpr (ABL != 1) {
+                    if constexpr (ABL == 10) {
+                        // timing probe (results are garbage): the same flops as v_mfma_f32_32x32x16_bf16 -- half the instructions, each
+                        // holding the matrix pipe twice as long: per PAIR of column groups 4 row tiles x 2 k halves
+                        if constexpr ((J & 1) == 0 && kRT == 8) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                acc32[i >> 1][J >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(v8s, fa[i]), acc32[i >> 1][J >> 1], 0, 0, 0);
+                        }
+                    } else if constexpr (ABL != 1) {
 #pragma unroll
                         for (int i = 0; i < kRT; ++i)
                             acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(v8s, fa[i]), acc[i][J], 0, 0, 0);
@@ -489,8 +521,8 @@ struct LinearFqt {
                 q.x = quant_pair(v.x, p[0], p[1], sign_mask); q.y = quant_pair(v.y, p[2], p[3], sign_mask);
                 q.z = quant_pair(v.z, p[4], p[5], sign_mask); q.w = quant_pair(v.w, p[6], p[7], sign_mask);
                 const uint32_t f = (p[0].y | p[1].y | p[2].y) | (p[3].y | p[4].y | p[5].y) | (p[6].y | p[7].y);
-                if constexpr (ABL == 0 || ABL == 9) flags |= real[i] ? f : 0u;
-                if constexpr (ABL != 0 && ABL != 9) q = v;
+                if constexpr (ABL == 0 || ABL == 9 || ABL == 8) flags |= real[i] ? f : 0u;
+                if constexpr (ABL != 0 && ABL != 9 && ABL != 8) q = v;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(piece_addr(i, w0)), "v"(q) : "memory");
             }
         }
@@ -625,10 +657,18 @@ struct LinearFqt {
         volatile int *flag = (volatile int *)lds;
         if (w == 0 && l == 0) *flag = 0;
         __syncthreads();
-        if ((flags & 1u) && (ABL == 0 || ABL == 9)) *flag = 1;
+        if ((flags & 1u) && (ABL == 0 || ABL == 9 || ABL == 8)) *flag = 1;      // (ABL 7 computes garbage: never redo)
         __syncthreads();
         if (*flag) return true;
 
+        if constexpr (ABL == 10 && NTW > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][0][e & 3] += acc32[i][j][e];
+        }
         // ---- epilogue.  Lane (r, g) of tile (i, j) holds y[row wm*TM/4 + i*16 + r][column group j, columns 4g .. 4g+3]; every wave
         // turns its tile around in its own LDS, 64 rows at a time (no barrier: wave-private), and stores whole rows, 16 bytes per lane.
         if constexpr (NTW > 0) {
@@ -738,8 +778,17 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
     using L = LinearFqt<TM, NB, SROWS, ABL, PP>;
     if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map is written in absolute addresses
+    // The two waves of a SIMD are w and w + 4; the SIMD's issue arbitration prefers the older one (waves 0-3), and the younger half then
+    // sets the pace of every k step (measured, tools/exp_fqt_stamps.py: 1750 against 1230 cycles of work per step, the older half
+    // waiting 600 cycles at the barrier).  A static priority for the younger half evens that out (MI355X_MICROARCH.md, "Two waves per
+    // SIMD", item 4).  a.prio (QT_FQT_PRIO): 0 none, 1-3 static priority of the younger half, 4 (default) the younger half at priority
+    // 1 for the first half of every step only (set inside the step; 183 against 190 us at 1024 x 13824 x 5120).
+    if (a.prio == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (a.prio == 2 && w >= 4) __builtin_amdgcn_s_setprio(2);
+    if (a.prio == 3 && w >= 4) __builtin_amdgcn_s_setprio(3);
+    if (a.prio == -1 && w < 4) __builtin_amdgcn_s_setprio(1);
     bool redo;
-#define QT_RUN(N) (PP && wn == 1 ? L::template run<N, 1>(a, lds_t, m0, tg0, nt, jbase, w, l) : L::template run<N, 0>(a, lds_t, m0, tg0, nt, jbase, w, l))
+#define QT_RUN(N) (wn == 1 ? L::template run<N, 1>(a, lds_t, m0, tg0, nt, jbase, w, l) : L::template run<N, 0>(a, lds_t, m0, tg0, nt, jbase, w, l))
     switch (ntw) {                                          // wave-uniform
         case 0: redo = QT_RUN(0); break;
         case 1: redo = QT_RUN(1); break;
@@ -793,6 +842,9 @@ int launch(const Args &a, hipStream_t st, int tm) {
                 case 3: return launch_one<512, 1, false, 3>(a, st);
                 case 5: return launch_one<512, 1, false, 5>(a, st);
                 case 6: return launch_one<512, 1, false, 6>(a, st);
+                case 7: return launch_one<512, 1, false, 7>(a, st);
+                case 10: return launch_one<512, 1, false, 10>(a, st);
+                case 8: return launch_one<512, 1, false, 8>(a, st);
                 case 9: return launch_one<512, 1, false, 9>(a, st);
                 default: break;
             }
@@ -844,6 +896,8 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     a.x = x_dev; a.y = y_dev; a.rows = rows_dev; a.map = map_dev; a.sign_mask = sign_mask;
     a.M = M; a.K = K; a.ldc = (int)ntot;
     {
+        const char *e_pr = getenv("QT_FQT_PRIO");
+        a.prio = e_pr ? atoi(e_pr) : 4;
         const char *e_st = getenv("QT_FQT_STAMPS");
         a.dbg = e_st ? (unsigned long long *)strtoull(e_st, nullptr, 0) : nullptr;
     }
