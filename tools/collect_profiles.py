@@ -95,11 +95,37 @@ for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_brea
                  ("bench_13b_posit8_2.json", "13b_posit8_2_bench.json"), ("mx_gemm.log", "mx_gemm.txt"), ("mx_linear.log", "mx_linear.txt"),
                  ("mx_quant.log", "mx_quant.txt"), ("mx_wide.log", "mx_wide_ablation.txt"), ("tile_fetch.log", "tile_fetch_probe.txt"),
                  ("fq8_session.txt", "linear_fq8_gemm.txt"), ("mlp_fq8.txt", "mlp_fq8.txt"), ("attention_fp8.txt", "attention_fp8.txt"), ("table_formats.txt", "table_formats.txt"), ("oracle_attention.txt", "oracle_attention.txt"),
-                 ("bert_batch.txt", "bert_batch.txt"), ("train_step.txt", "train_step.txt")):
+                 ("bert_batch.txt", "bert_batch.txt"), ("train_step.txt", "train_step.txt"),
+                 # round 3
+                 ("bench_llama-13b-posit8_2.json", "13b_posit8_2_bench.json"), ("bench_bert-base-squad-e4m3.json", "bert_base_squad_bench.json"),
+                 ("bench_roberta-mrpc-int8-e5m2-train.json", "roberta_mrpc_train_bench.json"), ("fqt_gemm.txt", "linear_fqt_gemm.txt"),
+                 ("fqt_ablate.txt", "linear_fqt_ablations.txt"), ("fqt_stamps.txt", "linear_fqt_step_stamps.txt"), ("fq8_routes.txt", "fq8_routes.txt")):
     clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
 for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
                      ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv"),
-                     ("prof_bert_stats/*/*kernel_stats.csv", "bert_kernel_stats.csv"), ("prof_train_stats/*/*kernel_stats.csv", "train_kernel_stats.csv")):
+                     ("prof_bert_stats/*/*kernel_stats.csv", "bert_kernel_stats.csv"), ("prof_train_stats/*/*kernel_stats.csv", "train_kernel_stats.csv"),
+                     ("prof_fqt/*/*kernel_stats.csv", "linear_fqt_kernel_stats.csv")):
     f = one(pattern)
     if f:
         shutil.copy(f, os.path.join(out, f"{tag}_{dst}"))
+
+# round 3: HBM traffic of the value-map GEMM (qt_linear_fqt_bf16, 1024 x 15360 x 5120) from its own PMC passes
+try:
+    fetch, nf = pmc(one("pmc_fetch_fqt/*/*counter_collection.csv"), "FETCH_SIZE", "linear_fqt_kernel")
+    write, nw = pmc(one("pmc_write_fqt/*/*counter_collection.csv"), "WRITE_SIZE", "linear_fqt_kernel")
+    krows = list(csv.DictReader(open(one("prof_fqt/*/*kernel_stats.csv"))))
+    k = [r for r in krows if "linear_fqt_kernel" in r["Name"]][0]
+    M_, N_, K_ = 1024, 15360, 5120
+    alg = N_ * K_ * 2 + M_ * K_ * 2 + M_ * N_ * 2
+    fq = {"kernel": k["Name"][:120], "launches_sampled": [nf, nw], "FETCH_SIZE_KB_raw_per_launch": fetch, "fetch_bytes_per_launch": int(fetch * 1024 * 2),
+          "WRITE_SIZE_KB_per_launch": write, "write_bytes_per_launch": int(write * 1024), "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+          "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch * 1024 * 2 + write * 1024) / alg,
+          "kernel_avg_duration_us_rocprof": float(k["AverageNs"]) / 1e3,
+          "note": "1024 x 15360 x 5120 (q / k / v of LLaMA-2-13B as one launch): bf16 weights once + bf16 activations once + bf16 output once"}
+    path = os.path.join(out, f"{tag}_pmc_traffic.json")
+    res = json.load(open(path)) if os.path.exists(path) else {}
+    res["value_map_gemm"] = fq
+    json.dump(res, open(path, "w"), indent=1)
+    print(json.dumps(fq, indent=1))
+except Exception as e:  # noqa: BLE001
+    print("no value-map GEMM rows in the PMC passes:", e)
