@@ -445,6 +445,15 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
                                                       const float *__restrict__ scale, uint32_t *amax_out,
                                                       uint2 *__restrict__ y8 = nullptr) {
     Rounder<KIND> rnd{fmt, lut};
+    if constexpr (KIND == kFmtRows) {                    // the row words behind the map, as in fq_kernel
+        __shared__ uint4 s_rows[512];
+        const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = lut;
+        __syncthreads();
+    }
     float s = scale ? qt_bf2f(qt_f2bf(*scale)) : 1.0f;
     const bool unit = (s == 1.0f);
     const UniformDiv dv(s);
@@ -1162,7 +1171,10 @@ int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, lo
         else fq_rows_kernel<K, false><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);      \
     } while (0)
     switch (fmt->kind) {
-        case QT_FMT_LUT: QT_ROWS(QT_FMT_LUT); break;
+        case QT_FMT_LUT:
+            if (fmt->p1 & 1) QT_ROWS(kFmtRows);          // row form behind the map
+            else QT_ROWS(QT_FMT_LUT);
+            break;
         case QT_FMT_FP_SAT: QT_ROWS(QT_FMT_FP_SAT); break;
         case QT_FMT_INT: QT_ROWS(QT_FMT_INT); break;
         case QT_FMT_IDENTITY: QT_ROWS(QT_FMT_IDENTITY); break;

@@ -82,6 +82,7 @@ def _table_for(dtype, device):
         if flat is None:
             idx, vals = m
             flat = vals[idx].contiguous()
+            flat._qt_dtype = dtype
             _MAP_CACHE[key] = flat
         return flat
     return m
@@ -272,7 +273,7 @@ def _forward_rows(input, rows, observe, qmap, amax_history, scale, quant_max, po
     v, transposed = rows
     L = _native.lib()
     st = _stream_ptr(v)
-    fmt = fmt if fmt is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0)
+    fmt = _launch_format(fmt if fmt is not None else _native.QtFormat(_native.QT_FMT_LUT, 0, 0, 0.0, 0.0), qmap)
     if observe:
         launch_scale_update(amax_history, scale, quant_max, pow2, st)
     y = torch.empty(v.shape, dtype=v.dtype, device=v.device)
@@ -662,7 +663,9 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
     def _move_to(self, device):
         if self.scale.device != device or self.amax_history.device != device:
             self.to(device)
-        if self.qmap.device != device:
+        # `model.to(device)` leaves a plain copy of the host map in the buffer: take the cached device map instead, which carries the
+        # row form behind its entries (_device_map) and the `_qt_dtype` tag the block-scaled GEMMs look for
+        if self.qmap.device != device or (device.type == "cuda" and getattr(self.qmap, "_qt_dtype", None) is None):
             self.qmap = _table_for(self.dtype, device)
             if self.scale_qmap is not None:
                 self.scale_qmap = _table_for(self.scale_dtype, device)

@@ -128,6 +128,21 @@ def test_row_form_pass_equals_the_value_map(nv, dtype, scale):
         fq = qt.FusedAmaxObsFakeQuantize(dtype=dtype).cuda()
         y = fq(xd.view(torch.bfloat16))
         assert np.array_equal(o.canon_nan16(host_u16(y.view(torch.int16))), exp)
+        # a module built on the host and moved (`model.to("cuda")` copies the plain map into the buffer) takes the cached device
+        # map -- and with it the row form -- on its first call
+        moved = qt.FusedAmaxObsFakeQuantize(dtype=dtype).to("cuda")
+        assert getattr(moved.qmap, "_qt_rows", 0) == 0
+        y = moved(xd.view(torch.bfloat16))
+        assert moved.qmap is qt.get_quantization_map(dtype, xd.device) and (_launch_format(moved._qt_format, moved.qmap).p1 & 1)
+        assert np.array_equal(o.canon_nan16(host_u16(y.view(torch.int16))), exp)
+        # strided rows (qt_fake_quant_rows_bf16: a [B, S, H, D] projection seen as [B, H, S, D], and K^T)
+        t = xd.view(torch.bfloat16)[:4 * 64 * 8 * 128].view(4, 64, 8, 128).transpose(1, 2)
+        e = torch.from_numpy(exp[:t.numel()].view(np.int16)).view(4, 64, 8, 128).transpose(1, 2)
+        for view, want in ((t, e), (t.transpose(-1, -2), e.transpose(-1, -2))):
+            assert not view.is_contiguous()
+            got = fq(view)
+            assert np.array_equal(o.canon_nan16(host_u16(got.contiguous().view(torch.int16))),
+                                  want.contiguous().numpy().view(np.uint16).reshape(-1)), dtype
 
 
 @pytest.mark.parametrize("dtype", ["e4m3", "int8"])

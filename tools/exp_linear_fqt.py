@@ -171,7 +171,10 @@ def main():
     s13 = [(1024, [13824], 5120), (1024, [5120], 13824), (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120), (1024, [32000], 5120)]
     s7 = [(1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096], 4096), (1024, [4096, 4096, 4096], 4096), (1024, [32000], 4096)]
     bert = [(6144, [768], 768), (6144, [3072], 768), (6144, [768], 3072), (6144, [768, 768, 768], 768)]
-    shapes = {"13b": s13, "7b": s7, "bert": bert, "all": s13 + s7 + bert, "one": s13[:1], "none": []}[args.shapes]
+    if "x" in args.shapes:      # custom: "1024x14336x5120,1024x12288x5120"
+        shapes = [(int(m), [int(n)], int(k)) for m, n, k in (t.split("x") for t in args.shapes.split(","))]
+    else:
+        shapes = {"13b": s13, "7b": s7, "bert": bert, "all": s13 + s7 + bert, "one": s13[:1], "none": []}[args.shapes]
     for d in args.bench_dtypes.split(","):
         for (M, Ns, K) in shapes:
             bench(M, Ns, K, args.iters, fmts[d])
