@@ -456,8 +456,8 @@ struct LinearFq8R {
         auto item = [&](auto ic, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < 4) {
-                if constexpr (ABL != 3) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
-            } else if constexpr (ABL != 2) {
+                if constexpr (ABL != 3 && ABL != 5 && ABL != 6) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
+            } else if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
                 store_w(std::integral_constant<int, I - 4>{}, ws);
                 load_w(std::integral_constant<int, I - 4>{}, kb);
             }
@@ -492,7 +492,7 @@ struct LinearFq8R {
         auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             if constexpr (NTW > 0) {
                 u32x4 fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
-                if constexpr (ABL != 4) {
+                if constexpr (ABL != 4 && ABL != 6) {
                     fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
                     fa_lo[1] = ds_read128<1 * 2048>(sa_ + a_lo); fa_hi[1] = ds_read128<1 * 2048>(sa_ + a_hi);
                     fa_lo[2] = ds_read128<2 * 2048>(sa_ + a_lo); fa_hi[2] = ds_read128<2 * 2048>(sa_ + a_hi);
@@ -500,7 +500,7 @@ struct LinearFq8R {
                 }
                 auto read_b = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
-                    if constexpr (ABL != 4) {
+                    if constexpr (ABL != 4 && ABL != 6) {
                         fb_lo[J % 3] = ds_read128<J * 2048>(sb_ + b_lo);
                         fb_hi[J % 3] = ds_read128<J * 2048>(sb_ + b_hi);
                     }
@@ -530,7 +530,7 @@ struct LinearFq8R {
                     }
                     const v8i fb = v8i{(int)fb_lo[P].x, (int)fb_lo[P].y, (int)fb_lo[P].z, (int)fb_lo[P].w,
                                        (int)fb_hi[P].x, (int)fb_hi[P].y, (int)fb_hi[P].z, (int)fb_hi[P].w};
-                    if constexpr (ABL != 1 && ABL != 4) {
+                    if constexpr (ABL != 1 && ABL != 4 && ABL != 6) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
@@ -1177,6 +1177,8 @@ int launch(const Args &a, hipStream_t st) {
                 case 2: return launch_r_nb<0, 0, 6, false, 2>(a, st);
                 case 3: return launch_r_nb<0, 0, 6, false, 3>(a, st);
                 case 4: return launch_r_nb<0, 0, 6, false, 4>(a, st);
+                case 5: return launch_r_nb<0, 0, 6, false, 5>(a, st);     // no operand traffic: fragment reads + multiplications + barriers
+                case 6: return launch_r_nb<0, 0, 6, false, 6>(a, st);     // barriers only
                 default: break;
             }
         }
