@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--stride", type=int, default=512)
     ap.add_argument("--activation", default=None)
     ap.add_argument("--weight", default=None)
+    ap.add_argument("--route", default="eager", choices=["eager", "pt2e"],
+                    help="(llama workloads) eager: quantize() hooks + QAT modules; pt2e: the reference's current wikitext.py flow -- "
+                         "torch.export + prepare_pt2e, chains rewritten to the fused kernels (pt2e_fusion)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--cache-eval-weights", action="store_true",
                     help="side experiment (line marked invalid): keep fq(W) across windows instead of re-quantizing, "
@@ -497,9 +500,14 @@ def main():
 
     model = harness.build_causal_lm(a.model, device=device, seed=0, num_layers=a.layers,
                                     dtype=torch.float32 if a.dry_run else torch.bfloat16)
-    qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--quantize_forward", "gemm"]
-                                           + ([] if a.dry_run else ["--bf16"]))
-    qt.quantize(model, qargs)
+    fusion_counts = None
+    if a.route == "pt2e":
+        model = harness.prepare_pt2e_causal_lm(model, a.activation, a.weight, a.max_length)
+        fusion_counts = getattr(model, "fusion_counts", None)
+    else:
+        qargs = qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--quantize_forward", "gemm"]
+                                               + ([] if a.dry_run else ["--bf16"]))
+        qt.quantize(model, qargs)
     if a.cache_eval_weights:
         model.eval()
         harness.cache_quantized_weights(True)
@@ -578,9 +586,12 @@ def main():
             "dtype": "f32" if a.dry_run else "bf16", "data": "synthetic",
             "config": {"workload": f"{a.model}-shaped LLaMA ({layers} layers, hidden {hidden}, random init) "
                                    f"WikiText-style window eval B=1 S={a.max_length} stride {a.stride}, "
-                                   f"fake-quant activation={a.activation} weight={a.weight}, --quantize_forward gemm "
+                                   f"fake-quant activation={a.activation} weight={a.weight}, "
+                                   + ("--quantize_forward gemm " if a.route == "eager" else
+                                      "PT2E route (torch.export + prepare_pt2e, wikitext.py:60-136; fused prepared graph) ")
                                    + ("(weights re-quantized every forward)" if not a.cache_eval_weights
                                       else "(EXPERIMENT: quantized weights cached across windows)"),
+                       "route": a.route, **({"pt2e_fusions": fusion_counts} if fusion_counts is not None else {}),
                        "elements_per_step": elems_per_step, "fake_quant_calls_per_step": calls_per_step,
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
                        "launch": "hipGraph replay" if graph_used else "eager",

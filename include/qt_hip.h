@@ -436,6 +436,13 @@ int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t
  * as in qt_rmsnorm_fq8_bf16. */
 int qt_add_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
                         uint16_t *y_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt, void *stream);
+/* qt_add_rmsnorm_bf16 for PT2E-prepared graphs, where the residual stream itself is fake-quantized in front of the NEXT add (the
+ * annotator quantizes the earlier-defined operand of a same-shape add, xnnpack_quantizer_utils.py:232-282): the sum is normalised
+ * unquantized, and written to sum_dev as sum_fmt(sum) (stateless E4M3 / E5M2) -- that fake-quantizer's call, evaluated where the
+ * tensor is in registers.  sum_fmt == NULL: exactly qt_add_rmsnorm_bf16. */
+int qt_add_rmsnorm_sumfq_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
+                              uint16_t *y_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt,
+                              const qt_format *sum_fmt, void *stream);
 /* RMSNorm (residual_dev / sum_dev both NULL) or residual add + RMSNorm with the stateless E4M3 / E5M2 input fake-quantizers of ALL the
  * Linears that consume the result (2 or 3: q, k, v -- gate, up) evaluated on it in the same launch: y = fq_0(result) as bf16, y8[i] =
  * the FP8 codes of fq_i(result).  Each consumer's hook then hands its codes through instead of launching its own pass over the tensor
@@ -475,6 +482,14 @@ int qt_rope_fq_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_
                      uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S, long Hq, long Hk, long D,
                      long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, const uint16_t *v_dev,
                      uint8_t *vt8_dev, long v_stride_b, long v_stride_h, long v_stride_k, const qt_format *fmt_v, void *stream);
+/* qt_rope_fq_value for PT2E-prepared graphs (wikitext.py:60-136 exports HF's apply_rotary_pos_emb as q * cos + rotate_half(q) * sin and
+ * the annotator fake-quantizes the add's earlier operand): out = fmt(inner(bf16(x * cos)) + bf16(rotate_half(x) * sin)) with inner_q /
+ * inner_k stateless closed-form FP formats (NULL: none -- exactly qt_rope_fq_value).  v_dev may be NULL (no value job). */
+int qt_rope_fq_inner_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
+                           uint16_t *k_out_dev, uint8_t *q_out8_dev, uint8_t *k_out8_dev, long B, long S, long Hq, long Hk, long D,
+                           long q_row_stride, long k_row_stride, const qt_format *fmt_q, const qt_format *fmt_k, const qt_format *inner_q,
+                           const qt_format *inner_k, const uint16_t *v_dev, uint8_t *vt8_dev, long v_stride_b, long v_stride_h,
+                           long v_stride_k, const qt_format *fmt_v, void *stream);
 
 /* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
  * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose

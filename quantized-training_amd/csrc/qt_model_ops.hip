@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                                                                uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
                                                                uint2 *__restrict__ y8, qt_format fmt,
                                                                const uint4 *__restrict__ res = nullptr, uint4 *__restrict__ sum = nullptr,
-                                                               NormExtra extra = NormExtra{}) {
+                                                               NormExtra extra = NormExtra{}, int sum_fq = 0, qt_format sum_fmt = qt_format{}) {
     __shared__ float s_part[kNormThreads / 64];
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
@@ -57,7 +57,14 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 v[i].y = pack_bf16x2(bf_lo(v[i].y) + bf_lo(r.y), bf_hi(v[i].y) + bf_hi(r.y));
                 v[i].z = pack_bf16x2(bf_lo(v[i].z) + bf_lo(r.z), bf_hi(v[i].z) + bf_hi(r.z));
                 v[i].w = pack_bf16x2(bf_lo(v[i].w) + bf_lo(r.w), bf_hi(v[i].w) + bf_hi(r.w));
-                sum[row * (size_t)nvec + c] = v[i];
+                if (sum_fq) {            // the NEXT residual add reads fq(sum) (PT2E graphs quantize an add's earlier operand): written quantized,
+                    uint32_t t[4] = {v[i].x, v[i].y, v[i].z, v[i].w};       // normalised unquantized
+                    if (sum_fq == 2) fq8_hw_vec8<true>(t, sum_fmt);
+                    else fq8_hw_vec8<false>(t, sum_fmt);
+                    sum[row * (size_t)nvec + c] = uint4{t[0], t[1], t[2], t[3]};
+                } else {
+                    sum[row * (size_t)nvec + c] = v[i];
+                }
             }
             const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
@@ -193,6 +200,8 @@ struct RopeFqArgs {
     qt_format fmt;
     uint8_t *y8;             // optional FP8 code of the output, same order (NULL = not wanted)
     int e5m2;
+    int inner;               // 1: x * cos goes through `inner_fmt` (stateless closed-form FP) before the sum -- PT2E graphs fake-quantize the
+    qt_format inner_fmt;     // earlier-defined operand of the rotary's add (xnnpack_quantizer_utils.py:232-282)
 };
 
 // One workgroup per token (b, s): its vectors are the H * D / 8 of a row of x, so the only divisions left are one per token
@@ -222,7 +231,11 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
             const float sgn = low ? -1.0f : 1.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+                float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
+                if (a.inner) {
+                    a0 = qt_u2f(qt_fp_sat_u32(qt_f2u(a0), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
+                    a1 = qt_u2f(qt_fp_sat_u32(qt_f2u(a1), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
+                }
                 const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
                 out[j] = pack_bf16x2(a0 + b0, a1 + b1);                  // the rotary output, bf16
             }
@@ -561,6 +574,26 @@ int qt_add_rmsnorm_bf16(const uint16_t *x, const uint16_t *residual, const uint1
     return launch_status();
 }
 
+int qt_add_rmsnorm_sumfq_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, uint8_t *y8,
+                              long rows, long cols, float eps, const qt_format *fmt, const qt_format *sum_fmt, void *stream) {
+    if (!sum_fmt) return qt_add_rmsnorm_bf16(x, residual, weight, sum, y, y8, rows, cols, eps, fmt, stream);
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !residual || !weight || !sum || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
+    const int fq = y8 ? fp8_code_of(fmt) : 0, sfq = fp8_code_of(sum_fmt);
+    if ((y8 && !fq) || !sfq) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)sum | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u))
+        return QT_ERR_UNALIGNED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (int)(cols / 8);
+    const float inv = 1.0f / (float)cols;
+    const qt_format f = fq ? *fmt : qt_format{};
+    if (fq == 2) rmsnorm_kernel<2, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    else if (fq == 1) rmsnorm_kernel<1, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    else rmsnorm_kernel<0, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    return launch_status();
+}
+
 int qt_rmsnorm_consumers_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, long rows,
                               long cols, float eps, int consumers, uint8_t *const *y8, const qt_format *const *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
@@ -726,8 +759,9 @@ int qt_rope_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, cons
 static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,
                           uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
                           const qt_format *fmt_q, const qt_format *fmt_k, bool need_values, const uint16_t *v, uint8_t *vt8, long v_sb, long v_sh,
-                          long v_sk, const qt_format *fmt_v, void *stream) {
+                          long v_sk, const qt_format *fmt_v, void *stream, const qt_format *inner_q = nullptr, const qt_format *inner_k = nullptr) {
     if (B * S * D == 0) return QT_OK;
+    if ((inner_q && inner_q->kind != QT_FMT_FP_SAT) || (inner_k && inner_k->kind != QT_FMT_FP_SAT) || ((inner_q || inner_k) && !cos)) return QT_ERR_BAD_ARG;
     if (!q || !k || (need_values && !cos) || (cos == nullptr) != (sin == nullptr) || !fmt_q || !fmt_k || B < 0 || S < 0 || Hq < 0 || Hk < 0)
         return QT_ERR_BAD_ARG;
     if (need_values ? (!q_out || !k_out) : (!q_out8 || !k_out8 || (q_out == nullptr) != (k_out == nullptr))) return QT_ERR_BAD_ARG;
@@ -739,8 +773,10 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
     auto is_e5m2 = [](const qt_format *f) { return f->p0 == 2 && f->p1 == -14 && f->fhi == 57344.0f; };
     auto is_e4m3 = [](const qt_format *f) { return f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f; };
     if ((q_out8 && !is_e5m2(fmt_q) && !is_e4m3(fmt_q)) || (k_out8 && !is_e5m2(fmt_k) && !is_e4m3(fmt_k))) return QT_ERR_BAD_ARG;
-    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0};
-    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0};
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0,
+                  inner_q ? 1 : 0, inner_q ? *inner_q : qt_format{}};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0,
+                  inner_k ? 1 : 0, inner_k ? *inner_k : qt_format{}};
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
     const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;                      // vectors of a token: a workgroup takes 256 / that many tokens
     const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
@@ -782,6 +818,14 @@ int qt_rope_fq_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, 
                      long v_stride_k, const qt_format *fmt_v, void *stream) {
     return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, false, v, vt8,
                           v_stride_b, v_stride_h, v_stride_k, fmt_v, stream);
+}
+
+int qt_rope_fq_inner_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,
+                           uint8_t *q_out8, uint8_t *k_out8, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                           const qt_format *fmt_q, const qt_format *fmt_k, const qt_format *inner_q, const qt_format *inner_k, const uint16_t *v,
+                           uint8_t *vt8, long v_stride_b, long v_stride_h, long v_stride_k, const qt_format *fmt_v, void *stream) {
+    return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, false, v, vt8,
+                          v_stride_b, v_stride_h, v_stride_k, fmt_v, stream, inner_q, inner_k);
 }
 
 int qt_causal_lm_loss_bf16(const uint16_t *logits, const long long *labels, long batch, long seq_len, long vocab, long row_stride,

@@ -44,6 +44,10 @@ def _window_loss(model, input_ids, labels, **kwargs):
     fp32 copy + softmax + reduction transformers runs (QT_FUSED_LOSS=0 keeps those); anything else takes the model's own loss."""
     import ctypes
     import os
+    if isinstance(model, torch.fx.GraphModule):
+        # a PT2E graph (prepare_pt2e_causal_lm): exported with exactly (input_ids, labels=, use_cache=) -- mask, positions and the loss
+        # are nodes of the graph (wikitext.py:83-96 exports the model's own forward)
+        return model(input_ids, labels=labels, use_cache=False).loss.float()
     if os.environ.get("QT_FUSED_LOSS", "1") != "0" and input_ids.is_cuda and not torch.is_grad_enabled():
         from . import _native
         out = model(input_ids, use_cache=False, **kwargs)
@@ -128,6 +132,31 @@ class GraphedWindow:
         self._set(ids, trg_len)
         self.graph.replay()
         return self.loss
+
+
+def prepare_pt2e_causal_lm(model, activation, weight, max_length: int, bias=None, fuse=None):
+    """The reference's current WikiText flow up to the evaluation loop (examples/language_modeling/wikitext.py:68-101): default
+    quantizer with the rotary matmul excluded, `torch.export` with a dynamic sequence length, fake-quantizers inserted as `call_module`
+    nodes, constructor nodes pinned to the model's device.  Returns the prepared GraphModule (called as `gm(input_ids, labels=...,
+    use_cache=False)`); for a device model its chains run on the fused HIP kernels (pt2e_fusion, `fuse=False` keeps the plain graph)."""
+    from . import pt2e_fusion, quantize_pt2e as qp
+    quantizer = qp.get_default_quantizer(input_activation=activation, weight=weight, bias=bias)
+    quantizer.set_module_name_object_type_order(r"model\.rotary_emb", torch.ops.aten.matmul.default, 0, None)
+    device = next(model.parameters()).device
+    ids = torch.randint(0, model.config.vocab_size, (1, max_length), device=device)
+    seq = torch.export.Dim("seq_length", min=3, max=max_length)
+    dynamic_shapes = {"input_ids": {1: seq}, "labels": {1: seq}, "use_cache": None}
+    config = model.config
+    with torch.no_grad():
+        gm = qp.prepare_pt2e(model, quantizer, (ids,), {"labels": ids.clone(), "use_cache": False}, dynamic_shapes, fuse=False)
+    for node in list(gm.graph.nodes):                       # the exporter does not record the inputs' device (wikitext.py:98-101)
+        if "device" in node.kwargs:
+            node.kwargs = dict(node.kwargs, device=device)
+    gm.recompile()
+    gm.config = config
+    if fuse or (fuse is None and device.type == "cuda"):
+        gm.fusion_counts = pt2e_fusion.fuse_prepared_graph(gm)
+    return gm
 
 
 def gather_in_order(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:

@@ -189,7 +189,8 @@ def consumer_fq(linear):
     """The input fake-quantizer of a QAT Linear when a producing kernel may apply it (see
     FusedAmaxObsFakeQuantize.producer_fusable), else None.  It exists only after the layer's first call."""
     holder = getattr(linear, "activation_pre_process", None)
-    if holder is None or len(linear._forward_pre_hooks) != 1 or "0" not in holder or len(holder) != 1:
+    hooked_once = len(linear._forward_pre_hooks) == 1 or linear.__dict__.get("_qt_prepared")    # pt2e_fusion.PreparedLinear: the fake-quantizer is a graph node
+    if holder is None or not hooked_once or "0" not in holder or len(holder) != 1:
         return None
     fq = holder["0"]
     if not isinstance(fq, FusedAmaxObsFakeQuantize) or not fq.producer_fusable():
@@ -533,7 +534,8 @@ def _fused_mlp_or_none(self, x):
     # The route is decided before any hook runs (a hook must not run twice): x has to arrive with the FP8 code its producer
     # (the RMSNorm kernel, for its first consumer) attached.
     x8 = getattr(x, "_qt_fp8", None) if handover_valid(x) else None
-    if x8 is None or getattr(x, "_qt_fq_done_by", None) is None or not fused.fq8_route_is_fused(x8.reshape(-1, x8.shape[-1]), [gate]):
+    prepared = bool(self.__dict__.get("_qt_prepared"))           # pt2e_fusion.PreparedMLP: no hooks, x comes out of the fake-quantizer's node
+    if x8 is None or (getattr(x, "_qt_fq_done_by", None) is None and not prepared) or not fused.fq8_route_is_fused(x8.reshape(-1, x8.shape[-1]), [gate]):
         return None
     x8f = x8.reshape(-1, x8.shape[-1])
 

@@ -140,15 +140,24 @@ def export_model(model: torch.nn.Module, args: Tuple[Any, ...], kwargs: Optional
     return torch.export.export(model, args, kwargs, dynamic_shapes=dynamic_shapes).module()
 
 
-def prepare_pt2e(model, quantizer, args=None, kwargs=None, dynamic_shapes=None):
+def prepare_pt2e(model, quantizer, args=None, kwargs=None, dynamic_shapes=None, fuse=None):
     """Export (unless already a GraphModule) and insert the fake-quant modules the quantizer asks for
-    (upstream :262-273)."""
+    (upstream :262-273).
+
+    The graph returned for a model on the CPU is upstream's node for node.  For a DEVICE model (`fuse=None`: any parameter on a GPU;
+    `fuse=True/False` forces it) the chains between the fake-quantizer nodes are then rewritten to the fused HIP kernels
+    (pt2e_fusion.fuse_prepared_graph: same values, fewer launches); `convert_pt2e` restores the plain graph first.  A model
+    prepared on the CPU and moved afterwards takes the same route through `pt2e_fusion.fuse_prepared_graph(model)`."""
     from torch.ao.quantization.pt2e import prepare as _prepare
     from torch.ao.quantization.quantize_pt2e import prepare_pt2e as _torch_prepare_pt2e
     _prepare._get_obs_or_fq_map = _get_obs_or_fq_map          # torch.ao only constructs its own spec type
     if not isinstance(model, GraphModule):
         model = export_model(model, args, kwargs, dynamic_shapes=dynamic_shapes)
-    return _torch_prepare_pt2e(model, quantizer)
+    model = _torch_prepare_pt2e(model, quantizer)
+    if fuse or (fuse is None and any(p.device.type == "cuda" for p in model.parameters())):
+        from . import pt2e_fusion
+        pt2e_fusion.fuse_prepared_graph(model)
+    return model
 
 
 # ---- convert -----------------------------------------------------------------------------------------------------
@@ -439,6 +448,8 @@ def convert_pt2e(model: GraphModule, output_dtype: str = None, eliminate_no_effe
     """Lower every FusedAmaxObsFakeQuantize `call_module` of a prepared (and calibrated) graph to
     quantized_ops nodes (upstream :975-1002): quantize / dequantize for per-tensor and per-channel specs,
     quantize_mx + *_mx GEMMs for microscaling, stored codes + dequantize for group-wise affine weights."""
+    from . import pt2e_fusion
+    pt2e_fusion.unfuse_prepared_graph(model)                  # the lowering below works on the plain prepared graph
     modules = dict(model.named_modules(remove_duplicate=False))
     for node in list(model.graph.nodes):
         if node.op != "call_module":

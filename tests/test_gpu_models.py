@@ -433,3 +433,84 @@ def test_perplexity_drift_mid_size_model():
     for k, v in res.items():
         assert abs(v - ref) <= bound * ref, res
     assert abs(res["fast"] - res["plain"]) <= bound * ref and abs(res["fast+fq8"] - res["fast"]) <= bound * ref, res
+
+
+def test_pt2e_prepared_route_at_size(monkeypatch):
+    """The reference's current WikiText flow (wikitext.py:60-136: torch.export + prepare_pt2e, fake-quantizers as graph nodes) at
+    LLaMA-2-7B width (hidden 4096, 32 heads of 128, FFN 11008, vocab 32000; 2 layers), S = 1024, E4M3 activations + weights: the
+    prepared graph with its chains rewritten to the fused kernels (pt2e_fusion) against the same graph run node by node.
+    Every chain is rewritten; the fused GEMM, MLP, norm, rotary and attention kernels are what runs; the fake-quantized element
+    count is unchanged; logits agree within the accumulation bound (different GEMM summation orders flip single 8-bit codes
+    downstream, as for the eager route); and a hipGraph replay of the fused graph is no slower than 1.15x the eager route's
+    (quantize() + model_fusions) window on the same model -- whose graph has FEWER fake-quantizers (the PT2E annotator also
+    quantizes the residual stream and the rotary's first product)."""
+    from quantized_training import fused
+    from quantized_training.fake_quantize import STATS
+    tok = torch.randint(0, 32000, (1, 1024), generator=torch.Generator().manual_seed(11)).cuda()
+    calls = {"attention": 0, "fq8": 0, "mlp": 0}
+
+    def counted(name, fn):
+        def wrapper(*a, **k):
+            out = fn(*a, **k)
+            if out is not None:
+                calls[name] += 1
+            return out
+        return wrapper
+    monkeypatch.setattr(fused, "_attention_fp8_or_none", counted("attention", fused._attention_fp8_or_none))
+    monkeypatch.setattr(fused, "hip_fq8_linear_or_none", counted("fq8", fused.hip_fq8_linear_or_none))
+    monkeypatch.setattr(fused, "hip_mlp_fq8_or_none", counted("mlp", fused.hip_mlp_fq8_or_none))
+
+    def build(fuse):
+        m = harness.build_causal_lm("llama-2-7b", device="cuda", seed=0, num_layers=2)
+        return harness.prepare_pt2e_causal_lm(m, "e4m3", "e4m3", 1024, fuse=fuse)
+
+    def timed(step, n=6):
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            step.replay(tok, 512)
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+
+    with torch.no_grad():
+        plain = build(False)
+        STATS.reset()
+        ref = plain(tok, labels=tok.clone(), use_cache=False)
+        e_plain = STATS.elements
+        ref_logits, ref_loss = ref.logits.float().cpu(), float(ref.loss)
+        assert sum(calls.values()) == 0
+        del plain, ref
+        torch.cuda.empty_cache()
+
+        gm = build(True)
+        assert {k: gm.fusion_counts[k] for k in ("linear", "sibling_groups", "mlp", "rmsnorm", "add_rmsnorm", "attention", "loss")} == \
+            {"linear": 15, "sibling_groups": 2, "mlp": 2, "rmsnorm": 1, "add_rmsnorm": 4, "attention": 2, "loss": 1}
+        STATS.reset()
+        out = gm(tok, labels=tok.clone(), use_cache=False)
+        assert STATS.elements == e_plain
+        assert calls["attention"] == 2 and calls["mlp"] == 2 and calls["fq8"] >= 2 + 2 + 2 + 1, calls     # q/k/v groups, o, down, lm head
+        got = out.logits.float().cpu()
+        assert torch.isfinite(got).all()
+        scale = float(ref_logits.abs().max())
+        d = (got - ref_logits).abs()
+        corr = float(torch.corrcoef(torch.stack([got.flatten()[::7], ref_logits.flatten()[::7]]))[0, 1])
+        assert float(d.pow(2).mean().sqrt()) <= 0.02 * scale and float(d.max()) <= 0.25 * scale and corr >= 0.995, \
+            (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale, corr)
+        assert abs(float(out.loss) - ref_loss) <= 2e-3 * ref_loss, (float(out.loss), ref_loss)
+        step = harness.GraphedWindow(gm, 1024, None, torch.device("cuda"))
+        step.capture(tok)
+        assert abs(float(step.replay(tok, 1024)) - float(out.loss)) <= 1e-6 * ref_loss      # replay == the eager launch sequence
+        t_pt2e = timed(step)
+        del step, gm, out
+        torch.cuda.empty_cache()
+
+        m = harness.build_causal_lm("llama-2-7b", device="cuda", seed=0, num_layers=2)
+        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+        harness.window_nll(m, tok, 1024)
+        step = harness.GraphedWindow(m, 1024, None, torch.device("cuda"))
+        step.capture(tok)
+        t_eager = timed(step)
+    print(f"pt2e fused window {t_pt2e:.3f} ms, eager route {t_eager:.3f} ms (2 layers + lm head)")
+    assert t_pt2e <= 1.15 * t_eager, (t_pt2e, t_eager)

@@ -331,3 +331,74 @@ def test_outlier_spec_lowering_matches_reference():
         y2 = gc(x1)
     assert np.array_equal(_canon32(y2).reshape(-1), arr["y_converted"].reshape(-1))
     assert float((y1 - y2).abs().max()) <= 1e-5 * float(y1.abs().max())      # the side path restores what the fake-quantizer kept
+
+
+# ---- fusion pass for prepared graphs (pt2e_fusion.py): the rewrite changes launches, never values ------------------------------
+def _tiny_llama_prepared(spec, layers=2):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=2, num_key_value_heads=2,
+                      vocab_size=512, max_position_embeddings=256, attn_implementation="eager")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).bfloat16().eval()
+    ids = torch.randint(0, 512, (1, 64))
+    q = qp.get_default_quantizer(spec, None, spec, "int24" if "qs=" in spec else None)
+    q.set_module_name_object_type_order(r"model\.rotary_emb", torch.ops.aten.matmul.default, 0, None)      # wikitext.py:76-78
+    seq = torch.export.Dim("seq_length", min=3, max=64)
+    dyn = {"input_ids": {1: seq}, "labels": {1: seq}, "use_cache": None}
+    with torch.no_grad():
+        gm = qp.prepare_pt2e(model, q, (ids,), {"labels": ids.clone(), "use_cache": False}, dyn)
+    return gm, ids
+
+
+@pytest.mark.parametrize("spec", ["e4m3", "posit8_1", "int8,qs=per_tensor_symmetric"])
+def test_fused_prepared_graph_is_the_prepared_graph(spec):
+    """upstream's wikitext.py flow (:60-136) on a LLaMA-shaped model: every chain pt2e_fusion recognises (15 Linears, 2 q/k/v groups,
+    2 MLPs, 5 RMSNorms -- 4 with the residual add in front --, 2 rotary + attention cores) is rewritten, and on CPU tensors, where each
+    fused module runs the node sequence it replaced, logits, loss and the fake-quantized element count are those of the plain graph bit
+    for bit -- other sequence lengths, live observers (int8 with a scale) and a later convert_pt2e included."""
+    from quantized_training import fake_quantize as fqm, pt2e_fusion
+    gm, ids = _tiny_llama_prepared(spec)
+    plain_nodes = len(list(gm.graph.nodes))
+    with torch.no_grad():
+        fqm.STATS.reset()
+        want = gm(ids, labels=ids.clone(), use_cache=False)
+        e_plain = fqm.STATS.elements
+        if "qs=" in spec:                                   # delayed scaling: the reference call above changed the observers' state
+            gm, ids = _tiny_llama_prepared(spec)
+        counts = pt2e_fusion.fuse_prepared_graph(gm)
+        assert {k: counts[k] for k in ("linear", "sibling_groups", "mlp", "rmsnorm", "add_rmsnorm", "attention", "loss")} == \
+            {"linear": 15, "sibling_groups": 2, "mlp": 2, "rmsnorm": 1, "add_rmsnorm": 4, "attention": 2, "loss": 1}
+        assert counts["shape_only_nodes"] >= 40            # causal mask + rotary tables: functions of the sequence length alone
+        assert len(list(gm.graph.nodes)) < plain_nodes // 2
+        assert pt2e_fusion.fuse_prepared_graph(gm) == {}    # idempotent
+        fqm.STATS.reset()
+        got = gm(ids, labels=ids.clone(), use_cache=False)
+        assert fqm.STATS.elements == e_plain
+        assert torch.equal(got.logits, want.logits) and torch.equal(got.loss, want.loss)
+        short = torch.randint(0, 512, (1, 40))
+        a = gm(short, labels=short.clone(), use_cache=False)
+        assert pt2e_fusion.unfuse_prepared_graph(gm) and len(list(gm.graph.nodes)) == plain_nodes
+        assert not [n for n, _ in gm.named_children() if n.startswith("_qt_")]
+        b = gm(short, labels=short.clone(), use_cache=False)
+        if "qs=" not in spec:
+            assert torch.equal(a.logits, b.logits)
+        pt2e_fusion.fuse_prepared_graph(gm)
+        gc = qp.convert_pt2e(gm)                            # restores the plain graph first, then lowers it as upstream does
+        assert not any(n.op == "call_module" and str(n.target).startswith("_qt_") for n in gc.graph.nodes)
+        assert any("quantized_ops" in str(n.target) for n in gc.graph.nodes)
+        gc(short, labels=short.clone(), use_cache=False)
+
+
+def test_fusion_leaves_unrecognised_chains_alone():
+    """The toy model of the golden traces has no chain the pass knows beyond its two Linears: they become QAT-Linear nodes (same values),
+    everything else stays node for node."""
+    from quantized_training import pt2e_fusion
+    arr = np.load(os.path.join(G, "pt2e.npz"))
+    kw = META["e4m3_noqs"]["kw"]
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((4, 16)).astype(np.float32))
+    g1 = qp.prepare_pt2e(_model(arr), qp.get_default_quantizer(**kw), (x,))
+    g2 = qp.prepare_pt2e(_model(arr), qp.get_default_quantizer(**kw), (x,))
+    counts = pt2e_fusion.fuse_prepared_graph(g2)
+    assert counts["linear"] == 2 and counts["attention"] == 0 and counts["mlp"] == 0
+    for _ in range(3):                                      # observers evolve identically
+        assert torch.equal(g1(x), g2(x))

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
 (
-for abl in 0 5 6 1 2 3 4 0; do echo "== ABLATE $abl"; QT_FQ8_ABLATE=$abl python tools/exp_linear_fq8.py --skip-checks --iters 60 --shapes probe 2>&1 | grep bench | cut -c1-90; done
-) > gpurun_out/fq8_abl.log 2>&1
-cat gpurun_out/fq8_abl.log
+python -m pytest tests/test_gpu_models.py -x -q -s -k "pt2e_prepared" 2>&1 | tail -40
+) > gpurun_out/pt2e_route.log 2>&1
+grep -v "Warning\|warn" gpurun_out/pt2e_route.log | tail -50
