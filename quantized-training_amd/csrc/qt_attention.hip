@@ -79,6 +79,17 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     const uint16_t *Mp = a.mask ? a.mask + b * a.mask_sb + h * a.mask_sh + (long)qload * a.mask_sq : nullptr;
 
     Rounder<KIND> rnd{a.fmt, a.lut};
+    if constexpr (KIND == kFmtRows) {
+        // table format with the row words behind the map (qt_format.p1 bit 0, csrc/qt_device.h): the probabilities' fake-quantizer is
+        // arithmetic on a 4 / 8 KiB row table in LDS instead of one gather per element from the 128 KiB map in global memory
+        __shared__ uint4 s_rows[512];
+        const uint4 *gr = (const uint4 *)(a.lut + QT_MAP_ENTRIES);
+        const int nrows = (a.fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = gr[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = a.lut;
+        __syncthreads();
+    }
     const float s = UNIT ? 1.0f : qt_bf2f(qt_f2bf(*a.scale));
     const UniformDiv dv(s);
 
@@ -393,7 +404,7 @@ int launch_attn_kind(const AttnArgs &a, hipStream_t st) {
 template <int D>
 int launch_attn(const AttnArgs &a, hipStream_t st) {
     switch (a.fmt.kind) {
-        case QT_FMT_LUT: return launch_attn_kind<D, QT_FMT_LUT>(a, st);
+        case QT_FMT_LUT: return (a.fmt.p1 & 1) ? launch_attn_kind<D, kFmtRows>(a, st) : launch_attn_kind<D, QT_FMT_LUT>(a, st);
         case QT_FMT_FP_SAT: return launch_attn_kind<D, QT_FMT_FP_SAT>(a, st);
         case QT_FMT_INT: return launch_attn_kind<D, QT_FMT_INT>(a, st);
         case QT_FMT_IDENTITY: return launch_attn_kind<D, QT_FMT_IDENTITY>(a, st);

@@ -43,10 +43,19 @@ def _enabled():
     return os.environ.get("QT_FUSED_MODEL_OPS", "1") != "0"
 
 
+def _tracing(t):
+    """True while torch.export / make_fx traces the caller (the module-level rotary patch is process-wide, so an export of ANOTHER model
+    can pass through it): traced tensors have no storage, and a HIP launch must never end up inside an exported graph unseen."""
+    from torch._subclasses.fake_tensor import FakeTensor
+    is_exporting = getattr(torch.compiler, "is_exporting", None)
+    return isinstance(t, FakeTensor) or (is_exporting is not None and is_exporting()) or torch._C._get_dispatch_mode(
+        torch._C._TorchDispatchModeKey.PROXY) is not None
+
+
 def _eligible(*tensors):
     if not _enabled() or torch.is_grad_enabled():
         return False
-    return all(t.device.type == "cuda" and t.dtype == torch.bfloat16 for t in tensors)
+    return all(t.device.type == "cuda" and t.dtype == torch.bfloat16 for t in tensors) and not (tensors and _tracing(tensors[0]))
 
 
 def _hooked(mod):

@@ -141,7 +141,7 @@ def test_row_form_pass_equals_the_value_map(nv, dtype, scale):
         for view, want in ((t, e), (t.transpose(-1, -2), e.transpose(-1, -2))):
             assert not view.is_contiguous()
             got = fq(view)
-            assert np.array_equal(o.canon_nan16(host_u16(got.contiguous().view(torch.int16))),
+            assert np.array_equal(o.canon_nan16(host_u16(got.contiguous().view(torch.int16))).reshape(-1),
                                   want.contiguous().numpy().view(np.uint16).reshape(-1)), dtype
 
 
@@ -715,6 +715,23 @@ def test_fused_attention_kernel(nv, B, H, Sq, Sk, D, mask_kind, pdtype):
     # the observer saw the largest probability BEFORE fake-quantization; the oracle's quantized maximum brackets it
     pmax = float(o.bf16_to_f32(pq).max())
     assert abs(amax.view(torch.float32).item() - pmax) <= 0.07 * pmax
+    if pdtype == "posit8_1":
+        # table formats: with the row form behind the map (qt_format.p1 bit 0) the kernel evaluates the probabilities' fake-quantizer
+        # from a row table in LDS instead of gathering from the map -- the same function, so the same output bit for bit
+        import quantized_training as qt
+        from quantized_training.fake_quantize import _launch_format
+        for dt in ("posit8_1", "posit8_2", "fp4_e2m1"):
+            m = qt.get_quantization_map(dt, torch.device("cuda"))
+            f_rows = _launch_format(nv.format_for(dt), m)
+            assert f_rows.p1 & 1
+            outs = []
+            for f in (nv.format_for(dt), f_rows):
+                o2 = torch.empty_like(out)
+                nv.check(L.qt_attention_fq_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                                o2.data_ptr(), B, H, Sq, Sk, D, msb, 0, msq, scaling, ctypes.byref(f), m.data_ptr(),
+                                                None, None, stream()), "attention")
+                outs.append(o2)
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), dt
 
 
 def test_llama_fused_attention_vs_module_chain(nv):

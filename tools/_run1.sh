@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
 (
-python -m pytest tests/test_gpu_models.py -x -q -s -k "pt2e_prepared" 2>&1 | tail -40
-) > gpurun_out/pt2e_route.log 2>&1
-grep -v "Warning\|warn" gpurun_out/pt2e_route.log | tail -50
+python -m pytest tests/test_gpu_models.py -x -q 2>&1 | grep -E "^E |Error|error" | head -30
+) > gpurun_out/attn13b.log 2>&1
+cat gpurun_out/attn13b.log
