@@ -40,8 +40,19 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                                                                uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
                                                                uint2 *__restrict__ y8, qt_format fmt,
                                                                const uint4 *__restrict__ res = nullptr, uint4 *__restrict__ sum = nullptr,
-                                                               NormExtra extra = NormExtra{}, int sum_fq = 0, qt_format sum_fmt = qt_format{}) {
+                                                               NormExtra extra = NormExtra{}, int sum_fq = 0, qt_format sum_fmt = qt_format{},
+                                                               const uint16_t *__restrict__ map = nullptr) {
     __shared__ float s_part[kNormThreads / 64];
+    // FQ == 3: the consumers' stateless TABLE-format fake-quantizer in its row form (qt_format.p1 bit 0; `map` = the 65 536 entries with
+    // the row words behind them, csrc/qt_device.h Rounder<kFmtRows>); bf16 values only
+    Rounder<kFmtRows> rnd{fmt, nullptr, map};
+    if constexpr (FQ == 3) {
+        __shared__ uint4 s_rows[512];
+        const uint4 *gr = (const uint4 *)(map + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += kNormThreads) s_rows[i] = gr[i];
+        rnd.lds = (const uint16_t *)s_rows;             // visible after the barrier of the row reduction below
+    }
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
     uint4 v[kNormMaxVec];
@@ -100,7 +111,12 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 uint32_t t[4] = {o[0], o[1], o[2], o[3]};
                 extra.y8[e][row * (size_t)nvec + c] = extra.e5m2[e] ? fq8_hw_vec8<true>(t, extra.fmt[e]) : fq8_hw_vec8<false>(t, extra.fmt[e]);
             }
-            if constexpr (FQ != 0) y8[row * (size_t)nvec + c] = fq8_hw_vec8<FQ == 2>(o, fmt);
+            if constexpr (FQ == 1 || FQ == 2) y8[row * (size_t)nvec + c] = fq8_hw_vec8<FQ == 2>(o, fmt);
+            if constexpr (FQ == 3) {
+                uint32_t unused = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fq_word_bf16<kFmtRows, true, false>(o[j], 1.0f, rnd, unused);
+            }
             y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
         }
     }
@@ -120,6 +136,33 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint4 *__restrict__
             const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
             const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
             o[j] = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));
+        }
+        y[i] = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// SiLU * up with the consumer's stateless TABLE-format fake-quantizer in its row form applied to the product (bf16 values out)
+__global__ __launch_bounds__(256) void silu_mul_map_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ u, uint4 *__restrict__ y,
+                                                           size_t nvec, qt_format fmt, const uint16_t *__restrict__ map, size_t cv, size_t rs_g,
+                                                           size_t rs_u) {
+    __shared__ uint4 s_rows[512];
+    {
+        const uint4 *gr = (const uint4 *)(map + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = gr[i];
+        __syncthreads();
+    }
+    const Rounder<kFmtRows> rnd{fmt, (const uint16_t *)s_rows, map};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / cv, col = i - row * cv;
+        const uint4 a = g[row * rs_g + col], b = u[row * rs_u + col];
+        const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4], unused = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
+            const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+            o[j] = fq_word_bf16<kFmtRows, true, false>(pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j])), 1.0f, rnd, unused);
         }
         y[i] = uint4{o[0], o[1], o[2], o[3]};
     }
@@ -202,6 +245,8 @@ struct RopeFqArgs {
     int e5m2;
     int inner;               // 1: x * cos goes through `inner_fmt` (stateless closed-form FP) before the sum -- PT2E graphs fake-quantize the
     qt_format inner_fmt;     // earlier-defined operand of the rotary's add (xnnpack_quantizer_utils.py:232-282)
+    const uint16_t *map;     // fmt.kind == QT_FMT_LUT: the map with its row words behind it (row form; rows staged in LDS by the kernel)
+    const uint16_t *rows_lds;
 };
 
 // One workgroup per token (b, s): its vectors are the H * D / 8 of a row of x, so the only divisions left are one per token
@@ -244,6 +289,11 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
         if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
             const uint2 codes = a.e5m2 ? fq8_hw_vec8<true>(out, a.fmt) : fq8_hw_vec8<false>(out, a.fmt);
             *(uint2 *)(a.y8 + o * 8) = codes;
+        } else if (a.map) {                                  // table format, row form
+            const Rounder<kFmtRows> rnd{a.fmt, a.rows_lds, a.map};
+            uint32_t unused = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = fq_word_bf16<kFmtRows, true, false>(out[j], 1.0f, rnd, unused);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -257,6 +307,14 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
 }
 
 __global__ __launch_bounds__(256) void rope_fq_kernel(RopeFqArgs q, RopeFqArgs k, unsigned tpb) {
+    __shared__ uint4 s_rope_rows[512];
+    if (q.map) {                                             // one table format for q and k (checked on the host)
+        const uint4 *gr = (const uint4 *)(q.map + QT_MAP_ENTRIES);
+        const int nrows = (q.fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rope_rows[i] = gr[i];
+        __syncthreads();
+        q.rows_lds = k.rows_lds = (const uint16_t *)s_rope_rows;
+    }
     const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;                 // q and k hold the same tokens
     for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)gridDim.x * tpb) {
         rope_fq_token(q, bs, tpb, tokens);
@@ -774,9 +832,9 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
     auto is_e4m3 = [](const qt_format *f) { return f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f; };
     if ((q_out8 && !is_e5m2(fmt_q) && !is_e4m3(fmt_q)) || (k_out8 && !is_e5m2(fmt_k) && !is_e4m3(fmt_k))) return QT_ERR_BAD_ARG;
     RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt_q, q_out8, is_e5m2(fmt_q) ? 1 : 0,
-                  inner_q ? 1 : 0, inner_q ? *inner_q : qt_format{}};
+                  inner_q ? 1 : 0, inner_q ? *inner_q : qt_format{}, nullptr, nullptr};
     RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt_k, k_out8, is_e5m2(fmt_k) ? 1 : 0,
-                  inner_k ? 1 : 0, inner_k ? *inner_k : qt_format{}};
+                  inner_k ? 1 : 0, inner_k ? *inner_k : qt_format{}, nullptr, nullptr};
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
     const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;                      // vectors of a token: a workgroup takes 256 / that many tokens
     const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
@@ -818,6 +876,59 @@ int qt_rope_fq_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, 
                      long v_stride_k, const qt_format *fmt_v, void *stream) {
     return rope_fq_launch(q, k, cos, sin, q_out, k_out, q_out8, k_out8, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt_q, fmt_k, false, v, vt8,
                           v_stride_b, v_stride_h, v_stride_k, fmt_v, stream);
+}
+
+static bool map_format_ok(const qt_format *fmt, const uint16_t *map) {
+    return fmt && map && fmt->kind == QT_FMT_LUT && (fmt->p1 & 1) && (((uintptr_t)map) & 15u) == 0;
+}
+
+int qt_rmsnorm_map_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, long rows, long cols,
+                        float eps, const qt_format *fmt, const uint16_t *map, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x || !weight || !y || rows < 0 || cols < 0 || (residual != nullptr) != (sum != nullptr) || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
+    if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)sum | (uintptr_t)y) & 15u))
+        return QT_ERR_UNALIGNED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (int)(cols / 8);
+    const float inv = 1.0f / (float)cols;
+    if (residual) rmsnorm_kernel<3, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, 0, qt_format{}, map);
+    else rmsnorm_kernel<3, false><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, nullptr, nullptr, NormExtra{}, 0, qt_format{}, map);
+    return launch_status();
+}
+
+int qt_silu_mul_map_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, size_t rows, size_t cols, size_t gate_row_stride,
+                         size_t up_row_stride, const qt_format *fmt, const uint16_t *map, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!gate || !up || !y || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
+    if (cols % 8 || gate_row_stride % 8 || up_row_stride % 8 || gate_row_stride < cols || up_row_stride < cols ||
+        (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)y) & 15u))
+        return QT_ERR_UNALIGNED;
+    const size_t nvec = rows * cols / 8;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    silu_mul_map_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const uint4 *)gate, (const uint4 *)up, (uint4 *)y, nvec, *fmt, map, cols / 8,
+                                                                          gate_row_stride / 8, up_row_stride / 8);
+    return launch_status();
+}
+
+int qt_rope_map_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
+                     long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
+                     void *stream) {
+    if (B * S * D == 0) return QT_OK;
+    if (!q || !k || !cos || !sin || !q_out || !k_out || B < 0 || S < 0 || Hq < 0 || Hk < 0 || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
+    if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
+        return QT_ERR_UNALIGNED;
+    if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
+    if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt, nullptr, 0, 0, qt_format{}, map, nullptr};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt, nullptr, 0, 0, qt_format{}, map, nullptr};
+    const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;
+    const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
+    size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak, tpb);
+    return launch_status();
 }
 
 int qt_rope_fq_inner_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,

@@ -637,6 +637,16 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         return (self._quantize and not self._observe and self.qscheme is None and not self.is_per_channel
                 and not self.record_histogram and self.outlier_threshold is None and getattr(self, "_scale_is_one", True))
 
+    def map_producer_format(self, device):
+        """(format with the row-form bits, device map) when a producing kernel may apply this fake-quantizer on the consumer's behalf in
+        its ROW FORM (csrc/qt_model_ops.hip, *_map_* entry points): a stateless table format whose device map carries the row words
+        (_device_map); else None."""
+        if not (self.stateless_map() and self._qt_format.kind == _native.QT_FMT_LUT):
+            return None
+        self._move_to(device)
+        fmt = _launch_format(self._qt_format, self.qmap)
+        return (fmt, self.qmap) if (fmt.p1 & 1) else None
+
     def sync_flags_from_buffers(self):
         """Re-read the enable buffers (one host sync); call after writing them directly."""
         self._observe = bool(self.observer_enabled[0].item())

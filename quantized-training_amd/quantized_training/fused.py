@@ -823,7 +823,10 @@ def fqt_linear_or_none(layer, x):
             afq = [getattr(l, "activation_pre_process", None) for l in group.layers]
             afq = [h["0"] if h is not None and "0" in h else None for h in afq]
             same = same and all(isinstance(f, FusedAmaxObsFakeQuantize) and f.stateless_map() and str(f.dtype) == str(afq[0].dtype) for f in afq)
-            if same and getattr(x, "_qt_origin", None) is not None and _fqt_route(M, Ns, K, x.device):
+            # x is the fake-quantized image of one tensor: a hook's output (`_qt_origin`), or a producer kernel's result that the leader's
+            # hook handed through (model_fusions.rmsnorm_map; the siblings' hooks then name it as their origin)
+            shared = getattr(x, "_qt_origin", None) is not None or (getattr(x, "_qt_fq_done_by", None) is not None and handover_valid(x))
+            if same and shared and _fqt_route(M, Ns, K, x.device):
                 if not x2.is_contiguous():
                     x2 = x2.contiguous()
                 y = hip_fqt_linear_or_none(x2, group.layers, tables)

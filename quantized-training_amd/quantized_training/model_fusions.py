@@ -98,6 +98,9 @@ def rmsnorm_fq(x, weight, eps, fq):
     launch evaluates them all, _norm_with_consumers)."""
     cols = x.shape[-1]
     x2 = x.contiguous()
+    if isinstance(fq, tuple) and fq and fq[0] == "map":
+        got = rmsnorm_map(x2, None, weight, eps, fq[1])
+        return got[1] if got is not None else rmsnorm(x2, weight, eps)
     if isinstance(fq, (list, tuple)):
         if len(fq) > 1:
             return _norm_with_consumers(x2, None, weight, eps, fq)[1]
@@ -118,6 +121,11 @@ def add_rmsnorm(x, residual, norm, fq=None):
     fake-quant exactly as rmsnorm_fq's does (a list: all consumers', as there)."""
     cols = x.shape[-1]
     x2, r2 = x.contiguous(), residual.contiguous()
+    if isinstance(fq, tuple) and fq and fq[0] == "map":
+        got = rmsnorm_map(x2, r2, norm.weight, norm.variance_epsilon, fq[1])
+        if got is not None:
+            return got
+        fq = None
     if isinstance(fq, (list, tuple)):
         if len(fq) > 1:
             return _norm_with_consumers(x2, r2, norm.weight, norm.variance_epsilon, fq)
@@ -144,10 +152,82 @@ def _add_rmsnorm_or_none(x, residual, norm):
             or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()
             or os.environ.get("QT_FUSED_ADD_NORM", "1") == "0"):
         return None
-    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm, allow_all=True))
+    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm, allow_all=True, allow_map=True))
 
 
-def _norm_consumer_fq(norm, allow_all=False):
+def consumer_fq_map(linear):
+    """consumer_fq for stateless TABLE formats (posit, fpN, ... without `qs`): the input fake-quantizer of a QAT Linear when a producing
+    kernel may apply it in its row form (FusedAmaxObsFakeQuantize.map_producer_format), else None."""
+    holder = getattr(linear, "activation_pre_process", None)
+    hooked_once = len(linear._forward_pre_hooks) == 1 or linear.__dict__.get("_qt_prepared")
+    if holder is None or not hooked_once or "0" not in holder or len(holder) != 1 or os.environ.get("QT_FUSED_PRODUCER_MAP", "1") == "0":
+        return None
+    fq = holder["0"]
+    if not isinstance(fq, FusedAmaxObsFakeQuantize) or not fq.stateless_map() or fq._qt_format.kind != _native.QT_FMT_LUT:
+        return None
+    return fq
+
+
+def _mark_done(y, fqs):
+    """y = fq(result) for every fake-quantizer in `fqs` (one stateless format: their calls are idempotent repeats): the first hands y
+    through, the others find themselves in `_qt_also_done` (fake_quantize.py, FusedAmaxObsFakeQuantize.forward)."""
+    y._qt_fq_done_by = fqs[0]
+    if len(fqs) > 1:
+        y._qt_also_done = [(f, None) for f in fqs[1:]]
+    y._qt_ver = y._version
+    return y
+
+
+def rmsnorm_map(x, residual, weight, eps, fqs):
+    """(sum or None, y): RMSNorm (+ the residual add in front) with the consumers' stateless table-format fake-quantizer applied in its row
+    form (qt_rmsnorm_map_bf16), or None when the device map does not carry the row words."""
+    pf = fqs[0].map_producer_format(x.device)
+    if pf is None:
+        return None
+    fmt, qmap = pf
+    cols = x.shape[-1]
+    x2 = x.contiguous()
+    r2 = residual.contiguous() if residual is not None else None
+    total = torch.empty_like(x2) if r2 is not None else None
+    y = torch.empty_like(x2)
+    _native.check(_native.lib().qt_rmsnorm_map_bf16(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, weight.data_ptr(),
+                                                    total.data_ptr() if total is not None else None, y.data_ptr(), x2.numel() // cols, cols,
+                                                    float(eps), ctypes.byref(fmt), qmap.data_ptr(), _stream_ptr(x2)), "qt_rmsnorm_map_bf16")
+    return total, _mark_done(y, fqs)
+
+
+def silu_mul_map(gate, up, fq):
+    """SiLU * up with the down projection's stateless table-format input fake-quantizer in its row form, or None."""
+    pf = fq.map_producer_format(gate.device)
+    if pf is None:
+        return None
+    fmt, qmap = pf
+    g, rows, cols, rs_g = _rows_view(gate)
+    u, _, _, rs_u = _rows_view(up)
+    y = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+    _native.check(_native.lib().qt_silu_mul_map_bf16(g.data_ptr(), u.data_ptr(), y.data_ptr(), rows, cols, rs_g, rs_u, ctypes.byref(fmt),
+                                                     qmap.data_ptr(), _stream_ptr(g)), "qt_silu_mul_map_bf16")
+    return _mark_done(y, [fq])
+
+
+def rope_map(q, k, cos, sin, fq_q, fq_k):
+    """Rotary embedding with qk_matmul's two stateless table-format input fake-quantizers (one format) in the same pass: contiguous
+    [B, H, S, D] outputs marked as done for them, or None."""
+    pf = fq_q.map_producer_format(q.device)
+    if pf is None or fq_k.map_producer_format(q.device) is None or fq_k.dtype != fq_q.dtype:
+        return None
+    fmt, qmap = pf
+    B, Hq, S, D = q.shape
+    Hk = k.shape[1]
+    q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
+    k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
+    _native.check(_native.lib().qt_rope_map_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
+                                                 B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
+                                                 _stream_ptr(q)), "qt_rope_map_bf16")
+    return _mark_done(q_out, [fq_q]), _mark_done(k_out, [fq_k])
+
+
+def _norm_consumer_fq(norm, allow_all=False, allow_map=False):
     """The fake-quantizer the norm kernel may apply: every Linear fed by this norm must quantize its input with the
     same stateless format (then the first one's pass is fused here and the siblings', run on the already quantized
     tensor, reproduce it -- the formats are idempotent)."""
@@ -156,6 +236,10 @@ def _norm_consumer_fq(norm, allow_all=False):
         return None
     fqs = [consumer_fq(lin) for lin in consumers]
     if any(f is None for f in fqs):
+        if allow_map:                                # table formats: one row-form evaluation serves every consumer (RMSNorm kernels only)
+            mfqs = [consumer_fq_map(lin) for lin in consumers]
+            if all(f is not None for f in mfqs) and len({f.dtype for f in mfqs}) == 1:
+                return ("map", mfqs)
         return None
     f0 = fqs[0]._qt_format
     for f in fqs[1:]:
@@ -468,15 +552,21 @@ def _attn_exit(module, args, kwargs, output):
         _CURRENT_ATTN.pop()
 
 
-def _qk_fqs(attn):
-    """(fq_q, fq_k) of attn.qk_matmul when both may be applied by the rotary kernel, else None."""
+def _qk_fqs(attn, table=False):
+    """(fq_q, fq_k) of attn.qk_matmul when both may be applied by the rotary kernel, else None.  table: stateless table formats (row
+    form) instead of exact FP8 ones."""
     mm = getattr(attn, "qk_matmul", None)
     holder = getattr(mm, "activation_pre_process", None) if mm is not None else None
     if holder is None or len(mm._forward_pre_hooks) != 1 or mm._forward_hooks or set(holder.keys()) != {"0", "1"}:
         return None
     fq_q, fq_k = holder["0"], holder["1"]
     for f in (fq_q, fq_k):
-        if not isinstance(f, FusedAmaxObsFakeQuantize) or not f.producer_fusable():
+        if not isinstance(f, FusedAmaxObsFakeQuantize):
+            return None
+        if table:
+            if not (f.stateless_map() and f._qt_format.kind == _native.QT_FMT_LUT) or os.environ.get("QT_FUSED_PRODUCER_MAP", "1") == "0":
+                return None
+        elif not f.producer_fusable():
             return None
     if getattr(attn, "num_key_value_groups", 1) != 1:
         return None                  # keys are repeated (new tensors) between the rotary and qk_matmul
@@ -491,7 +581,7 @@ def _rmsnorm_forward(self, hidden_states):
     w = self.weight
     if (_eligible(hidden_states, w) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384
             and hidden_states.numel() > 0 and w.is_contiguous()):
-        fq = _norm_consumer_fq(self, allow_all=True)
+        fq = _norm_consumer_fq(self, allow_all=True, allow_map=True)
         if fq is not None:
             return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq)
         return rmsnorm(hidden_states, w, self.variance_epsilon)
@@ -596,6 +686,11 @@ def _mlp_forward(self, x):
             fq = consumer_fq(self.down_proj)
             if fq is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0":
                 return self.down_proj(silu_mul_fq(gate, up, fq))
+            mfq = consumer_fq_map(self.down_proj) if os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None
+            if mfq is not None:
+                y = silu_mul_map(gate, up, mfq)
+                if y is not None:
+                    return self.down_proj(y)
             return self.down_proj(silu_mul(gate, up))
         return self.down_proj(self.act_fn(gate) * up)
     return self._qt_hf_forward(x)
@@ -715,6 +810,11 @@ def _patch_rope():
                 fqs = _qk_fqs(_CURRENT_ATTN[-1])
                 if fqs is not None:
                     return rope_fq(q, k, cos, sin, *fqs, value_job=_fp8_attention_plan(_CURRENT_ATTN[-1], q, fqs))
+                mfqs = _qk_fqs(_CURRENT_ATTN[-1], table=True)
+                if mfqs is not None:
+                    got = rope_map(q, k, cos, sin, *mfqs)
+                    if got is not None:
+                        return got
             return rope(q, k, cos, sin)
         return original(q, k, cos, sin, unsqueeze_dim)
 

@@ -435,6 +435,29 @@ def test_perplexity_drift_mid_size_model():
     assert abs(res["fast"] - res["plain"]) <= bound * ref and abs(res["fast+fq8"] - res["fast"]) <= bound * ref, res
 
 
+@pytest.mark.parametrize("spec", ["posit8_2", "fp6_e3m2"])
+def test_table_format_window_with_and_without_producer_fusion(spec, monkeypatch):
+    """LLaMA-shaped model (head_dim 128) under a stateless table format: with the consumers' fake-quantizers applied by the RMSNorm,
+    SiLU * up and rotary kernels in their row form (default) against every hook launching its own pass (QT_FUSED_PRODUCER_MAP=0).
+    Same arithmetic followed by the same function, so logits are bit-identical and the fake-quantized element count is unchanged."""
+    from quantized_training.fake_quantize import STATS
+    tok = torch.randint(0, 2048, (1, 512), generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(flag):
+        monkeypatch.setenv("QT_FUSED_PRODUCER_MAP", flag)
+        m = harness.build_causal_lm("llama-mid", device="cuda", seed=0, num_layers=2)
+        qt.quantize(m, _args("--activation", spec, "--weight", spec, "--bf16", "--quantize_forward", "gemm"))
+        with torch.no_grad():
+            m(tok)
+            STATS.reset()
+            out = m(tok).logits
+            return out.float().cpu(), STATS.elements, STATS.calls
+    a, ea, ca = run("1")
+    b, eb, cb = run("0")
+    assert ea == eb and ca == cb
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_pt2e_prepared_route_at_size(monkeypatch):
     """The reference's current WikiText flow (wikitext.py:60-136: torch.export + prepare_pt2e, fake-quantizers as graph nodes) at
     LLaMA-2-7B width (hidden 4096, 32 heads of 128, FFN 11008, vocab 32000; 2 layers), S = 1024, E4M3 activations + weights: the

@@ -1208,6 +1208,53 @@ def test_rmsnorm_fused_with_first_consumer_fake_quant(nv):
             assert torch.equal(sib_from_plain._qt_fp8.view(torch.uint8), sib_from_q._qt_fp8.view(torch.uint8))
 
 
+@pytest.mark.parametrize("dtype", ["posit8_2", "posit8_1", "fp6_e3m2", "fp4_e2m1"])
+def test_table_format_producers_equal_kernel_then_pass(nv, dtype):
+    """Stateless TABLE formats: the RMSNorm (with and without the residual add), SiLU * up and rotary kernels with the consumers'
+    fake-quantizer applied in its row form (qt_*_map_bf16) write exactly what the plain kernel followed by the fake-quantizer's own
+    pass writes -- same arithmetic, then the same function -- and mark the result so that every consumer's call hands it through
+    (siblings included: one format, idempotent)."""
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import STATS, FusedAmaxObsFakeQuantize
+    g = torch.Generator(device="cuda").manual_seed(5)
+    fqs = [FusedAmaxObsFakeQuantize(dtype=dtype).cuda() for _ in range(3)]
+    x = (torch.randn(1024, 5120, device="cuda", generator=g) * 20).bfloat16()
+    x.view(torch.int16)[:12, :5120] = torch.arange(12 * 5120, device="cuda", dtype=torch.int32).to(torch.int16).view(12, 5120)   # every bf16 pattern
+    r = torch.randn(1024, 5120, device="cuda", generator=g).bfloat16()
+    w = (1 + 0.2 * torch.randn(5120, device="cuda", generator=g)).bfloat16()
+    same = lambda a, b: torch.equal(a.contiguous().view(torch.int16), b.contiguous().view(torch.int16)) or bool(  # noqa: E731
+        ((a.float() == b.float()) | (a.float().isnan() & b.float().isnan())).all())
+    with torch.no_grad():
+        want = fqs[0](mf.rmsnorm(x.nan_to_num(0.0, 1e4, -1e4), w, 1e-5))
+        total, got = mf.rmsnorm_map(x.nan_to_num(0.0, 1e4, -1e4), None, w, 1e-5, fqs)
+        assert total is None and same(want, got)
+        STATS.reset()
+        assert fqs[0](got) is got and same(fqs[1](got), got) and same(fqs[2](got), got)
+        assert STATS.calls == 3 and STATS.elements == 3 * got.numel()       # handed through, each counted once, no launch of its own
+        xs = x.nan_to_num(0.0, 1e4, -1e4)
+        s_want = xs + r
+        want = fqs[0](mf.rmsnorm(s_want, w, 1e-5))
+        total, got = mf.rmsnorm_map(xs, r, w, 1e-5, fqs[:2])
+        assert same(total, s_want) and same(want, got)
+        # SiLU * up, operands as column slices of one wider product
+        gu = (torch.randn(1024, 2 * 13824, device="cuda", generator=g) * 3).bfloat16()
+        gate, up = gu[:, :13824], gu[:, 13824:]
+        want = fqs[0](mf.silu_mul(gate, up))
+        got = mf.silu_mul_map(gate, up, fqs[0])
+        assert same(want, got) and fqs[0](got) is got
+        # rotary on [B, S, H, D] buffers seen as [B, H, S, D], row stride of a q / k / v product
+        B, S, H, D = 2, 256, 8, 128
+        qkv = torch.randn(B, S, 3 * H * D, device="cuda", generator=g).bfloat16()
+        q = qkv[..., :H * D].view(B, S, H, D).transpose(1, 2)
+        k = qkv[..., H * D:2 * H * D].view(B, S, H, D).transpose(1, 2)
+        ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+        cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+        qp, kp = mf.rope(q, k, cos, sin)
+        qm, km = mf.rope_map(q, k, cos, sin, fqs[0], fqs[1])
+        assert qm.is_contiguous() and km.is_contiguous() and qm.shape == (B, H, S, D)
+        assert same(fqs[0](qp), qm) and same(fqs[1](kp), km) and fqs[0](qm) is qm and fqs[1](km) is km
+
+
 @pytest.mark.parametrize("B,S,V,stride", [(1, 1024, 32000, 32000), (3, 37, 1003, 1008), (2, 5, 8, 8)])
 def test_causal_lm_loss_from_bf16_logits(nv, B, S, V, stride):
     """qt_causal_lm_loss_bf16 == cross_entropy(logits.float()[:, :-1], labels[:, 1:], ignore_index=-100) (transformers' ForCausalLMLoss):
