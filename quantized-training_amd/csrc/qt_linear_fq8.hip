@@ -456,7 +456,11 @@ struct LinearFq8R {
         auto item = [&](auto ic, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < 4) {
-                if constexpr (ABL != 3 && ABL != 5 && ABL != 6) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
+                if constexpr (ABL != 3 && ABL != 5 && ABL != 6 && ABL != 8) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
+            } else if constexpr (ABL == 7 || ABL == 8) {
+                // transport probe: the weight piece travels by LDS-DMA (raw bf16 into the FP8 ring's space, results are garbage) instead of
+                // through registers + conversion + ds_write
+                dma16(gw[I - 4] + (long)kb * (2 * kBK), lds_addr(lds) + kADepth * kABytes + (w * NB + (I - 4)) * 1024);
             } else if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
                 store_w(std::integral_constant<int, I - 4>{}, ws);
                 load_w(std::integral_constant<int, I - 4>{}, kb);
@@ -1179,6 +1183,8 @@ int launch(const Args &a, hipStream_t st) {
                 case 4: return launch_r_nb<0, 0, 6, false, 4>(a, st);
                 case 5: return launch_r_nb<0, 0, 6, false, 5>(a, st);     // no operand traffic: fragment reads + multiplications + barriers
                 case 6: return launch_r_nb<0, 0, 6, false, 6>(a, st);     // barriers only
+                case 7: return launch_r_nb<0, 0, 6, false, 7>(a, st);     // transport probe: weights by LDS-DMA (raw, unconverted)
+                case 8: return launch_r_nb<0, 0, 6, false, 8>(a, st);     // the same without the activation DMA
                 default: break;
             }
         }
