@@ -29,3 +29,9 @@ timeout 600 python tools/exp_table_formats.py > gpurun_out/table_formats.txt 2>&
 grep -E "posit8_2|per-channel" gpurun_out/table_formats.txt | head -8
 # the FP8 route table
 (python tools/exp_linear_fq8.py --skip-checks --shapes all --iters 30; python tools/exp_linear_fq8.py --skip-checks --shapes sweep --iters 30) 2>&1 | grep bench > gpurun_out/fq8_routes.txt
+# the reference's current flow: PT2E prepared graph on the fused kernels (bench --route pt2e)
+timeout 900 python bench.py --route pt2e --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/pt2e_bench.json 2> gpurun_out/pt2e_bench.err
+head -c 400 gpurun_out/pt2e_bench.json; echo
+# what bounds the fused FP8 GEMM: compile-time ablations of variant R
+(for a in 0 1 2 3 4 5 6 7 8 0; do echo "QT_FQ8_ABLATE=$a"; QT_FQ8_ABLATE=$a timeout 200 python tools/exp_linear_fq8.py --iters 60 --shapes probe --skip-checks 2>&1 | grep bench | head -1; done) > gpurun_out/fq8_ablate.txt 2>&1
+cat gpurun_out/fq8_ablate.txt | cut -c1-100
