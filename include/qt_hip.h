@@ -487,14 +487,16 @@ int qt_rope_fq_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_
  * repeats of this one) is applied to the result in its ROW FORM -- `map_dev` is the 65 536-entry map with the 512 row words of
  * qt_build_rowparams behind it and fmt->p1 bit 0 set (see qt_format) -- and bf16 values are written; no separate elementwise pass.
  * qt_rmsnorm_map_bf16: RMSNorm (residual_dev / sum_dev NULL) or residual add + RMSNorm; qt_silu_mul_map_bf16: SiLU(gate) * up;
- * qt_rope_map_bf16: rotary embedding of q and k into contiguous [B][H][S][D] outputs (what qk_matmul's hooks would write). */
+ * qt_rope_map_bf16: rotary embedding of q and k into contiguous [B][H][S][D] outputs (what qk_matmul's hooks would write).
+ * PT2E-prepared graphs (see qt_add_rmsnorm_sumfq_bf16 / qt_rope_fq_inner_value): quantize_sum != 0 writes the sum through the same map,
+ * inner_q / inner_k != 0 put bf16(x * cos) through it before the rotary's add. */
 int qt_rmsnorm_map_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev, uint16_t *y_dev,
-                        long rows, long cols, float eps, const qt_format *fmt, const uint16_t *map_dev, void *stream);
+                        long rows, long cols, float eps, const qt_format *fmt, const uint16_t *map_dev, int quantize_sum, void *stream);
 int qt_silu_mul_map_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint16_t *y_dev, size_t rows, size_t cols, size_t gate_row_stride,
                          size_t up_row_stride, const qt_format *fmt, const uint16_t *map_dev, void *stream);
 int qt_rope_map_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
                      uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
-                     const qt_format *fmt, const uint16_t *map_dev, void *stream);
+                     const qt_format *fmt, const uint16_t *map_dev, int inner_q, int inner_k, void *stream);
 /* qt_rope_fq_value for PT2E-prepared graphs (wikitext.py:60-136 exports HF's apply_rotary_pos_emb as q * cos + rotate_half(q) * sin and
  * the annotator fake-quantizes the add's earlier operand): out = fmt(inner(bf16(x * cos)) + bf16(rotate_half(x) * sin)) with inner_q /
  * inner_k stateless closed-form FP formats (NULL: none -- exactly qt_rope_fq_value).  v_dev may be NULL (no value job). */

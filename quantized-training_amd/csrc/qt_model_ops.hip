@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
         const uint4 *gr = (const uint4 *)(map + QT_MAP_ENTRIES);
         const int nrows = (fmt.p1 & 2) ? 512 : 256;
         for (int i = threadIdx.x; i < nrows; i += kNormThreads) s_rows[i] = gr[i];
-        rnd.lds = (const uint16_t *)s_rows;             // visible after the barrier of the row reduction below
+        rnd.lds = (const uint16_t *)s_rows;
+        __syncthreads();                                // (the sum may go through the map before the row reduction's barrier)
     }
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
@@ -70,7 +71,11 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 v[i].w = pack_bf16x2(bf_lo(v[i].w) + bf_lo(r.w), bf_hi(v[i].w) + bf_hi(r.w));
                 if (sum_fq) {            // the NEXT residual add reads fq(sum) (PT2E graphs quantize an add's earlier operand): written quantized,
                     uint32_t t[4] = {v[i].x, v[i].y, v[i].z, v[i].w};       // normalised unquantized
-                    if (sum_fq == 2) fq8_hw_vec8<true>(t, sum_fmt);
+                    if constexpr (FQ == 3) {                                 // (sum_fq == 3: the same table format as the result's, row form)
+                        uint32_t unused = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = fq_word_bf16<kFmtRows, true, false>(t[j], 1.0f, rnd, unused);
+                    } else if (sum_fq == 2) fq8_hw_vec8<true>(t, sum_fmt);
                     else fq8_hw_vec8<false>(t, sum_fmt);
                     sum[row * (size_t)nvec + c] = uint4{t[0], t[1], t[2], t[3]};
                 } else {
@@ -278,8 +283,14 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
             for (int j = 0; j < 4; ++j) {
                 float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
                 if (a.inner) {
-                    a0 = qt_u2f(qt_fp_sat_u32(qt_f2u(a0), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
-                    a1 = qt_u2f(qt_fp_sat_u32(qt_f2u(a1), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
+                    if (a.map) {                                         // table format: the same map as the result's (host-checked)
+                        const Rounder<kFmtRows> rin{a.fmt, a.rows_lds, a.map};
+                        a0 = qt_u2f(rin(qt_f2u(a0)));
+                        a1 = qt_u2f(rin(qt_f2u(a1)));
+                    } else {
+                        a0 = qt_u2f(qt_fp_sat_u32(qt_f2u(a0), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
+                        a1 = qt_u2f(qt_fp_sat_u32(qt_f2u(a1), a.inner_fmt.p0, a.inner_fmt.p1, a.inner_fmt.fhi));
+                    }
                 }
                 const float b0 = rbf(sgn * bf_lo(P[j]) * bf_lo(S[j])), b1 = rbf(sgn * bf_hi(P[j]) * bf_hi(S[j]));
                 out[j] = pack_bf16x2(a0 + b0, a1 + b1);                  // the rotary output, bf16
@@ -883,7 +894,7 @@ static bool map_format_ok(const qt_format *fmt, const uint16_t *map) {
 }
 
 int qt_rmsnorm_map_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, long rows, long cols,
-                        float eps, const qt_format *fmt, const uint16_t *map, void *stream) {
+                        float eps, const qt_format *fmt, const uint16_t *map, int quantize_sum, void *stream) {
     if (rows * cols == 0) return QT_OK;
     if (!x || !weight || !y || rows < 0 || cols < 0 || (residual != nullptr) != (sum != nullptr) || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
     if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
@@ -892,7 +903,7 @@ int qt_rmsnorm_map_bf16(const uint16_t *x, const uint16_t *residual, const uint1
     hipStream_t st = (hipStream_t)stream;
     const int nvec = (int)(cols / 8);
     const float inv = 1.0f / (float)cols;
-    if (residual) rmsnorm_kernel<3, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, 0, qt_format{}, map);
+    if (residual) rmsnorm_kernel<3, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, quantize_sum ? 3 : 0, qt_format{}, map);
     else rmsnorm_kernel<3, false><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, nullptr, nullptr, NormExtra{}, 0, qt_format{}, map);
     return launch_status();
 }
@@ -914,15 +925,15 @@ int qt_silu_mul_map_bf16(const uint16_t *gate, const uint16_t *up, uint16_t *y, 
 
 int qt_rope_map_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
                      long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
-                     void *stream) {
+                     int inner_q, int inner_k, void *stream) {
     if (B * S * D == 0) return QT_OK;
     if (!q || !k || !cos || !sin || !q_out || !k_out || B < 0 || S < 0 || Hq < 0 || Hk < 0 || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
     if (D % 16 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out) & 15u))
         return QT_ERR_UNALIGNED;
     if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
-    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt, nullptr, 0, 0, qt_format{}, map, nullptr};
-    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt, nullptr, 0, 0, qt_format{}, map, nullptr};
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt, nullptr, 0, inner_q ? 1 : 0, qt_format{}, map, nullptr};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt, nullptr, 0, inner_k ? 1 : 0, qt_format{}, map, nullptr};
     const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;
     const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
     size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;

@@ -178,7 +178,7 @@ def _mark_done(y, fqs):
     return y
 
 
-def rmsnorm_map(x, residual, weight, eps, fqs):
+def rmsnorm_map(x, residual, weight, eps, fqs, sum_fq=None):
     """(sum or None, y): RMSNorm (+ the residual add in front) with the consumers' stateless table-format fake-quantizer applied in its row
     form (qt_rmsnorm_map_bf16), or None when the device map does not carry the row words."""
     pf = fqs[0].map_producer_format(x.device)
@@ -192,7 +192,10 @@ def rmsnorm_map(x, residual, weight, eps, fqs):
     y = torch.empty_like(x2)
     _native.check(_native.lib().qt_rmsnorm_map_bf16(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, weight.data_ptr(),
                                                     total.data_ptr() if total is not None else None, y.data_ptr(), x2.numel() // cols, cols,
-                                                    float(eps), ctypes.byref(fmt), qmap.data_ptr(), _stream_ptr(x2)), "qt_rmsnorm_map_bf16")
+                                                    float(eps), ctypes.byref(fmt), qmap.data_ptr(), int(sum_fq is not None), _stream_ptr(x2)),
+                  "qt_rmsnorm_map_bf16")
+    if sum_fq is not None:                           # (PT2E graphs) the residual stream's fake-quantizer, same format: written through the map
+        _mark_done(total, [sum_fq])
     return total, _mark_done(y, fqs)
 
 
@@ -210,7 +213,7 @@ def silu_mul_map(gate, up, fq):
     return _mark_done(y, [fq])
 
 
-def rope_map(q, k, cos, sin, fq_q, fq_k):
+def rope_map(q, k, cos, sin, fq_q, fq_k, inner_q=False, inner_k=False):
     """Rotary embedding with qk_matmul's two stateless table-format input fake-quantizers (one format) in the same pass: contiguous
     [B, H, S, D] outputs marked as done for them, or None."""
     pf = fq_q.map_producer_format(q.device)
@@ -223,7 +226,7 @@ def rope_map(q, k, cos, sin, fq_q, fq_k):
     k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
     _native.check(_native.lib().qt_rope_map_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
                                                  B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
-                                                 _stream_ptr(q)), "qt_rope_map_bf16")
+                                                 int(bool(inner_q)), int(bool(inner_k)), _stream_ptr(q)), "qt_rope_map_bf16")
     return _mark_done(q_out, [fq_q]), _mark_done(k_out, [fq_k])
 
 

@@ -62,6 +62,12 @@ def _producer_ok(fq):
     return isinstance(fq, FusedAmaxObsFakeQuantize) and fq.producer_fusable() and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0"
 
 
+def _table_ok(fq):
+    """A stateless table-format fake-quantizer (posit, fpN, ... without `qs`) a producing kernel may apply in its row form."""
+    return (isinstance(fq, FusedAmaxObsFakeQuantize) and fq.stateless_map() and fq._qt_format.kind == _native.QT_FMT_LUT
+            and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" and os.environ.get("QT_FUSED_PRODUCER_MAP", "1") != "0")
+
+
 class PreparedMLP(nn.Module):
     """`silu(gate(x)) * up(x)` with the down projection's input fake-quantizer behind it (a node of its own: it hands through)."""
 
@@ -82,6 +88,11 @@ class PreparedMLP(nn.Module):
             fq = mf.consumer_fq(down) if down is not None else None
             if fq is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0":
                 return mf.silu_mul_fq(gate, up, fq)
+            mfq = mf.consumer_fq_map(down) if down is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None
+            if mfq is not None:
+                y = mf.silu_mul_map(gate, up, mfq)
+                if y is not None:
+                    return y
             return mf.silu_mul(gate, up)
         return F.silu(gate) * up
 
@@ -105,6 +116,12 @@ class PreparedRMSNorm(nn.Module):
               and (b is None or (mf._eligible(b) and b.shape == a.shape)))
         if ok:
             fq = self.__dict__["consumer"]
+            if _table_ok(fq):                                 # table formats: the row form (and the same for the residual stream's)
+                sfq = self.__dict__["sum_fq"]
+                sfq = sfq if (b is not None and _table_ok(sfq) and sfq.dtype == fq.dtype) else None
+                got = mf.rmsnorm_map(a, b, w, self.eps, [fq], sum_fq=sfq)
+                if got is not None:
+                    return got[1] if b is None else got
             fq = fq if _producer_ok(fq) else None
             if b is None:
                 return mf.rmsnorm_fq(a, w, self.eps, fq) if fq is not None else mf.rmsnorm(a, w, self.eps)
@@ -162,6 +179,8 @@ class PreparedAttention(nn.Module):
 
     def forward(self, q, k, v, cos, sin, mask):
         out = self._fused(q, k, v, cos, sin, mask)
+        if out is None:
+            out = self._fused_table(q, k, v, cos, sin, mask)
         if out is not None:
             return out
         fq_q, fq_k, fq_p, fq_v = self.__dict__["fqs"]
@@ -176,6 +195,55 @@ class PreparedAttention(nn.Module):
         o = torch.matmul(fq_p(p), fq_v(v))
         o = o.transpose(1, 2).contiguous()
         return o.reshape(o.shape[0], o.shape[1], -1)
+
+    def _fused_table(self, q, k, v, cos, sin, mask):
+        """Stateless TABLE formats on all four matmul inputs: the rotary kernel applies fq_q / fq_k (and the inner pair) in their row
+        form, fq_v runs as its own strided pass, and the core is qt_attention_fq_bf16 (bf16 matrix instructions, the probabilities'
+        fake-quantizer inside, §4.4b of DESIGN.md)."""
+        from . import fused, model_fusions as mf
+        fq_q, fq_k, fq_p, fq_v = self.__dict__["fqs"]
+        inner_q, inner_k = self.__dict__["inner"]
+        if os.environ.get("QT_FUSED_ATTENTION", "auto") == "0":
+            return None
+        if not (mf._eligible(q, k, v, cos, sin) and q.dim() == 4 and q.shape == k.shape == v.shape):
+            return None
+        B, H, S, D = q.shape
+        if D not in (64, 128) or S % 4 != 0 or B * H > 65535:
+            return None
+        if not all(_table_ok(f) for f in (fq_q, fq_k, fq_p, fq_v)) or len({f.dtype for f in (fq_q, fq_k, fq_p, fq_v)}) != 1:
+            return None
+        if any(f is not None and not (_table_ok(f) and f.dtype == fq_q.dtype) for f in (inner_q, inner_k)):
+            return None
+        if mf._row_stride(q) is None or mf._row_stride(k) is None:
+            return None
+        if cos.dim() != 3 or cos.shape[0] not in (1, B) or cos.shape[-1] != D or cos.shape[-2] != S or sin.shape != cos.shape:
+            return None
+        mk = fused._mask_strides(mask, B, H, S, S, q.device, 4)
+        if mk is False:
+            return None
+        m, msb, msh, msq = mk
+        pf = fq_p.map_producer_format(q.device)
+        if pf is None:
+            return None
+        if cos.shape[0] != B:
+            cos, sin = cos.expand(B, -1, -1), sin.expand(B, -1, -1)
+        got = mf.rope_map(q, k, cos.contiguous(), sin.contiguous(), fq_q, fq_k, inner_q is not None, inner_k is not None)
+        if got is None:
+            return None
+        qq, kq = got
+        for f, t in ((fq_q, q), (fq_k, k), (inner_q, q), (inner_k, k)):      # evaluated inside the rotary launch
+            if f is not None:
+                f.__dict__["_qt_calls"] = f.__dict__.get("_qt_calls", 0) + 1
+                _FQ_STATS.add(t.numel())
+        vq = fq_v(v).contiguous()
+        fmt, qmap = pf
+        out = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=q.device)
+        _FQ_STATS.add(B * H * S * S)                          # fq_p, inside the kernel
+        fq_p.__dict__["_qt_calls"] = fq_p.__dict__.get("_qt_calls", 0) + 1
+        _native.check(_native.lib().qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), m.data_ptr() if m is not None else None,
+                                                         out.data_ptr(), B, H, S, S, D, msb, msh, msq, self.scaling, ctypes.byref(fmt),
+                                                         qmap.data_ptr(), None, None, _stream_ptr(q)), "qt_attention_fq_bf16")
+        return out.reshape(B, S, H * D)
 
     def _fused(self, q, k, v, cos, sin, mask):
         from . import fused, model_fusions as mf

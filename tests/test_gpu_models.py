@@ -458,6 +458,54 @@ def test_table_format_window_with_and_without_producer_fusion(spec, monkeypatch)
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_pt2e_prepared_route_table_format(monkeypatch):
+    """The PT2E prepared graph under a stateless TABLE format (posit8_2, config 3's spec), head_dim 128, S = 512: fused graph (value-map
+    GEMMs / pair by the route table, row-form producers in the norm, SiLU * up and rotary kernels -- the residual stream's and the rotary's
+    inner fake-quantizers included --, the one-launch attention core) against the same graph node by node: same element count, logits
+    within the accumulation bound, loss within 2e-3."""
+    from quantized_training import pt2e_fusion
+    from quantized_training.fake_quantize import STATS
+    tok = torch.randint(0, 2048, (1, 512), generator=torch.Generator().manual_seed(4)).cuda()
+    launched = {"attention": 0, "norm": 0, "rope": 0}
+    lib = nvlib()
+    with torch.no_grad():
+        def build(fuse):
+            m = harness.build_causal_lm("llama-mid", device="cuda", seed=0, num_layers=2)
+            return harness.prepare_pt2e_causal_lm(m, "posit8_2", "posit8_2", 512, fuse=fuse)
+        plain = build(False)
+        STATS.reset()
+        ref = plain(tok, labels=tok.clone(), use_cache=False)
+        e_plain = STATS.elements
+        ref_logits, ref_loss = ref.logits.float().cpu(), float(ref.loss)
+        del plain, ref
+        gm = build(True)
+        for name in ("_fused_table",):
+            orig = pt2e_fusion.PreparedAttention._fused_table
+
+            def counted(self, *a, _orig=orig, **k):
+                out = _orig(self, *a, **k)
+                launched["attention"] += out is not None
+                return out
+            monkeypatch.setattr(pt2e_fusion.PreparedAttention, name, counted)
+        STATS.reset()
+        out = gm(tok, labels=tok.clone(), use_cache=False)
+        assert STATS.elements == e_plain
+        assert launched["attention"] == 2
+        got = out.logits.float().cpu()
+        scale = float(ref_logits.abs().max())
+        d = (got - ref_logits).abs()
+        corr = float(torch.corrcoef(torch.stack([got.flatten()[::3], ref_logits.flatten()[::3]]))[0, 1])
+        assert torch.isfinite(got).all()
+        assert float(d.pow(2).mean().sqrt()) <= 0.02 * scale and float(d.max()) <= 0.25 * scale and corr >= 0.995, \
+            (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale, corr)
+        assert abs(float(out.loss) - ref_loss) <= 2e-3 * ref_loss, (float(out.loss), ref_loss)
+
+
+def nvlib():
+    from quantized_training import _native
+    return _native.lib()
+
+
 def test_pt2e_prepared_route_at_size(monkeypatch):
     """The reference's current WikiText flow (wikitext.py:60-136: torch.export + prepare_pt2e, fake-quantizers as graph nodes) at
     LLaMA-2-7B width (hidden 4096, 32 heads of 128, FFN 11008, vocab 32000; 2 layers), S = 1024, E4M3 activations + weights: the

@@ -12,7 +12,7 @@ for w in llama-13b-posit8_2 bert-base-squad-e4m3 roberta-mrpc-int8-e5m2-train; d
   head -c 300 gpurun_out/bench_$w.json; echo
 done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_13b_posit -- python3 bench.py --workload llama-13b-posit8_2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_13b_posit.log 2>&1
-python tools/window_breakdown.py gpurun_out/prof_13b_posit --windows 3 --layers 40 --anchor softmax > gpurun_out/window_breakdown_13b_posit.txt 2>&1
+python tools/window_breakdown.py gpurun_out/prof_13b_posit --windows 3 --layers 40 --anchor attention_fq > gpurun_out/window_breakdown_13b_posit.txt 2>&1
 head -25 gpurun_out/window_breakdown_13b_posit.txt
 find gpurun_out/prof_13b_posit -name "*kernel_trace.csv" -delete
 # the value-map GEMM: parity checks + timing against the pair at the 13B / 7B / BERT shapes, ablations, stamps, profiler passes
