@@ -134,9 +134,11 @@ _PENDING = {"device": None, "multi": None}
 
 
 def note_device(index):
-    """Called by the launch helpers with the device ordinal of the tensors about to be handed to a kernel: the next
-    native call runs with that device current (the C ABI takes raw pointers and a stream and launches on the calling
-    thread's current device; hipBLASLt handles are per device as well).  Free when the process sees one GPU."""
+    """Called by the launch helpers (fake_quantize._stream_ptr) with the device ordinal of the tensors about to be handed to a kernel:
+    every native call from now until the next note_device runs with that device current (the C ABI takes raw pointers and a stream
+    and launches on the calling thread's current device; hipBLASLt handles are per device as well).  A launch sequence that takes
+    its stream once and then issues several kernels (attention: mask scan, value codes, core) therefore stays on the tensors' device.
+    Free when the process sees one GPU."""
     _PENDING["device"] = index
 
 
@@ -154,7 +156,6 @@ class _GuardedLib:
             idx = _PENDING["device"]
             if idx is None:
                 return fn(*args)
-            _PENDING["device"] = None
             import torch
             if _PENDING["multi"] is None:
                 _PENDING["multi"] = torch.cuda.device_count() > 1

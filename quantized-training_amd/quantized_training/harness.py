@@ -48,7 +48,9 @@ def _window_loss(model, input_ids, labels, **kwargs):
         # a PT2E graph (prepare_pt2e_causal_lm): exported with exactly (input_ids, labels=, use_cache=) -- mask, positions and the loss
         # are nodes of the graph (wikitext.py:83-96 exports the model's own forward)
         return model(input_ids, labels=labels, use_cache=False).loss.float()
-    if os.environ.get("QT_FUSED_LOSS", "1") != "0" and input_ids.is_cuda and not torch.is_grad_enabled():
+    # the one-pass loss restates transformers' ForCausalLMLoss: only for models whose loss IS that function
+    stock_loss = getattr(getattr(model, "loss_function", None), "__name__", "") == "ForCausalLMLoss"
+    if os.environ.get("QT_FUSED_LOSS", "1") != "0" and input_ids.is_cuda and not torch.is_grad_enabled() and stock_loss:
         from . import _native
         out = model(input_ids, use_cache=False, **kwargs)
         logits = getattr(out, "logits", None)
@@ -58,6 +60,7 @@ def _window_loss(model, input_ids, labels, **kwargs):
             B, S, V = logits.shape
             scratch = torch.empty(B * S + 1, dtype=torch.float32, device=logits.device)
             with torch.cuda.device(logits.device):
+                _native.note_device(logits.device.index)
                 stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
                 _native.check(_native.lib().qt_causal_lm_loss_bf16(logits.data_ptr(), labels.data_ptr(), B, S, V, logits.stride(1), -100,
                                                                    scratch.data_ptr(), scratch.data_ptr() + 4 * B * S, stream),

@@ -239,7 +239,12 @@ def fuse_native_gemms(model: GraphModule) -> int:
             kind = qa[3].split(",")[0]
             if kind != "int8" or qb[3].split(",")[0] != kind:
                 continue
-            tail = _sole_dequantize(model, node, next(iter(model.parameters())).dtype)
+            first = next(iter(model.parameters()), None)
+            if first is None:
+                first = next(iter(model.buffers()), None)
+            if first is None:
+                continue                                     # a graph without parameters or buffers: nothing says what dtype it runs in
+            tail = _sole_dequantize(model, node, first.dtype)
             if tail is None:
                 continue
             dq, s_out, m_out = tail
