@@ -376,6 +376,14 @@ __device__ __forceinline__ void silu_mul4(const float (&gt)[4], const float (&up
 template <int FX, int FW, int NB, bool PAIR = false, int ABL = 0>
 struct LinearFq8R {
     static constexpr int kADepth = 3;
+    // ABL == 20 (not an ablation: the two-register-set variant): every weight piece has TWO register sets, so a weight request has two
+    // steps to land instead of one.  The requests are inline-asm loads with hand-counted waits: hipcc cannot count the (hidden)
+    // activation DMA entries that share the wave's in-order queue, and its own waits for ordinary loads came out up to eight entries
+    // too strict -- which is what kept a second register set from paying off in round 2.  The k loop is unrolled by two so that each
+    // set lives in fixed registers (nothing rotates: a register written by a load in flight must never be copied).
+    static constexpr bool W2 = (ABL == 20);
+    static constexpr int kWSets = W2 ? 2 : 1;
+    static constexpr int kWWait = 2 * NB + 3;               // queue entries allowed behind a weight request when its registers are read
     static constexpr int kWBytes = NB * 4 * 1024;           // FP8 weight tile: up to 8 NB pieces of 4 rows x 128 bytes
     static constexpr int kLds = kADepth * kABytes + 2 * kWBytes;
     static constexpr int kItems = 4 + NB;
@@ -411,6 +419,8 @@ struct LinearFq8R {
         // ---- weight pieces (4 rows x 256 bytes of bf16): piece p = w + 8 i; lane = (row l >> 4, 16-byte chunk l & 15 = k 8c .. 8c+7)
         const int npieces = nt * 4;
         const uint8_t *gw[NB];
+        const uint8_t *ub[NB];                                 // wave-uniform part of gw (first row of the piece): W2 keeps these in SGPRs
+        const uint32_t w_lane = (uint32_t)(l >> 4) * (uint32_t)a.K * 2u + (uint32_t)(l & 15) * 16u;      // the lane's part, same for every piece
         uint32_t wdst[NB];                                     // where the lane's 8 codes go inside an FP8 weight tile
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -419,17 +429,25 @@ struct LinearFq8R {
             const int row = pb * 4 + (l >> 4), c = l & 15;
             if constexpr (PAIR) {
                 const uint16_t *wb = (grp & 1) ? a.seg[1].w : a.seg[0].w;
-                gw[i] = (const uint8_t *)wb + ((long)((grp >> 1) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+                ub[i] = (const uint8_t *)wb + ((long)((grp >> 1) * 16 + (pb & 3) * 4) * a.K) * 2;
             } else {
                 const SegRef sg = seg_lookup(a, grp);
-                gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+                ub[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4) * a.K) * 2;
             }
+            gw[i] = ub[i] + w_lane;
             wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
         }
-        u32x4 wr[NB];
-        auto load_w = [&](auto ic, int kt) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            wr[I] = *(const u32x4 *)(gw[I] + (long)kt * (2 * kBK));
+        u32x4 wr[kWSets][NB];
+        auto load_w_asm = [](u32x4 &dst, uint32_t lane_off, const uint8_t *base) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base) : "memory");
+        };
+        auto wait_w_asm = [](u32x4 &reg) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(kWWait) : "memory");
+        };
+        auto load_w = [&](auto ic, auto sc, int kt) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value, S = decltype(sc)::value;
+            if constexpr (W2) load_w_asm(wr[S][I], w_lane, ub[I] + (long)kt * (2 * kBK));
+            else wr[S][I] = *(const u32x4 *)(gw[I] + (long)kt * (2 * kBK));
         };
         // The activation DMA as inline asm: with the builtin, hipcc's wait-count model sees a pending "flat" access to LDS and turns
         // every wait for a weight register into vmcnt(0), which also waits for the step's own DMA pieces.  Hidden from the model the
@@ -445,40 +463,41 @@ struct LinearFq8R {
         auto ds_write32 = [](uint32_t addr, uint32_t v) __attribute__((always_inline)) {
             asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
         };
-        auto store_w = [&](auto ic, uint32_t wbase) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[I].x, wr[I].y), cvt_bf16x4<FW == 1>(wr[I].z, wr[I].w)};
+        auto store_w = [&](auto ic, auto sc, uint32_t wbase) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value, S = decltype(sc)::value;
+            if constexpr (W2) wait_w_asm(wr[S][I]);
+            const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[S][I].x, wr[S][I].y), cvt_bf16x4<FW == 1>(wr[S][I].z, wr[S][I].w)};
             const uint32_t addr = wbase + wdst[I];
             ds_write64(addr, codes);
         };
         // item 0-3: activation pieces of k tile ka into `as`; item 4 + i: weight piece i -- its registers (k tile kb - 1) are
         // converted and written to the FP8 tile at LDS address `ws`, then reloaded with k tile kb
-        auto item = [&](auto ic, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+        auto item = [&](auto ic, auto sc, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < 4) {
-                if constexpr (ABL != 3 && ABL != 5 && ABL != 6 && ABL != 8) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
-            } else if constexpr (ABL == 7 || ABL == 8) {
+                if constexpr (ABL != 3 && ABL != 5 && ABL != 6 && ABL != 8 && ABL != 10) dma16(ga[I] + (long)ka * kBK, as + (w * 4 + I) * 1024);
+            } else if constexpr (ABL == 7 || ABL == 8 || ABL == 10 || ABL == 11) {
                 // transport probe: the weight piece travels by LDS-DMA (raw bf16 into the FP8 ring's space, results are garbage) instead of
                 // through registers + conversion + ds_write
                 dma16(gw[I - 4] + (long)kb * (2 * kBK), lds_addr(lds) + kADepth * kABytes + (w * NB + (I - 4)) * 1024);
-            } else if constexpr (ABL != 2 && ABL != 5 && ABL != 6) {
-                store_w(std::integral_constant<int, I - 4>{}, ws);
-                load_w(std::integral_constant<int, I - 4>{}, kb);
+            } else if constexpr (ABL != 2 && ABL != 5 && ABL != 6 && ABL != 9) {
+                store_w(std::integral_constant<int, I - 4>{}, sc, ws);
+                load_w(std::integral_constant<int, I - 4>{}, sc, kb);
             }
         };
-        auto items = [&](auto lo, auto hi, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+        auto items = [&](auto lo, auto hi, auto sc, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
             static_assert(HI - LO <= 10, "at most ten items");
-            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, ka, as, ws, kb);
-            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, ka, as, ws, kb);
-            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, ka, as, ws, kb);
-            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, ka, as, ws, kb);
-            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, ka, as, ws, kb);
-            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, ka, as, ws, kb);
-            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, ka, as, ws, kb);
-            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, ka, as, ws, kb);
-            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, ka, as, ws, kb);
-            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, ka, as, ws, kb);
+            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, sc, ka, as, ws, kb);
+            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, sc, ka, as, ws, kb);
         };
         constexpr auto kI0 = std::integral_constant<int, 0>{};
         constexpr auto kIA = std::integral_constant<int, 4>{};
@@ -493,10 +512,10 @@ struct LinearFq8R {
         const uint32_t a_lo = a_chunk_off(wm * 64 + r, g), a_hi = a_chunk_off(wm * 64 + r, 4 + g);
         const uint32_t b_lo = a_chunk_off(jbase * 16 + r, g), b_hi = a_chunk_off(jbase * 16 + r, 4 + g);
 
-        auto compute = [&](uint32_t sa_, uint32_t sb_, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
+        auto compute = [&](auto sc, uint32_t sa_, uint32_t sb_, int ka, uint32_t as, uint32_t ws, int kb) __attribute__((always_inline)) {
             if constexpr (NTW > 0) {
                 u32x4 fa_lo[4], fa_hi[4], fb_lo[3], fb_hi[3];
-                if constexpr (ABL != 4 && ABL != 6) {
+                if constexpr (ABL != 4 && ABL != 6 && (ABL < 9 || ABL >= 20)) {
                     fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
                     fa_lo[1] = ds_read128<1 * 2048>(sa_ + a_lo); fa_hi[1] = ds_read128<1 * 2048>(sa_ + a_hi);
                     fa_lo[2] = ds_read128<2 * 2048>(sa_ + a_lo); fa_hi[2] = ds_read128<2 * 2048>(sa_ + a_hi);
@@ -504,7 +523,7 @@ struct LinearFq8R {
                 }
                 auto read_b = [&](auto jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(jc)::value;
-                    if constexpr (ABL != 4 && ABL != 6) {
+                    if constexpr (ABL != 4 && ABL != 6 && (ABL < 9 || ABL >= 20)) {
                         fb_lo[J % 3] = ds_read128<J * 2048>(sb_ + b_lo);
                         fb_hi[J % 3] = ds_read128<J * 2048>(sb_ + b_hi);
                     }
@@ -534,12 +553,12 @@ struct LinearFq8R {
                     }
                     const v8i fb = v8i{(int)fb_lo[P].x, (int)fb_lo[P].y, (int)fb_lo[P].z, (int)fb_lo[P].w,
                                        (int)fb_hi[P].x, (int)fb_hi[P].y, (int)fb_hi[P].z, (int)fb_hi[P].w};
-                    if constexpr (ABL != 1 && ABL != 4 && ABL != 6) {
+                    if constexpr (ABL != 1 && ABL != 4 && ABL != 6 && (ABL < 9 || ABL >= 20)) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
                     }
-                    items(std::integral_constant<int, item_lo(J, NTW)>{}, std::integral_constant<int, item_hi(J, NTW)>{}, ka, as, ws, kb);
+                    items(std::integral_constant<int, item_lo(J, NTW)>{}, std::integral_constant<int, item_hi(J, NTW)>{}, sc, ka, as, ws, kb);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 read_b(std::integral_constant<int, 0>{});
@@ -551,34 +570,78 @@ struct LinearFq8R {
                 if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
                 if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
             } else {
-                items(kI0, kIN, ka, as, ws, kb);
+                items(kI0, kIN, sc, ka, as, ws, kb);
             }
         };
 
         const uint32_t l0 = lds_addr(lds), w0 = l0 + kADepth * kABytes;
         // prologue: activations of k tiles 0 and 1 on their way; weights of k tile 0 converted into FP8 tile 0, those of k tile 1
         // in registers
-        items(kI0, kIA, 0, l0, w0, 0);
-        items(kI0, kIA, min(1, klast), l0 + kABytes, w0, 0);
-        load_w(std::integral_constant<int, 0>{}, 0);
-        if constexpr (NB > 1) load_w(std::integral_constant<int, 1>{}, 0);
-        if constexpr (NB > 2) load_w(std::integral_constant<int, 2>{}, 0);
-        if constexpr (NB > 3) load_w(std::integral_constant<int, 3>{}, 0);
-        if constexpr (NB > 4) load_w(std::integral_constant<int, 4>{}, 0);
-        if constexpr (NB > 5) load_w(std::integral_constant<int, 5>{}, 0);
-        items(kIA, kIN, 0, l0, w0, min(1, klast));
+        constexpr auto kS0 = std::integral_constant<int, 0>{};
+        constexpr auto kS1 = std::integral_constant<int, kWSets - 1>{};
+        auto load_all = [&](auto sc, int kt) __attribute__((always_inline)) {
+            load_w(std::integral_constant<int, 0>{}, sc, kt);
+            if constexpr (NB > 1) load_w(std::integral_constant<int, 1>{}, sc, kt);
+            if constexpr (NB > 2) load_w(std::integral_constant<int, 2>{}, sc, kt);
+            if constexpr (NB > 3) load_w(std::integral_constant<int, 3>{}, sc, kt);
+            if constexpr (NB > 4) load_w(std::integral_constant<int, 4>{}, sc, kt);
+            if constexpr (NB > 5) load_w(std::integral_constant<int, 5>{}, sc, kt);
+        };
+        items(kI0, kIA, kS0, 0, l0, w0, 0);
+        items(kI0, kIA, kS0, min(1, klast), l0 + kABytes, w0, 0);
+        load_all(kS0, 0);
         int a_slot = 0, a_tgt = 2;
-        for (int kt = 0; kt < nk; ++kt) {
+        auto one_step = [&](auto sc, int kt, int ahead) __attribute__((always_inline)) {
             // this wave's FP8 codes of step kt are written (lgkmcnt) and its activation pieces have landed: they are older in the
             // vector-memory queue than the weight loads of step kt, which the conversions of the previous step waited for
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NB) : "memory");
             __builtin_amdgcn_s_barrier();                    // ... every wave's; and every wave is done with step kt - 1
-            const int ka = min(kt + 2, klast), kb = min(kt + 2, klast);
+            const int ka = min(kt + 2, klast), kb = min(kt + ahead, klast);
             const uint32_t sa_ = l0 + a_slot * kABytes, sb_ = w0 + (kt & 1) * kWBytes, ws = w0 + ((kt + 1) & 1) * kWBytes;
-            compute(sa_, sb_, ka, l0 + a_tgt * kABytes, ws, kb);
+            compute(sc, sa_, sb_, ka, l0 + a_tgt * kABytes, ws, kb);
             a_tgt = a_slot; a_slot = a_slot == 2 ? 0 : a_slot + 1;
+        };
+        if constexpr (!W2) {
+            // weights of k tile 0 converted into FP8 tile 0, those of k tile 1 in registers
+            items(kIA, kIN, kS0, 0, l0, w0, min(1, klast));
+            for (int kt = 0; kt < nk; ++kt) one_step(kS0, kt, 2);
+        } else {
+            // k tile 0: requested, awaited, converted into FP8 tile 0; then set 1 <- k tile 1, set 0 <- k tile 2.  Step kt converts k tile
+            // kt + 1 out of set (kt + 1) & 1 into FP8 tile (kt + 1) & 1 and refills that set with k tile kt + 3.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (ABL != 2) {
+                auto conv0 = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr int I = decltype(ic)::value;
+                    asm volatile("" : "+v"(wr[0][I]));
+                    const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[0][I].x, wr[0][I].y), cvt_bf16x4<FW == 1>(wr[0][I].z, wr[0][I].w)};
+                    ds_write64(w0 + wdst[I], codes);
+                };
+                conv0(std::integral_constant<int, 0>{});
+                if constexpr (NB > 1) conv0(std::integral_constant<int, 1>{});
+                if constexpr (NB > 2) conv0(std::integral_constant<int, 2>{});
+                if constexpr (NB > 3) conv0(std::integral_constant<int, 3>{});
+                if constexpr (NB > 4) conv0(std::integral_constant<int, 4>{});
+                if constexpr (NB > 5) conv0(std::integral_constant<int, 5>{});
+            }
+            load_all(kS1, min(1, klast));
+            load_all(kS0, min(2, klast));
+            int kt = 0;
+            one_step(kS1, kt, 3);
+            for (kt = 1; kt + 1 < nk; kt += 2) {
+                one_step(kS0, kt, 3);
+                one_step(kS1, kt + 1, 3);
+            }
+            if (kt < nk) one_step(kS0, kt, 3);
+            // requests past the last k tile are still in flight into the (now unused) weight registers: they stay reserved until the
+            // queue has drained
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(wr[0][i]), "+v"(wr[1][i]));
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (W2) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(wr[0][i]), "+v"(wr[kWSets - 1][i]));
+        }
         // Overflowed or non-finite weights (and NaN activations) leave NaN / Inf in the accumulators: such a tile is redone
         // by slow_tile.  The workgroup-wide vote goes through LDS (the rings are dead here).
         bool bad = false;
@@ -810,18 +873,29 @@ __device__ __forceinline__ void slow_tile_pair(const Args &a, int m0, int tg0, i
 // the weight registers, the LDS latency in front of the first multiplication -- are then ~0.7 of a 1.0 us step (1024 x 4096 x
 // 11008: 85 us for 86 steps).  Here a step is 256 deep: half as many of those, twice the work to cover them.  Activations two
 // steps of 64 KiB (the DMA of step s + 1 lands during step s), FP8 weight tiles 2 x 2 x 8 KiB: 160 KiB of LDS.
-template <int FX, int FW>
+// ABL (timing experiments, QT_FQ8_R2_ABLATE): 2 no weight items, 3 no activation DMA, 5 neither (fragment reads + multiplications only)
+template <int FX, int FW, int ABL = 0>
 struct LinearFq8R2 {
     static constexpr int NB = 2;                            // weight pieces per wave and k tile
     static constexpr int kAStage = 2 * kABytes, kWTile = NB * 4 * 1024, kWStage = 2 * kWTile;
     static constexpr int kLds = 2 * kAStage + 2 * kWStage;
     static constexpr int kItems = 8 + 2 * NB;               // per step and wave: 8 activation DMA pieces, 4 weight items
+    // ABL == 30 (not an ablation -- variant RX, "register-extended rings"): the kernel uses half the register file, and its k loop is
+    // paced by how many operand bytes a CU has in flight (one step of each operand: 96 KB against a latency of 1.1 - 2.2 us).  RX
+    // requests BOTH operands into registers two steps ahead (two register sets each: 64 + 32 VGPRs; inline-asm loads, hand-counted
+    // waits, the loop unrolled by two so that nothing rotates) and moves them into the LDS stage of the next step with ds_write
+    // (activations as they are, weights converted) -- twice the bytes in flight with the same 160 KiB of LDS.  EXPERIMENT, opt-in
+    // (QT_FQ8_R2_ABLATE=30; exact, all parity checks pass): it is NOT faster -- 1024 x 4096 x 11008 74.0 us against 71.9, 4096^3-shaped o
+    // projection 30.3 against 28.8 -- so the narrow-tile loop is not limited by the bytes it has in flight.
+    static constexpr bool RX = (ABL == 30);
+    static constexpr int kRxWait = 2 * kItems - 1;          // queue entries behind a request issued two steps earlier at the same place
     // items of group gi (k half h = gi / NTW, column group J = gi % NTW) out of G = 2 NTW: DMA pieces on the first half of the
     // groups, weight items (convert + ds_write + reload) on the second half
     static constexpr int item_lo(int gi, int G) { return gi < G / 2 ? gi * 8 / (G / 2) : 8 + (gi - G / 2) * (2 * NB) / (G - G / 2); }
     static constexpr int item_hi(int gi, int G) { return gi < G / 2 ? (gi + 1) * 8 / (G / 2) : 8 + (gi - G / 2 + 1) * (2 * NB) / (G - G / 2); }
     static constexpr int writes_in(int gi, int G) {
         const int lo = item_lo(gi, G), hi = item_hi(gi, G);
+        if (RX) return hi - lo;                              // every item ends in one ds_write
         return (hi > 8 ? hi : 8) - (lo > 8 ? lo : 8);
     }
 
@@ -836,8 +910,13 @@ struct LinearFq8R2 {
             const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
             ga[i] = a.x8 + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
         }
+        uint32_t aoff[4];                                      // RX: the lane's part of ga[i] (the base a.x8 + k offset is wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)(ga[i] - a.x8);
         const int npieces = nt * 4;
         const uint8_t *gw[NB];
+        const uint8_t *ub[NB];                                 // wave-uniform part of gw
+        const uint32_t w_lane = (uint32_t)(l >> 4) * (uint32_t)a.K * 2u + (uint32_t)(l & 15) * 16u;
         uint32_t wdst[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -845,10 +924,22 @@ struct LinearFq8R2 {
             const int grp = tg0 + (pb >> 2);
             const int row = pb * 4 + (l >> 4), c = l & 15;
             const SegRef sg = seg_lookup(a, grp);
-            gw[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4 + (l >> 4)) * a.K) * 2 + c * 16;
+            ub[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb & 3) * 4) * a.K) * 2;
+            gw[i] = ub[i] + w_lane;
             wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
         }
         u32x4 wr[2 * NB];                                      // [k half][piece]
+        u32x4 ar[RX ? 2 : 1][RX ? 8 : 1], wx[RX ? 2 : 1][RX ? 2 * NB : 1];      // RX: [set][item]
+        auto load_asm = [](u32x4 &dst, uint32_t lane_off, const uint8_t *base) __attribute__((always_inline)) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base) : "memory");
+        };
+        auto wait_asm = [](u32x4 &reg) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(kRxWait) : "memory");
+        };
+        auto ds_write128 = [](uint32_t addr, u32x4 v) __attribute__((always_inline)) {
+            asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        };
+        const uint32_t a_lane = (uint32_t)l * 16u;
         auto dma16 = [](const uint8_t *src, uint32_t dst) __attribute__((always_inline)) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
         };
@@ -857,11 +948,24 @@ struct LinearFq8R2 {
         };
         // item 0-7: activation piece (k half I / 4, piece I % 4) of step sa into `as`; item 8 + i: weight registers i (k half i / NB,
         // piece i % NB, holding step sb - 1) converted into the FP8 tiles at `ws`, then reloaded with step sb
-        auto item = [&](auto ic, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value;
-            if constexpr (I < 8) {
-                dma16(ga[I & 3] + (long)(2 * sa + (I >> 2)) * kBK, as + (I >> 2) * kABytes + (w * 4 + (I & 3)) * 1024);
-            } else {
+        auto item = [&](auto ic, auto sc, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value, S = decltype(sc)::value;
+            if constexpr (RX) {
+                // sb: the step these registers are refilled with (two ahead of the one they hold); the set in hand holds step sa's operands
+                if constexpr (I < 8) {
+                    wait_asm(ar[S][I]);
+                    ds_write128(as + (I >> 2) * kABytes + (w * 4 + (I & 3)) * 1024 + a_lane, ar[S][I]);
+                    load_asm(ar[S][I], aoff[I & 3], a.x8 + (long)(2 * sb + (I >> 2)) * kBK);
+                } else {
+                    constexpr int Wi = I - 8, H = Wi / NB, P = Wi % NB;
+                    wait_asm(wx[S][Wi]);
+                    const u32x2 codes = {cvt_bf16x4<FW == 1>(wx[S][Wi].x, wx[S][Wi].y), cvt_bf16x4<FW == 1>(wx[S][Wi].z, wx[S][Wi].w)};
+                    ds_write64(ws + H * kWTile + wdst[P], codes);
+                    load_asm(wx[S][Wi], w_lane, ub[P] + (long)(2 * sb + H) * (2 * kBK));
+                }
+            } else if constexpr (I < 8) {
+                if constexpr (ABL != 3 && ABL != 5) dma16(ga[I & 3] + (long)(2 * sa + (I >> 2)) * kBK, as + (I >> 2) * kABytes + (w * 4 + (I & 3)) * 1024);
+            } else if constexpr (ABL != 2 && ABL != 5) {
                 constexpr int Wi = I - 8, H = Wi / NB, P = Wi % NB;
                 const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[Wi].x, wr[Wi].y), cvt_bf16x4<FW == 1>(wr[Wi].z, wr[Wi].w)};
                 const uint32_t addr = ws + H * kWTile + wdst[P];
@@ -869,21 +973,21 @@ struct LinearFq8R2 {
                 wr[Wi] = *(const u32x4 *)(gw[P] + (long)(2 * sb + H) * (2 * kBK));
             }
         };
-        auto items = [&](auto lo, auto hi, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+        auto items = [&](auto lo, auto hi, auto sc, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
             constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
             static_assert(HI - LO <= 12, "at most twelve items");
-            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, sa, as, ws, sb);
-            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, sa, as, ws, sb);
-            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, sa, as, ws, sb);
-            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, sa, as, ws, sb);
-            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, sa, as, ws, sb);
-            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, sa, as, ws, sb);
-            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, sa, as, ws, sb);
-            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, sa, as, ws, sb);
-            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, sa, as, ws, sb);
-            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, sa, as, ws, sb);
-            if constexpr (LO + 10 < HI) item(std::integral_constant<int, LO + 10>{}, sa, as, ws, sb);
-            if constexpr (LO + 11 < HI) item(std::integral_constant<int, LO + 11>{}, sa, as, ws, sb);
+            if constexpr (LO + 0 < HI) item(std::integral_constant<int, LO + 0>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 1 < HI) item(std::integral_constant<int, LO + 1>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 2 < HI) item(std::integral_constant<int, LO + 2>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 3 < HI) item(std::integral_constant<int, LO + 3>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 4 < HI) item(std::integral_constant<int, LO + 4>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 5 < HI) item(std::integral_constant<int, LO + 5>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 6 < HI) item(std::integral_constant<int, LO + 6>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 7 < HI) item(std::integral_constant<int, LO + 7>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 8 < HI) item(std::integral_constant<int, LO + 8>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 9 < HI) item(std::integral_constant<int, LO + 9>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 10 < HI) item(std::integral_constant<int, LO + 10>{}, sc, sa, as, ws, sb);
+            if constexpr (LO + 11 < HI) item(std::integral_constant<int, LO + 11>{}, sc, sa, as, ws, sb);
         };
         constexpr auto kI0 = std::integral_constant<int, 0>{};
         constexpr auto kIA = std::integral_constant<int, 8>{};
@@ -898,7 +1002,7 @@ struct LinearFq8R2 {
         const uint32_t b_lo = a_chunk_off(jbase * 16 + r, g), b_hi = a_chunk_off(jbase * 16 + r, 4 + g);
 
         // one k half (activations at sa_, FP8 weights at sb_) of a step, carrying the step's items of its groups
-        auto half = [&](auto hc, uint32_t sa_, uint32_t sb_, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
+        auto half = [&](auto hc, auto sc, uint32_t sa_, uint32_t sb_, int sa, uint32_t as, uint32_t ws, int sb) __attribute__((always_inline)) {
             constexpr int H = decltype(hc)::value, G = 2 * NTW;
             u32x4 fa_lo[4], fa_hi[4], fb_lo[2], fb_hi[2];
             fa_lo[0] = ds_read128<0 * 2048>(sa_ + a_lo); fa_hi[0] = ds_read128<0 * 2048>(sa_ + a_hi);
@@ -930,7 +1034,7 @@ struct LinearFq8R2 {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
-                items(std::integral_constant<int, item_lo(gi, G)>{}, std::integral_constant<int, item_hi(gi, G)>{}, sa, as, ws, sb);
+                items(std::integral_constant<int, item_lo(gi, G)>{}, std::integral_constant<int, item_hi(gi, G)>{}, sc, sa, as, ws, sb);
                 __builtin_amdgcn_sched_barrier(0);
             };
             step(std::integral_constant<int, 0>{});
@@ -938,11 +1042,14 @@ struct LinearFq8R2 {
         };
 
         const uint32_t l0 = lds_addr(lds), w0 = l0 + 2 * kAStage;
+        constexpr auto kS0 = std::integral_constant<int, 0>{};
+        constexpr auto kS1 = std::integral_constant<int, RX ? 1 : 0>{};
+        if constexpr (!RX) {
         // prologue: activations of step 0 on their way; weights of step 0 converted into FP8 stage 0, those of step 1 in registers
-        items(kI0, kIA, 0, l0, w0, 0);
+        items(kI0, kIA, kS0, 0, l0, w0, 0);
 #pragma unroll
         for (int i = 0; i < 2 * NB; ++i) wr[i] = *(const u32x4 *)(gw[i % NB] + (long)(i / NB) * (2 * kBK));
-        items(kIA, kIN, 0, l0, w0, min(1, slast));
+        items(kIA, kIN, kS0, 0, l0, w0, min(1, slast));
         for (int s = 0; s < ns; ++s) {
             // the weight loads of step s + 1 are the newest entries of this wave's queue; its DMA pieces of step s are older
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NB) : "memory");
@@ -951,13 +1058,65 @@ struct LinearFq8R2 {
             const uint32_t sa_ = l0 + (s & 1) * kAStage, sb_ = w0 + (s & 1) * kWStage;
             const uint32_t as = l0 + ((s + 1) & 1) * kAStage, ws = w0 + ((s + 1) & 1) * kWStage;
             if constexpr (NTW > 0) {
-                half(std::integral_constant<int, 0>{}, sa_, sb_, sa, as, ws, sb);
-                half(std::integral_constant<int, 1>{}, sa_ + kABytes, sb_ + kWTile, sa, as, ws, sb);
+                half(std::integral_constant<int, 0>{}, kS0, sa_, sb_, sa, as, ws, sb);
+                half(std::integral_constant<int, 1>{}, kS0, sa_ + kABytes, sb_ + kWTile, sa, as, ws, sb);
             } else {
-                items(kI0, kIN, sa, as, ws, sb);
+                items(kI0, kIN, kS0, sa, as, ws, sb);
             }
         }
+        } else {
+            // RX prologue: step 0's operands requested into set 0, awaited, moved into stage 0; then set 1 <- step 1, set 0 <- step 2, in
+            // the order the loop issues them (activation items, then weight items), so that the loop's constant wait count holds from
+            // its first step.  Step s moves step s + 1 out of set (s + 1) & 1 into stage (s + 1) & 1 and refills that set with step s + 3.
+            auto request = [&](auto sc, int step) __attribute__((always_inline)) {
+                constexpr int S = decltype(sc)::value;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) load_asm(ar[S][i], aoff[i & 3], a.x8 + (long)(2 * step + (i >> 2)) * kBK);
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i) load_asm(wx[S][i], w_lane, ub[i % NB] + (long)(2 * step + i / NB) * (2 * kBK));
+            };
+            request(kS0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("" : "+v"(ar[0][i]));
+                ds_write128(l0 + (i >> 2) * kABytes + (w * 4 + (i & 3)) * 1024 + a_lane, ar[0][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) {
+                asm volatile("" : "+v"(wx[0][i]));
+                const u32x2 codes = {cvt_bf16x4<FW == 1>(wx[0][i].x, wx[0][i].y), cvt_bf16x4<FW == 1>(wx[0][i].z, wx[0][i].w)};
+                ds_write64(w0 + (i / NB) * kWTile + wdst[i % NB], codes);
+            }
+            request(kS1, min(1, slast));
+            request(kS0, min(2, slast));
+            auto rx_step = [&](auto sc, int s) __attribute__((always_inline)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's ds_writes into the stage about to be read
+                __builtin_amdgcn_s_barrier();                               // ... every wave's; and every wave is done with step s - 1
+                const int sa = min(s + 1, slast), sb = min(s + 3, slast);
+                const uint32_t sa_ = l0 + (s & 1) * kAStage, sb_ = w0 + (s & 1) * kWStage;
+                const uint32_t as = l0 + ((s + 1) & 1) * kAStage, ws = w0 + ((s + 1) & 1) * kWStage;
+                if constexpr (NTW > 0) {
+                    half(std::integral_constant<int, 0>{}, sc, sa_, sb_, sa, as, ws, sb);
+                    half(std::integral_constant<int, 1>{}, sc, sa_ + kABytes, sb_ + kWTile, sa, as, ws, sb);
+                } else {
+                    items(kI0, kIN, sc, sa, as, ws, sb);
+                }
+            };
+            int s = 0;
+            for (; s + 1 < ns; s += 2) {
+                rx_step(kS1, s);
+                rx_step(kS0, s + 1);
+            }
+            if (s < ns) rx_step(kS1, s);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (RX) {                                   // requests past the last step were still landing in these registers
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(ar[0][i]), "+v"(ar[1][i]));
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) asm volatile("" : "+v"(wx[0][i]), "+v"(wx[1][i]));
+        }
         bool bad = false;
         if constexpr (NTW > 0) {
 #pragma unroll
@@ -973,7 +1132,7 @@ struct LinearFq8R2 {
         __syncthreads();
         if (bad) *flag = 1;
         __syncthreads();
-        if (*flag) return true;
+        if ((ABL == 0 || RX) && *flag) return true;
         if constexpr (NTW > 0) {
             constexpr int kRowB = NTW * 32 + 8;
             const uint32_t tbase = l0 + w * (64 * (6 * 32 + 8));
@@ -1010,7 +1169,7 @@ struct LinearFq8R2 {
     }
 };
 
-template <int FX, int FW>
+template <int FX, int FW, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_r2[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1027,7 +1186,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFq8R2<FX, FW>;
+    using L = LinearFq8R2<FX, FW, ABL>;
     bool redo;
     switch (ntw) {                                          // wave-uniform
         case 0: redo = L::template run<0>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
@@ -1146,16 +1305,16 @@ int launch_r_nb(const Args &a, hipStream_t st) {
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
-template <int FX, int FW>
+template <int FX, int FW, int ABL = 0>
 int launch_r2(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFq8R2<FX, FW>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r2_kernel<FX, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r2_kernel<FX, FW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fq8r2_kernel<FX, FW><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fq8r2_kernel<FX, FW, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -1164,14 +1323,30 @@ template <int FX, int FW>
 int launch(const Args &a, hipStream_t st) {
     const char *e_var = getenv("QT_FQ8_VARIANT");            // 1: raw bf16 weight tiles by LDS-DMA, 2: weights converted in registers
     const int variant = e_var ? atoi(e_var) : 2;
+    // two weight register sets (LinearFq8R::W2, a weight request has two steps to land): the widest tiles, where it measured 2 - 6 % faster;
+    // QT_FQ8_W2=0 keeps one set
+    static const bool w2 = !(getenv("QT_FQ8_W2") && atoi(getenv("QT_FQ8_W2")) == 0);
     if (a.pair) {
         if (a.nb <= 2) return launch_r_nb<FX, FW, 2, true>(a, st);
         if (a.nb <= 4) return launch_r_nb<FX, FW, 4, true>(a, st);
+        if (w2) return launch_r_nb<FX, FW, 6, true, 20>(a, st);
         return launch_r_nb<FX, FW, 6, true>(a, st);
     }
     if (variant == 2) {
         const char *e_r2 = getenv("QT_FQ8_R2");              // 0: narrow tiles keep one k tile per step
-        if (a.nb <= 2 && a.K % (2 * kBK) == 0 && !(e_r2 && atoi(e_r2) == 0)) return launch_r2<FX, FW>(a, st);
+        if (a.nb <= 2 && a.K % (2 * kBK) == 0 && !(e_r2 && atoi(e_r2) == 0)) {
+            if constexpr (FX == 0 && FW == 0) {
+                const char *e_ra = getenv("QT_FQ8_R2_ABLATE");       // timing experiments: results are garbage (30: variant RX, exact)
+                switch (e_ra ? atoi(e_ra) : 0) {
+                    case 30: return launch_r2<0, 0, 30>(a, st);
+                    case 2: return launch_r2<0, 0, 2>(a, st);
+                    case 3: return launch_r2<0, 0, 3>(a, st);
+                    case 5: return launch_r2<0, 0, 5>(a, st);
+                    default: break;
+                }
+            }
+            return launch_r2<FX, FW>(a, st);
+        }
         if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
         if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
         if constexpr (FX == 0 && FW == 0) {
@@ -1185,9 +1360,14 @@ int launch(const Args &a, hipStream_t st) {
                 case 6: return launch_r_nb<0, 0, 6, false, 6>(a, st);     // barriers only
                 case 7: return launch_r_nb<0, 0, 6, false, 7>(a, st);     // transport probe: weights by LDS-DMA (raw, unconverted)
                 case 8: return launch_r_nb<0, 0, 6, false, 8>(a, st);     // the same without the activation DMA
+                case 9: return launch_r_nb<0, 0, 6, false, 9>(a, st);     // bare transport: activation DMA only (no weights, no fragment reads, no multiplications)
+                case 10: return launch_r_nb<0, 0, 6, false, 10>(a, st);   // bare transport: weight DMA only
+                case 11: return launch_r_nb<0, 0, 6, false, 11>(a, st);   // bare transport: both by DMA
+                case 20: return launch_r_nb<0, 0, 6, false, 20>(a, st);   // two weight register sets (see LinearFq8R::W2)
                 default: break;
             }
         }
+        if (w2) return launch_r_nb<FX, FW, 6, false, 20>(a, st);
         return launch_r_nb<FX, FW, 6>(a, st);
     }
     if (a.nb <= 2) return launch_nb<FX, FW, 2>(a, st);

@@ -168,7 +168,10 @@ def main():
     # other window lengths and the 13B widths: where does the fused kernel beat the pair?
     sweep = [(512, [11008], 4096), (2048, [11008], 4096), (2048, [4096], 4096), (4096, [4096], 4096), (1024, [13824], 5120), (1024, [5120], 13824),
              (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120), (1024, [8192], 4096), (1024, [6144], 4096), (256, [11008], 4096)]
-    shapes = {"llama": llama, "bert": bert, "all": llama + bert, "probe": probe, "sweep": sweep}[args.shapes]
+    if "x" in args.shapes:      # custom: "1024x4096x5504,1024x4096x11008"
+        shapes = [(int(m), [int(n)], int(k)) for m, n, k in (t.split("x") for t in args.shapes.split(","))]
+    else:
+        shapes = {"llama": llama, "bert": bert, "all": llama + bert, "probe": probe, "sweep": sweep}[args.shapes]
     for (M, Ns, K) in shapes:
         bench(M, Ns, K, args.iters)
     print("ALL CHECKS", "PASSED" if ok else "FAILED")
