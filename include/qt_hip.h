@@ -345,6 +345,11 @@ int qt_attention_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uin
                          uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
                          long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut_dev,
                          const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
+/* The same at unit scale without an observer, with the CONSUMER's input fake-quantizer (the output projection's hook,
+ * quantize.py:128-140) applied to the result as well when it is the probabilities' stateless format: out = fmt(attention output). */
+int qt_attention_fq_out_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, const uint16_t *mask_dev,
+                             uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh, long mask_sq,
+                             float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 
 /* ---- section 8(f).2: block-scaled (microscaling) GEMMs on the scaled matrix instruction ---------------------
  * Replaces linear_mx / matmul_mx (decomposed.py:304-363: operand * expand(block scale) twice, then F.linear /

@@ -47,6 +47,8 @@ struct AttnArgs {
     const float *scale;
     uint32_t *amax;
     int p8;                   // probabilities' format is exactly E4M3 (1) / E5M2 (2) at unit scale: hardware conversion
+    int out_fq;               // 1: the consumer's (output projection's input) fake-quantizer is the probabilities' stateless format at unit
+                              // scale and is applied to the result on its way out (qt_attention_fq_out_bf16)
 };
 
 __device__ __forceinline__ float bf16_round(float f) { return qt_u2f(pack_bf16x2(f, 0.0f) << 16); }
@@ -379,7 +381,11 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
         if (qo >= a.Sq) continue;
         uint16_t *dst = a.out + (((long)b * a.Sq + qo) * a.H + h) * D + qc;
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) dst[dt * 16] = (uint16_t)pack_bf16x2(o[dt][r], 0.0f);
+        for (int dt = 0; dt < D / 16; ++dt) {
+            uint32_t v = pack_bf16x2(o[dt][r], 0.0f);
+            if (a.out_fq) v = rnd(v << 16) >> 16;
+            dst[dt * 16] = (uint16_t)v;
+        }
     }
     if constexpr (OBS) {
         // rows past Sq were clamped duplicates of a valid row: they cannot raise the max
@@ -414,10 +420,10 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int qt_attention_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
-                                    uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
-                                    long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut,
-                                    const float *scale, uint32_t *amax, void *stream) {
+static int attention_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
+                               uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
+                               long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut,
+                               const float *scale, uint32_t *amax, int out_fq, void *stream) {
     if (B == 0 || H == 0 || Sq == 0) return QT_OK;
     if (!q || !k || !v || !out || !fmt || B < 0 || H < 1 || Sq < 0 || Sk < 1 || (long)B * H > 65535) return QT_ERR_BAD_ARG;
     if ((D != 64 && D != 128) || (Sk & 3)) return QT_ERR_BAD_ARG;
@@ -430,7 +436,21 @@ extern "C" int qt_attention_fq_bf16(const uint16_t *q, const uint16_t *k, const 
         if (fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f) p8 = 1;
         else if (fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f) p8 = 2;
     }
-    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8};
+    if (out_fq && (scale || fmt->kind == QT_FMT_IDENTITY)) return QT_ERR_BAD_ARG;      // unit scale, a real format
+    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8, out_fq};
     hipStream_t st = (hipStream_t)stream;
     return D == 128 ? launch_attn<128>(a, st) : launch_attn<64>(a, st);
+}
+
+extern "C" int qt_attention_fq_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
+                                    uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
+                                    long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut,
+                                    const float *scale, uint32_t *amax, void *stream) {
+    return attention_fq_launch(q, k, v, mask, out, B, H, Sq, Sk, D, mask_sb, mask_sh, mask_sq, scaling, fmt, lut, scale, amax, 0, stream);
+}
+
+extern "C" int qt_attention_fq_out_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
+                                        uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
+                                        long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut, void *stream) {
+    return attention_fq_launch(q, k, v, mask, out, B, H, Sq, Sk, D, mask_sb, mask_sh, mask_sq, scaling, fmt, lut, nullptr, nullptr, 1, stream);
 }

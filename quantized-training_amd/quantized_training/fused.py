@@ -1209,6 +1209,22 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
         STATS.add(B * H * Q * C)
     else:
         fmt, lut, scale_ptr, amax_ptr = _IDENTITY, None, None, None
+    # table formats: the output projection's stateless input fake-quantizer of the SAME format rides on the kernel's epilogue (its hook
+    # then hands the result through: fake_quantize.expect_prequantized)
+    fq_o = None
+    if (table_p and scale_ptr is None and amax_ptr is None and (fmt.p1 & 1) and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0"
+            and os.environ.get("QT_FUSED_PRODUCER_MAP", "1") != "0"):
+        from .model_fusions import consumer_fq_map
+        proj = getattr(attn, "o_proj", None) or attn.__dict__.get("_qt_out_proj")
+        cand = consumer_fq_map(proj) if proj is not None else None
+        if cand is not None and cand.dtype == fq_p.dtype:
+            fq_o = cand
+    if fq_o is not None:
+        _native.check(L.qt_attention_fq_out_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                                 out.data_ptr(), B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut, st),
+                      "qt_attention_fq_out_bf16")
+        fq_o.expect_prequantized(out, None)
+        return out
     _native.check(L.qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(),
                                          mask.data_ptr() if mask is not None else None, out.data_ptr(),
                                          B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut,

@@ -240,6 +240,15 @@ class PreparedAttention(nn.Module):
         out = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=q.device)
         _FQ_STATS.add(B * H * S * S)                          # fq_p, inside the kernel
         fq_p.__dict__["_qt_calls"] = fq_p.__dict__.get("_qt_calls", 0) + 1
+        proj = self.__dict__["_qt_out_proj"]
+        fq_o = mf.consumer_fq_map(proj) if proj is not None else None
+        if fq_o is not None and fq_o.dtype == fq_p.dtype and _table_ok(fq_o):
+            # the output projection's input fake-quantizer (same format) on the kernel's epilogue; its node hands the result through
+            _native.check(_native.lib().qt_attention_fq_out_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), m.data_ptr() if m is not None else None,
+                                                                 out.data_ptr(), B, H, S, S, D, msb, msh, msq, self.scaling, ctypes.byref(fmt),
+                                                                 qmap.data_ptr(), _stream_ptr(q)), "qt_attention_fq_out_bf16")
+            fq_o.expect_prequantized(out, None)
+            return out.reshape(B, S, H * D)
         _native.check(_native.lib().qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), m.data_ptr() if m is not None else None,
                                                          out.data_ptr(), B, H, S, S, D, msb, msh, msq, self.scaling, ctypes.byref(fmt),
                                                          qmap.data_ptr(), None, None, _stream_ptr(q)), "qt_attention_fq_bf16")

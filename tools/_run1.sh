@@ -1,7 +1,10 @@
 mkdir -p gpurun_out
 (
-echo "== RX checks"; QT_FQ8_R2_ABLATE=30 timeout 300 python tools/exp_linear_fq8.py --iters 40 --shapes 1024x4096x11008,1024x4096x4096,1024x4096x4224 2>&1 | grep -E "exact x=e4m3 w=e4m3|accuracy|CHECKS|bench" | cut -c1-120
-echo "== default"; python tools/exp_linear_fq8.py --skip-checks --iters 40 --shapes 1024x4096x11008,1024x4096x4096,1024x4096x4224 2>&1 | grep bench | cut -c1-100
-echo "== RX again"; QT_FQ8_R2_ABLATE=30 timeout 300 python tools/exp_linear_fq8.py --skip-checks --iters 40 --shapes 1024x4096x11008,1024x4096x4096,1024x4096x4224 2>&1 | grep bench | cut -c1-100
-) > gpurun_out/fq8_rx.log 2>&1
-cat gpurun_out/fq8_rx.log
+python -m pytest tests/test_gpu_models.py -x -q -k "table_format or pt2e_prepared_route_table" 2>&1 | grep -E "^E |passed|failed|Error" | head
+python -m pytest tests/test_gpu_parity.py -x -q -k "attention" 2>&1 | tail -2
+echo "== 13B posit8_2 eager"; python bench.py --workload llama-13b-posit8_2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['mean_window_nll'], d['config']['fake_quant_calls_per_step'], d['config']['elements_per_step'])"
+echo "== 13B posit8_2 eager, QT_FUSED_PRODUCER_MAP=0"; QT_FUSED_PRODUCER_MAP=0 python bench.py --workload llama-13b-posit8_2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['mean_window_nll'], d['config']['fake_quant_calls_per_step'], d['config']['elements_per_step'])"
+) > gpurun_out/attn_out.log 2>&1
+cat gpurun_out/attn_out.log
