@@ -64,9 +64,25 @@ __device__ __forceinline__ uint32_t encode_exact(float v, int ebits, int mbits, 
 }
 
 // PACK_BITS: 0 = no packed operand, else the element width (8 / 6 / 4) -- compile-time so the packing is straight-line.
-template <int IO, bool LDS_TABLE, int PACK_BITS>
+// ROWS: the value map in its row form (qt_format.p1 bit 0: the row words of qt_build_rowparams behind the map's 65 536 entries; csrc/qt_device.h
+// Rounder<kFmtRows>): arithmetic against a 4 - 8 KiB row table in LDS instead of table gathers, at 256-thread occupancy.
+template <int IO, bool LDS_TABLE, int PACK_BITS, bool ROWS = false>
 __global__ __launch_bounds__(LDS_TABLE ? 1024 : 256) void quantize_mx_kernel(MxQuantArgs a) {
     constexpr int kThreads = LDS_TABLE ? 1024 : 256;
+    static_assert(!(LDS_TABLE && ROWS), "one or the other");
+    Rounder<kFmtRows> rnd{a.fmt, nullptr, a.lut};
+    if constexpr (ROWS) {
+        __shared__ uint4 s_rows[512];
+        const uint4 *gr = (const uint4 *)(a.lut + QT_MAP_ENTRIES);
+        const int nrows = (a.fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += kThreads) s_rows[i] = gr[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        __syncthreads();
+    }
+    auto look = [&](uint32_t img) __attribute__((always_inline)) -> uint32_t {      // image of map[x]
+        if constexpr (ROWS) return rnd(img);
+        else return a.lut ? (uint32_t)a.lut[img >> 16] << 16 : qt_apply_format_img(a.fmt, img);
+    };
     if constexpr (LDS_TABLE) {
         extern __shared__ __attribute__((aligned(16))) uint16_t s_table[];
         const uint4 *src = (const uint4 *)a.lut;
@@ -141,12 +157,12 @@ __global__ __launch_bounds__(LDS_TABLE ? 1024 : 256) void quantize_mx_kernel(MxQ
                 const float x0 = qt_u2f(w[j] << 16), x1 = qt_u2f(w[j] & 0xFFFF0000u);
                 const uint32_t p = recip_ok ? pack_bf16x2(x0 * r, x1 * r) : pack_bf16x2(x0 / s, x1 / s);
                 const uint32_t i0 = p << 16, i1 = p & 0xFFFF0000u;
-                qv[2 * j] = qt_u2f(a.lut ? (uint32_t)a.lut[i0 >> 16] << 16 : qt_apply_format_img(a.fmt, i0));
-                qv[2 * j + 1] = qt_u2f(a.lut ? (uint32_t)a.lut[i1 >> 16] << 16 : qt_apply_format_img(a.fmt, i1));
+                qv[2 * j] = qt_u2f(look(i0));
+                qv[2 * j + 1] = qt_u2f(look(i1));
             } else {
                 const float x0 = qt_u2f(w[j]);
                 const uint32_t img = qt_fold_img(qt_f2u(recip_ok ? x0 * r : x0 / s));
-                qv[j] = qt_u2f(a.lut ? (uint32_t)a.lut[img >> 16] << 16 : qt_apply_format_img(a.fmt, img));
+                qv[j] = qt_u2f(look(img));
             }
         }
         if (!live) continue;
@@ -252,11 +268,16 @@ int launch(const void *x, void *q, void *sf, uint8_t *codes, uint8_t *e8m0, size
     MxQuantArgs a{(const uint4 *)x, (uint4 *)q, sf, codes, e8m0, rows * cols / kPer, bs / kPer, 32 / kPer, *fmt,
                   fmt->kind == QT_FMT_LUT ? lut : nullptr, scale_lut, quant_max, qe - 1, pow2, pack_fmt};
     const int pb = codes ? qt_mx::elem_bits(pack_fmt) : 0;
-    const bool lds = a.lut && rows * cols >= ((size_t)1 << 22) && (((uintptr_t)a.lut) & 15u) == 0;
+    static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;
+    const bool rowform = a.lut && (fmt->p1 & 1) && row_mode && (((uintptr_t)a.lut) & 15u) == 0;
+    const bool lds = !rowform && a.lut && rows * cols >= ((size_t)1 << 22) && (((uintptr_t)a.lut) & 15u) == 0;
     hipStream_t st = (hipStream_t)stream;
 #define QT_MXQ(PB)                                                                                                 \
     if (pb == PB) {                                                                                                \
-        if (lds) {                                                                                                 \
+        if (rowform) {                               /* (8 workgroups per CU measured slower: 3.6 against 4.4 TB/s) */     \
+            size_t want = (a.nvec + 255) / 256, cap = (size_t)num_cus() * 32;                                      \
+            quantize_mx_kernel<IO, false, PB, true><<<(unsigned)(want < cap ? want : cap), 256, 0, st>>>(a);       \
+        } else if (lds) {                                                                                              \
             static bool configured = false;                                                                        \
             if (!configured) {                                                                                     \
                 const hipError_t e = hipFuncSetAttribute((const void *)quantize_mx_kernel<IO, true, PB>,           \

@@ -232,7 +232,8 @@ def _quantize_mx_hip_or_none(input, qmap, axes, block_size, quant_max, pow2, sca
         fid = mx_gemm.FMT_ID[fmt_name]
         codes = torch.empty((rows, cols * mx_gemm._BITS[fid] // 8), dtype=torch.uint8, device=x.device)
         e8 = torch.empty((rows, cols // 32), dtype=torch.uint8, device=x.device)
-    fmt = _lut_format()
+    from .fake_quantize import _launch_format
+    fmt = _launch_format(_lut_format(), qmap)                # the row form behind the map, when this is a map from _device_map
     fn = L.qt_quantize_mx_bf16 if x.dtype == torch.bfloat16 else L.qt_quantize_mx_f32
     _native.check(fn(x.data_ptr(), q.data_ptr(), sf.data_ptr(), codes.data_ptr() if codes is not None else None,
                      e8.data_ptr() if e8 is not None else None, rows, cols, block_size, ctypes.byref(fmt), qmap.data_ptr(),
