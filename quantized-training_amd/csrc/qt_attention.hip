@@ -25,6 +25,7 @@
 // needs next (saves the transpose copy).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qt_device.h"
 
@@ -47,6 +48,7 @@ struct AttnArgs {
     const float *scale;
     uint32_t *amax;
     int p8;                   // probabilities' format is exactly E4M3 (1) / E5M2 (2) at unit scale: hardware conversion
+    int snake;                // > 0: workgroups dealt to `snake` slots by descending work, alternating direction (see the kernel)
     int out_fq;               // 1: the consumer's (output projection's input) fake-quantizer is the probabilities' stateless format at unit
                               // scale and is applied to the result on its way out (qt_attention_fq_out_bf16)
 };
@@ -69,8 +71,21 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     // and the light ones mirror them: with every workgroup resident at once and round-robin placement, the two
     // workgroups a CU receives (indices c and c + total/2) then hold nq + 1 live tiles between them instead of up to 2 nq
     const int BH = a.B * a.H, nq = (a.Sq + kBQ - 1) / kBQ;
-    const int kq = blockIdx.x / BH, bh = blockIdx.x % BH;
-    const int qb = kq < nq / 2 ? nq - 1 - kq : kq - nq / 2;
+    int kq, bh, qb;
+    if (a.snake > 0) {
+        // the general form of the same idea (the launch fits the chip all at once, workgroup i lands on slot i mod CUs): list the
+        // workgroups by descending work (query block nq - 1 first) and deal them to the slots forwards, backwards, forwards, ... so
+        // that a slot's workgroups add up alike for any head count -- 40 heads x 16 blocks on 256 CUs: 24 live tiles at most per
+        // slot instead of 31 (average 21)
+        const int total = nq * BH, round = (int)blockIdx.x / a.snake, pos = (int)blockIdx.x % a.snake;
+        const int len = min(a.snake, total - round * a.snake);
+        const int idx = round * a.snake + ((round & 1) ? len - 1 - pos : pos);
+        qb = nq - 1 - idx / BH;
+        bh = idx % BH;
+    } else {
+        kq = blockIdx.x / BH; bh = blockIdx.x % BH;
+        qb = kq < nq / 2 ? nq - 1 - kq : kq - nq / 2;
+    }
     const int b = bh / a.H, h = bh % a.H;
     const int q0 = qb * kBQ + wave * 16;
     const int qrow = q0 + qc;
@@ -437,7 +452,14 @@ static int attention_fq_launch(const uint16_t *q, const uint16_t *k, const uint1
         else if (fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f) p8 = 2;
     }
     if (out_fq && (scale || fmt->kind == QT_FMT_IDENTITY)) return QT_ERR_BAD_ARG;      // unit scale, a real format
-    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8, out_fq};
+    // causal-style masks make late query blocks heavier: balance the slots when the grid is not a multiple that the mirrored order
+    // already serves (QT_ATTN_SNAKE=0 keeps the mirrored order)
+    static const int snake_mode = getenv("QT_ATTN_SNAKE") ? atoi(getenv("QT_ATTN_SNAKE")) : 1;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long total = (long)((Sq + kBQ - 1) / kBQ) * B * H;
+    const int snake = (snake_mode && mask && total > cus && total % (2L * cus) != 0) ? cus : 0;
+    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8, snake, out_fq};
     hipStream_t st = (hipStream_t)stream;
     return D == 128 ? launch_attn<128>(a, st) : launch_attn<64>(a, st);
 }
