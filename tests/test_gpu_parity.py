@@ -1255,6 +1255,46 @@ def test_table_format_producers_equal_kernel_then_pass(nv, dtype):
         assert same(fqs[0](qp), qm) and same(fqs[1](kp), km) and fqs[0](qm) is qm and fqs[1](km) is km
 
 
+def test_table_format_producers_edge_shapes(nv):
+    """The row-form producer kernels at the edges of what they take: one row, the narrowest and the widest rows (8 and 16 384 columns),
+    fewer key heads than query heads in the rotary kernel, batch-shared tables, a token count that does not fill a workgroup; and what
+    they refuse (no row form behind the map, misaligned buffers) comes back as an error code, not as a launch."""
+    import quantized_training as qt
+    from quantized_training import model_fusions as mf
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize, _launch_format
+    g = torch.Generator(device="cuda").manual_seed(8)
+    fq = FusedAmaxObsFakeQuantize(dtype="posit8_1").cuda()
+    same = lambda a, b: torch.equal(a.contiguous().view(torch.int16), b.contiguous().view(torch.int16))  # noqa: E731
+    with torch.no_grad():
+        for rows, cols in ((1, 8), (3, 16384), (257, 24), (5, 4096)):
+            x = (torch.randn(rows, cols, device="cuda", generator=g) * 4).bfloat16()
+            r = torch.randn(rows, cols, device="cuda", generator=g).bfloat16()
+            w = (1 + 0.1 * torch.randn(cols, device="cuda", generator=g)).bfloat16()
+            total, y = mf.rmsnorm_map(x, r, w, 1e-6, [fq])
+            assert same(total, x + r) and same(y, fq(mf.rmsnorm(x + r, w, 1e-6))), (rows, cols)
+            assert same(mf.silu_mul_map(x, r, fq), fq(mf.silu_mul(x, r))), (rows, cols)
+        B, S, Hq, Hk, D = 3, 5, 8, 2, 64
+        q = torch.randn(B, S, Hq * D, device="cuda", generator=g).bfloat16().view(B, S, Hq, D).transpose(1, 2)
+        k = torch.randn(B, S, Hk * D, device="cuda", generator=g).bfloat16().view(B, S, Hk, D).transpose(1, 2)
+        ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+        cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+        qp, kp = mf.rope(q, k, cos, sin)
+        qm, km = mf.rope_map(q, k, cos, sin, fq, fq)
+        assert km.shape == (B, Hk, S, D) and same(fq(qp), qm) and same(fq(kp), km)
+    # refusals
+    L = nv.lib()
+    plain = nv.format_for("posit8_1")                       # p1 == 0: no row words announced
+    m = qt.get_quantization_map("posit8_1", torch.device("cuda"))
+    x = torch.zeros(4, 64, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty_like(x)
+    w = torch.ones(64, dtype=torch.bfloat16, device="cuda")
+    assert L.qt_rmsnorm_map_bf16(x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), 4, 64, 1e-6, ctypes.byref(plain), m.data_ptr(), 0, stream()) == nv.QT_ERR_BAD_ARG
+    rows = _launch_format(plain, m)
+    assert L.qt_rmsnorm_map_bf16(x.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), 4, 60, 1e-6, ctypes.byref(rows), m.data_ptr(), 0, stream()) == nv.QT_ERR_UNALIGNED
+    assert L.qt_silu_mul_map_bf16(x.data_ptr() + 2, x.data_ptr(), y.data_ptr(), 4, 56, 64, 64, ctypes.byref(rows), m.data_ptr(), stream()) == nv.QT_ERR_UNALIGNED
+    assert L.qt_rmsnorm_map_bf16(x.data_ptr(), x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 4, 64, 1e-6, ctypes.byref(rows), m.data_ptr(), 0, stream()) == nv.QT_ERR_BAD_ARG
+
+
 @pytest.mark.parametrize("B,S,V,stride", [(1, 1024, 32000, 32000), (3, 37, 1003, 1008), (2, 5, 8, 8)])
 def test_causal_lm_loss_from_bf16_logits(nv, B, S, V, stride):
     """qt_causal_lm_loss_bf16 == cross_entropy(logits.float()[:, :-1], labels[:, 1:], ignore_index=-100) (transformers' ForCausalLMLoss):

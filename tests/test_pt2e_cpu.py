@@ -334,9 +334,9 @@ def test_outlier_spec_lowering_matches_reference():
 
 
 # ---- fusion pass for prepared graphs (pt2e_fusion.py): the rewrite changes launches, never values ------------------------------
-def _tiny_llama_prepared(spec, layers=2):
+def _tiny_llama_prepared(spec, layers=2, kv_heads=2):
     from transformers import LlamaConfig, LlamaForCausalLM
-    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=2, num_key_value_heads=2,
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=2, num_key_value_heads=kv_heads,
                       vocab_size=512, max_position_embeddings=256, attn_implementation="eager")
     torch.manual_seed(0)
     model = LlamaForCausalLM(cfg).bfloat16().eval()
@@ -402,3 +402,17 @@ def test_fusion_leaves_unrecognised_chains_alone():
     assert counts["linear"] == 2 and counts["attention"] == 0 and counts["mlp"] == 0
     for _ in range(3):                                      # observers evolve identically
         assert torch.equal(g1(x), g2(x))
+
+
+def test_fusion_on_a_grouped_query_model_keeps_what_it_does_not_recognise():
+    """Grouped-query attention (one key / value head for two query heads) puts a repeat_kv chain between the rotary embedding and the
+    matmuls: the attention pattern does not match and stays node for node, everything else is rewritten, and the graph still computes
+    bit for bit what the plain one does."""
+    from quantized_training import pt2e_fusion
+    gm, ids = _tiny_llama_prepared("e4m3", kv_heads=1)
+    with torch.no_grad():
+        want = gm(ids, labels=ids.clone(), use_cache=False)
+        counts = pt2e_fusion.fuse_prepared_graph(gm)
+        assert counts["attention"] == 0 and counts["linear"] == 15 and counts["mlp"] == 2 and counts["add_rmsnorm"] == 4 and counts["loss"] == 1
+        got = gm(ids, labels=ids.clone(), use_cache=False)
+    assert torch.equal(got.logits, want.logits) and torch.equal(got.loss, want.loss)
