@@ -1620,7 +1620,10 @@ def test_linear_fq8_weight_codes_are_the_value_map(nv, xdtype, wdtype):
 @pytest.mark.parametrize("M,Ns,K", [(1024, [4096], 1024), (1024, [176], 256), (300, [48, 64, 16], 384), (1, [16], 128),
                                     (777, [2048, 512, 512], 512), (520, [11008], 256), (257, [208, 4096 - 208], 128),
                                     # BASELINE.json's full LLaMA-2-7B sizes: gate / up, down (two k tiles per step), q / k / v
-                                    (1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096, 4096, 4096], 4096)])
+                                    (1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096, 4096, 4096], 4096),
+                                    # BERT-base batch [16, 384] and the LLaMA-2-13B widths (shapes the route table sends to the pair by default:
+                                    # the fused kernel must be right there too, it is what QT_FQ8_GEMM=1 and the tuner run)
+                                    (6144, [768], 768), (6144, [3072], 768), (1024, [13824], 5120), (1024, [5120], 13824)])
 @pytest.mark.parametrize("xdtype,wdtype", [("e4m3", "e4m3"), ("e5m2", "e4m3")])
 def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     """Ragged M, column tiles spanning two weights, several weights per launch, bias: against the fp64 product of the
