@@ -347,6 +347,15 @@ int qt_attention_fq_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uin
                          const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
 /* The same at unit scale without an observer, with the CONSUMER's input fake-quantizer (the output projection's hook,
  * quantize.py:128-140) applied to the result as well when it is the probabilities' stateless format: out = fmt(attention output). */
+/* Both of the above (out_fq = 0 / 1; scale_dev / amax_bits_dev as in qt_attention_fq_bf16, both NULL with out_fq) with the mask's row
+ * extents (qt_mask_row_live_checked: row_live_dev, strides in rows for (b, h, q), and its device flag): when the flag says every mask
+ * row is "zeros, then the bf16 minimum" (causal masks, right padding) the kernel derives the mask values and the dead key tiles from
+ * the extents and does not read the mask at all.  Same results bit for bit. */
+int qt_attention_fq_live_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, const uint16_t *mask_dev,
+                              uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh, long mask_sq,
+                              float scaling, const qt_format *fmt, const uint16_t *lut_dev, const float *scale_dev,
+                              uint32_t *amax_bits_dev, int out_fq, const int *row_live_dev, long live_sb, long live_sh, long live_sq,
+                              const int *mask_irregular_dev, void *stream);
 int qt_attention_fq_out_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, const uint16_t *mask_dev,
                              uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh, long mask_sq,
                              float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream);

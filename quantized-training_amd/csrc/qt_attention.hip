@@ -48,6 +48,10 @@ struct AttnArgs {
     const float *scale;
     uint32_t *amax;
     int p8;                   // probabilities' format is exactly E4M3 (1) / E5M2 (2) at unit scale: hardware conversion
+    const int *row_live;      // optional (qt_mask_row_live_checked): one past the last unmasked column per mask row; strides in rows
+    long lsb, lsh, lsq;
+    const int *mask_irregular;// device flag behind it: 0 = every mask row is exactly "zeros, then the bf16 minimum" -- the mask is then
+                              // not read at all: its value at column c of a row is (c < row_live ? 0 : minimum)
     int snake;                // > 0: workgroups dealt to `snake` slots by descending work, alternating direction (see the kernel)
     int out_fq;               // 1: the consumer's (output projection's input) fake-quantizer is the probabilities' stateless format at unit
                               // scale and is applied to the result on its way out (qt_attention_fq_out_bf16)
@@ -94,6 +98,8 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     const uint16_t *Kp = a.k + (long)bh * a.Sk * D;
     const uint16_t *Vp = a.v + (long)bh * a.Sk * D;
     const uint16_t *Mp = a.mask ? a.mask + b * a.mask_sb + h * a.mask_sh + (long)qload * a.mask_sq : nullptr;
+    const bool simple = a.mask && a.row_live && a.mask_irregular && *a.mask_irregular == 0;      // uniform over the launch
+    const int lv = simple ? a.row_live[b * a.lsb + h * a.lsh + (long)qload * a.lsq] : 0;          // this lane's query row
 
     Rounder<KIND> rnd{a.fmt, a.lut};
     if constexpr (KIND == kFmtRows) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     uint2 mk0, mk1, mk2, mk3;
     mk0 = mk1 = mk2 = mk3 = uint2{0u, 0u};
     auto load_mask = [&](int k0) __attribute__((always_inline)) {
-        if (Mp) {           // Sk % 4 == 0 (checked on the host): a group of 4 keys is entirely inside or outside
+        if (Mp && !simple) {           // Sk % 4 == 0 (checked on the host): a group of 4 keys is entirely inside or outside
             const int kb = k0 + g * 4;
             mk0 = *(const uint2 *)(Mp + (kb + 4 <= a.Sk ? kb : a.Sk - 4));
             mk1 = *(const uint2 *)(Mp + (kb + 20 <= a.Sk ? kb + 16 : a.Sk - 4));
@@ -222,8 +228,13 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kbase = k0 + j * 16 + g * 4;
-            const float mv[4] = {qt_u2f(mk[j].x << 16), qt_u2f(mk[j].x & 0xFFFF0000u), qt_u2f(mk[j].y << 16),
-                                 qt_u2f(mk[j].y & 0xFFFF0000u)};
+            float mv[4] = {qt_u2f(mk[j].x << 16), qt_u2f(mk[j].x & 0xFFFF0000u), qt_u2f(mk[j].y << 16),
+                           qt_u2f(mk[j].y & 0xFFFF0000u)};
+            if (simple) {
+                const float mn = qt_u2f(0xFF7F0000u);        // the bf16 minimum, what the mask holds from the row's extent on
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mv[r] = kbase + r < lv ? 0.0f : mn;
+            }
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {                   // two scores per packed conversion
                 uint32_t w = pack_bf16x2(acc[j][r], acc[j][r + 1]);                                         // matmul output, bf16
@@ -241,7 +252,20 @@ __global__ __launch_bounds__(256) void attention_fq_kernel(AttnArgs a) {
     // the result (a row with NO unmasked key at all, which torch turns into a uniform row) is detected after
     // pass 1 and the whole thing is redone without skipping.
     unsigned long long live = ~0ull;
-    if (a.mask && ntiles <= 64) {
+    if (simple && ntiles <= 64) {
+        // tiles at or beyond the largest extent of the workgroup's 64 rows are dead for all of them (an extent of 0 is a row without any
+        // unmasked key: it keeps every tile alive, and the "row masked everywhere" redo below is what serves it)
+        int mx = (qrow < a.Sq) ? (lv <= 0 ? a.Sk : lv) : 0;
+        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        int *s_mx = (int *)lds;                                              // LDS is not in use yet
+        if (lane == 0) s_mx[wave] = mx;
+        __syncthreads();
+        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        __syncthreads();
+        const int nlive = min(ntiles, (mx + kBK - 1) / kBK);
+        live = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1ull);
+        if (nlive == ntiles) live = ~0ull;
+    } else if (a.mask && ntiles <= 64) {
         live = 0ull;
         const int qr = qb * kBQ + (tid >> 2);
         const uint16_t *mrow = a.mask + b * a.mask_sb + h * a.mask_sh + (long)(qr < a.Sq ? qr : a.Sq - 1) * a.mask_sq;
@@ -438,7 +462,8 @@ int launch_attn(const AttnArgs &a, hipStream_t st) {
 static int attention_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
                                uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
                                long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut,
-                               const float *scale, uint32_t *amax, int out_fq, void *stream) {
+                               const float *scale, uint32_t *amax, int out_fq, void *stream, const int *row_live = nullptr,
+                               long lsb = 0, long lsh = 0, long lsq = 0, const int *irregular = nullptr) {
     if (B == 0 || H == 0 || Sq == 0) return QT_OK;
     if (!q || !k || !v || !out || !fmt || B < 0 || H < 1 || Sq < 0 || Sk < 1 || (long)B * H > 65535) return QT_ERR_BAD_ARG;
     if ((D != 64 && D != 128) || (Sk & 3)) return QT_ERR_BAD_ARG;
@@ -459,7 +484,9 @@ static int attention_fq_launch(const uint16_t *q, const uint16_t *k, const uint1
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const long total = (long)((Sq + kBQ - 1) / kBQ) * B * H;
     const int snake = (snake_mode && mask && total > cus && total % (2L * cus) != 0) ? cus : 0;
-    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8, snake, out_fq};
+    if ((row_live != nullptr) != (irregular != nullptr) || (row_live && !mask)) return QT_ERR_BAD_ARG;
+    AttnArgs a{q, k, v, mask, out, B, H, Sq, Sk, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, p8,
+               row_live, lsb, lsh, lsq, irregular, snake, out_fq};
     hipStream_t st = (hipStream_t)stream;
     return D == 128 ? launch_attn<128>(a, st) : launch_attn<64>(a, st);
 }
@@ -469,6 +496,15 @@ extern "C" int qt_attention_fq_bf16(const uint16_t *q, const uint16_t *k, const 
                                     long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut,
                                     const float *scale, uint32_t *amax, void *stream) {
     return attention_fq_launch(q, k, v, mask, out, B, H, Sq, Sk, D, mask_sb, mask_sh, mask_sq, scaling, fmt, lut, scale, amax, 0, stream);
+}
+
+extern "C" int qt_attention_fq_live_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,
+                                         uint16_t *out, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh,
+                                         long mask_sq, float scaling, const qt_format *fmt, const uint16_t *lut, const float *scale,
+                                         uint32_t *amax, int out_fq, const int *row_live, long live_sb, long live_sh, long live_sq,
+                                         const int *mask_irregular, void *stream) {
+    return attention_fq_launch(q, k, v, mask, out, B, H, Sq, Sk, D, mask_sb, mask_sh, mask_sq, scaling, fmt, lut, scale, amax, out_fq, stream,
+                               row_live, live_sb, live_sh, live_sq, mask_irregular);
 }
 
 extern "C" int qt_attention_fq_out_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask,

@@ -90,6 +90,8 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_float, _P]),
     "qt_softmax_fq_bf16_fp8_live": (c_int, [_P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, c_long, c_long,
                                             c_long, _P]),
+    "qt_attention_fq_live_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_float, _FMT, _P, _P, _P,
+                                         c_int, _P, c_long, c_long, c_long, _P, _P]),
     "qt_attention_fq_out_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_float, _FMT, _P, _P]),
     "qt_attention_fq_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
                                     _FMT, _P, _P, _P, _P]),

@@ -1219,14 +1219,32 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
         cand = consumer_fq_map(proj) if proj is not None else None
         if cand is not None and cand.dtype == fq_p.dtype:
             fq_o = cand
+    launch_attention_fq(L, st, qq, kq, vq, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut, scale_ptr, amax_ptr,
+                        fq_o is not None)
     if fq_o is not None:
+        fq_o.expect_prequantized(out, None)
+    return out
+
+
+def launch_attention_fq(L, st, qq, kq, vq, mask, mask_owner, mask_strides, out, dims, scaling, fmt, lut, scale_ptr, amax_ptr, out_fq):
+    """qt_attention_fq_bf16 / _out_ / _live_: with a mask whose rows are evenly spaced the launch carries the mask's row extents
+    (_mask_row_live: scanned once per mask object), and the kernel does not read a causal / right-padding mask at all."""
+    B, H, Q, C, D = dims
+    msb, msh, msq = mask_strides
+    live = None
+    if mask is not None and mask_owner is not None and os.environ.get("QT_ATTN_ROW_LIVE", "1") != "0":
+        live = _mask_row_live(mask, mask_owner, B, H, Q, C, st)
+    if live is not None:
+        rl, lsb, lsh, lsq = live
+        _native.check(L.qt_attention_fq_live_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), mask.data_ptr(), out.data_ptr(), B, H, Q, C, D,
+                                                  msb, msh, msq, float(scaling), ctypes.byref(fmt), lut, scale_ptr, amax_ptr, int(bool(out_fq)),
+                                                  rl.data_ptr(), lsb, lsh, lsq, rl.data_ptr() + 4 * (rl.numel() - 1), st),
+                      "qt_attention_fq_live_bf16")
+    elif out_fq:
         _native.check(L.qt_attention_fq_out_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), mask.data_ptr() if mask is not None else None,
                                                  out.data_ptr(), B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut, st),
                       "qt_attention_fq_out_bf16")
-        fq_o.expect_prequantized(out, None)
-        return out
-    _native.check(L.qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(),
-                                         mask.data_ptr() if mask is not None else None, out.data_ptr(),
-                                         B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut,
-                                         scale_ptr, amax_ptr, st), "qt_attention_fq_bf16")
-    return out
+    else:
+        _native.check(L.qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                             out.data_ptr(), B, H, Q, C, D, msb, msh, msq, float(scaling), ctypes.byref(fmt), lut,
+                                             scale_ptr, amax_ptr, st), "qt_attention_fq_bf16")

@@ -242,16 +242,13 @@ class PreparedAttention(nn.Module):
         fq_p.__dict__["_qt_calls"] = fq_p.__dict__.get("_qt_calls", 0) + 1
         proj = self.__dict__["_qt_out_proj"]
         fq_o = mf.consumer_fq_map(proj) if proj is not None else None
-        if fq_o is not None and fq_o.dtype == fq_p.dtype and _table_ok(fq_o):
-            # the output projection's input fake-quantizer (same format) on the kernel's epilogue; its node hands the result through
-            _native.check(_native.lib().qt_attention_fq_out_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), m.data_ptr() if m is not None else None,
-                                                                 out.data_ptr(), B, H, S, S, D, msb, msh, msq, self.scaling, ctypes.byref(fmt),
-                                                                 qmap.data_ptr(), _stream_ptr(q)), "qt_attention_fq_out_bf16")
+        if not (fq_o is not None and fq_o.dtype == fq_p.dtype and _table_ok(fq_o)):
+            fq_o = None                                       # else: its node runs its own pass
+        # (with fq_o: the output projection's input fake-quantizer, same format, on the kernel's epilogue; its node hands the result through)
+        fused.launch_attention_fq(_native.lib(), _stream_ptr(q), qq, kq, vq, m, mask, (msb, msh, msq), out, (B, H, S, S, D), self.scaling, fmt,
+                                  qmap.data_ptr(), None, None, fq_o is not None)
+        if fq_o is not None:
             fq_o.expect_prequantized(out, None)
-            return out.reshape(B, S, H * D)
-        _native.check(_native.lib().qt_attention_fq_bf16(qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), m.data_ptr() if m is not None else None,
-                                                         out.data_ptr(), B, H, S, S, D, msb, msh, msq, self.scaling, ctypes.byref(fmt),
-                                                         qmap.data_ptr(), None, None, _stream_ptr(q)), "qt_attention_fq_bf16")
         return out.reshape(B, S, H * D)
 
     def _fused(self, q, k, v, cos, sin, mask):

@@ -715,6 +715,26 @@ def test_fused_attention_kernel(nv, B, H, Sq, Sk, D, mask_kind, pdtype):
     # the observer saw the largest probability BEFORE fake-quantization; the oracle's quantized maximum brackets it
     pmax = float(o.bf16_to_f32(pq).max())
     assert abs(amax.view(torch.float32).item() - pmax) <= 0.07 * pmax
+    if mask is not None:
+        # the same launch with the mask's row extents (qt_mask_row_live_checked): a causal / right-padding mask is then not read at all --
+        # values and dead key tiles come from the extents -- and the result is the same bit for bit; so is it for an irregular mask
+        # (the device flag keeps the kernel on the mask)
+        for irregular in (False, True):
+            mk = mask.clone()
+            if irregular:
+                mk[..., 0, 3] = -1.0
+            mrows = mk.shape[0] * mk.shape[1] * mk.shape[2]
+            rl = torch.empty(mrows + 1, dtype=torch.int32, device="cuda")
+            nv.check(L.qt_mask_row_live_checked(mk.data_ptr(), mrows, Sk, Sk, rl.data_ptr(), rl.data_ptr() + 4 * mrows, stream()), "row_live")
+            assert int(rl[-1]) == int(irregular)
+            lsb, lsq = (mk.shape[2] if mk.shape[0] > 1 else 0), (1 if mk.shape[2] > 1 else 0)
+            ref_o, live_o = torch.empty_like(out), torch.empty_like(out)
+            nv.check(L.qt_attention_fq_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mk.data_ptr(), ref_o.data_ptr(), B, H, Sq, Sk, D, msb, 0, msq,
+                                            scaling, ctypes.byref(fmt), lut.data_ptr(), None, None, stream()), "attention")
+            nv.check(L.qt_attention_fq_live_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mk.data_ptr(), live_o.data_ptr(), B, H, Sq, Sk, D, msb, 0,
+                                                 msq, scaling, ctypes.byref(fmt), lut.data_ptr(), None, None, 0, rl.data_ptr(), lsb, 0, lsq,
+                                                 rl.data_ptr() + 4 * mrows, stream()), "attention live")
+            assert torch.equal(ref_o.view(torch.int16), live_o.view(torch.int16)), (mask_kind, irregular)
     if pdtype == "posit8_1":
         # table formats: with the row form behind the map (qt_format.p1 bit 0) the kernel evaluates the probabilities' fake-quantizer
         # from a row table in LDS instead of gathering from the map -- the same function, so the same output bit for bit
