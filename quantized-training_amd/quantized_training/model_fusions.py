@@ -78,6 +78,26 @@ def _norm_with_consumers(x2, r2, weight, eps, fqs):
     (`_qt_also_done`): their hooks hand those through (fake_quantize.py) instead of launching a pass each over the tensor."""
     cols = x2.shape[-1]
     n = len(fqs)
+    if os.environ.get("QT_NORM_SHARED_CODES", "1") != "0":
+        # the consumers' formats are equal (_norm_consumer_fq checks it), so their codes are the same bytes: ONE evaluation, one code
+        # tensor, shared -- each consumer's call is still handed through and counted (8 MB less to write per norm at 1024 x 4096)
+        total = torch.empty_like(x2) if r2 is not None else None
+        y = torch.empty_like(x2)
+        y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+        f0 = fqs[0]
+        if r2 is not None:
+            _native.check(_native.lib().qt_add_rmsnorm_bf16(x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), total.data_ptr(), y.data_ptr(),
+                                                            y8.data_ptr(), x2.numel() // cols, cols, float(eps), ctypes.byref(f0._qt_format),
+                                                            _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
+        else:
+            _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols,
+                                                            float(eps), ctypes.byref(f0._qt_format), _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
+        codes = _fp8_view(y8, f0)
+        y._qt_fp8 = codes
+        y._qt_fq_done_by = f0
+        y._qt_also_done = [(f, codes) for f in fqs[1:]]
+        y._qt_ver = y._version
+        return total, y
     total = torch.empty_like(x2) if r2 is not None else None
     y = torch.empty_like(x2)
     y8 = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
@@ -421,6 +441,16 @@ def layernorm(x, norm, residual=None, fq=None):
             # (and the shared fake-quantized values) waiting for its next call
             fqs, n = fq, len(fq)
             yq = torch.empty_like(x2)
+            if os.environ.get("QT_NORM_SHARED_CODES", "1") != "0":
+                # equal formats (checked by _norm_consumer_fq): the consumers' codes are the same bytes -- one evaluation, one tensor
+                y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+                _native.check(_native.lib().qt_layernorm_bf16(
+                    x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
+                    yq.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(norm.eps), ctypes.byref(fqs[0]._qt_format),
+                    _stream_ptr(x2)), "qt_layernorm_bf16")
+                for f in fqs:
+                    f.expect_prequantized(y, _fp8_view(y8, f), replacement=yq)
+                return y
             y8s = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
             ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in y8s])
             fmts = (ctypes.c_void_p * n)(*[ctypes.addressof(f._qt_format) for f in fqs])
