@@ -787,6 +787,7 @@ def _hoist_shape_only(p):
         stack.extend(a for a in n.all_input_nodes if a in hoist)
     if sum(1 for n in need if n.op == "call_function") < 4:
         return
+    target_device = next((q.device for q in gm.parameters() if q.device.type == "cuda"), None)
     sub = torch.fx.Graph()
     env = {}
     for sz in sizes:
@@ -801,6 +802,11 @@ def _hoist_shape_only(p):
             env[n] = sub.get_attr(attr)
         else:
             env[n] = sub.node_copy(n, lambda a: env[a])
+            if target_device is not None and "device" in env[n].kwargs:
+                # the exporter records the example inputs' device in constructor nodes (arange, full, ...); upstream's driver pins them
+                # to the model's device after prepare_pt2e (wikitext.py:98-101) by walking model.graph -- which cannot see these nodes
+                # any more once they live in the memo's sub-graph
+                env[n].kwargs = dict(env[n].kwargs, device=target_device)
     sub.output(tuple(env[n] for n in frontier))
     memo = ShapeMemo(GraphModule(holder, sub))
     name = p.add_module("shapes", memo)

@@ -152,8 +152,25 @@ def prepare_pt2e(model, quantizer, args=None, kwargs=None, dynamic_shapes=None, 
     from torch.ao.quantization.quantize_pt2e import prepare_pt2e as _torch_prepare_pt2e
     _prepare._get_obs_or_fq_map = _get_obs_or_fq_map          # torch.ao only constructs its own spec type
     if not isinstance(model, GraphModule):
+        # upstream's driver hands CPU example ids to a model that already lives on a GPU (wikitext.py:81-96); this torch's exporter
+        # refuses mixed devices, so the examples follow the model
+        dev = next((p.device for p in model.parameters()), None)
+        if dev is not None and dev.type == "cuda":
+            from torch.utils._pytree import tree_map
+            follow = lambda t: t.to(dev) if isinstance(t, torch.Tensor) and t.device != dev else t      # noqa: E731
+            args, kwargs = tree_map(follow, args), tree_map(follow, kwargs)
         model = export_model(model, args, kwargs, dynamic_shapes=dynamic_shapes)
+        constants = {k: v for k, v in (kwargs or {}).items() if not isinstance(v, torch.Tensor)}
+    else:
+        constants = {}
     model = _torch_prepare_pt2e(model, quantizer)
+    if constants:
+        # the exported forward takes every example keyword as a required argument; upstream's calibration loop calls
+        # `model(input_ids, labels=target_ids)` (wikitext.py:128), so the non-tensor example keywords (`use_cache=False`) become defaults
+        def _fill_constants(module, call_args, call_kwargs, _c=constants):
+            missing = {k: v for k, v in _c.items() if k not in call_kwargs}
+            return (call_args, {**call_kwargs, **missing}) if missing else None
+        model.register_forward_pre_hook(_fill_constants, with_kwargs=True)
     if fuse or (fuse is None and any(p.device.type == "cuda" for p in model.parameters())):
         from . import pt2e_fusion
         pt2e_fusion.fuse_prepared_graph(model)

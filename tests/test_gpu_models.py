@@ -501,6 +501,32 @@ def test_pt2e_prepared_route_table_format(monkeypatch):
         assert abs(float(out.loss) - ref_loss) <= 2e-3 * ref_loss, (float(out.loss), ref_loss)
 
 
+def test_upstream_wikitext_call_sequence_runs_unchanged():
+    """examples/language_modeling/wikitext.py:68-101 statement for statement: a model that already lives on the GPU, CPU example ids, the
+    default quantizer with the rotary matmul excluded, prepare_pt2e with a dynamic sequence length, then the loop that pins every
+    constructor node of model.graph to the device.  The exporter of this torch refuses mixed devices (the examples follow the model),
+    the fused graph's shape-only nodes live in a sub-graph that loop cannot see (they are pinned when they are moved): the returned
+    module evaluates a window of another length on the device."""
+    from quantized_training import quantize_pt2e as qp
+    model = harness.build_causal_lm("llama-mid", device="cuda", seed=0, num_layers=2)
+    quantizer = qp.get_default_quantizer(input_activation="e4m3", weight="e4m3", bias=None)
+    quantizer.set_module_name_object_type_order(r"model\.rotary_emb", torch.ops.aten.matmul.default, 0, None)
+    input_ids = torch.randint(0, model.config.vocab_size, (1, 256))
+    example_kwargs = {"labels": input_ids.clone(), "use_cache": False}
+    seq_len = torch.export.Dim("seq_length", min=3, max=256)
+    dynamic_shapes = {"input_ids": {1: seq_len}, "labels": {1: seq_len}, "use_cache": None}
+    with torch.no_grad():
+        gm = qp.prepare_pt2e(model, quantizer, (input_ids,), example_kwargs, dynamic_shapes)
+    assert "_qt_unfused_graph" in gm.__dict__                  # device model: chains rewritten to the fused kernels
+    for node in list(gm.graph.nodes):
+        if "device" in node.kwargs:
+            node.kwargs = dict(node.kwargs, device=torch.device("cuda"))
+    x = torch.randint(0, model.config.vocab_size, (1, 128), device="cuda")
+    with torch.no_grad():
+        out = gm(x, labels=x.clone())
+    assert out.logits.is_cuda and out.logits.shape == (1, 128, model.config.vocab_size) and torch.isfinite(out.loss)
+
+
 def nvlib():
     from quantized_training import _native
     return _native.lib()
