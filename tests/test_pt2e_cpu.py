@@ -416,3 +416,22 @@ def test_fusion_on_a_grouped_query_model_keeps_what_it_does_not_recognise():
         assert counts["attention"] == 0 and counts["linear"] == 15 and counts["mlp"] == 2 and counts["add_rmsnorm"] == 4 and counts["loss"] == 1
         got = gm(ids, labels=ids.clone(), use_cache=False)
     assert torch.equal(got.logits, want.logits) and torch.equal(got.loss, want.loss)
+
+
+def test_fusion_on_a_statically_shaped_export_with_the_rotary_matmul_quantized():
+    """No dynamic sequence length (the shape-only sub-graph then has no size inputs and is computed once) and the rotary matmul left to
+    the default annotator (its fake-quantizers are modules, so that chain is NOT shape-only and stays in the graph): still bit for bit."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from quantized_training import pt2e_fusion
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2,
+                      vocab_size=512, max_position_embeddings=256, attn_implementation="eager")
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).bfloat16().eval()
+    ids = torch.randint(0, 512, (1, 64))
+    with torch.no_grad():
+        gm = qp.prepare_pt2e(model, qp.get_default_quantizer("e4m3", None, "e4m3", None), (ids,), {"labels": ids.clone(), "use_cache": False})
+        want = gm(ids, labels=ids.clone())                  # `use_cache` defaults to the example's value
+        counts = pt2e_fusion.fuse_prepared_graph(gm)
+        got = gm(ids, labels=ids.clone())
+    assert counts["attention"] == 1 and counts["linear"] == 8 and counts["shape_only_nodes"] >= 20
+    assert torch.equal(got.logits, want.logits) and torch.equal(got.loss, want.loss)
