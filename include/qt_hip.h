@@ -276,11 +276,27 @@ uint16_t qt_rowparams_apply_host(const qt_rowparams *rp, uint16_t bf16_bits, int
  * every weight tile goes through the row form of its value map on its way to LDS (rows_dev: the 512 x 4 words of
  * qt_build_rowparams in device memory), so fq(W) never exists in HBM and W is read once.  A tile that meets a flagged row is
  * redone with map_dev (the 65 536-entry map in device memory) -- results are exact for every bf16 weight.  Products of
- * quantized values are the reference's bf16 products.  K % 64 == 0, ns[i] % 16 == 0, up to 4 weights per launch; w_devs /
- * bias_devs / ns are HOST arrays. */
+ * quantized values are the reference's bf16 products.  K % 32 == 0, ns[i] % 16 == 0, up to 4 weights per launch; w_devs /
+ * bias_devs / ns are HOST arrays.  Alignment: x_dev, y_dev, w_devs[i], rows_dev 16 bytes (y rows are stored 16 bytes per lane),
+ * bias_devs[i] 8 bytes.  This entry point never splits K (no workspace): narrow outputs run on part of the chip. */
 int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
                        int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
                        uint16_t *y_dev, int M, int K, void *stream);
+
+/* The same product with split-K for narrow outputs (modules/qat/linear.py:40-41 at LLaMA's o / down projections: N <= 5120 at
+ * M = 1024 gives 80 tiles of 512 x 128 for 256 CUs).  qt_linear_fqt_plan says how the library cuts a problem: *ksplit workgroups
+ * share a tile (1: no split, no workspace needed), each multiplies a contiguous range of k steps and writes fp32 partial sums to
+ * ws_dev (*ws_bytes, 16-byte aligned, caller-owned scratch, contents irrelevant); the workgroup that draws the last of a tile's
+ * tickets adds the partial sums in split order (deterministic: independent of arrival order), adds the bias and writes y.
+ * tickets_dev: *n_tickets uint32, ZERO before the first launch; every launch leaves them zero again.  Launches that share
+ * a workspace must be ordered on one stream.  qt_linear_fqt_ws_bf16 returns QT_ERR_BAD_ARG when the plan needs more workspace
+ * or tickets than were passed.  Numerics: fp32 sums of the same exact products; with ksplit > 1 the summation order differs from
+ * the unsplit kernel's (k ranges are summed separately, then added). */
+int qt_linear_fqt_plan(int M, long n_total, int K, int *ksplit, size_t *ws_bytes, size_t *n_tickets);
+int qt_linear_fqt_ws_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
+                          int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
+                          uint16_t *y_dev, int M, int K, float *ws_dev, size_t ws_bytes, uint32_t *tickets_dev, size_t n_tickets,
+                          void *stream);
 
 
 /* ---- A10: attention-score path between the two attention GEMMs ------------------------------

@@ -65,6 +65,11 @@ struct Args {
     int M, K, ldc;
     int tiles_m, tiles_n, nseg;
     int gbase, gextra;        // column tile j covers gbase (+1 for gextra of them) groups of 16 columns
+    // split-K (narrow outputs: too few tiles to fill the chip): `ksplit` workgroups share a tile, each multiplies a contiguous range of
+    // k steps and writes its fp32 partial sums to `ws`; the LAST one to arrive at the tile's ticket adds them in split order and writes y
+    int ksplit;
+    float *ws;                // [tile][split][wave][kRT x kMaxNTW fragments][64 lanes][4] fp32
+    unsigned int *tickets;    // [tile] arrival counters, zero between launches (the last arriver resets its tile's)
     Segment seg[kMaxSeg];
 };
 
@@ -92,6 +97,18 @@ template <int OFF>
 __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
     u32x4 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// Split-K hand-off between workgroups: every byte is stored write-through (sc1) and loaded past the L1 (sc1); the stores are drained
+// (s_waitcnt vmcnt(0)) in front of the workgroup barrier that precedes the ticket's atomic add.
+// Addresses are a wave-uniform base (SGPR pair) + a 32-bit lane offset: no address registers per access.
+__device__ __forceinline__ void store16_sc1(const float *sbase, uint32_t voff, v4f v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ v4f load16_sc1(const float *sbase, uint32_t voff) {
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 }
 
@@ -190,7 +207,7 @@ constexpr int walk(int RT, int NTW, int NB, int from_kind, int from_idx, int to_
 //   first    request activation tile t+2 and RAW weight tile t+4
 //   then     the LDS stream above: RT multiplications per column group on tile t, and 2 NB units of weight tile t+1 converted IN
 //            PLACE, spread evenly over the groups; the rows of unit u+1 are in flight while unit u is computed
-template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
+template <int TM, int NB, bool SROWS, int ABL = 0>
 struct LinearFqt {
     static constexpr int kDA = 3, kDW = 5, kU = 2 * NB;
     static constexpr int kRT = TM / 64;                     // 16-row tiles of a wave's row band (TM / 4 rows)
@@ -215,9 +232,11 @@ struct LinearFqt {
     // One wave's share: rows [wm * TM / 4, + TM / 4) x NTW column groups starting at group jbase of the tile whose first group is
     // tg0.  Returns true when a flagged row was met (the caller redoes the tile).
     template <int NTW, int PH = 0>
-    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
+    // kbeg / nk: this workgroup's range of k steps (all of K / 32 without split-K); split / tile_lin: its place in the hand-off.
+    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l, int kbeg, int nk,
+                                               int split, int tile_lin) {
         const int r = l & 15, g = l >> 4, wm = w & 3;
-        const int nk = a.K / kBK, klast = nk - 1;
+        const int klast = nk - 1;                               // k steps are counted from kbeg inside this function
         const long krow = (long)a.K * 2;                        // bytes per row of x and W
         // LDS map (the dynamic segment starts at address 0: the kernel has no static LDS)
         constexpr uint32_t a0 = kTbl, w0 = a0 + kDA * kABytes, dummy = w0 + kDW * kWBytes;
@@ -279,12 +298,12 @@ struct LinearFqt {
         auto req_piece = [&](auto ic, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
             constexpr int I = decltype(ic)::value;
             if constexpr (I < kPA) {
-                const uint8_t *xb = (const uint8_t *)a.x + (ABL == 7 ? (long)(ka >> 1) * 128 : (long)ka * kRowBytes);
+                const uint8_t *xb = (const uint8_t *)a.x + (ABL == 7 ? (long)((ka + kbeg) >> 1) * 128 : (long)(ka + kbeg) * kRowBytes);
                 if constexpr (ABL != 3) dma16(xb, ga[I], as + (w * kPA + I) * 1024);
                 else dma16(xb, ga[I], dummy);
             } else {
                 constexpr int i = I - kPA;
-                dma16((const uint8_t *)wbase[i] + (long)kb * kRowBytes, gw[i], (real[i] && ABL != 2) ? ws + wofs[i] : dummy);
+                dma16((const uint8_t *)wbase[i] + (long)(kb + kbeg) * kRowBytes, gw[i], (real[i] && ABL != 2) ? ws + wofs[i] : dummy);
             }
         };
         auto req_range = [&](auto lo, auto hi, int ka, uint32_t as, int kb, uint32_t ws) __attribute__((always_inline)) {
@@ -424,7 +443,7 @@ struct LinearFqt {
                     __builtin_amdgcn_sched_barrier(0);
                     // the younger wave of a SIMD (column half 1) loses the issue arbitration to the older one and would set the pace of
                     // the step; it runs the first part of the step at priority 1 and the rest at 0, so that both finish together
-                    if constexpr (PH == 1 && !PP) {
+                    if constexpr (PH == 1) {
                         if (a.prio == 4) {
                             if constexpr (J == 0) __builtin_amdgcn_s_setprio(1);
                             if constexpr (J == (NTW + 1) / 2) __builtin_amdgcn_s_setprio(0);
@@ -527,114 +546,7 @@ struct LinearFqt {
             }
         }
         int sa = 0, sw = 0;                                        // stages multiplied in this step (activations, weights)
-        if constexpr (PP) {
-            // ---- ping-pong: the two waves of a SIMD (column halves PH = 0 / 1) run half a step apart.  A step is two phases with a
-            // barrier behind each: LOAD (fragments of the step into registers, the step's conversion units, the step's requests: LDS,
-            // vector and DMA-issue work) and COMPUTE (the step's multiplications, from registers only).  Half 0 loads while half 1
-            // multiplies the previous step, then the roles swap: the matrix pipe of a SIMD is fed by one wave while the other one
-            // does everything else (MI355X_MICROARCH.md, "Two waves per SIMD").
-            //   barrier 2t+1 | half 0: LOAD(t)     half 1: COMPUTE(t-1)
-            //   barrier 2t+2 | half 0: COMPUTE(t)  half 1: LOAD(t)
-            // LDS hazards: a stage is read only in LOAD phases (into registers), so it may be requested again two barriers later; the
-            // counted vmcnt sits at the end of every LOAD, in front of its barrier (same count as the lockstep loop's).
-            u32x4 pfa[kRT], pfb[NTW > 0 ? NTW : 1];
-            auto pp_load = [&](int kt) __attribute__((always_inline)) {
-                const int sa_req = sa == 0 ? kDA - 1 : sa - 1, sw_req = sw == 0 ? kDW - 1 : sw - 1, sw_cv = sw == kDW - 1 ? 0 : sw + 1;
-                const uint32_t sa_ = a0 + sa * kABytes, sb_ = w0 + sw * kWBytes, wc = w0 + sw_cv * kWBytes;
-                read_raw(wc);
-                if constexpr (NTW > 0) {
-                    pfa[0] = ds_read128<0 * 1024>(sa_ + a_frag); pfa[1] = ds_read128<1 * 1024>(sa_ + a_frag);
-                    pfa[2] = ds_read128<2 * 1024>(sa_ + a_frag); pfa[3] = ds_read128<3 * 1024>(sa_ + a_frag);
-                    if constexpr (kRT > 4) {
-                        pfa[4] = ds_read128<4 * 1024>(sa_ + a_frag); pfa[5] = ds_read128<5 * 1024>(sa_ + a_frag);
-                        pfa[6] = ds_read128<6 * 1024>(sa_ + a_frag); pfa[7] = ds_read128<7 * 1024>(sa_ + a_frag);
-                    }
-                    pfb[0] = ds_read128<0 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 1) pfb[1] = ds_read128<1 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 2) pfb[2] = ds_read128<2 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 3) pfb[3] = ds_read128<3 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 4) pfb[4] = ds_read128<4 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 5) pfb[5] = ds_read128<5 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 6) pfb[6] = ds_read128<6 * 1024>(sb_ + b_frag);
-                    if constexpr (NTW > 7) pfb[7] = ds_read128<7 * 1024>(sb_ + b_frag);
-                }
-                if constexpr (ABL != 2) {
-                    // the raw pieces were requested first: younger are the fragment reads
-                    constexpr int nraw = (NTW > 0 ? kRT + NTW : 0) > 15 ? 15 : (NTW > 0 ? kRT + NTW : 0);
-                    if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(raw[0]), "+v"(raw[1]) : "n"(nraw));
-                    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[0]) : "n"(nraw));
-                    unit_gather(std::integral_constant<int, 0>{});
-                    auto slot = [&](auto uc) __attribute__((always_inline)) {
-                        constexpr int U = decltype(uc)::value;
-                        if constexpr (U + 1 < kU) unit_gather(std::integral_constant<int, U + 1>{});
-                        if constexpr (ABL != 5 && ABL != 6) {
-                            // younger than G(U): the previous unit's write and the next unit's rows
-                            constexpr int n = (U + 1 < kU ? 4 : 0) + (U > 0 ? 1 : 0);
-                            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rows[U & 1][0]), "+v"(rows[U & 1][1]), "+v"(rows[U & 1][2]), "+v"(rows[U & 1][3]) : "n"(n));
-                        }
-                        unit_finish(uc, wc);
-                    };
-                    slot(std::integral_constant<int, 0>{});
-                    if constexpr (kU > 1) slot(std::integral_constant<int, 1>{});
-                    if constexpr (kU > 2) slot(std::integral_constant<int, 2>{});
-                    if constexpr (kU > 3) slot(std::integral_constant<int, 3>{});
-                }
-                request(min(kt + kDA - 1, klast), a0 + sa_req * kABytes, min(kt + kDW - 1, klast), w0 + sw_req * kWBytes);
-                if constexpr (NTW > 0) {
-                    if constexpr (kRT > 4) {
-                        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
-                                     : "+v"(pfa[0]), "+v"(pfa[1]), "+v"(pfa[2]), "+v"(pfa[3]), "+v"(pfa[4]), "+v"(pfa[5]), "+v"(pfa[6]), "+v"(pfa[7])
-                                     : "n"(kVmTop) : "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : "+v"(pfa[0]), "+v"(pfa[1]), "+v"(pfa[2]), "+v"(pfa[3]) : "n"(kVmTop) : "memory");
-                    }
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(pfb[j]));
-                } else {
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
-                }
-                sa = sa == kDA - 1 ? 0 : sa + 1;
-                sw = sw_cv;
-            };
-            auto pp_compute = [&]() __attribute__((always_inline)) {
-                if constexpr (NTW > 0 && ABL != 1) {
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) {
-                        const v8s bf = __builtin_bit_cast(v8s, pfb[j]);
-#pragma unroll
-                        for (int i = 0; i < kRT; ++i)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(v8s, pfa[i]), acc[i][j], 0, 0, 0);
-                    }
-                }
-            };
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the prologue's conversions are written
-            if constexpr (PH == 0) {
-                for (int kt = 0; kt < nk; ++kt) {
-                    __builtin_amdgcn_s_barrier();
-                    pp_load(kt);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    pp_compute();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_s_barrier();
-            } else {
-                for (int kt = 0; kt < nk; ++kt) {
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kt > 0) pp_compute();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    pp_load(kt);
-                }
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                pp_compute();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-            }
-        } else {
+        {
             for (int kt = 0; kt < nk; ++kt) {
                 stamp_kt = kt; stamp(29);
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kVmTop) : "memory");
@@ -659,15 +571,95 @@ struct LinearFqt {
         __syncthreads();
         if ((flags & 1u) && (ABL == 0 || ABL == 9 || ABL == 8)) *flag = 1;      // (ABL 7 computes garbage: never redo)
         __syncthreads();
-        if (*flag) return true;
-
+        const bool flagged = *flag != 0;
+        if (a.ksplit <= 1) {
+            if (flagged) return true;
         if constexpr (ABL == 10 && NTW > 0) {
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j)
+    #pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][0][e & 3] += acc32[i][j][e];
+            }
+        } else {
+            // ---- split-K hand-off.  Partial sums leave in fragment order (a wave's store instruction writes one contiguous KiB),
+            // write-through; every wave drains its stores; behind the workgroup barrier ONE lane takes the tile's ticket.  Whoever
+            // draws the last ticket owns the tile: it adds the partial sums IN SPLIT ORDER (so the result does not depend on who
+            // arrived last) and runs the ordinary epilogue.  Nobody ever waits for another workgroup.  A
+            // flagged split says so in the ticket's upper half and the owner redoes the whole tile through the map.
+            constexpr long kSlab = (long)kRT * kMaxNTW * 256;                    // floats per wave
+            float *const mine = a.ws + (((long)tile_lin * a.ksplit + split) * 8 + w) * kSlab;
+            if constexpr (NTW > 0) {
+                if (!flagged) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < kRT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NTW; ++j) store16_sc1(mine + (i * kMaxNTW + j) * 256, (uint32_t)l * 16u, acc[i][j]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (w == 0 && l == 0) {
+                const unsigned int old = __hip_atomic_fetch_add(a.tickets + tile_lin, 1u + (flagged ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = (int)old;
+            }
+            __syncthreads();
+            const unsigned int old = (unsigned int)*flag;
+            if ((int)(old & 0xFFFFu) != a.ksplit - 1) return false;               // not the last one: done
+            if (w == 0 && l == 0) __hip_atomic_store(a.tickets + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old >> 16) != 0u || flagged) return true;                        // some split met a flagged row: redo the tile
+            if constexpr (NTW > 0) {
+                // Every split's partial sums come back from the workspace, this workgroup's own included (no instruction depends
+                // on which split arrived last): t = p_0 + p_1 + ... in split order, + bias, rounded to bf16, stored straight from
+                // the fragment layout (8 bytes per lane: the owner's stores are a small part of the launch).  A rolled loop over
+                // batches of four fragments with nothing but the batch live: the unrolled form over the whole accumulator array made
+                // hipcc keep two copies of it and spill; S x 8 (S = 4: x 4) loads of 16 bytes in flight per lane.
+                const float *const base = a.ws + ((long)tile_lin * a.ksplit * 8 + w) * kSlab;
+                const uint32_t voff = (uint32_t)l * 16u;
+                const int row0 = m0 + wm * (TM / 4) + r;
+                auto reduce = [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int S = decltype(sc)::value, kB = 4, kFrag = kRT * NTW;
+#pragma unroll 1
+                    for (int f0 = 0; f0 < kFrag; f0 += kB) {
+                        v4f part[S][kB];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][0][e & 3] += acc32[i][j][e];
+                        for (int q = 0; q < S; ++q)
+#pragma unroll
+                            for (int b = 0; b < kB; ++b) {
+                                const int f = f0 + b < kFrag ? f0 + b : kFrag - 1;      // (a ragged last batch re-reads the last fragment)
+                                part[q][b] = load16_sc1(base + (long)q * 8 * kSlab + ((f / NTW) * kMaxNTW + f % NTW) * 256, voff);
+                            }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int q = 0; q < S; ++q)
+#pragma unroll
+                            for (int b = 0; b < kB; ++b) asm volatile("" : "+v"(part[q][b]));
+#pragma unroll
+                        for (int b = 0; b < kB; ++b) {
+                            const int f = f0 + b;
+                            if (f < kFrag) {
+                                v4f t = part[0][b] + part[1][b];
+                                if constexpr (S > 2) t += part[2][b];
+                                if constexpr (S > 3) t += part[3][b];
+                                const int i = f / NTW, j = f % NTW;
+                                const int grp = tg0 + jbase + j, grow = row0 + i * 16;
+                                const SegRef sg = seg_lookup(a, grp);
+                                if (sg.bias) {
+                                    const uint2 bb = *(const uint2 *)(sg.bias + (grp * 16 + 4 * g - sg.g0 * 16));
+                                    t[0] += qt_u2f(bb.x << 16); t[1] += qt_u2f(bb.x & 0xFFFF0000u);
+                                    t[2] += qt_u2f(bb.y << 16); t[3] += qt_u2f(bb.y & 0xFFFF0000u);
+                                }
+                                if (grow < a.M) *(uint2 *)(a.y + (long)grow * a.ldc + grp * 16 + 4 * g) = uint2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+                            }
+                        }
+                    }
+                };
+                if (a.ksplit == 2) reduce(std::integral_constant<int, 2>{});
+                else if (a.ksplit == 3) reduce(std::integral_constant<int, 3>{});
+                else reduce(std::integral_constant<int, 4>{});
+            }
+            return false;
         }
         // ---- epilogue.  Lane (r, g) of tile (i, j) holds y[row wm*TM/4 + i*16 + r][column group j, columns 4g .. 4g+3]; every wave
         // turns its tile around in its own LDS, 64 rows at a time (no barrier: wave-private), and stores whole rows, 16 bytes per lane.
@@ -757,7 +749,7 @@ __device__ __forceinline__ void slow_tile(const Args &a, int m0, int tg0, int jb
     }
 }
 
-template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
+template <int TM, int NB, bool SROWS, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_t[];
     const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -766,9 +758,16 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int ntiles = a.tiles_m * a.tiles_n;
     int id = blockIdx.x;
     {
-        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
+        const int total = ntiles * a.ksplit;
+        const int per = total / 8, rem = total % 8, x = id % 8, q = id / 8;
         id = x * per + (x < rem ? x : rem) + q;
     }
+    // with split-K the splits of one k range are neighbours (they walk the same columns of x and W): id = split * ntiles + tile
+    const int split = id / ntiles;
+    id -= split * ntiles;
+    const int tile_lin = id;
+    const int nk_all = a.K / kBK;
+    const int kbeg = (int)((long)split * nk_all / a.ksplit), nk = (int)((long)(split + 1) * nk_all / a.ksplit) - kbeg;
     const int tn = id / a.tiles_m, tm = id % a.tiles_m;
     int tg0, nt;
     tile_span(a, tn, tg0, nt);
@@ -776,7 +775,7 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     const int nt0 = (nt + 1) >> 1;
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFqt<TM, NB, SROWS, ABL, PP>;
+    using L = LinearFqt<TM, NB, SROWS, ABL>;
     if (lds_addr(lds_t) != 0) __builtin_trap();            // the LDS map is written in absolute addresses
     // The two waves of a SIMD are w and w + 4; the SIMD's issue arbitration prefers the older one (waves 0-3), and the younger half then
     // sets the pace of every k step (measured, tools/exp_fqt_stamps.py: 1750 against 1230 cycles of work per step, the older half
@@ -788,7 +787,8 @@ __global__ __launch_bounds__(512, 1) void linear_fqt_kernel(Args a) {
     if (a.prio == 3 && w >= 4) __builtin_amdgcn_s_setprio(3);
     if (a.prio == -1 && w < 4) __builtin_amdgcn_s_setprio(1);
     bool redo;
-#define QT_RUN(N) (wn == 1 ? L::template run<N, 1>(a, lds_t, m0, tg0, nt, jbase, w, l) : L::template run<N, 0>(a, lds_t, m0, tg0, nt, jbase, w, l))
+#define QT_RUN(N) (wn == 1 ? L::template run<N, 1>(a, lds_t, m0, tg0, nt, jbase, w, l, kbeg, nk, split, tile_lin) \
+                           : L::template run<N, 0>(a, lds_t, m0, tg0, nt, jbase, w, l, kbeg, nk, split, tile_lin))
     switch (ntw) {                                          // wave-uniform
         case 0: redo = QT_RUN(0); break;
         case 1: redo = QT_RUN(1); break;
@@ -817,16 +817,16 @@ int cu_count() {
     return n;
 }
 
-template <int TM, int NB, bool SROWS, int ABL = 0, bool PP = false>
+template <int TM, int NB, bool SROWS, int ABL = 0>
 int launch_one(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFqt<TM, NB, SROWS>::kLds;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    linear_fqt_kernel<TM, NB, SROWS, ABL, PP><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
+    linear_fqt_kernel<TM, NB, SROWS, ABL><<<a.tiles_m * a.tiles_n * a.ksplit, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -834,6 +834,7 @@ int launch_one(const Args &a, hipStream_t st) {
 template <bool SROWS>
 int launch(const Args &a, hipStream_t st, int tm) {
     if (tm == 512) {
+#ifdef QT_TUNING_BUILD
         if constexpr (!SROWS) {
             const char *e_abl = getenv("QT_FQT_ABLATE");       // timing experiments (tools/exp_linear_fqt.py --skip-checks): results are garbage
             switch (e_abl ? atoi(e_abl) : 0) {
@@ -849,8 +850,7 @@ int launch(const Args &a, hipStream_t st, int tm) {
                 default: break;
             }
         }
-        static const int pp = getenv("QT_FQT_PP") ? atoi(getenv("QT_FQT_PP")) : 0;      // A-B switch: the ping-pong loop
-        if (pp) return launch_one<512, 1, SROWS, 0, true>(a, st);
+#endif
         return launch_one<512, 1, SROWS>(a, st);
     }
     const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
@@ -867,13 +867,72 @@ void plan(long groups, int tiles_m, int max_nt, int cus, long &tn, long &rounds)
     if (tn > groups) tn = groups;
 }
 
-}  // namespace
+// How a problem is cut: row tile height, column tiles, and over how many workgroups the K loop of a tile is split.
+struct Tiling {
+    int tm, tiles_m, tiles_n, gbase, gextra, ksplit;
+    size_t ws_bytes() const { return ksplit > 1 ? (size_t)tiles_m * tiles_n * ksplit * 8 * 32 * 1024 : 0; }      // 32 KiB per wave and split
+    size_t tickets() const { return ksplit > 1 ? (size_t)tiles_m * tiles_n : 0; }
+};
 
-extern "C" {
+constexpr int kMinSplitSteps = 24;     // a split shorter than this does not pay for its prologue and the hand-off
 
-int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
-                       int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
-                       uint16_t *y_dev, int M, int K, void *stream) {
+Tiling make_tiling(int M, long groups, int K, bool may_split) {
+    const int cus = cu_count();
+    int force_tn = 0, force_tm = 0, force_ks = 0;
+#ifdef QT_TUNING_BUILD
+    const char *e_tn = getenv("QT_FQT_TILES_N"), *e_tm = getenv("QT_FQT_TM"), *e_ks = getenv("QT_FQT_KSPLIT");          // tools/ only
+    force_tn = e_tn ? atoi(e_tn) : 0; force_tm = e_tm ? atoi(e_tm) : 0; force_ks = e_ks ? atoi(e_ks) : 0;
+#endif
+    // 512-row tiles (half the conversion work per multiplication) where they fill the chip with tiles at least five groups wide;
+    // else 256-row tiles
+    long tn5, r5, tn2, r2;
+    plan(groups, (M + 511) / 512, 8, cus, tn5, r5);
+    plan(groups, (M + 255) / 256, 16, cus, tn2, r2);
+    int tm = 256;
+    if (M > 256) {
+        const double width5 = (double)groups / (double)tn5, fill5 = (double)((M + 511) / 512) * tn5 / ((double)r5 * cus);
+        const double fill2 = (double)((M + 255) / 256) * tn2 / ((double)r2 * cus);
+        if (width5 >= 5.0 && fill5 >= 0.9 * fill2) tm = 512;
+    }
+    // Narrow outputs: the widest 512-row tiles leave most of the chip idle, and narrower ones convert every weight for a handful of
+    // multiplications (1024 x 5120 x 13824: 256 x 80 tiles ran at 0.20 of the bf16 peak).  Keep 512 x 128 tiles and split K over the
+    // idle CUs instead: ksplit workgroups per tile, partial sums through the workspace, the last one to arrive writes the tile.
+    int ksplit = 1;
+    const int nk = K / kBK;
+    if (may_split && M > 256) {
+        const int tiles_m5 = (M + 511) / 512;
+        const long tn_wide = (groups + 7) / 8, tiles = tiles_m5 * tn_wide;
+        if (tiles * 4 <= (long)cus * 3) {                       // under three quarters of the chip
+            int ks = (int)(cus / tiles);
+            if (ks > 4) ks = 4;
+            while (ks > 1 && nk / ks < kMinSplitSteps) --ks;
+            if (ks > 1) { ksplit = ks; tm = 512; tn5 = tn_wide; }
+        }
+    }
+    if (force_tm == 256 || force_tm == 512) { tm = force_tm; if (force_tm == 256) ksplit = 1; }
+    Tiling t{};
+    t.tm = tm;
+    t.tiles_m = (M + tm - 1) / tm;
+    long tn = tm == 512 ? tn5 : tn2;
+    {
+        const int max_nt = tm == 512 ? 8 : 16;
+        const long tn_min = (groups + max_nt - 1) / max_nt;
+        if (force_tn > 0) tn = force_tn;
+        if (tn < tn_min) tn = tn_min;
+        if (tn > groups) tn = groups;
+    }
+    if (force_ks >= 1 && force_ks <= 4 && may_split && nk / force_ks >= 1) ksplit = force_ks;
+    if (tm != 512) ksplit = 1;
+    t.tiles_n = (int)tn;
+    t.gbase = (int)(groups / tn);
+    t.gextra = (int)(groups % tn);
+    t.ksplit = ksplit;
+    return t;
+}
+
+int linear_fqt(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns, int count,
+               const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev, uint16_t *y_dev, int M, int K,
+               float *ws_dev, size_t ws_bytes, uint32_t *tickets_dev, size_t n_tickets, bool may_split, void *stream) {
     if (count < 1 || count > kMaxSeg || !w_devs || !ns) return QT_ERR_BAD_ARG;
     long ntot = 0;
     for (int i = 0; i < count; ++i) {
@@ -886,48 +945,33 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     if ((long)M * K * 2 >= (1L << 32)) return QT_ERR_BAD_ARG;
     for (int i = 0; i < count; ++i)
         if ((long)ns[i] * K * 2 >= (1L << 32)) return QT_ERR_BAD_ARG;
-    if (((uintptr_t)x_dev & 15u) || ((uintptr_t)y_dev & 7u) || ((uintptr_t)rows_dev & 15u) || (ntot & 3)) return QT_ERR_UNALIGNED;
+    // y rows are stored 16 bytes per lane: y_dev and the row pitch (2 * sum n bytes) must keep them aligned
+    if (((uintptr_t)x_dev & 15u) || ((uintptr_t)y_dev & 15u) || ((uintptr_t)rows_dev & 15u) || (ntot & 7)) return QT_ERR_UNALIGNED;
     for (int i = 0; i < count; ++i) {
         if (ns[i] && (!w_devs[i] || ((uintptr_t)w_devs[i] & 15u))) return QT_ERR_UNALIGNED;
         if (bias_devs && bias_devs[i] && ((uintptr_t)bias_devs[i] & 7u)) return QT_ERR_UNALIGNED;
     }
     const long groups = ntot / 16;
+    const Tiling t = make_tiling(M, groups, K, may_split);
+    if (t.ksplit > 1) {
+        if (!ws_dev || !tickets_dev || ws_bytes < t.ws_bytes() || n_tickets < t.tickets()) return QT_ERR_BAD_ARG;
+        if (((uintptr_t)ws_dev & 15u) || ((uintptr_t)tickets_dev & 3u)) return QT_ERR_UNALIGNED;
+    }
     Args a{};
     a.x = x_dev; a.y = y_dev; a.rows = rows_dev; a.map = map_dev; a.sign_mask = sign_mask;
     a.M = M; a.K = K; a.ldc = (int)ntot;
+    a.prio = 4;
+    a.dbg = nullptr;
+#ifdef QT_TUNING_BUILD
     {
         const char *e_pr = getenv("QT_FQT_PRIO");
         a.prio = e_pr ? atoi(e_pr) : 4;
         const char *e_st = getenv("QT_FQT_STAMPS");
         a.dbg = e_st ? (unsigned long long *)strtoull(e_st, nullptr, 0) : nullptr;
     }
-    const char *e_tn = getenv("QT_FQT_TILES_N"), *e_tm = getenv("QT_FQT_TM");          // tuning / A-B switches
-    const int force_tn = e_tn ? atoi(e_tn) : 0, force_tm = e_tm ? atoi(e_tm) : 0;
-    const int cus = cu_count();
-    // 512-row tiles (half the conversion work per multiplication) where they fill the chip with tiles at least five groups wide;
-    // else 256-row tiles
-    long tn5, r5, tn2, r2;
-    plan(groups, (M + 511) / 512, 8, cus, tn5, r5);
-    plan(groups, (M + 255) / 256, 16, cus, tn2, r2);
-    int tm = 256;
-    if (M > 256) {
-        const double width5 = (double)groups / (double)tn5, fill5 = (double)((M + 511) / 512) * tn5 / ((double)r5 * cus);
-        const double fill2 = (double)((M + 255) / 256) * tn2 / ((double)r2 * cus);
-        if (width5 >= 5.0 && fill5 >= 0.9 * fill2) tm = 512;
-    }
-    if (force_tm == 256 || force_tm == 512) tm = force_tm;
-    a.tiles_m = (M + tm - 1) / tm;
-    long tn = tm == 512 ? tn5 : tn2;
-    {
-        const int max_nt = tm == 512 ? 8 : 16;
-        const long tn_min = (groups + max_nt - 1) / max_nt;
-        if (force_tn > 0) tn = force_tn;
-        if (tn < tn_min) tn = tn_min;
-        if (tn > groups) tn = groups;
-    }
-    a.tiles_n = (int)tn;
-    a.gbase = (int)(groups / tn);
-    a.gextra = (int)(groups % tn);
+#endif
+    a.tiles_m = t.tiles_m; a.tiles_n = t.tiles_n; a.gbase = t.gbase; a.gextra = t.gextra;
+    a.ksplit = t.ksplit; a.ws = ws_dev; a.tickets = tickets_dev;
     int nseg = 0, g0 = 0;
     for (int i = 0; i < count; ++i) {
         if (ns[i] == 0) continue;
@@ -939,7 +983,37 @@ int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, con
     }
     a.nseg = nseg;
     hipStream_t st = (hipStream_t)stream;
-    return signed_rows ? launch<true>(a, st, tm) : launch<false>(a, st, tm);
+    return signed_rows ? launch<true>(a, st, t.tm) : launch<false>(a, st, t.tm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qt_linear_fqt_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
+                       int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
+                       uint16_t *y_dev, int M, int K, void *stream) {
+    return linear_fqt(x_dev, w_devs, bias_devs, ns, count, rows_dev, signed_rows, sign_mask, map_dev, y_dev, M, K, nullptr, 0, nullptr, 0,
+                      false, stream);
+}
+
+int qt_linear_fqt_plan(int M, long n_total, int K, int *ksplit, size_t *ws_bytes, size_t *n_tickets) {
+    if (M < 0 || n_total < 0 || n_total % 16 != 0 || K < kBK || K % kBK != 0) return QT_ERR_BAD_ARG;
+    Tiling t{};
+    t.ksplit = 1;
+    if ((long)M * n_total != 0) t = make_tiling(M, n_total / 16, K, true);
+    if (ksplit) *ksplit = t.ksplit;
+    if (ws_bytes) *ws_bytes = t.ws_bytes();
+    if (n_tickets) *n_tickets = t.tickets();
+    return QT_OK;
+}
+
+int qt_linear_fqt_ws_bf16(const uint16_t *x_dev, const uint16_t *const *w_devs, const uint16_t *const *bias_devs, const int *ns,
+                          int count, const uint32_t *rows_dev, int signed_rows, uint32_t sign_mask, const uint16_t *map_dev,
+                          uint16_t *y_dev, int M, int K, float *ws_dev, size_t ws_bytes, uint32_t *tickets_dev, size_t n_tickets,
+                          void *stream) {
+    return linear_fqt(x_dev, w_devs, bias_devs, ns, count, rows_dev, signed_rows, sign_mask, map_dev, y_dev, M, K, ws_dev, ws_bytes,
+                      tickets_dev, n_tickets, true, stream);
 }
 
 }  // extern "C"

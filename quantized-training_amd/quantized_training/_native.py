@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_uint16, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqt_hip.so")
+# QT_HIP_LIB: tools/ only -- load the tuning build (make -C quantized-training_amd tuning) instead of the product library
+LIB_PATH = os.environ.get("QT_HIP_LIB") or os.path.join(_HERE, "libqt_hip.so")
 
 QT_MAP_ENTRIES = 65536
 QT_FMT_LUT, QT_FMT_IDENTITY, QT_FMT_FP_SAT, QT_FMT_INT = 0, 1, 2, 3
@@ -77,6 +78,8 @@ SIGNATURES = {
     "qt_build_rowparams": (c_int, [_P, POINTER(QtRowParams)]),
     "qt_rowparams_apply_host": (c_uint16, [POINTER(QtRowParams), c_uint16, POINTER(c_int)]),
     "qt_linear_fqt_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P]),
+    "qt_linear_fqt_plan": (c_int, [c_int, c_long, c_int, POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]),
+    "qt_linear_fqt_ws_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),
     "qt_mlp_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, _P]),
     "qt_bmm_fq_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long,
                                _OPQ, _OPQ, _P]),

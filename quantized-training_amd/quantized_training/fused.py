@@ -89,69 +89,11 @@ def _fq8_heuristic(M, ns, K, device):
     return M <= 1024 and nt >= 5.0 and K <= 8192
 
 
-def _fq8_measure(x8, layers):
-    """QT_FQ8_TUNE=1 only: times both routes on this very problem (device events around four launches after two warm-up ones, twice,
-    alternating) and returns True when the fused kernel is faster.  Outputs are discarded; no fake-quant call is counted.  Under
-    torch.distributed rank 0's verdict is broadcast, so every rank takes the same route."""
-    dev = x8.device
-    K = x8.shape[-1]
-    n = len(layers)
-    fq = layers[0].weight_fake_quant
-    total = sum(l.weight.shape[0] for l in layers)
-    buf = torch.empty((total, K), dtype=torch.uint8, device=dev)
-    L = _native.lib()
-    xs = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
-    ns = (ctypes.c_size_t * n)(*[l.weight.numel() for l in layers])
-    w8 = buf.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn)
-
-    def pair():
-        _native.check(L.qt_fake_quant_bf16_fp8_multi(xs, ns, n, buf.data_ptr(), ctypes.byref(fq._qt_format), _stream_ptr(x8)),
-                      "qt_fake_quant_bf16_fp8_multi")
-        return lt_fp8_gemm(x8, w8, None)
-
-    def fused():
-        return hip_fq8_linear_or_none(x8, layers)
-
-    if fused() is None:
-        verdict = False
-    elif pair() is None:
-        verdict = True
-    else:
-        best = [float("inf"), float("inf")]
-        for _ in range(2):                                     # two alternating rounds, the better one of each route counts
-            for i, fn in enumerate((fused, pair)):
-                for _ in range(2):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(torch.cuda.current_stream(dev))
-                for _ in range(4):
-                    fn()
-                e1.record(torch.cuda.current_stream(dev))
-                e1.synchronize()
-                best[i] = min(best[i], e0.elapsed_time(e1))
-        verdict = best[0] < best[1]
-    return _agree_across_ranks(verdict, dev)
-
-
-def _agree_across_ranks(flag, device):
-    """rank 0's value of a measured choice, on every rank (no-op without an initialised process group)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        return bool(flag)
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else "cpu")
-    dist.broadcast(t, src=0)
-    return bool(int(t.item()))
-
-
-def fq8_tune_enabled():
-    """QT_FQ8_TUNE=1: decide unknown shapes by timing both routes on the first call (outside stream capture).  Off by default: the
-    two routes sum in different orders, so a timing race would make logits depend on the box, the run and the rank."""
-    return os.environ.get("QT_FQ8_TUNE", "0") == "1"
-
-
 def fq8_route_is_fused(x8, layers):
     """Route of one fake-quant Linear problem (x8 [M, K] FP8 codes x the bf16 weights of `layers`): QT_FQ8_GEMM=0 / 1 forces it; else
-    the committed table, else (QT_FQ8_TUNE=1, outside a capture) a measurement agreed across ranks, else the rule."""
+    the committed table, else the closed-form rule.  Never a measurement: a timing race would make the summation order -- and so
+    the logits -- depend on the box, the run and the rank, and a lazily measured choice would need a collective that not every rank
+    reaches (windows are dealt round-robin)."""
     K = x8.shape[-1]
     M = x8.numel() // K
     ns = tuple(l.weight.shape[0] for l in layers)
@@ -164,11 +106,7 @@ def fq8_route_is_fused(x8, layers):
             key = (M, ns, K, x8.dtype, layers[0].weight_fake_quant._qt_format.key(), x8.device.index)
             hit = _FQ8_CHOICE.get(key)
             if hit is None:
-                if fq8_tune_enabled() and not torch.cuda.is_current_stream_capturing():
-                    hit = bool(_fq8_measure(x8, layers))
-                else:
-                    hit = _fq8_heuristic(M, ns, K, x8.device)
-                _FQ8_CHOICE[key] = hit
+                hit = _FQ8_CHOICE[key] = _fq8_heuristic(M, ns, K, x8.device)
     _note_route("fq8", M, ns, K, "fused_fp8_gemm" if hit else "weight_pass+library_fp8_gemm")
     return hit
 
@@ -439,10 +377,9 @@ _MLP_TABLE = {
 }
 
 
-def mlp_route_is_one_launch(x8, gate, up, out_fq, three_launches):
+def mlp_route_is_one_launch(x8, gate, up, out_fq):
     """Whether qt_mlp_fq8_bf16 runs the gated MLP's front half on this problem: QT_FQ8_MLP=2 forces it; else the committed table;
-    else (QT_FQ8_TUNE=1, outside a capture) a measurement against `three_launches()` agreed across ranks; else one launch where
-    it fills the chip in a single round."""
+    else one launch where it fills the chip in a single round (a rule, never a measurement: see fq8_route_is_fused)."""
     if os.environ.get("QT_FQ8_MLP", "1") == "2":              # always (tests, ablations)
         return True
     K = x8.shape[-1]
@@ -453,27 +390,8 @@ def mlp_route_is_one_launch(x8, gate, up, out_fq, three_launches):
         key = (M, N, K, x8.dtype, gate.weight_fake_quant._qt_format.key(), out_fq._qt_format.key(), x8.device.index)
         hit = _MLP_CHOICE.get(key)
         if hit is None:
-            if fq8_tune_enabled() and not torch.cuda.is_current_stream_capturing():
-                if hip_mlp_fq8_or_none(x8, gate, up, out_fq) is None:
-                    hit = False
-                else:
-                    times = []
-                    for fn in (lambda: hip_mlp_fq8_or_none(x8, gate, up, out_fq), three_launches):
-                        for _ in range(2):
-                            fn()
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(torch.cuda.current_stream(x8.device))
-                        for _ in range(3):
-                            fn()
-                        e1.record(torch.cuda.current_stream(x8.device))
-                        e1.synchronize()
-                        times.append(e0.elapsed_time(e1))
-                    hit = times[0] < times[1]
-                hit = _agree_across_ranks(hit, x8.device)
-            else:
-                cus = torch.cuda.get_device_properties(x8.device).multi_processor_count
-                hit = ((M + 255) // 256) * ((N // 16 + 5) // 6) <= cus
-            _MLP_CHOICE[key] = hit
+            cus = torch.cuda.get_device_properties(x8.device).multi_processor_count
+            hit = _MLP_CHOICE[key] = ((M + 255) // 256) * ((N // 16 + 5) // 6) <= cus
     _note_route("mlp", M, [N, N], K, "one_launch_gate_up_silu" if hit else "two_gemms+silu_mul")
     return hit
 
@@ -729,15 +647,28 @@ def fqt_tables(fq, device):
     return hit if hit["usable"] else None
 
 
+def fqt_plan(M, n_total, K):
+    """(ksplit, workspace bytes, tickets) qt_linear_fqt_ws_bf16 would use for this problem (host-only query)."""
+    ks, wb, nt = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _native.check(_native.lib().qt_linear_fqt_plan(M, n_total, K, ctypes.byref(ks), ctypes.byref(wb), ctypes.byref(nt)), "qt_linear_fqt_plan")
+    return ks.value, wb.value, nt.value
+
+
 def fqt_route_is_fused(M, ns, K, device):
-    """Fixed routing rule for qt_linear_fqt_bf16, from the measurements in DESIGN.md 6c (MI355X, posit(8,2)): the kernel wins where
-    512-row tiles at least seven column groups wide fill the chip (1024 x 15360 x 5120: 169 against 199 us; 1024 x 32000 x 5120: 350
-    against 397) and loses on narrower tiles (1024 x 13824 x 5120: 191 against 179; N = 5120: 113 against 71)."""
+    """Fixed routing rule for qt_linear_fqt_bf16, from the measurements in DESIGN.md 6c / 6d (MI355X, posit(8,2)): the kernel wins
+    where 512-row tiles at least seven column groups wide fill the chip (1024 x 15360 x 5120: 160 against 194 us for weight pass +
+    library GEMM; 1024 x 32000 x 5120: 332 against 395), and -- since round 4, with split-K -- on narrow outputs with a deep K
+    (1024 x 5120 x 13824: 167-177 against 181-200: three workgroups per 512 x 128 tile, 144 k steps each).  It loses where the
+    tiles are narrower (1024 x 13824 x 5120: 176-183 against 173-178) and where a split's k range is too short to pay for the
+    hand-off of the fp32 partial sums (1024 x 5120 x 5120: 83-91 against 70)."""
     mode = fqt_gemm_mode()
     if mode != "auto":
         return mode == "1"
     if M <= 256 or K % 32:
         return False
+    ksplit = fqt_plan(M, sum(ns), K)[0]
+    if ksplit > 1:
+        return (K // 32) // ksplit >= 128
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     groups = sum(ns) // 16
     tiles_m = (M + 511) // 512
@@ -771,12 +702,46 @@ def hip_fqt_linear_or_none(x2, layers, tables):
     wp = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
     bp = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
     nn = (ctypes.c_int * n)(*ns)
-    rc = _native.lib().qt_linear_fqt_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
-                                           tables["map"].data_ptr(), y.data_ptr(), M, K, _stream_ptr(x2))
+    ws, tickets = _fqt_workspace(M, sum(ns), K, x2.device)
+    if ws is False:
+        rc = _native.lib().qt_linear_fqt_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
+                                               tables["map"].data_ptr(), y.data_ptr(), M, K, _stream_ptr(x2))
+        if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
+            return None
+        _native.check(rc, "qt_linear_fqt_bf16")
+        return y
+    rc = _native.lib().qt_linear_fqt_ws_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
+                                              tables["map"].data_ptr(), y.data_ptr(), M, K,
+                                              ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
+                                              tickets.data_ptr() if tickets is not None else None, tickets.numel() if tickets is not None else 0,
+                                              _stream_ptr(x2))
     if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
         return None
-    _native.check(rc, "qt_linear_fqt_bf16")
+    _native.check(rc, "qt_linear_fqt_ws_bf16")
     return y
+
+
+# Split-K scratch of qt_linear_fqt_ws_bf16, per device: one fp32 workspace (grown to the largest plan seen) and one ticket array
+# (zeroed once; every launch leaves it zero).  Launches on a device are ordered on its stream, so they can share both.  Outgrown
+# buffers stay allocated: a hipGraph captured earlier replays launches that hold their addresses.
+_FQT_WS = {}
+_FQT_WS_OLD = []
+
+
+def _fqt_workspace(M, n_total, K, device):
+    ksplit, wbytes, ntick = fqt_plan(M, n_total, K)
+    if ksplit <= 1:
+        return None, None
+    ws, tickets = _FQT_WS.get(device, (None, None))
+    if ws is None or ws.numel() * 4 < wbytes or tickets.numel() < ntick:
+        if torch.cuda.is_current_stream_capturing():
+            return False, False                               # never allocate inside a capture: this launch runs unsplit
+        if ws is not None:
+            _FQT_WS_OLD.append((ws, tickets))
+        ws = torch.empty(((wbytes + 3) // 4,), dtype=torch.float32, device=device)
+        tickets = torch.zeros((max(ntick, 4096),), dtype=torch.int32, device=device)
+        _FQT_WS[device] = (ws, tickets)
+    return ws, tickets
 
 
 def _fqt_weight_ok(layer):

@@ -670,14 +670,9 @@ def _fused_mlp_or_none(self, x):
     if x8 is None or (getattr(x, "_qt_fq_done_by", None) is None and not prepared) or not fused.fq8_route_is_fused(x8.reshape(-1, x8.shape[-1]), [gate]):
         return None
     x8f = x8.reshape(-1, x8.shape[-1])
-
-    def three_launches():                                       # what the one launch replaces, for the measurement only
-        g = fused.hip_fq8_linear_or_none(x8f, [gate])
-        u = fused.hip_fq8_linear_or_none(x8f, [up])
-        return silu_mul_fq(g, u, fq_out)
     for l in (gate, up):
         l.weight_fake_quant._move_to(x.device)
-    if not fused.mlp_route_is_one_launch(x8f, gate, up, fq_out, three_launches):
+    if not fused.mlp_route_is_one_launch(x8f, gate, up, fq_out):
         return None
     xg = _run_pre_hooks(gate, x)                               # gate's input fake-quantizer: hands the producer's result through, counted
     x8 = getattr(xg, "_qt_fp8", None) if handover_valid(xg) else None

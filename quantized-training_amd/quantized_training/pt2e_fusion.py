@@ -337,24 +337,33 @@ class PreparedCausalLMLoss(nn.Module):
 class ShapeMemo(nn.Module):
     """The part of an exported forward that depends on the input SHAPES only (HF builds the causal mask and the rotary tables from
     `arange(seq_len)` on every call): computed once per shape, kept.  Nothing a fake-quantizer or a Parameter's value enters is
-    ever in here -- weights are fake-quantized on every forward, as the reference does."""
+    ever in here -- weights are fake-quantized on every forward, as the reference does.
+
+    Kept results are never freed while the module lives: a hipGraph captured earlier (harness.GraphedWindow) replays reads of their
+    addresses, so an eviction would hand that memory back to the allocator under a live graph.  Past `kMax` shapes a new shape is
+    computed and returned without being kept.  The key also holds the device and the version counters of the constants the
+    sub-graph reads, so `gm.to(other_device)` or an in-place update of one of them recomputes instead of returning stale tables."""
+
+    kMax = 64
 
     def __init__(self, sub):
         super().__init__()
         self.sub = sub
         self.__dict__["kept"] = {}
 
+    def _state_key(self):
+        return tuple((str(b.device), b._version, b.data_ptr()) for b in self.sub.buffers())
+
     def forward(self, *sizes):
-        key = tuple(int(v) for v in sizes)
+        key = (tuple(int(v) for v in sizes), self._state_key())
         kept = self.__dict__["kept"]
         out = kept.get(key)
         if out is None:
             if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
                 return self.sub(*sizes)                       # a shape first seen inside a capture: computed in the graph, not kept
             out = self.sub(*sizes)
-            if len(kept) >= 16:
-                kept.clear()
-            kept[key] = out
+            if len(kept) < self.kMax:
+                kept[key] = out
         return out
 
 
@@ -765,7 +774,10 @@ def _hoist_shape_only(p):
         elif n.op == "get_attr":
             obj = _attr(gm, n)
             if isinstance(obj, torch.Tensor) and not isinstance(obj, nn.Parameter) and not obj.requires_grad:
-                hoist[n] = True                             # buffers and lifted constants (inv_freq, eps, the mask's fill value)
+                # buffers and lifted constants (inv_freq, eps, the mask's fill value).  The exporter registers all of them as
+                # persistent buffers of the graph module, so a `load_state_dict` may rewrite them in place: ShapeMemo keys its
+                # results on their version counters (and device), and the root attributes stay where they are
+                hoist[n] = True
         elif n.op == "call_function" and n.target not in _IMPURE and "rand" not in str(n.target) and ok_arg(n.args) and ok_arg(n.kwargs):
             hoist[n] = True                                 # constructors without inputs (arange(1)) included
     # get_attr leaves that nothing hoisted reads stay where they are
@@ -850,6 +862,31 @@ def _copy_graph(graph):
     return g
 
 
+# The fused helper modules re-register Parameters and fake-quantizer modules the prepared graph already owns (shared objects, so
+# calibration state and `.to()` carry over).  Their `_qt_*` names must not leak into checkpoints: a state_dict of a fused graph has
+# exactly the keys of the plain prepared graph (upstream's format), and loading one -- strict -- into either form works.
+def _drop_helper_keys(module, state_dict, prefix, local_metadata):
+    for k in [k for k in state_dict if k[len(prefix):].startswith("_qt_")]:
+        del state_dict[k]
+    return state_dict
+
+
+def _forgive_helper_keys(module, incompatible):
+    incompatible.missing_keys[:] = [k for k in incompatible.missing_keys if not k.startswith("_qt_")]
+
+
+def _install_state_dict_hooks(model):
+    if "_qt_state_hooks" in model.__dict__:
+        return
+    model.__dict__["_qt_state_hooks"] = (model._register_state_dict_hook(_drop_helper_keys),
+                                         model.register_load_state_dict_post_hook(_forgive_helper_keys))
+
+
+def _remove_state_dict_hooks(model):
+    for h in model.__dict__.pop("_qt_state_hooks", ()):
+        h.remove()
+
+
 def unfuse_prepared_graph(model: GraphModule):
     """Put back the graph `fuse_prepared_graph` started from (fake-quantizer modules and Parameters are shared, so calibration state
     carries over) and drop the fused modules.  No-op on a graph that was not fused."""
@@ -860,6 +897,7 @@ def unfuse_prepared_graph(model: GraphModule):
     model.recompile()
     for name in [n for n, _ in model.named_children() if n.startswith("_qt_")]:
         delattr(model, name)
+    _remove_state_dict_hooks(model)
     return True
 
 
@@ -880,4 +918,5 @@ def fuse_prepared_graph(model: GraphModule):
         _hoist_shape_only(p)
     model.graph.lint()
     model.recompile()
+    _install_state_dict_hooks(model)
     return p.counts

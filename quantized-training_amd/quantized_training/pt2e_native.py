@@ -70,6 +70,7 @@ def _q8(a, b, bias, out_scale, out_map, out_shape, batch, M, N, K, a_bs, b_bs, d
 
 
 _UNIT_E8M0 = {}          # device -> uint8 tensor of 127s (scale 2^0): the block scales of a per-tensor FP8 operand
+_UNIT_E8M0_OLD = []      # outgrown buffers stay allocated: a hipGraph captured earlier still reads their addresses
 _MX_FMT = {torch.float8_e4m3fn: 0, torch.float8_e5m2: 1}
 
 
@@ -88,6 +89,8 @@ def _fp8_codes_gemm(a, w, bias):
     if ones is None or ones.numel() < need:
         if torch.cuda.is_current_stream_capturing():
             return None
+        if ones is not None:
+            _UNIT_E8M0_OLD.append(ones)
         ones = torch.full((need,), 127, dtype=torch.uint8, device=a.device)
         _UNIT_E8M0[a.device] = ones
     y = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)

@@ -178,11 +178,10 @@ def test_declined_attention_core_materializes_code_only_rotary_outputs(monkeypat
 
 def test_gemm_routes_are_fixed_and_reported(monkeypatch):
     """the route of a problem shape comes from the committed tables / rules in fused.py, never from a timing race
-    (QT_FQ8_TUNE is opt-in), so two evaluations of the same model give bit-identical logits and `fused.routes_report()` names the
+    (round 4 removed the opt-in measurement altogether), so two evaluations of the same model give bit-identical logits and `fused.routes_report()` names the
     route of every GEMM shape."""
     from quantized_training import fused
-    monkeypatch.delenv("QT_FQ8_TUNE", raising=False)
-    assert not fused.fq8_tune_enabled()
+    assert not hasattr(fused, "fq8_tune_enabled") and not hasattr(fused, "_agree_across_ranks")
 
     def run():
         fused._FQ8_CHOICE.clear(); fused._MLP_CHOICE.clear(); fused.ROUTES.clear()

@@ -1682,31 +1682,55 @@ class _Fqt:
         return hit
 
 
-def _linear_fqt(nv, x, ws, dtype, biases=None):
+_FQT_WS = {}
+
+
+def _fqt_plan(nv, M, N, K):
+    ks, wb, nt = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    nv.check(nv.lib().qt_linear_fqt_plan(M, N, K, ctypes.byref(ks), ctypes.byref(wb), ctypes.byref(nt)), "qt_linear_fqt_plan")
+    return ks.value, wb.value, nt.value
+
+
+def _linear_fqt(nv, x, ws, dtype, biases=None, split=True):
+    """split=True: qt_linear_fqt_ws_bf16 with the workspace qt_linear_fqt_plan asks for (split-K where the plan says so);
+    split=False: qt_linear_fqt_bf16, the entry point that never splits K."""
     f = _Fqt(nv, dtype)
     M, K = x.shape
     n = len(ws)
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
     bp = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in (biases or [None] * n)])
     ns = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
-    y = torch.empty((M, sum(w.shape[0] for w in ws)), dtype=torch.bfloat16, device="cuda")
-    nv.check(nv.lib().qt_linear_fqt_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
-                                         y.data_ptr(), M, K, stream()), "qt_linear_fqt_bf16")
+    N = sum(w.shape[0] for w in ws)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    if not split:
+        nv.check(nv.lib().qt_linear_fqt_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
+                                             y.data_ptr(), M, K, stream()), "qt_linear_fqt_bf16")
+        return y
+    ks, wb, nt = _fqt_plan(nv, M, N, K)
+    if "ws" not in _FQT_WS or _FQT_WS["ws"].numel() * 4 < wb or _FQT_WS["tickets"].numel() < nt:
+        _FQT_WS["ws"] = torch.empty((max(wb, 16) // 4,), dtype=torch.float32, device="cuda")
+        _FQT_WS["tickets"] = torch.zeros((max(nt, 1),), dtype=torch.int32, device="cuda")
+    nv.check(nv.lib().qt_linear_fqt_ws_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
+                                            y.data_ptr(), M, K, _FQT_WS["ws"].data_ptr(), _FQT_WS["ws"].numel() * 4,
+                                            _FQT_WS["tickets"].data_ptr(), _FQT_WS["tickets"].numel(), stream()), "qt_linear_fqt_ws_bf16")
+    assert not bool(_FQT_WS["tickets"].any())                  # every launch leaves its tickets zero
     return y
 
 
 @pytest.mark.parametrize("wdtype", ["posit8_1", "posit8_2", "int8", "fp6_e3m2", "fp4_e2m1", "posit8_0", "uint8", "fp8_e5m3", "e4m3"])
-@pytest.mark.parametrize("M", [512, 300])
-def test_linear_fqt_weight_values_are_the_value_map(nv, wdtype, M):
+@pytest.mark.parametrize("M,K", [(512, 512), (300, 512), (1536, 1536)])
+def test_linear_fqt_weight_values_are_the_value_map(nv, wdtype, M, K):
     """Identity activation: y[m][n] = fq(W)[n][m] -- one product per output, so the kernel's in-flight conversion of W (the row form
     of the map, and the redo path for the rows it flags) is compared bit for bit with the oracle's value map on ALL 65 536 bf16
-    patterns (rows 0..127 of W); rows holding +-Inf / NaN must come out all-NaN (0 * NaN).  M = 512 takes the 512-row tiles,
-    M = 300 (ragged) the 256-row ones."""
-    K = 512
+    patterns (the first 65 536 elements of W); rows holding +-Inf / NaN must come out all-NaN (0 * NaN).  M = 512 takes the 512-row
+    tiles, M = 300 (ragged) the 256-row ones, M = K = 1536 the split-K path (two workgroups per tile, 24 k steps each: partial sums
+    through the workspace, and the redo of a flagged tile decided by whichever workgroup draws the tile's last ticket)."""
     torch.manual_seed(1)
     W = (torch.randn(400, K, device="cuda") * 3).bfloat16()
-    W.view(torch.int16)[:128] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16).view(128, 512)
+    W.view(torch.int16).view(-1)[:65536] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16)
     eye = torch.eye(K, device="cuda").bfloat16()[:M] if M <= K else None
+    if K == 1536:
+        assert _fqt_plan(nv, M, 400, K)[0] == 2
     qmap = o.get_quantization_map(wdtype)
     bias = torch.randn(400, device="cuda").bfloat16()
     for sanitize in (True, False):
@@ -1731,7 +1755,11 @@ def test_linear_fqt_weight_values_are_the_value_map(nv, wdtype, M):
                                     (1024, [13824], 5120), (1024, [5120], 13824), (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120),
                                     (1024, [32000], 5120),
                                     # BERT-base (configs[0] / [1] shapes)
-                                    (6144, [768], 768), (6144, [3072], 768), (6144, [768], 3072)])
+                                    (6144, [768], 768), (6144, [3072], 768), (6144, [768], 3072),
+                                    # split-K (round 4): 2, 4 and 3 workgroups per tile, ragged rows, two weights, uneven k ranges
+                                    (1024, [1024], 2048), (1024, [2048], 3072), (777, [512, 512], 2400), (520, [1024], 3968),
+                                    # LLaMA-2-7B o / down under a table format
+                                    (1024, [4096], 4096), (1024, [4096], 11008)])
 @pytest.mark.parametrize("dtype", ["posit8_2", "int8"])
 def test_linear_fqt_vs_fp64_product_of_the_quantized_operands(nv, M, Ns, K, dtype):
     """Ragged M, both tile heights, column tiles spanning two weights, several weights per launch, bias: against the fp64 product of
@@ -1746,13 +1774,52 @@ def test_linear_fqt_vs_fp64_product_of_the_quantized_operands(nv, M, Ns, K, dtyp
     x = fq((torch.randn(M, K, device="cuda") * (1.0 if dtype != "int8" else 20.0)).bfloat16())
     ws = [(torch.randn(n, K, device="cuda") * (0.05 if dtype != "int8" else 3.0)).bfloat16() for n in Ns]
     bs = [torch.randn(n, device="cuda").bfloat16() if i % 2 == 0 else None for i, n in enumerate(Ns)]
-    y = _linear_fqt(nv, x, ws, dtype, bs).double()
+    y16 = _linear_fqt(nv, x, ws, dtype, bs)
+    # split-K adds the partial sums in split order, whoever arrives last: run to run bit-identical
+    assert torch.equal(y16.view(torch.int16), _linear_fqt(nv, x, ws, dtype, bs).view(torch.int16))
+    if _fqt_plan(nv, M, sum(Ns), K)[0] > 1:
+        # against the unsplit entry point: the same exact products, fp32 sums in another order
+        y1_16 = _linear_fqt(nv, x, ws, dtype, bs, split=False)
+        y1 = y1_16.double()
+        assert bool(((y16.double() - y1).abs() <= y1.abs() * 2.0 ** -7 + (xa_abs := x.double().abs().sum(dim=1, keepdim=True)) * 2.0 ** -20).all())
+        if dtype == "int8":
+            assert torch.equal(y16.view(torch.int16), y1_16.view(torch.int16))               # integer products: every order is exact
+    y = y16.double()
     xa = x.double()
     wa = torch.cat([fq(w).double() for w in ws])
     bias = torch.cat([b.double() if b is not None else torch.zeros(n, device="cuda", dtype=torch.float64) for b, n in zip(bs, Ns)])
     ref = xa @ wa.t() + bias
     tol = ref.abs() * 2.0 ** -8 + (xa.abs() @ wa.abs().t()) * 2.0 ** -18 + 1e-30
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
+
+
+def test_linear_fqt_split_k_plan_and_workspace_contract(nv):
+    """qt_linear_fqt_plan: no split for wide outputs or short K; 3 workgroups per tile at the 13B down projection, 4 at the 7B one;
+    qt_linear_fqt_ws_bf16 refuses a workspace smaller than the plan's instead of writing past it."""
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("plan figures are for 256 CUs")
+    assert _fqt_plan(nv, 1024, 15360, 5120) == (1, 0, 0)
+    assert _fqt_plan(nv, 1024, 5120, 512)[0] == 1                       # 16 k steps: too short to split
+    ks, wb, nt = _fqt_plan(nv, 1024, 5120, 13824)
+    assert (ks, nt) == (3, 80) and wb == 80 * 3 * 8 * 32 * 1024
+    assert _fqt_plan(nv, 1024, 4096, 11008)[0] == 4
+    f = _Fqt(nv, "posit8_1")
+    x = torch.zeros(1024, 2048, device="cuda", dtype=torch.bfloat16)
+    W = torch.zeros(1024, 2048, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(1024, 1024, device="cuda", dtype=torch.bfloat16)
+    ks, wb, nt = _fqt_plan(nv, 1024, 1024, 2048)
+    assert ks == 2
+    ws = torch.empty(wb // 4, dtype=torch.float32, device="cuda")
+    tk = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    wp = (ctypes.c_void_p * 1)(W.data_ptr())
+    ns = (ctypes.c_int * 1)(1024)
+    args = (x.data_ptr(), wp, None, ns, 1, f.rows.data_ptr(), 0, f.rp.sign_mask, f.map.data_ptr(), y.data_ptr(), 1024, 2048)
+    assert nv.lib().qt_linear_fqt_ws_bf16(*args, ws.data_ptr(), wb - 4, tk.data_ptr(), nt, stream()) == nv.QT_ERR_BAD_ARG
+    assert nv.lib().qt_linear_fqt_ws_bf16(*args, ws.data_ptr(), wb, tk.data_ptr(), nt - 1, stream()) == nv.QT_ERR_BAD_ARG
+    assert nv.lib().qt_linear_fqt_ws_bf16(*args, None, 0, None, 0, stream()) == nv.QT_ERR_BAD_ARG
+    assert nv.lib().qt_linear_fqt_ws_bf16(*args, ws.data_ptr(), wb, tk.data_ptr(), nt, stream()) == 0
+    torch.cuda.synchronize()
+    assert not bool(tk.any()) and not bool(y.any())
 
 
 def test_linear_fqt_rejects_what_it_does_not_take(nv):
@@ -1794,10 +1861,18 @@ def test_qat_linear_takes_the_fused_value_map_gemm(nv, dtype, monkeypatch):
     assert got.shape == ref.shape
     err = (got.float() - ref.float()).abs()
     assert float(err.max()) <= 2.0 ** -7 * float(ref.float().abs().max()) + 1e-6
-    assert fused.fqt_route_is_fused(1024, [15360], 5120, x.device) is False or True      # rule evaluates without timing anything
+    # the routing rule (a table of shapes, never a timing race) on the 256-CU part, for the five Linear shapes of BASELINE configs[3]
     monkeypatch.setenv("QT_FQT_GEMM", "auto")
-    assert fused.fqt_route_is_fused(1024, [5120], 5120, x.device) is False
-    assert fused.fqt_route_is_fused(1024, [5120, 5120, 5120], 5120, x.device) is True
+    if torch.cuda.get_device_properties(x.device).multi_processor_count == 256:
+        assert fused.fqt_route_is_fused(1024, [5120, 5120, 5120], 5120, x.device) is True       # q / k / v in one launch
+        assert fused.fqt_route_is_fused(1024, [15360], 5120, x.device) is True
+        assert fused.fqt_route_is_fused(1024, [32000], 5120, x.device) is True                  # lm head
+        assert fused.fqt_route_is_fused(1024, [5120], 13824, x.device) is True                  # down: split-K, 3 x 144 k steps
+        assert fused.fqt_plan(1024, 5120, 13824)[0] == 3
+        assert fused.fqt_route_is_fused(1024, [13824], 5120, x.device) is False                 # gate / up: 6.75-group tiles tie at best
+        assert fused.fqt_route_is_fused(1024, [5120], 5120, x.device) is False                  # o: 53 k steps per split do not pay
+        assert fused.fqt_route_is_fused(256, [15360], 5120, x.device) is False
+    assert isinstance(fused.fqt_route_is_fused(1024, [4096], 11008, x.device), bool)
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 11008, 512), (300, 96, 256), (520, 2064, 384), (1, 16, 128), (64, 4096, 1024),

@@ -435,3 +435,68 @@ def test_fusion_on_a_statically_shaped_export_with_the_rotary_matmul_quantized()
         got = gm(ids, labels=ids.clone())
     assert counts["attention"] == 1 and counts["linear"] == 8 and counts["shape_only_nodes"] >= 20
     assert torch.equal(got.logits, want.logits) and torch.equal(got.loss, want.loss)
+
+
+def test_fused_prepared_graph_keeps_the_prepared_graphs_state_dict():
+    """A checkpoint of a fused prepared graph has exactly the keys of the plain prepared graph (upstream's format): the fused helper
+    modules share Parameters and fake-quantizers with the graph and must not add `_qt_*` entries.  Strict loading works in both
+    directions, and the loaded calibration state (amax history, scale) is what the fused modules then use."""
+    from quantized_training import pt2e_fusion
+    spec = "int8,qs=per_tensor_symmetric"
+    plain, ids = _tiny_llama_prepared(spec)
+    fused, _ = _tiny_llama_prepared(spec)
+    with torch.no_grad():
+        plain(ids, labels=ids.clone(), use_cache=False)          # sizes the lazily built buffers, moves the observers
+        fused(ids, labels=ids.clone(), use_cache=False)
+    keys_plain = list(plain.state_dict().keys())
+    assert pt2e_fusion.fuse_prepared_graph(fused)["linear"] == 15
+    sd_fused = fused.state_dict()
+    assert list(sd_fused.keys()) == keys_plain and not [k for k in sd_fused if "_qt_" in k]
+    # fused -> plain: perturb the fused graph's state, save, load strictly into the plain graph
+    with torch.no_grad():
+        for name, buf in fused.named_buffers():
+            if name.endswith("scale") and "_qt_" not in name:
+                buf.mul_(2.0)
+    res = plain.load_state_dict(fused.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (ka, va), (kb, vb) in zip(plain.state_dict().items(), fused.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    # plain -> fused: strict load of a plain checkpoint into the fused graph; the fused modules see it (shared objects)
+    with torch.no_grad():
+        for name, buf in plain.named_buffers():
+            if name.endswith("scale"):
+                buf.mul_(0.25)
+    res = fused.load_state_dict(plain.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    short = torch.randint(0, 512, (1, 24))
+    with torch.no_grad():
+        a = fused(short, labels=short.clone(), use_cache=False)
+        b = plain(short, labels=short.clone(), use_cache=False)
+    assert torch.equal(a.logits, b.logits)
+    # unfusing removes the hooks with the helpers
+    assert pt2e_fusion.unfuse_prepared_graph(fused)
+    assert list(fused.state_dict().keys()) == keys_plain and "_qt_state_hooks" not in fused.__dict__
+
+
+def test_shape_memo_never_evicts_and_follows_its_constants():
+    """ShapeMemo keeps what it computed (a captured hipGraph may replay reads of those tensors), stops keeping past its cap instead of
+    evicting, and recomputes when a constant it reads is rewritten in place or moved."""
+    from quantized_training.pt2e_fusion import ShapeMemo
+
+    class Sub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("c", torch.ones(1), persistent=False)
+
+        def forward(self, n):
+            return (torch.arange(n) * self.c,)
+
+    memo = ShapeMemo(Sub())
+    first = memo(5)
+    assert memo(5) is first
+    for n in range(6, 6 + ShapeMemo.kMax + 8):
+        memo(n)
+    assert memo(5) is first and len(memo.__dict__["kept"]) == ShapeMemo.kMax       # nothing evicted; the surplus was not kept
+    memo.sub.c.mul_(3.0)
+    again = memo(5)
+    assert again is not first and float(again[0][1]) == 3.0

@@ -51,24 +51,44 @@ class Fmt:
         return y
 
 
-def linear_fqt(x, ws, f, biases=None):
+_WS = {}
+
+
+def plan(M, N, K):
+    ks, wb, nt = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _native.check(L.qt_linear_fqt_plan(M, N, K, ctypes.byref(ks), ctypes.byref(wb), ctypes.byref(nt)), "qt_linear_fqt_plan")
+    return ks.value, wb.value, nt.value
+
+
+def linear_fqt(x, ws, f, biases=None, split=True):
+    """split=True: qt_linear_fqt_ws_bf16 with the workspace its plan asks for; False: the entry point that never splits K."""
     M, K = x.shape
     n = len(ws)
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
     bp = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in (biases or [None] * n)])
     ns = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
-    y = torch.empty((M, sum(w.shape[0] for w in ws)), dtype=torch.bfloat16, device=DEV)
-    _native.check(L.qt_linear_fqt_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
-                                       y.data_ptr(), M, K, stream()), "qt_linear_fqt_bf16")
+    N = sum(w.shape[0] for w in ws)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    if not split:
+        _native.check(L.qt_linear_fqt_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
+                                           y.data_ptr(), M, K, stream()), "qt_linear_fqt_bf16")
+        return y
+    ks, wb, nt = plan(M, N, K)
+    if "ws" not in _WS or _WS["ws"].numel() * 4 < wb or _WS["tickets"].numel() < nt:
+        _WS["ws"] = torch.empty((max(wb, 16) // 4,), dtype=torch.float32, device=DEV)
+        _WS["tickets"] = torch.zeros((max(nt, 1),), dtype=torch.int32, device=DEV)
+    _native.check(L.qt_linear_fqt_ws_bf16(x.data_ptr(), wp, bp, ns, n, f.rows.data_ptr(), f.rp.signed_rows, f.rp.sign_mask, f.map.data_ptr(),
+                                          y.data_ptr(), M, K, _WS["ws"].data_ptr(), _WS["ws"].numel() * 4, _WS["tickets"].data_ptr(),
+                                          _WS["tickets"].numel(), stream()), "qt_linear_fqt_ws_bf16")
     return y
 
 
-def exact_check(f):
-    """x = identity: y[m][n] = fq(W)[n][m] exactly, for every bf16 pattern."""
-    K = 512
+def exact_check(f, K=512):
+    """x = identity: y[m][n] = fq(W)[n][m] exactly, for every bf16 pattern.  K = 1536 takes the split-K path (two workgroups per tile,
+    the flagged rows' redo decided by the tile's last arriver)."""
     torch.manual_seed(1)
     W = (torch.randn(400, K, device=DEV) * 3).bfloat16()
-    W.view(torch.int16)[:128] = torch.arange(65536, device=DEV, dtype=torch.int32).to(torch.int16).view(128, 512)
+    W.view(torch.int16).view(-1)[:65536] = torch.arange(65536, device=DEV, dtype=torch.int32).to(torch.int16)
     eye = torch.eye(K, device=DEV).bfloat16()
     bias = torch.randn(W.shape[0], device=DEV).bfloat16()
     ok = True
@@ -83,7 +103,7 @@ def exact_check(f):
         ok1 = bool(same[~bad_rows].all()) and bool(torch.isnan(y[bad_rows].float()).all())
         yb = linear_fqt(eye, [Wt], f, [bias]).t().contiguous()
         ok2 = torch.equal((want.float() + bias.float()[:, None]).bfloat16()[~bad_rows].view(torch.int16), yb[~bad_rows].view(torch.int16))
-        print(f"exact {f.dtype} sanitized={sanitize}: identity-activation parity {ok1} (mismatches {int((~same[~bad_rows]).sum())}), with bias {ok2}, "
+        print(f"exact {f.dtype} K={K} (ksplit {plan(K, 400, K)[0]}) sanitized={sanitize}: identity-activation parity {ok1} (mismatches {int((~same[~bad_rows]).sum())}), with bias {ok2}, "
               f"rows holding NaN {int(bad_rows.sum())}, flagged table rows {f.rp.n_flagged}", flush=True)
         ok = ok and ok1 and ok2
     return ok
@@ -94,7 +114,11 @@ def accuracy(M, Ns, K, f, scale=0.05):
     x = f.fq(torch.randn(M, K, device=DEV).bfloat16())
     ws = [(torch.randn(n, K, device=DEV) * scale).bfloat16() for n in Ns]
     bs = [torch.randn(n, device=DEV).bfloat16() if i % 2 == 0 else None for i, n in enumerate(Ns)]
-    y = linear_fqt(x, ws, f, bs).double()
+    y16 = linear_fqt(x, ws, f, bs)
+    again = linear_fqt(x, ws, f, bs)
+    det = torch.equal(y16.view(torch.int16), again.view(torch.int16))           # split-K sums in split order: run-to-run identical
+    clean = "tickets" not in _WS or not bool(_WS["tickets"].any())              # every launch leaves its tickets zero
+    y = y16.double()
     xa = x.double()
     wa = torch.cat([f.fq(w).double() for w in ws])
     bias = torch.cat([b.double() if b is not None else torch.zeros(n, device=DEV, dtype=torch.float64) for b, n in zip(bs, Ns)])
@@ -103,8 +127,9 @@ def accuracy(M, Ns, K, f, scale=0.05):
     err = (y - ref).abs()
     tol = ref.abs() * 2.0 ** -8 + bound * 2.0 ** -18 + 1e-30       # one bf16 rounding + fp32 accumulation
     rel = float((err / tol).max())
-    print(f"accuracy {f.dtype} {M}x{sum(Ns)}x{K}: max err / tolerance = {rel:.3f}  (max |err| {float(err.max()):.3e})", flush=True)
-    return rel <= 1.0
+    print(f"accuracy {f.dtype} {M}x{sum(Ns)}x{K} (ksplit {plan(M, sum(Ns), K)[0]}): max err / tolerance = {rel:.3f}  (max |err| {float(err.max()):.3e})  "
+          f"deterministic {det}  tickets zero {clean}", flush=True)
+    return rel <= 1.0 and det and clean
 
 
 def timeit(fn, iters):
@@ -133,6 +158,9 @@ def bench(M, Ns, K, iters, f):
     def fused(i):
         return linear_fqt(x, wsets[i % pool], f)
 
+    def unsplit(i):
+        return linear_fqt(x, wsets[i % pool], f, split=False)
+
     def two_kernel(i):
         W = wcat[i % pool]
         _native.check(L.qt_fake_quant_bf16(W.data_ptr(), wq.data_ptr(), W.numel(), ctypes.byref(f.fmt), f.map.data_ptr(), one.data_ptr(), None,
@@ -143,10 +171,12 @@ def bench(M, Ns, K, iters, f):
         return torch.nn.functional.linear(x, wcat[i % pool])
 
     t_f = timeit(fused, iters)
+    ks = plan(M, N, K)[0]
+    t_u = timeit(unsplit, iters) if ks > 1 else t_f
     t_2 = timeit(two_kernel, iters)
     t_g = timeit(gemm_only, iters)
     flops = 2.0 * M * N * K
-    print(f"bench {f.dtype} {M}x{N}x{K} (segments {Ns}): fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s = {flops / t_f / 1e6 / 2500:.3f} of bf16 peak)   "
+    print(f"bench {f.dtype} {M}x{N}x{K} (segments {Ns}, ksplit {ks}): unsplit {t_u:7.1f} us   fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s = {flops / t_f / 1e6 / 2500:.3f} of bf16 peak)   "
           f"pass + library {t_2:7.1f} us   library GEMM alone {t_g:7.1f} us   speed-up {t_2 / t_f:.2f}x", flush=True)
     return t_f, t_2
 
@@ -164,9 +194,12 @@ def main():
     if not args.skip_checks:
         for d in args.dtypes.split(","):
             ok &= exact_check(fmts[d])
+            ok &= exact_check(fmts[d], K=1536)
         for d in args.dtypes.split(",")[:3]:
             for (M, Ns, K) in ((1024, [4096], 1024), (1024, [176], 256), (300, [48, 64, 16], 384), (1, [16], 64), (777, [2048, 512, 512], 512),
-                               (257, [208, 4096 - 208], 128)):
+                               (257, [208, 4096 - 208], 128),
+                               # split-K: 2, 4 and 3 workgroups per tile, ragged rows, several weights, uneven k ranges
+                               (1024, [1024], 2048), (1024, [2048], 3072), (777, [512, 512], 2400), (520, [1024], 4000 - 32)):
                 ok &= accuracy(M, Ns, K, fmts[d])
     s13 = [(1024, [13824], 5120), (1024, [5120], 13824), (1024, [5120], 5120), (1024, [5120, 5120, 5120], 5120), (1024, [32000], 5120)]
     s7 = [(1024, [11008], 4096), (1024, [4096], 11008), (1024, [4096], 4096), (1024, [4096, 4096, 4096], 4096), (1024, [32000], 4096)]
