@@ -73,6 +73,8 @@ def parse():
                     help="debug: initialise torch.distributed (nccl) and take the multi-rank code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the three short secondary legs (the other BASELINE configs that fit one GPU) appended to the default line")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: tiny LLaMA on the CPU, gloo instead of RCCL, same sharding / timing / "
                          "gather code (the line is marked invalid)")
@@ -105,6 +107,41 @@ def launch_ranks(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+SECONDARY = ("bert-base-squad-e4m3", "llama-13b-posit8_2", "roberta-mrpc-int8-e5m2-train")
+
+
+def secondary_legs(budget_s=150.0):
+    """The other BASELINE.json configs that fit one GPU, three timed steps each, AFTER the headline leg (which alone is `value`): each
+    one runs as a child process of its own (`bench.py --workload ...`: model built, timed, freed), so the driver's default command
+    times them too.  A leg that fails or runs out of budget is reported as such, never fatal."""
+    import subprocess
+    out = {}
+    t_all = time.perf_counter()
+    for w in SECONDARY:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 20.0:
+            out[w] = {"error": "skipped: time budget of the secondary legs spent"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 90.0))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[w] = {"error": f"rc {r.returncode}: {r.stderr.strip()[-200:]}"}
+                continue
+            j = json.loads(line[-1])
+            out[w] = {"ms_per_step": round(j["ms_per_step"], 4), "steps": j["steps"], "elements_per_step": j["config"]["elements_per_step"],
+                      "value": j["value"], "unit": j["unit"], "launch": j["config"]["launch"], "routes": j["config"].get("routes", {}),
+                      "workload": j["config"]["workload"]}
+            if "mean_window_nll" in j:
+                out[w]["mean_window_nll"] = j["mean_window_nll"]
+        except subprocess.TimeoutExpired:
+            out[w] = {"error": "timeout"}
+        except Exception as e:  # noqa: BLE001
+            out[w] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def profiled_traffic(key):
@@ -616,6 +653,9 @@ def main():
                     out["roofline"] = leg
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(a.weight, model_shape)
+        if (world == 1 and not multi and not a.no_secondary and not a.dry_run and a.workload == "llama-7b-e4m3" and a.route == "eager"
+                and a.layers is None and a.model == "llama-2-7b" and not a.cache_eval_weights):
+            out["secondary"] = secondary_legs()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -162,10 +162,15 @@ def prepare_pt2e_causal_lm(model, activation, weight, max_length: int, bias=None
     return gm
 
 
+def _group_ready() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_in_order(local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
     """All ranks hold values for units rank, rank+world, ...; returns all n_total values in unit order.
-    One all_gather of a padded fp32 vector (<= a few KB): latency-bound, not bandwidth-bound."""
-    if world == 1:
+    One all_gather of a padded fp32 vector (<= a few KB): latency-bound, not bandwidth-bound.  With an initialised process group
+    the collective runs even for one rank (the same RCCL / gloo call path as N ranks); without one, a single rank returns its values."""
+    if world == 1 and not _group_ready():
         return local
     per = (n_total + world - 1) // world
     buf = torch.full((per,), float("nan"), dtype=torch.float32, device=local.device)
@@ -308,7 +313,7 @@ def collect_qa_logits(model, batches, device=None, rank: int = 0, world: int = 1
         out = model(**batch, start_positions=pos, end_positions=pos.clone())
         starts.append(out.start_logits.float())
         ends.append(out.end_logits.float())
-    if world == 1:
+    if world == 1 and not _group_ready():
         return torch.cat(starts).cpu(), torch.cat(ends).cpu()
     seq = batches[0]["input_ids"].shape[1]
     sizes = [b["input_ids"].shape[0] for b in batches]

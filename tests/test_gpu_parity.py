@@ -5,6 +5,7 @@ the GEMMs are compared within an fp32-accumulation tolerance stated in the test.
 Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 """
 import ctypes
+import math
 import json
 import os
 
@@ -752,6 +753,51 @@ def test_fused_attention_kernel(nv, B, H, Sq, Sk, D, mask_kind, pdtype):
                                                 None, None, stream()), "attention")
                 outs.append(o2)
             assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), dt
+
+
+@pytest.mark.parametrize("B,H,S,D", [(1, 40, 1024, 128), (2, 5, 256, 128)])
+def test_fused_attention_kernel_on_posit8_2_inputs_in_row_form(nv, B, H, S, D):
+    """BASELINE configs[3]'s own attention core (parity gap 1): posit(8,2)-VALUED q / k / v (the rotary producer's
+    output format there), the probabilities' fake-quantizer posit(8,2) in its ROW FORM (what fake_quantize._launch_format hands the
+    kernel in the window), 40 heads x 1024 x 1024, causal -- against oracle.attention_fq, not against another path of the same
+    kernel.  Both launch forms: with the mask read, and with the mask's row extents (qt_attention_fq_live_bf16, the window's)."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    torch.manual_seed(3 + H)
+    qmap = o.get_quantization_map("posit8_2")
+    qmap_dev = torch.from_numpy(qmap.view(np.int16)).cuda().view(torch.bfloat16)
+    fqin = lambda t: qmap_dev[(t.view(torch.int16).to(torch.int32) & 0xFFFF).long()]  # noqa: E731
+    q = fqin((torch.randn(B, H, S, D, device="cuda") * 1.5).bfloat16())
+    k = fqin((torch.randn(B, H, S, D, device="cuda") * 1.5).bfloat16())
+    v = fqin((torch.randn(B, H, S, D, device="cuda")).bfloat16())
+    scaling = D ** -0.5
+    minv = torch.finfo(torch.bfloat16).min
+    mask = torch.full((S, S), minv, device="cuda").triu(1).bfloat16()[None, None]
+    m = qt.get_quantization_map("posit8_2", torch.device("cuda"))
+    f_rows = _launch_format(nv.format_for("posit8_2"), m)
+    assert f_rows.p1 & 1                                                        # the row form is what runs
+    out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device="cuda")
+    nv.check(L.qt_attention_fq_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mask.data_ptr(), out.data_ptr(), B, H, S, S, D, 0, 0, mask.stride(2),
+                                    scaling, ctypes.byref(f_rows), m.data_ptr(), None, None, stream()), "attention")
+    rl = torch.empty(S + 1, dtype=torch.int32, device="cuda")
+    nv.check(L.qt_mask_row_live_checked(mask.data_ptr(), S, S, S, rl.data_ptr(), rl.data_ptr() + 4 * S, stream()), "row_live")
+    live = torch.empty_like(out)
+    nv.check(L.qt_attention_fq_live_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mask.data_ptr(), live.data_ptr(), B, H, S, S, D, 0, 0, mask.stride(2),
+                                         scaling, ctypes.byref(f_rows), m.data_ptr(), None, None, 0, rl.data_ptr(), 0, 0, 1,
+                                         rl.data_ptr() + 4 * S, stream()), "attention live")
+    torch.cuda.synchronize()
+    assert int(rl[-1]) == 0 and torch.equal(out.view(torch.int16), live.view(torch.int16))
+    u16 = lambda t: host_u16(t.contiguous().view(torch.int16))  # noqa: E731
+    exp, pq = o.attention_fq(u16(q), u16(k), u16(v), u16(mask), scaling, qmap)
+    got = u16(out.permute(0, 2, 1, 3))
+    differ = float((got != exp).mean())
+    assert differ <= 2e-3, differ
+    ev = o.bf16_to_f32(exp)
+    err = np.abs(o.bf16_to_f32(got) - ev) / (np.abs(ev).max(axis=-1, keepdims=True) + 1e-30)
+    assert float(err.max()) <= 0.08, float(err.max())
+    # every quantized probability the oracle produced is a posit(8,2) value (the map is idempotent on its image)
+    assert np.array_equal(o.vmap_bf16(pq.reshape(-1)[:: 97], qmap), pq.reshape(-1)[:: 97])
 
 
 def test_llama_fused_attention_vs_module_chain(nv):
@@ -1607,6 +1653,47 @@ def _linear_fq8(nv, x8, xdtype, ws, wdtype, biases=None):
     nv.check(nv.lib().qt_linear_fq8_bf16(x8.data_ptr(), F8_CODE[xdtype], wp, bp, ns, n, F8_CODE[wdtype], y.data_ptr(), M, K,
                                          stream()), "qt_linear_fq8_bf16")
     return y
+
+
+@pytest.mark.parametrize("xdtype,wdtype,big", [("e4m3", "e4m3", 448.0), ("e5m2", "e5m2", 57344.0), ("e4m3", "e5m2", 448.0)])
+@pytest.mark.parametrize("K", [128, 1024, 4096])
+def test_linear_fq8_worst_case_cancellation(nv, xdtype, wdtype, big, K, capsys):
+    """The scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4) adds its 128 products in a fixed-point tree that keeps fewer
+    bits than the reference's fp32 chain (deviation 5).  Worst case for such a tree: products of the largest magnitude
+    the format has with ALTERNATING signs -- they cancel exactly -- next to products thousands of times smaller that carry the
+    result.  Rows: (a) pure cancellation (exact result 0), (b) cancellation + a small tail, (c) cancellation + one product at the
+    bottom of the format.  The error must stay inside the bound the GEMM tests use, 2^-14 sum |a||b|; the measured ratio is printed
+    (pytest -s) and recorded in DESIGN.md."""
+    torch.manual_seed(K)
+    M, N = 64, 64
+    sign = torch.ones(K, device="cuda")
+    sign[1::2] = -1.0
+    x = (sign * big).repeat(M, 1)
+    w = torch.full((N, K), 1.0, device="cuda") * (448.0 if wdtype == "e4m3" else 57344.0)
+    # rows 16.. of x: the last 32 products are small (x tiny, w of order one): they carry the result
+    x[:16, K - 32:] = 0.0
+    x[16:, K - 32:] = torch.randn(M - 16, 32, device="cuda") * 2.0 ** -4
+    w[:, K - 32:] = torch.randn(N, 32, device="cuda")
+    # rows 32..: one more product at the bottom of the activation format
+    x[32:, K - 31] = 2.0 ** -9 if xdtype == "e4m3" else 2.0 ** -16
+    w[:, K - 31] = 1.0
+    x, w = x.bfloat16(), w.bfloat16()
+    x8 = _codes_of(nv, x, xdtype)
+    y = _linear_fq8(nv, x8, xdtype, [w], wdtype).double()
+    qx, qw = o.get_quantization_map(xdtype), o.get_quantization_map(wdtype)
+    xa = torch.from_numpy(o.bf16_to_f32(o.vmap_bf16(host_u16(x.view(torch.int16)), qx))).cuda().double()
+    wa = torch.from_numpy(o.bf16_to_f32(o.vmap_bf16(host_u16(w.view(torch.int16)), qw))).cuda().double()
+    ref = xa @ wa.t()
+    bound = xa.abs() @ wa.abs().t()
+    assert bool((ref[:16] == 0).all())                                          # (a): exact cancellation
+    err = (y - ref).abs()
+    ratio = float((err / bound).max())
+    with capsys.disabled():
+        print(f"\n[fq8 cancellation] {xdtype} x {wdtype} K={K}: max |err| / sum|a||b| = 2^{math.log2(ratio) if ratio > 0 else float('-inf'):.1f}, "
+              f"max |err| {float(err.max()):.4g} at |products| {big * float(wa.abs().max()):.4g}")
+    tol = ref.abs() * 2.0 ** -8 + bound * 2.0 ** -14
+    assert bool((err <= tol).all()), ratio
+    assert bool((y[:16] == 0).all())                                            # the tree cancels equal magnitudes exactly
 
 
 @pytest.mark.parametrize("xdtype,wdtype", [("e4m3", "e4m3"), ("e5m2", "e5m2"), ("e4m3", "e5m2"), ("e5m2", "e4m3")])

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
 cat gpurun_out/bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/prof_bench.log 2>&1
 python tools/window_breakdown.py gpurun_out/prof_bench --windows 5 > gpurun_out/window_breakdown.txt 2>&1
 cat gpurun_out/window_breakdown.txt | head -40
 if [ "$1" != "quick" ]; then
