@@ -169,6 +169,24 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_d
  * share an input (q / k / v projections), feeding one concatenated FP8 GEMM.  xs / ns are host arrays. */
 int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs_dev, const size_t *ns, int count, uint8_t *y8_dev,
                                  const qt_format *fmt, void *stream);
+
+/* Many per-tensor fake-quant calls of ONE format as one launch: item i is `qt_fake_quant_bf16(x, y, 8 * nvec, fmt, lut, scale, amax)`
+ * with its own scale and amax slot (fake_quantize.py:230-246 per tensor, unchanged).  For the weight fake-quantizers of a training
+ * step (modules/qat/linear.py:40-41 issues one per Linear and forward; run_glue_no_trainer.py:647-667): the weights do not change
+ * between the start of a step and its optimizer update, so the caller may run all of them first.  items_dev: DEVICE array of
+ * `count` items, tensors 16-byte aligned bf16 with 8 | n; `first_tile` = sum over earlier items of ceil(nvec / 1024) and
+ * total_tiles the sum over all (the launch geometry, computed by the caller once); amax_bits NULL = not observed.  Formats: intN,
+ * e4m3 / e5m2 closed forms, and table formats whose map carries the row form (qt_format.p1 bit 0). */
+typedef struct qt_fq_item {
+    const void *x_bf16;
+    void *y_bf16;
+    const float *scale_f32;
+    uint32_t *amax_bits;
+    unsigned long long nvec;
+    unsigned long long first_tile;
+} qt_fq_item;
+int qt_fake_quant_multi_bf16(const qt_fq_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt,
+                             const uint16_t *lut_dev, void *stream);
 int qt_fake_quant_rows_bf16(const uint16_t *x_dev, uint16_t *y_dev, long d0, long d1, long d2, long inner,
                             long s0, long s1, long s2, const qt_format *fmt, const uint16_t *lut_dev,
                             const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);

@@ -478,8 +478,11 @@ static int attention_fq_launch(const uint16_t *q, const uint16_t *k, const uint1
     }
     if (out_fq && (scale || fmt->kind == QT_FMT_IDENTITY)) return QT_ERR_BAD_ARG;      // unit scale, a real format
     // causal-style masks make late query blocks heavier: balance the slots when the grid is not a multiple that the mirrored order
-    // already serves (QT_ATTN_SNAKE=0 keeps the mirrored order)
-    static const int snake_mode = getenv("QT_ATTN_SNAKE") ? atoi(getenv("QT_ATTN_SNAKE")) : 1;
+    // already serves
+    int snake_mode = 1;
+#ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_ATTN_SNAKE")) snake_mode = atoi(e);     // tools/ only: 0 keeps the mirrored order
+#endif
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const long total = (long)((Sq + kBQ - 1) / kBQ) * B * H;

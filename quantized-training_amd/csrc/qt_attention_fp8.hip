@@ -33,7 +33,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kD = 128, kBlock = 128, kMaxBlocks = 8, kBuf = kBlock * kD;       // one K / V^T block: 16 KiB of codes
+constexpr int kBlock = 128, kMaxBlocks = 8;                                    // one K / V^T block: 128 keys x 128 B = 16 KiB of codes
 constexpr int kUnit = 127;                                                        // E8M0 2^0
 
 struct AttnArgs {
@@ -66,192 +66,13 @@ __device__ __forceinline__ void dma16(const uint8_t *src, uint32_t dst) {
 
 // F: operand format of q, k, v and p (0 = E4M3, 1 = E5M2)
 //
-// A workgroup = 8 waves takes TWO blocks of 64 query rows of one (batch, head): waves 0-3 the x-th block from the end, waves 4-7 the
-// x-th from the start.  Both walk the same K / V blocks, so each block is fetched once for the two; under a causal mask the second
-// group simply has fewer live key blocks and sits out the rest (it still joins the barriers).  Every workgroup then carries about the
-// same work -- all workgroups of a launch are resident at once, so the launch lasts as long as its heaviest one -- and every SIMD has
-// one wave of each group.
-template <int F>
-__global__ __launch_bounds__(512, 1) void attention_fp8_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r = l & 15, g = l >> 4, grp = w >> 2, wq = w & 3;
-    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int nkb = a.Sk / kBlock, nqb = (a.Sq + 63) / 64;
-    const int qb_heavy = nqb - 1 - (int)blockIdx.x, qb_light = (int)blockIdx.x;
-    const int qb = grp == 0 ? qb_heavy : qb_light;
-    const bool idle = grp == 1 && qb_light >= qb_heavy;                    // odd count: the middle block belongs to group 0 alone
-    const int q0 = qb * 64;
-    const int qrow = q0 + wq * 16 + r, qc = min(qrow, a.Sq - 1);
-    // key blocks that hold an unmasked column for at least one of a group's 64 rows (a fully masked row counts as all)
-    auto live_blocks = [&](int qblock) {
-        if (!a.row_live) return nkb;
-        const int qq = min(qblock * 64 + l, a.Sq - 1);
-        int lv = a.row_live[b * a.lsb + h * a.lsh + qq * a.lsq];
-        if (lv <= 0) lv = a.Sk;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) lv = max(lv, __shfl_xor(lv, off, 64));
-        return min(nkb, (lv + kBlock - 1) / kBlock);
-    };
-    const int nl_heavy = live_blocks(qb_heavy), nl_light = qb_light >= qb_heavy ? 0 : live_blocks(qb_light);
-    const int nmax = max(nl_heavy, nl_light);                              // blocks the workgroup walks
-    const int nlive = idle ? 0 : (grp == 0 ? nl_heavy : nl_light);         // blocks this wave multiplies
-    const uint32_t l0 = lds_addr(lds);
-    // DMA pieces of this wave: 8 rows x 128 bytes each, rows 16 w + 8 i + (l >> 3), 16-byte slot l & 7 (swizzled by the row)
-    const uint8_t *kp[2], *vp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (w * 2 + i) * 8 + (l >> 3), slot = l & 7, sw = ((slot ^ ((row >> 1) & 7)) << 4);
-        kp[i] = a.k8 + ((long)bh * a.Sk + row) * kD + sw;                   // + block * 128 * 128
-        vp[i] = a.vt8 + ((long)bh * kD + row) * a.Sk + sw;                  // + block * 128
-    }
-    auto issue_k = [&](int kb, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(kp[i] + (long)kb * kBuf, l0 + buf * kBuf + (w * 2 + i) * 1024);
-    };
-    auto issue_v = [&](int kb, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(vp[i] + (long)kb * kBlock, l0 + buf * kBuf + (w * 2 + i) * 1024);
-    };
-    // the query fragment: row r, bytes 16 g .. and 64 + 16 g ..
-    const uint8_t *qp = a.q8 + ((long)bh * a.Sq + qc) * kD;
-    const u32x4 qlo = *(const u32x4 *)(qp + 16 * g), qhi = *(const u32x4 *)(qp + 64 + 16 * g);
-    const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
-    const bool simple = a.mask && a.row_live && (a.mask_simple || (a.mask_irregular && *a.mask_irregular == 0));
-    const uint16_t *mrow = (a.mask && !simple) ? a.mask + b * a.msb + h * a.msh + (long)qc * a.msq + 4 * g : nullptr;
-    const int my_live = simple ? a.row_live[b * a.lsb + h * a.lsh + qc * a.lsq] : 0;      // this lane's row: keys >= my_live are masked
-    const int f_lo = chunk_off(r, g), f_hi = chunk_off(r, 4 + g);          // fragment of tile 0: tile i is 2048 bytes further
-
-    uint32_t sc[kMaxBlocks][8][2];                                          // the strip: bf16(bf16(score * scaling) + mask), packed pairs
-    float mx = -INFINITY;
-    // ---- sweep 1: scores
-    issue_k(0, 0);
-#pragma unroll
-    for (int kb = 0; kb < kMaxBlocks; ++kb) {
-        if (kb < nmax) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                  // block kb has landed; everyone is done with block kb - 1
-            if (kb + 1 < nmax) issue_k(kb + 1, (kb + 1) & 1);
-            if (kb < nlive) {
-                const uint8_t *blk = lds + (kb & 1) * kBuf;
-#pragma unroll
-                for (int ti = 0; ti < 8; ++ti) {
-                    const u32x4 klo = *(const u32x4 *)(blk + ti * 2048 + f_lo), khi = *(const u32x4 *)(blk + ti * 2048 + f_hi);
-                    const v8i kf = {(int)klo.x, (int)klo.y, (int)klo.z, (int)klo.w, (int)khi.x, (int)khi.y, (int)khi.z, (int)khi.w};
-                    const v4f s = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kf, qf, v4f{0.f, 0.f, 0.f, 0.f}, F, F, 0, kUnit, 0, kUnit);
-                    uint32_t w0 = pack_bf16x2(s[0], s[1]), w1 = pack_bf16x2(s[2], s[3]);                 // the matmul's bf16 output
-                    w0 = pack_bf16x2(blo(w0) * a.scaling, bhi(w0) * a.scaling);
-                    w1 = pack_bf16x2(blo(w1) * a.scaling, bhi(w1) * a.scaling);
-                    if (mrow) {
-                        const uint2 m = *(const uint2 *)(mrow + kb * kBlock + ti * 16);
-                        w0 = pack_bf16x2(blo(w0) + blo(m.x), bhi(w0) + bhi(m.x));
-                        w1 = pack_bf16x2(blo(w1) + blo(m.y), bhi(w1) + bhi(m.y));
-                    } else if (simple) {
-                        // x + 0 = x; bf16(x + min) = min for every finite x (NaN stays NaN): the mask's effect without reading it
-                        const int key = kb * kBlock + ti * 16 + 4 * g;
-                        if (key + 3 >= my_live) {
-                            const uint32_t lo0 = w0 & 0xFFFFu, hi0 = w0 >> 16, lo1 = w1 & 0xFFFFu, hi1 = w1 >> 16;
-                            auto sel = [&](uint32_t bits, int kk) { return (kk < my_live || (bits & 0x7FFFu) > 0x7F80u) ? bits : 0xFF7Fu; };
-                            w0 = sel(lo0, key) | (sel(hi0, key + 1) << 16);
-                            w1 = sel(lo1, key + 2) | (sel(hi1, key + 3) << 16);
-                        }
-                    }
-                    sc[kb][ti][0] = w0;
-                    sc[kb][ti][1] = w1;
-                    mx = fmaxf(mx, fmaxf(fmaxf(blo(w0), bhi(w0)), fmaxf(blo(w1), bhi(w1))));
-                }
-            }
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // ---- row sum of exp(t - max); a tile whose four logits all lie more than 110 below the maximum contributes exactly 0
-    const float cut = mx - 110.0f;
-    float sum = 0.0f;
-#pragma unroll
-    for (int kb = 0; kb < kMaxBlocks; ++kb) {
-        if (kb < nlive) {
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti) {
-                const float v0 = blo(sc[kb][ti][0]), v1 = bhi(sc[kb][ti][0]), v2 = blo(sc[kb][ti][1]), v3 = bhi(sc[kb][ti][1]);
-                if (!((v0 < cut) & (v1 < cut) & (v2 < cut) & (v3 < cut)))
-                    sum += __expf(v0 - mx) + __expf(v1 - mx) + __expf(v2 - mx) + __expf(v3 - mx);
-            }
-        }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    // ---- sweep 2: probabilities -> codes -> P.V
-    v4f acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_barrier();                                          // every wave is out of sweep 1: the buffers are free
-    issue_v(0, 0);
-#pragma unroll
-    for (int kb = 0; kb < kMaxBlocks; ++kb) {
-        if (kb < nmax) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kb + 1 < nmax) issue_v(kb + 1, (kb + 1) & 1);
-            if (kb < nlive) {
-                uint32_t pd[8];
-                uint32_t nz = 0;
-#pragma unroll
-                for (int ti = 0; ti < 8; ++ti) {
-                    const float v0 = blo(sc[kb][ti][0]), v1 = bhi(sc[kb][ti][0]), v2 = blo(sc[kb][ti][1]), v3 = bhi(sc[kb][ti][1]);
-                    uint32_t code = 0;
-                    if (!((v0 < cut) & (v1 < cut) & (v2 < cut) & (v3 < cut))) {
-                        const uint32_t p0 = pack_bf16x2(__expf(v0 - mx) * inv, __expf(v1 - mx) * inv);   // probabilities, bf16
-                        const uint32_t p1 = pack_bf16x2(__expf(v2 - mx) * inv, __expf(v3 - mx) * inv);
-                        code = qt_pack_fp8x4<F == 1>(blo(p0), bhi(p0), blo(p1), bhi(p1));                // fq_p: exact for a value in [0, 1]
-                    }
-                    pd[ti] = code;
-                    nz |= code;
-                }
-                if (__any(nz != 0)) {
-                    const v8i pf = {(int)pd[0], (int)pd[1], (int)pd[2], (int)pd[3], (int)pd[4], (int)pd[5], (int)pd[6], (int)pd[7]};
-                    const uint8_t *blk = lds + (kb & 1) * kBuf;
-#pragma unroll
-                    for (int dt = 0; dt < 8; ++dt) {
-                        const u32x4 vlo = *(const u32x4 *)(blk + dt * 2048 + f_lo), vhi = *(const u32x4 *)(blk + dt * 2048 + f_hi);
-                        const v8i vf = {(int)vlo.x, (int)vlo.y, (int)vlo.z, (int)vlo.w, (int)vhi.x, (int)vhi.y, (int)vhi.z, (int)vhi.w};
-                        acc[dt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, pf, acc[dt], F, F, 0, kUnit, 0, kUnit);
-                    }
-                }
-            }
-        }
-    }
-    // ---- output: lane (r, g) of d tile dt holds out[query r][d = 16 dt + 4 g .. + 3]
-    if (!idle && qrow < a.Sq) {
-        const long o0 = (((long)b * a.Sq + qrow) * a.H + h) * kD + 4 * g;
-        uint16_t *orow = a.out + o0;
-        if (a.out8) {
-            const bool oe5 = a.out_fmt.p0 == 2;
-#pragma unroll
-            for (int dt = 0; dt < 8; dt += 2) {
-                uint32_t o[4] = {pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3]),
-                                 pack_bf16x2(acc[dt + 1][0], acc[dt + 1][1]), pack_bf16x2(acc[dt + 1][2], acc[dt + 1][3])};
-                const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);     // o: now fq(values)
-                *(uint2 *)(orow + dt * 16) = uint2{o[0], o[1]};
-                *(uint2 *)(orow + dt * 16 + 16) = uint2{o[2], o[3]};
-                *(uint32_t *)(a.out8 + o0 + dt * 16) = codes.x;
-                *(uint32_t *)(a.out8 + o0 + dt * 16 + 16) = codes.y;
-            }
-        } else {
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
-                *(uint2 *)(orow + dt * 16) = uint2{pack_bf16x2(acc[dt][0], acc[dt][1]), pack_bf16x2(acc[dt][2], acc[dt][3])};
-        }
-    }
-}
-
-// ---- variant 2: the two wave groups split the KEYS of one block of 64 query rows ---------------------------------------------
+// ---- the kernel: the two wave groups split the KEYS of one block of 64 query rows ---------------------------------------------
 // Of every 128-key block group 0 takes tiles 0-3 (keys 0 .. 63) and group 1 tiles 4-7, so the two always carry the same work; an
 // iteration walks a PAIR of blocks, which gives each wave 8 score tiles = the 128 probabilities one P.V instruction contracts (its
 // low half from the first block, its high half from the second: with the slot <-> key permutation of the V^T blocks the group's tiles
 // are exactly the low (group 0) or high (group 1) 16-byte chunks of a lane's fragment).  A wave's strip is at most 4 x 8 tiles, which
-// leaves room to keep it in fp32: each exponential is evaluated once (variant 1 keeps bf16 logits and evaluates exp twice).  The row
+// leaves room to keep it in fp32: each exponential is evaluated once (round 2's first kernel -- two blocks of rows per workgroup,
+// bf16 logits, exp evaluated in both sweeps: 35 against 21 us -- was removed in round 4).  The row
 // maximum and sum and the partial P.V sums of the two groups meet in LDS.
 //
 // Control flow is wave-uniform throughout (extents are scalars), so the four tiles of a half-block form one basic block the
@@ -650,13 +471,6 @@ int qt_attention_fp8(const uint8_t *q8_dev, const uint8_t *k8_dev, const uint8_t
                out_dev, H, Sq, Sk, scaling, out8_dev, out8_dev ? *out_format : qt_format{}, mask_irregular_dev};
     const int nqb = (Sq + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    const char *e_var = getenv("QT_FP8_ATTENTION_VARIANT");               // 1: two blocks of rows per workgroup (head_dim 128 only); 2 (default): keys split over the groups
-    if (e_var && atoi(e_var) == 1 && head_dim == 128) {
-        const dim3 grid((unsigned)((nqb + 1) / 2), (unsigned)(B * H));
-        if (operand_format == 0) attention_fp8_kernel<0><<<grid, 512, 2 * kBuf, st>>>(a);
-        else attention_fp8_kernel<1><<<grid, 512, 2 * kBuf, st>>>(a);
-        return status();
-    }
     if (head_dim == 128) return operand_format == 0 ? launch_split<0, 128>(a, B * H, nqb, st) : launch_split<1, 128>(a, B * H, nqb, st);
     return operand_format == 0 ? launch_split<0, 64>(a, B * H, nqb, st) : launch_split<1, 64>(a, B * H, nqb, st);
 }

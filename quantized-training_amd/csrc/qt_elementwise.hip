@@ -427,6 +427,76 @@ __global__ __launch_bounds__(256) void fq8_multi_kernel(MultiArgs a, uint4 *__re
     }
 }
 
+// ---- many tensors, one launch: every weight fake-quantizer of a training step (harness.GraphedTrainStep) ---------------
+// A RoBERTa-base step fake-quantizes 74 weights of 0.6 - 2.4 M elements, each a ~10 us launch inside the replayed graph; the
+// weights do not change between the start of a step and the optimizer at its end, so all of them can go first, as one launch:
+// tensor i has its own scale and amax slot (the per-tensor state machine of fake_quantize.py:230-246 is untouched), the format is
+// shared.  A workgroup takes one tile of kMultiTile 16-byte vectors of one tensor (tiles never straddle tensors).
+struct qt_fq_item_dev {
+    const uint4 *x;
+    uint4 *y;
+    const float *scale;
+    uint32_t *amax;              // NULL: not observed
+    unsigned long long nvec;     // 16-byte vectors (8 bf16 each)
+    unsigned long long first;    // index of the tensor's first tile in the launch
+};
+constexpr int kMultiBlock = 256, kMultiUnroll = 4, kMultiTile = kMultiBlock * kMultiUnroll;
+
+template <int KIND>
+__global__ __launch_bounds__(kMultiBlock) void fq_multi_kernel(const qt_fq_item_dev *__restrict__ items, int count, qt_format fmt,
+                                                              const uint16_t *__restrict__ lut) {
+    Rounder<KIND> rnd{fmt, nullptr};
+    if constexpr (KIND == kFmtRows) {
+        __shared__ uint4 s_rows[512];
+        const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += kMultiBlock) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        rnd.glut = lut;
+        __syncthreads();
+    }
+    // the tensor this tile belongs to: last item whose first tile is <= blockIdx.x (uniform: every lane walks the same way)
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first <= (unsigned long long)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const qt_fq_item_dev it = items[lo];
+    const size_t v0 = ((size_t)blockIdx.x - it.first) * kMultiTile;
+    const float s = qt_bf2f(qt_f2bf(*it.scale));
+    const UniformDiv dv(s);
+    uint32_t amax = 0;
+    auto run = [&](auto divc, auto obsc) __attribute__((always_inline)) {
+        constexpr int DIV = decltype(divc)::value;
+        constexpr bool OBS = decltype(obsc)::value;
+        uint4 v[kMultiUnroll];
+#pragma unroll
+        for (int u = 0; u < kMultiUnroll; ++u) {
+            const size_t i = v0 + (size_t)u * kMultiBlock + threadIdx.x;
+            v[u] = i < it.nvec ? it.x[i] : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < kMultiUnroll; ++u) {
+            const size_t i = v0 + (size_t)u * kMultiBlock + threadIdx.x;
+            const uint4 r = fq_vec<kIoBf16, KIND, DIV, OBS>(v[u], dv, rnd, amax);
+            if (i < it.nvec) it.y[i] = r;
+        }
+    };
+    const bool obs = it.amax != nullptr;                      // uniform
+    if (s == 1.0f) {
+        if (obs) run(std::integral_constant<int, kDivUnit>{}, std::true_type{});
+        else run(std::integral_constant<int, kDivUnit>{}, std::false_type{});
+    } else if (dv.safe) {
+        if (obs) run(std::integral_constant<int, kDivFast>{}, std::true_type{});
+        else run(std::integral_constant<int, kDivFast>{}, std::false_type{});
+    } else {
+        if (obs) run(std::integral_constant<int, kDivExact>{}, std::true_type{});
+        else run(std::integral_constant<int, kDivExact>{}, std::false_type{});
+    }
+    if (obs) block_amax_commit<kMultiBlock>(amax, it.amax);
+}
+
 // ---- strided rows -> contiguous ----------------------------------------------------------------------
 // Attention hands the hooks permuted views (q / k / v are [B, S, H, D] storage seen as [B, H, S, D]).  The
 // reference's vmap returns a contiguous tensor (decomposed.py:155), i.e. the layout change is part of the
@@ -856,7 +926,9 @@ inline unsigned grid_for(size_t work_items, size_t per_block, int blocks_per_cu)
 // Tensors below this many elements use the global-table gather kernel instead of staging 128 KiB per CU.
 constexpr size_t kLutLdsMinElems = (size_t)1 << 21;
 
-int g_variant = 0;        // tuning only (tools/exp_stream.py): selects a launch geometry for bf16 closed-form passes
+#ifdef QT_TUNING_BUILD
+int g_variant = 0;        // tools/exp_stream.py: selects a launch geometry for bf16 closed-form passes
+#endif
 int g_blocks_per_cu = 32;
 
 template <int IO, int KIND, int BLOCK, int UNR, int NT>
@@ -879,19 +951,22 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15u) == 0;
     const bool gather = !aligned || (KIND == QT_FMT_LUT && (n < kLutLdsMinElems || y == nullptr)) || n < 4096;
     if constexpr (KIND == QT_FMT_LUT) {
-        // The row form (qt_format.p1 bit 0; QT_ROW_FORM=0 keeps the table): no 128 KiB staging, so the pass runs at the closed
+        // The row form (qt_format.p1 bit 0): no 128 KiB staging, so the pass runs at the closed
         // forms' occupancy and bandwidth, small tensors included.
-        static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;      // tuning / A-B switch
-        if ((fmt.p1 & 1) && row_mode && aligned && y != nullptr && n >= 4096) {
+        if ((fmt.p1 & 1) && aligned && y != nullptr && n >= 4096) {
             const size_t nv = n / kPer;
-            static const int row_blocks = getenv("QT_ROW_BLOCKS") ? atoi(getenv("QT_ROW_BLOCKS")) : 0;   // tuning: workgroups per CU
-            static const int row_wide = getenv("QT_ROW_WIDE") ? atoi(getenv("QT_ROW_WIDE")) : 0;         // tuning: 1024-thread workgroups
+            int row_blocks = 0;
+#ifdef QT_TUNING_BUILD
+            static const int e_row_blocks = getenv("QT_ROW_BLOCKS") ? atoi(getenv("QT_ROW_BLOCKS")) : 0;   // tools/ only: workgroups per CU
+            static const int row_wide = getenv("QT_ROW_WIDE") ? atoi(getenv("QT_ROW_WIDE")) : 0;           // tools/ only: 1024-thread workgroups
+            row_blocks = e_row_blocks;
             if (row_wide) {
                 unsigned grid = grid_for(nv, (size_t)1024, row_blocks ? row_blocks : 4);
                 if (amax) fq_kernel<IO, kFmtRows, true, 1024><<<grid, 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
                 else fq_kernel<IO, kFmtRows, false, 1024><<<grid, 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
                 return launch_status();
             }
+#endif
             unsigned grid = grid_for(nv, (size_t)kAluBlock * kUnroll, row_blocks ? row_blocks : 8);
             if (amax)
                 fq_kernel<IO, kFmtRows, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
@@ -918,11 +993,11 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
     }
     const size_t nvec = n / kPer;
     if constexpr (KIND == QT_FMT_LUT) {
-        // Opt-in (QT_LUT_HALF=1): odd-symmetric maps can stage only their non-negative half (64 KiB, two workgroups = 32 waves
-        // per CU).  Measured SLOWER on bf16 [4096, 11008]: posit8_1 41.3 us (4.37 TB/s) against 37.7 us (4.79 TB/s) with the
-        // whole table -- putting the sign back costs three more VALU operations per element than the second workgroup's extra
-        // waves recover (tools/exp_table_formats.py) -- so the whole table stays the default.
-        static const int half_mode = getenv("QT_LUT_HALF") ? atoi(getenv("QT_LUT_HALF")) : 0;      // tuning / A-B switch
+        // (Odd-symmetric maps could stage only their non-negative half -- 64 KiB, two workgroups per CU.  Measured SLOWER on bf16
+        // [4096, 11008]: posit8_1 4.37 against 4.79 TB/s with the whole table: putting the sign back costs three more VALU operations
+        // per element than the second workgroup's waves recover.  Tuning build only.)
+#ifdef QT_TUNING_BUILD
+        static const int half_mode = getenv("QT_LUT_HALF") ? atoi(getenv("QT_LUT_HALF")) : 0;
         if (fmt.p0 == 1 && half_mode) {
             unsigned grid = grid_for(nvec, (size_t)kLutBlock * 4 * 4, 2);
             if (amax)
@@ -931,12 +1006,14 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
                 fq_kernel<IO, kFmtLutHalf, false, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
             return launch_status();
         }
+#endif
         unsigned grid = grid_for(nvec, (size_t)kLutBlock * 4 * 4, 1);
         if (amax)
             fq_kernel<IO, KIND, true, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
         else
             fq_kernel<IO, KIND, false, kLutBlock, 4><<<grid, kLutBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
     } else {
+#ifdef QT_TUNING_BUILD
         if constexpr (IO == kIoBf16 && KIND == QT_FMT_FP_SAT) {
             switch (g_variant) {
                 case 1: return launch_variant<IO, KIND, 256, 4, 2>(x, y, n, fmt, lut, scale, amax, st);
@@ -959,6 +1036,7 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
                 default: break;
             }
         }
+#endif
         unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, g_blocks_per_cu);
         if (amax)
             fq_kernel<IO, KIND, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
@@ -1001,25 +1079,16 @@ int launch_pc_kind(const void *x, void *y, size_t outer, size_t C, size_t inner,
         fq_pc_last_kernel<IO, KIND><<<grid, 256, 0, st>>>(x, y, n, C, fmt, lut, scale, amax);
     } else if (inner % kPer == 0 && inner >= 64 * kPer && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0)) {
         if constexpr (KIND == QT_FMT_LUT) {
-            static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;      // see launch_fq_kind
-            if ((fmt.p1 & 1) && row_mode && y) {
+                if ((fmt.p1 & 1) && y) {
                 unsigned grid = grid_for(outer * C, 1, 16);
                 fq_pc_vec_kernel<IO, kFmtRows><<<grid, 256, 0, st>>>((const uint4 *)x, (uint4 *)y, outer * C, C, inner / kPer, fmt, lut, scale, amax);
                 return launch_status();
             }
-            static const int lds_mode = getenv("QT_PC_LDS") ? atoi(getenv("QT_PC_LDS")) : 1;          // tuning / A-B switch
-            if (lds_mode && y && outer * C * inner >= kLutLdsMinElems) {
+            if (y && outer * C * inner >= kLutLdsMinElems) {          // the 128 KiB table in LDS, a wave per row (3.0 -> 3.8 TB/s)
                 const size_t rows = outer * C;
-                static const int half_mode = getenv("QT_LUT_HALF") ? atoi(getenv("QT_LUT_HALF")) : 0;  // see launch_fq_kind
-                if (fmt.p0 == 1 && half_mode) {
-                    unsigned grid = grid_for(rows, 16, 2);
-                    fq_pc_vec_lds_kernel<IO, kFmtLutHalf><<<grid, 1024, 0, st>>>((const uint4 *)x, (uint4 *)y, rows, C, inner / kPer, fmt,
-                                                                               lut, scale, amax);
-                } else {
-                    unsigned grid = grid_for(rows, 16, 1);
-                    fq_pc_vec_lds_kernel<IO, QT_FMT_LUT><<<grid, 1024, 0, st>>>((const uint4 *)x, (uint4 *)y, rows, C, inner / kPer, fmt,
-                                                                              lut, scale, amax);
-                }
+                unsigned grid = grid_for(rows, 16, 1);
+                fq_pc_vec_lds_kernel<IO, QT_FMT_LUT><<<grid, 1024, 0, st>>>((const uint4 *)x, (uint4 *)y, rows, C, inner / kPer, fmt,
+                                                                          lut, scale, amax);
                 return launch_status();
             }
         }
@@ -1089,10 +1158,12 @@ int launch_mx(const void *x, void *y, void *sf, size_t rows, size_t cols, int bs
 
 extern "C" {
 
-void qt_internal_set_variant(int variant, int blocks_per_cu) {
+#ifdef QT_TUNING_BUILD
+void qt_internal_set_variant(int variant, int blocks_per_cu) {       // tools/exp_stream.py, tools/exp_fq8_grid.py: launch-geometry sweeps
     g_variant = variant;
     g_blocks_per_cu = blocks_per_cu > 0 ? blocks_per_cu : 32;
 }
+#endif
 
 int qt_scale_update(float *history_dev, int L, int C, float *scale_dev, float quant_max, int force_pow2, void *stream) {
     if (!history_dev || !scale_dev || L < 1 || C < 1) return QT_ERR_BAD_ARG;
@@ -1141,7 +1212,10 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     const uint4 *xv = (const uint4 *)x;
     uint4 *yv = (uint4 *)y;
     uint4 *y8v = (uint4 *)y8;
-    static const bool hw = getenv("QT_FQ8_CLOSED_FORM") == nullptr;       // A/B switch for DESIGN.md's measurement
+    bool hw = true;
+#ifdef QT_TUNING_BUILD
+    hw = getenv("QT_FQ8_CLOSED_FORM") == nullptr;                        // tools/ only: A/B for DESIGN.md's measurement
+#endif
 #define QT_FQ8(OBS, BOTH, E5)                                                                                  \
     fq8_kernel<OBS, BOTH, E5><<<grid, 256, 0, st>>>(xv, yv, y8v, nvec, *fmt, scale, amax, hw)
     if (e5m2) {
@@ -1209,6 +1283,27 @@ int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs, const size_t *ns, in
     hipStream_t st = (hipStream_t)stream;
     if (e5m2) fq8_multi_kernel<true><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
     else fq8_multi_kernel<false><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
+    return launch_status();
+}
+
+int qt_fake_quant_multi_bf16(const qt_fq_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt,
+                             const uint16_t *lut_dev, void *stream) {
+    if (count == 0 || total_tiles == 0) return QT_OK;
+    if (!items_dev || !fmt || count < 0 || total_tiles > 0x7FFFFFFFull) return QT_ERR_BAD_ARG;
+    if ((uintptr_t)items_dev & 7u) return QT_ERR_UNALIGNED;
+    static_assert(sizeof(qt_fq_item) == sizeof(qt_fq_item_dev), "layout of qt_fq_item");
+    const qt_fq_item_dev *it = (const qt_fq_item_dev *)items_dev;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)total_tiles;
+    switch (fmt->kind) {
+        case QT_FMT_LUT:
+            if (!lut_dev || !(fmt->p1 & 1)) return QT_ERR_BAD_ARG;          // table formats: the row form behind the map only
+            fq_multi_kernel<kFmtRows><<<grid, kMultiBlock, 0, st>>>(it, count, *fmt, lut_dev);
+            break;
+        case QT_FMT_FP_SAT: fq_multi_kernel<QT_FMT_FP_SAT><<<grid, kMultiBlock, 0, st>>>(it, count, *fmt, lut_dev); break;
+        case QT_FMT_INT: fq_multi_kernel<QT_FMT_INT><<<grid, kMultiBlock, 0, st>>>(it, count, *fmt, lut_dev); break;
+        default: return QT_ERR_BAD_ARG;
+    }
     return launch_status();
 }
 

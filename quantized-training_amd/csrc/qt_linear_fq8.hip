@@ -21,20 +21,16 @@
 // one column tile run on the same XCD at the same time: a weight tile leaves HBM once and is re-read from that XCD's L2.
 // Up to four weight tensors sharing one activation (q / k / v projections) form the "segments" of one launch.
 //
-// LDS, per stage: 32 KiB activation tile (256 rows x 128 FP8 codes, 16-byte chunks XOR-swizzled by row as in
-// qt_mx_gemm.hip) + NB x 8 KiB weight tile (16 nt rows x 128 bf16 = 256 B per row = exactly one bank row, so the
-// 16-byte chunk index is XORed with the row to spread a fragment's sixteen rows over sixteen slots).  Two stages: the
-// DMA of k-step t+1 is in flight while step t is multiplied (counted vmcnt + raw s_barrier; fragment reads are inline
-// asm so that hipcc does not drain the DMA queue in front of them, see qt_mx_gemm.hip).  The two waves of a SIMD issue their
-// DMA half a step apart (column half 0 in front of its multiplications, half 1 in the middle of them).
+// What runs (LinearFq8R / LinearFq8R2 below): a lane loads 8 bf16 weights (16 B) into registers, converts them a
+// step later and writes the 8 FP8 codes into a ring of FP8 weight tiles in LDS; the activations come by LDS-DMA into a ring three
+// deep; both operands' fragments are two ds_read_b128 each; counted vmcnt + one raw s_barrier per k step (fragment reads are inline
+// asm so that hipcc does not drain the DMA queue in front of them, see qt_mx_gemm.hip).  R2 (tiles of up to four column groups: the
+// o and down projections) makes a step two k tiles deep.  qt_mlp_fq8_bf16 is R's pair mode (gate and up segments interleaved, the
+// epilogue computes fq(silu(gate) * up)).  Round 2's first variant (raw bf16 weight tiles by LDS-DMA, converted by every wave that
+// multiplies them: 78 against 56 us at 1024 x 11008 x 4096) was removed in round 4.
 //
-// The text above describes variant 1 (LinearFq8: raw bf16 weight tiles by LDS-DMA, converted by every wave that multiplies them),
-// kept for the ablation.  What the host launches by default is variant R / R2 further down (LinearFq8R, LinearFq8R2: weights
-// converted in registers on the way in, FP8 weight tiles in LDS) and its pair mode (qt_mlp_fq8_bf16).
-//
-// Measured on MI355X (tools/exp_linear_fq8.py): 1024 x 11008 x 4096 in 56 us (variant R) against 66-70 us for the
-// weight pass + library GEMM pair and 78 us for variant 1, whose 76 KiB stages allow a ring of two only -- a two-deep ring pays the
-// tiles' issue-to-landed time on every step (DMA alone: 54 us; multiplications alone: 44 us).
+// Measured on MI355X (tools/exp_linear_fq8.py): 1024 x 11008 x 4096 in 54-57 us against 66-70 us for the weight pass +
+// library GEMM pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -155,197 +151,8 @@ __device__ __forceinline__ uint32_t exact_bf16x4(uint32_t p0, uint32_t p1) {
 
 #define QT_LDS_WAIT4(n, v) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
 
-// FX / FW: 0 = E4M3, 1 = E5M2 (the instruction's operand format codes); NB: weight DMA pieces (4 rows x 256 bytes) per wave
-// and stage (2, 4 or 6: tiles of up to 4, 8, 12 column groups)
-template <int FX, int FW, int NB>
-struct LinearFq8 {
-    static constexpr int kStage = kABytes + NB * 8 * 1024;
-    static constexpr int kGroup = 4 + NB;                   // vector-memory instructions of one issue()
-    // One wave's share: rows [wm * 64, +64) x NTW column groups starting at group jbase of the tile whose first group
-    // (in the concatenation of the weights) is tg0.
-    template <int NTW>
-    static __device__ __forceinline__ bool run(const Args &a, uint8_t *lds, int m0, int tg0, int nt, int jbase, int w, int l) {
-        const int r = l & 15, g = l >> 4, wm = w & 3, wn = w >> 2;
-        const int nk = a.K / kBK;
-        constexpr int stage_bytes = kStage;
-        // ---- DMA sources (k tile 0); LDS destinations are wave-uniform
-        const uint8_t *ga[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (w * 4 + i) * 8 + (l >> 3), slot = l & 7;
-            ga[i] = a.x8 + (long)min(m0 + row, a.M - 1) * a.K + ((slot ^ ((row >> 1) & 7)) << 4);
-        }
-        // Weight pieces (4 rows x 256 bytes): piece p = w + 8 i, so p & 3 == w & 3 for every piece of this wave and the
-        // swizzled lane offset is the same for all of them; only the (wave-uniform) base differs.  Surplus pieces repeat
-        // piece w & 3 (same bytes, same place).
-        const int npieces = nt * 4;
-        const uint8_t *ub[NB];                                 // wave-uniform: first row of the piece, k tile 0
-        int pb[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int p = w + 8 * i;
-            pb[i] = p < npieces ? p : (w & 3);
-            const int grp = tg0 + (pb[i] >> 2);
-            const SegRef sg = seg_lookup(a, grp);
-            ub[i] = (const uint8_t *)sg.w + ((long)((grp - sg.g0) * 16 + (pb[i] & 3) * 4) * a.K) * 2;
-        }
-        const int row16 = (w & 3) * 4 + (l >> 4);              // row & 15 of this lane's row in any of its pieces
-        const uint32_t b_lane = (uint32_t)(l >> 4) * (uint32_t)a.K * 2u + (((l & 15) ^ row16) << 4);
-        auto issue = [&](int kt, uint8_t *stage) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void *)(ga[i] + (long)kt * kBK), (lds_void *)(stage + (w * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void *)(ub[i] + (long)kt * (2 * kBK) + b_lane), (lds_void *)(stage + kABytes + pb[i] * 1024), 16, 0, 0);
-        };
-        // Wave half 1 issues its share in the middle of its multiplications instead of in front of them, so that one wave
-        // of every SIMD is on the matrix core while the other one feeds the DMA queue.
-        const int ipos = (wn == 1 && !(a.dbg & 128)) ? (NTW + 1) / 2 : -1;
-
-        v4f acc[4][NTW > 0 ? NTW : 1];
-        // lane-constant parts of the fragment addresses
-        const uint32_t a_lo = a_chunk_off(wm * 64 + r, g), a_hi = a_chunk_off(wm * 64 + r, 4 + g);
-        const uint32_t b_row = kABytes + (jbase * 16 + r) * 256;
-        const uint32_t b0 = b_row + (((2 * g) ^ r) << 4), b1 = b_row + (((2 * g + 1) ^ r) << 4);
-        const uint32_t b2 = b_row + (((8 + 2 * g) ^ r) << 4), b3 = b_row + (((9 + 2 * g) ^ r) << 4);
-
-        auto compute = [&](uint32_t s, int kt_next, uint8_t *next_stage) __attribute__((always_inline)) {
-            if constexpr (NTW > 0) {
-                u32x4 fa_lo[4], fa_hi[4];
-                fa_lo[0] = ds_read128<0 * 2048>(s + a_lo); fa_hi[0] = ds_read128<0 * 2048>(s + a_hi);
-                fa_lo[1] = ds_read128<1 * 2048>(s + a_lo); fa_hi[1] = ds_read128<1 * 2048>(s + a_hi);
-                fa_lo[2] = ds_read128<2 * 2048>(s + a_lo); fa_hi[2] = ds_read128<2 * 2048>(s + a_hi);
-                fa_lo[3] = ds_read128<3 * 2048>(s + a_lo); fa_hi[3] = ds_read128<3 * 2048>(s + a_hi);
-                u32x4 raw[2][4];
-                auto read_b = [&](auto jc) __attribute__((always_inline)) {
-                    constexpr int J = decltype(jc)::value;
-                    raw[J & 1][0] = ds_read128<J * 4096>(s + b0);
-                    raw[J & 1][1] = ds_read128<J * 4096>(s + b1);
-                    raw[J & 1][2] = ds_read128<J * 4096>(s + b2);
-                    raw[J & 1][3] = ds_read128<J * 4096>(s + b3);
-                };
-                v8i fa[4];
-                auto step = [&](auto jc) __attribute__((always_inline)) {
-                    constexpr int J = decltype(jc)::value;
-                    if constexpr (J + 1 < NTW) {
-                        read_b(std::integral_constant<int, J + 1>{});
-                        if constexpr (J == 0) {
-                            asm volatile("s_waitcnt lgkmcnt(4)"
-                                         : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]),
-                                           "+v"(fa_lo[3]), "+v"(fa_hi[3]), "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]));
-                        } else {
-                            QT_LDS_WAIT4(4, raw[J & 1]);
-                        }
-                    } else {
-                        if constexpr (J == 0) {
-                            asm volatile("s_waitcnt lgkmcnt(0)"
-                                         : "+v"(fa_lo[0]), "+v"(fa_hi[0]), "+v"(fa_lo[1]), "+v"(fa_hi[1]), "+v"(fa_lo[2]), "+v"(fa_hi[2]),
-                                           "+v"(fa_lo[3]), "+v"(fa_hi[3]), "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[0][3]));
-                        } else {
-                            QT_LDS_WAIT4(0, raw[J & 1]);
-                        }
-                    }
-                    if constexpr (J == 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            fa[i] = v8i{(int)fa_lo[i].x, (int)fa_lo[i].y, (int)fa_lo[i].z, (int)fa_lo[i].w,
-                                        (int)fa_hi[i].x, (int)fa_hi[i].y, (int)fa_hi[i].z, (int)fa_hi[i].w};
-                    }
-                    const v8i fb = convert_frag<FW == 1>(raw[J & 1]);
-                    // operands swapped: D rows = W rows (output columns), D columns = x rows, so a lane ends up with four
-                    // consecutive output columns of one row -- an 8-byte store in the epilogue
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][J], FW, FX, 0, kUnitE8M0, 0, kUnitE8M0);
-                    if (J + 1 == ipos && kt_next >= 0) issue(kt_next, next_stage);
-                };
-                read_b(std::integral_constant<int, 0>{});
-                step(std::integral_constant<int, 0>{});
-                if constexpr (NTW > 1) step(std::integral_constant<int, 1>{});
-                if constexpr (NTW > 2) step(std::integral_constant<int, 2>{});
-                if constexpr (NTW > 3) step(std::integral_constant<int, 3>{});
-                if constexpr (NTW > 4) step(std::integral_constant<int, 4>{});
-                if constexpr (NTW > 5) step(std::integral_constant<int, 5>{});
-            } else {
-                if (ipos >= 0 && kt_next >= 0) issue(kt_next, next_stage);
-            }
-        };
-
-        const uint32_t s_base = lds_addr(lds);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < (NTW > 0 ? NTW : 1); ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-        issue(0, lds);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            uint8_t *next_stage = lds + (cur ^ 1) * stage_bytes;
-            // Vector-memory queue of this wave, oldest first: [pieces of step kt] and, for the half that issues in front of its
-            // multiplications, the pieces of step kt + 1 behind them.
-            if (ipos < 0) {
-                if (more) {
-                    issue(kt + 1, next_stage);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGroup) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();                    // every wave's pieces of step kt have landed
-            if (!(a.dbg & 2)) compute(s_base + cur * stage_bytes, (more && ipos >= 0) ? kt + 1 : -1, next_stage);
-            else if (more && ipos >= 0) issue(kt + 1, next_stage);
-            __builtin_amdgcn_s_barrier();                    // this stage may be refilled
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Overflowed or non-finite weights (and NaN activations) leave NaN / Inf in the accumulators: such a tile is redone
-        // by slow_tile.  The workgroup-wide vote goes through LDS (the stages are dead here).
-        bool bad = false;
-        if constexpr (NTW > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
-        }
-        volatile int *flag = (volatile int *)lds;
-        if (w == 0 && l == 0) *flag = 0;
-        __syncthreads();
-        if (bad) *flag = 1;
-        __syncthreads();
-        if (*flag) return true;
-
-        // ---- epilogue: lane (r, g) of tile (i, j) holds y[row wm*64 + i*16 + r][column group j, columns 4g .. 4g+3]
-        if constexpr (NTW > 0) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int grp = tg0 + jbase + j;
-                const SegRef sg = seg_lookup(a, grp);
-                const int col = grp * 16 + 4 * g;                       // output column
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (sg.bias) {
-                    const uint2 b = *(const uint2 *)(sg.bias + (col - sg.g0 * 16));
-                    bv[0] = qt_u2f(b.x << 16); bv[1] = qt_u2f(b.x & 0xFFFF0000u);
-                    bv[2] = qt_u2f(b.y << 16); bv[3] = qt_u2f(b.y & 0xFFFF0000u);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * 64 + i * 16 + r;
-                    if (row < a.M) {
-                        const uint2 o = {pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
-                                         pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
-                        *(uint2 *)(a.y + (long)row * a.ldc + col) = o;
-                    }
-                }
-            }
-        }
-        return false;
-    }
-};
-
+// FX / FW: 0 = E4M3, 1 = E5M2 (the instruction's operand format codes); NB: weight pieces per wave and step (2, 4 or 6: tiles of up
+// to 4, 8, 12 column groups)
 // ---- variant R: weights converted in registers on the way in ------------------------------------------------------------
 // The raw bf16 weight tile is what keeps the ring above two deep (76 KiB per stage).  Here a lane loads 8 bf16 weights (16 bytes)
 // into registers with an ordinary global load -- hipcc places the vmcnt waits of those itself, copies of the registers included,
@@ -1196,39 +1003,6 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
     if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
 }
 
-template <int FX, int FW, int NB>
-__global__ __launch_bounds__(512, 1) void linear_fq8_kernel(Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    // Workgroup ids go round-robin over the 8 XCDs: give XCD x the contiguous run of tiles [x * per + min(x, rem), ...),
-    // column tile = id / tiles_m, so the row tiles of one column tile (one weight tile) are neighbours on one XCD.
-    const int ntiles = a.tiles_m * a.tiles_n;
-    int id = blockIdx.x;
-    {
-        const int per = ntiles / 8, rem = ntiles % 8, x = id % 8, q = id / 8;
-        id = x * per + (x < rem ? x : rem) + q;
-    }
-    const int tn = id / a.tiles_m, tm = id % a.tiles_m;
-    int tg0, nt;
-    tile_span(a, tn, tg0, nt);
-    const int m0 = tm * kTM;
-    const int nt0 = (nt + 1) >> 1;
-    const int wn = w >> 2;
-    const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
-    using L = LinearFq8<FX, FW, NB>;
-    bool redo;
-    switch (ntw) {                                          // wave-uniform
-        case 0: redo = L::template run<0>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        case 1: redo = L::template run<1>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        case 2: redo = L::template run<2>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        case 3: redo = L::template run<3>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        case 4: redo = L::template run<4>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        case 5: redo = L::template run<5>(a, lds, m0, tg0, nt, jbase, w, l); break;
-        default: redo = L::template run<6>(a, lds, m0, tg0, nt, jbase, w, l); break;
-    }
-    if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
-}
-
 template <int FX, int FW, int NB, bool PAIR, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_r[];
@@ -1277,20 +1051,6 @@ int cu_count() {
     return n;
 }
 
-template <int FX, int FW, int NB>
-int launch_nb(const Args &a, hipStream_t st) {
-    constexpr int kLds = 2 * LinearFq8<FX, FW, NB>::kStage;
-    static bool configured = false;
-    if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8_kernel<FX, FW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    linear_fq8_kernel<FX, FW, NB><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? QT_OK : (int)e;
-}
-
 template <int FX, int FW, int NB, bool PAIR = false, int ABL = 0>
 int launch_r_nb(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFq8R<FX, FW, NB, PAIR>::kLds;
@@ -1321,58 +1081,58 @@ int launch_r2(const Args &a, hipStream_t st) {
 
 template <int FX, int FW>
 int launch(const Args &a, hipStream_t st) {
-    const char *e_var = getenv("QT_FQ8_VARIANT");            // 1: raw bf16 weight tiles by LDS-DMA, 2: weights converted in registers
-    const int variant = e_var ? atoi(e_var) : 2;
-    // two weight register sets (LinearFq8R::W2, a weight request has two steps to land): the widest tiles, where it measured 2 - 6 % faster;
-    // QT_FQ8_W2=0 keeps one set
-    static const bool w2 = !(getenv("QT_FQ8_W2") && atoi(getenv("QT_FQ8_W2")) == 0);
+    // Two weight register sets (LinearFq8R::W2 = "ABL 20": a weight request has two steps to land) on the widest tiles, where it
+    // measured 2 - 6 % faster.  Narrow tiles (nb <= 2, K a multiple of two k tiles) run variant R2, two k tiles per step.
+    bool w2 = true, r2 = true;
+#ifdef QT_TUNING_BUILD
+    // tools/ only: timing ablations (results are garbage), the register-extended variant RX of R2 (exact, not faster) and A / B switches
+    w2 = !(getenv("QT_FQ8_W2") && atoi(getenv("QT_FQ8_W2")) == 0);
+    r2 = !(getenv("QT_FQ8_R2") && atoi(getenv("QT_FQ8_R2")) == 0);
+#endif
     if (a.pair) {
         if (a.nb <= 2) return launch_r_nb<FX, FW, 2, true>(a, st);
         if (a.nb <= 4) return launch_r_nb<FX, FW, 4, true>(a, st);
         if (w2) return launch_r_nb<FX, FW, 6, true, 20>(a, st);
         return launch_r_nb<FX, FW, 6, true>(a, st);
     }
-    if (variant == 2) {
-        const char *e_r2 = getenv("QT_FQ8_R2");              // 0: narrow tiles keep one k tile per step
-        if (a.nb <= 2 && a.K % (2 * kBK) == 0 && !(e_r2 && atoi(e_r2) == 0)) {
-            if constexpr (FX == 0 && FW == 0) {
-                const char *e_ra = getenv("QT_FQ8_R2_ABLATE");       // timing experiments: results are garbage (30: variant RX, exact)
-                switch (e_ra ? atoi(e_ra) : 0) {
-                    case 30: return launch_r2<0, 0, 30>(a, st);
-                    case 2: return launch_r2<0, 0, 2>(a, st);
-                    case 3: return launch_r2<0, 0, 3>(a, st);
-                    case 5: return launch_r2<0, 0, 5>(a, st);
-                    default: break;
-                }
-            }
-            return launch_r2<FX, FW>(a, st);
-        }
-        if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
-        if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
+    if (a.nb <= 2 && a.K % (2 * kBK) == 0 && r2) {
+#ifdef QT_TUNING_BUILD
         if constexpr (FX == 0 && FW == 0) {
-            const char *e_abl = getenv("QT_FQ8_ABLATE");     // timing experiments (tools/exp_linear_fq8.py --skip-checks): results are garbage
-            switch (e_abl ? atoi(e_abl) : 0) {
-                case 1: return launch_r_nb<0, 0, 6, false, 1>(a, st);
-                case 2: return launch_r_nb<0, 0, 6, false, 2>(a, st);
-                case 3: return launch_r_nb<0, 0, 6, false, 3>(a, st);
-                case 4: return launch_r_nb<0, 0, 6, false, 4>(a, st);
-                case 5: return launch_r_nb<0, 0, 6, false, 5>(a, st);     // no operand traffic: fragment reads + multiplications + barriers
-                case 6: return launch_r_nb<0, 0, 6, false, 6>(a, st);     // barriers only
-                case 7: return launch_r_nb<0, 0, 6, false, 7>(a, st);     // transport probe: weights by LDS-DMA (raw, unconverted)
-                case 8: return launch_r_nb<0, 0, 6, false, 8>(a, st);     // the same without the activation DMA
-                case 9: return launch_r_nb<0, 0, 6, false, 9>(a, st);     // bare transport: activation DMA only (no weights, no fragment reads, no multiplications)
-                case 10: return launch_r_nb<0, 0, 6, false, 10>(a, st);   // bare transport: weight DMA only
-                case 11: return launch_r_nb<0, 0, 6, false, 11>(a, st);   // bare transport: both by DMA
-                case 20: return launch_r_nb<0, 0, 6, false, 20>(a, st);   // two weight register sets (see LinearFq8R::W2)
+            const char *e_ra = getenv("QT_FQ8_R2_ABLATE");
+            switch (e_ra ? atoi(e_ra) : 0) {
+                case 30: return launch_r2<0, 0, 30>(a, st);
+                case 2: return launch_r2<0, 0, 2>(a, st);
+                case 3: return launch_r2<0, 0, 3>(a, st);
+                case 5: return launch_r2<0, 0, 5>(a, st);
                 default: break;
             }
         }
-        if (w2) return launch_r_nb<FX, FW, 6, false, 20>(a, st);
-        return launch_r_nb<FX, FW, 6>(a, st);
+#endif
+        return launch_r2<FX, FW>(a, st);
     }
-    if (a.nb <= 2) return launch_nb<FX, FW, 2>(a, st);
-    if (a.nb <= 4) return launch_nb<FX, FW, 4>(a, st);
-    return launch_nb<FX, FW, 6>(a, st);
+    if (a.nb <= 2) return launch_r_nb<FX, FW, 2>(a, st);
+    if (a.nb <= 4) return launch_r_nb<FX, FW, 4>(a, st);
+#ifdef QT_TUNING_BUILD
+    if constexpr (FX == 0 && FW == 0) {
+        const char *e_abl = getenv("QT_FQ8_ABLATE");
+        switch (e_abl ? atoi(e_abl) : 0) {
+            case 1: return launch_r_nb<0, 0, 6, false, 1>(a, st);
+            case 2: return launch_r_nb<0, 0, 6, false, 2>(a, st);
+            case 3: return launch_r_nb<0, 0, 6, false, 3>(a, st);
+            case 4: return launch_r_nb<0, 0, 6, false, 4>(a, st);
+            case 5: return launch_r_nb<0, 0, 6, false, 5>(a, st);     // no operand traffic: fragment reads + multiplications + barriers
+            case 6: return launch_r_nb<0, 0, 6, false, 6>(a, st);     // barriers only
+            case 7: return launch_r_nb<0, 0, 6, false, 7>(a, st);     // transport probe: weights by LDS-DMA (raw, unconverted)
+            case 8: return launch_r_nb<0, 0, 6, false, 8>(a, st);     // the same without the activation DMA
+            case 9: return launch_r_nb<0, 0, 6, false, 9>(a, st);     // bare transport: activation DMA only
+            case 10: return launch_r_nb<0, 0, 6, false, 10>(a, st);   // bare transport: weight DMA only
+            case 11: return launch_r_nb<0, 0, 6, false, 11>(a, st);   // bare transport: both by DMA
+            default: break;
+        }
+    }
+#endif
+    if (w2) return launch_r_nb<FX, FW, 6, false, 20>(a, st);
+    return launch_r_nb<FX, FW, 6>(a, st);
 }
 
 }  // namespace
@@ -1401,10 +1161,16 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
     a.tiles_m = (M + kTM - 1) / kTM;
     // Column tiles: as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than kMaxNT groups;
     // the weights are treated as one concatenated [sum n][K] matrix, a tile may span two of them.
-    const char *e_tn = getenv("QT_FQ8_TILES_N"), *e_nt = getenv("QT_FQ8_MAX_NT"), *e_dbg = getenv("QT_FQ8_DEBUG");   // tuning / A-B switches
-    const int force_tn = e_tn ? atoi(e_tn) : 0;
-    int max_nt = e_nt ? atoi(e_nt) : kMaxNT;
-    if (max_nt < 1 || max_nt > kMaxNT) max_nt = kMaxNT;
+    int force_tn = 0, max_nt = kMaxNT, dbg = 0;
+#ifdef QT_TUNING_BUILD
+    {
+        const char *e_tn = getenv("QT_FQ8_TILES_N"), *e_nt = getenv("QT_FQ8_MAX_NT"), *e_dbg = getenv("QT_FQ8_DEBUG");   // tools/ only
+        force_tn = e_tn ? atoi(e_tn) : 0;
+        max_nt = e_nt ? atoi(e_nt) : kMaxNT;
+        if (max_nt < 1 || max_nt > kMaxNT) max_nt = kMaxNT;
+        dbg = e_dbg ? atoi(e_dbg) : 0;
+    }
+#endif
     const int cus = cu_count();
     const long tn_min = (groups + max_nt - 1) / max_nt;
     const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
@@ -1418,7 +1184,7 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
     const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
     if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
     a.nb = (worst_nt * 4 + 7) / 8;
-    a.dbg = e_dbg ? atoi(e_dbg) : 0;
+    a.dbg = dbg;
     int nseg = 0, g0 = 0;
     for (int i = 0; i < count; ++i) {
         if (ns[i] == 0) continue;
@@ -1464,8 +1230,10 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
     const int worst_nt = 2 * (a.gbase + (a.gextra ? 1 : 0));
     if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
     a.nb = (worst_nt * 4 + 7) / 8;
-    const char *e_dbg = getenv("QT_FQ8_DEBUG");
-    a.dbg = e_dbg ? atoi(e_dbg) : 0;
+    a.dbg = 0;
+#ifdef QT_TUNING_BUILD
+    if (const char *e_dbg = getenv("QT_FQ8_DEBUG")) a.dbg = atoi(e_dbg);
+#endif
     a.seg[0].w = w_gate_dev; a.seg[0].bias = bias_gate_dev; a.seg[0].g0 = 0;
     a.seg[1].w = w_up_dev; a.seg[1].bias = bias_up_dev; a.seg[1].g0 = 0;
     a.nseg = 2;

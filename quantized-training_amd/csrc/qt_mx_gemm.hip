@@ -1073,10 +1073,14 @@ bool wide_geometry(int M, int N, long batch, WideGeom &geo) {
     if (N % 16 != 0 || M < 1) return false;
     const long groups = N / 16;
     const int cus = wide_cu_count();
-    static const int force_tn = getenv("QT_MX_WIDE_TILES_N") ? atoi(getenv("QT_MX_WIDE_TILES_N")) : 0;       // tuning / A-B switches
-    const char *e_tm = getenv("QT_MX_WIDE_TM");                     // read per call: the parity tests drive both heights
+    int force_tn = 0, dbg = 0;
+#ifdef QT_TUNING_BUILD
+    static const int e_force_tn = getenv("QT_MX_WIDE_TILES_N") ? atoi(getenv("QT_MX_WIDE_TILES_N")) : 0;     // tools/ only
+    static const int e_dbg = getenv("QT_MX_WIDE_DEBUG") ? atoi(getenv("QT_MX_WIDE_DEBUG")) : 0;
+    force_tn = e_force_tn; dbg = e_dbg;
+#endif
+    const char *e_tm = getenv("QT_MX_WIDE_TM");                     // test hook, read per call: the parity tests drive both tile heights
     const int force_tm = e_tm ? atoi(e_tm) : 0;
-    static const int dbg = getenv("QT_MX_WIDE_DEBUG") ? atoi(getenv("QT_MX_WIDE_DEBUG")) : 0;
     long best = -1;
     for (int tm : {256, 128}) {
         if (force_tm && tm != force_tm) continue;
@@ -1222,19 +1226,24 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
                  (long)M * N, c_is_f32, nullptr, 0, 0};
     const dim3 grid(((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM), (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_dma = getenv("QT_MX_NO_DMA") != nullptr;        // tuning / A-B switch
+    bool no_dma = false;
+    int force_stages = 0, force_big = -1;
+#ifdef QT_TUNING_BUILD
+    static const bool e_no_dma = getenv("QT_MX_NO_DMA") != nullptr;      // tools/ only: A-B switches of tools/exp_mx_gemm.py
+    static const int e_stages = getenv("QT_MX_STAGES") ? atoi(getenv("QT_MX_STAGES")) : 0;
+    static const int e_big = getenv("QT_MX_BIG") ? atoi(getenv("QT_MX_BIG")) : -1;
+    no_dma = e_no_dma; force_stages = e_stages; force_big = e_big;
+#endif
     const bool dma_ok = !no_dma && K % kBK == 0 && (((uintptr_t)a_e8m0 | (uintptr_t)b_e8m0) & 3u) == 0;
-    static const int force_stages = getenv("QT_MX_STAGES") ? atoi(getenv("QT_MX_STAGES")) : 0;          // tuning / A-B switch
     const long nblocks = (long)grid.x * grid.y;
     // Up to two workgroups per CU: the two-stage prefetch ring (a tile's load latency would otherwise be exposed on
     // every step).  Larger grids: one stage, three resident workgroups per CU cover each other.  Deeper rings
     // (4-8 stages at one workgroup per CU) measured no better than two stages at two workgroups per CU.
     const bool ring = force_stages ? force_stages >= 2 : nblocks <= 2L * 256;
-    static const int force_big = getenv("QT_MX_BIG") ? atoi(getenv("QT_MX_BIG")) : -1;                      // tuning / A-B switch
     const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool big = dma_ok && (force_big >= 0 ? force_big == 1 : (M >= 512 && N >= 512 && big_tiles >= 192));
     // 8-bit formats, at least two 256-row tiles, fewer tiles than the 256 x 256 kernel wants: column widths fitted to the chip
-    const char *e_wide = getenv("QT_MX_WIDE");                                                           // tuning / A-B switch, read per call
+    const char *e_wide = getenv("QT_MX_WIDE");                              // test hook, read per call: 0 / 1 force the 128 x 128 / the wide kernel
     const int force_wide = e_wide ? atoi(e_wide) : -1;
     WideGeom geo{};
     if (dma_ok && a_format < 2 && b_format < 2 && force_wide != 0 && (force_wide == 1 || (!big && M >= 512 && N >= 512))

@@ -268,8 +268,7 @@ int launch(const void *x, void *q, void *sf, uint8_t *codes, uint8_t *e8m0, size
     MxQuantArgs a{(const uint4 *)x, (uint4 *)q, sf, codes, e8m0, rows * cols / kPer, bs / kPer, 32 / kPer, *fmt,
                   fmt->kind == QT_FMT_LUT ? lut : nullptr, scale_lut, quant_max, qe - 1, pow2, pack_fmt};
     const int pb = codes ? qt_mx::elem_bits(pack_fmt) : 0;
-    static const int row_mode = getenv("QT_ROW_FORM") ? atoi(getenv("QT_ROW_FORM")) : 1;
-    const bool rowform = a.lut && (fmt->p1 & 1) && row_mode && (((uintptr_t)a.lut) & 15u) == 0;
+    const bool rowform = a.lut && (fmt->p1 & 1) && (((uintptr_t)a.lut) & 15u) == 0;
     const bool lds = !rowform && a.lut && rows * cols >= ((size_t)1 << 22) && (((uintptr_t)a.lut) & 15u) == 0;
     hipStream_t st = (hipStream_t)stream;
 #define QT_MXQ(PB)                                                                                                 \

@@ -135,7 +135,7 @@ def _device_map(host, dev):
     flagged = np.ctypeslib.as_array(rp.flagged)
     lo, hi = 127 - 30, 127 + 15      # flagged rows out there are rare enough for the kernel's per-element detour through the map
     usable = (rp.zero_sign in (0, 1) and not flagged[lo:hi].any() and not (rp.signed_rows and flagged[256 + lo:256 + hi].any()))
-    if not usable or os.environ.get("QT_ROW_FORM", "1") == "0":
+    if not usable:
         return host.to(dev)
     both = torch.empty(QT_MAP_ENTRIES + _ROWS_TAIL, dtype=torch.bfloat16)
     both[:QT_MAP_ENTRIES] = host
@@ -252,6 +252,79 @@ class BatchedScaleUpdate:
     def forget(self):
         for f in self.fqs:
             _PREUPDATED.discard(f.amax_history.data_ptr())
+
+
+class _PrecomputedFakeQuant(torch.autograd.Function):
+    """fq(X) that was already computed (BatchedWeightFakeQuant): hands `out` on with the straight-through gradient of
+    FusedAmaxObsFakeQuantFunction (fake_quantize.py:250-252 upstream)."""
+
+    @staticmethod
+    def forward(ctx, X, out):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None
+
+
+class BatchedWeightFakeQuant:
+    """Every per-tensor weight fake-quantizer of a step as ONE launch per format (qt_fake_quant_multi_bf16) in front of the step
+    (harness.GraphedTrainStep, after BatchedScaleUpdate): a weight does not change between the start of a step and the optimizer update
+    at its end, so `weight_fake_quant(W)` of every QAT Linear (modules/qat/linear.py:40-41) can run first -- each with its own scale
+    and amax slot, i.e. the per-tensor state machine is the reference's.  The call the Linear then issues finds its result
+    (`_qt_pre`: valid for the very next call, and only for that very weight at that very version), counts its elements and returns
+    it with the straight-through gradient.  `pairs`: (fake-quantizer, weight Parameter)."""
+
+    def __init__(self, pairs, device):
+        groups = {}
+        for fq, W in pairs:
+            if not (isinstance(fq, FusedAmaxObsFakeQuantize) and fq._quantize and not fq.is_per_channel and not fq.record_histogram
+                    and fq.outlier_threshold is None and fq.qscheme in (None, QScheme.PER_TENSOR_SYMMETRIC)):
+                continue
+            if not (W.device == device and W.dtype == torch.bfloat16 and W.is_contiguous() and W.numel() % 8 == 0 and W.numel() > 0
+                    and W.data_ptr() % 16 == 0 and fq.scale.numel() == 1 and fq.scale.dtype == torch.float32 and fq.scale.device == device):
+                continue
+            if fq._observe and (fq.amax_history.numel() == 0 or fq.amax_history.dim() != 1 or fq.amax_history.device != device):
+                continue
+            fq._move_to(device)
+            fmt = _launch_format(fq._qt_format, fq.qmap)
+            if fmt.kind == _native.QT_FMT_LUT and not (fmt.p1 & 1):
+                continue
+            if fmt.kind not in (_native.QT_FMT_LUT, _native.QT_FMT_FP_SAT, _native.QT_FMT_INT):
+                continue
+            lut = fq.qmap if fmt.kind == _native.QT_FMT_LUT else None
+            groups.setdefault((fmt.key(), lut.data_ptr() if lut is not None else 0), (fmt, lut, []))[2].append((fq, W))
+        self.groups = []
+        for fmt, lut, members in groups.values():
+            total = sum(W.numel() for _, W in members)
+            out = torch.empty(total, dtype=torch.bfloat16, device=device)
+            rows, outs, tiles, off = [], [], 0, 0
+            for fq, W in members:
+                y = out[off:off + W.numel()].view(W.shape)
+                off += W.numel()
+                nvec = W.numel() // 8
+                rows.append([W.data_ptr(), y.data_ptr(), fq.scale.data_ptr(), fq.amax_history.data_ptr() if fq._observe else 0, nvec, tiles])
+                tiles += (nvec + 1023) // 1024
+                outs.append(y)
+            items = torch.tensor(rows, dtype=torch.int64, device=device)
+            self.groups.append((fmt, lut, members, outs, items, tiles))
+        self.device = device
+
+    def __len__(self):
+        return sum(len(g[2]) for g in self.groups)
+
+    def launch(self):
+        for fmt, lut, members, outs, items, tiles in self.groups:
+            _native.check(_native.lib().qt_fake_quant_multi_bf16(items.data_ptr(), len(members), tiles, ctypes.byref(fmt),
+                                                                 lut.data_ptr() if lut is not None else None, _stream_ptr(items)),
+                          "qt_fake_quant_multi_bf16")
+            for (fq, W), y in zip(members, outs):
+                fq.__dict__["_qt_pre"] = (W.data_ptr(), W._version, y)
+
+    def forget(self):
+        for _, _, members, _, _, _ in self.groups:
+            for fq, _ in members:
+                fq.__dict__["_qt_pre"] = None
 
 
 def _rows_view(t):
@@ -718,7 +791,7 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
         if (done_by is not None and self._emit_fp8 and isinstance(done_by, FusedAmaxObsFakeQuantize) and handover_valid(X)
                 and getattr(X, "_qt_fp8", None) is not None and X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous()
                 and not (torch.is_grad_enabled() and X.requires_grad) and self.producer_fusable() and done_by.producer_fusable()
-                and done_by._qt_format.key() == self._qt_format.key() and os.environ.get("QT_FQ_IDEMPOTENT", "1") != "0"):
+                and done_by._qt_format.key() == self._qt_format.key()):
             # X was produced by an identical stateless fake-quantizer (a sibling's: q beside k, v; gate beside up), so it lies on
             # this format's grid, where the fake-quantizer is the identity: the result of this call is X, value for value.  The call
             # is still evaluated -- the pass below computes the FP8 code of every element of X -- but the bf16 tensor it would
@@ -749,6 +822,17 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
                 X._qt_fp8 = x8
                 X._qt_ver = X._version
                 return X
+        pre = self.__dict__.get("_qt_pre")
+        if pre is not None:
+            # BatchedWeightFakeQuant computed this call in front of the step (same scale, same amax slot): valid for this -- the very
+            # next -- call, on the very tensor it read
+            self.__dict__["_qt_pre"] = None
+            ptr, version, out = pre
+            if X.data_ptr() == ptr and X._version == version and X.shape == out.shape and X.is_contiguous():
+                _Stats.add(X.numel())
+                if self._observe:
+                    _take_preupdate(self.amax_history)                        # the batched scale update served this call
+                return _PrecomputedFakeQuant.apply(X, out)
         self._move_to(X.device)
 
         if self.record_histogram:                                            # upstream :348-350

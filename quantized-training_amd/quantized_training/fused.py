@@ -158,91 +158,7 @@ def mark_fp8_producer(consumer, act_fq):
         act_fq._emit_fp8 = "both"
 
 
-class _WeightPrefetcher:
-    """Runs the FP8 weight pass of the NEXT QAT Linear on a second HIP stream while the current layer's
-    GEMM (MFMA-bound) executes: the weight pass is HBM-bound and does not depend on activations, so the
-    two overlap.  Layers are numbered in first-call order; three rotating FP8 buffers (sized to the
-    largest weight seen) give write-after-read distance two, so pass N+1 may run beside GEMM N.  All
-    cross-stream edges are events, which also makes the pattern capturable into a hipGraph; the last
-    layer of a forward does not prefetch (nothing would join the side stream)."""
-
-    def __init__(self):
-        self.index = {}          # id(layer) -> position in first-call order
-        self.layers = []
-        self.bufs = None
-        self.buf_free = None     # event per buffer: last GEMM that read it
-        self.stream = None
-        self.pending = {}        # position -> (view, done_event, buffer slot)
-        self.capacity = 0
-
-    def _ensure(self, device, numel):
-        if self.stream is None:
-            self.stream = torch.cuda.Stream(device)
-        if self.bufs is None or numel > self.capacity:
-            if torch.cuda.is_current_stream_capturing():
-                return False
-            self.capacity = max(numel, self.capacity)
-            self.bufs = [torch.empty(self.capacity, dtype=torch.uint8, device=device) for _ in range(3)]
-            self.buf_free = [None, None, None]
-            self.pending.clear()
-        return True
-
-    def position(self, layer):
-        pos = self.index.get(id(layer))
-        if pos is None:
-            pos = len(self.layers)
-            self.index[id(layer)] = pos
-            self.layers.append(layer)
-        return pos
-
-    def take(self, pos):
-        return self.pending.pop(pos, None)
-
-    def launch(self, pos, device):
-        """Enqueue the weight pass of layer `pos` on the side stream (called right after a GEMM launch)."""
-        if pos >= len(self.layers) or pos in self.pending:
-            return
-        layer = self.layers[pos]
-        fq = layer.weight_fake_quant
-        W = layer.weight
-        if not (isinstance(fq, FusedAmaxObsFakeQuantize) and fq.fp8_exact() and W.is_contiguous()
-                and W.dtype == torch.bfloat16 and W.numel() % 16 == 0):
-            return
-        if not self._ensure(device, W.numel()):
-            return
-        slot = pos % 3
-        main = torch.cuda.current_stream(device)
-        fork = torch.cuda.Event()
-        fork.record(main)
-        self.stream.wait_event(fork)                         # fork point (also orders after the reader of `slot`)
-        if self.buf_free[slot] is not None:
-            self.stream.wait_event(self.buf_free[slot])
-        view = self.bufs[slot][: W.numel()].view(W.shape)
-        with torch.cuda.stream(self.stream):
-            L = _native.lib()
-            _native.check(L.qt_fake_quant_bf16_fp8(W.data_ptr(), None, view.data_ptr(), W.numel(),
-                                                   ctypes.byref(fq._qt_format), fq.scale.data_ptr(), None,
-                                                   _stream_ptr(W)), "qt_fake_quant_bf16_fp8")
-            done = torch.cuda.Event()
-            done.record(self.stream)
-        self.pending[pos] = (view.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn), done, slot)
-
-    def mark_read(self, slot, device):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        self.buf_free[slot] = ev
-
-
-_PREFETCH = _WeightPrefetcher()
-
-
-def prefetch_enabled():
-    # Measured on MI355X (LLaMA-2-7B window, hipGraph replay): 26.2 ms with the overlap vs 24.1 ms without --
-    # the HBM-bound pass and the FP8 GEMM contend for the same CUs and memory pipes -- so it is opt-in.
-    return os.environ.get("QT_WEIGHT_PREFETCH", "0") == "1"
-
-
-_WEIGHT_CACHE = {"on": os.environ.get("QT_CACHE_EVAL_WEIGHTS", "0") == "1", "epoch": 0}
+_WEIGHT_CACHE = {"on": False, "epoch": 0}      # harness.cache_quantized_weights(True) turns it on
 
 
 def cache_quantized_weights(enable: bool = True):
@@ -398,7 +314,7 @@ def mlp_route_is_one_launch(x8, gate, up, out_fq):
 
 def _sibling_linear_or_none(layer, x, x8):
     group = layer.__dict__.get("_qt_sibling_group")
-    if group is None or os.environ.get("QT_SIBLING_GEMM", "1") == "0" or prefetch_enabled() or _WEIGHT_CACHE["on"]:
+    if group is None or os.environ.get("QT_SIBLING_GEMM", "1") == "0" or _WEIGHT_CACHE["on"]:
         return None
     idx = group.layers.index(layer)
     key = _origin_key(x)
@@ -470,37 +386,22 @@ def fp8_linear_or_none(layer, x):
     shared = _sibling_linear_or_none(layer, x, x8)
     if shared is not None:
         return shared
-    if fq8_gemm_enabled() and not prefetch_enabled() and not _WEIGHT_CACHE["on"] and fq8_route_is_fused(x8.reshape(-1, K), [layer]):
+    if fq8_gemm_enabled() and not _WEIGHT_CACHE["on"] and fq8_route_is_fused(x8.reshape(-1, K), [layer]):
         y = hip_fq8_linear_or_none(x8.reshape(-1, K), [layer])
         if y is not None:
             STATS.add(W.numel())                   # the weight's fake-quant call, computed inside the GEMM
             return y.reshape(*x.shape[:-1], W.shape[0])
-    pf = _PREFETCH if prefetch_enabled() else None
-    slot = None
-    w8 = None
-    if pf is not None:
-        pos = pf.position(layer)
-        ready = pf.take(pos)
-        if ready is not None:
-            w8, done, slot = ready
-            torch.cuda.current_stream(x.device).wait_event(done)       # join
-            STATS.add(W.numel())
-    if w8 is None:
-        def make():
-            STATS.add(W.numel())
-            return FusedAmaxObsFakeQuantFunction.apply(W.detach(), False, True, fq.qmap, fq.amax_history, fq.scale,
-                                                       fq.amax_history_len, fq.quant_max, None, False, False,
-                                                       fq._qt_format, "only")
-        w8 = cached_weight(layer, "fp8", make)
+    def make():
+        STATS.add(W.numel())
+        return FusedAmaxObsFakeQuantFunction.apply(W.detach(), False, True, fq.qmap, fq.amax_history, fq.scale,
+                                                   fq.amax_history_len, fq.quant_max, None, False, False,
+                                                   fq._qt_format, "only")
+    w8 = cached_weight(layer, "fp8", make)
     one = _one(x.device)
     x2 = x8.reshape(-1, K)
     y = lt_fp8_gemm(x2, w8, layer.bias)
     if y is None:
         y = torch._scaled_mm(x2, w8.t(), scale_a=one, scale_b=one, bias=layer.bias, out_dtype=torch.bfloat16)
-    if pf is not None:
-        if slot is not None:
-            pf.mark_read(slot, x.device)
-        pf.launch(pos + 1, x.device)          # no wrap-around: the first layer of a forward runs its pass inline
     return y.reshape(*x.shape[:-1], W.shape[0])
 
 
@@ -944,19 +845,12 @@ def _fp8_probs_times_v_or_none(L, st, scores, mask, msb, msh, msq, scaling, fq_p
                                                     ctypes.byref(fq_v._qt_format), st), "qt_fake_quant_rows_bf16_fp8")
         v8 = v8u.view(torch.float8_e5m2 if fq_v._qt_format.p0 == 2 else torch.float8_e4m3fn)
     p8u = torch.empty((B, H, Q, C), dtype=torch.uint8, device=scores.device)
-    # Opt-in for the score pass: bit-identical, but not faster inside the window (12.97 against 12.88 ms on one box) -- there the scores the
-    # Q.K^T GEMM just wrote are cache-resident and the pieces it skips cost little; alone on cold buffers the pass gains about a tenth.
-    live = (_mask_row_live(mask, mask_owner, B, H, Q, C, st)
-            if (mask is not None and mask_owner is not None and C > 512 and os.environ.get("QT_SOFTMAX_ROW_LIVE", "0") == "1") else None)
-    if live is not None:
-        rl, lsb, lsh, lsq = live
-        _native.check(L.qt_softmax_fq_bf16_fp8_live(scores.data_ptr(), mask.data_ptr(), p8u.data_ptr(), B, H, Q, C, msb, msh, msq,
-                                                    float(scaling), ctypes.byref(fq_p._qt_format), rl.data_ptr(), lsb, lsh, lsq, st),
-                      "qt_softmax_fq_bf16_fp8_live")
-    else:
-        _native.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr() if mask is not None else None, None,
-                                               p8u.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling),
-                                               ctypes.byref(fq_p._qt_format), st), "qt_softmax_fq_bf16_fp8")
+    # (qt_softmax_fq_bf16_fp8_live -- the same pass told each mask row's extent -- is bit-identical and gains a tenth alone on cold
+    # buffers, nothing inside the window where the scores the Q.K^T GEMM just wrote are cache-resident: 12.97 against 12.88 ms; it
+    # stays in the C ABI, the module path does not take it)
+    _native.check(L.qt_softmax_fq_bf16_fp8(scores.data_ptr(), mask.data_ptr() if mask is not None else None, None,
+                                           p8u.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling),
+                                           ctypes.byref(fq_p._qt_format), st), "qt_softmax_fq_bf16_fp8")
     p8 = p8u.view(torch.float8_e5m2 if fq_p._qt_format.p0 == 2 else torch.float8_e4m3fn)
     out = lt_fp8_gemm(p8.view(B * H, Q, C), v8.view(B * H, C, D), None, b_is_kn=True)
     if out is None:
@@ -1197,7 +1091,7 @@ def launch_attention_fq(L, st, qq, kq, vq, mask, mask_owner, mask_strides, out, 
     B, H, Q, C, D = dims
     msb, msh, msq = mask_strides
     live = None
-    if mask is not None and mask_owner is not None and os.environ.get("QT_ATTN_ROW_LIVE", "1") != "0":
+    if mask is not None and mask_owner is not None:
         live = _mask_row_live(mask, mask_owner, B, H, Q, C, st)
     if live is not None:
         rl, lsb, lsh, lsq = live

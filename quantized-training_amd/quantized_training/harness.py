@@ -41,7 +41,7 @@ def shard_round_robin(items: Sequence, rank: int, world: int) -> List:
 def _window_loss(model, input_ids, labels, **kwargs):
     """`model(input_ids, labels=labels).loss` of a causal LM.  On the device with bf16 logits the loss comes from ONE pass over the
     logits (qt_causal_lm_loss_bf16: the same shifted-label fp32 cross entropy, mean over the scored positions) instead of the bf16 ->
-    fp32 copy + softmax + reduction transformers runs (QT_FUSED_LOSS=0 keeps those); anything else takes the model's own loss."""
+    fp32 copy + softmax + reduction transformers runs; anything else takes the model's own loss."""
     import ctypes
     import os
     if isinstance(model, torch.fx.GraphModule):
@@ -50,7 +50,7 @@ def _window_loss(model, input_ids, labels, **kwargs):
         return model(input_ids, labels=labels, use_cache=False).loss.float()
     # the one-pass loss restates transformers' ForCausalLMLoss: only for models whose loss IS that function
     stock_loss = getattr(getattr(model, "loss_function", None), "__name__", "") == "ForCausalLMLoss"
-    if os.environ.get("QT_FUSED_LOSS", "1") != "0" and input_ids.is_cuda and not torch.is_grad_enabled() and stock_loss:
+    if input_ids.is_cuda and not torch.is_grad_enabled() and stock_loss:
         from . import _native
         out = model(input_ids, use_cache=False, **kwargs)
         logits = getattr(out, "logits", None)
@@ -370,9 +370,12 @@ class GraphedTrainStep:
     changes it); `clip_grad_norm_` runs with `error_if_nonfinite=False` (the check is a host read).  Batches must keep one
     shape.  Warm-up steps run eagerly first (they also create the lazily built fake-quantizers) and DO train."""
 
-    def __init__(self, model, optimizer, lr_scheduler=None, max_grad_norm: float = 1.0, batch_scale_updates: bool = True):
+    def __init__(self, model, optimizer, lr_scheduler=None, max_grad_norm: float = 1.0, batch_scale_updates: bool = True,
+                 batch_weight_passes: bool = True):
         self.model, self.optimizer, self.lr_scheduler, self.max_grad_norm = model, optimizer, lr_scheduler, max_grad_norm
         self.batch_scale_updates = batch_scale_updates
+        self.batch_weight_passes = batch_weight_passes
+        self.weights = None               # fake_quantize.BatchedWeightFakeQuant over the QAT Linears' weight fake-quantizers
         self.graph = None
         self.static = None
         self.loss = None
@@ -381,6 +384,9 @@ class GraphedTrainStep:
     def _step(self, batch):
         if self.scales is not None:
             self.scales.launch()          # every delayed-scaling update of the step in one launch (356 -> 1 for RoBERTa-base)
+        if self.weights is not None:
+            self.weights.launch()         # every weight fake-quantizer of the step in one launch per format (74 -> 1): the weights
+                                          # only change in optimizer.step() below
         loss = self.model(**batch).loss
         loss.backward()
         if self.max_grad_norm is not None:
@@ -410,6 +416,14 @@ class GraphedTrainStep:
             if self.batch_scale_updates:
                 # those a step calls (at least once: a second call in the same step does its own update as before)
                 self.scales = BatchedScaleUpdate([f for f in fqs if f.__dict__.get("_qt_calls", 0) >= 1], device)
+            if self.batch_weight_passes and self.scales is not None:
+                from .fake_quantize import BatchedWeightFakeQuant
+                from .modules.qat.linear import Linear as QATLinear
+                # weight fake-quantizers a step calls exactly once (a shared / tied Linear called twice keeps its own passes)
+                pairs = [(m.weight_fake_quant, m.weight) for m in self.model.modules()
+                         if isinstance(m, QATLinear) and m.weight_fake_quant.__dict__.get("_qt_calls", 0) == 1]
+                batch = BatchedWeightFakeQuant(pairs, device)
+                self.weights = batch if len(batch) else None
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.optimizer.zero_grad(set_to_none=True)          # gradients are (re)allocated inside the graph's pool
@@ -418,6 +432,8 @@ class GraphedTrainStep:
             self.loss = self._step(self.static)
         if self.scales is not None:
             self.scales.forget()          # nothing may stay marked "already updated" outside the captured step
+        if self.weights is not None:
+            self.weights.forget()
         return warmup
 
     def replay(self, batch):

@@ -73,42 +73,29 @@ def rmsnorm(x, weight, eps):
 
 
 def _norm_with_consumers(x2, r2, weight, eps, fqs):
-    """One launch for (residual add +) RMSNorm and the input fake-quantizers of ALL the Linears consuming it (qt_rmsnorm_consumers_bf16):
-    returns (sum or None, y) where y = fq_0(result) carries the first consumer's codes as before and, for the others, their own codes
-    (`_qt_also_done`): their hooks hand those through (fake_quantize.py) instead of launching a pass each over the tensor."""
+    """One launch for (residual add +) RMSNorm and the input fake-quantizers of ALL the Linears consuming it: returns (sum or None, y)
+    where y = fq_0(result) carries the codes for every consumer (`_qt_also_done`): their hooks hand them through (fake_quantize.py)
+    instead of launching a pass each over the tensor.  (Round 2 wrote one code tensor per consumer, qt_rmsnorm_consumers_bf16 -- still
+    in the C ABI; with equal formats the codes are the same bytes, and sharing one tensor took 0.4 ms off the headline window.)"""
     cols = x2.shape[-1]
     n = len(fqs)
-    if os.environ.get("QT_NORM_SHARED_CODES", "1") != "0":
-        # the consumers' formats are equal (_norm_consumer_fq checks it), so their codes are the same bytes: ONE evaluation, one code
-        # tensor, shared -- each consumer's call is still handed through and counted (8 MB less to write per norm at 1024 x 4096)
-        total = torch.empty_like(x2) if r2 is not None else None
-        y = torch.empty_like(x2)
-        y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
-        f0 = fqs[0]
-        if r2 is not None:
-            _native.check(_native.lib().qt_add_rmsnorm_bf16(x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), total.data_ptr(), y.data_ptr(),
-                                                            y8.data_ptr(), x2.numel() // cols, cols, float(eps), ctypes.byref(f0._qt_format),
-                                                            _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
-        else:
-            _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols,
-                                                            float(eps), ctypes.byref(f0._qt_format), _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
-        codes = _fp8_view(y8, f0)
-        y._qt_fp8 = codes
-        y._qt_fq_done_by = f0
-        y._qt_also_done = [(f, codes) for f in fqs[1:]]
-        y._qt_ver = y._version
-        return total, y
+    # the consumers' formats are equal (_norm_consumer_fq checks it), so their codes are the same bytes: ONE evaluation, one code
+    # tensor, shared -- each consumer's call is still handed through and counted (8 MB less to write per norm at 1024 x 4096)
     total = torch.empty_like(x2) if r2 is not None else None
     y = torch.empty_like(x2)
-    y8 = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
-    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in y8])
-    fmts = (ctypes.c_void_p * n)(*[ctypes.addressof(f._qt_format) for f in fqs])
-    _native.check(_native.lib().qt_rmsnorm_consumers_bf16(
-        x2.data_ptr(), r2.data_ptr() if r2 is not None else None, weight.data_ptr(), total.data_ptr() if total is not None else None,
-        y.data_ptr(), x2.numel() // cols, cols, float(eps), n, ptrs, fmts, _stream_ptr(x2)), "qt_rmsnorm_consumers_bf16")
-    y._qt_fp8 = _fp8_view(y8[0], fqs[0])
-    y._qt_fq_done_by = fqs[0]
-    y._qt_also_done = [(f, _fp8_view(t, f)) for f, t in zip(fqs[1:], y8[1:])]
+    y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+    f0 = fqs[0]
+    if r2 is not None:
+        _native.check(_native.lib().qt_add_rmsnorm_bf16(x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), total.data_ptr(), y.data_ptr(),
+                                                        y8.data_ptr(), x2.numel() // cols, cols, float(eps), ctypes.byref(f0._qt_format),
+                                                        _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
+    else:
+        _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols,
+                                                        float(eps), ctypes.byref(f0._qt_format), _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
+    codes = _fp8_view(y8, f0)
+    y._qt_fp8 = codes
+    y._qt_fq_done_by = f0
+    y._qt_also_done = [(f, codes) for f in fqs[1:]]
     y._qt_ver = y._version
     return total, y
 
@@ -169,8 +156,7 @@ def _add_rmsnorm_or_none(x, residual, norm):
     other dtypes / devices, QT_FUSED_MODEL_OPS=0)."""
     w = getattr(norm, "weight", None)
     if (norm is None or w is None or norm.__dict__.get("_qt_hf_forward") is None or _hooked(norm) or not _eligible(x, residual, w)
-            or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()
-            or os.environ.get("QT_FUSED_ADD_NORM", "1") == "0"):
+            or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()):
         return None
     return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm, allow_all=True, allow_map=True))
 
@@ -269,7 +255,7 @@ def _norm_consumer_fq(norm, allow_all=False, allow_map=False):
         g = f._qt_format
         if (g.kind, g.p0, g.p1, g.flo, g.fhi) != (f0.kind, f0.p0, f0.p1, f0.flo, f0.fhi):
             return None
-    if allow_all and 2 <= len(fqs) <= 3 and len({id(f) for f in fqs}) == len(fqs) and os.environ.get("QT_NORM_ALL_CONSUMERS", "1") != "0":
+    if allow_all and 2 <= len(fqs) <= 3 and len({id(f) for f in fqs}) == len(fqs):
         return fqs                                   # all of them in the norm's launch (_norm_with_consumers)
     return fqs[0]
 
@@ -441,24 +427,14 @@ def layernorm(x, norm, residual=None, fq=None):
             # (and the shared fake-quantized values) waiting for its next call
             fqs, n = fq, len(fq)
             yq = torch.empty_like(x2)
-            if os.environ.get("QT_NORM_SHARED_CODES", "1") != "0":
-                # equal formats (checked by _norm_consumer_fq): the consumers' codes are the same bytes -- one evaluation, one tensor
-                y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
-                _native.check(_native.lib().qt_layernorm_bf16(
-                    x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
-                    yq.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(norm.eps), ctypes.byref(fqs[0]._qt_format),
-                    _stream_ptr(x2)), "qt_layernorm_bf16")
-                for f in fqs:
-                    f.expect_prequantized(y, _fp8_view(y8, f), replacement=yq)
-                return y
-            y8s = [torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) for _ in fqs]
-            ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in y8s])
-            fmts = (ctypes.c_void_p * n)(*[ctypes.addressof(f._qt_format) for f in fqs])
-            _native.check(_native.lib().qt_layernorm_consumers_bf16(
+            # equal formats (checked by _norm_consumer_fq): the consumers' codes are the same bytes -- one evaluation, one tensor
+            y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
+            _native.check(_native.lib().qt_layernorm_bf16(
                 x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
-                yq.data_ptr(), x2.numel() // cols, cols, float(norm.eps), n, ptrs, fmts, _stream_ptr(x2)), "qt_layernorm_consumers_bf16")
-            for f, t in zip(fqs, y8s):
-                f.expect_prequantized(y, _fp8_view(t, f), replacement=yq)
+                yq.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(norm.eps), ctypes.byref(fqs[0]._qt_format),
+                _stream_ptr(x2)), "qt_layernorm_bf16")
+            for f in fqs:
+                f.expect_prequantized(y, _fp8_view(y8, f), replacement=yq)
             return y
         fq = fq[0]
     yq = y8 = None
@@ -650,7 +626,7 @@ def _fused_mlp_or_none(self, x):
     from .fake_quantize import STATS, handover_valid
     from .modules.qat.linear import Linear as QATLinear
     gate, up, down = self.gate_proj, self.up_proj, self.down_proj
-    if os.environ.get("QT_FQ8_MLP", "1") == "0" or not fused.fq8_gemm_enabled() or fused.prefetch_enabled() or fused._WEIGHT_CACHE["on"]:
+    if os.environ.get("QT_FQ8_MLP", "1") == "0" or not fused.fq8_gemm_enabled() or fused._WEIGHT_CACHE["on"]:
         return None
     if not (isinstance(gate, QATLinear) and isinstance(up, QATLinear) and _eligible(x) and _only_pre_hooks(gate) and _only_pre_hooks(up)):
         return None
@@ -767,7 +743,7 @@ def _rotary_table_forward(self, x, position_ids):
     caller that passes the SAME position tensor again (same storage, same version -- the window harness's static arange) gets the
     tensors computed for it the first time; the cached entry keeps that position tensor alive, so its address cannot come back as
     another tensor's.  Anything else (a fresh tensor per forward, as transformers builds by default) is computed as before."""
-    if torch.is_grad_enabled() or not _enabled() or os.environ.get("QT_ROTARY_TABLE_CACHE", "1") == "0":
+    if torch.is_grad_enabled() or not _enabled():
         return self._qt_hf_forward(x, position_ids)
     key = (position_ids.data_ptr(), position_ids._version, tuple(position_ids.shape), position_ids.dtype, x.dtype, x.device)
     hit = self.__dict__.get("_qt_table")
@@ -903,13 +879,8 @@ def apply_llama_fusions(model):
                 for lin in group.layers:
                     lin.__dict__["_qt_sibling_group"] = group
             mod.post_attention_layernorm.__dict__["_qt_consumers"] = [mlp.gate_proj, mlp.up_proj]
-            # gate / up as a group measured slightly slower (one N = 22016 GEMM is no faster than two N = 11008 ones and
-            # SiLU * up then reads strided rows): 16.64 vs 16.48 ms per window -- opt-in
-            if os.environ.get("QT_SIBLING_MLP", "0") == "1" and all(hasattr(l, "weight_fake_quant") for l in (mlp.gate_proj, mlp.up_proj)):
-                from .fused import SiblingGroup
-                group = SiblingGroup([mlp.gate_proj, mlp.up_proj])
-                for lin in group.layers:
-                    lin.__dict__["_qt_sibling_group"] = group
+            # (gate / up as one sibling group measured slower -- one N = 22016 GEMM is no faster than two N = 11008 ones and SiLU * up
+            # then reads strided rows: 16.64 vs 16.48 ms per window; what pays is the one-launch MLP front half, qt_mlp_fq8_bf16)
     if n:
         _patch_rope()
     return n

@@ -41,7 +41,7 @@ class _Stats:
 
 
 STATS = _Stats()
-_DEBUG = os.environ.get("QT_MX_DEBUG") == "1"
+_DEBUG = False            # set mx_gemm._DEBUG = True to print why a problem took the reference formulation
 
 
 def _fallback(why):

@@ -321,8 +321,7 @@ class PreparedCausalLMLoss(nn.Module):
     def forward(self, logits, labels):
         if (logits.is_cuda and not torch.is_grad_enabled() and logits.dim() == 3 and logits.dtype == torch.bfloat16 and logits.stride(2) == 1
                 and logits.stride(0) == logits.shape[1] * logits.stride(1) and logits.stride(1) % 8 == 0 and logits.data_ptr() % 16 == 0
-                and labels.dtype == torch.long and labels.is_contiguous() and labels.shape == logits.shape[:2]
-                and os.environ.get("QT_FUSED_LOSS", "1") != "0"):
+                and labels.dtype == torch.long and labels.is_contiguous() and labels.shape == logits.shape[:2]):
             B, S, V = logits.shape
             scratch = torch.empty(B * S + 1, dtype=torch.float32, device=logits.device)
             _native.check(_native.lib().qt_causal_lm_loss_bf16(logits.data_ptr(), labels.data_ptr(), B, S, V, logits.stride(1), -100,
@@ -914,8 +913,7 @@ def fuse_prepared_graph(model: GraphModule):
     p.norms()
     p.attentions()
     _loss(p)
-    if os.environ.get("QT_PT2E_HOIST", "1") != "0":
-        _hoist_shape_only(p)
+    _hoist_shape_only(p)
     model.graph.lint()
     model.recompile()
     _install_state_dict_hooks(model)

@@ -78,8 +78,6 @@ def _fp8_codes_gemm(a, w, bias):
     """C = a . w^T (+ bias) on FP8 CODES through the in-tree scaled-MFMA GEMM (qt_mx_gemm, v_mfma_scale_f32_16x16x128_f8f6f4) at unit
     block scales: per-tensor FP8 operands are a block-scaled operand whose every scale is 2^0.  None when the kernel does not take
     the problem (the caller then keeps the library GEMM)."""
-    if os.environ.get("QT_PT2E_FP8_NATIVE", "1") == "0":
-        return None
     M, K = a.shape
     N = w.shape[0]
     if K % 32 or a.dtype not in _MX_FMT or w.dtype not in _MX_FMT or not a.is_contiguous() or not w.is_contiguous() or a.data_ptr() % 16 or w.data_ptr() % 16:

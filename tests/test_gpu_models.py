@@ -208,7 +208,7 @@ def test_bert_squad_style_batch_parity(monkeypatch):
     from transformers import BertConfig, BertForQuestionAnswering
     from quantized_training import fused
     from quantized_training.fake_quantize import STATS
-    for k in ("QT_FP8_ATTENTION_KERNEL", "QT_FP8_ATTENTION", "QT_FP8_ATTENTION_VARIANT"):
+    for k in ("QT_FP8_ATTENTION_KERNEL", "QT_FP8_ATTENTION"):
         monkeypatch.delenv(k, raising=False)                                   # the test asserts which kernel ran
     torch.manual_seed(0)
     cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=300,
