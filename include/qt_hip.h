@@ -187,6 +187,11 @@ typedef struct qt_fq_item {
 } qt_fq_item;
 int qt_fake_quant_multi_bf16(const qt_fq_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt,
                              const uint16_t *lut_dev, void *stream);
+
+/* out[c] = bf16(sum_r x[r][c]) for a contiguous bf16 [rows][cols] matrix, fp32 sums in a fixed order (deterministic): the bias
+ * gradient of nnqat.Linear's backward, grad_output.sum(0) of the fake-quantized gradient (modules/qat/linear.py:40-41 through
+ * autograd; quantize.py:116-179 quantizes grad_output first).  cols % 8 == 0, x_dev 16-byte aligned. */
+int qt_colsum_bf16(const uint16_t *x_dev, uint16_t *out_dev, long rows, long cols, void *stream);
 int qt_fake_quant_rows_bf16(const uint16_t *x_dev, uint16_t *y_dev, long d0, long d1, long d2, long inner,
                             long s0, long s1, long s2, const qt_format *fmt, const uint16_t *lut_dev,
                             const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);

@@ -2392,3 +2392,45 @@ def test_pt2e_fp8_linears_run_on_the_fp8_matrix_cores(nv, monkeypatch):
         assert (pt2e_native.STATS.get("linear_fp8_native", 0) - before_native) == (2 if native == "1" else 0)
     rel = ((outs["1"] - outs["0"]).norm(dim=-1) / outs["0"].norm(dim=-1).clamp_min(1e-6)).max()
     assert float(rel) <= 0.02, float(rel)
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 768), (2048, 3072), (1, 8), (777, 40), (64, 2304)])
+def test_colsum_is_the_bias_gradient(nv, rows, cols):
+    """qt_colsum_bf16 = grad_output.sum(0) (autograd's bias gradient of F.linear, modules/qat/linear.py:40-41): against an fp64 column
+    sum, within one bf16 rounding of the result plus fp32 accumulation; deterministic; and through the QAT Linear's backward the three
+    gradients equal autograd's own up to that rounding."""
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, device="cuda") * 3).bfloat16()
+    out = torch.empty(cols, dtype=torch.bfloat16, device="cuda")
+    nv.check(nv.lib().qt_colsum_bf16(x.data_ptr(), out.data_ptr(), rows, cols, stream()), "qt_colsum_bf16")
+    again = torch.empty_like(out)
+    nv.check(nv.lib().qt_colsum_bf16(x.data_ptr(), again.data_ptr(), rows, cols, stream()), "qt_colsum_bf16")
+    assert torch.equal(out.view(torch.int16), again.view(torch.int16))
+    ref = x.double().sum(0)
+    tol = ref.abs() * 2.0 ** -8 + x.double().abs().sum(0) * 2.0 ** -20 + 1e-30
+    assert bool(((out.double() - ref).abs() <= tol).all())
+    assert nv.lib().qt_colsum_bf16(x.data_ptr(), out.data_ptr(), rows, 12, stream()) == nv.QT_ERR_BAD_ARG       # cols % 8
+
+
+def test_qat_linear_training_backward_uses_colsum(nv):
+    import quantized_training as qt
+    from quantized_training.modules.qat.linear import Linear as QATLinear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 384, bias=True).cuda().bfloat16()
+    lin.qconfig = qt.QConfig(activation=None, weight=lambda **kw: qt.FusedAmaxObsFakeQuantize(dtype="posit8_1", **{k: v for k, v in kw.items() if k == "device"}),
+                             error=None)                                     # stateless: the second call below quantizes W to the same values
+    q = QATLinear.from_float(lin).cuda().train()
+    x = torch.randn(8, 64, 256, device="cuda").bfloat16().requires_grad_(True)
+    y = q(x)
+    assert y.grad_fn is not None and "LinearColsumBias" in type(y.grad_fn).__name__
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = (x.grad.clone(), q.weight.grad.clone(), q.bias.grad.clone())
+    # autograd's own backward on the same quantized weight
+    x2 = x.detach().clone().requires_grad_(True)
+    wq = q.weight_fake_quant(q.weight.detach()).detach().requires_grad_(True)
+    b2 = q.bias.detach().clone().requires_grad_(True)
+    torch.nn.functional.linear(x2, wq, b2).backward(gy)
+    assert torch.equal(got[0], x2.grad) and torch.equal(got[1], wq.grad)
+    ref = gy.reshape(-1, 384).double().sum(0)
+    assert bool(((got[2].double() - ref).abs() <= ref.abs() * 2.0 ** -8 + gy.double().abs().sum((0, 1)) * 2.0 ** -20).all())
