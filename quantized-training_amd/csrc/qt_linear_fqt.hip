@@ -244,7 +244,10 @@ struct LinearFqt {
         {
             const int t = w * 64 + l;
             if (t < (SROWS ? 512 : 256)) {
-                const u32x4 v = *(const u32x4 *)(a.rows + t * 4);
+                u32x4 v = *(const u32x4 *)(a.rows + t * 4);
+                // a flagged row (bit 0 of C) POISONS: C = lo = hi = NaN make every weight of the row a NaN, which reaches every sum it
+                // enters; the sums are checked once after the k loop (no per-weight flag arithmetic in the loop)
+                if (ABL == 0 && (v.y & 1u)) v = u32x4{0u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};
                 asm volatile("ds_write_b128 %0, %1" ::"v"(t * 16), "v"(v) : "memory");
             }
         }
@@ -278,7 +281,6 @@ struct LinearFqt {
             gw[i] = (uint32_t)((long)((grp - sg.g0) * 16 + (l >> 2)) * krow) + (chunk_pos(row, l & 3) << 4);
             wofs[i] = (uint32_t)pb * 1024u;
         }
-        uint32_t flags = 0;
         const uint32_t sign_mask = a.sign_mask;
         int stamp_kt = -1;
         auto stamp = [&](int slot) __attribute__((always_inline)) {
@@ -356,8 +358,6 @@ struct LinearFqt {
                 if constexpr (ABL != 5) {
                     q.x = quant_pair(raw_word(uc, 0), rp[0], rp[1], sign_mask);
                     q.y = quant_pair(raw_word(uc, 1), rp[2], rp[3], sign_mask);
-                    const uint32_t f = (rp[0].y | rp[1].y) | (rp[2].y | rp[3].y);
-                    flags |= real[I] ? f : 0u;
                 }
                 ds_write64(piece_addr(I, wc) + (U & 1) * 8, q);
             }
@@ -539,8 +539,6 @@ struct LinearFqt {
                 u32x4 q;
                 q.x = quant_pair(v.x, p[0], p[1], sign_mask); q.y = quant_pair(v.y, p[2], p[3], sign_mask);
                 q.z = quant_pair(v.z, p[4], p[5], sign_mask); q.w = quant_pair(v.w, p[6], p[7], sign_mask);
-                const uint32_t f = (p[0].y | p[1].y | p[2].y) | (p[3].y | p[4].y | p[5].y) | (p[6].y | p[7].y);
-                if constexpr (ABL == 0 || ABL == 9 || ABL == 8) flags |= real[i] ? f : 0u;
                 if constexpr (ABL != 0 && ABL != 9 && ABL != 8) q = v;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(piece_addr(i, w0)), "v"(q) : "memory");
             }
@@ -569,7 +567,18 @@ struct LinearFqt {
         volatile int *flag = (volatile int *)lds;
         if (w == 0 && l == 0) *flag = 0;
         __syncthreads();
-        if ((flags & 1u) && (ABL == 0 || ABL == 9 || ABL == 8)) *flag = 1;      // (ABL 7 computes garbage: never redo)
+        {
+            // a NaN among the sums: a weight of a flagged row (or a non-finite operand the reference would turn into NaN as well) --
+            // the tile is redone through the map itself, which gives the exact answer in either case
+            bool bad = false;
+            if constexpr (NTW > 0 && ABL == 0) {
+#pragma unroll
+                for (int i = 0; i < kRT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) bad |= (acc[i][j][0] != acc[i][j][0]) | (acc[i][j][1] != acc[i][j][1]) | (acc[i][j][2] != acc[i][j][2]) | (acc[i][j][3] != acc[i][j][3]);
+            }
+            if (bad) *flag = 1;
+        }
         __syncthreads();
         const bool flagged = *flag != 0;
         if (a.ksplit <= 1) {

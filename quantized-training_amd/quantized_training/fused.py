@@ -556,12 +556,13 @@ def fqt_plan(M, n_total, K):
 
 
 def fqt_route_is_fused(M, ns, K, device):
-    """Fixed routing rule for qt_linear_fqt_bf16, from the measurements in DESIGN.md 6c / 6d (MI355X, posit(8,2)): the kernel wins
-    where 512-row tiles at least seven column groups wide fill the chip (1024 x 15360 x 5120: 160 against 194 us for weight pass +
-    library GEMM; 1024 x 32000 x 5120: 332 against 395), and -- since round 4, with split-K -- on narrow outputs with a deep K
-    (1024 x 5120 x 13824: 167-177 against 181-200: three workgroups per 512 x 128 tile, 144 k steps each).  It loses where the
-    tiles are narrower (1024 x 13824 x 5120: 176-183 against 173-178) and where a split's k range is too short to pay for the
-    hand-off of the fp32 partial sums (1024 x 5120 x 5120: 83-91 against 70)."""
+    """Fixed routing rule for qt_linear_fqt_ws_bf16, from same-box A/B runs of the whole configs[3] window (tools/ab_13b_routes.py,
+    profiles/r04_13b_route_ab.txt; MI355X, posit(8,2)): the kernel takes every Linear whose 512-row tiles are at least five column
+    groups wide on a full chip -- q / k / v as one launch, the lm head, and since round 4 gate / up too: alone it ties with the weight
+    pass + library GEMM (161-183 against 173-179 us), inside the window it is worth 2.4 ms of 37 (the pair's pass and GEMM compete
+    with their neighbours for HBM) -- and, with split-K, narrow outputs with a deep K (down: 1024 x 5120 x 13824, three workgroups
+    per 512 x 128 tile, 144 k steps each: 167-177 against 181-200 us).  It loses where a split's k range is too short to pay for
+    the hand-off of the fp32 partial sums (o: 1024 x 5120 x 5120, 83 against 70 us; +0.2 ms per window), which stays on the pair."""
     mode = fqt_gemm_mode()
     if mode != "auto":
         return mode == "1"
@@ -576,7 +577,7 @@ def fqt_route_is_fused(M, ns, K, device):
     tn_min = (groups + 7) // 8
     rounds = (tiles_m * tn_min + cus - 1) // cus
     tn = max(tn_min, rounds * cus // tiles_m)
-    return groups / tn >= 7.0 and tiles_m * tn >= 0.9 * rounds * cus
+    return groups / tn >= 5.0 and tiles_m * tn >= 0.9 * rounds * cus
 
 
 def _fqt_route(M, ns, K, device):

@@ -1956,7 +1956,7 @@ def test_qat_linear_takes_the_fused_value_map_gemm(nv, dtype, monkeypatch):
         assert fused.fqt_route_is_fused(1024, [32000], 5120, x.device) is True                  # lm head
         assert fused.fqt_route_is_fused(1024, [5120], 13824, x.device) is True                  # down: split-K, 3 x 144 k steps
         assert fused.fqt_plan(1024, 5120, 13824)[0] == 3
-        assert fused.fqt_route_is_fused(1024, [13824], 5120, x.device) is False                 # gate / up: 6.75-group tiles tie at best
+        assert fused.fqt_route_is_fused(1024, [13824], 5120, x.device) is True                  # gate / up: ties alone, wins inside the window
         assert fused.fqt_route_is_fused(1024, [5120], 5120, x.device) is False                  # o: 53 k steps per split do not pay
         assert fused.fqt_route_is_fused(256, [15360], 5120, x.device) is False
     assert isinstance(fused.fqt_route_is_fused(1024, [4096], 11008, x.device), bool)
