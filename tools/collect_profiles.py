@@ -100,7 +100,11 @@ for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_brea
                  ("bench_llama-13b-posit8_2.json", "13b_posit8_2_bench.json"), ("bench_bert-base-squad-e4m3.json", "bert_base_squad_bench.json"),
                  ("bench_roberta-mrpc-int8-e5m2-train.json", "roberta_mrpc_train_bench.json"), ("fqt_gemm.txt", "linear_fqt_gemm.txt"),
                  ("fqt_ablate.txt", "linear_fqt_ablations.txt"), ("fqt_stamps.txt", "linear_fqt_step_stamps.txt"), ("fq8_routes.txt", "fq8_routes.txt"),
-                 ("pt2e_bench.json", "pt2e_route_bench.json"), ("fq8_ablate.txt", "linear_fq8_ablations.txt")):
+                 ("pt2e_bench.json", "pt2e_route_bench.json"), ("fq8_ablate.txt", "linear_fq8_ablations.txt"),
+                 # round 4
+                 ("train_step_breakdown.txt", "train_step_breakdown.txt"), ("bert_batch_breakdown.txt", "bert_batch_breakdown.txt"),
+                 ("ab_13b_routes.txt", "13b_route_ab.txt"), ("ab_7b_routes.txt", "7b_route_ab.txt"), ("ab_bert_routes.txt", "bert_route_ab.txt"),
+                 ("small_fq.txt", "small_fq.txt")):
     clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
 for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
                      ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv"),
