@@ -188,6 +188,18 @@ typedef struct qt_fq_item {
 int qt_fake_quant_multi_bf16(const qt_fq_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt,
                              const uint16_t *lut_dev, void *stream);
 
+/* The FP8-codes-only weight pass (item 9 of INTEGRATION.md: `qt_fake_quant_bf16_fp8` with y = NULL, stateless E4M3 / E5M2 at unit scale)
+ * of MANY tensors as one launch: every `weight_fake_quant(W)` of an evaluation forward whose GEMMs take the weight-pass + library-GEMM
+ * route (modules/qat/linear.py:40-41 issues one per Linear; the weights are constants of the forward).  items_dev: DEVICE array; tensors
+ * 16-byte aligned bf16 with 16 | n; `first_tile` = sum over earlier items of ceil(npair / 1024), total_tiles the sum over all. */
+typedef struct qt_fq8_item {
+    const void *x_bf16;
+    void *y8;
+    unsigned long long npair;     /* n / 16 */
+    unsigned long long first_tile;
+} qt_fq8_item;
+int qt_fake_quant_multi_bf16_fp8(const qt_fq8_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt, void *stream);
+
 /* out[c] = bf16(sum_r x[r][c]) for a contiguous bf16 [rows][cols] matrix, fp32 sums in a fixed order (deterministic): the bias
  * gradient of nnqat.Linear's backward, grad_output.sum(0) of the fake-quantized gradient (modules/qat/linear.py:40-41 through
  * autograd; quantize.py:116-179 quantizes grad_output first).  cols % 8 == 0, x_dev 16-byte aligned. */

@@ -156,8 +156,11 @@ __device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8i
     }
 }
 
-template <int F, int D>
-__global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a) {
+// MB: key blocks of 128 the strip is sized for (8: up to 1024 keys, one workgroup per CU; 4, head_dim 64 only: up to 512 keys -- half the
+// strip registers (113 in all) and a quarter of the LDS, so TWO workgroups share a CU and cover each other's sweeps and barriers:
+// BERT-base's 384-key batches.  At head_dim 128 the 32 accumulator registers more do not fit two workgroups without spilling.)
+template <int F, int D, int MB>
+__global__ __launch_bounds__(512, (MB == 4 && D == 64) ? 4 : 1) void attention_fp8_split_kernel(AttnArgs a) {
     constexpr int kBuf = kBlock * D;                                       // one K / V^T block of codes: 16 KiB at head_dim 128, 8 KiB at 64
     constexpr int kPieces = D / 32;                                        // 1 KiB request pieces per wave and pair of blocks
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // 8 x 16 KiB of K, then V^T, blocks (later the partial sums) + the row statistics
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     const v8i qf = {(int)qlo.x, (int)qlo.y, (int)qlo.z, (int)qlo.w, (int)qhi.x, (int)qhi.y, (int)qhi.z, (int)qhi.w};
     const int f_lo = D == 128 ? chunk_off(r, g) : r * 64 + ((g ^ (((r >> 3) & 1) << 1)) << 4), f_hi = chunk_off(r, 4 + g);
     const int f_v = chunk_off(r, 4 * grp + g);                             // V^T: this group's tiles are one 16-byte chunk per block
-    constexpr int kIter = kMaxBlocks / 2;
+    constexpr int kIter = MB / 2;
     // this wave's four tiles of block kb start at key kb * 128 + 64 grp; how many of them does one of its rows reach?
     auto tiles_of = [&](int kb) { return kb < nlive ? min(4, max(0, (wmax - (kb * kBlock + 64 * grp) + 15) >> 4)) : 0; };
 
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void attention_fp8_split_kernel(AttnArgs a)
     issue_v(0);
     if (niter > 1) issue_v(1);
     // the two groups' maxima meet in LDS
-    float *stat = (float *)(lds + kMaxBlocks * kBuf);                      // [max, sum][2 groups][64 rows]
+    float *stat = (float *)(lds + MB * kBuf);                              // [max, sum][2 groups][64 rows]
     if (g == 0) stat[grp * 64 + wq * 16 + r] = mx;
     __syncthreads();
     mx = fmaxf(stat[wq * 16 + r], stat[64 + wq * 16 + r]);
@@ -417,17 +420,26 @@ bool fp8_closed_form(const qt_format *f, bool &e5m2) {
     return e5m2 || (f->p0 == 3 && f->p1 == -6 && f->fhi == 448.0f);
 }
 
-template <int F, int D>
-int launch_split(const AttnArgs &a, long BH, int nqb, hipStream_t st) {
-    constexpr int kLds = kMaxBlocks * kBlock * D + 2 * 2 * 64 * 4;       // every block of a sweep + the row statistics
+template <int F, int D, int MB>
+int launch_split_mb(const AttnArgs &a, long BH, int nqb, hipStream_t st) {
+    constexpr int kLds = MB * kBlock * D + 2 * 2 * 64 * 4;               // every block of a sweep + the row statistics
+    static_assert(MB * kBlock * D >= 64 * (D + 4) * 4, "the partial sums of the second wave group reuse the block buffers");
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<F, D, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
             return QT_ERR_BAD_ARG;
         configured = true;
     }
-    attention_fp8_split_kernel<F, D><<<dim3((unsigned)BH, (unsigned)nqb), 512, kLds, st>>>(a);
+    attention_fp8_split_kernel<F, D, MB><<<dim3((unsigned)BH, (unsigned)nqb), 512, kLds, st>>>(a);
     return status();
+}
+
+template <int F, int D>
+int launch_split(const AttnArgs &a, long BH, int nqb, hipStream_t st) {
+    if constexpr (D == 64) {
+        if (a.Sk <= 4 * kBlock) return launch_split_mb<F, D, 4>(a, BH, nqb, st);
+    }
+    return launch_split_mb<F, D, 8>(a, BH, nqb, st);
 }
 
 }  // namespace

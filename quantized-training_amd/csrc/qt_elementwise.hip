@@ -497,6 +497,45 @@ __global__ __launch_bounds__(kMultiBlock) void fq_multi_kernel(const qt_fq_item_
     if (obs) block_amax_commit<kMultiBlock>(amax, it.amax);
 }
 
+// FP8 codes of many weights in one launch: every weight pass of an evaluation forward whose GEMMs take the pair route (weight pass +
+// library FP8 GEMM: BERT-base's 36 Linears of 0.6 - 2.4 M elements are 36 launches of ~5 us inside the replayed graph).  Stateless
+// E4M3 / E5M2 at unit scale only; item i is the codes-only qt_fake_quant_bf16_fp8 of tensor i.  A workgroup takes one tile of
+// 1024 pairs (16 384 elements) of one tensor.
+struct qt_fq8_item_dev {
+    const uint4 *x;
+    uint4 *y8;
+    unsigned long long npair;     // 32-byte input pairs (16 elements each)
+    unsigned long long first;     // index of the tensor's first tile in the launch
+};
+constexpr int kMulti8Tile = 256 * 4;
+
+template <bool E5M2>
+__global__ __launch_bounds__(256) void fq8_items_kernel(const qt_fq8_item_dev *__restrict__ items, int count, qt_format fmt) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first <= (unsigned long long)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const qt_fq8_item_dev it = items[lo];
+    const size_t p0 = ((size_t)blockIdx.x - it.first) * kMulti8Tile;
+    uint32_t mag = 0;
+    uint4 v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = p0 + (size_t)u * 256 + threadIdx.x;
+        if (i < it.npair) { v0[u] = it.x[2 * i]; v1[u] = it.x[2 * i + 1]; }
+        else { v0[u] = v1[u] = uint4{0u, 0u, 0u, 0u}; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = p0 + (size_t)u * 256 + threadIdx.x;
+        uint4 o8;
+        if (__builtin_expect(!fq8_fast16<E5M2>(v0[u], v1[u], mag, o8), 0)) o8 = fq8_closed16<E5M2>(v0[u], v1[u], fmt);
+        if (i < it.npair) it.y8[i] = o8;
+    }
+}
+
 // ---- strided rows -> contiguous ----------------------------------------------------------------------
 // Attention hands the hooks permuted views (q / k / v are [B, S, H, D] storage seen as [B, H, S, D]).  The
 // reference's vmap returns a contiguous tensor (decomposed.py:155), i.e. the layout change is part of the
@@ -1283,6 +1322,21 @@ int qt_fake_quant_bf16_fp8_multi(const uint16_t *const *xs, const size_t *ns, in
     hipStream_t st = (hipStream_t)stream;
     if (e5m2) fq8_multi_kernel<true><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
     else fq8_multi_kernel<false><<<grid, 256, 0, st>>>(a, (uint4 *)y8, *fmt);
+    return launch_status();
+}
+
+int qt_fake_quant_multi_bf16_fp8(const qt_fq8_item *items_dev, int count, unsigned long long total_tiles, const qt_format *fmt, void *stream) {
+    if (count == 0 || total_tiles == 0) return QT_OK;
+    if (!items_dev || !fmt || count < 0 || total_tiles > 0x7FFFFFFFull || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
+    const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
+    if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
+    if ((uintptr_t)items_dev & 7u) return QT_ERR_UNALIGNED;
+    static_assert(sizeof(qt_fq8_item) == sizeof(qt_fq8_item_dev), "layout of qt_fq8_item");
+    const qt_fq8_item_dev *it = (const qt_fq8_item_dev *)items_dev;
+    hipStream_t st = (hipStream_t)stream;
+    if (e5m2) fq8_items_kernel<true><<<(unsigned)total_tiles, 256, 0, st>>>(it, count, *fmt);
+    else fq8_items_kernel<false><<<(unsigned)total_tiles, 256, 0, st>>>(it, count, *fmt);
     return launch_status();
 }
 

@@ -254,9 +254,11 @@ def build_causal_lm(shape: str = "llama-2-7b", device="cuda", dtype=torch.bfloat
 class GraphedBatch:
     """Forward of one fixed-shape evaluation batch captured into a hipGraph (the SQuAD loop: 674 batches of [16, 384]); a
     BERT-base E4M3 batch is 9.8 ms launched eagerly and 3.2 ms replayed.  Needs frozen or stateless observers only in the
-    sense every capture does -- no host reads -- which holds for this engine's fake-quantizers."""
+    sense every capture does -- no host reads -- which holds for this engine's fake-quantizers.  `batch_weight_passes`: the FP8 weight
+    passes of the Linears on the weight-pass + library-GEMM route (stateless formats; logged during a warm-up forward) run as ONE
+    launch in front of the captured forward (fused.BatchedWeightCodes: 36 launches -> 1 for BERT-base) -- same codes, same counts."""
 
-    def __init__(self, model, example, extra=None):
+    def __init__(self, model, example, extra=None, batch_weight_passes: bool = True):
         self.model = model
         self.static = {k: v.clone() for k, v in example.items()}
         self.extra = dict(extra or {})
@@ -264,14 +266,26 @@ class GraphedBatch:
         device = next(iter(self.static.values())).device
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
+        from . import fused
+        self.weight_codes = None
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                model(**self.static, **self.extra)
+            model(**self.static, **self.extra)
+            fused.start_weight_pass_log()                       # which Linears run a separate FP8 weight pass (pair route)
+            model(**self.static, **self.extra)
+            batch = fused.BatchedWeightCodes(fused.stop_weight_pass_log(), device)
+            if batch_weight_passes and len(batch) > 1:
+                self.weight_codes = batch                       # ... all of them as ONE launch in front of the captured forward
+                batch.launch()
+                model(**self.static, **self.extra)              # (a warm-up of the path the capture will take)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            if self.weight_codes is not None:
+                self.weight_codes.launch()
             self.out = model(**self.static, **self.extra)
+        if self.weight_codes is not None:
+            self.weight_codes.forget()
 
     def matches(self, batch):
         return batch.keys() == self.static.keys() and all(batch[k].shape == v.shape and batch[k].dtype == v.dtype

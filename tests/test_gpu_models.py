@@ -806,3 +806,34 @@ def test_full_size_llama_13b_decoder_layer_against_the_cpu_path(monkeypatch):
     d = (dev_h - cpu_h).abs()
     assert torch.isfinite(dev_h).all()
     assert float(d.pow(2).mean().sqrt()) <= 0.01 * scale and float(d.max()) <= 0.1 * scale, (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale)
+
+
+def test_graphed_batch_runs_the_weight_passes_of_the_pair_route_as_one_launch():
+    """BERT-base-shaped layers at [16, 384] (BASELINE configs[1]): three of the four Linear shapes take the weight pass + library FP8
+    GEMM (fused._FQ8_TABLE); harness.GraphedBatch logs those passes during a warm-up forward and captures them as ONE launch
+    (qt_fake_quant_multi_bf16_fp8) in front of the forward.  Same logits as the eager forward bit for bit, same fake-quant element and
+    call counts; with batch_weight_passes=False the graph holds the separate passes and gives the same logits again."""
+    from transformers import BertConfig, BertForQuestionAnswering
+    from quantized_training.fake_quantize import STATS
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072, vocab_size=1000, max_position_embeddings=384)
+    m = BertForQuestionAnswering(cfg).cuda().bfloat16().eval()
+    qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+    g = torch.Generator().manual_seed(1)
+    batch = {"input_ids": torch.randint(3, 1000, (16, 384), generator=g).cuda(), "attention_mask": torch.ones(16, 384, dtype=torch.long).cuda()}
+    with torch.no_grad():
+        m(**batch)
+        STATS.reset()
+        ref = m(**batch)
+        eager_counts = (STATS.elements, STATS.calls)
+        ref = (ref.start_logits.clone(), ref.end_logits.clone())
+        STATS.reset()
+        step = harness.GraphedBatch(m, batch)
+        assert step.weight_codes is not None and len(step.weight_codes) == 2 * 3       # per layer: q / k / v group, intermediate, output
+        assert (STATS.elements, STATS.calls) == tuple(4 * v for v in eager_counts)      # 3 warm-ups + the capture, each counted in full
+        out = step.replay(batch)
+        assert torch.equal(out.start_logits, ref[0]) and torch.equal(out.end_logits, ref[1])
+        plain = harness.GraphedBatch(m, batch, batch_weight_passes=False)
+        assert plain.weight_codes is None
+        out2 = plain.replay(batch)
+        assert torch.equal(out2.start_logits, ref[0]) and torch.equal(out2.end_logits, ref[1])
