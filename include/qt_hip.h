@@ -411,6 +411,22 @@ int qt_attention_fq_out_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const
                              uint16_t *out_dev, int B, int H, int Sq, int Sk, int D, long mask_sb, long mask_sh, long mask_sq,
                              float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 
+/* The same attention core for stateless TABLE formats (posit, fpN, ...: BASELINE configs[3]) as ONE launch with the whole score strip
+ * in registers (round 4; the design of qt_attention_fp8 on v_mfma_f32_16x16x32_bf16): head_dim 128, Sk a multiple of 128 up to 1024,
+ * q / k [B][H][S][128] bf16 VALUES of fq(q), fq(k); the probabilities' fake-quantizer (and, with out_fq, the output projection's input
+ * fake-quantizer: the same format) is `fmt` in its row form -- lut_dev is the device map with the row words behind it and fmt->p1 bit 0
+ * set (fake_quantize._device_map).  vt_dev: fq(v) transposed to [B][H][128][Sk] with the keys of every 32-chunk in the k-slot order of
+ * the P.V instruction, written by qt_value_t_rows from a [B, H, Sk, 128] view with element strides (this IS the `fq_v` call of
+ * modeling_llama.py:244-246).  Mask: additive bf16 with element strides, or -- with row_live_dev / mask_irregular_dev from
+ * qt_mask_row_live_checked -- never read when every row is "zeros, then the bf16 minimum".  Every rounding point of the module chain
+ * is kept (S, S * scaling, + mask in bf16; fp32 softmax rounded to bf16; fq_P; bf16 output). */
+int qt_value_t_rows(const uint16_t *v_dev, uint16_t *vt_dev, long B, long H, long Sk, int head_dim, long stride_b, long stride_h, long stride_k,
+                    const qt_format *fmt, const uint16_t *lut_dev, void *stream);
+int qt_attention_rows_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *vt_dev, const uint16_t *mask_dev, long mask_sb, long mask_sh,
+                           long mask_sq, const int *row_live_dev, long live_sb, long live_sh, long live_sq, const int *mask_irregular_dev,
+                           uint16_t *out_dev, int out_fq, const qt_format *fmt, const uint16_t *lut_dev, long B, int H, int Sq, int Sk, int head_dim,
+                           float scaling, void *stream);
+
 /* ---- section 8(f).2: block-scaled (microscaling) GEMMs on the scaled matrix instruction ---------------------
  * Replaces linear_mx / matmul_mx (decomposed.py:304-363: operand * expand(block scale) twice, then F.linear /
  * torch.matmul) when both operands are in a format v_mfma_scale_f32_16x16x128_f8f6f4 takes -- element formats

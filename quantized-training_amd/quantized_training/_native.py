@@ -80,6 +80,9 @@ SIGNATURES = {
     "qt_linear_fqt_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P]),
     "qt_fake_quant_multi_bf16": (c_int, [_P, c_int, ctypes.c_ulonglong, _FMT, _P, _P]),
     "qt_fake_quant_multi_bf16_fp8": (c_int, [_P, c_int, ctypes.c_ulonglong, _FMT, _P]),
+    "qt_value_t_rows": (c_int, [_P, _P, c_long, c_long, c_long, c_int, c_long, c_long, c_long, _FMT, _P, _P]),
+    "qt_attention_rows_bf16": (c_int, [_P, _P, _P, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, _P, _P, c_int, _FMT, _P, c_long, c_int, c_int,
+                                       c_int, c_int, c_float, _P]),
     "qt_colsum_bf16": (c_int, [_P, _P, c_long, c_long, _P]),
     "qt_linear_fqt_plan": (c_int, [c_int, c_long, c_int, POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]),
     "qt_linear_fqt_ws_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P, c_size_t, _P, c_size_t, _P]),

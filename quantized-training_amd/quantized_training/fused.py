@@ -1139,7 +1139,6 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
     st = _stream_ptr(query)
     qq = (fq_q(query) if fq_q is not None else query).contiguous()
     kq = (fq_k(key) if fq_k is not None else key).contiguous()          # K, not K^T: elementwise, same statistics
-    vq = (fq_v(value) if fq_v is not None else value).contiguous()
     out = torch.empty((B, Q, H, D), dtype=torch.bfloat16, device=query.device)
     if fq_p is not None and (fq_p._observe or fq_p._quantize):
         fq_p._move_to(query.device)
@@ -1169,11 +1168,54 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
         cand = consumer_fq_map(proj) if proj is not None else None
         if cand is not None and cand.dtype == fq_p.dtype:
             fq_o = cand
-    launch_attention_fq(L, st, qq, kq, vq, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut, scale_ptr, amax_ptr,
-                        fq_o is not None)
+    if not (table_p and scale_ptr is None and amax_ptr is None and fq_v is not None and not _has_table_hooks(fq_v)
+            and attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut,
+                                       fq_o is not None)):
+        vq = (fq_v(value) if fq_v is not None else value).contiguous()
+        launch_attention_fq(L, st, qq, kq, vq, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut, scale_ptr, amax_ptr,
+                            fq_o is not None)
     if fq_o is not None:
         fq_o.expect_prequantized(out, None)
     return out
+
+
+def _has_table_hooks(fq):
+    """A fake-quantizer somebody hooked (forward hooks / pre-hooks) must run as the module it is."""
+    return bool(fq._forward_hooks or fq._forward_pre_hooks)
+
+
+def attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, mask_owner, mask_strides, out, dims, scaling, fmt, lut, out_fq):
+    """qt_attention_rows_bf16 (round 4): the table-format attention core with the score strip in registers -- head_dim 128, key counts in
+    blocks of 128 up to 1024, the probabilities' fake-quantizer a stateless table format in its row form (fmt / lut as handed to
+    launch_attention_fq), and `fq_v` a stateless table format in its row form too: its call IS the kernel's value pass
+    (qt_value_t_rows: fq_v(value), transposed, keys in the k-slot order), counted here.  `value`: the UNQUANTIZED [B, H, C, D] view.
+    Returns True when the launch was made; False: the caller takes the two-pass kernel."""
+    B, H, Q, C, D = dims
+    if D != 128 or C % 128 != 0 or C > 1024 or B * H > 65535 or not (fmt.kind == _native.QT_FMT_LUT and (fmt.p1 & 1)) or lut is None:
+        return False
+    if not (isinstance(fq_v, FusedAmaxObsFakeQuantize) and fq_v.stateless_map() and fq_v._qt_format.kind == _native.QT_FMT_LUT):
+        return False
+    from .fake_quantize import _launch_format
+    fq_v._move_to(value.device)
+    vfmt = _launch_format(fq_v._qt_format, fq_v.qmap)
+    if not (vfmt.p1 & 1) or value.dtype != torch.bfloat16 or value.stride(3) != 1 or any(s_ % 8 for s_ in value.stride()[:3]) or value.data_ptr() % 16:
+        return False
+    msb, msh, msq = mask_strides
+    live = _mask_row_live(mask, mask_owner, B, H, Q, C, st) if (mask is not None and mask_owner is not None) else None
+    vt = torch.empty((B, H, D, C), dtype=torch.bfloat16, device=value.device)
+    _native.check(L.qt_value_t_rows(value.data_ptr(), vt.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2), ctypes.byref(vfmt),
+                                    fq_v.qmap.data_ptr(), st), "qt_value_t_rows")
+    STATS.add(value.numel())                                   # the fq_v call
+    fq_v.__dict__["_qt_calls"] = fq_v.__dict__.get("_qt_calls", 0) + 1
+    if live is not None:
+        rl, lsb, lsh, lsq = live
+        rlp, irr = rl.data_ptr(), rl.data_ptr() + 4 * (rl.numel() - 1)
+    else:
+        rlp, irr, lsb, lsh, lsq = None, None, 0, 0, 0
+    _native.check(L.qt_attention_rows_bf16(qq.data_ptr(), kq.data_ptr(), vt.data_ptr(), mask.data_ptr() if mask is not None else None, msb, msh, msq,
+                                           rlp, lsb, lsh, lsq, irr, out.data_ptr(), int(bool(out_fq)), ctypes.byref(fmt), lut, B, H, Q, C, D,
+                                           float(scaling), st), "qt_attention_rows_bf16")
+    return True
 
 
 def launch_attention_fq(L, st, qq, kq, vq, mask, mask_owner, mask_strides, out, dims, scaling, fmt, lut, scale_ptr, amax_ptr, out_fq):

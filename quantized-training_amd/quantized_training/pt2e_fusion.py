@@ -235,7 +235,6 @@ class PreparedAttention(nn.Module):
             if f is not None:
                 f.__dict__["_qt_calls"] = f.__dict__.get("_qt_calls", 0) + 1
                 _FQ_STATS.add(t.numel())
-        vq = fq_v(v).contiguous()
         fmt, qmap = pf
         out = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=q.device)
         _FQ_STATS.add(B * H * S * S)                          # fq_p, inside the kernel
@@ -245,8 +244,13 @@ class PreparedAttention(nn.Module):
         if not (fq_o is not None and fq_o.dtype == fq_p.dtype and _table_ok(fq_o)):
             fq_o = None                                       # else: its node runs its own pass
         # (with fq_o: the output projection's input fake-quantizer, same format, on the kernel's epilogue; its node hands the result through)
-        fused.launch_attention_fq(_native.lib(), _stream_ptr(q), qq, kq, vq, m, mask, (msb, msh, msq), out, (B, H, S, S, D), self.scaling, fmt,
-                                  qmap.data_ptr(), None, None, fq_o is not None)
+        if fused.attention_rows_or_none(_native.lib(), _stream_ptr(q), qq, kq, v, fq_v, m, mask, (msb, msh, msq), out, (B, H, S, S, D), self.scaling, fmt,
+                                        qmap.data_ptr(), fq_o is not None):
+            pass                                              # (the value pass of the launch pair was fq_v's call: counted there)
+        else:
+            vq = fq_v(v).contiguous()
+            fused.launch_attention_fq(_native.lib(), _stream_ptr(q), qq, kq, vq, m, mask, (msb, msh, msq), out, (B, H, S, S, D), self.scaling, fmt,
+                                      qmap.data_ptr(), None, None, fq_o is not None)
         if fq_o is not None:
             fq_o.expect_prequantized(out, None)
         return out.reshape(B, S, H * D)

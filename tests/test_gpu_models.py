@@ -800,8 +800,10 @@ def test_full_size_llama_13b_decoder_layer_against_the_cpu_path(monkeypatch):
     routes = fused.routes_report()
     assert routes.get("fqt:1024x5120x13824") == "fused_value_map_gemm" and routes.get("fqt:1024x15360x5120") == "fused_value_map_gemm", routes
     n, share, far = _code_steps(cpu_taps, dev_taps, "posit8_2", min_taps=3)
-    # measured: 13 taps, 5.0 % of a tap's elements one step away at worst (K up to 13824, a grid with 1 - 3 fraction bits), 7.3e-4 further
-    assert share <= 0.08 and far <= 1.5e-3, (n, share, far)
+    # measured: 11 taps (fq_v and the output projection's input fake-quantizer are evaluated inside the attention launches and have no module
+    # output to tap), 5.0 % of a tap's elements one step away at worst (K up to 13824, a grid with 1 - 3 fraction bits), 2.0e-3 of all
+    # tapped elements further (7.3e-4 with the two exact taps of the value pass in the denominator, round 3's kernel)
+    assert share <= 0.08 and far <= 4e-3, (n, share, far)
     scale = float(cpu_h.abs().max())
     d = (dev_h - cpu_h).abs()
     assert torch.isfinite(dev_h).all()

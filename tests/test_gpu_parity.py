@@ -800,6 +800,88 @@ def test_fused_attention_kernel_on_posit8_2_inputs_in_row_form(nv, B, H, S, D):
     assert np.array_equal(o.vmap_bf16(pq.reshape(-1)[:: 97], qmap), pq.reshape(-1)[:: 97])
 
 
+@pytest.mark.parametrize("B,H,S,D,mask_kind", [(1, 40, 1024, 128, "causal"), (2, 5, 256, 128, "causal"), (2, 3, 384, 128, "padding"), (1, 4, 128, 128, None),
+                                               (1, 2, 640, 128, "full")])
+@pytest.mark.parametrize("pdtype", ["posit8_2", "posit8_1", "fp4_e2m1"])
+def test_attention_rows_split_kernel(nv, B, H, S, D, mask_kind, pdtype):
+    """qt_attention_rows_bf16 (+ qt_value_t_rows): the one-launch attention core for stateless TABLE formats with the score strip in
+    registers (round 4) against oracle.attention_fq -- table-format-valued q / k / v, the probabilities' fake-quantizer in its row form,
+    causal / right-padding masks through their row extents (never read), an irregular mask read in full, no mask; same bounds as the
+    other attention cores (<= 2e-3 of the outputs differ, <= 0.08 of the row maximum).  The value pass is checked on its own: fq(v)
+    transposed with the keys of every 32-chunk in the k-slot order.  With out_fq the epilogue applies the same value map."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    torch.manual_seed(11 + H + S)
+    qmap = o.get_quantization_map(pdtype)
+    qmap_dev = torch.from_numpy(qmap.view(np.int16)).cuda().view(torch.bfloat16)
+    fqin = lambda t: qmap_dev[(t.view(torch.int16).to(torch.int32) & 0xFFFF).long()]  # noqa: E731
+    q = fqin((torch.randn(B, H, S, D, device="cuda") * 1.5).bfloat16())
+    k = fqin((torch.randn(B, H, S, D, device="cuda") * 1.5).bfloat16())
+    v_raw = torch.randn(B, S, H, D, device="cuda").bfloat16().transpose(1, 2)         # [B, H, S, D] view of a [B, S, H, D] buffer, unquantized
+    v = fqin(v_raw.contiguous())
+    scaling = D ** -0.5
+    minv = torch.finfo(torch.bfloat16).min
+    mask, msb, msq = None, 0, 0
+    if mask_kind == "causal":
+        mask = torch.full((S, S), minv, device="cuda").triu(1).bfloat16()[None, None]
+        msq = mask.stride(2)
+    elif mask_kind == "padding":
+        mask = torch.zeros(B, 1, 1, S, device="cuda", dtype=torch.bfloat16)
+        mask[:, :, :, S - 29:] = minv
+        msb = mask.stride(0)
+    elif mask_kind == "full":
+        mask = (torch.randn(1, 1, S, S, device="cuda") * 2).bfloat16()
+        mask[..., S // 2:] = minv
+        mask[..., 5, 3] = -1.0
+        msq = mask.stride(2)
+    m = qt.get_quantization_map(pdtype, torch.device("cuda"))
+    f_rows = _launch_format(nv.format_for(pdtype), m)
+    assert f_rows.p1 & 1
+    # the value pass: fq_v + transpose + slot permutation
+    vt = torch.empty(B, H, D, S, dtype=torch.bfloat16, device="cuda")
+    nv.check(L.qt_value_t_rows(v_raw.data_ptr(), vt.data_ptr(), B, H, S, D, v_raw.stride(0), v_raw.stride(1), v_raw.stride(2), ctypes.byref(f_rows),
+                               m.data_ptr(), stream()), "qt_value_t_rows")
+    key = torch.arange(S, device="cuda")
+    slot = (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3)
+    want_vt = torch.empty_like(vt)
+    want_vt[..., slot] = v.transpose(2, 3)
+    assert torch.equal(vt.view(torch.int16), want_vt.view(torch.int16))
+    rl = irr = None
+    lsb = lsq = 0
+    if mask is not None:
+        mrows = mask.shape[0] * mask.shape[1] * mask.shape[2]
+        rlbuf = torch.empty(mrows + 1, dtype=torch.int32, device="cuda")
+        nv.check(L.qt_mask_row_live_checked(mask.data_ptr(), mrows, S, S, rlbuf.data_ptr(), rlbuf.data_ptr() + 4 * mrows, stream()), "row_live")
+        assert int(rlbuf[-1]) == int(mask_kind == "full")
+        rl, irr = rlbuf.data_ptr(), rlbuf.data_ptr() + 4 * mrows
+        lsb, lsq = (mask.shape[2] if mask.shape[0] > 1 else 0), (1 if mask.shape[2] > 1 else 0)
+    outs = []
+    for out_fq in (0, 1):
+        out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device="cuda")
+        nv.check(L.qt_attention_rows_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mask.data_ptr() if mask is not None else None, msb, 0, msq,
+                                          rl, lsb, 0, lsq, irr, out.data_ptr(), out_fq, ctypes.byref(f_rows), m.data_ptr(), B, H, S, S, D, scaling,
+                                          stream()), "qt_attention_rows_bf16")
+        outs.append(out)
+    torch.cuda.synchronize()
+    u16 = lambda t: host_u16(t.contiguous().view(torch.int16))  # noqa: E731
+    exp, pq = o.attention_fq(u16(q), u16(k), u16(v), u16(mask) if mask is not None else None, scaling, qmap)
+    got = u16(outs[0].permute(0, 2, 1, 3))
+    differ = float((got != exp).mean())
+    assert differ <= 2e-3, differ
+    ev = o.bf16_to_f32(exp)
+    err = np.abs(o.bf16_to_f32(got) - ev) / (np.abs(ev).max(axis=-1, keepdims=True) + 1e-30)
+    assert float(err.max()) <= 0.08, float(err.max())
+    # out_fq: the value map applied to the unquantized result, bit for bit
+    assert np.array_equal(o.canon_nan16(u16(outs[1])), o.canon_nan16(o.vmap_bf16(u16(outs[0]), qmap)))
+    # and against round 3's two-pass kernel on the same inputs: the same rounding points, fp32 sums in another order
+    if mask_kind != "full":
+        old = torch.empty_like(outs[0])
+        nv.check(L.qt_attention_fq_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), mask.data_ptr() if mask is not None else None, old.data_ptr(), B, H, S, S, D,
+                                        msb, 0, msq, scaling, ctypes.byref(f_rows), m.data_ptr(), None, None, stream()), "attention")
+        assert float((old.view(torch.int16) != outs[0].view(torch.int16)).float().mean()) <= 4e-3
+
+
 def test_llama_fused_attention_vs_module_chain(nv):
     """Tiny LLaMA (head_dim 64) through quantize(): fused attention core vs the unfused module chain."""
     import quantized_training as qt
