@@ -40,7 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 128, kMaxBlocks = 8, kD = 128;
 constexpr int kRowB = 256;                       // bytes of a K row (128 d) and of a V^T row segment (128 keys)
 constexpr int kBuf = kBlock * kRowB;             // one block: 32 KiB
-constexpr int kRing = 4 * kBuf;                  // two pairs
+constexpr int kRing = 4 * kBuf;                  // four blocks
 constexpr int kTbl = 8192;                       // the row table (512 rows x 16 B; 256 used by maps indexed by exponent only)
 constexpr int kLds = kRing + kTbl + 2 * 2 * 64 * 4;
 
@@ -57,6 +57,9 @@ struct Args {
     qt_format fmt;                      // the probabilities' format: table format with the row words behind the map (p1 bit 0)
     const uint16_t *lut;
     int out_fq;                         // 1: the output projection's input fake-quantizer (same format) applied on the way out
+#ifdef QT_TUNING_BUILD
+    unsigned long long *dbg;            // QT_AR_STAMPS = device address: s_memtime stamps of workgroup (0, 0), waves 0 and 4, 64 slots each
+#endif
 };
 
 __device__ __forceinline__ float blo(uint32_t w) { return qt_u2f(w << 16); }
@@ -88,25 +91,23 @@ __device__ __forceinline__ void score_half(const uint8_t *blk, int t0, const v8s
         for (int j = 0; j < 4; ++j) m[j] = *(const uint2 *)(mrow + key0 + j * 16);
     }
     v4f s[4];
-    // two tiles at a time: eight fragment reads, then eight multiplications
+    // staged by hand: all sixteen fragment reads of the four tiles, then their sixteen multiplications back to back, then the rounding
+    // chains (a read -> multiply -> chain sequence per tile would expose the LDS and matrix latencies four times over)
+    u32x4 kf[4][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; jj += 2) {
-        u32x4 kf[2][4];
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == 1 && j >= tiles) continue;
+        const int row = (t0 + j) * 16 + r;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (MODE == 1 && jj + j >= tiles) continue;
-            const int row = (t0 + jj + j) * 16 + r;
+        for (int ks = 0; ks < 4; ++ks) kf[j][ks] = *(const u32x4 *)(blk + chunk_off(row, 4 * ks + g));
+    }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[j][ks] = *(const u32x4 *)(blk + chunk_off(row, 4 * ks + g));
-        }
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == 1 && j >= tiles) continue;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (MODE == 1 && jj + j >= tiles) continue;
-            v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8s, kf[j][ks]), qf[ks], acc, 0, 0, 0);
-            s[jj + j] = acc;
-        }
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8s, kf[j][ks]), qf[ks], acc, 0, 0, 0);
+        s[j] = acc;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -179,10 +180,18 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     if (!simple) wmin = a.Sk;                                              // extents then only bound the walk; inside them the mask is read
     if (!simple && !a.row_live) wmax = a.Sk;
     const uint32_t l0 = lds_addr(lds);
-    // ---- DMA geometry.  A pair of blocks is 64 pieces of 1 KiB (4 rows x 256 bytes); wave w issues pieces 8 w .. 8 w + 7: piece
-    // 8 w + i lies in block (w >> 2) of the pair, rows 4 pb .. 4 pb + 3 with pb = (8 w + i) & 31.  Lane l lands at row 4 pb + (l >> 4),
-    // 16-byte slot l & 15 of the LDS image, which must hold logical chunk (l & 15) ^ (row & 15); (row & 15) = 4 (i & 3) + (l >> 4), so
-    // four lane-offset registers per operand serve all eight pieces, the rest of the address is uniform.
+#ifdef QT_TUNING_BUILD
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && l == 0 && (w & 3) == 0) a.dbg[(w >> 2) * 64 + slot] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [](int) __attribute__((always_inline)) {};
+#endif
+    stamp(0);
+    // ---- DMA geometry.  A block is 32 pieces of 1 KiB (4 rows x 256 bytes); wave w issues pieces 4 w .. 4 w + 3 of every block: piece
+    // pb = 4 w + i holds rows 4 pb .. 4 pb + 3.  Lane l lands at row 4 pb + (l >> 4), 16-byte slot l & 15 of the LDS image, which must hold
+    // logical chunk (l & 15) ^ (row & 15); (row & 15) = 4 i + (l >> 4), so four lane-offset registers per operand serve every piece, the
+    // rest of the address is uniform.  Block kb sits in ring slot kb & 3.
     uint32_t koff[4], voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -192,24 +201,28 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     }
     const uint8_t *kbase = (const uint8_t *)a.k + (long)bh * a.Sk * kRowB;
     const uint8_t *vbase = (const uint8_t *)a.vt + (long)bh * kD * a.Sk * 2;
-    // the second block of the last pair may lie beyond the live blocks: it is then fetched from the last one and never multiplied
-    auto issue_k = [&](int it) __attribute__((always_inline)) {
-        const int blk = w >> 2, kb = min(2 * it + blk, nkb - 1);
-        const uint32_t dst0 = l0 + ((it & 1) * 2 + blk) * kBuf;
+    auto issue_k = [&](int kb) __attribute__((always_inline)) {
+        const uint32_t dst0 = l0 + (kb & 3) * kBuf;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pb = (8 * w + i) & 31;
-            dma16(kbase + ((long)kb * kBlock + 4 * pb) * kRowB, koff[i & 3], dst0 + pb * 1024);
+        for (int i = 0; i < 4; ++i) {
+            const int pb = 4 * w + i;
+            dma16(kbase + ((long)kb * kBlock + 4 * pb) * kRowB, koff[i], dst0 + pb * 1024);
         }
     };
-    auto issue_v = [&](int it) __attribute__((always_inline)) {
-        const int blk = w >> 2, kb = min(2 * it + blk, nkb - 1);
-        const uint32_t dst0 = l0 + ((it & 1) * 2 + blk) * kBuf;
+    auto issue_v = [&](int kb) __attribute__((always_inline)) {
+        const uint32_t dst0 = l0 + (kb & 3) * kBuf;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pb = (8 * w + i) & 31;
-            dma16(vbase + ((long)(4 * pb) * a.Sk + (long)kb * kBlock) * 2, voff[i & 3], dst0 + pb * 1024);
+        for (int i = 0; i < 4; ++i) {
+            const int pb = 4 * w + i;
+            dma16(vbase + ((long)(4 * pb) * a.Sk + (long)kb * kBlock) * 2, voff[i], dst0 + pb * 1024);
         }
+    };
+    // block kb is awaited with the requests of up to two later blocks (four per wave each) still in flight
+    auto await_block = [&](int kb) __attribute__((always_inline)) {
+        const int ahead = nlive - 1 - kb;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // Q^T fragments (B operand): lane (r, g) holds Q[query r][32 ks + 8 g + j]
     v8s qf[4];
@@ -227,38 +240,45 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
 
     float e[kIter][8][4];                                                  // this wave's part of the strip: logits, then their exponentials
     float mx = -INFINITY;
-    // ---- sweep 1: scores.  Pair `it` sits in ring slot it & 1; at the top of an iteration every wave is done with pair it - 1, whose
-    // slot then takes pair it + 1
+    // ---- sweep 1: scores.  Three blocks are in flight ahead of the one being multiplied; at the barrier of step kb every wave is done
+    // with block kb - 1, whose slot then takes block kb + 3
+    stamp(1);
     issue_k(0);
+    if (nlive > 1) issue_k(1);
+    if (nlive > 2) issue_k(2);
 #pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-        if (it < niter) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kb = 0; kb < kMaxBlocks; ++kb) {
+        if (kb < nlive) {
+            await_block(kb);
+            stamp(2 + 3 * kb);
             __builtin_amdgcn_s_barrier();
-            if (it + 1 < niter) issue_k(it + 1);
+            stamp(3 + 3 * kb);
+            if (kb + 3 < nlive) issue_k(kb + 3);
+            const int key0 = kb * kBlock + 64 * grp, nt = tiles_of(kb);
+            const uint8_t *blk = lds + (kb & 3) * kBuf;
+            float (*ev)[4] = &e[kb >> 1][4 * (kb & 1)];
+            if (nt == 0) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int kb = 2 * it + c, key0 = kb * kBlock + 64 * grp, nt = tiles_of(kb);
-                const uint8_t *blk = lds + ((it & 1) * 2 + c) * kBuf;
-                float (*ev)[4] = &e[it][4 * c];
-                if (nt == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ev[j][0] = ev[j][1] = ev[j][2] = ev[j][3] = -INFINITY;
-                } else if (full) {
-                    score_half<2>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, mrow, key0, 0, 4);
-                } else if (!simple || key0 + 64 <= wmin) {
-                    score_half<0>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, nullptr, key0, 0, 4);
-                } else {
-                    score_half<1>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, nullptr, key0 + 4 * g, my_live, nt);
-                }
+                for (int j = 0; j < 4; ++j) ev[j][0] = ev[j][1] = ev[j][2] = ev[j][3] = -INFINITY;
+            } else if (full) {
+                score_half<2>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, mrow, key0, 0, 4);
+            } else if (!simple || key0 + 64 <= wmin) {
+                score_half<0>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, nullptr, key0, 0, 4);
+            } else {
+                score_half<1>(blk, 4 * grp, qf, r, g, a.scaling, ev, mx, nullptr, key0 + 4 * g, my_live, nt);
             }
+            stamp(4 + 3 * kb);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // everyone is through sweep 1: the V^T blocks replace the K blocks while the exponentials are evaluated
+    stamp(26);
     __builtin_amdgcn_s_barrier();
+    stamp(27);
     issue_v(0);
+    if (nlive > 1) issue_v(1);
+    if (nlive > 2) issue_v(2);
     // the two groups' maxima meet in LDS
     float *stat = (float *)(lds + kRing + kTbl);                           // [max, sum][2 groups][64 rows]
     if (g == 0) stat[grp * 64 + wq * 16 + r] = mx;
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     if (g == 0) stat[128 + grp * 64 + wq * 16 + r] = sum;
     __syncthreads();
     const float inv = 1.0f / (stat[128 + wq * 16 + r] + stat[128 + 64 + wq * 16 + r]);
+    stamp(28);
     // ---- sweep 2: probabilities (bf16, fake-quantized in the row form) x V.  Output tile dt: D[16 d x 16 queries], lane (r, g) holds
     // d = 16 dt + 4 g + {0..3} of query r.  Per 32-key chunk (two neighbouring tiles 2 c2, 2 c2 + 1 of this wave's half block) the lane's
     // eight probabilities are its B fragment; the A fragment is V^T rows 16 dt + r, slots 8 g .. 8 g + 7 of that chunk.
@@ -300,39 +321,40 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     v4f acc[kDT];
 #pragma unroll
     for (int i = 0; i < kDT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
-    uint32_t unused_amax = 0;
 #pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-        if (it < niter) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kb = 0; kb < kMaxBlocks; ++kb) {
+        if (kb < nlive) {
+            await_block(kb);
+            stamp(29 + 3 * kb);
             __builtin_amdgcn_s_barrier();
-            if (it + 1 < niter) issue_v(it + 1);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (tiles_of(2 * it + c) == 0) continue;
-                const uint8_t *blk = lds + ((it & 1) * 2 + c) * kBuf;
+            stamp(30 + 3 * kb);
+            if (kb + 3 < nlive) issue_v(kb + 3);
+            if (tiles_of(kb) != 0) {
+                const uint8_t *blk = lds + (kb & 3) * kBuf;
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     const int chunk0 = 4 * (2 * grp + c2) + g;              // 16-byte chunk of this lane's slots inside the 256-byte row
                     u32x4 vf[kDT];
 #pragma unroll
                     for (int dt = 0; dt < kDT; ++dt) vf[dt] = *(const u32x4 *)(blk + chunk_off(dt * 16 + r, chunk0));
-                    uint32_t pw[4];
+                    uint32_t pb[4], pw[4];
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        const float *v = e[it][4 * c + 2 * c2 + hh];
-                        const uint32_t p0 = pack_bf16x2(v[0] * inv, v[1] * inv), p1 = pack_bf16x2(v[2] * inv, v[3] * inv);   // probabilities, bf16
-                        pw[2 * hh] = fq_word_bf16<kFmtRows, true, false>(p0, 1.0f, rnd, unused_amax);                        // fq_p
-                        pw[2 * hh + 1] = fq_word_bf16<kFmtRows, true, false>(p1, 1.0f, rnd, unused_amax);
+                        const float *v = e[kb >> 1][4 * (kb & 1) + 2 * c2 + hh];
+                        pb[2 * hh] = pack_bf16x2(v[0] * inv, v[1] * inv);  // probabilities, bf16
+                        pb[2 * hh + 1] = pack_bf16x2(v[2] * inv, v[3] * inv);
                     }
+                    fq_rows_words<4, true>(pb, pw, rnd);                    // fq_p
                     const v8s pf = __builtin_bit_cast(v8s, u32x4{pw[0], pw[1], pw[2], pw[3]});
 #pragma unroll
                     for (int dt = 0; dt < kDT; ++dt)
                         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8s, vf[dt]), pf, acc[dt], 0, 0, 0);
                 }
             }
+            stamp(31 + 3 * kb);
         }
     }
+    stamp(53);
     // ---- the two partial sums meet in LDS: group 1 parks its accumulators ([64 rows][128 d] fp32), group 0 adds and stores
     __syncthreads();
     float *part = (float *)lds;
@@ -350,8 +372,11 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
             const float4 o = *(const float4 *)(part + prow * kPartRow + dt * 16 + 4 * g);
             uint32_t o0 = pack_bf16x2(acc[dt][0] + o.x, acc[dt][1] + o.y), o1 = pack_bf16x2(acc[dt][2] + o.z, acc[dt][3] + o.w);
             if (a.out_fq) {                                                // the output projection's input fake-quantizer (same format, unit scale)
-                o0 = fq_word_bf16<kFmtRows, true, false>(o0, 1.0f, rnd, unused_amax);
-                o1 = fq_word_bf16<kFmtRows, true, false>(o1, 1.0f, rnd, unused_amax);
+                const uint32_t ow[2] = {o0, o1};
+                uint32_t oq[2];
+                fq_rows_words<2, false>(ow, oq, rnd);
+                o0 = oq[0];
+                o1 = oq[1];
             }
             *(uint2 *)(orow + dt * 16) = uint2{o0, o1};
         }
@@ -375,23 +400,32 @@ __global__ __launch_bounds__(256) void value_t_rows_kernel(const uint16_t *v, ui
     __syncthreads();
     const int t = threadIdx.x, kb = blockIdx.x;
     const long bh = blockIdx.y, b = bh / H, h = bh % H;
-    uint32_t unused_amax = 0;
+    // a thread takes TWO adjacent keys (k, k + 1: adjacent slots too) and one 8-wide d chunk, so every LDS write is a 32-bit
+    // {fq(V)[k][d], fq(V)[k + 1][d]} pair into row d of the image
+    constexpr int kRow = kBlock + 8;                                        // uint16 per image row
 #pragma unroll
-    for (int it = 0; it < kD / 16; ++it) {
-        const int vi = it * 256 + t, key = vi / (kD / 8), dv = vi % (kD / 8);
-        const uint4 in = *(const uint4 *)(v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8);
-        const uint32_t o[4] = {fq_word_bf16<kFmtRows, true, false>(in.x, 1.0f, rnd, unused_amax), fq_word_bf16<kFmtRows, true, false>(in.y, 1.0f, rnd, unused_amax),
-                               fq_word_bf16<kFmtRows, true, false>(in.z, 1.0f, rnd, unused_amax), fq_word_bf16<kFmtRows, true, false>(in.w, 1.0f, rnd, unused_amax)};
-        // key = 32 c + 16 hh + 4 gg + ee  ->  slot 32 c + 8 gg + 4 hh + ee
+    for (int it = 0; it < (kBlock / 2) * (kD / 8) / 256; ++it) {
+        const int item = it * 256 + t, kp = item & 63, dv = item >> 6, key = 2 * kp;
+        const uint16_t *src = v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8;
+        const uint4 i0 = *(const uint4 *)src, i1 = *(const uint4 *)(src + sk);
+        const uint32_t w0[4] = {i0.x, i0.y, i0.z, i0.w}, w1[4] = {i1.x, i1.y, i1.z, i1.w};
+        uint32_t a[4], c[4];
+        fq_rows_words<4, false>(w0, a, rnd);
+        fq_rows_words<4, false>(w1, c, rnd);
+        // key = 32 c + 16 hh + 4 gg + ee  ->  slot 32 c + 8 gg + 4 hh + ee (ee even here: slot even)
         const int p = (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
+        uint32_t *base = (uint32_t *)(tile + (dv * 8) * kRow + p);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tile[(dv * 8 + j) * (kBlock + 8) + p] = (uint16_t)((j & 1) ? (o[j >> 1] >> 16) : (o[j >> 1] & 0xFFFFu));
+        for (int j = 0; j < 4; ++j) {
+            base[(2 * j) * (kRow / 2)] = (a[j] & 0xFFFFu) | (c[j] << 16);
+            base[(2 * j + 1) * (kRow / 2)] = (a[j] >> 16) | (c[j] & 0xFFFF0000u);
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kD * kBlock / 8 / 256; ++it) {
         const int ci = it * 256 + t, d = ci >> 4, ch = ci & 15;
-        *(uint4 *)(vt + (bh * kD + d) * Sk + (long)kb * kBlock + ch * 8) = *(const uint4 *)(tile + d * (kBlock + 8) + ch * 8);
+        *(uint4 *)(vt + (bh * kD + d) * Sk + (long)kb * kBlock + ch * 8) = *(const uint4 *)(tile + d * kRow + ch * 8);
     }
 }
 
@@ -432,6 +466,12 @@ int qt_attention_rows_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const u
         return QT_ERR_UNALIGNED;
     Args a{q_dev, k_dev, vt_dev, mask_dev, mask_sb, mask_sh, mask_sq, row_live_dev, live_sb, live_sh, live_sq, mask_irregular_dev,
            out_dev, H, Sq, Sk, scaling, *fmt, lut_dev, out_fq ? 1 : 0};
+#ifdef QT_TUNING_BUILD
+    {
+        const char *e_st = getenv("QT_AR_STAMPS");
+        a.dbg = e_st ? (unsigned long long *)strtoull(e_st, nullptr, 0) : nullptr;
+    }
+#endif
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void *)attention_rows_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return QT_ERR_BAD_ARG;

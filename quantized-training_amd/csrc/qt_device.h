@@ -178,6 +178,51 @@ __device__ __forceinline__ uint32_t fq_word_bf16(uint32_t w, float s, const Roun
     return (r0 >> 16) | (r1 & 0xFFFF0000u);
 }
 
+// N words (2 N values) through the row form at once: every row gather is issued before the first result is needed and the flagged rows
+// of all of them share ONE branch, so a wave pays the LDS latency once per batch instead of once per value (fq_word_bf16<kFmtRows>
+// serialises: gather, wait, arithmetic, branch, for each value).  NONNEG: the caller's values carry no sign except on a NaN (softmax
+// probabilities); a set sign bit then takes the same rare branch as a flagged row, and the common path drops the sign handling.
+// There the first input of a flagged row (mantissa 0 -- exact zero in row 0, which posit maps flag because every bf16 subnormal
+// rounds up to minpos) does not branch either: qt_build_rowparams leaves its result in the row's lo = hi.  The branch matters
+// beyond its own cost: it reads the map from global memory, and the wait for that read also waits for every LDS-DMA request the
+// caller has in flight.
+template <int N, bool NONNEG>
+__device__ __forceinline__ void fq_rows_words(const uint32_t (&w)[N], uint32_t (&o)[N], const Rounder<kFmtRows> &rnd) {
+    const uint32_t rowmask = (rnd.fmt.p1 & 2) ? 0x1FFu : 0xFFu;
+    const uint4 *rows = (const uint4 *)rnd.lds;
+    uint32_t img[2 * N], r[2 * N], rare = 0;
+    uint4 p[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        img[2 * i] = w[i] << 16;
+        img[2 * i + 1] = w[i] & 0xFFFF0000u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) p[j] = rows[(img[j] >> 23) & rowmask];
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) {
+        const float t = qt_u2f((img[j] & 0x7FFFFFFFu) + p[j].x), c = qt_u2f(p[j].y);
+        const uint32_t z = qt_f2u(__builtin_amdgcn_fmed3f((t + c) - c, qt_u2f(p[j].z), qt_u2f(p[j].w)));
+        if constexpr (NONNEG) {
+            r[j] = z;
+            const uint32_t later = min((img[j] & 0x007F0000u) | p[j].x, 1u);   // flagged rows: 0 = the row's first input, covered by lo = hi
+            rare |= (p[j].y & later) | (img[j] >> 31);
+        } else {
+            uint32_t sign = (rnd.fmt.p1 & 4) ? (img[j] & 0x80000000u) : 0u;
+            if (!(rnd.fmt.p1 & 8)) sign = z ? sign : 0u;
+            r[j] = z | sign;
+            if ((rnd.fmt.p1 & 16) && img[j] == 0x80000000u) r[j] = qt_f2u(rnd.fmt.fhi);
+            rare |= p[j].y;
+        }
+    }
+    if (__builtin_expect(rare & 1u, 0)) {
+#pragma unroll
+        for (int j = 0; j < 2 * N; ++j) r[j] = rnd(img[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = (r[2 * i] >> 16) | (r[2 * i + 1] & 0xFFFF0000u);
+}
+
 // Vector-level variants.  DIV: 0 = scale 1 (no division / multiply), 1 = fast quotient (sets `bad`),
 // 2 = full IEEE division.
 constexpr int kDivUnit = 0, kDivFast = 1, kDivExact = 2;
