@@ -291,7 +291,7 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
  * that cannot be written this way (non-finite inputs, a few rows at the far ends of some formats) are `flagged`.
  *   row[r] = {D (int32), C (fp32 bits; bit 0 set = flagged), lo, hi (fp32 bits)};  r = bits >> 7 (rows 256.. = negative inputs)
  *   a flagged row holds {0, 1, y0, y0} with y0 = |map| of the row's first input (mantissa 0; row 0: of zero itself), so the formula
- *   is still right for that one input -- the exact zeros of a flagged row 0 need no map lookup -- or {1, 1, 0, 0} if y0 is a NaN
+ *   is still right for that one input -- the exact zeros of a flagged row 0 need no map lookup -- or {1, 1, 0, 0} if y0 is a NaN or has its sign bit set
  *   signed_rows 0: rows 256..511 equal rows 0..255 (|map(-x)| == |map(x)|), the kernel indexes by exponent only
  *   sign_mask 0x80008000: the result takes the input's sign; 0: it stays positive (unsigned formats such as fp8_e5m3)
  *   zero_sign: what a zero result of a negative non-zero input looks like in the map -- 0: +0, 1: -0, 2: both occur (a GEMM operand's

@@ -373,8 +373,8 @@ int qt_build_rowparams(const uint16_t *map, qt_rowparams *out) {
         if (!fit) {
             // D = 0 and lo = hi = the result of the row's first input (mantissa 0; row 0: of zero itself): callers that branch to the
             // map for a flagged row may skip the branch for that one input -- exact zeros are the common case of a flagged row 0.
-            // D = 1: the first result is a NaN, which a clamp cannot produce; every input of the row takes the branch.
-            const bool usable = expect[0] == expect[0];
+            // D = 1: the first result is a NaN or carries a sign, which a clamp cannot produce; every input of the row takes the branch.
+            const bool usable = expect[0] == expect[0] && !(map[row << 7] & 0x8000);   // (the clamp carries no sign either)
             const uint32_t first = usable ? qt_f2u(expect[0]) : 0u;
             p[0] = usable ? 0u : 1u; p[1] = 1u; p[2] = first; p[3] = first;
             out->flagged[row] = 1;

@@ -72,9 +72,8 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 if (sum_fq) {            // the NEXT residual add reads fq(sum) (PT2E graphs quantize an add's earlier operand): written quantized,
                     uint32_t t[4] = {v[i].x, v[i].y, v[i].z, v[i].w};       // normalised unquantized
                     if constexpr (FQ == 3) {                                 // (sum_fq == 3: the same table format as the result's, row form)
-                        uint32_t unused = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) t[j] = fq_word_bf16<kFmtRows, true, false>(t[j], 1.0f, rnd, unused);
+                        const uint32_t tin[4] = {t[0], t[1], t[2], t[3]};
+                        fq_rows_words<4, false>(tin, t, rnd);
                     } else if (sum_fq == 2) fq8_hw_vec8<true>(t, sum_fmt);
                     else fq8_hw_vec8<false>(t, sum_fmt);
                     sum[row * (size_t)nvec + c] = uint4{t[0], t[1], t[2], t[3]};
@@ -118,9 +117,8 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
             }
             if constexpr (FQ == 1 || FQ == 2) y8[row * (size_t)nvec + c] = fq8_hw_vec8<FQ == 2>(o, fmt);
             if constexpr (FQ == 3) {
-                uint32_t unused = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = fq_word_bf16<kFmtRows, true, false>(o[j], 1.0f, rnd, unused);
+                const uint32_t oin[4] = {o[0], o[1], o[2], o[3]};
+                fq_rows_words<4, false>(oin, o, rnd);
             }
             y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
         }
@@ -162,13 +160,14 @@ __global__ __launch_bounds__(256) void silu_mul_map_kernel(const uint4 *__restri
         const size_t row = i / cv, col = i - row * cv;
         const uint4 a = g[row * rs_g + col], b = u[row * rs_u + col];
         const uint32_t p[4] = {a.x, a.y, a.z, a.w}, q[4] = {b.x, b.y, b.z, b.w};
-        uint32_t o[4], unused = 0;
+        uint32_t pr[4], o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float g0 = bf_lo(p[j]), g1 = bf_hi(p[j]);
             const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
-            o[j] = fq_word_bf16<kFmtRows, true, false>(pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j])), 1.0f, rnd, unused);
+            pr[j] = pack_bf16x2(s0 * bf_lo(q[j]), s1 * bf_hi(q[j]));
         }
+        fq_rows_words<4, false>(pr, o, rnd);
         y[i] = uint4{o[0], o[1], o[2], o[3]};
     }
 }
@@ -302,9 +301,8 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
             *(uint2 *)(a.y8 + o * 8) = codes;
         } else if (a.map) {                                  // table format, row form
             const Rounder<kFmtRows> rnd{a.fmt, a.rows_lds, a.map};
-            uint32_t unused = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = fq_word_bf16<kFmtRows, true, false>(out[j], 1.0f, rnd, unused);
+            const uint32_t oin[4] = {out[0], out[1], out[2], out[3]};
+            fq_rows_words<4, false>(oin, out, rnd);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

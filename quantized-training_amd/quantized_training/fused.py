@@ -199,8 +199,9 @@ class SiblingGroup:
     (`_qt_origin` of the hook's output) and all members quantize inputs and weights with the same stateless FP8
     format, so the leader's FP8 activation IS theirs, byte for byte."""
 
-    def __init__(self, layers):
+    def __init__(self, layers, value_map_only=False):
         self.layers = list(layers)
+        self.value_map_only = value_map_only   # gate / up: one launch only on the value-map GEMM (qt_linear_fqt_ws_bf16), see model_fusions
         self.buf = None
         self.bias = None                       # (key of the members' bias versions, concatenated bias [sum N])
         self.stash = None                      # (origin key, product [M, sum N], taken flags)
@@ -395,7 +396,7 @@ class BatchedWeightCodes:
 
 def _sibling_linear_or_none(layer, x, x8):
     group = layer.__dict__.get("_qt_sibling_group")
-    if group is None or os.environ.get("QT_SIBLING_GEMM", "1") == "0" or _WEIGHT_CACHE["on"]:
+    if group is None or group.value_map_only or os.environ.get("QT_SIBLING_GEMM", "1") == "0" or _WEIGHT_CACHE["on"]:
         return None
     idx = group.layers.index(layer)
     key = _origin_key(x)
@@ -762,6 +763,8 @@ def fqt_linear_or_none(layer, x):
     x2 = x.reshape(-1, K)
     M = x2.shape[0]
     group = layer.__dict__.get("_qt_sibling_group")
+    if group is not None and group.value_map_only and os.environ.get("QT_GATE_UP_GROUP", "1") == "0":      # A/B hook (tools/ab_13b_routes.py)
+        group = None
     if group is not None and os.environ.get("QT_SIBLING_GEMM", "1") != "0":
         idx = group.layers.index(layer)
         Ns = [l.weight.shape[0] for l in group.layers]

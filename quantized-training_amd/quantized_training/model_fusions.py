@@ -879,8 +879,18 @@ def apply_llama_fusions(model):
                 for lin in group.layers:
                     lin.__dict__["_qt_sibling_group"] = group
             mod.post_attention_layernorm.__dict__["_qt_consumers"] = [mlp.gate_proj, mlp.up_proj]
-            # (gate / up as one sibling group measured slower -- one N = 22016 GEMM is no faster than two N = 11008 ones and SiLU * up
-            # then reads strided rows: 16.64 vs 16.48 ms per window; what pays is the one-launch MLP front half, qt_mlp_fq8_bf16)
+            # gate / up as one sibling group: on the FP8 routes it measured slower -- one N = 22016 GEMM is no faster than two N = 11008
+            # ones and SiLU * up then reads strided rows: 16.64 vs 16.48 ms per window; what pays there is the one-launch MLP front half,
+            # qt_mlp_fq8_bf16.  On the value-map GEMM (qt_linear_fqt_ws_bf16) one launch is two full rounds of 6.75-group tiles instead
+            # of two launches that each fill 84 % of the chip: 32.68 -> 32.46 ms per configs[3] window (same-box A/B,
+            # tools/ab_13b_routes.py) -- the group is taken by that route only.  (Folding SiLU * up and the consumer's fake-quantizer
+            # into that launch's epilogue as well was built and measured: a tie with this -- at one workgroup per CU the epilogue's
+            # ~45 vector instructions per value run with the matrix pipe idle and cost what the separate HBM-bound launch costs.)
+            if all(hasattr(l, "weight_fake_quant") for l in (mlp.gate_proj, mlp.up_proj)):
+                from .fused import SiblingGroup
+                group = SiblingGroup([mlp.gate_proj, mlp.up_proj], value_map_only=True)
+                for lin in group.layers:
+                    lin.__dict__["_qt_sibling_group"] = group
     if n:
         _patch_rope()
     return n

@@ -1,7 +1,7 @@
 """A/B on ONE box: the configs[3] window (LLaMA-2-13B-shaped, posit(8,2)) with different Linear routes -- each variant runs bench.py's
 workload in a child process of its own, alternating, so box-to-box spread (+-5 %) does not enter the comparison.
 
-    python tools/ab_13b_routes.py            # default rule | gate / up fused as well | everything fused | split-K route off
+    python tools/ab_13b_routes.py            # default rule | gate / up as two launches | everything fused | split-K route off
 """
 import json
 import os
@@ -16,8 +16,8 @@ sys.argv = ["bench.py", "--workload", "llama-13b-posit8_2", "--steps", "5", "--w
 from quantized_training import fused
 rule = fused.fqt_route_is_fused
 ab = os.environ.get("AB", "default")
-if ab == "gate_up_fused":
-    fused.fqt_route_is_fused = lambda M, ns, K, dev: True if (sum(ns), K) == (13824, 5120) else rule(M, ns, K, dev)
+if ab == "gate_up_separate":
+    os.environ["QT_GATE_UP_GROUP"] = "0"
 elif ab == "all_fused":
     fused.fqt_route_is_fused = lambda M, ns, K, dev: M > 256
 elif ab == "no_split":
@@ -26,7 +26,7 @@ import bench
 bench.main()
 ''' % (ROOT, ROOT)
 
-variants = sys.argv[1:] or ["default", "gate_up_fused", "all_fused", "no_split"]
+variants = sys.argv[1:] or ["default", "gate_up_separate", "all_fused", "no_split"]
 for rep in range(2):
     for ab in variants:
         out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, AB=ab), capture_output=True, text=True)
