@@ -580,6 +580,14 @@ int qt_silu_mul_map_bf16(const uint16_t *gate_dev, const uint16_t *up_dev, uint1
 int qt_rope_map_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
                      uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
                      const qt_format *fmt, const uint16_t *map_dev, int inner_q, int inner_k, void *stream);
+/* qt_rope_map_bf16 and qt_value_t_rows (the table-format attention core's value pass, below) in ONE launch, as qt_rope_fq_value does
+ * for FP8: both read slices of the q / k / v projections' product, neither depends on the other, each alone is too small to fill the
+ * chip.  v_dev: [B][Hk][S][D] by element strides, D = 128 contiguous, S % 128 == 0; vt_dev: [B][Hk][128][S] bf16 (qt_value_t_rows'
+ * layout); `fmt` / `map_dev` serve q, k and v -- the value's fake-quantizer must be that format too. */
+int qt_rope_map_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
+                      uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                      const qt_format *fmt, const uint16_t *map_dev, int inner_q, int inner_k, const uint16_t *v_dev, uint16_t *vt_dev,
+                      long v_stride_b, long v_stride_h, long v_stride_k, void *stream);
 /* qt_rope_fq_value for PT2E-prepared graphs (wikitext.py:60-136 exports HF's apply_rotary_pos_emb as q * cos + rotate_half(q) * sin and
  * the annotator fake-quantizes the add's earlier operand): out = fmt(inner(bf16(x * cos)) + bf16(rotate_half(x) * sin)) with inner_q /
  * inner_k stateless closed-form FP formats (NULL: none -- exactly qt_rope_fq_value).  v_dev may be NULL (no value job). */

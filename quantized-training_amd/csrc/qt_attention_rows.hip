@@ -29,6 +29,7 @@
 
 #include "../../include/qt_hip.h"
 #include "qt_device.h"
+#include "qt_value_rows.h"
 
 namespace {
 
@@ -384,10 +385,10 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
 }
 
 // fq_v(V) as bf16 values, transposed to [d][key] with the keys of every 32-chunk permuted into the k-slot order of the kernel's P.V
-// instruction (slot 8 g + 4 h + e <-> key 16 h + 4 g + e).  One 256-thread workgroup per (batch * head, block of 128 keys).
+// instruction (csrc/qt_value_rows.h).  One 256-thread workgroup per (batch * head, block of 128 keys).
 __global__ __launch_bounds__(256) void value_t_rows_kernel(const uint16_t *v, uint16_t *vt, int H, long Sk, long sb, long sh, long sk, qt_format fmt,
                                                            const uint16_t *lut) {
-    __shared__ __attribute__((aligned(16))) uint16_t tile[kD * (kBlock + 8)];          // [d][key slot], rows padded by 16 bytes
+    __shared__ __attribute__((aligned(16))) uint16_t tile[value_rows_tile_elems<kBlock>()];
     __shared__ uint4 s_rows[512];
     Rounder<kFmtRows> rnd{fmt, nullptr, nullptr};
     {
@@ -398,35 +399,7 @@ __global__ __launch_bounds__(256) void value_t_rows_kernel(const uint16_t *v, ui
         rnd.glut = lut;
     }
     __syncthreads();
-    const int t = threadIdx.x, kb = blockIdx.x;
-    const long bh = blockIdx.y, b = bh / H, h = bh % H;
-    // a thread takes TWO adjacent keys (k, k + 1: adjacent slots too) and one 8-wide d chunk, so every LDS write is a 32-bit
-    // {fq(V)[k][d], fq(V)[k + 1][d]} pair into row d of the image
-    constexpr int kRow = kBlock + 8;                                        // uint16 per image row
-#pragma unroll
-    for (int it = 0; it < (kBlock / 2) * (kD / 8) / 256; ++it) {
-        const int item = it * 256 + t, kp = item & 63, dv = item >> 6, key = 2 * kp;
-        const uint16_t *src = v + b * sb + h * sh + ((long)kb * kBlock + key) * sk + dv * 8;
-        const uint4 i0 = *(const uint4 *)src, i1 = *(const uint4 *)(src + sk);
-        const uint32_t w0[4] = {i0.x, i0.y, i0.z, i0.w}, w1[4] = {i1.x, i1.y, i1.z, i1.w};
-        uint32_t a[4], c[4];
-        fq_rows_words<4, false>(w0, a, rnd);
-        fq_rows_words<4, false>(w1, c, rnd);
-        // key = 32 c + 16 hh + 4 gg + ee  ->  slot 32 c + 8 gg + 4 hh + ee (ee even here: slot even)
-        const int p = (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
-        uint32_t *base = (uint32_t *)(tile + (dv * 8) * kRow + p);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            base[(2 * j) * (kRow / 2)] = (a[j] & 0xFFFFu) | (c[j] << 16);
-            base[(2 * j + 1) * (kRow / 2)] = (a[j] >> 16) | (c[j] & 0xFFFF0000u);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < kD * kBlock / 8 / 256; ++it) {
-        const int ci = it * 256 + t, d = ci >> 4, ch = ci & 15;
-        *(uint4 *)(vt + (bh * kD + d) * Sk + (long)kb * kBlock + ch * 8) = *(const uint4 *)(tile + d * kRow + ch * 8);
-    }
+    value_t_rows_block<kBlock>(tile, rnd, v, vt, H, Sk, sb, sh, sk, (long)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 int status() {

@@ -13,6 +13,7 @@
 #include "qt_device.h"
 #include "qt_formats.h"
 #include "qt_value_codes.h"
+#include "qt_value_rows.h"
 
 namespace {
 
@@ -354,6 +355,39 @@ __global__ __launch_bounds__(256) void rope_fq_value_kernel(RopeFqArgs q, RopeFq
     } else {
         const unsigned vb = blockIdx.x - rope_blocks;
         value_codes_block<VE5M2, VD>(tile, v.v, v.vt8, (int)(vb % (unsigned)v.nkb), (long)(vb / (unsigned)v.nkb), v.H, v.Sk, v.sb, v.sh, v.sk, v.fmt);
+    }
+}
+
+// The same pairing for TABLE formats: the rotary kernel in its row form (rope_fq_kernel with a map) and the table-format attention
+// core's value pass (csrc/qt_value_rows.h, 64 keys per workgroup here so that six workgroups share a CU's LDS) in one launch; one
+// format -- one row table -- for q, k and v (checked on the host).
+struct ValueRowsArgs {
+    const uint16_t *v;
+    uint16_t *vt;
+    long sb, sh, sk, Sk;
+    int H, nkb;
+};
+
+__global__ __launch_bounds__(256) void rope_map_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueRowsArgs v, unsigned rope_blocks, unsigned tpb) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[value_rows_tile_elems<64>()];
+    __shared__ uint4 s_rows[512];
+    {
+        const uint4 *gr = (const uint4 *)(q.map + QT_MAP_ENTRIES);
+        const int nrows = (q.fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = gr[i];
+        __syncthreads();
+        q.rows_lds = k.rows_lds = (const uint16_t *)s_rows;
+    }
+    if (blockIdx.x < rope_blocks) {
+        const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;
+        for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)rope_blocks * tpb) {
+            rope_fq_token(q, bs, tpb, tokens);
+            rope_fq_token(k, bs, tpb, tokens);
+        }
+    } else {
+        const unsigned vb = blockIdx.x - rope_blocks;
+        const Rounder<kFmtRows> rnd{q.fmt, (const uint16_t *)s_rows, q.map};
+        value_t_rows_block<64>(tile, rnd, v.v, v.vt, v.H, v.Sk, v.sb, v.sh, v.sk, (long)(vb / (unsigned)v.nkb), (int)(vb % (unsigned)v.nkb), (int)threadIdx.x);
     }
 }
 
@@ -978,6 +1012,29 @@ int qt_rope_map_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, 
     size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     rope_fq_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(aq, ak, tpb);
+    return launch_status();
+}
+
+int qt_rope_map_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
+                      long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
+                      int inner_q, int inner_k, const uint16_t *v, uint16_t *vt, long v_stride_b, long v_stride_h, long v_stride_k, void *stream) {
+    if (B * S * D == 0) return QT_OK;
+    if (!q || !k || !cos || !sin || !q_out || !k_out || !v || !vt || B < 0 || S < 0 || Hq < 0 || Hk < 1 || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
+    if (D != kValueRowsD || S % 128 != 0 || B * Hk > 65535) return QT_ERR_BAD_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)v | (uintptr_t)vt) & 15u) ||
+        ((v_stride_b | v_stride_h | v_stride_k) & 7))
+        return QT_ERR_UNALIGNED;
+    if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
+    if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
+    RopeFqArgs aq{{q, q_out, cos, sin, B, S, Hq, D, (size_t)(B * S * Hq * D / 8), q_row_stride / 8}, *fmt, nullptr, 0, inner_q ? 1 : 0, qt_format{}, map, nullptr};
+    RopeFqArgs ak{{k, k_out, cos, sin, B, S, Hk, D, (size_t)(B * S * Hk * D / 8), k_row_stride / 8}, *fmt, nullptr, 0, inner_k ? 1 : 0, qt_format{}, map, nullptr};
+    const long nv_max = (Hq > Hk ? Hq : Hk) * D / 8;
+    const unsigned tpb = nv_max >= 256 || nv_max < 1 ? 1u : (unsigned)(256 / nv_max);
+    size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    ValueRowsArgs av{v, vt, v_stride_b, v_stride_h, v_stride_k, S, (int)Hk, (int)(S / 64)};
+    const unsigned total = (unsigned)blocks + (unsigned)(B * Hk * (S / 64));
+    rope_map_value_kernel<<<total, 256, 0, (hipStream_t)stream>>>(aq, ak, av, (unsigned)blocks, tpb);
     return launch_status();
 }
 

@@ -1173,7 +1173,7 @@ def fused_attention_or_none(attn, query, key, value, attention_mask, scaling, dr
             fq_o = cand
     if not (table_p and scale_ptr is None and amax_ptr is None and fq_v is not None and not _has_table_hooks(fq_v)
             and attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut,
-                                       fq_o is not None)):
+                                       fq_o is not None, attn=attn)):
         vq = (fq_v(value) if fq_v is not None else value).contiguous()
         launch_attention_fq(L, st, qq, kq, vq, mask, attention_mask, (msb, msh, msq), out, (B, H, Q, C, D), scaling, fmt, lut, scale_ptr, amax_ptr,
                             fq_o is not None)
@@ -1187,7 +1187,7 @@ def _has_table_hooks(fq):
     return bool(fq._forward_hooks or fq._forward_pre_hooks)
 
 
-def attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, mask_owner, mask_strides, out, dims, scaling, fmt, lut, out_fq):
+def attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, mask_owner, mask_strides, out, dims, scaling, fmt, lut, out_fq, attn=None):
     """qt_attention_rows_bf16 (round 4): the table-format attention core with the score strip in registers -- head_dim 128, key counts in
     blocks of 128 up to 1024, the probabilities' fake-quantizer a stateless table format in its row form (fmt / lut as handed to
     launch_attention_fq), and `fq_v` a stateless table format in its row form too: its call IS the kernel's value pass
@@ -1205,9 +1205,13 @@ def attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, mask_owner, mask_st
         return False
     msb, msh, msq = mask_strides
     live = _mask_row_live(mask, mask_owner, B, H, Q, C, st) if (mask is not None and mask_owner is not None) else None
-    vt = torch.empty((B, H, D, C), dtype=torch.bfloat16, device=value.device)
-    _native.check(L.qt_value_t_rows(value.data_ptr(), vt.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2), ctypes.byref(vfmt),
-                                    fq_v.qmap.data_ptr(), st), "qt_value_t_rows")
+    early = attn.__dict__.pop("_qt_vt_rows", None) if attn is not None else None
+    if early is not None and early[0] == value_key(value) and early[1] is fq_v:
+        vt = early[2]                                          # written by the launch that carried the rotary kernel (model_fusions.rope_map)
+    else:
+        vt = torch.empty((B, H, D, C), dtype=torch.bfloat16, device=value.device)
+        _native.check(L.qt_value_t_rows(value.data_ptr(), vt.data_ptr(), B, H, C, D, value.stride(0), value.stride(1), value.stride(2),
+                                        ctypes.byref(vfmt), fq_v.qmap.data_ptr(), st), "qt_value_t_rows")
     STATS.add(value.numel())                                   # the fq_v call
     fq_v.__dict__["_qt_calls"] = fq_v.__dict__.get("_qt_calls", 0) + 1
     if live is not None:

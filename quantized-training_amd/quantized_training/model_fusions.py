@@ -219,9 +219,13 @@ def silu_mul_map(gate, up, fq):
     return _mark_done(y, [fq])
 
 
-def rope_map(q, k, cos, sin, fq_q, fq_k, inner_q=False, inner_k=False):
+def rope_map(q, k, cos, sin, fq_q, fq_k, inner_q=False, inner_k=False, value_job=None):
     """Rotary embedding with qk_matmul's two stateless table-format input fake-quantizers (one format) in the same pass: contiguous
-    [B, H, S, D] outputs marked as done for them, or None."""
+    [B, H, S, D] outputs marked as done for them, or None.
+
+    value_job = (attn, value, fq_v), set when the table-format attention core is what will consume these tensors (_rows_attention_plan):
+    the launch then also carries that kernel's value pass (qt_rope_map_value) and leaves V^T with the attention module for the core's
+    call (fused.attention_rows_or_none, which counts fq_v's call when it takes it)."""
     pf = fq_q.map_producer_format(q.device)
     if pf is None or fq_k.map_producer_format(q.device) is None or fq_k.dtype != fq_q.dtype:
         return None
@@ -230,6 +234,16 @@ def rope_map(q, k, cos, sin, fq_q, fq_k, inner_q=False, inner_k=False):
     Hk = k.shape[1]
     q_out = torch.empty((B, Hq, S, D), dtype=q.dtype, device=q.device)
     k_out = torch.empty((B, Hk, S, D), dtype=k.dtype, device=k.device)
+    if value_job is not None:
+        from . import fused
+        attn, value, fq_v = value_job
+        vt = torch.empty((B, Hk, D, S), dtype=torch.bfloat16, device=q.device)
+        _native.check(_native.lib().qt_rope_map_value(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
+                                                      B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
+                                                      int(bool(inner_q)), int(bool(inner_k)), value.data_ptr(), vt.data_ptr(), value.stride(0),
+                                                      value.stride(1), value.stride(2), _stream_ptr(q)), "qt_rope_map_value")
+        attn.__dict__["_qt_vt_rows"] = (fused.value_key(value), fq_v, vt)
+        return _mark_done(q_out, [fq_q]), _mark_done(k_out, [fq_k])
     _native.check(_native.lib().qt_rope_map_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
                                                  B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
                                                  int(bool(inner_q)), int(bool(inner_k)), _stream_ptr(q)), "qt_rope_map_bf16")
@@ -789,6 +803,40 @@ def _fp8_attention_plan(attn, q, qk_fqs):
     return attn, value, holder["1"]
 
 
+def _rows_attention_plan(attn, q, qk_fqs):
+    """(attn, value, fq_v) when the attention core of this call will be qt_attention_rows_bf16 as far as can be told here -- the same
+    conditions as _fp8_attention_plan with the four fake-quantizers stateless TABLE formats of one dtype in their row form, head_dim 128
+    -- else None."""
+    if (os.environ.get("QT_ROPE_VALUE_LAUNCH", "1") == "0" or os.environ.get("QT_FUSED_ATTENTION", "auto") == "0"
+            or not attn.__dict__.get("_qt_cacheless", False)):
+        return None
+    vproj = getattr(attn, "v_proj", None)
+    group = vproj.__dict__.get("_qt_sibling_group") if vproj is not None else None
+    av = getattr(attn, "av_matmul", None)
+    holder = getattr(av, "activation_pre_process", None) if av is not None else None
+    if (group is None or group.stash is None or holder is None or set(holder.keys()) != {"0", "1"} or vproj not in group.layers
+            or len(av._forward_pre_hooks) != 1 or av._forward_hooks):
+        return None
+    fqs = (*qk_fqs, holder["0"], holder["1"])
+    for f in fqs:
+        if not (isinstance(f, FusedAmaxObsFakeQuantize) and f.stateless_map() and f._qt_format.kind == _native.QT_FMT_LUT
+                and f.map_producer_format(q.device) is not None) or f._forward_hooks or f._forward_pre_hooks:
+            return None
+    if len({str(f.dtype) for f in fqs}) != 1:
+        return None
+    B, H, S, D = q.shape
+    Ns = [l.weight.shape[0] for l in group.layers]
+    idx = group.layers.index(vproj)
+    y = group.stash[1]
+    if D != 128 or S % 128 != 0 or S > 1024 or B * H > 65535 or Ns[idx] != H * D or y.shape[0] != B * S or not group.stash[2][idx]:
+        return None
+    off = sum(Ns[:idx])
+    value = y[:, off:off + Ns[idx]].view(B, S, H, D).transpose(1, 2)
+    if value.dtype != torch.bfloat16 or any(st % 8 for st in value.stride()[:3]) or value.data_ptr() % 16:
+        return None
+    return attn, value, holder["1"]
+
+
 def _patch_rope():
     """HF's LlamaAttention.forward calls the module-level apply_rotary_pos_emb; route it through the fused kernel when
     the tensors are the layout it produces ([B, S, H, D] buffers seen as [B, H, S, D], cos / sin [B, S, D])."""
@@ -816,7 +864,7 @@ def _patch_rope():
                     return rope_fq(q, k, cos, sin, *fqs, value_job=_fp8_attention_plan(_CURRENT_ATTN[-1], q, fqs))
                 mfqs = _qk_fqs(_CURRENT_ATTN[-1], table=True)
                 if mfqs is not None:
-                    got = rope_map(q, k, cos, sin, *mfqs)
+                    got = rope_map(q, k, cos, sin, *mfqs, value_job=_rows_attention_plan(_CURRENT_ATTN[-1], q, mfqs))
                     if got is not None:
                         return got
             return rope(q, k, cos, sin)

@@ -800,6 +800,52 @@ def test_fused_attention_kernel_on_posit8_2_inputs_in_row_form(nv, B, H, S, D):
     assert np.array_equal(o.vmap_bf16(pq.reshape(-1)[:: 97], qmap), pq.reshape(-1)[:: 97])
 
 
+@pytest.mark.parametrize("B,S,H", [(1, 1024, 40), (2, 128, 3), (3, 256, 5)])
+@pytest.mark.parametrize("dtype", ["posit8_2", "fp6_e3m2"])
+def test_rope_map_value_is_the_two_launches(nv, B, S, H, dtype):
+    """qt_rope_map_value (the table-format rotary kernel and the attention core's value pass in ONE launch, 64-key value blocks) writes
+    exactly what qt_rope_map_bf16 and qt_value_t_rows write as two launches, with q / k / v the column slices of one [B * S, 3 H D]
+    projection product (LLaMA-2-13B's shape first); and refuses what the value pass does not take."""
+    import quantized_training as qt
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    D = 128
+    g = torch.Generator(device="cuda").manual_seed(3 + S)
+    m = qt.get_quantization_map(dtype, torch.device("cuda"))
+    f = _launch_format(nv.format_for(dtype), m)
+    qkv = (torch.randn(B * S, 3 * H * D, device="cuda", generator=g) * 2).bfloat16()
+    qkv.view(-1)[::1013] = 0.0                                                        # exact zeros: the flagged row 0 of posit maps
+    q = qkv[:, :H * D].view(B, S, H, D).transpose(1, 2)
+    k = qkv[:, H * D:2 * H * D].view(B, S, H, D).transpose(1, 2)
+    v = qkv[:, 2 * H * D:].view(B, S, H, D).transpose(1, 2)
+    ang = torch.rand(B, S, D, device="cuda", generator=g) * 6.28
+    cos, sin = ang.cos().bfloat16(), ang.sin().bfloat16()
+    rs = 3 * H * D
+    outs = []
+    for merged in (False, True):
+        qo, ko = torch.empty(B, H, S, D, dtype=torch.bfloat16, device="cuda"), torch.empty(B, H, S, D, dtype=torch.bfloat16, device="cuda")
+        vt = torch.empty(B, H, D, S, dtype=torch.bfloat16, device="cuda")
+        if merged:
+            nv.check(L.qt_rope_map_value(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr(), B, S, H, H, D, rs, rs,
+                                         ctypes.byref(f), m.data_ptr(), 0, 0, v.data_ptr(), vt.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+                                         stream()), "qt_rope_map_value")
+        else:
+            nv.check(L.qt_rope_map_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr(), B, S, H, H, D, rs, rs,
+                                        ctypes.byref(f), m.data_ptr(), 0, 0, stream()), "qt_rope_map_bf16")
+            nv.check(L.qt_value_t_rows(v.data_ptr(), vt.data_ptr(), B, H, S, D, v.stride(0), v.stride(1), v.stride(2), ctypes.byref(f), m.data_ptr(),
+                                       stream()), "qt_value_t_rows")
+        outs.append((qo, ko, vt))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    qo, ko, vt = outs[0]
+    args = (q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr())
+    tail = (ctypes.byref(f), m.data_ptr(), 0, 0, v.data_ptr(), vt.data_ptr(), v.stride(0), v.stride(1), v.stride(2), stream())
+    assert L.qt_rope_map_value(*args, B, S, H, H, 64, rs, rs, *tail) == nv.QT_ERR_BAD_ARG                 # head_dim 64: no value pass for it
+    plain = nv.format_for(dtype)
+    assert L.qt_rope_map_value(*args, B, S, H, H, D, rs, rs, ctypes.byref(plain), *tail[1:]) == nv.QT_ERR_BAD_ARG
+    assert L.qt_rope_map_value(*args, B, S, H, H, D, rs, rs, *tail[:4], v.data_ptr() + 2, *tail[5:]) == nv.QT_ERR_UNALIGNED
+
+
 @pytest.mark.parametrize("B,H,S,D,mask_kind", [(1, 40, 1024, 128, "causal"), (2, 5, 256, 128, "causal"), (2, 3, 384, 128, "padding"), (1, 4, 128, 128, None),
                                                (1, 2, 640, 128, "full")])
 @pytest.mark.parametrize("pdtype", ["posit8_2", "posit8_1", "fp4_e2m1"])
