@@ -7,9 +7,11 @@ import json
 import os
 import shutil
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+FRESH_S = float(os.environ.get("FRESH_HOURS", "4")) * 3600.0
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 
@@ -83,7 +85,7 @@ print(json.dumps(res, indent=1))
 
 def clean(src, dst):
     """Experiment logs without the profiler's own chatter."""
-    if not os.path.exists(src):
+    if not os.path.exists(src) or time.time() - os.path.getmtime(src) > FRESH_S:       # an older session's file: not this round's evidence
         return
     keep = [ln for ln in open(src, errors="replace") if not any(t in ln for t in ("amdgpu.ids", "rocprofv3", "output_stream.cpp", "simple_timer.cpp", "tool.cpp"))]
     open(dst, "w").writelines(keep)
@@ -104,14 +106,14 @@ for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_brea
                  # round 4
                  ("train_step_breakdown.txt", "train_step_breakdown.txt"), ("bert_batch_breakdown.txt", "bert_batch_breakdown.txt"),
                  ("ab_13b_routes.txt", "13b_route_ab.txt"), ("ab_7b_routes.txt", "7b_route_ab.txt"), ("ab_bert_routes.txt", "bert_route_ab.txt"),
-                 ("small_fq.txt", "small_fq.txt")):
+                 ("small_fq.txt", "small_fq.txt"), ("attention_rows.txt", "attention_rows.txt"), ("attention_rows_stamps.txt", "attention_rows_stamps.txt")):
     clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
 for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
                      ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv"),
                      ("prof_bert_stats/*/*kernel_stats.csv", "bert_kernel_stats.csv"), ("prof_train_stats/*/*kernel_stats.csv", "train_kernel_stats.csv"),
                      ("prof_fqt/*/*kernel_stats.csv", "linear_fqt_kernel_stats.csv")):
     f = one(pattern)
-    if f:
+    if f and time.time() - os.path.getmtime(f) <= FRESH_S:
         shutil.copy(f, os.path.join(out, f"{tag}_{dst}"))
 
 # round 3: HBM traffic of the value-map GEMM (qt_linear_fqt_bf16, 1024 x 15360 x 5120) from its own PMC passes

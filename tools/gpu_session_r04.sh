@@ -13,7 +13,7 @@ for w in llama-13b-posit8_2 bert-base-squad-e4m3 roberta-mrpc-int8-e5m2-train; d
 done
 # per-window / per-step launch lists of the three secondary workloads
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_13b_posit -- python3 bench.py --workload llama-13b-posit8_2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_13b_posit.log 2>&1
-python tools/window_breakdown.py gpurun_out/prof_13b_posit --windows 3 --layers 40 --anchor attention_fq > gpurun_out/window_breakdown_13b_posit.txt 2>&1
+python tools/window_breakdown.py gpurun_out/prof_13b_posit --windows 3 --layers 40 --anchor attention_rows > gpurun_out/window_breakdown_13b_posit.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train_stats -- python3 bench.py --workload roberta-mrpc-int8-e5m2-train --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_train4.log 2>&1
 python tools/window_breakdown.py gpurun_out/prof_train_stats --windows 3 --layers 1 --anchor scale_update_multi_kernel > gpurun_out/train_step_breakdown.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bert_stats -- python3 bench.py --workload bert-base-squad-e4m3 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_bert4.log 2>&1
@@ -31,6 +31,9 @@ find gpurun_out/prof_fqt -name "*kernel_trace.csv" -delete
 timeout 600 python tools/ab_13b_routes.py > gpurun_out/ab_13b_routes.txt 2>&1; cat gpurun_out/ab_13b_routes.txt
 timeout 600 python tools/ab_7b_routes.py > gpurun_out/ab_7b_routes.txt 2>&1; cat gpurun_out/ab_7b_routes.txt
 timeout 600 python tools/ab_bert_routes.py > gpurun_out/ab_bert_routes.txt 2>&1; cat gpurun_out/ab_bert_routes.txt
+# the table-format attention core: against round 3's two-pass kernel, and the s_memtime stamps of its heaviest workgroup (tuning build)
+timeout 300 python tools/exp_attention_rows.py > gpurun_out/attention_rows.txt 2>&1; cat gpurun_out/attention_rows.txt
+if [ -f tools/build/libqt_hip_tuning.so ]; then QT_HIP_LIB=tools/build/libqt_hip_tuning.so timeout 300 python tools/exp_attention_rows_stamps.py > gpurun_out/attention_rows_stamps.txt 2>&1; fi
 ABI=1 timeout 300 python tools/exp_small_fq.py > gpurun_out/small_fq.txt 2>&1; cat gpurun_out/small_fq.txt | cut -c1-200
 # the reference's current flow (PT2E prepared graph, fused)
 timeout 900 python bench.py --route pt2e --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary > gpurun_out/pt2e_bench.json 2> gpurun_out/pt2e_bench.err
