@@ -298,10 +298,11 @@ __global__ __launch_bounds__(512, (MB == 4 && D == 64) ? 4 : 1) void attention_f
 #pragma unroll
                     for (int j = 4 * c; j < 4 * c + 4; ++j) {
                         float *v = e[it][j];
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) v[x] = (v[x] - mx) * kLog2e;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) v[x] = __builtin_amdgcn_exp2f(v[x]);
+                        // packed subtract and multiply (two values per instruction), the same roundings as the scalar forms
+                        const float2_t a0 = (float2_t{v[0], v[1]} - float2_t{mx, mx}) * float2_t{kLog2e, kLog2e};
+                        const float2_t a1 = (float2_t{v[2], v[3]} - float2_t{mx, mx}) * float2_t{kLog2e, kLog2e};
+                        v[0] = __builtin_amdgcn_exp2f(a0[0]); v[1] = __builtin_amdgcn_exp2f(a0[1]);
+                        v[2] = __builtin_amdgcn_exp2f(a1[0]); v[3] = __builtin_amdgcn_exp2f(a1[1]);
                         sum2 += float2_t{v[0], v[1]};
                         sum2 += float2_t{v[2], v[3]};
                     }
