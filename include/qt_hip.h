@@ -493,17 +493,19 @@ int qt_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t 
                     void *stream);
 /* qt_rmsnorm_bf16 with the FIRST consumer's stateless E4M3 / E5M2 fake-quantizer applied to the result (bf16 + FP8
  * code).  Its sibling consumers (k/v projections beside q, up beside gate) still run their own passes on the result;
- * those formats are idempotent, so what they compute is unchanged. */
+ * those formats are idempotent, so what they compute is unchanged.  y_dev may be NULL: the codes only (consumers that multiply codes
+ * need nothing else; the codes decode to exactly the values y would hold). */
 int qt_rmsnorm_fq8_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, uint16_t *y_dev, uint8_t *y8_dev, long rows,
                         long cols, float eps, const qt_format *fmt, void *stream);
 /* BERT-style blocks (transformers modeling_bert.py BertSelfOutput / BertOutput / BertIntermediate, and the twins of
  * upstream modules/quantizable/modeling_bert.py:174-214): `LayerNorm(dense(x) + residual)` and the erf-form GELU.
  *   qt_layernorm_bf16: s = bf16(x + residual) (residual may be NULL: s = x); y = bf16(w * (rstd * (s - mean)) + b) with the
- *                      row mean / biased variance in fp32; cols % 8 == 0, cols <= 16384.  With yq / y8 (both or neither) the
- *                      consumer's stateless E4M3 / E5M2 fake-quantizer `fmt` is applied as well: yq = fq(y) as bf16, y8 its
+ *                      row mean / biased variance in fp32; cols % 8 == 0, cols <= 16384.  With y8 (and optionally yq) the
+ *                      consumer's stateless E4M3 / E5M2 fake-quantizer `fmt` is applied as well: yq = fq(y) as bf16 (NULL: not
+ *                      written -- a consumer that multiplies codes needs nothing else, and they decode to exactly fq(y)), y8 its
  *                      FP8 code; y itself stays unquantized (it also feeds the next residual connection).
  *   qt_gelu_bf16:      y = bf16((x * 0.5) * (1 + erf(x * sqrt(1/2)))); with y8 the consumer's fake-quantizer is applied on
- *                      the way out (y = fq(gelu(x)) as bf16, y8 its FP8 code); n % 8 == 0 */
+ *                      the way out (y = fq(gelu(x)) as bf16 -- may then be NULL: codes only --, y8 its FP8 code); n % 8 == 0 */
 int qt_layernorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, const uint16_t *bias_dev,
                       uint16_t *y_dev, uint16_t *yq_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt,
                       void *stream);
@@ -516,7 +518,7 @@ int qt_gelu_bf16(const uint16_t *x_dev, uint16_t *y_dev, uint8_t *y8_dev, size_t
 /* The residual add of a LLaMA block (modeling_llama.py LlamaDecoderLayer.forward: `hidden = residual + hidden`) absorbed into
  * the RMSNorm behind it: sum = bf16(x + residual) (written out: it is the next residual), y = RMSNorm(sum) as
  * qt_rmsnorm_bf16 computes it; with y8 (non-NULL) the first consumer's stateless E4M3 / E5M2 fake-quantizer is applied to y
- * as in qt_rmsnorm_fq8_bf16. */
+ * as in qt_rmsnorm_fq8_bf16 (y_dev may then be NULL: codes only). */
 int qt_add_rmsnorm_bf16(const uint16_t *x_dev, const uint16_t *residual_dev, const uint16_t *weight_dev, uint16_t *sum_dev,
                         uint16_t *y_dev, uint8_t *y8_dev, long rows, long cols, float eps, const qt_format *fmt, void *stream);
 /* qt_add_rmsnorm_bf16 for PT2E-prepared graphs, where the residual stream itself is fake-quantized in front of the NEXT add (the

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
                 const uint32_t oin[4] = {o[0], o[1], o[2], o[3]};
                 fq_rows_words<4, false>(oin, o, rnd);
             }
-            y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};
+            if ((FQ != 1 && FQ != 2) || y) y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};      // NULL with FP8 codes: codes only
         }
     }
 }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
                     a.extra.y8[e][base + c] = a.extra.e5m2[e] ? fq8_hw_vec8<true>(t, a.extra.fmt[e]) : fq8_hw_vec8<false>(t, a.extra.fmt[e]);
                 }
                 const uint2 codes = fq8_hw_vec8<FQ == 2>(o, a.fmt);
-                a.yq[base + c] = uint4{o[0], o[1], o[2], o[3]};
+                if (a.yq) a.yq[base + c] = uint4{o[0], o[1], o[2], o[3]};         // NULL: codes only (they decode to exactly these values)
                 a.y8[base + c] = codes;
             }
         }
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const uint4 *__restrict__ x, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(gelu_erf(bf_lo(p[j])), gelu_erf(bf_hi(p[j])));
         if constexpr (FQ != 0) y8[i] = fq8_hw_vec8<FQ == 2>(o, fmt);
-        y[i] = uint4{o[0], o[1], o[2], o[3]};
+        if (FQ == 0 || y) y[i] = uint4{o[0], o[1], o[2], o[3]};                  // NULL with FQ: codes only
     }
 }
 
@@ -681,7 +681,7 @@ int qt_rmsnorm_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, long
 int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, uint8_t *y8, long rows, long cols, float eps,
                         const qt_format *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
-    if (!x || !weight || !y || !y8 || !fmt || rows < 0 || cols < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;
+    if (!x || !weight || !y8 || !fmt || rows < 0 || cols < 0 || fmt->kind != QT_FMT_FP_SAT) return QT_ERR_BAD_ARG;       // y NULL: codes only
     const bool e5m2 = fmt->p0 == 2 && fmt->p1 == -14 && fmt->fhi == 57344.0f;
     const bool e4m3 = fmt->p0 == 3 && fmt->p1 == -6 && fmt->fhi == 448.0f;
     if (!e5m2 && !e4m3) return QT_ERR_BAD_ARG;
@@ -700,7 +700,7 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, 
 int qt_add_rmsnorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, uint8_t *y8,
                         long rows, long cols, float eps, const qt_format *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
-    if (!x || !residual || !weight || !sum || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
+    if (!x || !residual || !weight || !sum || (!y && !y8) || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;              // y NULL with y8: codes only
     const int fq = y8 ? fp8_code_of(fmt) : 0;
     if (y8 && !fq) return QT_ERR_BAD_ARG;
     if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
@@ -778,9 +778,9 @@ static int launch_layernorm_any(const LnArgs &a, int fq, bool with_residual, voi
 int qt_layernorm_bf16(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, const uint16_t *bias, uint16_t *y,
                       uint16_t *yq, uint8_t *y8, long rows, long cols, float eps, const qt_format *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
-    if (!x || !weight || !bias || !y || rows < 0 || cols < 0 || ((yq != nullptr) != (y8 != nullptr))) return QT_ERR_BAD_ARG;
-    const int fq = yq ? fp8_code_of(fmt) : 0;
-    if (yq && !fq) return QT_ERR_BAD_ARG;
+    if (!x || !weight || !bias || !y || rows < 0 || cols < 0 || (yq && !y8)) return QT_ERR_BAD_ARG;
+    const int fq = y8 ? fp8_code_of(fmt) : 0;
+    if (y8 && !fq) return QT_ERR_BAD_ARG;
     if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 ||
         (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)yq) & 15u) || ((uintptr_t)y8 & 7u))
         return QT_ERR_UNALIGNED;
@@ -793,7 +793,7 @@ int qt_layernorm_consumers_bf16(const uint16_t *x, const uint16_t *residual, con
                                 uint16_t *yq, long rows, long cols, float eps, int consumers, uint8_t *const *y8,
                                 const qt_format *const *fmt, void *stream) {
     if (rows * cols == 0) return QT_OK;
-    if (!x || !weight || !bias || !y || !yq || rows < 0 || cols < 0 || consumers < 2 || consumers > 3 || !y8 || !fmt) return QT_ERR_BAD_ARG;
+    if (!x || !weight || !bias || !y || rows < 0 || cols < 0 || consumers < 2 || consumers > 3 || !y8 || !fmt) return QT_ERR_BAD_ARG;
     int code[3] = {0, 0, 0};
     for (int i = 0; i < consumers; ++i) {
         if (!y8[i] || !fmt[i] || ((uintptr_t)y8[i] & 7u)) return QT_ERR_BAD_ARG;
@@ -830,7 +830,7 @@ static int launch_layernorm_any(const LnArgs &a, int fq, bool with_residual, voi
 
 int qt_gelu_bf16(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n, const qt_format *fmt, void *stream) {
     if (n == 0) return QT_OK;
-    if (!x || !y) return QT_ERR_BAD_ARG;
+    if (!x || (!y && !y8)) return QT_ERR_BAD_ARG;
     const int fq = y8 ? fp8_code_of(fmt) : 0;
     if (y8 && !fq) return QT_ERR_BAD_ARG;
     if ((n & 7) || (((uintptr_t)x | (uintptr_t)y) & 15u) || ((uintptr_t)y8 & 7u)) return QT_ERR_UNALIGNED;

@@ -773,7 +773,8 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             # the kernel that produced X already applied this fake-quantizer (and attached X._qt_fp8): the call the
             # reference issues here is satisfied by that fused computation, counted once
             _Stats.add(X.numel())
-            materialize_lazy(X)
+            if not self.__dict__.get("_qt_lazy_ok"):          # (set by model_fusions.codes_only_ok: the consumer decodes on demand)
+                materialize_lazy(X)
             return X
         also = getattr(X, "_qt_also_done", None)
         if also is not None and handover_valid(X):
@@ -783,11 +784,16 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
             for fq, x8 in also:
                 if fq is self:
                     _Stats.add(X.numel())
+                    if X.__dict__.get("_qt_lazy", False) and not self.__dict__.get("_qt_lazy_ok"):
+                        materialize_lazy(X)
                     out = X.view(X.shape)
                     out._qt_fp8 = x8
                     out._qt_ver = out._version
                     out._qt_origin = (X.data_ptr(), X._version, tuple(X.shape))
+                    if X.__dict__.get("_qt_lazy", False):
+                        out._qt_lazy = True                   # the producer wrote the codes only; this consumer decodes on demand
                     return out
+        materialize_lazy(X)          # every path below reads X's values: a producer may have written its FP8 codes only
         if (done_by is not None and self._emit_fp8 and isinstance(done_by, FusedAmaxObsFakeQuantize) and handover_valid(X)
                 and getattr(X, "_qt_fp8", None) is not None and X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous()
                 and not (torch.is_grad_enabled() and X.requires_grad) and self.producer_fusable() and done_by.producer_fusable()
@@ -818,6 +824,10 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
                     out._qt_fp8 = x8.view(X.shape)
                     out._qt_ver = out._version
                     out._qt_origin = (ptr, version, tuple(X.shape))       # fq(.) of X, for sibling GEMMs
+                    if replacement.__dict__.get("_qt_lazy", False):       # the producer wrote the codes only
+                        out._qt_lazy = True
+                        if not self.__dict__.get("_qt_lazy_ok"):
+                            materialize_lazy(out)
                     return out
                 X._qt_fp8 = x8
                 X._qt_ver = X._version

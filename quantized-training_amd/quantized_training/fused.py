@@ -11,7 +11,7 @@ import torch
 
 from . import _native
 from .fake_quantize import (STATS, FusedAmaxObsFakeQuantFunction, FusedAmaxObsFakeQuantize, _stream_ptr, handover_valid,
-                            launch_scale_update)
+                            launch_scale_update, materialize_lazy)
 from .quantizer.quantizer import QScheme
 
 _IDENTITY = _native.QtFormat(_native.QT_FMT_IDENTITY, 0, 0, 0.0, 0.0)
@@ -564,6 +564,7 @@ def fused_linear_or_none(layer, x):
     out = fp8_linear_or_none(layer, x)
     if out is not None:
         return out
+    materialize_lazy(x)                      # every other route reads the values: a producer may have written the FP8 codes only
     out = fqt_linear_or_none(layer, x)
     if out is not None:
         return out

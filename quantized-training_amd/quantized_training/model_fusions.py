@@ -72,7 +72,7 @@ def rmsnorm(x, weight, eps):
     return y
 
 
-def _norm_with_consumers(x2, r2, weight, eps, fqs):
+def _norm_with_consumers(x2, r2, weight, eps, fqs, codes_only=False):
     """One launch for (residual add +) RMSNorm and the input fake-quantizers of ALL the Linears consuming it: returns (sum or None, y)
     where y = fq_0(result) carries the codes for every consumer (`_qt_also_done`): their hooks hand them through (fake_quantize.py)
     instead of launching a pass each over the tensor.  (Round 2 wrote one code tensor per consumer, qt_rmsnorm_consumers_bf16 -- still
@@ -86,21 +86,24 @@ def _norm_with_consumers(x2, r2, weight, eps, fqs):
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
     f0 = fqs[0]
     if r2 is not None:
-        _native.check(_native.lib().qt_add_rmsnorm_bf16(x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), total.data_ptr(), y.data_ptr(),
-                                                        y8.data_ptr(), x2.numel() // cols, cols, float(eps), ctypes.byref(f0._qt_format),
-                                                        _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
+        _native.check(_native.lib().qt_add_rmsnorm_bf16(x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), total.data_ptr(),
+                                                        None if codes_only else y.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(eps),
+                                                        ctypes.byref(f0._qt_format), _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
     else:
-        _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols,
-                                                        float(eps), ctypes.byref(f0._qt_format), _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
+        _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), None if codes_only else y.data_ptr(), y8.data_ptr(),
+                                                        x2.numel() // cols, cols, float(eps), ctypes.byref(f0._qt_format), _stream_ptr(x2)),
+                      "qt_rmsnorm_fq8_bf16")
     codes = _fp8_view(y8, f0)
     y._qt_fp8 = codes
     y._qt_fq_done_by = f0
     y._qt_also_done = [(f, codes) for f in fqs[1:]]
     y._qt_ver = y._version
+    if codes_only:
+        _mark_lazy(y)                                 # (model_fusions.codes_only_ok: every consumer multiplies the codes)
     return total, y
 
 
-def rmsnorm_fq(x, weight, eps, fq):
+def rmsnorm_fq(x, weight, eps, fq, codes_only=False):
     """RMSNorm with `fq` applied to the result: the first consumer's input fake-quantizer, or the list of all consumers' (then one
     launch evaluates them all, _norm_with_consumers)."""
     cols = x.shape[-1]
@@ -110,20 +113,22 @@ def rmsnorm_fq(x, weight, eps, fq):
         return got[1] if got is not None else rmsnorm(x2, weight, eps)
     if isinstance(fq, (list, tuple)):
         if len(fq) > 1:
-            return _norm_with_consumers(x2, None, weight, eps, fq)[1]
+            return _norm_with_consumers(x2, None, weight, eps, fq, codes_only)[1]
         fq = fq[0]
     y = torch.empty_like(x2)
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
-    _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), y.data_ptr(), y8.data_ptr(),
+    _native.check(_native.lib().qt_rmsnorm_fq8_bf16(x2.data_ptr(), weight.data_ptr(), None if codes_only else y.data_ptr(), y8.data_ptr(),
                                                     x2.numel() // cols, cols, float(eps), ctypes.byref(fq._qt_format),
                                                     _stream_ptr(x2)), "qt_rmsnorm_fq8_bf16")
     y._qt_fp8 = _fp8_view(y8, fq)
     y._qt_fq_done_by = fq
     y._qt_ver = y._version
+    if codes_only:
+        _mark_lazy(y)
     return y
 
 
-def add_rmsnorm(x, residual, norm, fq=None):
+def add_rmsnorm(x, residual, norm, fq=None, codes_only=False):
     """(bf16(x + residual), RMSNorm of that sum) in one launch; with `fq` the norm result carries the first consumer's
     fake-quant exactly as rmsnorm_fq's does (a list: all consumers', as there)."""
     cols = x.shape[-1]
@@ -135,19 +140,22 @@ def add_rmsnorm(x, residual, norm, fq=None):
         fq = None
     if isinstance(fq, (list, tuple)):
         if len(fq) > 1:
-            return _norm_with_consumers(x2, r2, norm.weight, norm.variance_epsilon, fq)
+            return _norm_with_consumers(x2, r2, norm.weight, norm.variance_epsilon, fq, codes_only)
         fq = fq[0]
     total = torch.empty_like(x2)
     y = torch.empty_like(x2)
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) if fq is not None else None
+    codes_only = bool(codes_only and fq is not None)
     _native.check(_native.lib().qt_add_rmsnorm_bf16(
-        x2.data_ptr(), r2.data_ptr(), norm.weight.data_ptr(), total.data_ptr(), y.data_ptr(),
+        x2.data_ptr(), r2.data_ptr(), norm.weight.data_ptr(), total.data_ptr(), None if codes_only else y.data_ptr(),
         y8.data_ptr() if y8 is not None else None, x2.numel() // cols, cols, float(norm.variance_epsilon),
         ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)), "qt_add_rmsnorm_bf16")
     if fq is not None:
         y._qt_fp8 = _fp8_view(y8, fq)
         y._qt_fq_done_by = fq
         y._qt_ver = y._version
+        if codes_only:
+            _mark_lazy(y)
     return total, y
 
 
@@ -158,7 +166,9 @@ def _add_rmsnorm_or_none(x, residual, norm):
     if (norm is None or w is None or norm.__dict__.get("_qt_hf_forward") is None or _hooked(norm) or not _eligible(x, residual, w)
             or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()):
         return None
-    return add_rmsnorm(x, residual, norm, _norm_consumer_fq(norm, allow_all=True, allow_map=True))
+    fq = _norm_consumer_fq(norm, allow_all=True, allow_map=True)
+    lazy = fq is not None and not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(norm.__dict__.get("_qt_consumers"))
+    return add_rmsnorm(x, residual, norm, fq, codes_only=lazy)
 
 
 def consumer_fq_map(linear):
@@ -314,6 +324,37 @@ def consumer_fq(linear):
     return fq
 
 
+def codes_only_ok(linears):
+    """True when a producer kernel may write ONLY the FP8 codes of its fake-quantized result for these consumers (the bf16 tensor stays
+    unwritten, `_qt_lazy`): every consumer is a QAT Linear whose own forward runs (it multiplies the codes, and asks
+    fake_quantize.materialize_lazy for the values on every other route), reached through its single input hook, under no_grad."""
+    from . import fused
+    from .modules.qat.linear import Linear as QATLinear
+    if os.environ.get("QT_CODES_ONLY", "1") == "0" or torch.is_grad_enabled() or not fused.fp8_gemm_enabled() or not linears:
+        return False
+    for lin in linears:
+        if not isinstance(lin, QATLinear) or type(lin).forward is not QATLinear.forward or lin._forward_hooks or lin.__dict__.get("_qt_prepared"):
+            return False
+        fq = consumer_fq(lin)
+        if fq is None or fq._forward_hooks or fq._forward_pre_hooks:
+            return False
+    for lin in linears:
+        consumer_fq(lin).__dict__["_qt_lazy_ok"] = True          # (its hook then hands a lazy tensor through instead of decoding it)
+    return True
+
+
+def _mark_lazy(t):
+    """t's values were not written (its FP8 codes were).  QT_LAZY_POISON=1 (tests): fill it with NaN, so that a read that bypasses
+    fake_quantize.materialize_lazy cannot go unnoticed."""
+    if os.environ.get("QT_LAZY_POISON", "0") == "1":
+        stamped = getattr(t, "_qt_ver", None) == t._version
+        t.fill_(float("nan"))
+        if stamped:
+            t._qt_ver = t._version                    # (the fill is not a modification of the result the hand-over describes)
+    t._qt_lazy = True
+    return t
+
+
 def _fp8_view(t8, fq):
     return t8.view(torch.float8_e5m2 if fq._qt_format.p0 == 2 else torch.float8_e4m3fn)
 
@@ -427,10 +468,11 @@ def rope_fq(q, k, cos, sin, fq_q, fq_k, value_job=None):
 
 
 # ---- BERT-style blocks -----------------------------------------------------------------------------------------------
-def layernorm(x, norm, residual=None, fq=None):
+def layernorm(x, norm, residual=None, fq=None, codes_only=False):
     """LayerNorm(x [+ residual]) in one launch.  With `fq` (the first consuming Linear's input fake-quantizer) the kernel
     also writes fq(y) as bf16 + FP8 code and leaves them for that fake-quantizer's next call; y itself stays
-    unquantized because the next residual connection reads it too."""
+    unquantized because the next residual connection reads it too.  codes_only (model_fusions.codes_only_ok): fq(y) is left as codes,
+    its bf16 tensor allocated but not written (`_qt_lazy`: decoded on demand, exactly)."""
     cols = x.shape[-1]
     x2 = x.contiguous()
     r2 = residual.contiguous() if residual is not None else None
@@ -445,8 +487,10 @@ def layernorm(x, norm, residual=None, fq=None):
             y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
             _native.check(_native.lib().qt_layernorm_bf16(
                 x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
-                yq.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(norm.eps), ctypes.byref(fqs[0]._qt_format),
-                _stream_ptr(x2)), "qt_layernorm_bf16")
+                None if codes_only else yq.data_ptr(), y8.data_ptr(), x2.numel() // cols, cols, float(norm.eps),
+                ctypes.byref(fqs[0]._qt_format), _stream_ptr(x2)), "qt_layernorm_bf16")
+            if codes_only:
+                _mark_lazy(yq)
             for f in fqs:
                 f.expect_prequantized(y, _fp8_view(y8, f), replacement=yq)
             return y
@@ -457,25 +501,31 @@ def layernorm(x, norm, residual=None, fq=None):
         y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device)
     _native.check(_native.lib().qt_layernorm_bf16(
         x2.data_ptr(), r2.data_ptr() if r2 is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(),
-        yq.data_ptr() if yq is not None else None, y8.data_ptr() if y8 is not None else None, x2.numel() // cols, cols,
+        yq.data_ptr() if (yq is not None and not codes_only) else None, y8.data_ptr() if y8 is not None else None, x2.numel() // cols, cols,
         float(norm.eps), ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)), "qt_layernorm_bf16")
     if fq is not None:
+        if codes_only:
+            _mark_lazy(yq)
         fq.expect_prequantized(y, _fp8_view(y8, fq), replacement=yq)
     return y
 
 
-def gelu(x, fq=None):
-    """erf-form GELU; with `fq` (the consuming Linear's input fake-quantizer) applied in the same pass (result marked)."""
+def gelu(x, fq=None, codes_only=False):
+    """erf-form GELU; with `fq` (the consuming Linear's input fake-quantizer) applied in the same pass (result marked).  codes_only
+    (model_fusions.codes_only_ok): only the FP8 codes are written, the bf16 tensor is `_qt_lazy`."""
     x2 = x.contiguous()
     y = torch.empty_like(x2)
     y8 = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device) if fq is not None else None
-    _native.check(_native.lib().qt_gelu_bf16(x2.data_ptr(), y.data_ptr(), y8.data_ptr() if y8 is not None else None, x2.numel(),
+    lazy = bool(codes_only and fq is not None)
+    _native.check(_native.lib().qt_gelu_bf16(x2.data_ptr(), None if lazy else y.data_ptr(), y8.data_ptr() if y8 is not None else None, x2.numel(),
                                              ctypes.byref(fq._qt_format) if fq is not None else None, _stream_ptr(x2)),
                   "qt_gelu_bf16")
     if fq is not None:
         y._qt_fp8 = _fp8_view(y8, fq)
         y._qt_fq_done_by = fq
         y._qt_ver = y._version
+        if lazy:
+            _mark_lazy(y)
     return y
 
 
@@ -496,12 +546,12 @@ def add_layernorm_or_none(block, hidden, residual):
     norm = getattr(block, "LayerNorm", None)
     if norm is None or add is None or _hooked(add) or not _layernorm_ok(norm, hidden, residual):
         return None
-    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm, allow_all=True))
+    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm, allow_all=True), codes_only=codes_only_ok(norm.__dict__.get("_qt_consumers")))
 
 
 def _layernorm_forward(self, x):
     if _layernorm_ok(self, x):
-        return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True))
+        return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True), codes_only=codes_only_ok(self.__dict__.get("_qt_consumers")))
     return self._qt_hf_forward(x)
 
 
@@ -517,7 +567,7 @@ def _intermediate_forward(self, hidden_states):
         if _eligible(h) and h.numel() % 8 == 0 and h.numel() > 0:
             consumer = self.__dict__.get("_qt_consumer")
             fq = consumer_fq(consumer) if consumer is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None
-            return gelu(h, fq)
+            return gelu(h, fq, codes_only=fq is not None and codes_only_ok([consumer]))
         return act(h)
     return self._qt_hf_forward(hidden_states)
 
@@ -606,7 +656,8 @@ def _rmsnorm_forward(self, hidden_states):
             and hidden_states.numel() > 0 and w.is_contiguous()):
         fq = _norm_consumer_fq(self, allow_all=True, allow_map=True)
         if fq is not None:
-            return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq)
+            lazy = not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(self.__dict__.get("_qt_consumers"))
+            return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq, codes_only=lazy)
         return rmsnorm(hidden_states, w, self.variance_epsilon)
     return self._qt_hf_forward(hidden_states)
 

@@ -10,6 +10,9 @@ for p in (ROOT, PKG_DIR):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# producers that hand over FP8 codes only leave the bf16 tensor unwritten (model_fusions._mark_lazy): under test it is filled with NaN, so
+# that a consumer that reads it without fake_quantize.materialize_lazy fails loudly instead of reading stale memory
+os.environ.setdefault("QT_LAZY_POISON", "1")
 
 
 def pytest_configure(config):

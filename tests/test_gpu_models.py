@@ -302,6 +302,66 @@ def test_bert_block_fusions_vs_hf_chains(family):
         assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01, float((a - b).abs().max())
 
 
+def test_codes_only_handover_is_invisible(monkeypatch):
+    """LayerNorm / GELU producers that leave fq(result) as FP8 codes only (the bf16 tensor allocated, not written: `_qt_lazy`) for QAT
+    Linears that multiply the codes: logits bit-identical to the same model with QT_CODES_ONLY=0 (values written); with the unwritten
+    tensors poisoned (QT_LAZY_POISON=1: NaN) nothing changes, i.e. nobody reads them; and when the Linear takes another route after
+    all (the FP8 route declined behind the hook), the values are decoded on demand -- bit-identical again.  Same fake-quant counts."""
+    import copy
+    from transformers import BertConfig, BertForQuestionAnswering
+    from quantized_training import fused, model_fusions as mf
+    from quantized_training.fake_quantize import STATS
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=300,
+                     max_position_embeddings=256)
+    base = BertForQuestionAnswering(cfg).eval().bfloat16()
+    ids = torch.randint(3, 300, (4, 256), generator=torch.Generator().manual_seed(1)).cuda()
+    att = torch.ones_like(ids)
+    att[2, 200:] = 0
+    lazy_made = {"n": 0}
+    real_mark = mf._mark_lazy
+
+    def counting_mark(t):
+        lazy_made["n"] += 1
+        return real_mark(t)
+    monkeypatch.setattr(mf, "_mark_lazy", counting_mark)
+
+    def run():
+        m = copy.deepcopy(base).cuda()
+        qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+        with torch.no_grad():
+            m(ids, attention_mask=att)
+            STATS.reset()
+            o = m(ids, attention_mask=att)
+        torch.cuda.synchronize()
+        return o.start_logits.float(), o.end_logits.float(), STATS.elements, STATS.calls
+    monkeypatch.setenv("QT_CODES_ONLY", "0")
+    ref = run()
+    assert lazy_made["n"] == 0
+    monkeypatch.delenv("QT_CODES_ONLY")
+    got = run()
+    assert lazy_made["n"] >= 3 * cfg.num_hidden_layers                          # second forward: the embedding norm, two LayerNorms and one GELU per layer, less the last norm
+    monkeypatch.setenv("QT_LAZY_POISON", "1")
+    poisoned = run()
+    for r in (got, poisoned):
+        assert torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1]) and r[2:] == ref[2:]
+    # the FP8 route declines behind the hook for the GELU's consumer: its Linear must decode the values itself
+    real = fused.fp8_linear_or_none
+    declined = {"n": 0}
+
+    def picky(layer, x):
+        if layer.in_features == cfg.intermediate_size and getattr(x, "_qt_lazy", False):
+            declined["n"] += 1
+            return None
+        return real(layer, x)
+    monkeypatch.setattr(fused, "fp8_linear_or_none", picky)
+    fallback = run()
+    assert declined["n"] >= cfg.num_hidden_layers
+    assert torch.isfinite(fallback[0]).all() and fallback[2:] == ref[2:]
+    for a, b in ((fallback[0], ref[0]), (fallback[1], ref[1])):                 # a bf16 GEMM on the decoded values instead of the FP8 GEMM on the codes
+        assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01
+
+
 def test_mobilebert_blocks_on_device(monkeypatch):
     """MobileBERT has BertLayer-shaped blocks with NoNorm, ReLU and bottlenecked q / k / v inputs: the BERT block fusions
     must step aside (different input widths -> no sibling GEMM, NoNorm -> HF's code) and the device path must agree with
