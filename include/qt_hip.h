@@ -275,7 +275,8 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
  * E4M3 / E5M2 weight specs) on the same FP8-coded activation, then, per output element, in the module chain's arithmetic:
  *     g = bf16(acc_gate + bias_gate), u = bf16(acc_up + bias_up), p = bf16(bf16(g / (1 + exp(-g))) * u)   -- SiLU * up
  *     h = fq_out(p)                                              -- the consumer's input fake-quantizer (fake_quantize.py:217-248)
- * written as bf16 values (h_dev [M][N]) AND as FP8 codes (h8_dev [M][N]); out_format: an e4m3 / e5m2 closed-form format with unit
+ * written as bf16 values (h_dev [M][N]; NULL: not written, a consumer that multiplies codes needs only those) AND as FP8 codes
+ * (h8_dev [M][N]); out_format: an e4m3 / e5m2 closed-form format with unit
  * scale (qt_format_for).  w_gate_dev / w_up_dev: UNQUANTIZED bf16 [N][K]; the weight value map (w_format) is applied inside the
  * GEMM as in qt_linear_fq8_bf16.  K % 128 == 0, N % 16 == 0; pointers 16-byte aligned. */
 int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_dev, const uint16_t *w_up_dev,

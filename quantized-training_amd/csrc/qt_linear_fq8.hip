@@ -503,8 +503,10 @@ struct LinearFq8R {
                         silu_mul4(gt, up, o[2 * ii], o[2 * ii + 1]);
                     }
                     const uint2 codes = oe5 ? fq8_hw_vec8<true>(o, a.out_fmt) : fq8_hw_vec8<false>(o, a.out_fmt);   // o: now fq(product)
-                    ds_write64(tv + ((2 * ih) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[0], o[1]});
-                    ds_write64(tv + ((2 * ih + 1) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[2], o[3]});
+                    if (a.y) {                                         // NULL: the codes only (they decode to exactly these values)
+                        ds_write64(tv + ((2 * ih) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[0], o[1]});
+                        ds_write64(tv + ((2 * ih + 1) * 16 + r) * kRowV + jp * 32 + g * 8, u32x2{o[2], o[3]});
+                    }
                     ds_write32(tc + ((2 * ih) * 16 + r) * kRowC + jp * 16 + g * 4, codes.x);
                     ds_write32(tc + ((2 * ih + 1) * 16 + r) * kRowC + jp * 16 + g * 4, codes.y);
                 }
@@ -512,14 +514,16 @@ struct LinearFq8R {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const long col0 = (long)((tg0 + jbase) / 2) * 16;
             constexpr int kVChunks = 64 * NTW, kCChunks = 64 * (NTW / 2);       // 16-byte chunks of the values / of the codes
+            if (a.y) {
 #pragma unroll
-            for (int it = 0; it < (kVChunks + 63) / 64; ++it) {
-                const int c = it * 64 + l, row = c / NTW, ch = c % NTW;
-                uint2 lo_, hi_;
-                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(lo_), "=&v"(hi_) : "v"(tv + row * kRowV + ch * 16) : "memory");
-                const int grow = m0 + wm * 64 + row;
-                if (c < kVChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+                for (int it = 0; it < (kVChunks + 63) / 64; ++it) {
+                    const int c = it * 64 + l, row = c / NTW, ch = c % NTW;
+                    uint2 lo_, hi_;
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo_), "=&v"(hi_) : "v"(tv + row * kRowV + ch * 16) : "memory");
+                    const int grow = m0 + wm * 64 + row;
+                    if (c < kVChunks && grow < a.M) *(uint4 *)(a.y + (long)grow * a.ldc + col0 + ch * 8) = uint4{lo_.x, lo_.y, hi_.x, hi_.y};
+                }
             }
 #pragma unroll
             for (int it = 0; it < (kCChunks + 63) / 64; ++it) {
@@ -667,7 +671,7 @@ __device__ __forceinline__ void slow_tile_pair(const Args &a, int m0, int tg0, i
             for (int ii = 0; ii < 2; ++ii) {
                 const int row = m0 + wm * 64 + (2 * ih + ii) * 16 + r;
                 if (row < a.M) {
-                    *(uint2 *)(a.y + (long)row * a.ldc + col) = uint2{o[2 * ii], o[2 * ii + 1]};
+                    if (a.y) *(uint2 *)(a.y + (long)row * a.ldc + col) = uint2{o[2 * ii], o[2 * ii + 1]};
                     *(uint32_t *)(a.y8 + (long)row * a.ldc + col) = ii ? codes.y : codes.x;
                 }
             }
@@ -1210,7 +1214,7 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
     if (!out_format || out_format->kind != QT_FMT_FP_SAT || !(out_format->p0 == 2 || out_format->p0 == 3)) return QT_ERR_BAD_DTYPE;
     if (N < 0 || N % 16 != 0) return QT_ERR_BAD_ARG;
     if ((long)M * N == 0) return QT_OK;
-    if (!x8_dev || !w_gate_dev || !w_up_dev || !h_dev || !h8_dev || M < 0 || K < kBK || K % kBK != 0) return QT_ERR_BAD_ARG;
+    if (!x8_dev || !w_gate_dev || !w_up_dev || !h8_dev || M < 0 || K < kBK || K % kBK != 0) return QT_ERR_BAD_ARG;       // h_dev NULL: codes only
     if (((uintptr_t)x8_dev | (uintptr_t)w_gate_dev | (uintptr_t)w_up_dev | (uintptr_t)h_dev | (uintptr_t)h8_dev) & 15u) return QT_ERR_UNALIGNED;
     if ((bias_gate_dev && ((uintptr_t)bias_gate_dev & 7u)) || (bias_up_dev && ((uintptr_t)bias_up_dev & 7u))) return QT_ERR_UNALIGNED;
     Args a{};

@@ -171,6 +171,18 @@ def handover_valid(t):
     return getattr(t, "_qt_ver", None) == t._version
 
 
+_LAZY = {}          # data_ptr -> weakref of a tensor whose values were not written (its FP8 codes were): views of it lose the attribute
+
+
+def note_lazy(t):
+    """Registers t (model_fusions._mark_lazy, rope_fq) so that a VIEW of it -- a reshape between the producer and the consuming hook
+    drops Python attributes -- is still recognised by materialize_lazy.  The entry dies with the tensor."""
+    import weakref
+    ptr = t.data_ptr()
+    _LAZY[ptr] = weakref.ref(t)
+    weakref.finalize(t, lambda p=ptr: _LAZY.pop(p, None) if (_LAZY.get(p) is not None and _LAZY[p]() is None) else None)
+
+
 def materialize_lazy(t):
     """A producer that knew its consumer multiplies FP8 codes wrote ONLY the codes of fq(t) (t._qt_lazy; model_fusions.rope_fq).  The
     fake-quantized values are exactly what the codes decode to, so whoever asks for them after all gets them here."""
@@ -178,6 +190,16 @@ def materialize_lazy(t):
         t.copy_(t._qt_fp8.to(t.dtype))
         t._qt_lazy = False
         t._qt_ver = t._version
+        return
+    if _LAZY:
+        ref = _LAZY.get(t.data_ptr())
+        base = ref() if ref is not None else None
+        if base is not None and base is not t and base.__dict__.get("_qt_lazy", False) and base.numel() == t.numel() and t.is_contiguous():
+            # a view of a lazy tensor (same storage, same extent): decode through the owner
+            stamped = getattr(t, "_qt_ver", None) == t._version
+            materialize_lazy(base)
+            if stamped:
+                t._qt_ver = t._version
 
 
 def _stream_ptr(t):

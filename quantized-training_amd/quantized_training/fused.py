@@ -253,7 +253,7 @@ def _origin_key(x):
     return (x.data_ptr(), x._version, tuple(x.shape))         # the leader's input was handed through by its hook
 
 
-def hip_mlp_fq8_or_none(x8, gate, up, out_fq):
+def hip_mlp_fq8_or_none(x8, gate, up, out_fq, codes_only=False):
     """(h, h8) = the gated MLP's front half in one launch (qt_mlp_fq8_bf16): fq_out(silu(gate(x)) * up(x)) as bf16 values and FP8
     codes from the FP8 codes of x and the UNQUANTIZED bf16 weights of the QAT Linears `gate` / `up`.  None when the kernel does
     not take the problem."""
@@ -275,8 +275,8 @@ def hip_mlp_fq8_or_none(x8, gate, up, out_fq):
     h8 = torch.empty((M, N), dtype=torch.uint8, device=x8.device)
     rc = _native.lib().qt_mlp_fq8_bf16(x8.data_ptr(), _F8_CODE[x8.dtype], Wg.data_ptr(), Wu.data_ptr(),
                                         gate.bias.data_ptr() if gate.bias is not None else None, up.bias.data_ptr() if up.bias is not None else None,
-                                        N, 1 if fg.p0 == 2 else 0, h.data_ptr(), h8.data_ptr(), ctypes.byref(out_fq._qt_format), M, K,
-                                        _stream_ptr(x8))
+                                        N, 1 if fg.p0 == 2 else 0, None if codes_only else h.data_ptr(), h8.data_ptr(),
+                                        ctypes.byref(out_fq._qt_format), M, K, _stream_ptr(x8))      # codes_only: h stays unwritten (`_qt_lazy`)
     if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
         return None
     _native.check(rc, "qt_mlp_fq8_bf16")

@@ -167,7 +167,7 @@ def _add_rmsnorm_or_none(x, residual, norm):
             or x.shape != residual.shape or x.shape[-1] % 8 != 0 or x.shape[-1] > 16384 or x.numel() == 0 or not w.is_contiguous()):
         return None
     fq = _norm_consumer_fq(norm, allow_all=True, allow_map=True)
-    lazy = fq is not None and not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(norm.__dict__.get("_qt_consumers"))
+    lazy = fq is not None and not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(norm.__dict__.get("_qt_consumers"), norm)
     return add_rmsnorm(x, residual, norm, fq, codes_only=lazy)
 
 
@@ -324,13 +324,16 @@ def consumer_fq(linear):
     return fq
 
 
-def codes_only_ok(linears):
+def codes_only_ok(linears, producer=None):
     """True when a producer kernel may write ONLY the FP8 codes of its fake-quantized result for these consumers (the bf16 tensor stays
     unwritten, `_qt_lazy`): every consumer is a QAT Linear whose own forward runs (it multiplies the codes, and asks
-    fake_quantize.materialize_lazy for the values on every other route), reached through its single input hook, under no_grad."""
+    fake_quantize.materialize_lazy for the values on every other route), reached through its single input hook, under no_grad; and
+    nobody hooked the producing module (a forward hook would be handed the unwritten tensor)."""
     from . import fused
     from .modules.qat.linear import Linear as QATLinear
     if os.environ.get("QT_CODES_ONLY", "1") == "0" or torch.is_grad_enabled() or not fused.fp8_gemm_enabled() or not linears:
+        return False
+    if producer is not None and _hooked(producer):
         return False
     for lin in linears:
         if not isinstance(lin, QATLinear) or type(lin).forward is not QATLinear.forward or lin._forward_hooks or lin.__dict__.get("_qt_prepared"):
@@ -352,6 +355,8 @@ def _mark_lazy(t):
         if stamped:
             t._qt_ver = t._version                    # (the fill is not a modification of the result the hand-over describes)
     t._qt_lazy = True
+    from .fake_quantize import note_lazy
+    note_lazy(t)
     return t
 
 
@@ -546,12 +551,12 @@ def add_layernorm_or_none(block, hidden, residual):
     norm = getattr(block, "LayerNorm", None)
     if norm is None or add is None or _hooked(add) or not _layernorm_ok(norm, hidden, residual):
         return None
-    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm, allow_all=True), codes_only=codes_only_ok(norm.__dict__.get("_qt_consumers")))
+    return layernorm(hidden, norm, residual, _norm_consumer_fq(norm, allow_all=True), codes_only=codes_only_ok(norm.__dict__.get("_qt_consumers"), norm))
 
 
 def _layernorm_forward(self, x):
     if _layernorm_ok(self, x):
-        return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True), codes_only=codes_only_ok(self.__dict__.get("_qt_consumers")))
+        return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True), codes_only=codes_only_ok(self.__dict__.get("_qt_consumers"), self))
     return self._qt_hf_forward(x)
 
 
@@ -567,7 +572,7 @@ def _intermediate_forward(self, hidden_states):
         if _eligible(h) and h.numel() % 8 == 0 and h.numel() > 0:
             consumer = self.__dict__.get("_qt_consumer")
             fq = consumer_fq(consumer) if consumer is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None
-            return gelu(h, fq, codes_only=fq is not None and codes_only_ok([consumer]))
+            return gelu(h, fq, codes_only=fq is not None and codes_only_ok([consumer], self))
         return act(h)
     return self._qt_hf_forward(hidden_states)
 
@@ -656,7 +661,7 @@ def _rmsnorm_forward(self, hidden_states):
             and hidden_states.numel() > 0 and w.is_contiguous()):
         fq = _norm_consumer_fq(self, allow_all=True, allow_map=True)
         if fq is not None:
-            lazy = not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(self.__dict__.get("_qt_consumers"))
+            lazy = not (isinstance(fq, tuple) and fq and fq[0] == "map") and codes_only_ok(self.__dict__.get("_qt_consumers"), self)
             return rmsnorm_fq(hidden_states, w, self.variance_epsilon, fq, codes_only=lazy)
         return rmsnorm(hidden_states, w, self.variance_epsilon)
     return self._qt_hf_forward(hidden_states)
@@ -722,7 +727,8 @@ def _fused_mlp_or_none(self, x):
         return _after_hooks_unfused(self, xg, xu)
     for l in (gate, up):
         l.weight_fake_quant._move_to(x.device)
-    got = fused.hip_mlp_fq8_or_none(x8.reshape(-1, x8.shape[-1]), gate, up, fq_out)
+    lazy = codes_only_ok([down], self)
+    got = fused.hip_mlp_fq8_or_none(x8.reshape(-1, x8.shape[-1]), gate, up, fq_out, codes_only=lazy)
     if got is None:
         return _after_hooks_unfused(self, xg, xu)
     STATS.add(gate.weight.numel())
@@ -732,6 +738,8 @@ def _fused_mlp_or_none(self, x):
     y._qt_fp8 = _fp8_view(h8.reshape(y.shape), fq_out)
     y._qt_fq_done_by = fq_out
     y._qt_ver = y._version
+    if lazy:
+        _mark_lazy(y)
     return y
 
 

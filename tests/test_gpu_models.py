@@ -360,6 +360,23 @@ def test_codes_only_handover_is_invisible(monkeypatch):
     assert torch.isfinite(fallback[0]).all() and fallback[2:] == ref[2:]
     for a, b in ((fallback[0], ref[0]), (fallback[1], ref[1])):                 # a bf16 GEMM on the decoded values instead of the FP8 GEMM on the codes
         assert float((a - b).abs().max()) <= 0.02 * float(b.abs().max()) + 0.01
+    monkeypatch.setattr(fused, "fp8_linear_or_none", real)
+    # a VIEW of a codes-only tensor reaches the consuming hook (Python attributes are gone): recognised by its storage, decoded
+    m = copy.deepcopy(base).cuda()
+    qt.quantize(m, _args("--activation", "e4m3", "--weight", "e4m3", "--bf16", "--quantize_forward", "gemm"))
+    with torch.no_grad():
+        m(ids, attention_mask=att)
+        layer = m.bert.encoder.layer[0]
+        dense = layer.output.dense
+        fq = mf.consumer_fq(dense)
+        assert fq is not None and mf.codes_only_ok([dense], layer.intermediate)
+        h = torch.randn(4, 256, cfg.intermediate_size, device="cuda").bfloat16()
+        outs = []
+        for lazy in (True, False):
+            y = mf.gelu(h, fq, codes_only=lazy)
+            assert bool(y.__dict__.get("_qt_lazy", False)) == lazy
+            outs.append(dense(y.view(-1, cfg.intermediate_size)))
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
 def test_mobilebert_blocks_on_device(monkeypatch):
