@@ -29,10 +29,34 @@ constexpr int kIoF32 = 1;
 constexpr int kLutBlock = 1024;   // one workgroup per CU (128 KiB LDS), 16 waves
 constexpr int kAluBlock = 256;
 constexpr int kUnroll = 1;        // 16-B loads per lane per tile (measured best: many small tiles)
+constexpr size_t kRowsDirectMaxVecs = (size_t)256 * 8 * 256 * 2;   // row form: up to two vectors per lane of a full chip read the table from global memory
 
 template <int IO, int KIND, int DIV, bool OBS>
 __device__ __forceinline__ uint4 fq_vec_d(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax, bool &bad) {
-    if constexpr (IO == kIoBf16) {
+    if constexpr (IO == kIoBf16 && KIND == kFmtRows) {
+        // the row form on all eight values at once (csrc/qt_device.h, fq_rows_words): eight row gathers in flight and one rare branch per
+        // vector instead of a gather, a wait and a branch per value -- what a short pass (one vector per lane) spends its time on
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t q[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = w[i] << 16, hi = w[i] & 0xFFFF0000u;
+            if constexpr (OBS) {
+                const uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+                amax = amax > a0 ? amax : a0;     // integer order == float order on |x|; NaN patterns win -> propagate
+                amax = amax > a1 ? amax : a1;
+            }
+            if constexpr (DIV == kDivFast) q[i] = pack_bf16x2(dv.fast16(qt_u2f(lo), bad), dv.fast16(qt_u2f(hi), bad));
+            else if constexpr (DIV == kDivExact) q[i] = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
+            else q[i] = w[i];
+        }
+        fq_rows_words<4, false>(q, r, rnd);
+        if constexpr (DIV != kDivUnit) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(qt_u2f(r[i] << 16) * dv.s, qt_u2f(r[i] & 0xFFFF0000u) * dv.s);
+        }
+        v = uint4{r[0], r[1], r[2], r[3]};
+    } else if constexpr (IO == kIoBf16) {
         v.x = fq_word_bf16_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
         v.y = fq_word_bf16_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
         v.z = fq_word_bf16_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
@@ -216,6 +240,36 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         fq_one<IO, KIND, OBS>(xv, yv, i, s, unit, rnd, amax);
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
+// The row form for SHORT passes (a lane has one or two vectors: the [2048, 768 .. 3072] activations and gradients of a training step):
+// the 4 - 8 KiB row table is read where it lies, in global memory behind the map (L1 / L2 hits), eight gathers in flight per vector --
+// no staging into LDS and no barrier in front of the first load.  An OBSERVED short pass runs 1024-thread workgroups: every workgroup
+// that can raise the running maximum issues an atomicMax on ONE address, the slot starts each step at zero, and same-address atomics
+// serialise at ~12 ns each -- 768 workgroups of 256 threads spent most of a [2048, 768] launch's 10.9 us queueing there.
+template <int IO, bool OBS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fq_rows_direct_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec, size_t n,
+                                                            qt_format fmt, const uint16_t *__restrict__ lut, const float *__restrict__ scale,
+                                                            uint32_t *amax_out) {
+    Rounder<kFmtRows> rnd{fmt, lut + QT_MAP_ENTRIES, lut};
+    float s = scale ? *scale : 1.0f;
+    if constexpr (IO == kIoBf16) s = qt_bf2f(qt_f2bf(s));
+    const bool unit = (s == 1.0f);
+    uint32_t amax = 0;
+    const uint4 *x = (const uint4 *)xv;
+    uint4 *y = (uint4 *)yv;
+    const UniformDiv dv(s);
+    if (unit)
+        fq_stream<IO, kFmtRows, kDivUnit, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+    else if (dv.safe)
+        fq_stream<IO, kFmtRows, kDivFast, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+    else
+        fq_stream<IO, kFmtRows, kDivExact, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+    constexpr int kPer = IO == kIoBf16 ? 8 : 4;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (size_t i = nvec * kPer + threadIdx.x; i < n; i += BLOCK) fq_one<IO, kFmtRows, OBS>(xv, yv, i, s, unit, rnd, amax);
+    }
+    if constexpr (OBS) block_amax_commit<BLOCK>(amax, amax_out);
 }
 
 // Vector-granular variant of the same (aligned tensors too small for the LDS table: a [2048, 768] gradient is 1.5 M
@@ -549,16 +603,16 @@ struct RowsArgs {
     size_t nvec;
 };
 
-template <int KIND, bool OBS, int FP8 = 0>          // FP8: 0 none, 1 also write E4M3 bytes, 2 E5M2 bytes (unit scale, FP_SAT kinds)
-__global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt, const uint16_t *__restrict__ lut,
-                                                      const float *__restrict__ scale, uint32_t *amax_out,
-                                                      uint2 *__restrict__ y8 = nullptr) {
+template <int KIND, bool OBS, int FP8 = 0, int BLOCK = 256>          // FP8: 0 none, 1 also write E4M3 bytes, 2 E5M2 bytes (unit scale, FP_SAT kinds)
+__global__ __launch_bounds__(BLOCK) void fq_rows_kernel(RowsArgs a, qt_format fmt, const uint16_t *__restrict__ lut,
+                                                        const float *__restrict__ scale, uint32_t *amax_out,
+                                                        uint2 *__restrict__ y8 = nullptr) {
     Rounder<KIND> rnd{fmt, lut};
     if constexpr (KIND == kFmtRows) {                    // the row words behind the map, as in fq_kernel
         __shared__ uint4 s_rows[512];
         const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
         const int nrows = (fmt.p1 & 2) ? 512 : 256;
-        for (int i = threadIdx.x; i < nrows; i += 256) s_rows[i] = g[i];
+        for (int i = threadIdx.x; i < nrows; i += BLOCK) s_rows[i] = g[i];
         rnd.lds = (const uint16_t *)s_rows;
         rnd.glut = lut;
         __syncthreads();
@@ -567,7 +621,7 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
     const bool unit = (s == 1.0f);
     const UniformDiv dv(s);
     uint32_t amax = 0;
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < a.nvec; v += (size_t)gridDim.x * 256) {
+    for (size_t v = (size_t)blockIdx.x * BLOCK + threadIdx.x; v < a.nvec; v += (size_t)gridDim.x * BLOCK) {
         const long row = (long)(v / (size_t)a.vpr), c = (long)(v % (size_t)a.vpr);
         const long i2 = row % a.d2, t = row / a.d2;
         const long i1 = t % a.d1, i0 = t / a.d1;
@@ -591,7 +645,7 @@ __global__ __launch_bounds__(256) void fq_rows_kernel(RowsArgs a, qt_format fmt,
                           qt_pack_fp8x4<FP8 == 2>(qt_u2f(r.z << 16), qt_u2f(r.z & 0xFFFF0000u), qt_u2f(r.w << 16), qt_u2f(r.w & 0xFFFF0000u))};
         }
     }
-    if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+    if constexpr (OBS) block_amax_commit<BLOCK>(amax, amax_out);
 }
 
 // ---- microscaling: one scale per block of `bs` consecutive elements of the last axis -----------------
@@ -1006,6 +1060,11 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
                 return launch_status();
             }
 #endif
+            if (IO == kIoBf16 && nv <= kRowsDirectMaxVecs) {           // short pass: the table where it lies (fq_rows_direct_kernel)
+                if (amax) fq_rows_direct_kernel<IO, true, 1024><<<grid_for(nv, 1024, 2), 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                else fq_rows_direct_kernel<IO, false, 256><<<grid_for(nv, 256, 8), 256, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                return launch_status();
+            }
             unsigned grid = grid_for(nv, (size_t)kAluBlock * kUnroll, row_blocks ? row_blocks : 8);
             if (amax)
                 fq_kernel<IO, kFmtRows, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
@@ -1077,7 +1136,9 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
         }
 #endif
         unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, g_blocks_per_cu);
-        if (amax)
+        if (amax && nvec <= kRowsDirectMaxVecs)     // observed short pass: a quarter of the workgroups, i.e. of the same-address atomics
+            fq_kernel<IO, KIND, true, 1024><<<grid_for(nvec, 1024, 2), 1024, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+        else if (amax)
             fq_kernel<IO, KIND, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
         else
             fq_kernel<IO, KIND, false, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
@@ -1280,7 +1341,9 @@ int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, lo
     hipStream_t st = (hipStream_t)stream;
 #define QT_ROWS(K)                                                                           \
     do {                                                                                     \
-        if (amax) fq_rows_kernel<K, true><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);  \
+        if (amax && a.nvec <= kRowsDirectMaxVecs)                                            \
+            fq_rows_kernel<K, true, 0, 1024><<<grid_for(a.nvec, 1024, 2), 1024, 0, st>>>(a, *fmt, lut, scale, amax);  \
+        else if (amax) fq_rows_kernel<K, true><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);  \
         else fq_rows_kernel<K, false><<<grid, 256, 0, st>>>(a, *fmt, lut, scale, amax);      \
     } while (0)
     switch (fmt->kind) {

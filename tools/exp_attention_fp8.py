@@ -76,6 +76,28 @@ def main():
             print("library route unavailable"); continue
         t1, tc = timeit(one_launch), timeit(chain)
         tv, ta, tn = timeit(vpass_t), timeit(core), timeit(lambda: core(False))
+        if mask is not None and B == 1 and S == 1024:
+            # the call as the model issues it: the output projection's fake-quantizer on the epilogue, the mask's regularity as a device
+            # flag; and the same call with a large GEMM-like stream of other work in between (cold caches, sustained clocks)
+            out8 = torch.empty(B, S, H, D, dtype=torch.uint8, device=DEV)
+            rl = torch.empty(S + 1, dtype=torch.int32, device=DEV)
+            _native.check(L.qt_mask_row_live_checked(mask.data_ptr(), S, S, S, rl.data_ptr(), rl.data_ptr() + 4 * S, st()), "live")
+
+            def as_issued():
+                _native.check(L.qt_attention_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), 0, mp, 0, 0, S, rl.data_ptr(), 0, 0, 1, 0,
+                                                 rl.data_ptr() + 4 * S, out.data_ptr(), out8.data_ptr(), ctypes.byref(fmt), B, H, S, S, D, scaling,
+                                                 st()), "attn")
+            big_a = torch.randn(4096, 4096, device=DEV).bfloat16()
+            big_b = torch.randn(4096, 8192, device=DEV).bfloat16()
+
+            def busy():
+                torch.mm(big_a, big_b)
+
+            def busy_then_attn():
+                busy(); as_issued()
+            ti, tb, tba = timeit(as_issued), timeit(busy), timeit(busy_then_attn)
+            print(f"    as issued by the model (epilogue codes, device flag): {ti:6.1f} us; behind a 275-GFLOP bf16 GEMM: {tba - tb:6.1f} us "
+                  f"(GEMM alone {tb:6.1f})", flush=True)
         print(f"B{B} H{H} S{S} D{D} {'causal' if causal else 'no mask'}: one launch {t1:6.1f} us (value codes {tv:5.1f} + core {ta:6.1f}; core without row extents {tn:6.1f})"
               f" | chain {tc:6.1f} us", flush=True)
 
