@@ -46,15 +46,9 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
     __shared__ float s_part[kNormThreads / 64];
     // FQ == 3: the consumers' stateless TABLE-format fake-quantizer in its row form (qt_format.p1 bit 0; `map` = the 65 536 entries with
     // the row words behind them, csrc/qt_device.h Rounder<kFmtRows>); bf16 values only
-    Rounder<kFmtRows> rnd{fmt, nullptr, map};
-    if constexpr (FQ == 3) {
-        __shared__ uint4 s_rows[512];
-        const uint4 *gr = (const uint4 *)(map + QT_MAP_ENTRIES);
-        const int nrows = (fmt.p1 & 2) ? 512 : 256;
-        for (int i = threadIdx.x; i < nrows; i += kNormThreads) s_rows[i] = gr[i];
-        rnd.lds = (const uint16_t *)s_rows;
-        __syncthreads();                                // (the sum may go through the map before the row reduction's barrier)
-    }
+    // (the 4 - 8 KiB row table is read where it lies, behind the map in global memory: a row of the tensor is two or three vectors per
+    // lane, and staging the table into LDS put a load, a store and a barrier in front of them)
+    Rounder<kFmtRows> rnd{fmt, FQ == 3 ? map + QT_MAP_ENTRIES : nullptr, map};
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
     uint4 v[kNormMaxVec];
