@@ -74,7 +74,8 @@ if __name__ == "__main__":
 
 
 def abi_level():
-    """The pieces of one observed call at the C ABI: the pass with / without the amax slot, the scale update alone."""
+    """The pieces of one observed call at the C ABI: the pass with / without the amax slot, with the slot zeroed before every pass (the
+    state a training step presents: round 4 found the atomics' queue only there), the scale update alone."""
     import ctypes
     from quantized_training import _native
     L = _native.lib()
@@ -94,8 +95,16 @@ def abi_level():
         def upd():
             s = ctypes.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
             _native.check(L.qt_scale_update(hist.data_ptr(), 10, 1, scale.data_ptr(), 127.0, 0, s), "upd")
+        def run_fresh():
+            # what a training step sees: the slot was zeroed since the last pass (here by a 4-byte memset node), so every workgroup can
+            # raise the running maximum and issues its atomicMax; `run(True)` alone leaves the maximum in place and nobody does
+            hist[:1].zero_()
+            run(True)
+
+        def zero_only():
+            hist[:1].zero_()
         print(f"ABI {shape}: pass without observer {graph_time(lambda: run(False)):.2f} us   with amax slot {graph_time(lambda: run(True)):.2f} us   "
-              f"scale update alone {graph_time(upd):.2f} us", flush=True)
+              f"with a freshly zeroed slot {graph_time(run_fresh) - graph_time(zero_only):.2f} us   scale update alone {graph_time(upd):.2f} us", flush=True)
 
 
 if __name__ == "__main__" and os.environ.get("ABI", "1") == "1":
