@@ -95,6 +95,17 @@ def main():
 
             def busy_then_attn():
                 busy(); as_issued()
+            # inputs rewritten by another kernel in front of every launch (as the rotary kernel does in the window): are the core's reads
+            # served from the writer's L2, or from the Infinity Cache?
+            q_src, k_src, v_src = q8.clone(), k8.clone(), vt8.clone()
+
+            def rewrite():
+                q8.copy_(q_src); k8.copy_(k_src); vt8.copy_(v_src)
+
+            def rewrite_then_attn():
+                rewrite(); as_issued()
+            tr, tra = timeit(rewrite), timeit(rewrite_then_attn)
+            print(f"    behind kernels that rewrite q / k / v codes: {tra - tr:6.1f} us (the copies alone {tr:6.1f})", flush=True)
             ti, tb, tba = timeit(as_issued), timeit(busy), timeit(busy_then_attn)
             print(f"    as issued by the model (epilogue codes, device flag): {ti:6.1f} us; behind a 275-GFLOP bf16 GEMM: {tba - tb:6.1f} us "
                   f"(GEMM alone {tb:6.1f})", flush=True)
