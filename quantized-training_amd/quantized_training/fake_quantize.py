@@ -194,7 +194,8 @@ def materialize_lazy(t):
     if _LAZY:
         ref = _LAZY.get(t.data_ptr())
         base = ref() if ref is not None else None
-        if base is not None and base is not t and base.__dict__.get("_qt_lazy", False) and base.numel() == t.numel() and t.is_contiguous():
+        if (base is not None and base is not t and base.__dict__.get("_qt_lazy", False) and base.device == t.device and base.dtype == t.dtype
+                and base.numel() == t.numel() and t.is_contiguous()):
             # a view of a lazy tensor (same storage, same extent): decode through the owner
             stamped = getattr(t, "_qt_ver", None) == t._version
             materialize_lazy(base)
