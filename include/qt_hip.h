@@ -591,6 +591,15 @@ int qt_rope_map_value(const uint16_t *q_dev, const uint16_t *k_dev, const uint16
                       uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
                       const qt_format *fmt, const uint16_t *map_dev, int inner_q, int inner_k, const uint16_t *v_dev, uint16_t *vt_dev,
                       long v_stride_b, long v_stride_h, long v_stride_k, void *stream);
+/* qt_rope_map_value with a third independent job of the same format in the launch: y = fq(W) for a weight tensor (w_elems bf16 elements,
+ * w_elems % 8 == 0, both pointers 16-byte aligned) -- the `weight_fake_quant(self.weight)` call of a Linear that runs as weight pass +
+ * library GEMM right behind the attention core (modules/qat/linear.py:40-41: LLaMA's o_proj), HBM-bound where the other two jobs wait
+ * on latency.  w_elems == 0: qt_rope_map_value. */
+int qt_rope_map_value_weight(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *cos_dev, const uint16_t *sin_dev, uint16_t *q_out_dev,
+                             uint16_t *k_out_dev, long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride,
+                             const qt_format *fmt, const uint16_t *map_dev, int inner_q, int inner_k, const uint16_t *v_dev, uint16_t *vt_dev,
+                             long v_stride_b, long v_stride_h, long v_stride_k, const uint16_t *w_dev, uint16_t *wq_dev, size_t w_elems,
+                             void *stream);
 /* qt_rope_fq_value for PT2E-prepared graphs (wikitext.py:60-136 exports HF's apply_rotary_pos_emb as q * cos + rotate_half(q) * sin and
  * the annotator fake-quantizes the add's earlier operand): out = fmt(inner(bf16(x * cos)) + bf16(rotate_half(x) * sin)) with inner_q /
  * inner_k stateless closed-form FP formats (NULL: none -- exactly qt_rope_fq_value).  v_dev may be NULL (no value job). */

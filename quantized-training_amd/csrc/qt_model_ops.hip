@@ -361,8 +361,18 @@ struct ValueRowsArgs {
     long sb, sh, sk, Sk;
     int H, nkb;
 };
+// A third independent job of the same format for the same launch: the fake-quant pass of a WEIGHT -- the output projection's, where that
+// Linear runs as weight pass + library GEMM.  HBM-bound (26 M elements in and out for a 5120 x 5120 weight) next to two latency-bound
+// jobs: its workgroups come first in the grid so that its stream is under way while the rotary workgroups wait on theirs.
+struct WeightPassArgs {
+    const uint4 *w;
+    uint4 *wq;
+    size_t nvec;
+    unsigned blocks;
+};
 
-__global__ __launch_bounds__(256) void rope_map_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueRowsArgs v, unsigned rope_blocks, unsigned tpb) {
+__global__ __launch_bounds__(256) void rope_map_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueRowsArgs v, WeightPassArgs wp, unsigned rope_blocks,
+                                                             unsigned tpb) {
     __shared__ __attribute__((aligned(16))) uint16_t tile[value_rows_tile_elems<64>()];
     __shared__ uint4 s_rows[512];
     {
@@ -372,14 +382,38 @@ __global__ __launch_bounds__(256) void rope_map_value_kernel(RopeFqArgs q, RopeF
         __syncthreads();
         q.rows_lds = k.rows_lds = (const uint16_t *)s_rows;
     }
-    if (blockIdx.x < rope_blocks) {
+    if (blockIdx.x < wp.blocks) {
+        const Rounder<kFmtRows> rnd{q.fmt, (const uint16_t *)s_rows, q.map};
+        // two workgroups per CU with four loads in flight per lane: the bytes in flight of the stand-alone pass (eight workgroups of one
+        // load), in a third of the workgroup slots -- the rest are the rotary and value jobs', which need them to cover their latency
+        constexpr int kU = 4;
+        const size_t stride = (size_t)wp.blocks * 256;
+        for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < wp.nvec; i0 += stride * kU) {
+            uint4 a[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (i0 + u * stride < wp.nvec) a[u] = wp.w[i0 + u * stride];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (i0 + u * stride < wp.nvec) {
+                    const uint32_t in[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+                    uint32_t o[4];
+                    fq_rows_words<4, false>(in, o, rnd);
+                    wp.wq[i0 + u * stride] = uint4{o[0], o[1], o[2], o[3]};
+                }
+            }
+        }
+        return;
+    }
+    const unsigned bid = blockIdx.x - wp.blocks;
+    if (bid < rope_blocks) {
         const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;
-        for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)rope_blocks * tpb) {
+        for (size_t bs = (size_t)bid * tpb; bs < tokens; bs += (size_t)rope_blocks * tpb) {
             rope_fq_token(q, bs, tpb, tokens);
             rope_fq_token(k, bs, tpb, tokens);
         }
     } else {
-        const unsigned vb = blockIdx.x - rope_blocks;
+        const unsigned vb = bid - rope_blocks;
         const Rounder<kFmtRows> rnd{q.fmt, (const uint16_t *)s_rows, q.map};
         value_t_rows_block<64>(tile, rnd, v.v, v.vt, v.H, v.Sk, v.sb, v.sh, v.sk, (long)(vb / (unsigned)v.nkb), (int)(vb % (unsigned)v.nkb), (int)threadIdx.x);
     }
@@ -1009,14 +1043,15 @@ int qt_rope_map_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *cos, 
     return launch_status();
 }
 
-int qt_rope_map_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
-                      long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
-                      int inner_q, int inner_k, const uint16_t *v, uint16_t *vt, long v_stride_b, long v_stride_h, long v_stride_k, void *stream) {
+static int rope_map_value_launch(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,
+                                 long B, long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt,
+                                 const uint16_t *map, int inner_q, int inner_k, const uint16_t *v, uint16_t *vt, long v_stride_b, long v_stride_h,
+                                 long v_stride_k, const uint16_t *w, uint16_t *wq, size_t w_elems, void *stream) {
     if (B * S * D == 0) return QT_OK;
     if (!q || !k || !cos || !sin || !q_out || !k_out || !v || !vt || B < 0 || S < 0 || Hq < 0 || Hk < 1 || !map_format_ok(fmt, map)) return QT_ERR_BAD_ARG;
-    if (D != kValueRowsD || S % 128 != 0 || B * Hk > 65535) return QT_ERR_BAD_ARG;
+    if (D != kValueRowsD || S % 128 != 0 || B * Hk > 65535 || (w_elems != 0 && (!w || !wq))) return QT_ERR_BAD_ARG;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)v | (uintptr_t)vt) & 15u) ||
-        ((v_stride_b | v_stride_h | v_stride_k) & 7))
+        ((v_stride_b | v_stride_h | v_stride_k) & 7) || (w_elems != 0 && ((((uintptr_t)w | (uintptr_t)wq) & 15u) || (w_elems & 7))))
         return QT_ERR_UNALIGNED;
     if (q_row_stride < Hq * D || k_row_stride < Hk * D || (q_row_stride | k_row_stride) % 8) return QT_ERR_BAD_ARG;
     if (Hq * D / 8 > 0xFFFFFFFFl || Hk * D / 8 > 0xFFFFFFFFl || B > 0x7FFFFFFFl || S > 0x7FFFFFFFl) return QT_ERR_BAD_ARG;
@@ -1027,9 +1062,30 @@ int qt_rope_map_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos,
     size_t blocks = ((size_t)B * (size_t)S + tpb - 1) / tpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     ValueRowsArgs av{v, vt, v_stride_b, v_stride_h, v_stride_k, S, (int)Hk, (int)(S / 64)};
-    const unsigned total = (unsigned)blocks + (unsigned)(B * Hk * (S / 64));
-    rope_map_value_kernel<<<total, 256, 0, (hipStream_t)stream>>>(aq, ak, av, (unsigned)blocks, tpb);
+    WeightPassArgs aw{(const uint4 *)w, (uint4 *)wq, w_elems / 8, 0};
+    if (aw.nvec) {
+        size_t wb = (aw.nvec + 256 * 4 - 1) / (256 * 4);                  // four vectors per lane and trip, at most two workgroups per CU
+        if (wb > 256 * 2) wb = 256 * 2;
+        aw.blocks = (unsigned)wb;
+    }
+    const unsigned total = aw.blocks + (unsigned)blocks + (unsigned)(B * Hk * (S / 64));
+    rope_map_value_kernel<<<total, 256, 0, (hipStream_t)stream>>>(aq, ak, av, aw, (unsigned)blocks, tpb);
     return launch_status();
+}
+
+int qt_rope_map_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
+                      long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
+                      int inner_q, int inner_k, const uint16_t *v, uint16_t *vt, long v_stride_b, long v_stride_h, long v_stride_k, void *stream) {
+    return rope_map_value_launch(q, k, cos, sin, q_out, k_out, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt, map, inner_q, inner_k, v, vt,
+                                 v_stride_b, v_stride_h, v_stride_k, nullptr, nullptr, 0, stream);
+}
+
+int qt_rope_map_value_weight(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out, long B,
+                             long S, long Hq, long Hk, long D, long q_row_stride, long k_row_stride, const qt_format *fmt, const uint16_t *map,
+                             int inner_q, int inner_k, const uint16_t *v, uint16_t *vt, long v_stride_b, long v_stride_h, long v_stride_k,
+                             const uint16_t *w, uint16_t *wq, size_t w_elems, void *stream) {
+    return rope_map_value_launch(q, k, cos, sin, q_out, k_out, B, S, Hq, Hk, D, q_row_stride, k_row_stride, fmt, map, inner_q, inner_k, v, vt,
+                                 v_stride_b, v_stride_h, v_stride_k, w, wq, w_elems, stream);
 }
 
 int qt_rope_fq_inner_value(const uint16_t *q, const uint16_t *k, const uint16_t *cos, const uint16_t *sin, uint16_t *q_out, uint16_t *k_out,

@@ -126,6 +126,8 @@ SIGNATURES = {
     "qt_rope_map_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _P, c_int, c_int, _P]),
     "qt_rope_map_value": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _P, c_int, c_int, _P, _P,
                                   c_long, c_long, c_long, _P]),
+    "qt_rope_map_value_weight": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT, _P, c_int, c_int, _P,
+                                         _P, c_long, c_long, c_long, _P, _P, c_size_t, _P]),
     "qt_add_rmsnorm_sumfq_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, _FMT, _FMT, _P]),
     "qt_rope_fq_inner_value": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, _FMT,
                                       _FMT, _FMT, _FMT, _P, _P, c_long, c_long, c_long, _FMT, _P]),

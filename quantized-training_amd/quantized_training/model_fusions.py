@@ -248,11 +248,18 @@ def rope_map(q, k, cos, sin, fq_q, fq_k, inner_q=False, inner_k=False, value_job
         from . import fused
         attn, value, fq_v = value_job
         vt = torch.empty((B, Hk, D, S), dtype=torch.bfloat16, device=q.device)
-        _native.check(_native.lib().qt_rope_map_value(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
-                                                      B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
-                                                      int(bool(inner_q)), int(bool(inner_k)), value.data_ptr(), vt.data_ptr(), value.stride(0),
-                                                      value.stride(1), value.stride(2), _stream_ptr(q)), "qt_rope_map_value")
+        wjob = _o_proj_weight_job(attn, q, fq_q, qmap)
+        W, wq = (wjob[1], torch.empty_like(wjob[1])) if wjob is not None else (None, None)
+        _native.check(_native.lib().qt_rope_map_value_weight(
+            q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(), B, S, Hq, Hk, D, _row_stride(q),
+            _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(), int(bool(inner_q)), int(bool(inner_k)), value.data_ptr(), vt.data_ptr(),
+            value.stride(0), value.stride(1), value.stride(2), W.data_ptr() if W is not None else None, wq.data_ptr() if wq is not None else None,
+            W.numel() if W is not None else 0, _stream_ptr(q)), "qt_rope_map_value_weight")
         attn.__dict__["_qt_vt_rows"] = (fused.value_key(value), fq_v, vt)
+        if wjob is not None:
+            # the output projection's weight_fake_quant(W) call finds its result (valid for the very next call on this weight at this
+            # version, counted there: fake_quantize.py, `_qt_pre`)
+            wjob[0].__dict__["_qt_pre"] = (W.data_ptr(), W._version, wq)
         return _mark_done(q_out, [fq_q]), _mark_done(k_out, [fq_k])
     _native.check(_native.lib().qt_rope_map_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_out.data_ptr(), k_out.data_ptr(),
                                                  B, S, Hq, Hk, D, _row_stride(q), _row_stride(k), ctypes.byref(fmt), qmap.data_ptr(),
@@ -860,6 +867,30 @@ def _fp8_attention_plan(attn, q, qk_fqs):
     if value.dtype != torch.bfloat16 or any(st % 8 for st in value.stride()[:3]) or value.data_ptr() % 16:
         return None
     return attn, value, holder["1"]
+
+
+def _o_proj_weight_job(attn, q, fq_q, qmap):
+    """(weight fake-quantizer, W) when the output projection behind this attention block will run as weight pass + library GEMM with a
+    stateless table-format weight fake-quantizer of the rotary launch's format: that pass then rides in the launch (qt_rope_map_value_weight)
+    -- HBM-bound work beside two latency-bound jobs -- else None."""
+    from . import fused
+    from .modules.qat.linear import Linear as QATLinear
+    proj = getattr(attn, "o_proj", None)
+    if (os.environ.get("QT_ROPE_WEIGHT_PASS", "1") == "0" or not isinstance(proj, QATLinear) or type(proj).forward is not QATLinear.forward
+            or torch.is_grad_enabled() or fused._WEIGHT_CACHE["on"] or not fused._fqt_weight_ok(proj)):
+        return None
+    fqw, W = proj.weight_fake_quant, proj.weight
+    if str(fqw.dtype) != str(fq_q.dtype) or fqw._forward_hooks or fqw._forward_pre_hooks:
+        return None
+    if W.dtype != torch.bfloat16 or not W.is_contiguous() or W.numel() % 8 or W.data_ptr() % 16 or W.device != q.device:
+        return None
+    fqw._move_to(q.device)
+    if fqw.qmap is None or fqw.qmap.data_ptr() != qmap.data_ptr():             # one cached device map per dtype: the same table, or no deal
+        return None
+    B, H, S, D = q.shape
+    if fused.fqt_gemm_mode() != "0" and fused.fqt_route_is_fused(B * S, [W.shape[0]], W.shape[1], q.device):
+        return None                                                             # the value-map GEMM converts the weight itself
+    return fqw, W
 
 
 def _rows_attention_plan(attn, q, qk_fqs):

@@ -837,6 +837,20 @@ def test_rope_map_value_is_the_two_launches(nv, B, S, H, dtype):
         outs.append((qo, ko, vt))
     for a, b in zip(*outs):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # ... and with a weight's fake-quant pass as the launch's third job (qt_rope_map_value_weight): the same three tensors, and fq(W) bit for
+    # bit the oracle's value map (all 65 536 patterns in front, a ragged count of vectors behind them)
+    W = (torch.randn(H * D + 3, 5 * 8 + H * D, device="cuda", generator=g) * 0.1).bfloat16().contiguous()
+    W.view(torch.int16).view(-1)[:65536] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16)
+    wq = torch.empty_like(W)
+    qo3, ko3 = torch.empty_like(outs[0][0]), torch.empty_like(outs[0][1])
+    vt3 = torch.empty_like(outs[0][2])
+    nv.check(L.qt_rope_map_value_weight(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo3.data_ptr(), ko3.data_ptr(), B, S, H, H, D, rs,
+                                        rs, ctypes.byref(f), m.data_ptr(), 0, 0, v.data_ptr(), vt3.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+                                        W.data_ptr(), wq.data_ptr(), W.numel(), stream()), "qt_rope_map_value_weight")
+    for a, b in zip((qo3, ko3, vt3), outs[0]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    exp_w = o.canon_nan16(o.vmap_bf16(host_u16(W.view(torch.int16)), o.get_quantization_map(dtype)))
+    assert np.array_equal(o.canon_nan16(host_u16(wq.view(torch.int16))), exp_w)
     qo, ko, vt = outs[0]
     args = (q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr())
     tail = (ctypes.byref(f), m.data_ptr(), 0, 0, v.data_ptr(), vt.data_ptr(), v.stride(0), v.stride(1), v.stride(2), stream())
