@@ -130,6 +130,17 @@ def test_row_form_reproduces_the_value_map(key):
     assert np.array_equal(fl, expect_flag)
     same = (got == m) | (((got | m) & 0x7FFF) == 0)
     assert same[~fl].all(), np.flatnonzero(~same & ~fl)[:8]
+    # a flagged row still answers for its FIRST input (mantissa 0; row 0: exact zero, the commonest input of all) -- {0, 1, y0, y0} with
+    # y0 the map's value there -- unless that value is a NaN or carries a sign, which a clamp cannot produce: {1, 1, 0, 0}
+    rows = np.ctypeslib.as_array(rp.row).reshape(512, 4).astype(np.uint32)
+    for r in np.flatnonzero(flagged):
+        first = int(m[r << 7])
+        usable = (first & 0x7FFF) <= 0x7F80 and not (first & 0x8000)
+        assert rows[r, 1] == 1
+        if usable:
+            assert rows[r, 0] == 0 and rows[r, 2] == rows[r, 3] == (first << 16), (key, r)
+        else:
+            assert rows[r, 0] == 1, (key, r)
     # the rows weights live in (2^-40 .. 2^15) are all covered for the formats of BASELINE.json and the README tables
     if key in ("posit8_0", "posit8_1", "posit8_2", "int8", "int4", "e4m3", "e5m2", "fp8_e4m3", "fp6_e3m2", "fp6_e2m3", "fp4_e2m1"):
         assert not flagged[127 - 40:127 + 15].any()
