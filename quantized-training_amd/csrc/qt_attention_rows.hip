@@ -20,8 +20,8 @@
 //     statistics are lane-local plus two shuffles, and a lane's quantized probabilities of two neighbouring tiles ARE its B
 //     fragment of v_mfma_f32_16x16x32_bf16 for P.V if V arrives transposed, [D][Sk], with slot 8 g + 4 h + e <-> key 16 h + 4 g + e
 //     inside every 32-key chunk -- qt_value_t_rows writes that image while fake-quantizing V (this is the `fq_v` call);
-//   * K blocks and V^T blocks (32 KiB each) come by LDS-DMA into a ring of two pairs (128 KiB), one pair in flight ahead of the
-//     arithmetic, one barrier per pair; 256-byte rows with the 16-byte chunk index XORed with the row, so every fragment read
+//   * K blocks and V^T blocks (32 KiB each) come by LDS-DMA into a ring of three (96 KiB; behind it 32 KiB of the value map: the
+//     probabilities' fake-quantizer as a gather), two blocks in flight ahead of the arithmetic, one barrier per block; 256-byte rows with the 16-byte chunk index XORed with the row, so every fragment read
 //     (sixteen rows x one chunk per lane group of ds_read_b128) is conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,7 +41,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 128, kMaxBlocks = 8, kD = 128;
 constexpr int kRowB = 256;                       // bytes of a K row (128 d) and of a V^T row segment (128 keys)
 constexpr int kBuf = kBlock * kRowB;             // one block: 32 KiB
-constexpr int kRing = 4 * kBuf;                  // four blocks
+constexpr int kSlots = 3;                        // ring slots: the block being multiplied and two in flight
+constexpr int kProbLut = 32768;                  // the map's entries 0 .. 0x3FFF (bf16 patterns of [0, 2)): the probabilities' fake-quantizer as a gather
+constexpr int kRing = kSlots * kBuf + kProbLut;  // three blocks | the probability table
 constexpr int kTbl = 8192;                       // the row table (512 rows x 16 B; 256 used by maps indexed by exponent only)
 constexpr int kLds = kRing + kTbl + 2 * 2 * 64 * 4;
 
@@ -189,6 +191,11 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     auto stamp = [](int) __attribute__((always_inline)) {};
 #endif
     stamp(0);
+    // the probabilities' fake-quantizer as a table: the map's first 16 384 entries (32 KiB: every bf16 pattern of [0, 2), a probability is
+    // in [0, 1]) by LDS-DMA behind the ring, long before sweep 2 reads them -- one 2-byte gather per probability instead of the row form's
+    // ~15 instructions (the stamps: sweep 2 was 2 300 cycles per block of a 55 k-cycle workgroup, all of it vector issue)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16((const uint8_t *)a.lut + (4 * w + i) * 1024, (uint32_t)l * 16u, l0 + kSlots * kBuf + (4 * w + i) * 1024);
     // ---- DMA geometry.  A block is 32 pieces of 1 KiB (4 rows x 256 bytes); wave w issues pieces 4 w .. 4 w + 3 of every block: piece
     // pb = 4 w + i holds rows 4 pb .. 4 pb + 3.  Lane l lands at row 4 pb + (l >> 4), 16-byte slot l & 15 of the LDS image, which must hold
     // logical chunk (l & 15) ^ (row & 15); (row & 15) = 4 i + (l >> 4), so four lane-offset registers per operand serve every piece, the
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     const uint8_t *kbase = (const uint8_t *)a.k + (long)bh * a.Sk * kRowB;
     const uint8_t *vbase = (const uint8_t *)a.vt + (long)bh * kD * a.Sk * 2;
     auto issue_k = [&](int kb) __attribute__((always_inline)) {
-        const uint32_t dst0 = l0 + (kb & 3) * kBuf;
+        const uint32_t dst0 = l0 + (kb % kSlots) * kBuf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pb = 4 * w + i;
@@ -211,18 +218,16 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
         }
     };
     auto issue_v = [&](int kb) __attribute__((always_inline)) {
-        const uint32_t dst0 = l0 + (kb & 3) * kBuf;
+        const uint32_t dst0 = l0 + (kb % kSlots) * kBuf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pb = 4 * w + i;
             dma16(vbase + ((long)(4 * pb) * a.Sk + (long)kb * kBlock) * 2, voff[i], dst0 + pb * 1024);
         }
     };
-    // block kb is awaited with the requests of up to two later blocks (four per wave each) still in flight
+    // block kb is awaited with the requests of the next block (four per wave) still in flight
     auto await_block = [&](int kb) __attribute__((always_inline)) {
-        const int ahead = nlive - 1 - kb;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (nlive - 1 - kb >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // Q^T fragments (B operand): lane (r, g) holds Q[query r][32 ks + 8 g + j]
@@ -241,12 +246,11 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
 
     float e[kIter][8][4];                                                  // this wave's part of the strip: logits, then their exponentials
     float mx = -INFINITY;
-    // ---- sweep 1: scores.  Three blocks are in flight ahead of the one being multiplied; at the barrier of step kb every wave is done
-    // with block kb - 1, whose slot then takes block kb + 3
+    // ---- sweep 1: scores.  Two blocks are in flight ahead of the one being multiplied (the stamps put the block waits at ~180 cycles:
+    // depth is not what paces the kernel); at the barrier of step kb every wave is done with block kb - 1, whose slot then takes block kb + 2
     stamp(1);
     issue_k(0);
     if (nlive > 1) issue_k(1);
-    if (nlive > 2) issue_k(2);
 #pragma unroll
     for (int kb = 0; kb < kMaxBlocks; ++kb) {
         if (kb < nlive) {
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
             stamp(2 + 3 * kb);
             __builtin_amdgcn_s_barrier();
             stamp(3 + 3 * kb);
-            if (kb + 3 < nlive) issue_k(kb + 3);
+            if (kb + 2 < nlive) issue_k(kb + 2);
             const int key0 = kb * kBlock + 64 * grp, nt = tiles_of(kb);
-            const uint8_t *blk = lds + (kb & 3) * kBuf;
+            const uint8_t *blk = lds + (kb % kSlots) * kBuf;
             float (*ev)[4] = &e[kb >> 1][4 * (kb & 1)];
             if (nt == 0) {
 #pragma unroll
@@ -279,7 +283,6 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
     stamp(27);
     issue_v(0);
     if (nlive > 1) issue_v(1);
-    if (nlive > 2) issue_v(2);
     // the two groups' maxima meet in LDS
     float *stat = (float *)(lds + kRing + kTbl);                           // [max, sum][2 groups][64 rows]
     if (g == 0) stat[grp * 64 + wq * 16 + r] = mx;
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
             stamp(29 + 3 * kb);
             __builtin_amdgcn_s_barrier();
             stamp(30 + 3 * kb);
-            if (kb + 3 < nlive) issue_v(kb + 3);
+            if (kb + 2 < nlive) issue_v(kb + 2);
             if (tiles_of(kb) != 0) {
-                const uint8_t *blk = lds + (kb & 3) * kBuf;
+                const uint8_t *blk = lds + (kb % kSlots) * kBuf;
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
                     const int chunk0 = 4 * (2 * grp + c2) + g;              // 16-byte chunk of this lane's slots inside the 256-byte row
@@ -346,7 +349,16 @@ __global__ __launch_bounds__(512, 1) void attention_rows_split_kernel(Args a) {
                         pb[2 * hh] = pack_bf16x2(v[0] * inv, v[1] * inv);  // probabilities, bf16
                         pb[2 * hh + 1] = pack_bf16x2(v[2] * inv, v[3] * inv);
                     }
-                    fq_rows_words<4, true>(pb, pw, rnd);                    // fq_p
+                    {                                                       // fq_p
+                        const uint16_t *plut = (const uint16_t *)(lds + kSlots * kBuf);
+                        const uint32_t beyond = (pb[0] | pb[1] | pb[2] | pb[3]) & 0xC000C000u;   // a pattern >= 0x4000: not a probability (NaN inputs)
+                        if (__builtin_expect(beyond == 0u, 1)) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)plut[pb[i] & 0xFFFFu] | ((uint32_t)plut[pb[i] >> 16] << 16);
+                        } else {
+                            fq_rows_words<4, true>(pb, pw, rnd);            // the row form (and through it the map) takes anything
+                        }
+                    }
                     const v8s pf = __builtin_bit_cast(v8s, u32x4{pw[0], pw[1], pw[2], pw[3]});
 #pragma unroll
                     for (int dt = 0; dt < kDT; ++dt)
