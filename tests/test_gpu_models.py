@@ -377,6 +377,15 @@ def test_codes_only_handover_is_invisible(monkeypatch):
             assert bool(y.__dict__.get("_qt_lazy", False)) == lazy
             outs.append(dense(y.view(-1, cfg.intermediate_size)))
         assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+        # somebody hooks the producing module: its forward hook must see VALUES, so the producer writes them (no codes-only there)
+        seen = []
+        handle = layer.intermediate.register_forward_hook(lambda mod, args, out: seen.append(out))
+        before = lazy_made["n"]
+        o = m(ids, attention_mask=att)
+        handle.remove()
+        assert len(seen) == 1 and not seen[0].__dict__.get("_qt_lazy", False) and torch.isfinite(seen[0].float()).all()
+        assert lazy_made["n"] - before == 3 * cfg.num_hidden_layers - 1          # every other producer still hands codes only
+        assert torch.equal(o.start_logits.float(), ref[0])
 
 
 def test_mobilebert_blocks_on_device(monkeypatch):
