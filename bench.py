@@ -148,7 +148,7 @@ def profiled_traffic(key):
     """HBM bytes per launch of the roofline kernels from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE x 2 on gfx950 as the microarchitecture guide prescribes).  Collected by
     tools/gpu_session_prof.sh on the same launch, NOT in this run: the JSON names the file next to the number."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -275,23 +275,91 @@ def fused_gemm_leg(device):
     if run(0) != 0:
         return None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for iters in (pool, 5 * pool):
+    for i in range(pool):                                     # warm-up
+        run(i)
+    samples = []
+    for _ in range(3):                                        # three timed repeats of 5 x pool launches: the median is reported
         e0.record()
-        for i in range(iters):
+        for i in range(5 * pool):
             run(i)
         e1.record()
         e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+        samples.append(e0.elapsed_time(e1) / (5 * pool))
+    ms = sorted(samples)[1]
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
     nbytes = N * K * 2 + M * K + M * N * 2
     gbs = nbytes / (ms * 1e-3) / 1e9
     del x8, w, y
     torch.cuda.empty_cache()
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_PEAK_TFLOPS, 4),
-            "ms_per_launch": round(ms, 5), "flops_per_launch": 2 * M * N * K,
+            "ms_per_launch": round(ms, 5), "ms_per_launch_min": round(min(samples), 5), "ms_per_launch_max": round(max(samples), 5),
+            "timing": "median of 3 x 40 launches, HIP events on the launch stream", "flops_per_launch": 2 * M * N * K,
             "kernel": "linear_fq8r_kernel: FP8 E4M3 GEMM 1024x11008x4096 with the bf16 weight fake-quantized in its operand path",
             "hbm_view": {"algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBPS, 4)}}
+
+
+def linears_in_window_leg(model, device, M):
+    """Every Linear launch of one headline window -- 32 x (q / k / v as one launch, o, gate + up + SiLU * up as one launch, down) and the lm
+    head -- on the model's own weights in the window's order, back to back in one hipGraph WITHOUT the kernels between them: the
+    flop-weighted matrix-core fraction of the window's GEMMs (the single-shape `roofline.frac` is its widest member alone)."""
+    from quantized_training import fused
+    try:
+        layers = model.model.layers
+        K = model.config.hidden_size
+        I = model.config.intermediate_size
+        x8 = torch.randn(M, K, device=device).to(torch.float8_e4m3fn)
+        h8 = torch.randn(M, I, device=device).to(torch.float8_e4m3fn)
+        flops = 0
+
+        def forward():
+            nonlocal flops
+            flops = 0
+            for l in layers:
+                a, m = l.self_attn, l.mlp
+                ok = fused.hip_fq8_linear_or_none(x8, [a.q_proj, a.k_proj, a.v_proj]) is not None
+                ok = ok and fused.hip_fq8_linear_or_none(x8, [a.o_proj]) is not None
+                ok = ok and fused.hip_mlp_fq8_or_none(x8, m.gate_proj, m.up_proj, m.down_proj.activation_pre_process["0"], codes_only=True) is not None
+                ok = ok and fused.hip_fq8_linear_or_none(h8, [m.down_proj]) is not None
+                if not ok:
+                    return False
+                flops += 2 * M * K * (a.q_proj.weight.shape[0] + a.k_proj.weight.shape[0] + a.v_proj.weight.shape[0] + K + 3 * I)
+            if fused.hip_fq8_linear_or_none(x8, [model.lm_head]) is None:
+                return False
+            flops += 2 * M * K * model.lm_head.weight.shape[0]
+            return True
+        with torch.no_grad():
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                if not forward():
+                    return None
+            torch.cuda.current_stream(device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                forward()
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            samples = []
+            for _ in range(3):
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                samples.append(e0.elapsed_time(e1))
+        ms = sorted(samples)[1]
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"what": "all Linear launches of one window back to back (model weights, window order, one hipGraph, no other kernels)",
+                "launches": 4 * len(layers) + 1, "flops": flops, "ms": round(ms, 4), "ms_min": round(min(samples), 4), "ms_max": round(max(samples), 4),
+                "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_PEAK_TFLOPS, 4)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def native_library_note():
+    """{} for the product library; names the file when QT_HIP_LIB made the package load another one (tools/ only)."""
+    from quantized_training import _native
+    return {"native_library_override": _native.LIB_PATH} if _native.LIB_OVERRIDDEN else {}
 
 
 def fused_routes():
@@ -633,18 +701,24 @@ def main():
                        "parallelism": f"dp{world} (windows round-robin, metric all_gather only)",
                        "launch": "hipGraph replay" if graph_used else "eager",
                        "valid": bool(full) and not a.cache_eval_weights and not a.dry_run,
-                       "routes": fused_routes()},
+                       "routes": fused_routes(), **native_library_note()},
             "mean_window_nll": float(allnll.double().mean().item()),
             # north_star: elements/s "as absolute and as fraction of HBM roofline" -- SURVEY 8(d)'s 4 B per quantized element
             # (bf16 in + bf16 out) against the HBM peak of the GPUs used
             "fraction_of_hbm_roofline": None if a.dry_run else round(total_elems / el * 4.0 / (HBM_PEAK_GBPS * 1e9 * world), 4),
         }
     if rank == 0:                                   # outside the timed region; the other ranks wait at the barrier below
+        in_window = None
+        if (not a.no_roofline and not a.dry_run and a.route == "eager" and a.weight in ("e4m3", "e5m2") and a.activation == a.weight
+                and a.layers is None and a.model == "llama-2-7b"):
+            in_window = linears_in_window_leg(model, device, a.max_length)
         del model
         if device.type == "cuda":
             torch.cuda.empty_cache()
         if not a.no_roofline:
             out["roofline"] = roofline_leg(device, a.weight, model_shape)
+            if in_window is not None:
+                out["roofline"]["linears_in_window"] = in_window
             if a.weight.split(",")[0] not in ("e4m3", "e5m2") and "qs=" not in a.weight:
                 # every other stateless spec: the widest Linears (q / k / v as one launch, the lm head) run the value map inside a bf16 GEMM
                 leg = fqt_gemm_leg(device, a.weight, a.max_length, [hidden, hidden, hidden], hidden)

@@ -65,6 +65,12 @@ typedef struct qt_format {
 int qt_abi_version(void);
 const char *qt_status_string(int code);
 
+/* *id = the identifier of the stream capture `stream` is recording into, 0 when it is not capturing.  The host side keys scratch that
+ * launches share (the split-K workspace of qt_linear_fqt_ws_bf16, which must be used by ONE ordered sequence
+ * of launches) by (device, stream, capture): every captured graph and every eager stream gets its own.  No reference counterpart:
+ * the reference has no native scratch (modules/qat/linear.py:40-41 allocates through torch). */
+int qt_stream_capture_id(void *stream, unsigned long long *id);
+
 /* ---- A1: value-map builder (host) ------------------------------------------------------
  * Replaces get_quantization_map(dtype)                       fake_quantize.py:31-95
  * (and through it quantize_to_fp8_e4m3/_e5m2 fp8.py:10-67, _quantize_elemwise_core in bf16
@@ -609,17 +615,26 @@ int qt_rope_fq_inner_value(const uint16_t *q_dev, const uint16_t *k_dev, const u
                            const qt_format *inner_k, const uint16_t *v_dev, uint8_t *vt8_dev, long v_stride_b, long v_stride_h,
                            long v_stride_k, const qt_format *fmt_v, void *stream);
 
-/* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with a measured algorithm choice ----------
+/* ---- plain FP8 GEMM on already fake-quantized operands, through hipBLASLt with the algorithm NAMED by the caller ----------
  * C[b][M][N] (bf16) = A[b][M][K] . op(B) (+ bias[N], bf16); A, B are OCP FP8 bytes (format 0 = E4M3, 1 = E5M2) whose
- * values are exactly the fake-quantized bf16 values (unit scale), so the products are the reference's.  b_is_kn = 0: B
- * is [N][K] row-major (a Linear weight, or K for Q.K^T); 1: B is [K][N] row-major (V for P.V).  Batch strides in
- * elements (0 = shared).  `workspace` is caller-owned scratch for the library (64 MiB is plenty; may be NULL).  With
- * tune != 0 the library's top suggestions for this problem are timed once (skipped while the stream is capturing) and
- * the fastest is cached.  Returns QT_ERR_NO_DEVICE when libhipblaslt cannot be resolved in the process and
+ * values are exactly the fake-quantized bf16 values (unit scale), so the products are the reference's
+ * (modules/qat/linear.py:40-41 after both fake-quantizers; modules/quantizable/modeling_bert.py:118-158 for the two
+ * attention matmuls).  b_is_kn = 0: B is [N][K] row-major (a Linear weight, or K for Q.K^T); 1: B is [K][N] row-major (V
+ * for P.V).  Batch strides in elements (0 = shared).  `workspace` is caller-owned scratch for the library (64 MiB is plenty;
+ * may be NULL).  `algo`: index into the library's ordered list of suggestions for this problem (0 = its first; an index
+ * it did not return, or one that needs more workspace than given, runs the first).  Nothing is ever timed here: the choice
+ * -- and with it the order of the fp32 additions -- is the same in every process, rank and box (the package passes a committed
+ * per-shape table, fused._LT_ALGO_TABLE).  Returns QT_ERR_NO_DEVICE when libhipblaslt cannot be resolved in the process and
  * QT_ERR_BAD_DTYPE when it has no kernel for the problem -- the caller then keeps its other route. */
 int qt_fp8_gemm(const uint8_t *a8_dev, int a_format, const uint8_t *b8_dev, int b_format, int b_is_kn, void *c_bf16_dev,
                 const void *bias_bf16_dev, long batch, int M, int N, int K, long a_batch_stride, long b_batch_stride,
-                long c_batch_stride, void *workspace_dev, size_t workspace_bytes, int tune, void *stream);
+                long c_batch_stride, void *workspace_dev, size_t workspace_bytes, int algo, void *stream);
+/* Tools only (tools/tune_lt_algos.py fills the committed table with it): times every suggestion of the library for the problem
+ * (20 launches each on `stream`, which must not be capturing), *best = index of the fastest, us[i] = microseconds per launch of
+ * suggestion i (-1: not runnable; nullable, max_us entries).  Returns the number of suggestions (>= 1) or a negative error. */
+int qt_fp8_gemm_tune(const uint8_t *a8_dev, int a_format, const uint8_t *b8_dev, int b_format, int b_is_kn, void *c_bf16_dev,
+                     const void *bias_bf16_dev, long batch, int M, int N, int K, long a_batch_stride, long b_batch_stride,
+                     long c_batch_stride, void *workspace_dev, size_t workspace_bytes, int *best, float *us, int max_us, void *stream);
 
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).

@@ -425,11 +425,11 @@ template <int F, int D, int MB>
 int launch_split_mb(const AttnArgs &a, long BH, int nqb, hipStream_t st) {
     constexpr int kLds = MB * kBlock * D + 2 * 2 * 64 * 4;               // every block of a sweep + the row statistics
     static_assert(MB * kBlock * D >= 64 * (D + 4) * 4, "the partial sums of the second wave group reuse the block buffers");
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         if (hipFuncSetAttribute((const void *)attention_fp8_split_kernel<F, D, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
             return QT_ERR_BAD_ARG;
-        configured = true;
+        configured.done();
     }
     attention_fp8_split_kernel<F, D, MB><<<dim3((unsigned)BH, (unsigned)nqb), 512, kLds, st>>>(a);
     return status();

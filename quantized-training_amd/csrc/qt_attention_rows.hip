@@ -458,10 +458,10 @@ int qt_attention_rows_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const u
         a.dbg = e_st ? (unsigned long long *)strtoull(e_st, nullptr, 0) : nullptr;
     }
 #endif
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         if (hipFuncSetAttribute((const void *)attention_rows_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return QT_ERR_BAD_ARG;
-        configured = true;
+        configured.done();
     }
     attention_rows_split_kernel<<<dim3((unsigned)(B * H), (unsigned)((Sq + 63) / 64)), 512, kLds, (hipStream_t)stream>>>(a);
     return status();

@@ -3,6 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Only gfx942 / gfx950 implement what these kernels rely on (cache-policy bits of the split-K hand-off, the scaled matrix instructions,
+// LDS-DMA widths); ARCH is a Makefile variable, so say so at compile time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "libqt_hip is written for gfx950 (MI355X); gfx942 is the only other target its inline assembly is valid for"
+#endif
+
+// hipFuncSetAttribute is per DEVICE, a `static bool` is per process: the package runs models on several devices of one process
+// (_native.note_device), and the second device would never get the large-LDS attribute.  One bit per device ordinal.
+struct QtOncePerDevice {
+    unsigned long long bits = 0;
+    int dev = 0;
+    bool needed() {
+        dev = 0;
+        (void)hipGetDevice(&dev);
+        return dev < 0 || dev > 63 || !((__atomic_load_n(&bits, __ATOMIC_ACQUIRE) >> dev) & 1ull);
+    }
+    void done() {
+        if (dev >= 0 && dev <= 63) __atomic_fetch_or(&bits, 1ull << dev, __ATOMIC_RELEASE);
+    }
+};
+
 #include "qt_formats.h"
 
 namespace {

@@ -232,7 +232,13 @@ struct LinearFq8R {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int p = w + 8 * i, pb = p < npieces ? p : (w & 3);          // surplus pieces repeat one (same bytes, same place)
+#ifdef QT_TUNING_BUILD
+            // timing probe (QT_FQ8_DEBUG=256, results are garbage): every column tile reads the FIRST tile's weights, so the weight
+            // stream hits in L2 -- the upper bound of anything that would bring the weights into L2 ahead of the demand loads
+            const int grp = ((a.dbg & 256) ? 0 : tg0) + (pb >> 2);
+#else
             const int grp = tg0 + (pb >> 2);
+#endif
             const int row = pb * 4 + (l >> 4), c = l & 15;
             if constexpr (PAIR) {
                 const uint16_t *wb = (grp & 1) ? a.seg[1].w : a.seg[0].w;
@@ -460,7 +466,11 @@ struct LinearFq8R {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bad |= (qt_f2u(acc[i][j][e]) & 0x7F800000u) == 0x7F800000u;
         }
-        if constexpr (ABL != 0) bad = false;
+        // (ABL 20 is the shipped two-register-set loop, not an ablation.  Rounds 3 and 4 cleared `bad` for it as well, so the widest
+        // tiles -- gate / up, q / k / v -- never took the redo path: an overflowing weight came out as NaN instead of saturating.  No
+        // test held such a weight in a twelve-group tile; tests/test_gpu_parity.py::test_linear_fq8_wide_tiles_redo_overflowing_weights
+        // does now.)
+        if constexpr (ABL != 0 && ABL != 20) bad = false;
         __syncthreads();
         volatile int *flag = (volatile int *)(lds + 8 * 64 * (6 * 32 + 8));     // past the eight waves' epilogue tiles
         if (w == 0 && l == 0) *flag = 0;
@@ -1058,11 +1068,11 @@ int cu_count() {
 template <int FX, int FW, int NB, bool PAIR = false, int ABL = 0>
 int launch_r_nb(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFq8R<FX, FW, NB, PAIR>::kLds;
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r_kernel<FX, FW, NB, PAIR, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured.done();
     }
     linear_fq8r_kernel<FX, FW, NB, PAIR, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
@@ -1072,11 +1082,11 @@ int launch_r_nb(const Args &a, hipStream_t st) {
 template <int FX, int FW, int ABL = 0>
 int launch_r2(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFq8R2<FX, FW>::kLds;
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         const hipError_t e = hipFuncSetAttribute((const void *)linear_fq8r2_kernel<FX, FW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured.done();
     }
     linear_fq8r2_kernel<FX, FW, ABL><<<a.tiles_m * a.tiles_n, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
@@ -1139,6 +1149,42 @@ int launch(const Args &a, hipStream_t st) {
     return launch_r_nb<FX, FW, 6>(a, st);
 }
 
+// How a problem is cut (host): column tiles as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than
+// kMaxNT groups; the weights are treated as one concatenated [sum n][K] matrix, a tile may span two of them.
+// (Round 5 built a split along K for the down projection -- 256 x 128 tiles over K / 2, fp32 partial sums through a workspace, ticket
+// per tile -- and removed it: -6 % alone, nothing inside the window; the weight bytes per CU depend on the row tile only and the weight
+// stream is what paces the loop.  profiles/r05_fq8_splitk.txt.)
+struct Fq8Plan {
+    int tiles_m, tiles_n, gbase, gextra, nb;
+};
+
+int plan_fq8(int M, long groups, Fq8Plan &p) {
+    int force_tn = 0, max_nt = kMaxNT;
+#ifdef QT_TUNING_BUILD
+    {
+        const char *e_tn = getenv("QT_FQ8_TILES_N"), *e_nt = getenv("QT_FQ8_MAX_NT");   // tools/ only
+        force_tn = e_tn ? atoi(e_tn) : 0;
+        max_nt = e_nt ? atoi(e_nt) : kMaxNT;
+        if (max_nt < 1 || max_nt > kMaxNT) max_nt = kMaxNT;
+    }
+#endif
+    const int cus = cu_count();
+    p.tiles_m = (M + kTM - 1) / kTM;
+    const long tn_min = (groups + max_nt - 1) / max_nt;
+    const long rounds = (p.tiles_m * tn_min + cus - 1) / cus;
+    long tn = rounds * cus / p.tiles_m;
+    if (force_tn > 0) tn = force_tn;
+    if (tn < tn_min) tn = tn_min;
+    if (tn > groups) tn = groups;
+    p.tiles_n = (int)tn;
+    p.gbase = (int)(groups / tn);
+    p.gextra = (int)(groups % tn);
+    const int worst_nt = p.gbase + (p.gextra ? 1 : 0);
+    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
+    p.nb = (worst_nt * 4 + 7) / 8;
+    return QT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1160,35 +1206,15 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
         if (bias_devs && bias_devs[i] && ((uintptr_t)bias_devs[i] & 7u)) return QT_ERR_UNALIGNED;
     }
     groups = ntot / 16;
+    Fq8Plan p;
+    if (const int rc = plan_fq8(M, groups, p)) return rc;
     Args a{};
     a.x8 = x8_dev; a.y = y_dev; a.M = M; a.K = K; a.ldc = (int)ntot;
-    a.tiles_m = (M + kTM - 1) / kTM;
-    // Column tiles: as many as make whole rounds over the CUs (one 512-thread workgroup per CU), no wider than kMaxNT groups;
-    // the weights are treated as one concatenated [sum n][K] matrix, a tile may span two of them.
-    int force_tn = 0, max_nt = kMaxNT, dbg = 0;
+    a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.gbase = p.gbase; a.gextra = p.gextra; a.nb = p.nb;
+    a.dbg = 0;
 #ifdef QT_TUNING_BUILD
-    {
-        const char *e_tn = getenv("QT_FQ8_TILES_N"), *e_nt = getenv("QT_FQ8_MAX_NT"), *e_dbg = getenv("QT_FQ8_DEBUG");   // tools/ only
-        force_tn = e_tn ? atoi(e_tn) : 0;
-        max_nt = e_nt ? atoi(e_nt) : kMaxNT;
-        if (max_nt < 1 || max_nt > kMaxNT) max_nt = kMaxNT;
-        dbg = e_dbg ? atoi(e_dbg) : 0;
-    }
+    if (const char *e_dbg = getenv("QT_FQ8_DEBUG")) a.dbg = atoi(e_dbg);
 #endif
-    const int cus = cu_count();
-    const long tn_min = (groups + max_nt - 1) / max_nt;
-    const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
-    long tn = rounds * cus / a.tiles_m;
-    if (force_tn > 0) tn = force_tn;
-    if (tn < tn_min) tn = tn_min;
-    if (tn > groups) tn = groups;
-    a.tiles_n = (int)tn;
-    a.gbase = (int)(groups / tn);
-    a.gextra = (int)(groups % tn);
-    const int worst_nt = a.gbase + (a.gextra ? 1 : 0);
-    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
-    a.nb = (worst_nt * 4 + 7) / 8;
-    a.dbg = dbg;
     int nseg = 0, g0 = 0;
     for (int i = 0; i < count; ++i) {
         if (ns[i] == 0) continue;

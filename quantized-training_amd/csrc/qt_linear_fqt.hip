@@ -610,7 +610,7 @@ struct LinearFqt {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (w == 0 && l == 0) {
-                const unsigned int old = __hip_atomic_fetch_add(a.tickets + tile_lin, 1u + (flagged ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int old = __hip_atomic_fetch_add(a.tickets + tile_lin, 1u + (flagged ? 0x10000u : 0u), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = (int)old;
             }
             __syncthreads();
@@ -829,11 +829,11 @@ int cu_count() {
 template <int TM, int NB, bool SROWS, int ABL = 0>
 int launch_one(const Args &a, hipStream_t st) {
     constexpr int kLds = LinearFqt<TM, NB, SROWS>::kLds;
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         const hipError_t e = hipFuncSetAttribute((const void *)linear_fqt_kernel<TM, NB, SROWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured.done();
     }
     linear_fqt_kernel<TM, NB, SROWS, ABL><<<a.tiles_m * a.tiles_n * a.ksplit, 512, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();

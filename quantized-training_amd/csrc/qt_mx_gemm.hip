@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "../../include/qt_hip.h"
+#include "qt_device.h"
 #include "qt_formats.h"
 #include "qt_mx.h"
 
@@ -1110,11 +1111,11 @@ template <int FA, int FB, int TM, int NBP>
 int launch_wide_nbp(const MxGemmArgs &g, const WideGeom &geo, long batch, hipStream_t st) {
     constexpr int kLds = MxWide<FA, FB, TM, NBP>::kLds;
     static_assert(kLds <= 160 * 1024, "LDS rings of the wide kernel exceed a CU's 160 KiB");
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_wide_kernel<FA, FB, TM, NBP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured.done();
     }
     mx_gemm_wide_kernel<FA, FB, TM, NBP><<<dim3((unsigned)(geo.tiles_m * geo.tiles_n), (unsigned)batch), 512, kLds, st>>>(g, geo);
     const hipError_t e = hipGetLastError();
@@ -1278,12 +1279,12 @@ int qt_mx_gemm(const uint8_t *a_codes, const uint8_t *a_e8m0, int a_format, cons
 #define QT_MX(FA, FB)                                                                                              \
     if (a_format == FA && b_format == FB) {                                                                        \
         constexpr int kLds = 2 * Tile<FA>::kBytes + 2 * Tile<FB>::kBytes;                                          \
-        static bool configured = false;                                                                            \
-        if (!configured) {                                                                                         \
+        static QtOncePerDevice configured;                                                                                  \
+        if (configured.needed()) {                                                                                         \
             const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_kernel<FA, FB>,                         \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);            \
             if (e != hipSuccess) return (int)e;                                                                    \
-            configured = true;                                                                                     \
+            configured.done();                                                                                      \
         }                                                                                                          \
         mx_gemm_kernel<FA, FB><<<grid, 256, kLds, st>>>(g);                                                        \
         return launch_status();                                                                                    \
@@ -1323,11 +1324,11 @@ int qt_q8_gemm(const int8_t *a_codes, const int8_t *b_codes, void *c_dev, int c_
         return launch_status();
     }
     constexpr int kLds = 4 * Tile<0>::kBytes;
-    static bool configured = false;
-    if (!configured) {
+    static QtOncePerDevice configured;      
+    if (configured.needed()) {
         const hipError_t e = hipFuncSetAttribute((const void *)mx_gemm_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured.done();
     }
     mx_gemm_kernel<0, 0, true><<<grid, 256, kLds, st>>>(g);
     return launch_status();

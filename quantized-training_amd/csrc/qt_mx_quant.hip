@@ -277,12 +277,12 @@ int launch(const void *x, void *q, void *sf, uint8_t *codes, uint8_t *e8m0, size
             size_t want = (a.nvec + 255) / 256, cap = (size_t)num_cus() * 32;                                      \
             quantize_mx_kernel<IO, false, PB, true><<<(unsigned)(want < cap ? want : cap), 256, 0, st>>>(a);       \
         } else if (lds) {                                                                                              \
-            static bool configured = false;                                                                        \
-            if (!configured) {                                                                                     \
+            static QtOncePerDevice configured;                                                                              \
+            if (configured.needed()) {                                                                                     \
                 const hipError_t e = hipFuncSetAttribute((const void *)quantize_mx_kernel<IO, true, PB>,           \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2);   \
                 if (e != hipSuccess) return (int)e;                                                                \
-                configured = true;                                                                                 \
+                configured.done();                                                                                  \
             }                                                                                                      \
             quantize_mx_kernel<IO, true, PB><<<(unsigned)num_cus(), 1024, 65536 * 2, st>>>(a);                     \
         } else {                                                                                                   \

@@ -9,8 +9,14 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_uint16, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# QT_HIP_LIB: tools/ only -- load the tuning build (make -C quantized-training_amd tuning) instead of the product library
+# QT_HIP_LIB: tools/ only -- load the tuning build (make -C quantized-training_amd tuning) instead of the product library.  Never
+# silent: a warning names the file, and `LIB_OVERRIDDEN` lets callers (bench.py's config) record it.
+LIB_OVERRIDDEN = bool(os.environ.get("QT_HIP_LIB"))
 LIB_PATH = os.environ.get("QT_HIP_LIB") or os.path.join(_HERE, "libqt_hip.so")
+if LIB_OVERRIDDEN:
+    import warnings
+    warnings.warn(f"quantized_training loads {LIB_PATH} instead of its own libqt_hip.so (QT_HIP_LIB is set): a tuning build's ablation "
+                  f"switches produce wrong results on purpose", RuntimeWarning, stacklevel=2)
 
 QT_MAP_ENTRIES = 65536
 QT_FMT_LUT, QT_FMT_IDENTITY, QT_FMT_FP_SAT, QT_FMT_INT = 0, 1, 2, 3
@@ -47,6 +53,7 @@ _OPQ = POINTER(QtOperandQ)
 SIGNATURES = {
     "qt_abi_version": (c_int, []),
     "qt_status_string": (c_char_p, [c_int]),
+    "qt_stream_capture_id": (c_int, [_P, POINTER(ctypes.c_ulonglong)]),
     "qt_build_map": (c_int, [c_char_p, _P]),
     "qt_format_for": (c_int, [c_char_p, _FMT]),
     "qt_format_apply_host": (c_uint16, [_FMT, c_uint16]),
@@ -135,6 +142,8 @@ SIGNATURES = {
                                 _FMT, _P, _P, c_long, c_long, c_long, _FMT, _P]),
     "qt_fp8_gemm": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_long, c_int, c_int, c_int, c_long, c_long, c_long, _P,
                            c_size_t, c_int, _P]),
+    "qt_fp8_gemm_tune": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_long, c_int, c_int, c_int, c_long, c_long, c_long, _P,
+                           c_size_t, POINTER(c_int), _P, c_int, _P]),
     "qt_mx_pack": (c_int, [_P, _P, c_int, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_int,
                           c_int, _P, _P]),
     "qt_mx_gemm": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_long, c_int, c_int, c_int, c_long, c_long, _P]),

@@ -72,8 +72,11 @@ def _note_route(kind, M, ns, K, route):
 
 
 def routes_report():
-    """The GEMM routes taken so far, per problem shape (bench.py puts them into its JSON line)."""
-    return dict(sorted(ROUTES.items()))
+    """The GEMM routes taken so far, per problem shape, and for library FP8 GEMMs which of the library's suggestions ran
+    (bench.py puts them into its JSON line)."""
+    out = dict(sorted(ROUTES.items()))
+    out.update(sorted(LT_ALGOS.items()))
+    return out
 
 
 def _fq8_heuristic(M, ns, K, device):
@@ -498,9 +501,32 @@ def fp8_linear_or_none(layer, x):
 
 _LT = {"ok": True, "ws": {}}                  # "ok" turns False when libhipblaslt cannot be resolved in the process
 
+# Which of hipBLASLt's suggestions runs a problem: (batch, M, N, K, b_is_kn, bias) -> index into the library's ordered list.
+# Measured once on MI355X by tools/tune_lt_algos.py (profiles/r05_lt_algos.txt: microseconds of every suggestion) and COMMITTED, so
+# every process, rank and box runs the same library kernel -- the same order of fp32 additions -- for a shape; rounds 1-4 timed the
+# suggestions in each process and two ranks could disagree.  Shapes not listed run the library's first suggestion (index 0).
+_LT_ALGO_TABLE = {
+    (1, 6144, 768, 3072, 0, 1): 3,        # BERT-base output dense: 20.2 us against 22.1 for the first suggestion
+    (1, 2048, 4096, 4096, 0, 0): 1,       # 32.2 / 35.5
+    (1, 1024, 5120, 13824, 0, 0): 5,      # 71.1 / 80.0
+    (1, 1024, 5120, 5120, 0, 0): 2,       # 31.8 / 33.4
+    (40, 1024, 1024, 128, 0, 0): 1,       # 13B Q.K^T chain: 26.9 / 27.8
+    (40, 1024, 128, 1024, 1, 0): 2,       # 13B P.V chain: 19.8 / 31.6
+    (192, 384, 384, 64, 0, 0): 12,        # BERT-base Q.K^T chain: 56.3 / 66.6
+    (192, 384, 64, 384, 1, 0): 5,         # BERT-base P.V chain: 13.5 / 32.6
+}
+LT_ALGOS = {}              # what ran: "bxMxNxK[kn][+bias]" -> index (routes_report)
+
+
+def lt_algo_index(batch, M, N, K, b_is_kn, with_bias):
+    forced = os.environ.get("QT_LT_ALGO")                     # tools only: the tuner's A/B runs
+    idx = int(forced) if forced is not None else _LT_ALGO_TABLE.get((batch, M, N, K, int(bool(b_is_kn)), int(bool(with_bias))), 0)
+    LT_ALGOS.setdefault(f"lt:{batch}x{M}x{N}x{K}{'kn' if b_is_kn else ''}{'+bias' if with_bias else ''}", idx)
+    return idx
+
 
 def lt_fp8_gemm(a8, b8, bias=None, b_is_kn=False):
-    """C = A . op(B) on FP8 operands through qt_fp8_gemm (hipBLASLt with a measured algorithm choice).  a8 [.., M, K];
+    """C = A . op(B) on FP8 operands through qt_fp8_gemm (hipBLASLt; which of its suggestions runs is a committed table, _LT_ALGO_TABLE).  a8 [.., M, K];
     b8 [N, K] (b_is_kn False) or [.., K, N] (True); leading dims of a8 / b8 are a batch.  None when the library route is
     unavailable for this problem (the caller falls back to torch._scaled_mm / bf16)."""
     if not _LT["ok"] or os.environ.get("QT_LT_GEMM", "1") == "0":
@@ -529,7 +555,7 @@ def lt_fp8_gemm(a8, b8, bias=None, b_is_kn=False):
     out = torch.empty(a8.shape[:-1] + (N,), dtype=torch.bfloat16, device=dev)
     rc = _native.lib().qt_fp8_gemm(a8.data_ptr(), fmt[a8.dtype], b8.data_ptr(), fmt[b8.dtype], int(b_is_kn), out.data_ptr(),
                                    bias.data_ptr() if bias is not None else None, batch, M, N, K, M * K, b_stride, M * N,
-                                   ws.data_ptr(), ws.numel(), 1, _stream_ptr(a8))
+                                   ws.data_ptr(), ws.numel(), lt_algo_index(batch, M, N, K, b_is_kn, bias is not None), _stream_ptr(a8))
     if rc != 0:
         if rc in (_native.QT_ERR_NO_DEVICE,):
             _LT["ok"] = False                      # the library cannot be resolved in this process: stop trying
@@ -696,14 +722,8 @@ def hip_fqt_linear_or_none(x2, layers, tables):
     wp = (ctypes.c_void_p * n)(*[l.weight.data_ptr() for l in layers])
     bp = (ctypes.c_void_p * n)(*[(l.bias.data_ptr() if l.bias is not None else None) for l in layers])
     nn = (ctypes.c_int * n)(*ns)
+    _native.note_device(x2.device.index)
     ws, tickets = _fqt_workspace(M, sum(ns), K, x2.device)
-    if ws is False:
-        rc = _native.lib().qt_linear_fqt_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
-                                               tables["map"].data_ptr(), y.data_ptr(), M, K, _stream_ptr(x2))
-        if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED, _native.QT_ERR_BAD_DTYPE):
-            return None
-        _native.check(rc, "qt_linear_fqt_bf16")
-        return y
     rc = _native.lib().qt_linear_fqt_ws_bf16(x2.data_ptr(), wp, bp, nn, n, tables["rows"].data_ptr(), tables["signed"], tables["mask"],
                                               tables["map"].data_ptr(), y.data_ptr(), M, K,
                                               ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
@@ -715,27 +735,45 @@ def hip_fqt_linear_or_none(x2, layers, tables):
     return y
 
 
-# Split-K scratch of qt_linear_fqt_ws_bf16, per device: one fp32 workspace (grown to the largest plan seen) and one ticket array
-# (zeroed once; every launch leaves it zero).  Launches on a device are ordered on its stream, so they can share both.  Outgrown
-# buffers stay allocated: a hipGraph captured earlier replays launches that hold their addresses.
-_FQT_WS = {}
-_FQT_WS_OLD = []
+# Split-K scratch (qt_linear_fqt_ws_bf16): an fp32 workspace and a ticket array that ONE ordered sequence of
+# launches may share -- so they are keyed by (kernel, device, stream, capture): every eager stream and every captured graph has its
+# own (include/qt_hip.h: "launches that share a workspace must be ordered on one stream"; a graph replay may overlap eager work on
+# another stream, and a second capture may be replayed beside the first).  Inside a capture the buffers come from the graph's
+# memory pool (the zero fill of the tickets becomes a node of the graph; every launch leaves them zero anyway).  Outgrown buffers
+# stay allocated: a hipGraph captured earlier replays launches that hold their addresses.
+_SPLITK_WS = {}
+_SPLITK_WS_OLD = []
+
+
+def _capture_id(stream_ptr):
+    cid = ctypes.c_ulonglong(0)
+    _native.check(_native.lib().qt_stream_capture_id(stream_ptr, ctypes.byref(cid)), "qt_stream_capture_id")
+    return cid.value
+
+
+def splitk_scratch(kind, wbytes, ntick, device):
+    """(workspace, tickets) for the launch about to be issued on `device`'s current stream."""
+    st = torch.cuda.current_stream(device).cuda_stream
+    key = (kind, device.index if device.index is not None else torch.cuda.current_device(), st, _capture_id(ctypes.c_void_p(st)))
+    ws, tickets = _SPLITK_WS.get(key, (None, None))
+    if ws is None and len(_SPLITK_WS) > 8:
+        # entries of captures that have ended: the graph's pool keeps their memory alive for its replays, this table need not
+        for k in [k for k in _SPLITK_WS if k[3] not in (0, key[3])]:
+            del _SPLITK_WS[k]
+    if ws is None or ws.numel() * 4 < wbytes or tickets.numel() < ntick:
+        if ws is not None:
+            _SPLITK_WS_OLD.append((ws, tickets))
+        ws = torch.empty(((wbytes + 3) // 4,), dtype=torch.float32, device=device)
+        tickets = torch.zeros((max(ntick, 4096),), dtype=torch.int32, device=device)
+        _SPLITK_WS[key] = (ws, tickets)
+    return ws, tickets
 
 
 def _fqt_workspace(M, n_total, K, device):
     ksplit, wbytes, ntick = fqt_plan(M, n_total, K)
     if ksplit <= 1:
         return None, None
-    ws, tickets = _FQT_WS.get(device, (None, None))
-    if ws is None or ws.numel() * 4 < wbytes or tickets.numel() < ntick:
-        if torch.cuda.is_current_stream_capturing():
-            return False, False                               # never allocate inside a capture: this launch runs unsplit
-        if ws is not None:
-            _FQT_WS_OLD.append((ws, tickets))
-        ws = torch.empty(((wbytes + 3) // 4,), dtype=torch.float32, device=device)
-        tickets = torch.zeros((max(ntick, 4096),), dtype=torch.int32, device=device)
-        _FQT_WS[device] = (ws, tickets)
-    return ws, tickets
+    return splitk_scratch("fqt", wbytes, ntick, device)
 
 
 def _fqt_weight_ok(layer):
@@ -1205,6 +1243,11 @@ def attention_rows_or_none(L, st, qq, kq, value, fq_v, mask, mask_owner, mask_st
     if not (vfmt.p1 & 1) or value.dtype != torch.bfloat16 or value.stride(3) != 1 or any(s_ % 8 for s_ in value.stride()[:3]) or value.data_ptr() % 16:
         return False
     msb, msh, msq = mask_strides
+    # everything qt_attention_rows_bf16 would refuse, BEFORE the value pass is issued and counted
+    if (qq.data_ptr() | kq.data_ptr() | lut) % 16 or out.data_ptr() % 8:
+        return False
+    if mask is not None and (mask.data_ptr() % 8 or (msb | msh | msq) % 4):
+        return False
     live = _mask_row_live(mask, mask_owner, B, H, Q, C, st) if (mask is not None and mask_owner is not None) else None
     early = attn.__dict__.pop("_qt_vt_rows", None) if attn is not None else None
     if early is not None and early[0] == value_key(value) and early[1] is fq_v:

@@ -271,8 +271,11 @@ class GraphedBatch:
         with torch.cuda.stream(side), torch.no_grad():
             model(**self.static, **self.extra)
             fused.start_weight_pass_log()                       # which Linears run a separate FP8 weight pass (pair route)
-            model(**self.static, **self.extra)
-            batch = fused.BatchedWeightCodes(fused.stop_weight_pass_log(), device)
+            try:
+                model(**self.static, **self.extra)
+            finally:
+                logged = fused.stop_weight_pass_log()           # (never left active: it holds strong references to the owners)
+            batch = fused.BatchedWeightCodes(logged, device)
             if batch_weight_passes and len(batch) > 1:
                 self.weight_codes = batch                       # ... all of them as ONE launch in front of the captured forward
                 batch.launch()

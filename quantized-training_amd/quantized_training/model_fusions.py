@@ -784,6 +784,29 @@ _LAYER_PARAMS = ["self", "hidden_states", "attention_mask", "position_ids", "pas
                  "position_embeddings", "kwargs"]
 
 
+def _drop_layer_handovers(layer):
+    """One-shot hand-overs a block's kernels leave for each other, dropped at the end of the block whichever route ran (each holds
+    10 - 56 MB per layer at 13B widths): the sibling groups' [M, sum N] products once their members have taken their slices, the
+    value pass the rotary launch wrote ahead (`_qt_vt_rows`), the o projection's pre-quantized weight (`_qt_pre`)."""
+    attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+    for owner, names in ((attn, ("q_proj", "k_proj", "v_proj", "o_proj")), (mlp, ("gate_proj", "up_proj"))):
+        if owner is None:
+            continue
+        for name in names:
+            lin = getattr(owner, name, None)
+            if lin is None:
+                continue
+            group = lin.__dict__.get("_qt_sibling_group")
+            if group is not None:
+                group.stash = None
+    if attn is not None:
+        attn.__dict__.pop("_qt_vt_rows", None)
+        o = getattr(attn, "o_proj", None)
+        fq = getattr(o, "weight_fake_quant", None) if o is not None else None
+        if fq is not None and not torch.is_grad_enabled():
+            fq.__dict__["_qt_pre"] = None
+
+
 def _decoder_layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                            position_embeddings=None, **kwargs):
     """transformers' LlamaDecoderLayer.forward, statement for statement, with each `residual + hidden_states` absorbed into
@@ -802,6 +825,7 @@ def _decoder_layer_forward(self, hidden_states, attention_mask=None, position_id
         residual = hidden_states
         hidden_states = self.post_attention_layernorm(hidden_states)
     hidden_states = self.mlp(hidden_states)
+    _drop_layer_handovers(self)
     nxt = self.__dict__.get("_qt_next_norm")
     fused = _add_rmsnorm_or_none(hidden_states, residual, nxt) if nxt is not None else None
     if fused is None:

@@ -36,9 +36,17 @@ class _LinearColsumBias(torch.autograd.Function):
             gw = gy2.t().mm(x.reshape(-1, x.shape[-1]))
         if ctx.needs_input_grad[2]:
             g = gy2 if gy2.is_contiguous() else gy2.contiguous()
-            gb = torch.empty(g.shape[1], dtype=g.dtype, device=g.device)
-            _native.check(_native.lib().qt_colsum_bf16(g.data_ptr(), gb.data_ptr(), g.shape[0], g.shape[1],
-                                                       ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "qt_colsum_bf16")
+            if g.dtype != torch.bfloat16 or g.data_ptr() % 16 or g.shape[1] % 8 or g.shape[0] == 0:
+                gb = gy2.sum(0)                         # a view at an odd storage offset, another dtype: what F.linear's backward does
+            else:
+                gb = torch.empty(g.shape[1], dtype=g.dtype, device=g.device)
+                _native.note_device(g.device.index)
+                rc = _native.lib().qt_colsum_bf16(g.data_ptr(), gb.data_ptr(), g.shape[0], g.shape[1],
+                                                  ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+                if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED):
+                    gb = gy2.sum(0)
+                else:
+                    _native.check(rc, "qt_colsum_bf16")
         return gx, gw, gb
 
 

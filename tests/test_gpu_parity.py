@@ -18,6 +18,7 @@ from oracle import qt_oracle as o
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -1601,7 +1602,7 @@ def test_layernorm_with_all_consumers_fake_quant(nv):
 
 @pytest.mark.parametrize("M,N,K,bias", [(1024, 4096, 4096, False), (256, 768, 3072, True), (1000, 1008, 512, True)])
 def test_lt_fp8_gemm_matches_scaled_mm(nv, M, N, K, bias):
-    """qt_fp8_gemm (hipBLASLt, measured algorithm choice) against the exact product of the FP8 operands; bf16 output.
+    """qt_fp8_gemm (hipBLASLt; the suggestion a committed table names) against the exact product of the FP8 operands; bf16 output.
     The library's bias epilogue adds the bias to the already rounded product, so with a bias there are two bf16
     roundings (of the product and of the sum); torch._scaled_mm drives the same epilogue."""
     from quantized_training import fused
@@ -1891,6 +1892,121 @@ def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     ref = xa @ wa.t() + bias
     tol = ref.abs() * 2.0 ** -8 + (xa.abs() @ wa.abs().t()) * 2.0 ** -14 + 1e-30
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
+
+
+def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
+    """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
+    the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,
+    and another suggestion of the library gives the same product within the accumulation bound."""
+    import subprocess
+    import sys
+    from quantized_training import fused
+    code = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from quantized_training import fused
+torch.manual_seed(0)
+out = []
+for (M, N, K, bias) in ((6144, 768, 3072, True), (777, 512, 640, False)):
+    a = torch.randn(M, K, device="cuda").to(torch.float8_e4m3fn)
+    b = (torch.randn(N, K, device="cuda") * 0.05).to(torch.float8_e4m3fn)
+    bv = torch.randn(N, device="cuda").bfloat16() if bias else None
+    y = fused.lt_fp8_gemm(a, b, bv)
+    out.append(hashlib.sha256(y.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+print("HASH", " ".join(out), fused.routes_report())
+""" % os.path.join(ROOT, "quantized-training_amd")
+    lines = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert lines[0] == lines[1]
+    assert "'lt:1x6144x768x3072+bias': 3" in lines[0] and "'lt:1x777x512x640': 0" in lines[0]
+    torch.manual_seed(0)
+    a = torch.randn(6144, 3072, device="cuda").to(torch.float8_e4m3fn)
+    b = (torch.randn(768, 3072, device="cuda") * 0.05).to(torch.float8_e4m3fn)
+    y3 = fused.lt_fp8_gemm(a, b, None)
+    os.environ["QT_LT_ALGO"] = "0"
+    try:
+        y0 = fused.lt_fp8_gemm(a, b, None)
+    finally:
+        del os.environ["QT_LT_ALGO"]
+    bound = (a.float().abs() @ b.float().abs().t())
+    assert bool(((y3.float() - y0.float()).abs() <= y0.float().abs() * 2.0 ** -7 + bound * 2.0 ** -14).all())
+
+
+def test_splitk_scratch_is_per_stream_and_per_capture(nv):
+    """fused.splitk_scratch: launches that share a split-K workspace must be ONE ordered sequence, so every eager stream and every
+    stream capture gets buffers of its own (the capture's from the graph's pool), and the same stream gets the same ones again."""
+    from quantized_training import fused
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a_ws, a_tk = fused.splitk_scratch("test", 1 << 16, 64, dev)
+    b_ws, b_tk = fused.splitk_scratch("test", 1 << 16, 64, dev)
+    assert a_ws.data_ptr() == b_ws.data_ptr() and a_tk.data_ptr() == b_tk.data_ptr()
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        c_ws, c_tk = fused.splitk_scratch("test", 1 << 16, 64, dev)
+    assert c_ws.data_ptr() != a_ws.data_ptr() and c_tk.data_ptr() != a_tk.data_ptr()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        d_ws, d_tk = fused.splitk_scratch("test", 1 << 16, 64, dev)
+        d2_ws, _ = fused.splitk_scratch("test", 1 << 16, 64, dev)
+        d_tk.add_(0)
+    assert d_ws.data_ptr() == d2_ws.data_ptr() and d_ws.data_ptr() not in (a_ws.data_ptr(), c_ws.data_ptr())
+    g.replay()
+    torch.cuda.synchronize()
+    assert not bool(d_tk.any()) and not bool(a_tk.any())
+    e_ws, _ = fused.splitk_scratch("test", 1 << 16, 64, dev)           # eager again: the stream's own buffers, not the graph's
+    assert e_ws.data_ptr() == a_ws.data_ptr()
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_linear_fq8_wide_tiles_redo_overflowing_weights(nv, pair):
+    """The widest tiles (twelve column groups: gate / up, q / k / v -- the two-register-set loop) on ALL 65 536 bf16 weight patterns:
+    identity activation, N = 11008 at M = K = 1024.  Overflowing weights saturate (fp8.py:32), rows holding +-Inf / NaN come out
+    all-NaN: the redo path of the kernels the headline window spends most of its time in, checked against the ORACLE's value map
+    (test_mlp_fq8_equals_two_gemms_and_silu_mul compares two kernels that share that path).  pair: qt_mlp_fq8_bf16 whose gate weight
+    holds every finite pattern, against the oracle-checked gate product + qt_silu_mul_fq8_bf16."""
+    K = M = 1024
+    N = 11008
+    torch.manual_seed(3)
+    W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    W.view(torch.int16)[:64] = torch.arange(65536, device="cuda", dtype=torch.int32).to(torch.int16).view(64, K)
+    x8 = _codes_of(nv, torch.eye(K, device="cuda").bfloat16(), "e4m3")
+    qmap = o.get_quantization_map("e4m3")
+
+    def check_gate(Wt, n_nan_rows):
+        exp = o.canon_nan16(o.vmap_bf16(host_u16(Wt.view(torch.int16)), qmap)).reshape(N, K)
+        y = _linear_fq8(nv, x8, "e4m3", [Wt], "e4m3")
+        got = o.canon_nan16(host_u16(y.t().contiguous().view(torch.int16)))
+        nan_rows = (exp == 0x7FC0).any(axis=1)
+        assert nan_rows.sum() == n_nan_rows
+        same = (got == exp) | (((got | exp) & 0x7FFF) == 0)
+        assert same[~nan_rows].all()
+        assert (got[nan_rows] == 0x7FC0).all()
+        return y
+
+    Wf = W.clone()
+    Wf[~torch.isfinite(Wf.float())] = 0
+    g = check_gate(Wf, 0)
+    if not pair:
+        check_gate(W, 2)                                        # the rows holding +Inf / NaNs and -Inf / NaNs
+        return
+    Wu = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    Wu[7, 9] = 3.0e4                                            # beyond E4M3's range: saturates to 448
+    u = _linear_fq8(nv, x8, "e4m3", [Wu], "e4m3")
+    assert float(u[9, 7]) == 448.0
+    fmt = nv.format_for("e4m3")
+    want = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    want8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+    nv.check(nv.lib().qt_silu_mul_fq8_bf16(g.data_ptr(), u.data_ptr(), want.data_ptr(), want8.data_ptr(), M, N, N, N, ctypes.byref(fmt),
+                                           stream()), "qt_silu_mul_fq8_bf16")
+    h = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    h8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+    nv.check(nv.lib().qt_mlp_fq8_bf16(x8.data_ptr(), 0, Wf.data_ptr(), Wu.data_ptr(), None, None, N, 0, h.data_ptr(), h8.data_ptr(),
+                                      ctypes.byref(fmt), M, K, stream()), "qt_mlp_fq8_bf16")
+    assert torch.equal(h.view(torch.int16), want.view(torch.int16)) and torch.equal(h8, want8)
 
 
 # ---- qt_linear_fqt_bf16: bf16 GEMM with ANY value map applied to the weights in its operand path --------------------------

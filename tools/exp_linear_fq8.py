@@ -140,9 +140,12 @@ def bench(M, Ns, K, iters, fx=0, fw=0):
 
     two_kernel(0)
     t_f = timeit(fused, iters)
+    flops = 2.0 * M * N * K
+    if os.environ.get("FUSED_ONLY"):
+        print(f"bench {M}x{N}x{K}: fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s)", flush=True)
+        return t_f, t_f
     t_2 = timeit(two_kernel, iters)
     t_g = timeit(gemm_only, iters)
-    flops = 2.0 * M * N * K
     print(f"bench {M}x{N}x{K} (segments {Ns}): fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s)   "
           f"pass + hipBLASLt {t_2:7.1f} us   hipBLASLt alone {t_g:7.1f} us   speed-up {t_2 / t_f:.2f}x", flush=True)
     return t_f, t_2
