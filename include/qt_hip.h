@@ -264,6 +264,30 @@ int qt_bmm_fq_bf16(const uint16_t *a_dev, const uint16_t *b_dev, uint16_t *y_dev
                    long lda, long sa, long ldb_k, long ldb_n, long sb, const qt_operand_q *qa,
                    const qt_operand_q *qb, void *stream);
 
+/* ---- A7 / A11, several fake-quantizer calls of a training step over ONE tensor as one launch --------------------------------
+ * The reference's hooks (quantize.py:116-179: activation_pre_process, error_pre_process, error_post_process) call fake-quantizers
+ * back to back on the same bf16 tensor x [rows][cols]: stage i reads x (src = -1) or the RESULT of stage src < i, applies the
+ * format `fmt` (one format for all stages: QT_FMT_INT, QT_FMT_FP_SAT, or a table format whose device map carries the row form,
+ * p1 bit 0) with ITS scale (scale_f32_dev, NULL = 1: y = fq(x / s) * s, fake_quantize.py:243-246) and accumulates the amax of ITS
+ * input into amax_bits_dev (NULL: not observed; the slot was zeroed by qt_scale_update, fake_quantize.py:230-242) -- i.e. every
+ * stage is exactly one qt_fake_quant_bf16 call, bit for bit.  out_dev (nullable, 16-byte aligned): where the stage's result goes.
+ * colsum_stage >= 0: also colsum_out_dev[c] = bf16(sum over rows of that stage's result[., c]) (grad_bias = grad_output.sum(0) of
+ * the Linear behind the quantizer, run_glue_no_trainer.py:660-667): fp32 sums in a fixed order inside a workgroup, 64-bit
+ * fixed-point (one unit = 2^-42 of the largest value the stage can produce, colsum_max x scale) across workgroups -- run-to-run
+ * bit-identical.  colsum_max: the largest finite magnitude of the format's value map.  ws_dev: qt_fake_quant_chain_ws_bytes(rows,
+ * cols) bytes, ZERO before the first launch, left zero by every launch, used by one ordered sequence of launches only.
+ * `stages` is a HOST array.  cols % 8 == 0, nstage <= 4. */
+typedef struct {
+    const float *scale_f32_dev;
+    uint32_t *amax_bits_dev;
+    uint16_t *out_dev;
+    int src;
+} qt_chain_stage;
+int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
+                             const uint16_t *lut_dev, int colsum_stage, float colsum_max, uint16_t *colsum_out_dev, void *ws_dev,
+                             size_t ws_bytes, void *stream);
+size_t qt_fake_quant_chain_ws_bytes(long rows, long cols);
+
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
  *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const void *__restrict__
 // no staging into LDS and no barrier in front of the first load.  An OBSERVED short pass runs 1024-thread workgroups: every workgroup
 // that can raise the running maximum issues an atomicMax on ONE address, the slot starts each step at zero, and same-address atomics
 // serialise at ~12 ns each -- 768 workgroups of 256 threads spent most of a [2048, 768] launch's 10.9 us queueing there.
-template <int IO, bool OBS, int BLOCK>
+template <int IO, bool OBS, int BLOCK, int UNR = 1>
 __global__ __launch_bounds__(BLOCK) void fq_rows_direct_kernel(const void *__restrict__ xv, void *__restrict__ yv, size_t nvec, size_t n,
                                                             qt_format fmt, const uint16_t *__restrict__ lut, const float *__restrict__ scale,
                                                             uint32_t *amax_out) {
@@ -260,11 +260,11 @@ __global__ __launch_bounds__(BLOCK) void fq_rows_direct_kernel(const void *__res
     uint4 *y = (uint4 *)yv;
     const UniformDiv dv(s);
     if (unit)
-        fq_stream<IO, kFmtRows, kDivUnit, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+        fq_stream<IO, kFmtRows, kDivUnit, OBS, BLOCK, UNR, 0>(x, y, nvec, dv, rnd, amax);
     else if (dv.safe)
-        fq_stream<IO, kFmtRows, kDivFast, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+        fq_stream<IO, kFmtRows, kDivFast, OBS, BLOCK, UNR, 0>(x, y, nvec, dv, rnd, amax);
     else
-        fq_stream<IO, kFmtRows, kDivExact, OBS, BLOCK, 1, 0>(x, y, nvec, dv, rnd, amax);
+        fq_stream<IO, kFmtRows, kDivExact, OBS, BLOCK, UNR, 0>(x, y, nvec, dv, rnd, amax);
     constexpr int kPer = IO == kIoBf16 ? 8 : 4;
     if (blockIdx.x == gridDim.x - 1) {
         for (size_t i = nvec * kPer + threadIdx.x; i < n; i += BLOCK) fq_one<IO, kFmtRows, OBS>(xv, yv, i, s, unit, rnd, amax);
@@ -298,6 +298,171 @@ __global__ __launch_bounds__(256) void fq_gather_vec_kernel(const void *__restri
         for (size_t i = nvec * kPer + threadIdx.x; i < n; i += 256) fq_one<IO, QT_FMT_LUT, OBS>(xv, yv, i, s, unit, rnd, amax);
     }
     if constexpr (OBS) block_amax_commit<256>(amax, amax_out);
+}
+
+// ---- several fake-quantizers of one training step over ONE tensor, as one launch (qt_fake_quant_chain_bf16) -----------------------------
+// The reference's hooks call fake-quantizers back to back on the same tensor (quantize.py:116-179): a gradient leaving a LayerNorm
+// goes through the residual add's backward-pre quantizer, its two backward quantizers and the dense layer's backward-pre quantizer
+// -- four observed E5M2 passes over [tokens, hidden]; a LayerNorm's output goes through the input quantizers of query / key / value.
+// Inside a replayed step every such pass is a launch of its own (>= 4.5 us each, 8 us observed).  Here stage i reads x or the result
+// of an earlier stage, applies ITS fake-quantizer (own scale, own amax slot: the per-tensor state machines stay the reference's) and
+// writes its result; optionally the fp32 column sums of one stage's result are produced on the way (the bias gradient of the Linear
+// behind it: grad_output.sum(0), run_glue_no_trainer.py:660-667) -- rows are dealt to workgroups in bands, a lane adds its rows in
+// row order, the lanes of a column in lane order, the workgroups in workgroup order (last arriver, through a workspace): deterministic.
+constexpr int kChainMax = 4, kChainBlock = 512, kChainStripV = 8, kChainRowLanes = kChainBlock / kChainStripV;
+// Work decomposition: a workgroup (512 threads: up to 256 registers, the row form keeps many live) owns a STRIP of 64 columns (8 vectors =
+// one 128-byte line per row) x a BAND of rows; lane (rl = t / 8, v = t % 8) walks rows rl, rl + 64, ... of the band, two or four loads in flight.  Column sums: a lane adds its rows in row order,
+// the 64 row lanes of a column meet in a fixed-order tree in LDS, and the bands of a strip meet in fixed-point accumulators (below).
+struct ChainStageDev {
+    const float *scale;
+    uint32_t *amax;
+    uint4 *out;
+    int src;                  // -1: x; else the stage whose result this one reads
+};
+struct ChainArgs {
+    const uint4 *x;
+    long rows;
+    int cv;                   // 16-byte vectors per row
+    int nstage;
+    ChainStageDev st[kChainMax];
+    int strips, bands;
+    long band_rows;           // rows per band (a multiple of kChainRowLanes)
+    int colsum_stage;         // -1: none
+    float colsum_max;         // largest magnitude the format produces at scale 1 (bounds the fixed-point range)
+    long long *acc;           // [strip][64] fixed-point column sums, zero between launches
+    unsigned int *ticket;     // [strip]
+    uint16_t *colsum_out;     // [cols] bf16
+};
+
+template <int KIND>
+__device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
+    if (s == 1.0f) return fq_vec<kIoBf16, KIND, kDivUnit, true>(v, dv, rnd, amax);
+    if (dv.safe) return fq_vec<kIoBf16, KIND, kDivFast, true>(v, dv, rnd, amax);
+    return fq_vec<kIoBf16, KIND, kDivExact, true>(v, dv, rnd, amax);
+}
+
+template <int KIND, int NS>
+__global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
+    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    const int t = threadIdx.x;
+    const int v = t % kChainStripV, rl = t / kChainStripV;
+    const int strip = blockIdx.x % a.strips, band = blockIdx.x / a.strips;
+    const int cvec = strip * kChainStripV + v;
+    const bool live = cvec < a.cv;
+    float sc[NS];
+    uint32_t amax[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        sc[i] = a.st[i].scale ? qt_bf2f(qt_f2bf(*a.st[i].scale)) : 1.0f;       // scale.to(X.dtype), as the single passes do
+        amax[i] = 0u;
+    }
+    float col[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long r_begin = (long)band * a.band_rows, r_end = min(a.rows, r_begin + a.band_rows);
+    constexpr int kChainUnroll = KIND == kFmtRows ? 2 : 4;      // rows in flight per lane (the row form keeps eight table rows live per vector)
+    if (live) {
+        for (long r0 = r_begin + rl; r0 < r_end; r0 += (long)kChainRowLanes * kChainUnroll) {
+            uint4 q[kChainUnroll];
+#pragma unroll
+            for (int u = 0; u < kChainUnroll; ++u) {
+                const long r = r0 + (long)u * kChainRowLanes;
+                if (r < r_end) q[u] = a.x[r * a.cv + cvec];
+            }
+#pragma unroll
+            for (int u = 0; u < kChainUnroll; ++u) {
+                const long r = r0 + (long)u * kChainRowLanes;
+                if (r >= r_end) continue;
+                uint4 res[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    uint4 in = q[u];
+#pragma unroll
+                    for (int j = 0; j < i; ++j)
+                        if (a.st[i].src == j) in = res[j];
+                    const UniformDiv dv(sc[i]);
+                    res[i] = chain_apply<KIND>(in, sc[i], dv, rnd, amax[i]);
+                    if (a.st[i].out) a.st[i].out[r * a.cv + cvec] = res[i];
+                    if (a.colsum_stage == i) {
+                        col[0] += qt_u2f(res[i].x << 16); col[1] += qt_u2f(res[i].x & 0xFFFF0000u);
+                        col[2] += qt_u2f(res[i].y << 16); col[3] += qt_u2f(res[i].y & 0xFFFF0000u);
+                        col[4] += qt_u2f(res[i].z << 16); col[5] += qt_u2f(res[i].z & 0xFFFF0000u);
+                        col[6] += qt_u2f(res[i].w << 16); col[7] += qt_u2f(res[i].w & 0xFFFF0000u);
+                    }
+                }
+            }
+        }
+    }
+    // ---- amax of every stage's input: wave, then workgroup, then at most one atomic per stage and workgroup
+    __shared__ uint32_t s_amax[NS][kChainBlock / 64];
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const uint32_t m = wave_max_u32(amax[i]);
+        if (lane == 0) s_amax[i][wave] = m;
+    }
+    __shared__ float s_col[kChainRowLanes][kChainStripV * 8 + 1];
+    if (a.colsum_stage >= 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_col[rl][v * 8 + e] = col[e];
+    }
+    __syncthreads();
+    // (compile-time stage indices only: a run-time index into the kernel-argument struct makes hipcc copy it to scratch memory and read
+    // every field from there, inside the row loop too)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (t == i * 64 && a.st[i].amax) {                       // one lane of wave i
+            uint32_t m = s_amax[i][0];
+#pragma unroll
+            for (int k = 1; k < kChainBlock / 64; ++k) m = m > s_amax[i][k] ? m : s_amax[i][k];
+            if (m != 0u && m > __hip_atomic_load(a.st[i].amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.st[i].amax, m);
+        }
+    }
+    if (a.colsum_stage < 0) return;
+    // ---- column sums: the row lanes of a column in a fixed-order tree; then the bands of a strip meet in 64-bit FIXED-POINT accumulators
+    // by agent-scope atomic adds -- integer addition is associative, so the result does not depend on the arrival order, and atomics are
+    // coherent across the XCDs' L2s without the release fence a plain hand-off would need (on this part that fence writes back the whole
+    // L2: + 30 us behind 12 MB of results, measured).  The band that draws the strip's last ticket reads the sums (atomically), rounds
+    // them to bf16 and leaves the accumulators zero.  Fixed point: one unit = 2^(E - 42), E = exponent of the largest value the stage
+    // can produce (format maximum x scale): a band's fp32 partial sum converts exactly unless it is below 2^-42 of that.
+    constexpr int kC = kChainStripV * 8;
+    for (int half = kChainRowLanes / 2; half >= 1; half >>= 1) {
+        for (int i = t; i < half * kC; i += kChainBlock) {
+            const int r = i / kC, c = i % kC;
+            s_col[r][c] += s_col[r + half][c];
+        }
+        __syncthreads();
+    }
+    float s_cs = 1.0f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (a.colsum_stage == i) s_cs = sc[i];
+    int E;
+    (void)frexpf(a.colsum_max * s_cs, &E);                          // max value < 2^E
+    long long *acc = a.acc + (size_t)strip * kC;
+    if (a.bands == 1) {
+        const int c = strip * kC + t;
+        if (t < kC && c < a.cv * 8) a.colsum_out[c] = (uint16_t)(pack_bf16x2(s_col[0][t], 0.0f) & 0xFFFFu);
+        return;
+    }
+    if (t < kC) {
+        const float part = s_col[0][t];
+        long long fx = (part == part && fabsf(part) < 3.0e38f) ? (long long)rintf(ldexpf(part, 42 - E)) : 0ll;
+        // a NaN / Inf in a column is recorded in the accumulator's top bits (bit 62 set survives any sum of 2^53-sized terms)
+        if (!(part == part && fabsf(part) < 3.0e38f)) fx = 1ll << 62;
+        (void)__hip_atomic_fetch_add(acc + t, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // returning form: performed when it returns
+    }
+    __syncthreads();
+    __shared__ unsigned int s_old;
+    if (t == 0) s_old = __hip_atomic_fetch_add(a.ticket + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_old != (unsigned)a.bands - 1u) return;
+    if (t == 0) __hip_atomic_store(a.ticket + strip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < kC) {
+        const int c = strip * kC + t;
+        const long long fx = __hip_atomic_exchange(acc + t, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read and re-zero
+        float sum = ldexpf((float)fx, E - 42);
+        if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
+        if (c < a.cv * 8) a.colsum_out[c] = (uint16_t)(pack_bf16x2(sum, 0.0f) & 0xFFFFu);
+    }
 }
 
 // ---- OCP FP8 side output ------------------------------------------------------------------------
@@ -1022,6 +1187,17 @@ constexpr size_t kLutLdsMinElems = (size_t)1 << 21;
 #ifdef QT_TUNING_BUILD
 int g_variant = 0;        // tools/exp_stream.py: selects a launch geometry for bf16 closed-form passes
 #endif
+// Observed SHORT passes (the [2048, 768 .. 3072] tensors of a training step): 16-byte loads in flight per lane, i.e. how few
+// workgroups -- and same-address atomics on the freshly zeroed amax slot -- the launch has.  (Measured in the training step, round 5:
+// 1 or 2 makes no difference, 9.0 against 9.1 us per launch.)
+inline int obs_unroll() {
+#ifdef QT_TUNING_BUILD
+    static const int v = getenv("QT_OBS_UNR") ? atoi(getenv("QT_OBS_UNR")) : 1;
+    return v;
+#else
+    return 1;
+#endif
+}
 int g_blocks_per_cu = 32;
 
 template <int IO, int KIND, int BLOCK, int UNR, int NT>
@@ -1061,7 +1237,8 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
             }
 #endif
             if (IO == kIoBf16 && nv <= kRowsDirectMaxVecs) {           // short pass: the table where it lies (fq_rows_direct_kernel)
-                if (amax) fq_rows_direct_kernel<IO, true, 1024><<<grid_for(nv, 1024, 2), 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                if (amax && obs_unroll() == 2) fq_rows_direct_kernel<IO, true, 1024, 2><<<grid_for(nv, 2048, 2), 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
+                else if (amax) fq_rows_direct_kernel<IO, true, 1024><<<grid_for(nv, 1024, 2), 1024, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
                 else fq_rows_direct_kernel<IO, false, 256><<<grid_for(nv, 256, 8), 256, 0, st>>>(x, y, nv, n, fmt, lut, scale, amax);
                 return launch_status();
             }
@@ -1136,7 +1313,9 @@ int launch_fq_kind(const void *x, void *y, size_t n, const qt_format &fmt, const
         }
 #endif
         unsigned grid = grid_for(nvec, (size_t)kAluBlock * kUnroll, g_blocks_per_cu);
-        if (amax && nvec <= kRowsDirectMaxVecs)     // observed short pass: a quarter of the workgroups, i.e. of the same-address atomics
+        if (amax && nvec <= kRowsDirectMaxVecs && obs_unroll() == 2)     // observed short pass: an eighth of the workgroups, two loads in flight per lane
+            fq_kernel<IO, KIND, true, 1024, 2><<<grid_for(nvec, 2048, 2), 1024, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
+        else if (amax && nvec <= kRowsDirectMaxVecs)     // observed short pass: a quarter of the workgroups, i.e. of the same-address atomics
             fq_kernel<IO, KIND, true, 1024><<<grid_for(nvec, 1024, 2), 1024, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
         else if (amax)
             fq_kernel<IO, KIND, true, kAluBlock><<<grid, kAluBlock, 0, st>>>(x, y, nvec, n, fmt, lut, scale, amax);
@@ -1327,6 +1506,72 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     }
 #undef QT_FQ8
     return launch_status();
+}
+
+// strips x bands of one chain launch: about 192 workgroups, bands of whole 64-row groups, at most 32 bands
+static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows) {
+    strips = (int)((cols / 8 + kChainStripV - 1) / kChainStripV);
+    const long groups = (rows + kChainRowLanes - 1) / kChainRowLanes;           // 64-row groups
+    long want = (192 + strips - 1) / strips;
+    if (want < 1) want = 1;
+    if (want > 32) want = 32;
+    if (want > groups) want = groups;
+    const long per = (groups + want - 1) / want;
+    band_rows = per * kChainRowLanes;
+    bands = (int)((groups + per - 1) / per);
+}
+
+int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
+                             const uint16_t *lut_dev, int colsum_stage, float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes,
+                             void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x_dev || !stages || !fmt || nstage < 1 || nstage > kChainMax || rows < 0 || cols < 8 || cols % 8 != 0) return QT_ERR_BAD_ARG;
+    if ((uintptr_t)x_dev & 15u) return QT_ERR_UNALIGNED;
+    ChainArgs a{};
+    a.x = (const uint4 *)x_dev; a.rows = rows; a.cv = (int)(cols / 8); a.nstage = nstage;
+    for (int i = 0; i < nstage; ++i) {
+        if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
+        if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
+        a.st[i] = ChainStageDev{stages[i].scale_f32_dev, stages[i].amax_bits_dev, (uint4 *)stages[i].out_dev, stages[i].src};
+    }
+    chain_geometry(rows, cols, a.strips, a.bands, a.band_rows);
+    a.colsum_stage = -1;
+    if (colsum_stage >= 0) {
+        if (colsum_stage >= nstage || !colsum_out_dev || !(colsum_max > 0.0f) || !(colsum_max < 3.0e38f)) return QT_ERR_BAD_ARG;
+        if (a.bands > 1 && (!ws_dev || ws_bytes < qt_fake_quant_chain_ws_bytes(rows, cols))) return QT_ERR_BAD_ARG;
+        if (((uintptr_t)ws_dev & 15u) || ((uintptr_t)colsum_out_dev & 1u)) return QT_ERR_UNALIGNED;
+        a.colsum_stage = colsum_stage; a.colsum_max = colsum_max; a.colsum_out = colsum_out_dev;
+        a.acc = (long long *)ws_dev;
+        a.ticket = (unsigned int *)((char *)ws_dev + (size_t)a.strips * kChainStripV * 8 * sizeof(long long));
+    }
+    const unsigned grid = (unsigned)(a.strips * a.bands);
+    hipStream_t st = (hipStream_t)stream;
+#define QT_CHAIN(K, NS) fq_chain_kernel<K, NS><<<grid, kChainBlock, 0, st>>>(a, *fmt, lut_dev)
+#define QT_CHAIN_NS(K)                                                                  \
+    switch (nstage) {                                                                   \
+        case 1: QT_CHAIN(K, 1); break;                                                  \
+        case 2: QT_CHAIN(K, 2); break;                                                  \
+        case 3: QT_CHAIN(K, 3); break;                                                  \
+        default: QT_CHAIN(K, 4); break;                                                 \
+    }
+    switch (fmt->kind) {
+        case QT_FMT_LUT:
+            if (!lut_dev || !(fmt->p1 & 1)) return QT_ERR_BAD_DTYPE;             // table formats in their row form only
+            QT_CHAIN_NS(kFmtRows)
+            break;
+        case QT_FMT_FP_SAT: QT_CHAIN_NS(QT_FMT_FP_SAT) break;
+        case QT_FMT_INT: QT_CHAIN_NS(QT_FMT_INT) break;
+        default: return QT_ERR_BAD_DTYPE;
+    }
+#undef QT_CHAIN_NS
+#undef QT_CHAIN
+    return launch_status();
+}
+
+size_t qt_fake_quant_chain_ws_bytes(long rows, long cols) {
+    if (rows <= 0 || cols < 8 || cols % 8) return 0;
+    const size_t strips = (size_t)((cols / 8 + kChainStripV - 1) / kChainStripV);
+    return strips * kChainStripV * 8 * sizeof(long long) + strips * sizeof(unsigned int);      // accumulators, then tickets
 }
 
 int qt_fake_quant_rows_bf16(const uint16_t *x, uint16_t *y, long d0, long d1, long d2, long inner, long s0, long s1,

@@ -609,8 +609,11 @@ struct LinearFqt {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            // (RELAXED on purpose: the ordering is the sc1 stores + s_waitcnt + barrier in front and the sc1 loads behind -- valid on gfx942 /
+            // gfx950, which qt_device.h asserts at compile time; an agent-scope acquire / release here writes back and invalidates the
+            // whole L2, behind 20 MB of partial sums)
             if (w == 0 && l == 0) {
-                const unsigned int old = __hip_atomic_fetch_add(a.tickets + tile_lin, 1u + (flagged ? 0x10000u : 0u), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int old = __hip_atomic_fetch_add(a.tickets + tile_lin, 1u + (flagged ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *flag = (int)old;
             }
             __syncthreads();
@@ -618,6 +621,9 @@ struct LinearFqt {
             if ((int)(old & 0xFFFFu) != a.ksplit - 1) return false;               // not the last one: done
             if (w == 0 && l == 0) __hip_atomic_store(a.tickets + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((old >> 16) != 0u || flagged) return true;                        // some split met a flagged row: redo the tile
+            // reader's side: whatever this XCD's L2 still holds of the workspace from an earlier launch is dropped (acquire = invalidate,
+            // nothing is written back; only the owner of a tile pays it)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if constexpr (NTW > 0) {
                 // Every split's partial sums come back from the workspace, this workgroup's own included (no instruction depends
                 // on which split arrived last): t = p_0 + p_1 + ... in split order, + bias, rounded to bf16, stored straight from

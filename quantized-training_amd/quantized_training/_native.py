@@ -35,6 +35,10 @@ class QtOperandQ(ctypes.Structure):
     _fields_ = [("fmt", QtFormat), ("lut_dev", c_void_p), ("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p)]
 
 
+class QtChainStage(ctypes.Structure):
+    _fields_ = [("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p), ("out_dev", c_void_p), ("src", ctypes.c_int)]
+
+
 class QtRowParams(ctypes.Structure):
     """Row form of a value map (qt_build_rowparams): 512 rows {D, C | flagged bit, lo, hi}, see include/qt_hip.h."""
     _fields_ = [("row", (c_uint32 * 4) * 512), ("signed_rows", ctypes.c_int32), ("sign_mask", c_uint32),
@@ -82,6 +86,8 @@ SIGNATURES = {
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "qt_fake_quant_chain_bf16": (c_int, [_P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
+    "qt_fake_quant_chain_ws_bytes": (c_size_t, [c_long, c_long]),
     "qt_build_rowparams": (c_int, [_P, POINTER(QtRowParams)]),
     "qt_rowparams_apply_host": (c_uint16, [POINTER(QtRowParams), c_uint16, POINTER(c_int)]),
     "qt_linear_fqt_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P]),

@@ -791,6 +791,17 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
         self.__dict__["_qt_calls"] = self.__dict__.get("_qt_calls", 0) + 1      # harness.GraphedTrainStep reads this
+        if "_qt_chain_result" in self.__dict__ or "_qt_chain" in self.__dict__:
+            # training-step chains (train_fusions.py): a chain launch already evaluated this call, or this call heads a chain
+            from . import train_fusions
+            out = train_fusions.take_member_result(self, X)
+            if out is not None:
+                return out
+            chain = self.__dict__.get("_qt_chain")
+            if chain is not None:
+                out = train_fusions.run_chain(self, chain, X)
+                if out is not None:
+                    return out
         done_by = getattr(X, "_qt_fq_done_by", None)
         if done_by is self and handover_valid(X):
             # the kernel that produced X already applied this fake-quantizer (and attached X._qt_fp8): the call the

@@ -362,7 +362,9 @@ def train_steps(model, batches, optimizer, lr_scheduler=None, max_grad_norm: flo
     model.train()
     device = next(model.parameters()).device
     losses = []
+    from . import train_fusions
     for step, batch in enumerate(batches):
+        train_fusions.ensure_planned(model)                 # launch fusions over the fake-quantizers that exist by now (values unchanged)
         batch = {k: v.to(device) for k, v in batch.items()}
         loss = model(**batch).loss
         losses.append(float(loss.detach().float()))
@@ -430,6 +432,8 @@ class GraphedTrainStep:
                     self.lr_scheduler.step()
                 if i == 0:                 # the first step created the lazily built fake-quantizers
                     fqs = [mod for mod in self.model.modules() if isinstance(mod, FusedAmaxObsFakeQuantize)]
+                    from . import train_fusions
+                    train_fusions.ensure_planned(self.model)      # chains of fake-quantizer calls as single launches (train_fusions.py)
             if self.batch_scale_updates:
                 # those a step calls (at least once: a second call in the same step does its own update as before)
                 self.scales = BatchedScaleUpdate([f for f in fqs if f.__dict__.get("_qt_calls", 0) >= 1], device)

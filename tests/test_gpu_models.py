@@ -896,6 +896,166 @@ def test_full_size_llama_13b_decoder_layer_against_the_cpu_path(monkeypatch):
     assert float(d.pow(2).mean().sqrt()) <= 0.01 * scale and float(d.max()) <= 0.1 * scale, (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale)
 
 
+_TRAIN_FLAGS = ("--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric", "--error",
+                "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual", "--bf16")
+
+
+def _roberta_layer_training_run(dev, base, batches, graphed=False):
+    """Three steps of the reference's training loop (run_glue_no_trainer.py:647-667) on a copy of `base` on `dev`; from the second step
+    on every fake-quantizer call (forward activations / weights AND the gradient fake-quantizers of the backward hooks) is tapped as its
+    CODES, output / scale, with the scale the call applied.  Returns (taps, losses, delayed-scaling state, parameters after the steps)."""
+    import copy
+    from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+    m = copy.deepcopy(base).to(dev).train()
+    qt.quantize(m, _args(*_TRAIN_FLAGS))
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
+    taps, losses = {}, []
+
+    def hook(name):
+        def fn(mod, args, out):
+            t = out[0] if isinstance(out, tuple) else out
+            if isinstance(t, torch.Tensor) and mod.scale.numel() == 1:
+                taps.setdefault(name, []).append((t.detach().float() / mod.scale.detach().float()).cpu())
+        return fn
+    hs = []
+    for i, b in enumerate(batches):
+        if i == 1:
+            hs = [mod.register_forward_hook(hook(n)) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)]
+        losses += harness.train_steps(m, [b], opt)
+    for h in hs:
+        h.remove()
+    state = {n: (mod.scale.detach().float().cpu().reshape(-1), mod.amax_history.detach().float().cpu().reshape(-1))
+             for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize) and mod.amax_history.numel() > 0}
+    params = {n: p.detach().float().cpu() for n, p in m.named_parameters()}
+    return taps, losses, state, params
+
+
+def test_full_size_roberta_layer_training_steps_against_the_cpu_path():
+    """BASELINE configs[4] at full width: one RoBERTa-base layer (hidden 768, 12 heads, FFN 3072) + classifier, batches [16, 128], bf16,
+    int8 activations and weights with delayed scaling, E5M2 gradients through the backward hooks (quantize.py:116-179,
+    fake_quantize.py:217-246), clip 1.0 + AdamW, THREE steps (so the delayed-scaling state machine is compared too) -- device against
+    CPU tensors (the path pinned to the reference's traces by tests/test_blocks_golden.py).  Per fake-quantizer call of steps 2 and 3:
+    the device's codes (output / applied scale) are integers in [-128, 127] resp. E5M2 values, and differ from the CPU run's by at
+    most one code step on a bounded share of elements (a GEMM summed in another order moves an input across a rounding boundary;
+    a scale that differs in its last bits moves every boundary a little).  Scales and amax histories agree to bf16 resolution, losses
+    to 1 %, updated parameters to the size of one AdamW step."""
+    import numpy as np
+    from oracle import qt_oracle as o
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072, vocab_size=1000,
+                        max_position_embeddings=132, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base = RobertaForSequenceClassification(cfg).bfloat16()
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 1000, (16, 128), generator=g), "labels": torch.randint(0, 2, (16,), generator=g)} for _ in range(3)]
+    cpu = _roberta_layer_training_run("cpu", base, batches)
+    dev = _roberta_layer_training_run("cuda", base, batches)
+    e5 = o.bf16_to_f32(o.get_quantization_map("fp8_e5m2"))
+    e5grid = np.unique(e5[np.isfinite(e5)].astype(np.float64))
+    igrid = np.arange(-128, 128, dtype=np.float64)
+    fwd = bwd = 0
+    report = []
+    worst = {"fwd": 0.0, "bwd": 0.0}
+    far = {"fwd": 0, "bwd": 0}
+    total = {"fwd": 0, "bwd": 0}
+    common = [k for k in cpu[0] if k in dev[0] and len(cpu[0][k]) == len(dev[0][k])]
+    assert len(common) >= 0.9 * len(cpu[0]) and len(common) >= 30, (len(common), len(cpu[0]), len(dev[0]))
+    for k in common:
+        kind = "bwd" if ("error_pre_process" in k or "error_post_process" in k) else "fwd"
+        grid = e5grid if kind == "bwd" else igrid
+        for a, b in zip(cpu[0][k], dev[0][k]):
+            if a.shape != b.shape:
+                continue
+            a, b = a.numpy().astype(np.float64).ravel(), b.numpy().astype(np.float64).ravel()
+            # codes = value / scale, both bf16-rounded products: snap to the grid (a code times a scale divided by that scale is the code
+            # up to 2^-8 relative)
+            ia, ib = np.searchsorted(grid, a * (1 - 2.0 ** -7) if False else a), np.searchsorted(grid, b)
+            ia = np.clip(ia, 0, grid.size - 1); ib = np.clip(ib, 0, grid.size - 1)
+            ia = np.where((ia > 0) & (np.abs(grid[ia - 1] - a) < np.abs(grid[ia] - a)), ia - 1, ia)
+            ib = np.where((ib > 0) & (np.abs(grid[ib - 1] - b) < np.abs(grid[ib] - b)), ib - 1, ib)
+            on = np.abs(grid[ib] - b) <= np.maximum(np.abs(b), 2.0 ** -16) * 2.0 ** -6
+            assert on[:: max(1, on.size // 200000)].all(), (k, "device codes off the grid")
+            steps = np.abs(ia - ib)
+            report.append((float((steps > 0).mean()), float((steps > 1).mean()), k))
+            worst[kind] = max(worst[kind], float((steps > 0).mean()))
+            far[kind] += int((steps > 1).sum())
+            total[kind] += steps.size
+            fwd += kind == "fwd"
+            bwd += kind == "bwd"
+    assert fwd >= 20 and bwd >= 20, (fwd, bwd)
+    print(f"\n[roberta layer, 3 steps] taps fwd {fwd} bwd {bwd}; worst share one step away fwd {worst['fwd']:.4f} bwd {worst['bwd']:.4f}; "
+          f"further: fwd {far['fwd'] / max(total['fwd'], 1):.2e} bwd {far['bwd'] / max(total['bwd'], 1):.2e}")
+    for share, farshare, k in sorted(report, reverse=True)[:16]:
+        print(f"    {share:.4f} one step, {farshare:.2e} further: {k}")
+    for k in sorted(cpu[2]):
+        print(f"    scale cpu {float(cpu[2][k][0][0]):.6g} dev {float(dev[2][k][0][0]):.6g}  amax[0] cpu {float(cpu[2][k][1][0]):.6g} dev {float(dev[2][k][1][0]):.6g}  {k}")
+    assert worst["fwd"] <= 0.05 and far["fwd"] / max(total["fwd"], 1) <= 2e-3, (worst, far, total)
+    assert worst["bwd"] <= 0.10 and far["bwd"] / max(total["bwd"], 1) <= 5e-3, (worst, far, total)
+    # delayed-scaling state after three steps
+    assert set(cpu[2]) == set(dev[2])
+    for k in cpu[2]:
+        for a, b in zip(cpu[2][k], dev[2][k]):
+            assert a.shape == b.shape, k
+            assert bool(((a - b).abs() <= 2.0 ** -6 * torch.maximum(a.abs(), b.abs()) + 1e-30).all()), (k, a, b)
+    for lc, ld in zip(cpu[1], dev[1]):
+        assert abs(lc - ld) <= 1e-2 * abs(lc) + 1e-3, (cpu[1], dev[1])
+    for k in cpu[3]:
+        d = (cpu[3][k] - dev[3][k]).abs().max()
+        assert float(d) <= 3 * 3 * 2e-5 + 2.0 ** -7 * float(cpu[3][k].abs().max()), (k, float(d))       # three AdamW steps of lr 2e-5, bf16 weights
+
+
+def test_training_chains_change_launches_not_values(monkeypatch):
+    """train_fusions: the fake-quantizer chains of a training step (one launch for the four gradient quantizers behind a LayerNorm, one
+    for the input quantizers of query / key / value, the bias gradient's column sums on the way) leave every value as it was: three
+    steps of a 2-layer RoBERTa-shaped classifier with and without chains -- losses, every fake-quantizer's scale and amax history and
+    every parameter bit-identical when the column sums stay with qt_colsum_bf16 (QT_TRAIN_COLSUM=0), and within one AdamW step's noise
+    with them (another, fixed summation order).  The counters say the chains ran, and that no member missed its tensor."""
+    import copy
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    from quantized_training import train_fusions
+    from quantized_training.fake_quantize import STATS, FusedAmaxObsFakeQuantize
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=500,
+                        max_position_embeddings=70, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base = RobertaForSequenceClassification(cfg).bfloat16()
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 500, (8, 64), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)} for _ in range(3)]
+
+    def run(chains, colsum):
+        monkeypatch.setenv("QT_TRAIN_CHAINS", "1" if chains else "0")
+        monkeypatch.setenv("QT_TRAIN_COLSUM", "1" if colsum else "0")
+        m = copy.deepcopy(base).cuda().train()
+        qt.quantize(m, _args(*_TRAIN_FLAGS))
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
+        train_fusions.STATS.reset()
+        STATS.reset()
+        losses = harness.train_steps(m, batches, opt)
+        state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
+        params = {n: p.detach().clone() for n, p in m.named_parameters()}
+        return losses, state, params, (train_fusions.STATS.chains, train_fusions.STATS.members, train_fusions.STATS.colsums,
+                                       train_fusions.STATS.misses), (STATS.elements, STATS.calls)
+    plain = run(False, False)
+    chained = run(True, False)
+    assert plain[3] == (0, 0, 0, 0)
+    # steps 2 and 3 run chained (the first step creates the fake-quantizers): per layer and step 2 gradient chains of 4, one q / k / v
+    # chain of 3, and single-member chains for the other Linears' grad_output quantizers
+    assert chained[3][0] >= 2 * 2 * 3 and chained[3][1] >= 2 * 2 * (4 + 4 + 3) and chained[3][2] == 0 and chained[3][3] == 0, chained[3]
+    assert chained[4] == plain[4]                                  # same fake-quantized element and call counts
+    assert chained[0] == plain[0]
+    for k in plain[1]:
+        assert torch.equal(plain[1][k][0], chained[1][k][0]) and torch.equal(plain[1][k][1], chained[1][k][1]), k
+    for k in plain[2]:
+        assert torch.equal(plain[2][k], chained[2][k]), k
+    full = run(True, True)
+    assert full[3][2] >= 2 * (2 * 6 + 2) and full[3][3] == 0, full[3]      # every biased Linear's gradient came with its column sums
+    assert full[4] == plain[4]
+    for a, b in zip(plain[0], full[0]):
+        assert abs(a - b) <= 2e-2 * abs(a) + 1e-3
+    for k in plain[2]:
+        d = (plain[2][k].float() - full[2][k].float()).abs().max()
+        assert float(d) <= 3 * 3 * 2e-5 + 2.0 ** -7 * float(plain[2][k].float().abs().max()), k
+
+
 def test_graphed_batch_runs_the_weight_passes_of_the_pair_route_as_one_launch():
     """BERT-base-shaped layers at [16, 384] (BASELINE configs[1]): three of the four Linear shapes take the weight pass + library FP8
     GEMM (fused._FQ8_TABLE); harness.GraphedBatch logs those passes during a warm-up forward and captures them as ONE launch

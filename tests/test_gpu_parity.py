@@ -1894,6 +1894,77 @@ def test_linear_fq8_vs_fp64_product_of_the_codes(nv, M, Ns, K, xdtype, wdtype):
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
 
 
+@pytest.mark.parametrize("dtype,scales", [("int8", (0.0173, 0.031, 1.0, 0.25)), ("fp8_e5m2", (3.1e-7, 1.7e-6, 2.0 ** -20, 1.0)),
+                                          ("e4m3", (1.0, 1.0, 0.37, 2.0))])
+@pytest.mark.parametrize("rows,cols", [(2048, 768), (2048, 3072), (77, 64), (1, 8), (4097, 1000)])
+def test_fake_quant_chain_equals_the_single_passes(nv, dtype, scales, rows, cols):
+    """qt_fake_quant_chain_bf16: four fake-quantizer calls over one tensor in ONE launch -- stage 0 on x, stages 1 and 2 on stage 0's
+    result, stage 3 on stage 1's (the gradient chain behind a LayerNorm, quantize.py:116-179) -- each bit for bit the result and the
+    amax of its own qt_fake_quant_bf16 launch (oracle-pinned elsewhere), for int8 (closed form), E5M2 as a table format in its row
+    form and E4M3 (closed form), scaled and unscaled; the column sums of stage 3's result equal its fp64 column sums rounded to bf16
+    within one bf16 step, and are run-to-run bit-identical."""
+    import quantized_training as qt_pkg
+    L = nv.lib()
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, device="cuda") * (scales[0] * 40)).bfloat16()
+    x.view(-1)[:: max(1, x.numel() // 7)] = 0.0
+    fmt = nv.format_for(dtype)
+    lut = qt_pkg.get_quantization_map(dtype, torch.device("cuda"))
+    from quantized_training.fake_quantize import _launch_format
+    fmt = _launch_format(fmt, lut)
+    src = (-1, 0, 0, 1)
+    sc = [torch.tensor([s_], dtype=torch.float32, device="cuda") for s_ in scales]
+    # reference: one launch per stage
+    want, want_amax, outs = [], [], []
+    for i in range(4):
+        inp = x if src[i] < 0 else want[src[i]]
+        y = torch.empty_like(inp)
+        am = torch.zeros(1, dtype=torch.float32, device="cuda")
+        nv.check(L.qt_fake_quant_bf16(inp.data_ptr(), y.data_ptr(), inp.numel(), ctypes.byref(fmt), lut.data_ptr(), sc[i].data_ptr(), am.data_ptr(),
+                                      stream()), "qt_fake_quant_bf16")
+        want.append(y)
+        want_amax.append(am)
+    for nstage in (4, 1, 3):
+        outs = [torch.full_like(x, float("nan")) for _ in range(nstage)]
+        amax = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(nstage)]
+        stages = (nv.QtChainStage * nstage)()
+        for i in range(nstage):
+            stages[i].scale_f32_dev = sc[i].data_ptr()
+            stages[i].amax_bits_dev = amax[i].data_ptr()
+            stages[i].out_dev = outs[i].data_ptr()
+            stages[i].src = src[i]
+        cs = nstage - 1
+        wb = L.qt_fake_quant_chain_ws_bytes(rows, cols)
+        assert wb > 0
+        ws = torch.zeros(wb, dtype=torch.uint8, device="cuda")
+        gb = torch.empty(cols, dtype=torch.bfloat16, device="cuda")
+        fmax = float(np.abs(o.bf16_to_f32(o.get_quantization_map(dtype))[np.isfinite(o.bf16_to_f32(o.get_quantization_map(dtype)))]).max())
+        nv.check(L.qt_fake_quant_chain_bf16(x.data_ptr(), rows, cols, stages, nstage, ctypes.byref(fmt), lut.data_ptr(), cs, fmax, gb.data_ptr(),
+                                            ws.data_ptr(), wb, stream()), "qt_fake_quant_chain_bf16")
+        torch.cuda.synchronize()
+        assert not bool(ws.any())                                   # accumulators and tickets are left zero
+        for i in range(nstage):
+            assert torch.equal(outs[i].view(torch.int16), want[i].view(torch.int16)), (nstage, i)
+            assert torch.equal(amax[i].view(torch.int32), want_amax[i].view(torch.int32)), (nstage, i)
+        ref = want[cs].double().sum(0)
+        got = gb.double()
+        tol = ref.abs() * 2.0 ** -7 + want[cs].double().abs().sum(0) * 2.0 ** -20 + 1e-30
+        assert bool(((got - ref).abs() <= tol).all()), (nstage, float(((got - ref).abs() / tol).max()))
+        for _ in range(3):
+            gb2 = torch.empty_like(gb)
+            nv.check(L.qt_fake_quant_chain_bf16(x.data_ptr(), rows, cols, stages, nstage, ctypes.byref(fmt), lut.data_ptr(), cs, fmax, gb2.data_ptr(),
+                                                ws.data_ptr(), wb, stream()), "qt_fake_quant_chain_bf16")
+            assert torch.equal(gb.view(torch.int16), gb2.view(torch.int16))
+    # what it refuses
+    stages[0].src = 0
+    assert L.qt_fake_quant_chain_bf16(x.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), lut.data_ptr(), -1, 0.0, None, None, 0,
+                                      stream()) == nv.QT_ERR_BAD_ARG
+    stages[0].src = -1
+    if rows > 64:
+        assert L.qt_fake_quant_chain_bf16(x.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), lut.data_ptr(), 0, fmax, gb.data_ptr(), ws.data_ptr(), 4,
+                                          stream()) == nv.QT_ERR_BAD_ARG
+
+
 def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
     """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
     the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,
