@@ -1,0 +1,120 @@
+// qt_chain.h -- one 16-byte vector through a fake-quantizer (shared by the elementwise, chain and training kernels), and the stage
+// description of qt_fake_quant_chain_bf16: several fake-quantizer calls of a training step applied to values a kernel holds in registers.
+#pragma once
+#include "qt_device.h"
+
+namespace {
+
+constexpr int kIoBf16 = 0;
+constexpr int kIoF32 = 1;
+
+template <int IO, int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint4 fq_vec_d(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax, bool &bad) {
+    if constexpr (IO == kIoBf16 && KIND == kFmtRows) {
+        // the row form on all eight values at once (csrc/qt_device.h, fq_rows_words): eight row gathers in flight and one rare branch per
+        // vector instead of a gather, a wait and a branch per value -- what a short pass (one vector per lane) spends its time on
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t q[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = w[i] << 16, hi = w[i] & 0xFFFF0000u;
+            if constexpr (OBS) {
+                const uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+                amax = amax > a0 ? amax : a0;     // integer order == float order on |x|; NaN patterns win -> propagate
+                amax = amax > a1 ? amax : a1;
+            }
+            if constexpr (DIV == kDivFast) q[i] = pack_bf16x2(dv.fast16(qt_u2f(lo), bad), dv.fast16(qt_u2f(hi), bad));
+            else if constexpr (DIV == kDivExact) q[i] = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
+            else q[i] = w[i];
+        }
+        fq_rows_words<4, false>(q, r, rnd);
+        if constexpr (DIV != kDivUnit) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(qt_u2f(r[i] << 16) * dv.s, qt_u2f(r[i] & 0xFFFF0000u) * dv.s);
+        }
+        v = uint4{r[0], r[1], r[2], r[3]};
+    } else if constexpr (IO == kIoBf16) {
+        v.x = fq_word_bf16_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
+        v.y = fq_word_bf16_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
+        v.z = fq_word_bf16_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
+        v.w = fq_word_bf16_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
+    } else {
+        v.x = fq_word_f32_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
+        v.y = fq_word_f32_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
+        v.z = fq_word_f32_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
+        v.w = fq_word_f32_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
+    }
+    return v;
+}
+
+// One 16-B vector.  With a non-unit scale the fast quotient is tried first and the whole vector is redone
+// with the full division only if one of its elements left the range where the fast form is exact.
+template <int IO, int KIND, int DIV, bool OBS>
+__device__ __forceinline__ uint4 fq_vec(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
+    bool bad = false;
+    uint4 r = fq_vec_d<IO, KIND, DIV, OBS>(v, dv, rnd, amax, bad);
+    if constexpr (DIV == kDivFast) {
+        if (__builtin_expect(bad, 0)) {
+            uint32_t unused = 0;
+            r = fq_vec_d<IO, KIND, kDivExact, false>(v, dv, rnd, unused, bad);
+        }
+    }
+    return r;
+}
+
+// ---- stages of a chain (include/qt_hip.h, qt_chain_stage): stage i reads the producer's value (src -1) or the result of stage src < i
+constexpr int kChainMax = 4;
+struct ChainStageDev {
+    const float *scale;
+    uint32_t *amax;
+    uint4 *out;
+    int src;                  // -1: x; else the stage whose result this one reads
+};
+
+template <int KIND>
+__device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
+    if (s == 1.0f) return fq_vec<kIoBf16, KIND, kDivUnit, true>(v, dv, rnd, amax);
+    if (dv.safe) return fq_vec<kIoBf16, KIND, kDivFast, true>(v, dv, rnd, amax);
+    return fq_vec<kIoBf16, KIND, kDivExact, true>(v, dv, rnd, amax);
+}
+
+// All stages of a chain on one vector `v` (the producer's bf16 values): results written where a stage has an output, amax of every
+// stage's input accumulated, res[] left for the caller (column sums).  Stage indices are compile-time (a run-time index into the
+// kernel-argument struct would send it to scratch memory).
+template <int KIND, int NS>
+__device__ __forceinline__ void chain_stages(const ChainStageDev (&st)[kChainMax], const float (&sc)[NS], const Rounder<KIND> &rnd, uint4 v,
+                                             size_t index, uint32_t (&amax)[NS], uint4 (&res)[NS]) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        uint4 in = v;
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+            if (st[i].src == j) in = res[j];
+        const UniformDiv dv(sc[i]);
+        res[i] = chain_apply<KIND>(in, sc[i], dv, rnd, amax[i]);
+        if (st[i].out) st[i].out[index] = res[i];
+    }
+}
+
+// amax of every stage: wave, workgroup (LDS [NS][BLOCK / 64]), then at most one atomic per stage and workgroup
+template <int NS, int BLOCK>
+__device__ __forceinline__ void chain_amax_commit(const ChainStageDev (&st)[kChainMax], const uint32_t (&amax)[NS], uint32_t (*s_amax)[BLOCK / 64]) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const uint32_t m = wave_max_u32(amax[i]);
+        if (lane == 0) s_amax[i][wave] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (t == i * 64 && st[i].amax) {                         // one lane of wave i
+            uint32_t m = s_amax[i][0];
+#pragma unroll
+            for (int k = 1; k < BLOCK / 64; ++k) m = m > s_amax[i][k] ? m : s_amax[i][k];
+            if (m != 0u && m > __hip_atomic_load(st[i].amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st[i].amax, m);
+        }
+    }
+}
+
+}  // namespace

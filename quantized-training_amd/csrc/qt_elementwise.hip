@@ -17,73 +17,17 @@
 #include <stdlib.h>
 
 #include "qt_device.h"
+#include "qt_chain.h"
 
 extern "C" float qt_internal_posit_threshold(int nbits, int es);
 extern "C" int qt_internal_fp8_emin(float fp8_min);
 
 namespace {
 
-constexpr int kIoBf16 = 0;
-constexpr int kIoF32 = 1;
-
 constexpr int kLutBlock = 1024;   // one workgroup per CU (128 KiB LDS), 16 waves
 constexpr int kAluBlock = 256;
 constexpr int kUnroll = 1;        // 16-B loads per lane per tile (measured best: many small tiles)
 constexpr size_t kRowsDirectMaxVecs = (size_t)256 * 8 * 256 * 2;   // row form: up to two vectors per lane of a full chip read the table from global memory
-
-template <int IO, int KIND, int DIV, bool OBS>
-__device__ __forceinline__ uint4 fq_vec_d(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax, bool &bad) {
-    if constexpr (IO == kIoBf16 && KIND == kFmtRows) {
-        // the row form on all eight values at once (csrc/qt_device.h, fq_rows_words): eight row gathers in flight and one rare branch per
-        // vector instead of a gather, a wait and a branch per value -- what a short pass (one vector per lane) spends its time on
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t q[4], r[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = w[i] << 16, hi = w[i] & 0xFFFF0000u;
-            if constexpr (OBS) {
-                const uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
-                amax = amax > a0 ? amax : a0;     // integer order == float order on |x|; NaN patterns win -> propagate
-                amax = amax > a1 ? amax : a1;
-            }
-            if constexpr (DIV == kDivFast) q[i] = pack_bf16x2(dv.fast16(qt_u2f(lo), bad), dv.fast16(qt_u2f(hi), bad));
-            else if constexpr (DIV == kDivExact) q[i] = pack_bf16x2(dv.exact(qt_u2f(lo)), dv.exact(qt_u2f(hi)));
-            else q[i] = w[i];
-        }
-        fq_rows_words<4, false>(q, r, rnd);
-        if constexpr (DIV != kDivUnit) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(qt_u2f(r[i] << 16) * dv.s, qt_u2f(r[i] & 0xFFFF0000u) * dv.s);
-        }
-        v = uint4{r[0], r[1], r[2], r[3]};
-    } else if constexpr (IO == kIoBf16) {
-        v.x = fq_word_bf16_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
-        v.y = fq_word_bf16_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
-        v.z = fq_word_bf16_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
-        v.w = fq_word_bf16_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
-    } else {
-        v.x = fq_word_f32_d<KIND, DIV, OBS>(v.x, dv, rnd, amax, bad);
-        v.y = fq_word_f32_d<KIND, DIV, OBS>(v.y, dv, rnd, amax, bad);
-        v.z = fq_word_f32_d<KIND, DIV, OBS>(v.z, dv, rnd, amax, bad);
-        v.w = fq_word_f32_d<KIND, DIV, OBS>(v.w, dv, rnd, amax, bad);
-    }
-    return v;
-}
-
-// One 16-B vector.  With a non-unit scale the fast quotient is tried first and the whole vector is redone
-// with the full division only if one of its elements left the range where the fast form is exact.
-template <int IO, int KIND, int DIV, bool OBS>
-__device__ __forceinline__ uint4 fq_vec(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
-    bool bad = false;
-    uint4 r = fq_vec_d<IO, KIND, DIV, OBS>(v, dv, rnd, amax, bad);
-    if constexpr (DIV == kDivFast) {
-        if (__builtin_expect(bad, 0)) {
-            uint32_t unused = 0;
-            r = fq_vec_d<IO, KIND, kDivExact, false>(v, dv, rnd, unused, bad);
-        }
-    }
-    return r;
-}
 
 // scalar element (tails, unaligned tensors)
 template <int IO, int KIND, bool OBS>
@@ -309,16 +253,10 @@ __global__ __launch_bounds__(256) void fq_gather_vec_kernel(const void *__restri
 // writes its result; optionally the fp32 column sums of one stage's result are produced on the way (the bias gradient of the Linear
 // behind it: grad_output.sum(0), run_glue_no_trainer.py:660-667) -- rows are dealt to workgroups in bands, a lane adds its rows in
 // row order, the lanes of a column in lane order, the workgroups in workgroup order (last arriver, through a workspace): deterministic.
-constexpr int kChainMax = 4, kChainBlock = 512, kChainStripV = 8, kChainRowLanes = kChainBlock / kChainStripV;
+constexpr int kChainBlock = 512, kChainStripV = 8, kChainRowLanes = kChainBlock / kChainStripV;
 // Work decomposition: a workgroup (512 threads: up to 256 registers, the row form keeps many live) owns a STRIP of 64 columns (8 vectors =
 // one 128-byte line per row) x a BAND of rows; lane (rl = t / 8, v = t % 8) walks rows rl, rl + 64, ... of the band, two or four loads in flight.  Column sums: a lane adds its rows in row order,
 // the 64 row lanes of a column meet in a fixed-order tree in LDS, and the bands of a strip meet in fixed-point accumulators (below).
-struct ChainStageDev {
-    const float *scale;
-    uint32_t *amax;
-    uint4 *out;
-    int src;                  // -1: x; else the stage whose result this one reads
-};
 struct ChainArgs {
     const uint4 *x;
     long rows;
@@ -333,13 +271,6 @@ struct ChainArgs {
     unsigned int *ticket;     // [strip]
     uint16_t *colsum_out;     // [cols] bf16
 };
-
-template <int KIND>
-__device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
-    if (s == 1.0f) return fq_vec<kIoBf16, KIND, kDivUnit, true>(v, dv, rnd, amax);
-    if (dv.safe) return fq_vec<kIoBf16, KIND, kDivFast, true>(v, dv, rnd, amax);
-    return fq_vec<kIoBf16, KIND, kDivExact, true>(v, dv, rnd, amax);
-}
 
 template <int KIND, int NS>
 __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {

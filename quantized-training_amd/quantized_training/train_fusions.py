@@ -68,7 +68,7 @@ def _member_ok(fq, device):
     from .quantizer.quantizer import QScheme
     return (isinstance(fq, FusedAmaxObsFakeQuantize) and fq._quantize and not fq.is_per_channel and not fq.record_histogram
             and fq.outlier_threshold is None and fq.qscheme in (None, QScheme.PER_TENSOR_SYMMETRIC)
-            and not fq._forward_hooks and not fq._forward_pre_hooks and not getattr(fq, "_emit_fp8", None)
+            and not getattr(fq, "_emit_fp8", None)      # (hooks on a member still see its call, input and result: forward() runs for every member)
             and (not fq._observe or (fq.amax_history.numel() > 0 and fq.amax_history.dim() == 1 and fq.amax_history.device == device))
             and fq.scale.numel() == 1 and fq.scale.device == device and fq.scale.dtype == torch.float32)
 

@@ -900,22 +900,39 @@ _TRAIN_FLAGS = ("--activation", "int8,qs=per_tensor_symmetric", "--weight", "int
                 "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm", "--quantize_backprop", "gemm,residual", "--bf16")
 
 
-def _roberta_layer_training_run(dev, base, batches, graphed=False):
+def _roberta_layer_training_run(dev, base, batches, oracle_check=False):
     """Three steps of the reference's training loop (run_glue_no_trainer.py:647-667) on a copy of `base` on `dev`; from the second step
     on every fake-quantizer call (forward activations / weights AND the gradient fake-quantizers of the backward hooks) is tapped as its
-    CODES, output / scale, with the scale the call applied.  Returns (taps, losses, delayed-scaling state, parameters after the steps)."""
+    CODES, output / scale, with the scale the call applied.  oracle_check: every tapped call is also compared, bit for bit, with the
+    oracle's fake-quantizer on the call's own input and scale, and its amax with the input's.  Returns (taps, losses, delayed-scaling
+    state, parameters after the steps, number of calls checked against the oracle)."""
     import copy
+    import numpy as np
+    from oracle import qt_oracle as o
     from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
     m = copy.deepcopy(base).to(dev).train()
     qt.quantize(m, _args(*_TRAIN_FLAGS))
     opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
     taps, losses = {}, []
+    checked = [0]
+    maps = {}
 
     def hook(name):
         def fn(mod, args, out):
             t = out[0] if isinstance(out, tuple) else out
-            if isinstance(t, torch.Tensor) and mod.scale.numel() == 1:
-                taps.setdefault(name, []).append((t.detach().float() / mod.scale.detach().float()).cpu())
+            if not (isinstance(t, torch.Tensor) and mod.scale.numel() == 1):
+                return
+            taps.setdefault(name, []).append((t.detach().float() / mod.scale.detach().float()).cpu())
+            if oracle_check and t.dtype == torch.bfloat16:
+                x = args[0].detach().contiguous()
+                qmap = maps.setdefault(str(mod.dtype), o.get_quantization_map(str(mod.dtype).split(",")[0]))
+                xb = x.view(torch.int16).cpu().numpy().view(np.uint16)
+                sb = o.f32_to_bf16(mod.scale.detach().float().cpu().numpy().reshape(1))
+                want = o.canon_nan16(o.fq_bf16(xb, qmap, sb))
+                got = o.canon_nan16(t.detach().contiguous().view(torch.int16).cpu().numpy().view(np.uint16))
+                assert np.array_equal(want, got), (name, int((want != got).sum()), want.size)
+                assert float(mod.amax_history[0]) == float(x.float().abs().max()), name
+                checked[0] += 1
         return fn
     hs = []
     for i, b in enumerate(batches):
@@ -927,18 +944,28 @@ def _roberta_layer_training_run(dev, base, batches, graphed=False):
     state = {n: (mod.scale.detach().float().cpu().reshape(-1), mod.amax_history.detach().float().cpu().reshape(-1))
              for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize) and mod.amax_history.numel() > 0}
     params = {n: p.detach().float().cpu() for n, p in m.named_parameters()}
-    return taps, losses, state, params
+    return taps, losses, state, params, checked[0]
 
 
-def test_full_size_roberta_layer_training_steps_against_the_cpu_path():
+# gradient tensors that are differences of nearly equal terms (the key gradient: every row of the softmax Jacobian sums to zero) or are
+# produced by torch's transposed batched bf16 matmuls, whose CPU and device kernels differ by far more than a rounding (measured: 59 - 68 %
+# of the E5M2 codes one step apart, against <= 0.6 % on the query branch), and the classifier head's [16, .] tensors: their fake-quantizer
+# calls are pinned by the oracle check, not by the CPU run
+_NOISY_TAPS = ("attention.self.key.error_", "attention.self.value.error_", "classifier.")
+
+
+def test_full_size_roberta_layer_training_steps_against_the_cpu_path(monkeypatch):
     """BASELINE configs[4] at full width: one RoBERTa-base layer (hidden 768, 12 heads, FFN 3072) + classifier, batches [16, 128], bf16,
     int8 activations and weights with delayed scaling, E5M2 gradients through the backward hooks (quantize.py:116-179,
-    fake_quantize.py:217-246), clip 1.0 + AdamW, THREE steps (so the delayed-scaling state machine is compared too) -- device against
-    CPU tensors (the path pinned to the reference's traces by tests/test_blocks_golden.py).  Per fake-quantizer call of steps 2 and 3:
-    the device's codes (output / applied scale) are integers in [-128, 127] resp. E5M2 values, and differ from the CPU run's by at
-    most one code step on a bounded share of elements (a GEMM summed in another order moves an input across a rounding boundary;
-    a scale that differs in its last bits moves every boundary a little).  Scales and amax histories agree to bf16 resolution, losses
-    to 1 %, updated parameters to the size of one AdamW step."""
+    fake_quantize.py:217-246), clip 1.0 + AdamW, THREE steps (so the delayed-scaling state machine is compared too).
+      (1) Every fake-quantizer call of steps 2 and 3 on the device -- 80 calls, forward and backward, chained launches
+          (train_fusions.py) included -- equals the ORACLE's fake-quantizer on that call's own input and scale bit for bit, and leaves
+          exactly max |input| in amax_history[0].  Once with the chains, once without.
+      (2) Device against CPU tensors (the path pinned to the reference's traces by tests/test_blocks_golden.py): per call the device's
+          codes (output / applied scale) lie on the format's grid and differ from the CPU run's by at most one code step on a bounded
+          share of elements (a GEMM summed in another order moves an input across a rounding boundary); scales and amax histories
+          agree to a few per cent, losses to 1 %, updated parameters to the size of the AdamW steps.  Tensors whose values torch's own
+          CPU and device kernels disagree on (_NOISY_TAPS) are reported and bounded loosely."""
     import numpy as np
     from oracle import qt_oracle as o
     from transformers import RobertaConfig, RobertaForSequenceClassification
@@ -949,28 +976,34 @@ def test_full_size_roberta_layer_training_steps_against_the_cpu_path():
     g = torch.Generator().manual_seed(1)
     batches = [{"input_ids": torch.randint(3, 1000, (16, 128), generator=g), "labels": torch.randint(0, 2, (16,), generator=g)} for _ in range(3)]
     cpu = _roberta_layer_training_run("cpu", base, batches)
-    dev = _roberta_layer_training_run("cuda", base, batches)
+    monkeypatch.setenv("QT_TRAIN_CHAINS", "0")
+    plain = _roberta_layer_training_run("cuda", base, batches, oracle_check=True)
+    monkeypatch.setenv("QT_TRAIN_CHAINS", "1")
+    from quantized_training import train_fusions
+    train_fusions.STATS.reset()
+    dev = _roberta_layer_training_run("cuda", base, batches, oracle_check=True)
+    assert plain[4] == 80 and dev[4] == 80, (plain[4], dev[4])
+    assert train_fusions.STATS.chains >= 2 * 3 and train_fusions.STATS.misses == 0
     e5 = o.bf16_to_f32(o.get_quantization_map("fp8_e5m2"))
     e5grid = np.unique(e5[np.isfinite(e5)].astype(np.float64))
     igrid = np.arange(-128, 128, dtype=np.float64)
-    fwd = bwd = 0
     report = []
-    worst = {"fwd": 0.0, "bwd": 0.0}
-    far = {"fwd": 0, "bwd": 0}
-    total = {"fwd": 0, "bwd": 0}
+    worst = {"fwd": 0.0, "bwd": 0.0, "noisy": 0.0}
+    far = {"fwd": 0, "bwd": 0, "noisy": 0}
+    total = {"fwd": 0, "bwd": 0, "noisy": 0}
+    count = {"fwd": 0, "bwd": 0, "noisy": 0}
     common = [k for k in cpu[0] if k in dev[0] and len(cpu[0][k]) == len(dev[0][k])]
-    assert len(common) >= 0.9 * len(cpu[0]) and len(common) >= 30, (len(common), len(cpu[0]), len(dev[0]))
+    assert len(common) == len(cpu[0]) == 40, (len(common), len(cpu[0]), len(dev[0]))
     for k in common:
-        kind = "bwd" if ("error_pre_process" in k or "error_post_process" in k) else "fwd"
-        grid = e5grid if kind == "bwd" else igrid
+        grad = "error_pre_process" in k or "error_post_process" in k
+        kind = "noisy" if any(tag in k for tag in _NOISY_TAPS) else ("bwd" if grad else "fwd")
+        grid = e5grid if grad else igrid
         for a, b in zip(cpu[0][k], dev[0][k]):
-            if a.shape != b.shape:
-                continue
+            assert a.shape == b.shape, k
             a, b = a.numpy().astype(np.float64).ravel(), b.numpy().astype(np.float64).ravel()
-            # codes = value / scale, both bf16-rounded products: snap to the grid (a code times a scale divided by that scale is the code
-            # up to 2^-8 relative)
-            ia, ib = np.searchsorted(grid, a * (1 - 2.0 ** -7) if False else a), np.searchsorted(grid, b)
-            ia = np.clip(ia, 0, grid.size - 1); ib = np.clip(ib, 0, grid.size - 1)
+            # codes = value / scale with value = bf16(code * scale): snap to the nearest grid point
+            ia = np.clip(np.searchsorted(grid, a), 0, grid.size - 1)
+            ib = np.clip(np.searchsorted(grid, b), 0, grid.size - 1)
             ia = np.where((ia > 0) & (np.abs(grid[ia - 1] - a) < np.abs(grid[ia] - a)), ia - 1, ia)
             ib = np.where((ib > 0) & (np.abs(grid[ib - 1] - b) < np.abs(grid[ib] - b)), ib - 1, ib)
             on = np.abs(grid[ib] - b) <= np.maximum(np.abs(b), 2.0 ** -16) * 2.0 ** -6
@@ -980,28 +1013,31 @@ def test_full_size_roberta_layer_training_steps_against_the_cpu_path():
             worst[kind] = max(worst[kind], float((steps > 0).mean()))
             far[kind] += int((steps > 1).sum())
             total[kind] += steps.size
-            fwd += kind == "fwd"
-            bwd += kind == "bwd"
-    assert fwd >= 20 and bwd >= 20, (fwd, bwd)
-    print(f"\n[roberta layer, 3 steps] taps fwd {fwd} bwd {bwd}; worst share one step away fwd {worst['fwd']:.4f} bwd {worst['bwd']:.4f}; "
-          f"further: fwd {far['fwd'] / max(total['fwd'], 1):.2e} bwd {far['bwd'] / max(total['bwd'], 1):.2e}")
-    for share, farshare, k in sorted(report, reverse=True)[:16]:
+            count[kind] += 1
+    print(f"\n[roberta layer, 3 steps] calls compared {count}; worst share one step away {worst}; further: "
+          f"{ {k: far[k] / max(total[k], 1) for k in far} }")
+    for share, farshare, k in sorted(report, reverse=True)[:12]:
         print(f"    {share:.4f} one step, {farshare:.2e} further: {k}")
-    for k in sorted(cpu[2]):
-        print(f"    scale cpu {float(cpu[2][k][0][0]):.6g} dev {float(dev[2][k][0][0]):.6g}  amax[0] cpu {float(cpu[2][k][1][0]):.6g} dev {float(dev[2][k][1][0]):.6g}  {k}")
-    assert worst["fwd"] <= 0.05 and far["fwd"] / max(total["fwd"], 1) <= 2e-3, (worst, far, total)
-    assert worst["bwd"] <= 0.10 and far["bwd"] / max(total["bwd"], 1) <= 5e-3, (worst, far, total)
+    assert count["fwd"] >= 30 and count["bwd"] >= 24, count
+    # measured (MI355X): forward 4.4 % at worst (the output dense's [16, 128, 3072] input), 2e-5 further; gradients 0.6 % / 3e-3
+    assert worst["fwd"] <= 0.08 and far["fwd"] / max(total["fwd"], 1) <= 5e-4, (worst, far, total)
+    assert worst["bwd"] <= 0.03 and far["bwd"] / max(total["bwd"], 1) <= 8e-3, (worst, far, total)
+    assert worst["noisy"] <= 0.8, worst
     # delayed-scaling state after three steps
     assert set(cpu[2]) == set(dev[2])
     for k in cpu[2]:
+        tol = 0.2 if any(tag in k for tag in _NOISY_TAPS) or "error_" in k else 2.0 ** -6
         for a, b in zip(cpu[2][k], dev[2][k]):
             assert a.shape == b.shape, k
-            assert bool(((a - b).abs() <= 2.0 ** -6 * torch.maximum(a.abs(), b.abs()) + 1e-30).all()), (k, a, b)
+            assert bool(((a - b).abs() <= tol * torch.maximum(a.abs(), b.abs()) + 1e-30).all()), (k, a, b)
     for lc, ld in zip(cpu[1], dev[1]):
         assert abs(lc - ld) <= 1e-2 * abs(lc) + 1e-3, (cpu[1], dev[1])
     for k in cpu[3]:
         d = (cpu[3][k] - dev[3][k]).abs().max()
         assert float(d) <= 3 * 3 * 2e-5 + 2.0 ** -7 * float(cpu[3][k].abs().max()), (k, float(d))       # three AdamW steps of lr 2e-5, bf16 weights
+    # the chains change launches, not values: with and without them the device runs agree bit for bit up to the bias gradients'
+    # summation order (test_training_chains_change_launches_not_values pins that separately)
+    assert dev[1] == plain[1] or all(abs(a - b) <= 2e-2 * abs(a) + 1e-3 for a, b in zip(dev[1], plain[1]))
 
 
 def test_training_chains_change_launches_not_values(monkeypatch):
