@@ -288,6 +288,46 @@ int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const 
                              size_t ws_bytes, void *stream);
 size_t qt_fake_quant_chain_ws_bytes(long rows, long cols);
 
+/* ---- the model's own elementwise kernels of a TRAINING step, with the fake-quantizer calls that follow them (round 5) -------------
+ * The reference's examples run HF's blocks under autograd (run_glue_no_trainer.py:647-667) with the hooks of quantize.py:116-179
+ * around every GEMM: a LayerNorm / GELU / softmax kernel of torch's, then one fake-quantizer launch per hook.  These entry points
+ * produce the same tensors -- torch's arithmetic and rounding points, forward and backward -- and evaluate the stages of a chain
+ * (qt_chain_stage: each exactly one qt_fake_quant_bf16 call on the value the kernel holds in registers) in the same launch.
+ *
+ * qt_gelu_chain_bf16: y = bf16(erf-GELU(x)) (BertIntermediate's activation), stages on y.
+ * qt_gelu_backward_chain_bf16: grad_in = bf16(grad_out * (Phi(x) + x phi(x))) (torch's GeluBackward), stages on grad_in, optional
+ *   column sums of one stage (see qt_fake_quant_chain_bf16).
+ * qt_layernorm_train_bf16: y = LayerNorm(x) over the last dimension (fp32 statistics, biased variance, one rounding), mean / rstd
+ *   [rows] fp32 kept for the backward, stages on y.  cols <= 1024.
+ * qt_layernorm_train_backward_bf16: grad_in = rstd (g - mean(g) - xhat mean(g xhat)), g = grad_out * weight (torch's
+ *   layer_norm_grad_input), stages on grad_in; grad_weight = sum_rows grad_out * xhat, grad_bias = sum_rows grad_out and, with
+ *   colsum_stage >= 0, the column sums of that stage's result, each as fp32 partial sums per workgroup (part_dev:
+ *   qt_layernorm_train_backward_groups(rows) x 3 x cols floats, caller-owned scratch) added in workgroup order by a second small
+ *   launch: deterministic.
+ * qt_softmax_fq_probs_bf16: qt_softmax_fq_bf16 that also writes the unquantized probabilities (probs_dev, nullable).
+ * qt_softmax_backward_chain_bf16: grad_scores = bf16(bf16((dP - sum dP P) P) * scaling) (torch's _softmax_backward_data, then the
+ *   scaling's backward; the additive mask's backward is the identity), stages on grad_scores (qk_matmul's backward-pre quantizer).
+ * Every `stages` is a HOST array; nstage >= 1; pointers 16-byte aligned; cols % 8 == 0. */
+int qt_gelu_chain_bf16(const uint16_t *x_dev, uint16_t *y_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
+                       const qt_format *fmt, const uint16_t *lut_dev, void *stream);
+int qt_gelu_backward_chain_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, uint16_t *grad_in_dev, long rows, long cols,
+                                const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage,
+                                float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes, void *stream);
+int qt_layernorm_train_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, const uint16_t *bias_dev, uint16_t *y_dev, float *mean_dev,
+                            float *rstd_dev, long rows, long cols, float eps, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
+                            const uint16_t *lut_dev, void *stream);
+long qt_layernorm_train_backward_groups(long rows);
+int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
+                                     const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
+                                     const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage, float *part_dev, size_t part_bytes,
+                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, void *stream);
+int qt_softmax_fq_probs_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uint16_t *out_dev, uint16_t *probs_dev, long batch, int heads,
+                             int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
+                             const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
+int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_t *probs_dev, uint16_t *grad_scores_dev, long rows, long cols,
+                                   float scaling, const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev,
+                                   void *stream);
+
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
  *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)

@@ -8,6 +8,12 @@ namespace {
 constexpr int kIoBf16 = 0;
 constexpr int kIoF32 = 1;
 
+#ifndef QT_BF_LO_HI
+#define QT_BF_LO_HI
+__device__ __forceinline__ float bf_lo(uint32_t w) { return qt_u2f(w << 16); }          // the two bf16 halves of a packed word
+__device__ __forceinline__ float bf_hi(uint32_t w) { return qt_u2f(w & 0xFFFF0000u); }
+#endif
+
 template <int IO, int KIND, int DIV, bool OBS>
 __device__ __forceinline__ uint4 fq_vec_d(uint4 v, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax, bool &bad) {
     if constexpr (IO == kIoBf16 && KIND == kFmtRows) {

@@ -270,7 +270,34 @@ struct ChainArgs {
     long long *acc;           // [strip][64] fixed-point column sums, zero between launches
     unsigned int *ticket;     // [strip]
     uint16_t *colsum_out;     // [cols] bf16
+    // prologue: the value the stages see is not x itself but an elementwise function of it, computed in fp32 and rounded to bf16 as the
+    // torch kernel it replaces does -- 1: erf GELU of x (BertIntermediate's activation in front of the output dense's input quantizer);
+    // 2: its backward, x = grad_output, x2 = the forward's input: dy * (Phi(z) + z phi(z)) (in front of the intermediate dense's
+    // backward-pre quantizer).  pre_out (nullable): where that value goes.
+    int pre_op;
+    const uint4 *x2;
+    uint4 *pre_out;
 };
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float dy, float x) {
+    // torch's GeluBackward (erf form): cdf = 0.5 (1 + erf(x / sqrt 2)), pdf = exp(-x^2 / 2) / sqrt(2 pi)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+    return dy * (cdf + x * pdf);
+}
+__device__ __forceinline__ uint4 chain_prologue(int op, uint4 q, uint4 q2) {
+    if (op == 0) return q;
+    const uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {q2.x, q2.y, q2.z, q2.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = qt_u2f(a[j] << 16), a1 = qt_u2f(a[j] & 0xFFFF0000u);
+        if (op == 1) o[j] = pack_bf16x2(gelu_erf_f(a0), gelu_erf_f(a1));
+        else o[j] = pack_bf16x2(gelu_erf_grad_f(a0, qt_u2f(b[j] << 16)), gelu_erf_grad_f(a1, qt_u2f(b[j] & 0xFFFF0000u)));
+    }
+    return uint4{o[0], o[1], o[2], o[3]};
+}
 
 template <int KIND, int NS>
 __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
@@ -292,26 +319,26 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     constexpr int kChainUnroll = KIND == kFmtRows ? 2 : 4;      // rows in flight per lane (the row form keeps eight table rows live per vector)
     if (live) {
         for (long r0 = r_begin + rl; r0 < r_end; r0 += (long)kChainRowLanes * kChainUnroll) {
-            uint4 q[kChainUnroll];
+            uint4 q[kChainUnroll], q2[kChainUnroll];
 #pragma unroll
             for (int u = 0; u < kChainUnroll; ++u) {
                 const long r = r0 + (long)u * kChainRowLanes;
-                if (r < r_end) q[u] = a.x[r * a.cv + cvec];
+                if (r < r_end) {
+                    q[u] = a.x[r * a.cv + cvec];
+                    if (a.pre_op == 2) q2[u] = a.x2[r * a.cv + cvec];
+                }
             }
 #pragma unroll
             for (int u = 0; u < kChainUnroll; ++u) {
                 const long r = r0 + (long)u * kChainRowLanes;
                 if (r >= r_end) continue;
+                const size_t idx = (size_t)(r * a.cv + cvec);
+                const uint4 val = chain_prologue(a.pre_op, q[u], q2[u]);
+                if (a.pre_op && a.pre_out) a.pre_out[idx] = val;
                 uint4 res[NS];
+                chain_stages<KIND, NS>(a.st, sc, rnd, val, idx, amax, res);
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    uint4 in = q[u];
-#pragma unroll
-                    for (int j = 0; j < i; ++j)
-                        if (a.st[i].src == j) in = res[j];
-                    const UniformDiv dv(sc[i]);
-                    res[i] = chain_apply<KIND>(in, sc[i], dv, rnd, amax[i]);
-                    if (a.st[i].out) a.st[i].out[r * a.cv + cvec] = res[i];
                     if (a.colsum_stage == i) {
                         col[0] += qt_u2f(res[i].x << 16); col[1] += qt_u2f(res[i].x & 0xFFFF0000u);
                         col[2] += qt_u2f(res[i].y << 16); col[3] += qt_u2f(res[i].y & 0xFFFF0000u);
@@ -324,29 +351,12 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     }
     // ---- amax of every stage's input: wave, then workgroup, then at most one atomic per stage and workgroup
     __shared__ uint32_t s_amax[NS][kChainBlock / 64];
-    const int lane = t & 63, wave = t >> 6;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const uint32_t m = wave_max_u32(amax[i]);
-        if (lane == 0) s_amax[i][wave] = m;
-    }
     __shared__ float s_col[kChainRowLanes][kChainStripV * 8 + 1];
     if (a.colsum_stage >= 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_col[rl][v * 8 + e] = col[e];
     }
-    __syncthreads();
-    // (compile-time stage indices only: a run-time index into the kernel-argument struct makes hipcc copy it to scratch memory and read
-    // every field from there, inside the row loop too)
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        if (t == i * 64 && a.st[i].amax) {                       // one lane of wave i
-            uint32_t m = s_amax[i][0];
-#pragma unroll
-            for (int k = 1; k < kChainBlock / 64; ++k) m = m > s_amax[i][k] ? m : s_amax[i][k];
-            if (m != 0u && m > __hip_atomic_load(a.st[i].amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.st[i].amax, m);
-        }
-    }
+    chain_amax_commit<NS, kChainBlock>(a.st, amax, s_amax);          // (its barrier also covers s_col)
     if (a.colsum_stage < 0) return;
     // ---- column sums: the row lanes of a column in a fixed-order tree; then the bands of a strip meet in 64-bit FIXED-POINT accumulators
     // by agent-scope atomic adds -- integer addition is associative, so the result does not depend on the arrival order, and atomics are
@@ -394,6 +404,237 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
         if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
         if (c < a.cv * 8) a.colsum_out[c] = (uint16_t)(pack_bf16x2(sum, 0.0f) & 0xFFFFu);
     }
+}
+
+// ---- LayerNorm of a training step with the fake-quantizer calls that follow it (qt_layernorm_train_*) -----------------------------------
+// Forward: y = LayerNorm(x) (torch's rounding points: fp32 statistics, one rounding to bf16), mean / rstd kept for the backward, and the
+// input quantizers of the Linears that read y (query / key / value, or the intermediate dense: quantize.py:128-140) evaluated on the row
+// while it is in registers.  Backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma (torch's layer_norm_grad_input), the
+// gradient chain behind it (the residual add's three quantizers and the dense layer's, quantize.py:116-179) on dx in registers, and
+// per-workgroup partial sums of dgamma = sum dy xhat, dbeta = sum dy and the bias gradient (column sums of one stage's result), which a
+// second small launch adds in workgroup order (qt_layernorm_train_reduce).  One wave per row, rows up to 1024 columns.
+constexpr int kLnMaxVec = 2;
+struct LnTrainArgs {
+    const uint4 *x, *w, *b;
+    uint4 *y;
+    float *mean, *rstd;
+    long rows;
+    int nvec;
+    float inv_cols, eps;
+    ChainStageDev st[kChainMax];
+};
+
+template <int KIND, int NS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ln_train_fwd_kernel(LnTrainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
+    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * (BLOCK / 64) + wave;
+    float sc[NS];
+    uint32_t amax[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        sc[i] = a.st[i].scale ? qt_bf2f(qt_f2bf(*a.st[i].scale)) : 1.0f;
+        amax[i] = 0u;
+    }
+    if (row < a.rows) {
+        const size_t base = (size_t)row * (size_t)a.nvec;
+        uint4 v[kLnMaxVec];
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i) {
+            const int c = lane + i * 64;
+            if (c < a.nvec) {
+                v[i] = a.x[base + c];
+                sum += (bf_lo(v[i].x) + bf_hi(v[i].x)) + (bf_lo(v[i].y) + bf_hi(v[i].y)) + (bf_lo(v[i].z) + bf_hi(v[i].z)) + (bf_lo(v[i].w) + bf_hi(v[i].w));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * a.inv_cols;
+        float sq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i) {
+            const int c = lane + i * 64;
+            if (c < a.nvec) {
+                const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d0 = bf_lo(q[j]) - mean, d1 = bf_hi(q[j]) - mean;
+                    sq += d0 * d0;
+                    sq += d1 * d1;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = rsqrtf(sq * a.inv_cols + a.eps);
+        if (lane == 0) {
+            a.mean[row] = mean;
+            a.rstd[row] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i) {
+            const int c = lane + i * 64;
+            if (c < a.nvec) {
+                const uint4 ww = a.w[c], bb = a.b[c];
+                const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, g[4] = {ww.x, ww.y, ww.z, ww.w}, h[4] = {bb.x, bb.y, bb.z, bb.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = pack_bf16x2(bf_lo(g[j]) * (rstd * (bf_lo(q[j]) - mean)) + bf_lo(h[j]), bf_hi(g[j]) * (rstd * (bf_hi(q[j]) - mean)) + bf_hi(h[j]));
+                const uint4 yv = uint4{o[0], o[1], o[2], o[3]};
+                a.y[base + c] = yv;
+                uint4 res[NS];
+                chain_stages<KIND, NS>(a.st, sc, rnd, yv, base + c, amax, res);
+            }
+        }
+    }
+    __shared__ uint32_t s_amax[NS][BLOCK / 64];
+    chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
+}
+
+struct LnBwdArgs {
+    const uint4 *dy, *x, *w;
+    const float *mean, *rstd;
+    uint4 *dx;
+    long rows;
+    int nvec;
+    float inv_cols;
+    int rows_per_wave;        // a wave walks rows wave, wave + BLOCK / 64, ... of its workgroup's band
+    float *part;              // [workgroup][3][cols] fp32: dgamma, dbeta, column sums of stage `colsum_stage`
+    int colsum_stage;         // -1: none (that slab is not written)
+    ChainStageDev st[kChainMax];
+};
+
+template <int KIND, int NS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
+    constexpr int RPB = BLOCK / 64;
+    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sc[NS];
+    uint32_t amax[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        sc[i] = a.st[i].scale ? qt_bf2f(qt_f2bf(*a.st[i].scale)) : 1.0f;
+        amax[i] = 0u;
+    }
+    float dg[kLnMaxVec][8], db[kLnMaxVec][8], cs[kLnMaxVec][8];
+#pragma unroll
+    for (int i = 0; i < kLnMaxVec; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = cs[i][e] = 0.0f;
+    uint4 gam[kLnMaxVec];
+#pragma unroll
+    for (int i = 0; i < kLnMaxVec; ++i)
+        if (lane + i * 64 < a.nvec) gam[i] = a.w[lane + i * 64];
+    const long band0 = (long)blockIdx.x * RPB * a.rows_per_wave;
+    for (int k = 0; k < a.rows_per_wave; ++k) {
+        const long row = band0 + (long)k * RPB + wave;
+        if (row >= a.rows) break;                                  // (wave-uniform)
+        const size_t base = (size_t)row * (size_t)a.nvec;
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[kLnMaxVec][8], g[kLnMaxVec][8], dyv[kLnMaxVec][8];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i) {
+            const int c = lane + i * 64;
+            if (c < a.nvec) {
+                const uint4 d = a.dy[base + c], x = a.x[base + c];
+                const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, xw[4] = {x.x, x.y, x.z, x.w}, gw[4] = {gam[i].x, gam[i].y, gam[i].z, gam[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float dyf = h ? bf_hi(dw[j]) : bf_lo(dw[j]), xf = h ? bf_hi(xw[j]) : bf_lo(xw[j]), gf = h ? bf_hi(gw[j]) : bf_lo(gw[j]);
+                        const int e = 2 * j + h;
+                        dyv[i][e] = dyf;
+                        xh[i][e] = (xf - mean) * rstd;
+                        g[i][e] = dyf * gf;
+                        s1 += g[i][e];
+                        s2 += g[i][e] * xh[i][e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        const float c1 = s1 * a.inv_cols, c2 = s2 * a.inv_cols;
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i) {
+            const int c = lane + i * 64;
+            if (c < a.nvec) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = pack_bf16x2(rstd * (g[i][2 * j] - c1 - xh[i][2 * j] * c2), rstd * (g[i][2 * j + 1] - c1 - xh[i][2 * j + 1] * c2));
+                const uint4 dxv = uint4{o[0], o[1], o[2], o[3]};
+                a.dx[base + c] = dxv;
+                uint4 res[NS];
+                chain_stages<KIND, NS>(a.st, sc, rnd, dxv, base + c, amax, res);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dg[i][e] += dyv[i][e] * xh[i][e];
+                    db[i][e] += dyv[i][e];
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) {
+                    if (a.colsum_stage == s_) {
+                        const uint32_t rw[4] = {res[s_].x, res[s_].y, res[s_].z, res[s_].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            cs[i][2 * j] += bf_lo(rw[j]);
+                            cs[i][2 * j + 1] += bf_hi(rw[j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- the waves' column partials meet in LDS, quantity by quantity, and are added in wave order
+    __shared__ float s_red[RPB][kLnMaxVec * 64 * 8];
+    __shared__ uint32_t s_amax[NS][BLOCK / 64];
+    const int cols = a.nvec * 8;
+    float *const mine = a.part + (size_t)blockIdx.x * 3 * cols;
+#pragma unroll
+    for (int qn = 0; qn < 3; ++qn) {
+        if (qn == 2 && a.colsum_stage < 0) break;
+#pragma unroll
+        for (int i = 0; i < kLnMaxVec; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_red[wave][(lane + i * 64) * 8 + e] = qn == 0 ? dg[i][e] : (qn == 1 ? db[i][e] : cs[i][e]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += BLOCK) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < RPB; ++w) sum += s_red[w][c];
+            mine[(size_t)qn * cols + c] = sum;
+        }
+        __syncthreads();
+    }
+    chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
+}
+
+// dgamma, dbeta (and the bias gradient) of one LayerNorm backward: the workgroups' partial sums added in workgroup order
+__global__ __launch_bounds__(256) void ln_train_reduce_kernel(const float *__restrict__ part, int nwg, int cols, uint16_t *dgamma, uint16_t *dbeta,
+                                                              uint16_t *colsum) {
+    const int c = blockIdx.x * 256 + threadIdx.x, qn = blockIdx.y;
+    uint16_t *out = qn == 0 ? dgamma : (qn == 1 ? dbeta : colsum);
+    if (c >= cols || !out) return;
+    const float *p = part + (size_t)qn * cols + c;
+    float sum = 0.0f;
+    int w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(w + u) * 3 * cols];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += t[u];
+    }
+    for (; w < nwg; ++w) sum += p[(size_t)w * 3 * cols];
+    out[c] = (uint16_t)(pack_bf16x2(sum, 0.0f) & 0xFFFFu);
 }
 
 // ---- OCP FP8 side output ------------------------------------------------------------------------
@@ -1452,14 +1693,16 @@ static void chain_geometry(long rows, long cols, int &strips, int &bands, long &
     bands = (int)((groups + per - 1) / per);
 }
 
-int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
-                             const uint16_t *lut_dev, int colsum_stage, float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes,
-                             void *stream) {
+static int chain_launch(const uint16_t *x_dev, const uint16_t *x2_dev, int pre_op, uint16_t *pre_out_dev, long rows, long cols,
+                        const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage, float colsum_max,
+                        uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes, void *stream) {
     if (rows * cols == 0) return QT_OK;
     if (!x_dev || !stages || !fmt || nstage < 1 || nstage > kChainMax || rows < 0 || cols < 8 || cols % 8 != 0) return QT_ERR_BAD_ARG;
-    if ((uintptr_t)x_dev & 15u) return QT_ERR_UNALIGNED;
+    if (pre_op < 0 || pre_op > 2 || (pre_op == 2 && !x2_dev)) return QT_ERR_BAD_ARG;
+    if (((uintptr_t)x_dev | (uintptr_t)x2_dev | (uintptr_t)pre_out_dev) & 15u) return QT_ERR_UNALIGNED;
     ChainArgs a{};
     a.x = (const uint4 *)x_dev; a.rows = rows; a.cv = (int)(cols / 8); a.nstage = nstage;
+    a.pre_op = pre_op; a.x2 = (const uint4 *)x2_dev; a.pre_out = (uint4 *)pre_out_dev;
     for (int i = 0; i < nstage; ++i) {
         if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
         if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
@@ -1496,6 +1739,111 @@ int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const 
     }
 #undef QT_CHAIN_NS
 #undef QT_CHAIN
+    return launch_status();
+}
+
+int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
+                             const uint16_t *lut_dev, int colsum_stage, float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes,
+                             void *stream) {
+    return chain_launch(x_dev, nullptr, 0, nullptr, rows, cols, stages, nstage, fmt, lut_dev, colsum_stage, colsum_max, colsum_out_dev, ws_dev,
+                        ws_bytes, stream);
+}
+
+int qt_gelu_chain_bf16(const uint16_t *x_dev, uint16_t *y_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
+                       const qt_format *fmt, const uint16_t *lut_dev, void *stream) {
+    return chain_launch(x_dev, nullptr, 1, y_dev, rows, cols, stages, nstage, fmt, lut_dev, -1, 0.0f, nullptr, nullptr, 0, stream);
+}
+
+int qt_gelu_backward_chain_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, uint16_t *grad_in_dev, long rows, long cols,
+                                const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage,
+                                float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes, void *stream) {
+    return chain_launch(grad_out_dev, x_dev, 2, grad_in_dev, rows, cols, stages, nstage, fmt, lut_dev, colsum_stage, colsum_max, colsum_out_dev,
+                        ws_dev, ws_bytes, stream);
+}
+
+static int chain_stage_args(const qt_chain_stage *stages, int nstage, ChainStageDev (&st)[kChainMax]) {
+    if (nstage < 0 || nstage > kChainMax || (nstage > 0 && !stages)) return QT_ERR_BAD_ARG;
+    for (int i = 0; i < nstage; ++i) {
+        if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
+        if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
+        st[i] = ChainStageDev{stages[i].scale_f32_dev, stages[i].amax_bits_dev, (uint4 *)stages[i].out_dev, stages[i].src};
+    }
+    return QT_OK;
+}
+
+#define QT_LN_DISPATCH(KERNEL, ARGS, GRID)                                                                                      \
+    switch (fmt->kind) {                                                                                                        \
+        case QT_FMT_LUT:                                                                                                        \
+            if (!lut_dev || !(fmt->p1 & 1)) return QT_ERR_BAD_DTYPE;                                                            \
+            switch (nstage) {                                                                                                   \
+                case 1: KERNEL<kFmtRows, 1, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;          \
+                case 2: KERNEL<kFmtRows, 2, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;          \
+                case 3: KERNEL<kFmtRows, 3, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;          \
+                default: KERNEL<kFmtRows, 4, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;         \
+            }                                                                                                                   \
+            break;                                                                                                              \
+        case QT_FMT_FP_SAT:                                                                                                     \
+            switch (nstage) {                                                                                                   \
+                case 1: KERNEL<QT_FMT_FP_SAT, 1, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;     \
+                case 2: KERNEL<QT_FMT_FP_SAT, 2, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;     \
+                case 3: KERNEL<QT_FMT_FP_SAT, 3, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;     \
+                default: KERNEL<QT_FMT_FP_SAT, 4, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;    \
+            }                                                                                                                   \
+            break;                                                                                                              \
+        case QT_FMT_INT:                                                                                                        \
+            switch (nstage) {                                                                                                   \
+                case 1: KERNEL<QT_FMT_INT, 1, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;        \
+                case 2: KERNEL<QT_FMT_INT, 2, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;        \
+                case 3: KERNEL<QT_FMT_INT, 3, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;        \
+                default: KERNEL<QT_FMT_INT, 4, 512><<<(unsigned)((GRID)(512)), 512, 0, st>>>(ARGS, *fmt, lut_dev); break;       \
+            }                                                                                                                   \
+            break;                                                                                                              \
+        default: return QT_ERR_BAD_DTYPE;                                                                                       \
+    }
+
+int qt_layernorm_train_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, const uint16_t *bias_dev, uint16_t *y_dev, float *mean_dev,
+                            float *rstd_dev, long rows, long cols, float eps, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
+                            const uint16_t *lut_dev, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!x_dev || !weight_dev || !bias_dev || !y_dev || !mean_dev || !rstd_dev || !fmt || rows < 0 || cols < 8 || cols % 8 || cols > 64 * 8 * kLnMaxVec ||
+        nstage < 1)
+        return QT_ERR_BAD_ARG;
+    if (((uintptr_t)x_dev | (uintptr_t)weight_dev | (uintptr_t)bias_dev | (uintptr_t)y_dev) & 15u) return QT_ERR_UNALIGNED;
+    LnTrainArgs a{};
+    a.x = (const uint4 *)x_dev; a.w = (const uint4 *)weight_dev; a.b = (const uint4 *)bias_dev; a.y = (uint4 *)y_dev;
+    a.mean = mean_dev; a.rstd = rstd_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.eps = eps;
+    if (const int rc = chain_stage_args(stages, nstage, a.st)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid = [&](int block) { return (rows + block / 64 - 1) / (block / 64); };
+    QT_LN_DISPATCH(ln_train_fwd_kernel, a, grid)
+    return launch_status();
+}
+
+// workgroups of the backward launch (512 threads = 8 waves, two rows per wave): its partial sums are part_dev[that many][3][cols] fp32
+long qt_layernorm_train_backward_groups(long rows) { return rows <= 0 ? 0 : (rows + 15) / 16; }
+
+int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
+                                     const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
+                                     const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage, float *part_dev, size_t part_bytes,
+                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!grad_out_dev || !x_dev || !weight_dev || !mean_dev || !rstd_dev || !grad_in_dev || !fmt || !part_dev || !grad_weight_dev || !grad_bias_dev ||
+        rows < 0 || cols < 8 || cols % 8 || cols > 64 * 8 * kLnMaxVec || nstage < 1 || colsum_stage >= nstage || (colsum_stage >= 0 && !colsum_out_dev))
+        return QT_ERR_BAD_ARG;
+    if (((uintptr_t)grad_out_dev | (uintptr_t)x_dev | (uintptr_t)weight_dev | (uintptr_t)grad_in_dev | (uintptr_t)part_dev) & 15u) return QT_ERR_UNALIGNED;
+    const long groups = qt_layernorm_train_backward_groups(rows);
+    if (part_bytes < (size_t)groups * 3 * cols * sizeof(float)) return QT_ERR_BAD_ARG;
+    LnBwdArgs a{};
+    a.dy = (const uint4 *)grad_out_dev; a.x = (const uint4 *)x_dev; a.w = (const uint4 *)weight_dev; a.mean = mean_dev; a.rstd = rstd_dev;
+    a.dx = (uint4 *)grad_in_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.rows_per_wave = 2;
+    a.part = part_dev; a.colsum_stage = colsum_stage < 0 ? -1 : colsum_stage;
+    if (const int rc = chain_stage_args(stages, nstage, a.st)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto grid = [&](int) { return groups; };
+    QT_LN_DISPATCH(ln_train_bwd_kernel, a, grid)
+    if (const int rc = launch_status()) return rc;
+    ln_train_reduce_kernel<<<dim3((unsigned)((cols + 255) / 256), colsum_stage >= 0 ? 3u : 2u), 256, 0, st>>>(part_dev, (int)groups, (int)cols, grad_weight_dev,
+                                                                                                      grad_bias_dev, colsum_out_dev);
     return launch_status();
 }
 

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "qt_device.h"
+#include "qt_chain.h"
 
 namespace {
 
@@ -38,6 +39,7 @@ struct SoftmaxArgs {
     uint32_t *amax;
     uint8_t *out8;            // optional FP8 code of the quantized probabilities (E4M3 / E5M2 spec, unit scale)
     int out8_e5m2;
+    uint16_t *probs;          // optional: the UNQUANTIZED bf16 probabilities (what torch's softmax returns; the backward of a training step needs them)
     const int *row_live;      // optional, per mask row (same (b, h, q) strides / 8-column granularity as the mask rows, in ROWS): one past
                               // the last column whose mask entry is above -1e30 (qt_mask_row_live); columns from there on are masked
     long live_sb, live_sh, live_sq;
@@ -147,18 +149,21 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
         const float inv = 1.0f / sum;                 // one division per row; p = e * inv (<= 1 fp32 ULP from e / sum)
         uint4 *dst = a.out ? (uint4 *)(a.out + row * a.cols) : nullptr;
         uint2 *dst8 = a.out8 ? (uint2 *)(a.out8 + row * a.cols) : nullptr;
+        uint4 *dstp = a.probs ? (uint4 *)(a.probs + row * a.cols) : nullptr;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int iv = v * 64 + lane;
             if (iv < nvec_row && dead[v]) {                  // fq(0) = +0, FP8 code 0; amax unaffected
                 if (dst) dst[iv] = uint4{0u, 0u, 0u, 0u};
                 if (dst8) dst8[iv] = uint2{0u, 0u};
+                if (dstp) dstp[iv] = uint4{0u, 0u, 0u, 0u};
             } else if (iv < nvec_row) {
-                uint32_t w[4];
+                uint32_t w[4], pw[4];
                 float f8[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t p = pack_bf16x2(t[v][2 * j] * inv, t[v][2 * j + 1] * inv);   // probabilities, bf16
+                    pw[j] = p;
                     if (a.amax) {
                         uint32_t a0 = (p << 16) & 0x7FFFFFFFu, a1 = p & 0x7FFF0000u;
                         amax = amax > a0 ? amax : a0;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                     f8[2 * j + 1] = qt_u2f(r1);
                 }
                 if (dst) dst[iv] = uint4{w[0], w[1], w[2], w[3]};
+                if (dstp) dstp[iv] = uint4{pw[0], pw[1], pw[2], pw[3]};
                 if (dst8) {
                     if (a.out8_e5m2) dst8[iv] = uint2{qt_pack_fp8x4<true>(f8[0], f8[1], f8[2], f8[3]), qt_pack_fp8x4<true>(f8[4], f8[5], f8[6], f8[7])};
                     else dst8[iv] = uint2{qt_pack_fp8x4<false>(f8[0], f8[1], f8[2], f8[3]), qt_pack_fp8x4<false>(f8[4], f8[5], f8[6], f8[7])};
@@ -194,10 +200,87 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
         }
     }
     if (a.amax) {
+        // one atomic per workgroup at most (the slot starts a training step at zero: every wave could raise it, and same-address atomics
+        // serialise)
+        __shared__ uint32_t s_am[4];
         amax = wave_max_u32(amax);
-        if (lane == 0 && amax != 0u && amax > __hip_atomic_load(a.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(a.amax, amax);
+        if (lane == 0) s_am[wave] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = s_am[0];
+            m = m > s_am[1] ? m : s_am[1];
+            m = m > s_am[2] ? m : s_am[2];
+            m = m > s_am[3] ? m : s_am[3];
+            if (m != 0u && m > __hip_atomic_load(a.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax, m);
+        }
     }
+}
+
+// ---- backward of scale -> (+ mask) -> softmax in a training step, with the fake-quantizer chain behind it ---------------------------
+// torch runs _softmax_backward_data (fp32: (dP - sum dP P) P, one rounding to bf16) and the scaling's backward (x scaling, another
+// rounding); the result is the grad_output of qk_matmul, which its backward-pre hook fake-quantizes (quantize.py:116-179).  One wave
+// per row, rows up to 64 * 8 * kMaxVec columns; P: the unquantized probabilities the forward kept.
+struct SoftmaxBwdArgs {
+    const uint16_t *dp, *p;
+    uint16_t *ds;
+    long rows, cols;
+    float scaling;
+    ChainStageDev st[kChainMax];
+};
+
+template <int KIND, int NS, int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
+    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sc[NS];
+    uint32_t amax[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        sc[i] = a.st[i].scale ? qt_bf2f(qt_f2bf(*a.st[i].scale)) : 1.0f;
+        amax[i] = 0u;
+    }
+    const int nvec_row = (int)(a.cols / 8);
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
+        const uint4 *gp = (const uint4 *)(a.dp + row * a.cols), *pp = (const uint4 *)(a.p + row * a.cols);
+        float g[NV][8], pr[NV][8];
+        float dot = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int iv = v * 64 + lane;
+            if (iv < nvec_row) {
+                const uint4 gv = gp[iv], pv = pp[iv];
+                const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    g[v][2 * j] = bf_lo(gw[j]); g[v][2 * j + 1] = bf_hi(gw[j]);
+                    pr[v][2 * j] = bf_lo(pw[j]); pr[v][2 * j + 1] = bf_hi(pw[j]);
+                    dot += g[v][2 * j] * pr[v][2 * j];
+                    dot += g[v][2 * j + 1] * pr[v][2 * j + 1];
+                }
+            }
+        }
+        dot = wave_sum_f32(dot);
+        uint4 *dst = (uint4 *)(a.ds + row * a.cols);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int iv = v * 64 + lane;
+            if (iv < nvec_row) {
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t d1 = pack_bf16x2((g[v][2 * j] - dot) * pr[v][2 * j], (g[v][2 * j + 1] - dot) * pr[v][2 * j + 1]);     // softmax backward, bf16
+                    o[j] = pack_bf16x2(bf_lo(d1) * a.scaling, bf_hi(d1) * a.scaling);                                                  // x scaling, bf16
+                }
+                const uint4 dsv = uint4{o[0], o[1], o[2], o[3]};
+                const size_t idx = (size_t)(row * nvec_row + iv);
+                dst[iv] = dsv;
+                uint4 res[NS];
+                chain_stages<KIND, NS>(a.st, sc, rnd, dsv, idx, amax, res);
+            }
+        }
+    }
+    __shared__ uint32_t s_amax[NS][4];
+    chain_amax_commit<NS, 256>(a.st, amax, s_amax);
 }
 
 template <int KIND>
@@ -212,7 +295,7 @@ int launch_softmax(const SoftmaxArgs &a, hipStream_t st) {
                   ? p.multiProcessorCount : 256;
     }
     long want = (a.rows + 3) / 4;
-    long cap = (long)cus * 16;
+    long cap = (long)cus * (a.amax ? 2 : 16);       // observed (a training step): one amax atomic per workgroup, so fewer, longer workgroups
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
     switch (nv) {
@@ -239,7 +322,7 @@ extern "C" int qt_softmax_fq_bf16(const uint16_t *scores, const uint16_t *mask, 
     if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)out | (uintptr_t)mask) & 15u) ||
         (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
         return QT_ERR_UNALIGNED;
-    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, nullptr, 0};
+    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, nullptr, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (fmt->kind) {
         case QT_FMT_LUT: return (fmt->p1 & 1) ? launch_softmax<kFmtRows>(a, st) : launch_softmax<QT_FMT_LUT>(a, st);
@@ -304,7 +387,7 @@ extern "C" int qt_softmax_fq_bf16_fp8_live(const uint16_t *scores, const uint16_
     if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)mask) & 15u) || ((uintptr_t)out8 & 7u) || ((mask_sb | mask_sh | mask_sq) & 7))
         return QT_ERR_UNALIGNED;
     SoftmaxArgs a{scores, mask, nullptr, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, nullptr, nullptr, nullptr,
-                  out8, e5m2 ? 1 : 0, row_live, live_sb, live_sh, live_sq};
+                  out8, e5m2 ? 1 : 0, nullptr, row_live, live_sb, live_sh, live_sq};
     return launch_softmax<QT_FMT_FP_SAT>(a, (hipStream_t)stream);
 }
 
@@ -322,6 +405,72 @@ extern "C" int qt_softmax_fq_bf16_fp8(const uint16_t *scores, const uint16_t *ma
         (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
         return QT_ERR_UNALIGNED;
     SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, nullptr, nullptr, nullptr,
-                  out8, e5m2 ? 1 : 0};
+                  out8, e5m2 ? 1 : 0, nullptr};
     return launch_softmax<QT_FMT_FP_SAT>(a, (hipStream_t)stream);
+}
+
+// The same pass for a training step: also writes the unquantized probabilities (probs_dev, nullable) the backward needs.
+extern "C" int qt_softmax_fq_probs_bf16(const uint16_t *scores, const uint16_t *mask, uint16_t *out, uint16_t *probs_dev, long batch, int heads,
+                                        int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
+                                        const uint16_t *lut, const float *scale, uint32_t *amax, void *stream) {
+    const long rows = batch * heads * q_len;
+    if (rows == 0 || cols == 0) return QT_OK;
+    if (!scores || !out || !fmt || batch < 0 || heads < 1 || q_len < 1 || cols < 0) return QT_ERR_BAD_ARG;
+    if (fmt->kind == QT_FMT_LUT && !lut) return QT_ERR_BAD_ARG;
+    if (cols > 64L * 8 * kMaxVec) return QT_ERR_BAD_ARG;
+    if ((cols & 7) || (((uintptr_t)scores | (uintptr_t)out | (uintptr_t)mask | (uintptr_t)probs_dev) & 15u) ||
+        (mask && ((mask_sb | mask_sh | mask_sq) & 7)))
+        return QT_ERR_UNALIGNED;
+    SoftmaxArgs a{scores, mask, out, rows, cols, heads, q_len, mask_sb, mask_sh, mask_sq, scaling, *fmt, lut, scale, amax, nullptr, 0, probs_dev};
+    hipStream_t st = (hipStream_t)stream;
+    switch (fmt->kind) {
+        case QT_FMT_LUT: return (fmt->p1 & 1) ? launch_softmax<kFmtRows>(a, st) : launch_softmax<QT_FMT_LUT>(a, st);
+        case QT_FMT_FP_SAT: return launch_softmax<QT_FMT_FP_SAT>(a, st);
+        case QT_FMT_INT: return launch_softmax<QT_FMT_INT>(a, st);
+        case QT_FMT_IDENTITY: return launch_softmax<QT_FMT_IDENTITY>(a, st);
+        default: return QT_ERR_BAD_ARG;
+    }
+}
+
+namespace {
+template <int KIND, int NS>
+int launch_softmax_bwd(const SoftmaxBwdArgs &a, const qt_format &fmt, const uint16_t *lut, hipStream_t st) {
+    const int nv = (int)((a.cols / 8 + 63) / 64);
+    long want = (a.rows + 3) / 4;
+    if (want > 512) want = 512;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : want);
+    switch (nv) {
+        case 1: softmax_bwd_kernel<KIND, NS, 1><<<grid, 256, 0, st>>>(a, fmt, lut); break;
+        case 2: softmax_bwd_kernel<KIND, NS, 2><<<grid, 256, 0, st>>>(a, fmt, lut); break;
+        default: softmax_bwd_kernel<KIND, NS, 4><<<grid, 256, 0, st>>>(a, fmt, lut); break;
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+}  // namespace
+
+extern "C" int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_t *probs_dev, uint16_t *grad_scores_dev, long rows, long cols,
+                                              float scaling, const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev,
+                                              void *stream) {
+    if (rows * cols == 0) return QT_OK;
+    if (!grad_probs_dev || !probs_dev || !grad_scores_dev || !stages || !fmt || rows < 0 || cols < 8 || cols % 8 || cols > 64L * 8 * 4 || nstage < 1 ||
+        nstage > 2)
+        return QT_ERR_BAD_ARG;
+    if (((uintptr_t)grad_probs_dev | (uintptr_t)probs_dev | (uintptr_t)grad_scores_dev) & 15u) return QT_ERR_UNALIGNED;
+    SoftmaxBwdArgs a{};
+    a.dp = grad_probs_dev; a.p = probs_dev; a.ds = grad_scores_dev; a.rows = rows; a.cols = cols; a.scaling = scaling;
+    for (int i = 0; i < nstage; ++i) {
+        if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
+        if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
+        a.st[i] = ChainStageDev{stages[i].scale_f32_dev, stages[i].amax_bits_dev, (uint4 *)stages[i].out_dev, stages[i].src};
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (fmt->kind) {
+        case QT_FMT_LUT:
+            if (!lut_dev || !(fmt->p1 & 1)) return QT_ERR_BAD_DTYPE;
+            return nstage == 1 ? launch_softmax_bwd<kFmtRows, 1>(a, *fmt, lut_dev, st) : launch_softmax_bwd<kFmtRows, 2>(a, *fmt, lut_dev, st);
+        case QT_FMT_FP_SAT: return nstage == 1 ? launch_softmax_bwd<QT_FMT_FP_SAT, 1>(a, *fmt, lut_dev, st) : launch_softmax_bwd<QT_FMT_FP_SAT, 2>(a, *fmt, lut_dev, st);
+        case QT_FMT_INT: return nstage == 1 ? launch_softmax_bwd<QT_FMT_INT, 1>(a, *fmt, lut_dev, st) : launch_softmax_bwd<QT_FMT_INT, 2>(a, *fmt, lut_dev, st);
+        default: return QT_ERR_BAD_DTYPE;
+    }
 }

@@ -88,6 +88,14 @@ SIGNATURES = {
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "qt_fake_quant_chain_bf16": (c_int, [_P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
     "qt_fake_quant_chain_ws_bytes": (c_size_t, [c_long, c_long]),
+    "qt_gelu_chain_bf16": (c_int, [_P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
+    "qt_gelu_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
+    "qt_layernorm_train_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
+    "qt_layernorm_train_backward_groups": (c_long, [c_long]),
+    "qt_layernorm_train_backward_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, _P, c_size_t,
+                                                 _P, _P, _P, _P]),
+    "qt_softmax_fq_probs_bf16": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P, _P, _P]),
+    "qt_softmax_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
     "qt_build_rowparams": (c_int, [_P, POINTER(QtRowParams)]),
     "qt_rowparams_apply_host": (c_uint16, [POINTER(QtRowParams), c_uint16, POINTER(c_int)]),
     "qt_linear_fqt_bf16": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_uint32, _P, _P, c_int, c_int, _P]),
