@@ -84,6 +84,22 @@ __device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv 
     return fq_vec<kIoBf16, KIND, kDivExact, true>(v, dv, rnd, amax);
 }
 
+// A table format's row words (4 - 8 KiB behind the map's 65 536 entries) into LDS: a chain applies several fake-quantizers per vector, and
+// eight row gathers per stage from global memory made its kernels latency-bound (an LDS gather returns in ~100 cycles, an L1 hit in ~500).
+// s_rows: __shared__ uint4[512].  Other kinds: nothing to stage.
+template <int KIND>
+__device__ __forceinline__ Rounder<KIND> chain_rounder(const qt_format &fmt, const uint16_t *lut, uint4 *s_rows, int block) {
+    Rounder<KIND> rnd{fmt, nullptr, lut};
+    if constexpr (KIND == kFmtRows) {
+        const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
+        const int nrows = (fmt.p1 & 2) ? 512 : 256;
+        for (int i = threadIdx.x; i < nrows; i += block) s_rows[i] = g[i];
+        rnd.lds = (const uint16_t *)s_rows;
+        __syncthreads();
+    }
+    return rnd;
+}
+
 // All stages of a chain on one vector `v` (the producer's bf16 values): results written where a stage has an output, amax of every
 // stage's input accumulated, res[] left for the caller (column sums).  Stage indices are compile-time (a run-time index into the
 // kernel-argument struct would send it to scratch memory).

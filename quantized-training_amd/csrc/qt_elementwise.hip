@@ -301,7 +301,8 @@ __device__ __forceinline__ uint4 chain_prologue(int op, uint4 q, uint4 q2) {
 
 template <int KIND, int NS>
 __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
-    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock);
     const int t = threadIdx.x;
     const int v = t % kChainStripV, rl = t / kChainStripV;
     const int strip = blockIdx.x % a.strips, band = blockIdx.x / a.strips;
@@ -426,7 +427,8 @@ struct LnTrainArgs {
 
 template <int KIND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ln_train_fwd_kernel(LnTrainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
-    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, BLOCK);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * (BLOCK / 64) + wave;
     float sc[NS];
@@ -509,7 +511,8 @@ struct LnBwdArgs {
 template <int KIND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
     constexpr int RPB = BLOCK / 64;
-    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, BLOCK);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[NS];
     uint32_t amax[NS];
@@ -617,24 +620,31 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
     chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
 }
 
-// dgamma, dbeta (and the bias gradient) of one LayerNorm backward: the workgroups' partial sums added in workgroup order
+// dgamma, dbeta (and the bias gradient) of one LayerNorm backward: the workgroups' partial sums added in a fixed order -- a workgroup owns
+// 64 columns of one quantity, its four waves each add a quarter of the partials (eight loads in flight), the quarters meet in wave order
 __global__ __launch_bounds__(256) void ln_train_reduce_kernel(const float *__restrict__ part, int nwg, int cols, uint16_t *dgamma, uint16_t *dbeta,
                                                               uint16_t *colsum) {
-    const int c = blockIdx.x * 256 + threadIdx.x, qn = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, qn = blockIdx.y;
     uint16_t *out = qn == 0 ? dgamma : (qn == 1 ? dbeta : colsum);
-    if (c >= cols || !out) return;
-    const float *p = part + (size_t)qn * cols + c;
+    __shared__ float s_q[4][64];
     float sum = 0.0f;
-    int w = 0;
-    for (; w + 8 <= nwg; w += 8) {
-        float t[8];
+    if (c < cols && out) {
+        const int per = (nwg + 3) / 4, w0 = wave * per, w1 = min(nwg, w0 + per);
+        const float *p = part + (size_t)qn * cols + c;
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(w + u) * 3 * cols];
+            for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(w + u) * 3 * cols];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum += t[u];
+            for (int u = 0; u < 8; ++u) sum += t[u];
+        }
+        for (; w < w1; ++w) sum += p[(size_t)w * 3 * cols];
     }
-    for (; w < nwg; ++w) sum += p[(size_t)w * 3 * cols];
-    out[c] = (uint16_t)(pack_bf16x2(sum, 0.0f) & 0xFFFFu);
+    s_q[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && c < cols && out) out[c] = (uint16_t)(pack_bf16x2((s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]), 0.0f) & 0xFFFFu);
 }
 
 // ---- OCP FP8 side output ------------------------------------------------------------------------
@@ -1680,11 +1690,11 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     return launch_status();
 }
 
-// strips x bands of one chain launch: about 192 workgroups, bands of whole 64-row groups, at most 32 bands
+// strips x bands of one chain launch: about 384 workgroups, bands of whole 64-row groups, at most 32 bands
 static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows) {
     strips = (int)((cols / 8 + kChainStripV - 1) / kChainStripV);
     const long groups = (rows + kChainRowLanes - 1) / kChainRowLanes;           // 64-row groups
-    long want = (192 + strips - 1) / strips;
+    long want = (384 + strips - 1) / strips;
     if (want < 1) want = 1;
     if (want > 32) want = 32;
     if (want > groups) want = groups;
@@ -1819,8 +1829,8 @@ int qt_layernorm_train_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, c
     return launch_status();
 }
 
-// workgroups of the backward launch (512 threads = 8 waves, two rows per wave): its partial sums are part_dev[that many][3][cols] fp32
-long qt_layernorm_train_backward_groups(long rows) { return rows <= 0 ? 0 : (rows + 15) / 16; }
+// workgroups of the backward launch (512 threads = 8 waves, one row per wave): its partial sums are part_dev[that many][3][cols] fp32
+long qt_layernorm_train_backward_groups(long rows) { return rows <= 0 ? 0 : (rows + 7) / 8; }
 
 int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
                                      const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
@@ -1835,14 +1845,14 @@ int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     if (part_bytes < (size_t)groups * 3 * cols * sizeof(float)) return QT_ERR_BAD_ARG;
     LnBwdArgs a{};
     a.dy = (const uint4 *)grad_out_dev; a.x = (const uint4 *)x_dev; a.w = (const uint4 *)weight_dev; a.mean = mean_dev; a.rstd = rstd_dev;
-    a.dx = (uint4 *)grad_in_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.rows_per_wave = 2;
+    a.dx = (uint4 *)grad_in_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.rows_per_wave = 1;
     a.part = part_dev; a.colsum_stage = colsum_stage < 0 ? -1 : colsum_stage;
     if (const int rc = chain_stage_args(stages, nstage, a.st)) return rc;
     hipStream_t st = (hipStream_t)stream;
     auto grid = [&](int) { return groups; };
     QT_LN_DISPATCH(ln_train_bwd_kernel, a, grid)
     if (const int rc = launch_status()) return rc;
-    ln_train_reduce_kernel<<<dim3((unsigned)((cols + 255) / 256), colsum_stage >= 0 ? 3u : 2u), 256, 0, st>>>(part_dev, (int)groups, (int)cols, grad_weight_dev,
+    ln_train_reduce_kernel<<<dim3((unsigned)((cols + 63) / 64), colsum_stage >= 0 ? 3u : 2u), 256, 0, st>>>(part_dev, (int)groups, (int)cols, grad_weight_dev,
                                                                                                       grad_bias_dev, colsum_out_dev);
     return launch_status();
 }

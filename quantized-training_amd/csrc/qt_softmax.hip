@@ -56,9 +56,13 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
-template <int KIND, int NV>
+// G lanes per row: 64, or 16 / 32 for short rows (128 / 256 columns: the [16, 12, 128, 128] scores of a training step would leave three
+// lanes in four idle with a wave per row), NV vectors per lane
+template <int KIND, int NV, int G = 64>
 __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % G, sub = lane / G;
+    constexpr int RPW = 64 / G;
     Rounder<KIND> rnd{a.fmt, a.lut};
     if constexpr (KIND == kFmtRows) {
         // table formats whose map came with its row form (qt_format.p1 bit 0): the row words in LDS instead of a gather from the
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
     const UniformDiv dv(s);
     const int nvec_row = (int)(a.cols / 8);
     uint32_t amax = 0;
-    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RPW; row0 < a.rows; row0 += (long)gridDim.x * 4 * RPW) {
+        const long row = row0 + sub < a.rows ? row0 + sub : a.rows - 1;       // (a group past the last row recomputes it and stores nothing)
+        const bool row_ok = row0 + sub < a.rows;
         const uint4 *src = (const uint4 *)(a.scores + row * a.cols);
         const uint4 *msk = nullptr;
         if (a.mask) {
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
         float mx = -INFINITY;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int iv = v * 64 + lane;
-            if (iv < nvec_row && (long)v * 512 < live) {
+            const int iv = v * G + li;
+            if (iv < nvec_row && (long)v * G * 8 < live) {
                 const uint4 x = src[iv];
                 uint4 m = {0u, 0u, 0u, 0u};
                 if (msk) m = msk[iv];
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                 for (int j = 0; j < 8; ++j) t[v][j] = -INFINITY;
             }
         }
-        mx = wave_max_f32(mx);
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         float sum = 0.0f;
         // A 16-byte vector whose eight logits all lie more than 110 below the row maximum (a causal mask's -3.4e38)
         // contributes exp(.) == 0 exactly -- v_exp_f32 of anything below -158 is 0 -- so its exponentials, roundings and
@@ -145,14 +152,15 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                 }
             }
         }
-        sum = wave_sum_f32(sum);
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
         const float inv = 1.0f / sum;                 // one division per row; p = e * inv (<= 1 fp32 ULP from e / sum)
-        uint4 *dst = a.out ? (uint4 *)(a.out + row * a.cols) : nullptr;
-        uint2 *dst8 = a.out8 ? (uint2 *)(a.out8 + row * a.cols) : nullptr;
-        uint4 *dstp = a.probs ? (uint4 *)(a.probs + row * a.cols) : nullptr;
+        uint4 *dst = (a.out && row_ok) ? (uint4 *)(a.out + row * a.cols) : nullptr;
+        uint2 *dst8 = (a.out8 && row_ok) ? (uint2 *)(a.out8 + row * a.cols) : nullptr;
+        uint4 *dstp = (a.probs && row_ok) ? (uint4 *)(a.probs + row * a.cols) : nullptr;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int iv = v * 64 + lane;
+            const int iv = v * G + li;
             if (iv < nvec_row && dead[v]) {                  // fq(0) = +0, FP8 code 0; amax unaffected
                 if (dst) dst[iv] = uint4{0u, 0u, 0u, 0u};
                 if (dst8) dst8[iv] = uint2{0u, 0u};
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void softmax_fq_kernel(SoftmaxArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     uint32_t p = pack_bf16x2(t[v][2 * j] * inv, t[v][2 * j + 1] * inv);   // probabilities, bf16
                     pw[j] = p;
-                    if (a.amax) {
+                    if (a.amax && row_ok) {
                         uint32_t a0 = (p << 16) & 0x7FFFFFFFu, a1 = p & 0x7FFF0000u;
                         amax = amax > a0 ? amax : a0;
                         amax = amax > a1 ? amax : a1;
@@ -228,10 +236,14 @@ struct SoftmaxBwdArgs {
     ChainStageDev st[kChainMax];
 };
 
-template <int KIND, int NS, int NV>
+// G lanes per row (16 / 32 / 64: rows of 128 / 256 / more columns keep every lane busy), NV vectors per lane
+template <int KIND, int NS, int NV, int G>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
-    Rounder<KIND> rnd{fmt, KIND == kFmtRows ? lut + QT_MAP_ENTRIES : nullptr, lut};
+    __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, 256);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / G, li = lane % G;
+    constexpr int RPW = 64 / G;                                  // rows per wave
     float sc[NS];
     uint32_t amax[NS];
 #pragma unroll
@@ -240,14 +252,16 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxBwdArgs a, qt_f
         amax[i] = 0u;
     }
     const int nvec_row = (int)(a.cols / 8);
-    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += (long)gridDim.x * 4) {
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RPW; row0 < a.rows; row0 += (long)gridDim.x * 4 * RPW) {
+        const long row = row0 + sub;
+        const bool live = row < a.rows;
         const uint4 *gp = (const uint4 *)(a.dp + row * a.cols), *pp = (const uint4 *)(a.p + row * a.cols);
         float g[NV][8], pr[NV][8];
         float dot = 0.0f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int iv = v * 64 + lane;
-            if (iv < nvec_row) {
+            const int iv = v * G + li;
+            if (live && iv < nvec_row) {
                 const uint4 gv = gp[iv], pv = pp[iv];
                 const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
@@ -259,12 +273,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxBwdArgs a, qt_f
                 }
             }
         }
-        dot = wave_sum_f32(dot);
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
         uint4 *dst = (uint4 *)(a.ds + row * a.cols);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int iv = v * 64 + lane;
-            if (iv < nvec_row) {
+            const int iv = v * G + li;
+            if (live && iv < nvec_row) {
                 uint32_t o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -295,9 +310,20 @@ int launch_softmax(const SoftmaxArgs &a, hipStream_t st) {
                   ? p.multiProcessorCount : 256;
     }
     long want = (a.rows + 3) / 4;
-    long cap = (long)cus * (a.amax ? 2 : 16);       // observed (a training step): one amax atomic per workgroup, so fewer, longer workgroups
+    long cap = (long)cus * (a.amax ? 3 : 16);       // observed (a training step): one amax atomic per workgroup, so fewer, longer workgroups
     unsigned grid = (unsigned)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
+    if (nvec_row <= 32 && !a.row_live) {                        // short rows: several rows per wave
+        const int g = nvec_row <= 16 ? 16 : 32;
+        const long per_wg = 4L * (64 / g);
+        want = (a.rows + per_wg - 1) / per_wg;
+        grid = (unsigned)(want < cap ? want : cap);
+        if (grid < 1) grid = 1;
+        if (g == 16) softmax_fq_kernel<KIND, 1, 16><<<grid, 256, 0, st>>>(a);
+        else softmax_fq_kernel<KIND, 1, 32><<<grid, 256, 0, st>>>(a);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? QT_OK : (int)e;
+    }
     switch (nv) {
         case 1: softmax_fq_kernel<KIND, 1><<<grid, 256, 0, st>>>(a); break;
         case 2: softmax_fq_kernel<KIND, 2><<<grid, 256, 0, st>>>(a); break;
@@ -435,15 +461,17 @@ extern "C" int qt_softmax_fq_probs_bf16(const uint16_t *scores, const uint16_t *
 namespace {
 template <int KIND, int NS>
 int launch_softmax_bwd(const SoftmaxBwdArgs &a, const qt_format &fmt, const uint16_t *lut, hipStream_t st) {
-    const int nv = (int)((a.cols / 8 + 63) / 64);
-    long want = (a.rows + 3) / 4;
-    if (want > 512) want = 512;
+    const int nvec = (int)(a.cols / 8);
+    const int g = nvec <= 16 ? 16 : (nvec <= 32 ? 32 : 64);
+    const long per_wg = 4L * (64 / g);
+    long want = (a.rows + per_wg - 1) / per_wg;
+    if (want > 768) want = 768;                                 // (one amax atomic per stage and workgroup)
     const unsigned grid = (unsigned)(want < 1 ? 1 : want);
-    switch (nv) {
-        case 1: softmax_bwd_kernel<KIND, NS, 1><<<grid, 256, 0, st>>>(a, fmt, lut); break;
-        case 2: softmax_bwd_kernel<KIND, NS, 2><<<grid, 256, 0, st>>>(a, fmt, lut); break;
-        default: softmax_bwd_kernel<KIND, NS, 4><<<grid, 256, 0, st>>>(a, fmt, lut); break;
-    }
+    if (g == 16) softmax_bwd_kernel<KIND, NS, 1, 16><<<grid, 256, 0, st>>>(a, fmt, lut);
+    else if (g == 32) softmax_bwd_kernel<KIND, NS, 1, 32><<<grid, 256, 0, st>>>(a, fmt, lut);
+    else if (nvec <= 64) softmax_bwd_kernel<KIND, NS, 1, 64><<<grid, 256, 0, st>>>(a, fmt, lut);
+    else if (nvec <= 128) softmax_bwd_kernel<KIND, NS, 2, 64><<<grid, 256, 0, st>>>(a, fmt, lut);
+    else softmax_bwd_kernel<KIND, NS, 4, 64><<<grid, 256, 0, st>>>(a, fmt, lut);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }

@@ -562,6 +562,11 @@ def add_layernorm_or_none(block, hidden, residual):
 
 
 def _layernorm_forward(self, x):
+    if torch.is_grad_enabled() and x.is_cuda:
+        from . import train_fusions
+        y = train_fusions.layernorm_or_none(self, x)      # a training step: LayerNorm + the consumers' input quantizers in one launch
+        if y is not None:
+            return y
     if _layernorm_ok(self, x):
         return layernorm(x, self, None, _norm_consumer_fq(self, allow_all=True), codes_only=codes_only_ok(self.__dict__.get("_qt_consumers"), self))
     return self._qt_hf_forward(x)
@@ -576,6 +581,11 @@ def _intermediate_forward(self, hidden_states):
     act = self.intermediate_act_fn
     if isinstance(act, torch.nn.Module) and not _hooked(act) and _is_erf_gelu(act):
         h = self.dense(hidden_states)
+        if torch.is_grad_enabled() and h.is_cuda:
+            from . import train_fusions
+            y = train_fusions.gelu_or_none(self, h)           # a training step: GELU + the output dense's input quantizer in one launch
+            if y is not None:
+                return y
         if _eligible(h) and h.numel() % 8 == 0 and h.numel() > 0:
             consumer = self.__dict__.get("_qt_consumer")
             fq = consumer_fq(consumer) if consumer is not None and os.environ.get("QT_FUSED_PRODUCER_FQ", "1") != "0" else None

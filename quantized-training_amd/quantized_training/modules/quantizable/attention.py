@@ -115,6 +115,13 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
         probs, out = fused
         from ...model_fusions import attention_output
         return attention_output(module, out), probs
+    probs = None
+    if torch.is_grad_enabled() and scores.is_cuda:
+        from ...train_fusions import softmax_or_none
+        probs = softmax_or_none(module, scores, attention_mask, scaling, dropout)      # a training step: scaling, mask, softmax and
+        if probs is not None:                                                          # av_matmul's input quantizer in one launch
+            out = module.av_matmul(probs, value)
+            return out.transpose(1, 2).contiguous(), probs
     scores = module.attn_scaling(scores, scaling)
     if attention_mask is not None:
         scores = scores + attention_mask[..., : key.shape[-2]]

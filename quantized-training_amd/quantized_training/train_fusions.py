@@ -30,10 +30,12 @@ class _Counters:
     members = 0           # fake-quantizer calls served by a chain launch (heads included)
     colsums = 0           # bias gradients handed over
     misses = 0            # members that received another tensor than predicted
+    missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
         cls.chains = cls.members = cls.colsums = cls.misses = 0
+        cls.missed = []
 
 
 STATS = _Counters
@@ -71,24 +73,6 @@ def _member_ok(fq, device):
             and not getattr(fq, "_emit_fp8", None)      # (hooks on a member still see its call, input and result: forward() runs for every member)
             and (not fq._observe or (fq.amax_history.numel() > 0 and fq.amax_history.dim() == 1 and fq.amax_history.device == device))
             and fq.scale.numel() == 1 and fq.scale.device == device and fq.scale.dtype == torch.float32)
-
-
-class _ChainFn(torch.autograd.Function):
-    """The chain's results with the straight-through gradient of every member (fake_quantize.py:250-252 upstream): the gradient of x
-    is the sum of the gradients of the results that were used, added in member order."""
-
-    @staticmethod
-    def forward(ctx, x, run):
-        outs = run(x)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        total = None
-        for g in grads:
-            if g is not None:
-                total = g if total is None else total + g
-        return total, None
 
 
 _MAX = {}
@@ -178,7 +162,8 @@ def run_chain(head, chain, X):
             _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gb
         return outs
 
-    outs = _ChainFn.apply(X, launch) if need_grad else launch(X)
+    with torch.no_grad():
+        outs = launch(X)
     STATS.chains += 1
     STATS.members += 1
     _Stats.add(X.numel())                                      # the head's own call
@@ -186,7 +171,12 @@ def run_chain(head, chain, X):
         if i == 0:
             continue
         want = X if src < 0 else outs[src]
-        fq.__dict__["_qt_chain_result"] = (want.data_ptr(), want._version, tuple(want.shape), outs[i], want)
+        fq.__dict__["_qt_chain_result"] = (want.data_ptr(), want._version, tuple(want.shape), outs[i], want, False)
+    if need_grad:
+        # every member keeps an autograd node of its own (the straight-through gradient, fake_quantize.py:250-252), as in the unchained
+        # path: the engine then adds the members' gradients into x in the very order it would have, bit for bit
+        from .fake_quantize import _PrecomputedFakeQuant
+        return _PrecomputedFakeQuant.apply(X, outs[0])
     return outs[0]
 
 
@@ -197,15 +187,19 @@ def take_member_result(fq, X):
     if pend is None:
         return None
     fq.__dict__["_qt_chain_result"] = None
-    ptr, version, shape, out, _keep = pend
-    from .fake_quantize import _Stats, _take_preupdate
+    ptr, version, shape, out, _keep, connected = pend
+    from .fake_quantize import _Stats, _take_preupdate, _PrecomputedFakeQuant
     if X.data_ptr() == ptr and X._version == version and tuple(X.shape) == shape and X.is_contiguous():
         STATS.members += 1
         _Stats.add(X.numel())
         if fq._observe:
             _take_preupdate(fq.amax_history)                   # the batched scale update (or the chain's own) served this call
+        if not connected and torch.is_grad_enabled() and X.requires_grad:
+            return _PrecomputedFakeQuant.apply(X, out)         # the straight-through gradient of this call (fake_quantize.py:250-252)
         return out
     STATS.misses += 1
+    if len(STATS.missed) < 8:
+        STATS.missed.append((getattr(fq, "name", "?"), X.data_ptr() == ptr, X._version == version, tuple(X.shape), shape, X.is_contiguous()))
     if fq._observe and fq.amax_history.numel() > 0:
         # the chain has already rolled this quantizer's history for the call and added an amax that belongs to no call: start the slot again
         from .fake_quantize import _PREUPDATED
@@ -234,6 +228,8 @@ def unplan(model):
         if isinstance(m, FusedAmaxObsFakeQuantize):
             m.__dict__.pop("_qt_chain", None)
             m.__dict__.pop("_qt_chain_result", None)
+        elif isinstance(m, torch.nn.LayerNorm):
+            m.__dict__.pop("_qt_grad_head", None)
 
 
 def plan(model):
@@ -271,6 +267,7 @@ def plan(model):
             if len(members) > 1:
                 pre.__dict__["_qt_chain"] = Chain(members, colsum, name=type(mod).__name__)
                 chained.update(id(f) for f, _ in members)
+                ln.__dict__["_qt_grad_head"] = pre             # the gradient of this LayerNorm's input is exactly that chain's input
                 n += 1
     for mod in model.modules():
         q, k, v = getattr(mod, "query", None), getattr(mod, "key", None), getattr(mod, "value", None)
@@ -288,3 +285,309 @@ def plan(model):
                 chained.add(id(dpre))
                 n += 1
     return n
+
+
+# ---- producer kernels of a training step that evaluate the chain behind them in their own launch ---------------------------------
+def producers_enabled():
+    return enabled() and os.environ.get("QT_TRAIN_PRODUCERS", "1") != "0"
+
+
+def _members_format(members, dev):
+    """The one launch format of all members (same dtype, same map), or None."""
+    from .fake_quantize import _launch_format
+    if not members or not all(_member_ok(fq, dev) for fq, _ in members):
+        return None
+    head = members[0][0]
+    for fq, _ in members:
+        fq._move_to(dev)
+    fmt0 = _launch_format(head._qt_format, head.qmap)
+    if any(_launch_format(fq._qt_format, fq.qmap).key() != fmt0.key() or str(fq.dtype) != str(head.dtype) for fq, _ in members[1:]):
+        return None
+    if fmt0.kind == _native.QT_FMT_LUT and not (fmt0.p1 & 1):
+        return None
+    if fmt0.kind not in (_native.QT_FMT_LUT, _native.QT_FMT_FP_SAT, _native.QT_FMT_INT):
+        return None
+    return fmt0
+
+
+def _stages(members, like, st):
+    """(ctypes stage array, result tensors): every member's delayed-scaling update is issued (unless the step's batched update did it)."""
+    from .fake_quantize import launch_scale_update
+    outs = [torch.empty_like(like) for _ in members]
+    stages = (_native.QtChainStage * len(members))()
+    for i, (fq, src) in enumerate(members):
+        if fq._observe:
+            launch_scale_update(fq.amax_history, fq.scale, fq.quant_max, fq.force_scale_power_of_two, st)
+        stages[i].scale_f32_dev = fq.scale.data_ptr()
+        stages[i].amax_bits_dev = fq.amax_history.data_ptr() if fq._observe else None
+        stages[i].out_dev = outs[i].data_ptr()
+        stages[i].src = src
+    return stages, outs
+
+
+def _hand_over(members, produced, outs):
+    """Leaves every member's result for its call: member i will be called on `produced` (src -1) or on member src's result."""
+    for i, (fq, src) in enumerate(members):
+        want = produced if src < 0 else outs[src]
+        fq.__dict__["_qt_chain_result"] = (want.data_ptr(), want._version, tuple(want.shape), outs[i], want, False)
+    STATS.chains += 1
+
+
+def _lut_ptr(head, fmt):
+    return head.qmap.data_ptr() if fmt.kind == _native.QT_FMT_LUT else None
+
+
+def _grad_chain(head):
+    """(members, colsum) of the chain that starts at the backward quantizer `head`, validated for `head`'s device; (None, None) else."""
+    chain = head.__dict__.get("_qt_chain") if head is not None else None
+    if chain is None or chain.members[0][0] is not head:
+        return None, None
+    colsum = chain.colsum if os.environ.get("QT_TRAIN_COLSUM", "1") != "0" else None
+    if colsum is not None and (colsum[1].bias is None or not colsum[1].bias.requires_grad):
+        colsum = None
+    return chain.members, colsum
+
+
+def _float_scratch(kind, nbytes, dev):
+    from .fused import splitk_scratch
+    return splitk_scratch(kind, nbytes, 0, dev)[0]
+
+
+class _LayerNormTrainFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of a bf16 device tensor inside a training step: qt_layernorm_train_bf16 evaluates the input
+    quantizers of the Linears that read the result in its launch; the backward (qt_layernorm_train_backward_bf16) evaluates the
+    gradient chain of the residual add in front of it, and the dense layer's bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, consumers, grad_head):
+        from .fake_quantize import _stream_ptr
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        st = _stream_ptr(x)
+        members = [(fq, -1) for fq in consumers]
+        fmt = _members_format(members, x.device)
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        stages, outs = _stages(members, x, st)
+        _native.check(_native.lib().qt_layernorm_train_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                            rstd.data_ptr(), rows, cols, float(eps), stages, len(members), ctypes.byref(fmt),
+                                                            _lut_ptr(members[0][0], fmt), st), "qt_layernorm_train_bf16")
+        _hand_over(members, y, outs)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.grad_head = grad_head
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .fake_quantize import _stream_ptr
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        dy = dy.contiguous()
+        members, colsum = _grad_chain(ctx.grad_head)
+        fmt = _members_format(members, x.device) if members is not None else None
+        if fmt is None or dy.dtype != torch.bfloat16 or dy.data_ptr() % 16:
+            gx, gw, gb = torch.ops.aten.native_layer_norm_backward(dy, x, [cols], mean.view(*x.shape[:-1], 1), rstd.view(*x.shape[:-1], 1), weight, bias,
+                                                                   [True, True, True])
+            return gx, gw, gb, None, None, None
+        if colsum is not None and colsum[1].out_features != cols:
+            colsum = None
+        L = _native.lib()
+        st = _stream_ptr(x)
+        dx = torch.empty_like(x)
+        gw = torch.empty(cols, dtype=torch.bfloat16, device=x.device)
+        gb = torch.empty(cols, dtype=torch.bfloat16, device=x.device)
+        gbias = torch.empty(cols, dtype=torch.bfloat16, device=x.device) if colsum is not None else None
+        stages, outs = _stages(members, x, st)
+        pbytes = L.qt_layernorm_train_backward_groups(rows) * 3 * cols * 4
+        part = _float_scratch("lnbwd", pbytes, x.device)
+        _native.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                                         rows, cols, stages, len(members), ctypes.byref(fmt), _lut_ptr(members[0][0], fmt),
+                                                         colsum[0] if colsum is not None else -1, part.data_ptr(), part.numel() * 4, gw.data_ptr(),
+                                                         gb.data_ptr(), gbias.data_ptr() if gbias is not None else None, st),
+                      "qt_layernorm_train_backward_bf16")
+        _hand_over(members, dx, outs)
+        if gbias is not None:
+            g = outs[colsum[0]]
+            if len(_COLSUM) > 64:
+                _COLSUM.clear()
+            _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gbias
+        return dx, gw, gb, None, None, None
+
+
+def layernorm_or_none(norm, x):
+    """`norm(x)` of a training step through _LayerNormTrainFn, or None (the caller runs the module): bf16 device tensors under grad mode,
+    rows of at most 1024 columns, and at least one consuming Linear whose input quantizer can ride on the launch (`_qt_consumers`,
+    set by model_fusions.apply_bert_fusions)."""
+    if not (producers_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
+            and type(norm) is torch.nn.LayerNorm and norm.elementwise_affine and norm.bias is not None and len(norm.normalized_shape) == 1
+            and norm.weight.dtype == torch.bfloat16 and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
+            and x.data_ptr() % 16 == 0 and not norm._forward_hooks and not norm._forward_pre_hooks and not norm._backward_hooks):
+        return None
+    consumers = []
+    for lin in norm.__dict__.get("_qt_consumers") or []:
+        holder = getattr(lin, "activation_pre_process", None)
+        fq = _fq(holder, "0")
+        if fq is None or len(holder) != 1:
+            return None
+        consumers.append(fq)
+    if not consumers or len(consumers) > 4 or _members_format([(f, -1) for f in consumers], x.device) is None:
+        return None
+    return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"))
+
+
+class _GeluTrainFn(torch.autograd.Function):
+    """BertIntermediate's erf GELU inside a training step (qt_gelu_chain_bf16 / qt_gelu_backward_chain_bf16): the output dense's input
+    quantizer rides on the forward, the intermediate dense's backward-pre quantizer and its bias gradient on the backward."""
+
+    @staticmethod
+    def forward(ctx, h, consumer, grad_head):
+        from .fake_quantize import _stream_ptr
+        cols = h.shape[-1]
+        rows = h.numel() // cols
+        st = _stream_ptr(h)
+        members = [(consumer, -1)]
+        fmt = _members_format(members, h.device)
+        y = torch.empty_like(h)
+        stages, outs = _stages(members, h, st)
+        _native.check(_native.lib().qt_gelu_chain_bf16(h.data_ptr(), y.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), _lut_ptr(consumer, fmt), st),
+                      "qt_gelu_chain_bf16")
+        _hand_over(members, y, outs)
+        ctx.save_for_backward(h)
+        ctx.grad_head = grad_head
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .fake_quantize import _stream_ptr
+        (h,) = ctx.saved_tensors
+        cols = h.shape[-1]
+        rows = h.numel() // cols
+        dy = dy.contiguous()
+        members, colsum = _grad_chain(ctx.grad_head)
+        fmt = _members_format(members, h.device) if members is not None else None
+        if fmt is None or dy.dtype != torch.bfloat16 or dy.data_ptr() % 16:
+            return torch.ops.aten.gelu_backward(dy, h, approximate="none"), None, None
+        if colsum is not None and colsum[1].out_features != cols:
+            colsum = None
+        L = _native.lib()
+        st = _stream_ptr(h)
+        dx = torch.empty_like(h)
+        stages, outs = _stages(members, h, st)
+        gbias = ws = None
+        if colsum is not None:
+            ws = _chain_scratch(L.qt_fake_quant_chain_ws_bytes(rows, cols), h.device)
+            gbias = torch.empty(cols, dtype=torch.bfloat16, device=h.device)
+        _native.check(L.qt_gelu_backward_chain_bf16(dy.data_ptr(), h.data_ptr(), dx.data_ptr(), rows, cols, stages, len(members), ctypes.byref(fmt),
+                                                    _lut_ptr(members[0][0], fmt), colsum[0] if colsum is not None else -1, _format_max(members[0][0]),
+                                                    gbias.data_ptr() if gbias is not None else None, ws.data_ptr() if ws is not None else None,
+                                                    ws.numel() if ws is not None else 0, st), "qt_gelu_backward_chain_bf16")
+        _hand_over(members, dx, outs)
+        if gbias is not None:
+            g = outs[colsum[0]]
+            if len(_COLSUM) > 64:
+                _COLSUM.clear()
+            _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gbias
+        return dx, None, None
+
+
+def gelu_or_none(intermediate, h):
+    """`intermediate_act_fn(h)` of a BertIntermediate inside a training step, or None."""
+    consumer = intermediate.__dict__.get("_qt_consumer")
+    holder = getattr(consumer, "activation_pre_process", None) if consumer is not None else None
+    fq = _fq(holder, "0")
+    if not (producers_enabled() and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.bfloat16 and h.is_contiguous() and h.dim() >= 2
+            and h.shape[-1] % 8 == 0 and h.data_ptr() % 16 == 0 and fq is not None and len(holder) == 1
+            and _members_format([(fq, -1)], h.device) is not None):
+        return None
+    dense = getattr(intermediate, "dense", None)
+    head = _fq(getattr(dense, "error_pre_process", None), "0") if dense is not None else None
+    return _GeluTrainFn.apply(h, fq, head)
+
+
+class _SoftmaxTrainFn(torch.autograd.Function):
+    """attn_scaling -> (+ mask) -> softmax of the quantizable attention blocks inside a training step (modules/quantizable/attention.py;
+    upstream modeling_bert.py:142-158): qt_softmax_fq_probs_bf16 writes the probabilities and evaluates av_matmul's input quantizer on
+    them; the backward (qt_softmax_backward_chain_bf16) evaluates qk_matmul's backward-pre quantizer on the gradient of the scores."""
+
+    @staticmethod
+    def forward(ctx, scores, mask, strides, scaling, fq_p, grad_head):
+        from .fake_quantize import _stream_ptr, launch_scale_update
+        B, H, Q, C = scores.shape
+        st = _stream_ptr(scores)
+        fmt = _members_format([(fq_p, -1)], scores.device)
+        probs = torch.empty_like(scores)
+        out = torch.empty_like(scores)
+        if fq_p._observe:
+            launch_scale_update(fq_p.amax_history, fq_p.scale, fq_p.quant_max, fq_p.force_scale_power_of_two, st)
+        msb, msh, msq = strides
+        _native.check(_native.lib().qt_softmax_fq_probs_bf16(scores.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(),
+                                                             probs.data_ptr(), B, H, Q, C, msb, msh, msq, float(scaling), ctypes.byref(fmt),
+                                                             fq_p.qmap.data_ptr(), fq_p.scale.data_ptr(),
+                                                             fq_p.amax_history.data_ptr() if fq_p._observe else None, st), "qt_softmax_fq_probs_bf16")
+        _hand_over([(fq_p, -1)], probs, [out])
+        ctx.save_for_backward(probs)
+        ctx.scaling = float(scaling)
+        ctx.grad_head = grad_head
+        return probs
+
+    @staticmethod
+    def backward(ctx, dp):
+        from .fake_quantize import _stream_ptr
+        (probs,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        members, _ = _grad_chain(ctx.grad_head)
+        if members is None and ctx.grad_head is not None:
+            members = [(ctx.grad_head, -1)]
+        fmt = _members_format(members, probs.device) if members is not None else None
+        if fmt is None or len(members) > 2 or dp.dtype != torch.bfloat16 or dp.data_ptr() % 16:
+            ds = torch.ops.aten._softmax_backward_data(dp, probs, -1, probs.dtype)
+            return ds * ctx.scaling, None, None, None, None, None
+        st = _stream_ptr(probs)
+        C = probs.shape[-1]
+        rows = probs.numel() // C
+        ds = torch.empty_like(probs)
+        stages, outs = _stages(members, probs, st)
+        _native.check(_native.lib().qt_softmax_backward_chain_bf16(dp.data_ptr(), probs.data_ptr(), ds.data_ptr(), rows, C, ctx.scaling, stages,
+                                                                   len(members), ctypes.byref(fmt), _lut_ptr(members[0][0], fmt), st),
+                      "qt_softmax_backward_chain_bf16")
+        _hand_over(members, ds, outs)
+        return ds, None, None, None, None, None
+
+
+def softmax_or_none(attn, scores, attention_mask, scaling, dropout):
+    """probs = softmax(attn_scaling(scores, scaling) + mask) of a quantizable attention block inside a training step, or None: nothing
+    hooks the scaling or the softmax (`--quantize_forward gemm`), no active dropout, av_matmul's input quantizers exist."""
+    if not (producers_enabled() and torch.is_grad_enabled() and scores.requires_grad and scores.is_cuda and scores.dtype == torch.bfloat16
+            and scores.dim() == 4 and scores.is_contiguous() and scores.shape[-1] % 8 == 0 and scores.shape[-1] <= 2048 and scores.data_ptr() % 16 == 0):
+        return None
+    if dropout and attn.training:
+        return None
+    for name in ("attn_scaling", "softmax"):
+        mod = getattr(attn, name, None)
+        if mod is None or mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks \
+                or getattr(mod, "activation_pre_process", None) is not None:
+            return None
+    if type(attn.softmax) is not torch.nn.Softmax:             # (the fp32 softmax of the LLaMA twin rounds at other points)
+        return None
+    holder = getattr(attn.av_matmul, "activation_pre_process", None)
+    fq_p = _fq(holder, "0")
+    if fq_p is None or _members_format([(fq_p, -1)], scores.device) is None:
+        return None
+    B, H, Q, C = scores.shape
+    mask = None
+    strides = (0, 0, 0)
+    if attention_mask is not None:
+        m = attention_mask[..., :C]
+        if m.dtype != torch.bfloat16 or m.dim() != 4 or m.stride(-1) != 1 or m.device != scores.device or m.requires_grad:
+            return None
+        if m.shape[0] not in (1, B) or m.shape[1] not in (1, H) or m.shape[2] not in (1, Q):
+            return None
+        strides = (m.stride(0) if m.shape[0] == B and B > 1 else 0, m.stride(1) if m.shape[1] == H and H > 1 else 0,
+                   m.stride(2) if m.shape[2] == Q and Q > 1 else 0)
+        if (strides[0] | strides[1] | strides[2]) % 8 != 0 or m.data_ptr() % 16 != 0:
+            return None
+        mask = m
+    head = _fq(getattr(attn.qk_matmul, "error_pre_process", None), "0")
+    return _SoftmaxTrainFn.apply(scores, mask, strides, scaling, fq_p, head)

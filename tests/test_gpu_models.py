@@ -1042,7 +1042,8 @@ def test_full_size_roberta_layer_training_steps_against_the_cpu_path(monkeypatch
 
 def test_training_chains_change_launches_not_values(monkeypatch):
     """train_fusions: the fake-quantizer chains of a training step (one launch for the four gradient quantizers behind a LayerNorm, one
-    for the input quantizers of query / key / value, the bias gradient's column sums on the way) leave every value as it was: three
+    for the input quantizers of query / key / value, the bias gradient's column sums on the way; QT_TRAIN_PRODUCERS=0: torch's own
+    LayerNorm / GELU / softmax kernels) leave every value as it was: three
     steps of a 2-layer RoBERTa-shaped classifier with and without chains -- losses, every fake-quantizer's scale and amax history and
     every parameter bit-identical when the column sums stay with qt_colsum_bf16 (QT_TRAIN_COLSUM=0), and within one AdamW step's noise
     with them (another, fixed summation order).  The counters say the chains ran, and that no member missed its tensor."""
@@ -1057,9 +1058,10 @@ def test_training_chains_change_launches_not_values(monkeypatch):
     g = torch.Generator().manual_seed(1)
     batches = [{"input_ids": torch.randint(3, 500, (8, 64), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)} for _ in range(3)]
 
-    def run(chains, colsum):
+    def run(chains, colsum, producers=False):
         monkeypatch.setenv("QT_TRAIN_CHAINS", "1" if chains else "0")
         monkeypatch.setenv("QT_TRAIN_COLSUM", "1" if colsum else "0")
+        monkeypatch.setenv("QT_TRAIN_PRODUCERS", "1" if producers else "0")
         m = copy.deepcopy(base).cuda().train()
         qt.quantize(m, _args(*_TRAIN_FLAGS))
         opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
@@ -1070,19 +1072,28 @@ def test_training_chains_change_launches_not_values(monkeypatch):
         params = {n: p.detach().clone() for n, p in m.named_parameters()}
         return losses, state, params, (train_fusions.STATS.chains, train_fusions.STATS.members, train_fusions.STATS.colsums,
                                        train_fusions.STATS.misses), (STATS.elements, STATS.calls)
-    plain = run(False, False)
-    chained = run(True, False)
+    det = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)      # (torch's own scatter-add kernels: run-to-run bit-identical for this comparison)
+    try:
+        plain = run(False, False)
+        again = run(False, False)
+        chained = run(True, False)
+    finally:
+        torch.use_deterministic_algorithms(det)
+    if again[0] != plain[0] or any(not torch.equal(plain[2][k], again[2][k]) for k in plain[2]):
+        pytest.skip("torch's own kernels are not run-to-run bit-identical on this box: nothing to compare bit for bit")
     assert plain[3] == (0, 0, 0, 0)
     # steps 2 and 3 run chained (the first step creates the fake-quantizers): per layer and step 2 gradient chains of 4, one q / k / v
     # chain of 3, and single-member chains for the other Linears' grad_output quantizers
-    assert chained[3][0] >= 2 * 2 * 3 and chained[3][1] >= 2 * 2 * (4 + 4 + 3) and chained[3][2] == 0 and chained[3][3] == 0, chained[3]
+    assert chained[3][0] >= 2 * 2 * 3 and chained[3][1] >= 2 * 2 * (4 + 4 + 3) and chained[3][2] == 0 and chained[3][3] == 0, (chained[3], train_fusions.STATS.missed)
     assert chained[4] == plain[4]                                  # same fake-quantized element and call counts
     assert chained[0] == plain[0]
-    for k in plain[1]:
-        assert torch.equal(plain[1][k][0], chained[1][k][0]) and torch.equal(plain[1][k][1], chained[1][k][1]), k
+    bad = [k for k in plain[1] if not (torch.equal(plain[1][k][0], chained[1][k][0]) and torch.equal(plain[1][k][1], chained[1][k][1]))]
+    assert not bad, (len(bad), bad[:8], [(plain[1][k][1][:3].tolist(), chained[1][k][1][:3].tolist()) for k in bad[:3]])
     for k in plain[2]:
         assert torch.equal(plain[2][k], chained[2][k]), k
-    full = run(True, True)
+    full = run(True, True, producers=True)          # + the LayerNorm / GELU / softmax kernels that evaluate the chains behind them (other
+    # summation orders than torch's kernels: close, not bit-identical)
     # (most biased Linears' gradients come with their column sums: not those whose grad_output arrives as a permuted view, nor the 2-column head)
     assert full[3][2] >= 2 * 9 and full[3][3] == 0, full[3]
     assert full[4] == plain[4]

@@ -1965,6 +1965,170 @@ def test_fake_quant_chain_equals_the_single_passes(nv, dtype, scales, rows, cols
                                           stream()) == nv.QT_ERR_BAD_ARG
 
 
+def _chain_setup(nv, dtype, scales, like, src):
+    """Stage array + outputs + amax slots for a producer kernel, and a checker: every stage equals its own qt_fake_quant_bf16 launch on the
+    tensor it reads (bit for bit, amax included)."""
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    lut = qt_pkg.get_quantization_map(dtype, torch.device("cuda"))
+    fmt = _launch_format(nv.format_for(dtype), lut)
+    n = len(scales)
+    sc = [torch.tensor([s_], dtype=torch.float32, device="cuda") for s_ in scales]
+    outs = [torch.full_like(like, float("nan")) for _ in range(n)]
+    amax = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(n)]
+    stages = (nv.QtChainStage * n)()
+    for i in range(n):
+        stages[i].scale_f32_dev, stages[i].amax_bits_dev, stages[i].out_dev, stages[i].src = sc[i].data_ptr(), amax[i].data_ptr(), outs[i].data_ptr(), src[i]
+
+    def check(produced):
+        for i in range(n):
+            inp = produced if src[i] < 0 else outs[src[i]]
+            want = torch.empty_like(inp)
+            am = torch.zeros(1, dtype=torch.float32, device="cuda")
+            nv.check(L.qt_fake_quant_bf16(inp.data_ptr(), want.data_ptr(), inp.numel(), ctypes.byref(fmt), lut.data_ptr(), sc[i].data_ptr(), am.data_ptr(),
+                                          stream()), "qt_fake_quant_bf16")
+            assert torch.equal(o.canon_nan16(host_u16(outs[i].view(torch.int16))) if False else outs[i].view(torch.int16), want.view(torch.int16)), i
+            assert torch.equal(amax[i].view(torch.int32), am.view(torch.int32)), i
+    return stages, fmt, lut, outs, check
+
+
+def _ulp_close(a, b, share):
+    """bf16 tensors equal up to one bf16 step on at most `share` of the elements (and never further)."""
+    ia, ib = a.view(torch.int16).int(), b.view(torch.int16).int()
+    ia = torch.where(ia < 0, -32768 - ia, ia)
+    ib = torch.where(ib < 0, -32768 - ib, ib)
+    d = (ia - ib).abs()
+    ok = int(d.max()) <= 1 and float((d > 0).float().mean()) <= share
+    if not ok:
+        print(f"[_ulp_close] max code distance {int(d.max())}, share differing {float((d > 0).float().mean()):.5f} (allowed {share})")
+    return ok
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 768), (37, 1024), (300, 264)])
+def test_layernorm_train_kernels_against_torch_and_the_single_passes(nv, rows, cols):
+    """qt_layernorm_train_bf16 / _backward_bf16 (the LayerNorm of a training step with the fake-quantizer calls around it): y, mean, rstd
+    against torch's layer_norm on the same bf16 input (one bf16 step on < 0.5 % of the elements: another summation order of the
+    statistics); grad_in / grad_weight / grad_bias against torch's native_layer_norm_backward on the kernel's own mean / rstd; every
+    stage bit for bit its own fake-quantizer launch on the tensor the kernel produced; the bias-gradient column sums against fp64."""
+    L = nv.lib()
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, cols, device="cuda") * 2 + 0.3).bfloat16()
+    w = (1 + 0.1 * torch.randn(cols, device="cuda")).bfloat16()
+    b = (0.1 * torch.randn(cols, device="cuda")).bfloat16()
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device="cuda")
+    rstd = torch.empty(rows, dtype=torch.float32, device="cuda")
+    stages, fmt, lut, outs, check = _chain_setup(nv, "int8", (0.031, 0.029, 0.04), x, (-1, -1, -1))
+    nv.check(L.qt_layernorm_train_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, stages, 3,
+                                       ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_layernorm_train_bf16")
+    ref = torch.nn.functional.layer_norm(x, (cols,), w, b, 1e-5)
+    big = ref.float().abs() >= 2.0 ** -4                        # (outputs near zero come from a cancellation: compare those absolutely)
+    assert _ulp_close(torch.where(big, y, ref), ref, 5e-3)
+    assert float((y.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+    assert float((y.float() - ref.float())[~big].abs().max()) <= 2.0 ** -9
+    xf = x.float()
+    assert torch.allclose(mean, xf.mean(-1), rtol=1e-5, atol=1e-6) and torch.allclose(rstd, (xf.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5)
+    check(y)
+    # backward
+    dy = (torch.randn(rows, cols, device="cuda") * 3e-5).bfloat16()
+    dx = torch.empty_like(x)
+    gw, gb, gbias = (torch.empty(cols, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    stages, fmt, lut, outs, check = _chain_setup(nv, "fp8_e5m2", (2.1e-9, 1.7e-9, 2.6e-9, 1.0), dx, (-1, 0, 0, 1))
+    groups = L.qt_layernorm_train_backward_groups(rows)
+    part = torch.empty(groups * 3 * cols, dtype=torch.float32, device="cuda")
+    nv.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), rows, cols, stages, 4,
+                                                ctypes.byref(fmt), lut.data_ptr(), 3, part.data_ptr(), part.numel() * 4, gw.data_ptr(), gb.data_ptr(),
+                                                gbias.data_ptr(), stream()), "qt_layernorm_train_backward_bf16")
+    rx, rw, rb = torch.ops.aten.native_layer_norm_backward(dy, x, [cols], mean.view(rows, 1), rstd.view(rows, 1), w, b, [True, True, True])
+    scale = float(rx.float().abs().max())
+    assert float((dx.float() - rx.float()).abs().max()) <= 2.0 ** -7 * scale
+    assert float((dx.float() - rx.float()).abs().mean()) <= 2.0 ** -10 * scale
+    xhat = (xf - mean[:, None]) * rstd[:, None]
+    ref_w, ref_b = (dy.double() * xhat.double()).sum(0), dy.double().sum(0)
+    tol_w = ref_w.abs() * 2.0 ** -7 + (dy.double().abs() * xhat.double().abs()).sum(0) * 2.0 ** -18
+    tol_b = ref_b.abs() * 2.0 ** -7 + dy.double().abs().sum(0) * 2.0 ** -18
+    assert bool(((gw.double() - ref_w).abs() <= tol_w).all()) and bool(((gb.double() - ref_b).abs() <= tol_b).all())
+    check(dx)
+    ref_c = outs[3].double().sum(0)
+    assert bool(((gbias.double() - ref_c).abs() <= ref_c.abs() * 2.0 ** -7 + outs[3].double().abs().sum(0) * 2.0 ** -18).all())
+    gw2, gb2 = torch.empty_like(gw), torch.empty_like(gb)
+    nv.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), rows, cols, stages, 4,
+                                                ctypes.byref(fmt), lut.data_ptr(), -1, part.data_ptr(), part.numel() * 4, gw2.data_ptr(), gb2.data_ptr(), None,
+                                                stream()), "qt_layernorm_train_backward_bf16")
+    assert torch.equal(gw.view(torch.int16), gw2.view(torch.int16)) and torch.equal(gb.view(torch.int16), gb2.view(torch.int16))
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 3072), (77, 64)])
+def test_gelu_train_kernels_against_torch_and_the_single_passes(nv, rows, cols):
+    """qt_gelu_chain_bf16 equals torch's erf GELU on bf16 bit for bit; qt_gelu_backward_chain_bf16 equals torch's gelu_backward up to one
+    bf16 step on a small share (expf / erff of another library); stages bit for bit their own launches; column sums against fp64."""
+    L = nv.lib()
+    torch.manual_seed(cols)
+    x = (torch.randn(rows, cols, device="cuda") * 1.5).bfloat16()
+    y = torch.empty_like(x)
+    stages, fmt, lut, outs, check = _chain_setup(nv, "int8", (0.023,), x, (-1,))
+    nv.check(L.qt_gelu_chain_bf16(x.data_ptr(), y.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_gelu_chain_bf16")
+    assert torch.equal(y.view(torch.int16), torch.nn.functional.gelu(x).view(torch.int16))
+    check(y)
+    dy = (torch.randn(rows, cols, device="cuda") * 2e-5).bfloat16()
+    dx = torch.empty_like(x)
+    gb = torch.empty(cols, dtype=torch.bfloat16, device="cuda")
+    stages, fmt, lut, outs, check = _chain_setup(nv, "fp8_e5m2", (1.5e-9,), dx, (-1,))
+    wb = L.qt_fake_quant_chain_ws_bytes(rows, cols)
+    ws = torch.zeros(wb, dtype=torch.uint8, device="cuda")
+    nv.check(L.qt_gelu_backward_chain_bf16(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), lut.data_ptr(), 0, 57344.0,
+                                           gb.data_ptr(), ws.data_ptr(), wb, stream()), "qt_gelu_backward_chain_bf16")
+    assert _ulp_close(dx, torch.ops.aten.gelu_backward(dy, x, approximate="none"), 2e-2)
+    check(dx)
+    ref = outs[0].double().sum(0)
+    assert bool(((gb.double() - ref).abs() <= ref.abs() * 2.0 ** -7 + outs[0].double().abs().sum(0) * 2.0 ** -20).all())
+    assert not bool(ws.any())
+
+
+@pytest.mark.parametrize("B,H,Q,C,masked", [(16, 12, 128, 128, True), (2, 3, 40, 384, False)])
+def test_softmax_train_kernels_against_torch_and_the_single_passes(nv, B, H, Q, C, masked):
+    """qt_softmax_fq_probs_bf16: the unquantized probabilities equal the module chain's (bf16(score * scaling), bf16(+ mask), softmax:
+    one bf16 step on a small share) and the quantized ones are exactly the fake-quantizer of those; qt_softmax_backward_chain_bf16 against
+    torch's _softmax_backward_data and the scaling's backward, its stage bit for bit its own launch."""
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    torch.manual_seed(C)
+    scores = (torch.randn(B, H, Q, C, device="cuda") * 3).bfloat16()
+    mask = None
+    if masked:
+        mask = torch.zeros(B, 1, 1, C, device="cuda", dtype=torch.bfloat16)
+        mask[::2, :, :, C - 24:] = torch.finfo(torch.bfloat16).min
+    scaling = 0.125
+    lut = qt_pkg.get_quantization_map("int8", torch.device("cuda"))
+    fmt = _launch_format(nv.format_for("int8"), lut)
+    sc = torch.tensor([0.0079], dtype=torch.float32, device="cuda")
+    am = torch.zeros(1, dtype=torch.float32, device="cuda")
+    out, probs = torch.empty_like(scores), torch.empty_like(scores)
+    nv.check(L.qt_softmax_fq_probs_bf16(scores.data_ptr(), mask.data_ptr() if masked else None, out.data_ptr(), probs.data_ptr(), B, H, Q, C,
+                                        mask.stride(0) if masked else 0, 0, 0, scaling, ctypes.byref(fmt), lut.data_ptr(), sc.data_ptr(), am.data_ptr(),
+                                        stream()), "qt_softmax_fq_probs_bf16")
+    t = scores * scaling
+    if masked:
+        t = t + mask
+    ref = torch.softmax(t, -1)
+    assert _ulp_close(probs, ref, 2e-2)
+    want = torch.empty_like(probs)
+    am2 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    nv.check(L.qt_fake_quant_bf16(probs.data_ptr(), want.data_ptr(), probs.numel(), ctypes.byref(fmt), lut.data_ptr(), sc.data_ptr(), am2.data_ptr(), stream()), "fq")
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16)) and torch.equal(am.view(torch.int32), am2.view(torch.int32))
+    dp = (torch.randn(B, H, Q, C, device="cuda") * 1e-4).bfloat16()
+    ds = torch.empty_like(scores)
+    stages, fmt5, lut5, outs, check = _chain_setup(nv, "fp8_e5m2", (3.0e-10,), ds, (-1,))
+    nv.check(L.qt_softmax_backward_chain_bf16(dp.data_ptr(), probs.data_ptr(), ds.data_ptr(), B * H * Q, C, scaling, stages, 1, ctypes.byref(fmt5), lut5.data_ptr(),
+                                              stream()), "qt_softmax_backward_chain_bf16")
+    rs = torch.ops.aten._softmax_backward_data(dp, probs, -1, probs.dtype) * scaling
+    scale = float(rs.float().abs().max())
+    assert float((ds.float() - rs.float()).abs().max()) <= 2.0 ** -7 * scale and float((ds.float() - rs.float()).abs().mean()) <= 2.0 ** -10 * scale
+    check(ds)
+
+
 def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
     """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
     the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,
