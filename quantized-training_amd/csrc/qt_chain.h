@@ -88,9 +88,13 @@ __device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv 
 // eight row gathers per stage from global memory made its kernels latency-bound (an LDS gather returns in ~100 cycles, an L1 hit in ~500).
 // s_rows: __shared__ uint4[512].  Other kinds: nothing to stage.
 template <int KIND>
-__device__ __forceinline__ Rounder<KIND> chain_rounder(const qt_format &fmt, const uint16_t *lut, uint4 *s_rows, int block) {
+__device__ __forceinline__ Rounder<KIND> chain_rounder(const qt_format &fmt, const uint16_t *lut, uint4 *s_rows, int block, bool in_lds = true) {
     Rounder<KIND> rnd{fmt, nullptr, lut};
     if constexpr (KIND == kFmtRows) {
+        if (!in_lds) {                                            // (tuning: the table where it lies, as fq_rows_direct_kernel reads it)
+            rnd.lds = lut + QT_MAP_ENTRIES;
+            return rnd;
+        }
         const uint4 *g = (const uint4 *)(lut + QT_MAP_ENTRIES);
         const int nrows = (fmt.p1 & 2) ? 512 : 256;
         for (int i = threadIdx.x; i < nrows; i += block) s_rows[i] = g[i];

@@ -277,6 +277,7 @@ struct ChainArgs {
     int pre_op;
     const uint4 *x2;
     uint4 *pre_out;
+    int table_in_lds;         // table formats: stage the row words in LDS (else gather them from global memory)
 };
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -302,7 +303,7 @@ __device__ __forceinline__ uint4 chain_prologue(int op, uint4 q, uint4 q2) {
 template <int KIND, int NS>
 __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
-    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock);
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock, a.table_in_lds != 0);
     const int t = threadIdx.x;
     const int v = t % kChainStripV, rl = t / kChainStripV;
     const int strip = blockIdx.x % a.strips, band = blockIdx.x / a.strips;
@@ -1690,11 +1691,15 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     return launch_status();
 }
 
-// strips x bands of one chain launch: about 384 workgroups, bands of whole 64-row groups, at most 32 bands
+// strips x bands of one chain launch: about 192 workgroups, bands of whole 64-row groups, at most 32 bands
 static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows) {
     strips = (int)((cols / 8 + kChainStripV - 1) / kChainStripV);
     const long groups = (rows + kChainRowLanes - 1) / kChainRowLanes;           // 64-row groups
-    long want = (384 + strips - 1) / strips;
+    int target = 192;                                              // measured (profiles/r05_chain_geometry.txt): 96 and 384 workgroups are both slower
+#ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_CHAIN_WGS")) target = atoi(e) > 0 ? atoi(e) : target;          // tools/ only
+#endif
+    long want = (target + strips - 1) / strips;
     if (want < 1) want = 1;
     if (want > 32) want = 32;
     if (want > groups) want = groups;
@@ -1713,6 +1718,10 @@ static int chain_launch(const uint16_t *x_dev, const uint16_t *x2_dev, int pre_o
     ChainArgs a{};
     a.x = (const uint4 *)x_dev; a.rows = rows; a.cv = (int)(cols / 8); a.nstage = nstage;
     a.pre_op = pre_op; a.x2 = (const uint4 *)x2_dev; a.pre_out = (uint4 *)pre_out_dev;
+    a.table_in_lds = 1;
+#ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_CHAIN_LDS")) a.table_in_lds = atoi(e);                          // tools/ only
+#endif
     for (int i = 0; i < nstage; ++i) {
         if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
         if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
