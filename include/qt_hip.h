@@ -328,6 +328,37 @@ int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_
                                    float scaling, const qt_chain_stage *stages, int nstage, const qt_format *fmt, const uint16_t *lut_dev,
                                    void *stream);
 
+/* ---- the attention core of a TRAINING step, one launch forward and one backward (round 5) ------------------------------------------
+ * Replaces everything between the query / key / value projections and the output projection of the reference's quantizable
+ * attention block (modules/quantizable/modeling_bert.py:118-158, functional_modules.py:22-26, hooks: quantize.py:116-179) for
+ * head_dim 64 and 32..128 positions (a multiple of 32) -- qt_attention_train_supported says whether a shape is covered:
+ *   forward   q' = fq0(q), k' = fq1(k), v' = fq2(v);  S = bf16(q' k'^T);  P = softmax(bf16(bf16(S * scaling) + mask)) (fp32 inside,
+ *             one rounding);  P' = fq3(P);  O = bf16(P' v');  optionally fq4(O) (the output projection's input quantizer)
+ *   backward  g = e0(dO);  dP = bf16(g v'^T), dV = bf16(P'^T g);  dS = bf16(bf16((dP - sum dP P) P) * scaling);  dS' = e1(dS);
+ *             dQ = bf16(dS' k'), dK = bf16(dS'^T q')
+ * Every fq / e is one qt_fake_quant_bf16 call with its own scale and amax slot (fqs[i]: scale_f32_dev, amax_bits_dev -- nullable:
+ * not observed --, out_dev; src ignored); all quantizers of a launch share `fmt`.  One workgroup per (batch, head), the products on
+ * the matrix cores with fp32 accumulation; the softmax arithmetic is qt_softmax_fq_probs_bf16's / qt_softmax_backward_chain_bf16's.
+ * q, k, v: [batch, heads, positions, 64] views given by the element strides of batch, position and head (the 64 values of a head
+ *   contiguous, strides % 8 == 0); fqs[0..2].out_dev (q', k', v') are written with the SAME strides and are what the backward reads.
+ * mask: additive bf16, nullable, element strides of (batch, head, query row), columns contiguous.
+ * probs_dev, fqs[3].out_dev: P and P', [batch, heads, positions, positions].  out_dev, fqs[4].out_dev (nullable): O and fq4(O) in
+ *   [batch, positions, heads, 64] -- the layout the output projection reads, so no permute copy follows.
+ * backward: grad_out_dev and grad_q/k/v_dev in [batch, positions, heads, 64]; fqs[0] = e0 (av_matmul's backward-pre quantizer),
+ *   fqs[1] = e1 (qk_matmul's).  g, dS and dS' stay on the chip unless asked for (a caller whose hooks want to see those calls):
+ *   fqs[0].out_dev (nullable) receives g in [batch, positions, heads, 64], grad_scores_dev / fqs[1].out_dev (nullable) dS / dS' in
+ *   [batch, heads, positions, positions]. */
+int qt_attention_train_supported(long batch, int heads, int positions, int head_dim);
+int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, long stride_b, long stride_s, long stride_h,
+                            const uint16_t *mask_dev, long mask_sb, long mask_sh, long mask_sq, const qt_chain_stage *fqs, uint16_t *probs_dev,
+                            uint16_t *out_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
+                            const uint16_t *lut_dev, void *stream);
+int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *qq_dev, const uint16_t *kq_dev, const uint16_t *vq_dev,
+                                     long stride_b, long stride_s, long stride_h, const uint16_t *probs_dev, const uint16_t *pq_dev,
+                                     const qt_chain_stage *fqs, uint16_t *grad_scores_dev, uint16_t *grad_q_dev, uint16_t *grad_k_dev,
+                                     uint16_t *grad_v_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
+                                     const uint16_t *lut_dev, void *stream);
+
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
  *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)

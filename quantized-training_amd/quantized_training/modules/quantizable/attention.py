@@ -103,6 +103,11 @@ def quantizable_attention_forward(module, query, key, value, attention_mask, sca
     from ...fake_quantize import materialize_lazy
     materialize_lazy(query)
     materialize_lazy(key)
+    if torch.is_grad_enabled() and query.is_cuda:
+        from ...train_fusions import attention_or_none
+        out = attention_or_none(module, query, key, value, attention_mask, scaling, dropout)     # a training step: the whole core, one launch
+        if out is not None:
+            return out, None
     key_t = key.transpose(2, 3)
     if getattr(key, "_qt_fq_done_by", None) is not None and getattr(key, "_qt_ver", None) == key._version:
         key_t._qt_ver = key._qt_ver                          # a view shares the version counter

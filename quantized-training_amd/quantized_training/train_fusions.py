@@ -30,11 +30,12 @@ class _Counters:
     members = 0           # fake-quantizer calls served by a chain launch (heads included)
     colsums = 0           # bias gradients handed over
     misses = 0            # members that received another tensor than predicted
+    attention = 0         # attention-core launches (forward or backward), each standing for 4 / 2 fake-quantizer calls
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.misses = 0
+        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = 0
         cls.missed = []
 
 
@@ -189,7 +190,7 @@ def take_member_result(fq, X):
     fq.__dict__["_qt_chain_result"] = None
     ptr, version, shape, out, _keep, connected = pend
     from .fake_quantize import _Stats, _take_preupdate, _PrecomputedFakeQuant
-    if X.data_ptr() == ptr and X._version == version and tuple(X.shape) == shape and X.is_contiguous():
+    if X.data_ptr() == ptr and X._version == version and tuple(X.shape) == shape and (X.is_contiguous() or X.stride() == _keep.stride()):
         STATS.members += 1
         _Stats.add(X.numel())
         if fq._observe:
@@ -591,3 +592,177 @@ def softmax_or_none(attn, scores, attention_mask, scaling, dropout):
         mask = m
     head = _fq(getattr(attn.qk_matmul, "error_pre_process", None), "0")
     return _SoftmaxTrainFn.apply(scores, mask, strides, scaling, fq_p, head)
+
+
+def _hooked(fq):
+    return bool(fq._forward_hooks or fq._forward_pre_hooks)
+
+
+def _served_call(fq, x, y, numel=None):
+    """One hook call that a fused launch has already served (scale update issued, amax accumulated, result `y` written): counted as the
+    hook counts it.  A fake-quantizer somebody hooked is called as the module it is, on the tensor the reference's hook would hand it,
+    and finds `y` (take_member_result) -- its hooks see the call, its input and its result."""
+    from .fake_quantize import _Stats
+    if y is not None and _hooked(fq):
+        fq.__dict__["_qt_chain_result"] = (x.data_ptr(), x._version, tuple(x.shape), y, x, False)
+        with torch.no_grad():
+            got = fq(x)
+        if got.data_ptr() != y.data_ptr():
+            raise RuntimeError("a fake-quantizer call served by the attention launch did not take its result")
+        return
+    STATS.members += 1
+    _Stats.add(x.numel() if numel is None else numel)
+    fq.__dict__["_qt_calls"] = fq.__dict__.get("_qt_calls", 0) + 1      # (harness.GraphedTrainStep batches the scale updates of the quantizers a step calls)
+
+
+class _AttentionTrainFn(torch.autograd.Function):
+    """The attention core between the query / key / value projections and the output projection inside a training step, one launch each
+    way (qt_attention_train_bf16 / qt_attention_train_backward_bf16; modules/quantizable/attention.py, upstream modeling_bert.py:118-158):
+    the four input quantizers of qk_matmul / av_matmul, both products, scaling + mask + softmax and -- when it shares their format -- the
+    output projection's input quantizer forward; the two backward-pre quantizers, the four products and the softmax backward backward.
+    The result and the gradients are laid out [B, S, H, D], so the permute copies of the unfused path do not exist."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, mstrides, scaling, fqs, fq_o, efqs):
+        from .fake_quantize import _stream_ptr, _Stats, launch_scale_update
+        B, H, S, D = q.shape
+        dev = q.device
+        st = _stream_ptr(q)
+        members = [(f, -1) for f in fqs] + ([(fq_o, -1)] if fq_o is not None else [])
+        fmt = _members_format(members, dev)
+        qq, kq, vq = (torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=dev) for _ in range(3))
+        probs = torch.empty((B, H, S, S), dtype=q.dtype, device=dev)
+        pq = torch.empty_like(probs)
+        out = torch.empty((B, S, H * D), dtype=q.dtype, device=dev)
+        oq = torch.empty_like(out) if fq_o is not None else None
+        outs = [qq, kq, vq, pq, oq]
+        stages = (_native.QtChainStage * 5)()
+        for i, (fq, _) in enumerate(members):
+            if fq._observe:
+                launch_scale_update(fq.amax_history, fq.scale, fq.quant_max, fq.force_scale_power_of_two, st)
+            stages[i].scale_f32_dev = fq.scale.data_ptr()
+            stages[i].amax_bits_dev = fq.amax_history.data_ptr() if fq._observe else None
+            stages[i].out_dev = outs[i].data_ptr()
+            stages[i].src = -1
+        msb, msh, msq = mstrides
+        _native.check(_native.lib().qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1),
+                                                            mask.data_ptr() if mask is not None else None, msb, msh, msq, stages, probs.data_ptr(),
+                                                            out.data_ptr(), B, H, S, D, float(scaling), ctypes.byref(fmt), _lut_ptr(fqs[0], fmt), st),
+                      "qt_attention_train_bf16")
+        STATS.attention += 1
+        # the four hook calls this launch stands for, in the hooks' order (qk_matmul: q, k^T; av_matmul: P, v): counted as the hooks count
+        # them -- and a fake-quantizer somebody hooked is CALLED, on the view the reference's hook would hand it, and finds its result
+        for fq, x, y in ((fqs[0], q, qq), (fqs[1], k.transpose(2, 3), kq.transpose(2, 3)), (fqs[3], probs, pq), (fqs[2], v, vq)):
+            _served_call(fq, x, y)
+        if fq_o is not None:
+            _hand_over([(fq_o, -1)], out, [oq])                # (called by the output projection's own hook, on `out` viewed [B, S, H * D])
+        ctx.save_for_backward(qq, kq, vq, probs, pq)
+        ctx.scaling = float(scaling)
+        ctx.efqs = efqs
+        return out.view(B, S, H, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .fake_quantize import _stream_ptr, _Stats, launch_scale_update
+        qq, kq, vq, probs, pq = ctx.saved_tensors
+        B, H, S, D = qq.shape
+        dev = qq.device
+        ev, eq = ctx.efqs
+        members = [(ev, -1), (eq, -1)]
+        fmt = _members_format(members, dev)
+        dout = dout.contiguous()
+        if fmt is None or dout.dtype != torch.bfloat16 or dout.data_ptr() % 16:
+            g = ev(dout.view(B, S, H, D).permute(0, 2, 1, 3))               # the hooks' own calls, torch's kernels
+            dp, dv = g @ vq.transpose(2, 3), pq.transpose(2, 3) @ g
+            ds = eq(torch.ops.aten._softmax_backward_data(dp, probs, -1, probs.dtype) * ctx.scaling)
+            return ds @ kq, ds.transpose(2, 3) @ qq, dv, None, None, None, None, None, None
+        st = _stream_ptr(qq)
+        dq, dk, dv = (torch.empty((B, S, H, D), dtype=qq.dtype, device=dev) for _ in range(3))
+        stages = (_native.QtChainStage * 2)()
+        for i, (fq, _) in enumerate(members):
+            if fq._observe:
+                launch_scale_update(fq.amax_history, fq.scale, fq.quant_max, fq.force_scale_power_of_two, st)
+            stages[i].scale_f32_dev = fq.scale.data_ptr()
+            stages[i].amax_bits_dev = fq.amax_history.data_ptr() if fq._observe else None
+            stages[i].out_dev = None
+            stages[i].src = -1
+        # g = ev(dO), dS and dS' = eq(dS) stay on the chip -- unless somebody hooked those fake-quantizers and wants to see the calls
+        g = torch.empty((B, S, H, D), dtype=qq.dtype, device=dev) if _hooked(ev) else None
+        ds, dsq = (torch.empty_like(probs), torch.empty_like(probs)) if _hooked(eq) else (None, None)
+        if g is not None:
+            stages[0].out_dev = g.data_ptr()
+        if dsq is not None:
+            stages[1].out_dev = dsq.data_ptr()
+        _native.check(_native.lib().qt_attention_train_backward_bf16(dout.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0),
+                                                                     qq.stride(2), qq.stride(1), probs.data_ptr(), pq.data_ptr(), stages,
+                                                                     ds.data_ptr() if ds is not None else None, dq.data_ptr(), dk.data_ptr(),
+                                                                     dv.data_ptr(), B, H, S, D, ctx.scaling, ctypes.byref(fmt), _lut_ptr(ev, fmt), st),
+                      "qt_attention_train_backward_bf16")
+        STATS.attention += 1
+        _served_call(ev, dout.view(B, S, H, D).permute(0, 2, 1, 3), g.permute(0, 2, 1, 3) if g is not None else None, dout.numel())
+        _served_call(eq, ds, dsq, probs.numel())
+        return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None
+
+
+def attention_enabled():
+    return producers_enabled() and os.environ.get("QT_TRAIN_ATTENTION", "1") != "0"
+
+
+def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout):
+    """The attention core of a quantizable attention block inside a training step through _AttentionTrainFn -- the result in
+    [B, S, H, D] -- or None (the caller takes the sub-modules one by one): head_dim 64 and 32..128 positions, q / k / v views of one
+    layout, no active dropout, nothing but the reference's own hooks on qk_matmul / av_matmul (forward-pre on both inputs, backward-pre;
+    quantize.py:143-148) and none on the scaling or the softmax, and every one of those fake-quantizers already created (the first
+    step creates them)."""
+    if not (attention_enabled() and torch.is_grad_enabled() and query.is_cuda and query.dtype == torch.bfloat16 and query.dim() == 4
+            and key.shape == query.shape and value.shape == query.shape and key.dtype == torch.bfloat16 and value.dtype == torch.bfloat16
+            and (query.requires_grad or key.requires_grad or value.requires_grad)):
+        return None
+    B, H, S, D = query.shape
+    if not _native.lib().qt_attention_train_supported(B, H, S, D):
+        return None
+    if (query.stride() != key.stride() or query.stride() != value.stride() or query.stride(3) != 1 or any(s % 8 for s in query.stride()[:3])
+            or any(t.data_ptr() % 16 for t in (query, key, value))):
+        return None
+    if dropout and attn.training:
+        return None
+    for name in ("attn_scaling", "softmax"):
+        mod = getattr(attn, name, None)
+        if mod is None or mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or mod._backward_pre_hooks \
+                or getattr(mod, "activation_pre_process", None) is not None:
+            return None
+    if type(attn.softmax) is not torch.nn.Softmax:
+        return None
+    qk, av = getattr(attn, "qk_matmul", None), getattr(attn, "av_matmul", None)
+    if qk is None or av is None:
+        return None
+    for mod in (qk, av):
+        ha, he = getattr(mod, "activation_pre_process", None), getattr(mod, "error_pre_process", None)
+        if (mod._forward_hooks or mod._backward_hooks or len(mod._forward_pre_hooks) != 1 or len(mod._backward_pre_hooks) != 1
+                or getattr(mod, "error_post_process", None) is not None or ha is None or he is None or len(ha) != 2 or len(he) != 1
+                or "0" not in ha or "1" not in ha or "0" not in he):
+            return None
+    fqs = [qk.activation_pre_process["0"], qk.activation_pre_process["1"], av.activation_pre_process["1"], av.activation_pre_process["0"]]
+    efqs = (av.error_pre_process["0"], qk.error_pre_process["0"])
+    dev = query.device
+    if _members_format([(f, -1) for f in fqs], dev) is None or _members_format([(f, -1) for f in efqs], dev) is None:
+        return None
+    proj = attn.__dict__.get("_qt_out_proj")
+    holder = getattr(proj, "activation_pre_process", None) if proj is not None else None
+    fq_o = _fq(holder, "0") if holder is not None and len(holder) == 1 else None
+    if fq_o is not None and (fq_o.__dict__.get("_qt_chain") is not None or _members_format([(f, -1) for f in fqs + [fq_o]], dev) is None):
+        fq_o = None
+    mask = None
+    strides = (0, 0, 0)
+    if attention_mask is not None:
+        m = attention_mask[..., :S]
+        if m.dtype != torch.bfloat16 or m.dim() != 4 or m.stride(-1) != 1 or m.device != dev or m.requires_grad:
+            return None
+        if m.shape[0] not in (1, B) or m.shape[1] not in (1, H) or m.shape[2] not in (1, S) or m.shape[3] != S:
+            return None
+        strides = (m.stride(0) if m.shape[0] == B and B > 1 else 0, m.stride(1) if m.shape[1] == H and H > 1 else 0,
+                   m.stride(2) if m.shape[2] == S and S > 1 else 0)
+        if (strides[0] | strides[1] | strides[2]) % 8 != 0 or m.data_ptr() % 16 != 0:
+            return None
+        mask = m
+    return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs)

@@ -1106,6 +1106,52 @@ def test_training_chains_change_launches_not_values(monkeypatch):
         assert float(d) <= 3 * 3 * 2e-5 + 2.0 ** -7 * float(plain[2][k].float().abs().max()), k
 
 
+def test_training_attention_core_is_one_launch_each_way(monkeypatch):
+    """train_fusions.attention_or_none: from the second step on (the first creates the fake-quantizers) the attention core of every layer
+    is qt_attention_train_bf16 forward and qt_attention_train_backward_bf16 backward.  Against the same steps with QT_TRAIN_ATTENTION=0
+    (the sub-modules one by one: library GEMMs, qt_softmax_*): the same fake-quantized element and call counts, no chain member missing
+    its tensor, losses / parameters / quantizer scales within the noise of another accumulation order in the four products."""
+    import copy
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    from quantized_training import train_fusions
+    from quantized_training.fake_quantize import STATS, FusedAmaxObsFakeQuantize
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=500,
+                        max_position_embeddings=70, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base = RobertaForSequenceClassification(cfg).bfloat16()
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 500, (8, 64), generator=g), "attention_mask": torch.ones(8, 64, dtype=torch.long),
+                "labels": torch.randint(0, 2, (8,), generator=g)} for _ in range(3)]
+    for b in batches:
+        b["attention_mask"][::3, 50:] = 0                           # padded rows: the additive mask path
+
+    def run(fused):
+        monkeypatch.setenv("QT_TRAIN_ATTENTION", "1" if fused else "0")
+        m = copy.deepcopy(base).cuda().train()
+        qt.quantize(m, _args(*_TRAIN_FLAGS))
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
+        train_fusions.STATS.reset()
+        STATS.reset()
+        losses = harness.train_steps(m, batches, opt)
+        state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
+        params = {n: p.detach().clone() for n, p in m.named_parameters()}
+        return losses, state, params, (train_fusions.STATS.attention, train_fusions.STATS.misses), (STATS.elements, STATS.calls)
+    plain, fused = run(False), run(True)
+    assert plain[3] == (0, 0), plain[3]
+    assert fused[3] == (2 * 2 * 2, 0), (fused[3], train_fusions.STATS.missed)          # layers x steps 2..3 x (forward, backward)
+    assert fused[4] == plain[4]
+    assert fused[0][0] == plain[0][0]                                 # the first step runs the same launches
+    for a, b in zip(plain[0], fused[0]):
+        assert abs(a - b) <= 2e-2 * abs(a) + 1e-3, (plain[0], fused[0])
+    for k in plain[2]:
+        d = (plain[2][k].float() - fused[2][k].float()).abs().max()
+        assert float(d) <= 3 * 3 * 2e-5 + 2.0 ** -7 * float(plain[2][k].float().abs().max()), k
+    assert set(plain[1]) == set(fused[1])
+    for k in plain[1]:
+        sa, sb = float(plain[1][k][0].float().max()), float(fused[1][k][0].float().max())
+        assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
+
+
 def test_graphed_batch_runs_the_weight_passes_of_the_pair_route_as_one_launch():
     """BERT-base-shaped layers at [16, 384] (BASELINE configs[1]): three of the four Linear shapes take the weight pass + library FP8
     GEMM (fused._FQ8_TABLE); harness.GraphedBatch logs those passes during a warm-up forward and captures them as ONE launch

@@ -2129,6 +2129,147 @@ def test_softmax_train_kernels_against_torch_and_the_single_passes(nv, B, H, Q, 
     check(ds)
 
 
+def _products_close(got, ref64, share=1e-2):
+    """A bf16 product tensor against the same product evaluated in fp64: all but `share` of the elements are the fp64 result rounded once,
+    the others within one bf16 step of it (fp32 accumulation order), counted relative to each element with a floor for cancelling sums."""
+    ref = ref64.float().bfloat16()
+    same = float((got.view(torch.int16) == ref.view(torch.int16)).float().mean())
+    err = (got.double() - ref64).abs()
+    bound = 2.0 ** -7 * ref64.abs() + 2.0 ** -16 * float(ref64.abs().max())
+    ok = same >= 1.0 - share and bool((err <= bound).all())
+    if not ok:
+        print(f"[_products_close] bit-equal share {same:.5f}, worst excess {float((err - bound).max()):.3e}")
+    return ok
+
+
+@pytest.mark.parametrize("B,H,S,masked,pow2", [(16, 12, 128, True, True), (2, 3, 64, False, True), (3, 5, 96, True, False), (1, 2, 32, False, False)])
+def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, masked, pow2):
+    """qt_attention_train_bf16 / qt_attention_train_backward_bf16 against the launches of the unfused training step: the fake-quantizers
+    (own launches of qt_fake_quant_bf16, amax included), torch.matmul for the four products, qt_softmax_fq_probs_bf16 and
+    qt_softmax_backward_chain_bf16 for the softmax.  With power-of-two scales every dot of int8 values is exact in fp32 whatever the
+    order of its additions, so the forward has to agree BIT FOR BIT (q', k', v', P, P', the result and its quantized form, every amax),
+    and so do dV and the amax of both gradient quantizers; dQ / dK (E5M2 values of many binades: order-dependent in fp32) and every
+    product under general scales are held to the fp64 product rounded once."""
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    D = 64
+    assert L.qt_attention_train_supported(B, H, S, D) == 1 and L.qt_attention_train_supported(B, H, 384, D) == 0
+    torch.manual_seed(S + B)
+    dev = torch.device("cuda")
+
+    def proj():
+        return torch.randn(B, S, H * D, device=dev).bfloat16().view(B, S, H, D).permute(0, 2, 1, 3)
+    q, k, v = proj(), proj(), proj()
+    mask = None
+    if masked:
+        mask = torch.zeros(B, 1, 1, S, device=dev, dtype=torch.bfloat16)
+        mask[::2, :, :, S - 24:] = torch.finfo(torch.bfloat16).min
+    scaling = 0.125
+    lut = qt_pkg.get_quantization_map("int8", dev)
+    fmt = _launch_format(nv.format_for("int8"), lut)
+    scales = (2.0 ** -5, 2.0 ** -5, 2.0 ** -5, 2.0 ** -7, 2.0 ** -4) if pow2 else (0.0317, 0.0291, 0.0333, 0.00787, 0.0171)
+    sc = [torch.tensor([x], dtype=torch.float32, device=dev) for x in scales]
+    am = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in scales]
+    qq, kq, vq = (torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=dev) for _ in range(3))
+    probs = torch.empty(B, H, S, S, dtype=torch.bfloat16, device=dev)
+    pq = torch.empty_like(probs)
+    out = torch.empty(B, S, H * D, dtype=torch.bfloat16, device=dev)
+    oq = torch.empty_like(out)
+    outs = [qq, kq, vq, pq, oq]
+    stages = (nv.QtChainStage * 5)()
+    for i in range(5):
+        stages[i].scale_f32_dev, stages[i].amax_bits_dev, stages[i].out_dev, stages[i].src = sc[i].data_ptr(), am[i].data_ptr(), outs[i].data_ptr(), -1
+    nv.check(L.qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1), mask.data_ptr() if masked else None,
+                                       mask.stride(0) if masked else 0, 0, 0, stages, probs.data_ptr(), out.data_ptr(), B, H, S, D, scaling,
+                                       ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_attention_train_bf16")
+
+    def fq(x, i, f=fmt, lt=lut, scl=None):
+        x = x.contiguous()
+        want = torch.empty_like(x)
+        a = torch.zeros(1, dtype=torch.float32, device=dev)
+        nv.check(L.qt_fake_quant_bf16(x.data_ptr(), want.data_ptr(), x.numel(), ctypes.byref(f), lt.data_ptr(), (scl if scl is not None else sc[i]).data_ptr(),
+                                      a.data_ptr(), stream()), "qt_fake_quant_bf16")
+        return want, a
+    for i, (x, y) in enumerate(((q, qq), (k, kq), (v, vq))):
+        want, a = fq(x, i)
+        assert torch.equal(y.contiguous().view(torch.int16), want.view(torch.int16)) and torch.equal(am[i].view(torch.int32), a.view(torch.int32)), i
+    # the unfused chain from here on, on the kernel's own q', k', v'
+    s_ref = torch.matmul(qq.contiguous(), kq.contiguous().transpose(2, 3))
+    pq_ref, p_ref = torch.empty_like(probs), torch.empty_like(probs)
+    a3 = torch.zeros(1, dtype=torch.float32, device=dev)
+    nv.check(L.qt_softmax_fq_probs_bf16(s_ref.data_ptr(), mask.data_ptr() if masked else None, pq_ref.data_ptr(), p_ref.data_ptr(), B, H, S, S,
+                                        mask.stride(0) if masked else 0, 0, 0, scaling, ctypes.byref(fmt), lut.data_ptr(), sc[3].data_ptr(), a3.data_ptr(),
+                                        stream()), "qt_softmax_fq_probs_bf16")
+    o_log = out.view(B, S, H, D).permute(0, 2, 1, 3)
+    if pow2:
+        assert torch.equal(probs.view(torch.int16), p_ref.view(torch.int16)) and torch.equal(pq.view(torch.int16), pq_ref.view(torch.int16))
+        assert torch.equal(am[3].view(torch.int32), a3.view(torch.int32))
+        o_ref = torch.matmul(pq, vq.contiguous())
+        assert torch.equal(o_log.contiguous().view(torch.int16), o_ref.view(torch.int16))
+    else:
+        d = (probs.float() - p_ref.float()).abs()
+        assert float((d > 0).float().mean()) <= 2e-2 and float(d.max()) <= 2.0 ** -5, (float((d > 0).float().mean()), float(d.max()))
+    # (whatever the scales) P' is the fake-quantizer of the kernel's own P, the result the product of its own P' and v', fq4 of its own result
+    want, a = fq(probs, 3)
+    assert torch.equal(pq.view(torch.int16), want.view(torch.int16)) and torch.equal(am[3].view(torch.int32), a.view(torch.int32))
+    assert _products_close(o_log, torch.matmul(pq.double(), vq.contiguous().double()))
+    want, a = fq(out, 4)
+    assert torch.equal(oq.view(torch.int16), want.view(torch.int16)) and torch.equal(am[4].view(torch.int32), a.view(torch.int32))
+
+    # ---- backward
+    lut5 = qt_pkg.get_quantization_map("fp8_e5m2", dev)
+    fmt5 = _launch_format(nv.format_for("fp8_e5m2"), lut5)
+    if pow2:      # one binade, eight mantissa bits: E5M2 rounds them, and every sum of the products stays exact
+        gy = (torch.rand(B, S, H, D, device=dev) + 1.0) * 2.0 ** -10 * torch.where(torch.rand(B, S, H, D, device=dev) < 0.5, -1.0, 1.0)
+    else:
+        gy = torch.randn(B, S, H, D, device=dev) * 1e-3
+    gy = gy.bfloat16()
+    esc = [torch.tensor([x], dtype=torch.float32, device=dev) for x in ((2.0 ** -24, 2.0 ** -24) if pow2 else (1.1e-7, 0.9e-7))]
+    eam = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in esc]
+    est = (nv.QtChainStage * 2)()
+    for i in range(2):
+        est[i].scale_f32_dev, est[i].amax_bits_dev, est[i].out_dev, est[i].src = esc[i].data_ptr(), eam[i].data_ptr(), None, -1
+    dq, dk, dv = (torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(3))
+    keep = masked                      # with and without the optional outputs (g, dS, dS')
+    g_out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev) if keep else None
+    ds_out, dsq_out = (torch.empty_like(probs), torch.empty_like(probs)) if keep else (None, None)
+    if keep:
+        est[0].out_dev, est[1].out_dev = g_out.data_ptr(), dsq_out.data_ptr()
+    nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
+                                                probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if keep else None, dq.data_ptr(), dk.data_ptr(),
+                                                dv.data_ptr(), B, H, S, D, scaling, ctypes.byref(fmt5), lut5.data_ptr(), stream()),
+             "qt_attention_train_backward_bf16")
+    g, a0 = fq(gy.permute(0, 2, 1, 3), 0, fmt5, lut5, esc[0])
+    assert torch.equal(eam[0].view(torch.int32), a0.view(torch.int32))
+    if keep:
+        assert torch.equal(g_out.permute(0, 2, 1, 3).contiguous().view(torch.int16), g.view(torch.int16))
+        want, a = fq(ds_out, 1, fmt5, lut5, esc[1])
+        assert torch.equal(dsq_out.view(torch.int16), want.view(torch.int16)) and torch.equal(eam[1].view(torch.int32), a.view(torch.int32))
+    dv_log, dq_log, dk_log = (t.permute(0, 2, 1, 3) for t in (dv, dq, dk))
+    assert _products_close(dv_log, torch.matmul(pq.double().transpose(2, 3), g.double()))
+    dp_ref = torch.matmul(g, vq.contiguous().transpose(2, 3))
+    ds_ref, dsq_ref = torch.empty_like(probs), torch.empty_like(probs)
+    a1 = torch.zeros(1, dtype=torch.float32, device=dev)
+    st1 = (nv.QtChainStage * 1)()
+    st1[0].scale_f32_dev, st1[0].amax_bits_dev, st1[0].out_dev, st1[0].src = esc[1].data_ptr(), a1.data_ptr(), dsq_ref.data_ptr(), -1
+    nv.check(L.qt_softmax_backward_chain_bf16(dp_ref.data_ptr(), probs.data_ptr(), ds_ref.data_ptr(), B * H * S, S, scaling, st1, 1, ctypes.byref(fmt5),
+                                              lut5.data_ptr(), stream()), "qt_softmax_backward_chain_bf16")
+    rq, rk = torch.matmul(dsq_ref.double(), kq.contiguous().double()), torch.matmul(dsq_ref.double().transpose(2, 3), qq.contiguous().double())
+    if pow2:
+        assert torch.equal(dv_log.contiguous().view(torch.int16), torch.matmul(pq.transpose(2, 3), g).view(torch.int16))
+        assert torch.equal(eam[1].view(torch.int32), a1.view(torch.int32))
+        if keep:
+            assert torch.equal(ds_out.view(torch.int16), ds_ref.view(torch.int16)) and torch.equal(dsq_out.view(torch.int16), dsq_ref.view(torch.int16))
+        assert _products_close(dq_log, rq) and _products_close(dk_log, rk)
+    else:
+        # a score gradient that rounds the other way moves E5M2 codes of dS': compare in the large
+        for got, ref in ((dq_log, rq), (dk_log, rk)):
+            e = (got.double() - ref).abs()
+            assert float(e.max()) <= 0.05 * float(ref.abs().max()) and float(e.mean()) <= 2e-3 * float(ref.abs().mean()) + 1e-12, (float(e.max()), float(e.mean()))
+    assert not any(bool(torch.isnan(t.float()).any()) for t in (dq, dk, dv))
+
+
 def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
     """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
     the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,
