@@ -21,6 +21,7 @@
 // the products of a dot (the library GEMM's is not defined either) -- tests/test_gpu_parity.py states the tolerance.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qt_device.h"
 #include "qt_chain.h"
@@ -64,6 +65,11 @@ __device__ __forceinline__ void store_tile(unsigned char *tile, int row_bytes, i
         *(uint16_t *)(tile + (r0 + 4 * (lane >> 4) + i) * row_bytes + (c0 + (lane & 15)) * 2) = bf16_bits(acc[i]);
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over ALL address spaces: on this target it waits
+// for every outstanding global store and load of the wave (s_waitcnt vmcnt(0)) -- here that would put the round trip of the q' / k' / v' /
+// P / P' stores in front of every phase.  Nothing in these kernels reads global memory another wave of the launch has written.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N, int WAVES>
 __device__ __forceinline__ void amax_commit_w(const FqDev (&fq)[N], const uint32_t (&amax)[N], uint32_t (*s_amax)[WAVES]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -72,7 +78,7 @@ __device__ __forceinline__ void amax_commit_w(const FqDev (&fq)[N], const uint32
         const uint32_t m = wave_max_u32(amax[i]);
         if (lane == 0) s_amax[i][wave] = m;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (t == i * 32 && fq[i].amax) {
@@ -95,6 +101,7 @@ struct AttnTrainFwdArgs {
     int H, S;
     float scaling;
     FqDev fq[5];                       // q, k, v, probabilities, result
+    unsigned long long *dbg;           // tuning build, QT_AT_STAMPS = device address: s_memtime stamps of workgroup 0, waves 0 and 7 (16 slots each)
 };
 
 constexpr int kThreads = 512;                       // 8 waves: wave w owns the 16 query (or key) rows of tile w
@@ -103,12 +110,22 @@ constexpr int kRowIters = kSMax / (kThreads / 16);  // rows of the softmax per 1
 
 template <int KIND>
 __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kTileD + kTileS];
+    // q', k', v', the scores (then P'), P and the result each keep a tile of their own until the end: every global store of the launch is
+    // issued in the last phase, where nothing waits behind it (a store in flight stalls the next write to its data registers)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileD + 2 * kTileS];
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
     __shared__ uint32_t s_amax[5][kThreads / 64];
-    unsigned char *Qs = lds, *Ks = lds + kTileD, *Vs = lds + 2 * kTileD, *Ss = lds + 3 * kTileD;
+    unsigned char *Qs = lds, *Ks = lds + kTileD, *Vs = lds + 2 * kTileD, *Os = lds + 3 * kTileD, *Ss = lds + 4 * kTileD, *Pr = Ss + kTileS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, S = a.S, mt = S / 16;
+#ifdef QT_TUNING_BUILD
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) a.dbg[0 + (wave ? 16 : 0) + slot] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [](int) __attribute__((always_inline)) {};
+#endif
+    stamp(0);
     // every global read of the launch is issued before anything waits (one round trip, not one per loop iteration)
     const long base = (long)b * a.sb + (long)h * a.sh;
     uint4 xq[kVecIters], xk[kVecIters], xv[kVecIters];
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
         sc[i] = a.fq[i].scale ? qt_bf2f(qt_f2bf(*a.fq[i].scale)) : 1.0f;
         amax[i] = 0u;
     }
-    // ---- q' = fq(q), k' = fq(k), v' = fq(v): kept for the backward, and into LDS
+    // ---- q' = fq(q), k' = fq(k), v' = fq(v) into LDS
     {
         const UniformDiv dq(sc[0]), dk(sc[1]), dv(sc[2]);
 #pragma unroll
@@ -142,20 +159,15 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
             const int id = tid + i * kThreads;
             if (id < S * 8) {
                 const int r = id >> 3, c = id & 7;
-                const long off = base + (long)r * a.ss + c * 8;
-                const uint4 yq = chain_apply<KIND>(xq[i], sc[0], dq, rnd, amax[0]);
-                const uint4 yk = chain_apply<KIND>(xk[i], sc[1], dk, rnd, amax[1]);
-                const uint4 yv = chain_apply<KIND>(xv[i], sc[2], dv, rnd, amax[2]);
-                *(uint4 *)(a.qq + off) = yq;
-                *(uint4 *)(a.kq + off) = yk;
-                *(uint4 *)(a.vq + off) = yv;
-                *(uint4 *)(Qs + r * kRowD + c * 16) = yq;
-                *(uint4 *)(Ks + r * kRowD + c * 16) = yk;
-                *(uint4 *)(Vs + r * kRowD + c * 16) = yv;
+                *(uint4 *)(Qs + r * kRowD + c * 16) = chain_apply<KIND>(xq[i], sc[0], dq, rnd, amax[0]);
+                *(uint4 *)(Ks + r * kRowD + c * 16) = chain_apply<KIND>(xk[i], sc[1], dk, rnd, amax[1]);
+                *(uint4 *)(Vs + r * kRowD + c * 16) = chain_apply<KIND>(xv[i], sc[2], dv, rnd, amax[2]);
             }
         }
     }
-    __syncthreads();
+    stamp(1);
+    lds_barrier();
+    stamp(2);
     // ---- S = bf16(q' k'^T)
     if (wave < mt) {
         f32x4_t acc[8];
@@ -172,16 +184,18 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
         for (int n = 0; n < 8; ++n)
             if (n < mt) store_tile(Ss, kRowS, wave * 16, n * 16, acc[n], lane);
     }
-    __syncthreads();
+    stamp(3);
+    lds_barrier();
+    stamp(4);
     // ---- P = softmax(bf16(bf16(S * scaling) + mask)), P' = fq(P): 16 lanes per row, eight columns per lane -- the row code of
     //      softmax_fq_kernel<KIND, 1, 16> (qt_softmax.hip) on the scores in LDS
     {
         const float s = sc[3];
         const UniformDiv dv(s);
-#pragma unroll
-        for (int it = 0; it < kRowIters; ++it) {
-            const int row = gi + it * (kThreads / 16);
-            if (row >= S) break;                               // (uniform per wave: a wave holds four whole rows)
+        // (loops of these kernels are NOT unrolled: a launch runs once through its code with a cold instruction cache, and the code of
+        // an unrolled fake-quantizer -- three division variants per call site -- was most of the 66 KiB the first version fetched)
+#pragma unroll 1
+        for (int row = gi; row < S; row += kThreads / 16) {
             const bool act = li < nvec_row;
             float t[8];
             float mx = -INFINITY;
@@ -225,20 +239,20 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
             for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
             const float inv = 1.0f / sum;
             if (act) {
-                const long o = ((long)bh * S + row) * S + li * 8;
                 uint4 pv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
                 if (!dead) {
                     pv = uint4{pack_bf16x2(t[0] * inv, t[1] * inv), pack_bf16x2(t[2] * inv, t[3] * inv), pack_bf16x2(t[4] * inv, t[5] * inv),
                                pack_bf16x2(t[6] * inv, t[7] * inv)};
                     qv = chain_apply<KIND>(pv, s, dv, rnd, amax[3]);
                 }
-                *(uint4 *)(a.probs + o) = pv;
-                *(uint4 *)(a.pq + o) = qv;
+                *(uint4 *)(Pr + row * kRowS + li * 16) = pv;
                 *(uint4 *)(Ss + row * kRowS + li * 16) = qv;
             }
         }
     }
-    __syncthreads();
+    stamp(5);
+    lds_barrier();
+    stamp(6);
     // ---- O = bf16(P' v'): four column tiles, k over the positions
     if (wave < mt) {
         f32x4_t o[4];
@@ -250,24 +264,39 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
             for (int n = 0; n < 4; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_cols(Vs, kRowD, n * 16, ks * 32, lane), o[n], 0, 0, 0);
         }
 #pragma unroll
-        for (int n = 0; n < 4; ++n) store_tile(Qs, kRowD, wave * 16, n * 16, o[n], lane);      // (q' is no longer needed)
+        for (int n = 0; n < 4; ++n) store_tile(Os, kRowD, wave * 16, n * 16, o[n], lane);
     }
-    __syncthreads();
+    stamp(7);
+    lds_barrier();
+    stamp(8);
+    // ---- everything leaves: q', k', v' (what the backward reads), P, P', the result in [B, S, H, 64] and its quantized form
     {
         const UniformDiv dv(sc[4]);
-#pragma unroll
-        for (int i = 0; i < kVecIters; ++i) {
-            const int id = tid + i * kThreads;
-            if (id < S * 8) {
+#pragma unroll 1
+        for (int id = tid; id < S * 8; id += kThreads) {
+            {
                 const int r = id >> 3, c = id & 7;
-                const uint4 y = *(const uint4 *)(Qs + r * kRowD + c * 16);
-                const long off = (((long)b * S + r) * a.H + h) * kD + c * 8;
-                *(uint4 *)(a.out + off) = y;
-                if (a.oq) *(uint4 *)(a.oq + off) = chain_apply<KIND>(y, sc[4], dv, rnd, amax[4]);
+                const long off = base + (long)r * a.ss + c * 8, ooff = (((long)b * S + r) * a.H + h) * kD + c * 8;
+                *(uint4 *)(a.qq + off) = *(const uint4 *)(Qs + r * kRowD + c * 16);
+                *(uint4 *)(a.kq + off) = *(const uint4 *)(Ks + r * kRowD + c * 16);
+                *(uint4 *)(a.vq + off) = *(const uint4 *)(Vs + r * kRowD + c * 16);
+                const uint4 y = *(const uint4 *)(Os + r * kRowD + c * 16);
+                *(uint4 *)(a.out + ooff) = y;
+                if (a.oq) *(uint4 *)(a.oq + ooff) = chain_apply<KIND>(y, sc[4], dv, rnd, amax[4]);
+            }
+        }
+#pragma unroll 1
+        for (int row = gi; row < S; row += kThreads / 16) {
+            if (li < nvec_row) {
+                const long o = ((long)bh * S + row) * S + li * 8;
+                *(uint4 *)(a.probs + o) = *(const uint4 *)(Pr + row * kRowS + li * 16);
+                *(uint4 *)(a.pq + o) = *(const uint4 *)(Ss + row * kRowS + li * 16);
             }
         }
     }
+    stamp(9);
     amax_commit_w<5, kThreads / 64>(a.fq, amax, s_amax);
+    stamp(10);
 }
 
 struct AttnTrainBwdArgs {
@@ -281,6 +310,7 @@ struct AttnTrainBwdArgs {
     int H, S;
     float scaling;
     FqDev fq[2];                       // grad of the result (av_matmul's backward-pre quantizer), grad of the scores (qk_matmul's)
+    unsigned long long *dbg;           // as in the forward, slots 32..
 };
 
 template <int KIND>
@@ -292,6 +322,14 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, S = a.S, mt = S / 16, nvec_row = S / 8;
     const int gi = tid >> 4, li = tid & 15;
+#ifdef QT_TUNING_BUILD
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) a.dbg[32 + (wave ? 16 : 0) + slot] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [](int) __attribute__((always_inline)) {};
+#endif
+    stamp(0);
     // every global read of the launch is issued before anything waits
     const long base = (long)b * a.sb + (long)h * a.sh;
     // (named registers, not arrays: arrays of loaded vectors went through scratch memory or serialised the loads with copies)
@@ -358,7 +396,9 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
         row_stage(2, xp2);
         row_stage(3, xp3);
     }
-    __syncthreads();
+    stamp(1);
+    lds_barrier();
+    stamp(2);
     // ---- dV = bf16(P'^T g) (rows: key positions), dP = bf16(g v'^T) (rows: query positions); wave w owns tile w of either
     const int m0 = (wave < mt ? wave : 0) * 16;
     f32x4_t accv[4], accp[8];
@@ -380,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
                 if (n < mt) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, frag_rows(Vs, kRowD, n * 16, ks * 32, lane), accp[n], 0, 0, 0);
         }
     }
-    __syncthreads();                   // every wave has read P', g and v': their tiles take dP and dV
+    lds_barrier();                   // every wave has read P', g and v': their tiles take dP and dV
     if (wave < mt) {
 #pragma unroll
         for (int n = 0; n < 8; ++n)
@@ -388,7 +428,9 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
 #pragma unroll
         for (int n = 0; n < 4; ++n) store_tile(Vs, kRowD, m0, n * 16, accv[n], lane);
     }
-    __syncthreads();
+    stamp(3);
+    lds_barrier();
+    stamp(4);
     // ---- dS = bf16(bf16((dP - sum dP P) P) * scaling), dS' = fq_e(dS): the row code of softmax_bwd_kernel<KIND, 1, 1, 16>; dV leaves
     {
         const UniformDiv dv(sc[1]);
@@ -438,7 +480,9 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             }
         }
     }
-    __syncthreads();
+    stamp(5);
+    lds_barrier();
+    stamp(6);
     // ---- dQ = bf16(dS' k') (rows: query positions), dK = bf16(dS'^T q') (rows: key positions)
     if (wave < mt) {
         f32x4_t accq[4], acck[4];
@@ -458,7 +502,9 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             store_tile(Vs, kRowD, m0, n * 16, acck[n], lane);
         }
     }
-    __syncthreads();
+    stamp(7);
+    lds_barrier();
+    stamp(8);
 #pragma unroll
     for (int i = 0; i < kVecIters; ++i) {
         const int id = tid + i * kThreads;
@@ -469,7 +515,9 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             *(uint4 *)(a.dk + off) = *(const uint4 *)(Vs + r * kRowD + c * 16);
         }
     }
+    stamp(9);
     amax_commit_w<2, kThreads / 64>(a.fq, amax, s_amax);
+    stamp(10);
 }
 
 inline int launch_rc() {
@@ -520,6 +568,9 @@ int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const 
     a.out = out_dev; a.oq = fqs[4].out_dev;
     a.H = heads; a.S = positions; a.scaling = scaling;
     for (int i = 0; i < 5; ++i) a.fq[i] = FqDev{fqs[i].scale_f32_dev, fqs[i].amax_bits_dev};
+#ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_AT_STAMPS")) a.dbg = (unsigned long long *)strtoull(e, nullptr, 16);
+#endif
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(batch * heads);
     return dispatch<AttnTrainFwdArgs>(
@@ -548,6 +599,9 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     a.g_out = fqs[0].out_dev; a.ds_out = grad_scores_dev; a.dsq_out = fqs[1].out_dev;
     a.H = heads; a.S = positions; a.scaling = scaling;
     for (int i = 0; i < 2; ++i) a.fq[i] = FqDev{fqs[i].scale_f32_dev, fqs[i].amax_bits_dev};
+#ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_AT_STAMPS")) a.dbg = (unsigned long long *)strtoull(e, nullptr, 16);
+#endif
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(batch * heads);
     return dispatch<AttnTrainBwdArgs>(
