@@ -347,7 +347,13 @@ int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_
  * backward: grad_out_dev and grad_q/k/v_dev in [batch, positions, heads, 64]; fqs[0] = e0 (av_matmul's backward-pre quantizer),
  *   fqs[1] = e1 (qk_matmul's).  g, dS and dS' stay on the chip unless asked for (a caller whose hooks want to see those calls):
  *   fqs[0].out_dev (nullable) receives g in [batch, positions, heads, 64], grad_scores_dev / fqs[1].out_dev (nullable) dS / dS' in
- *   [batch, heads, positions, positions]. */
+ *   [batch, heads, positions, positions].
+ *   grad_fqs (nullable, 3 entries: dQ, dK, dV): the projections' own backward-pre quantizers (quantize.py:145-146 on the query / key /
+ *   value Linears) applied to the gradients on their way out -- entry i with out_dev != NULL writes fq(gradient i) there
+ *   ([batch, positions, heads, 64]) next to the unquantized gradient; colsum_out_devs (nullable HOST array of 3 nullable device
+ *   pointers): [heads * 64] bf16 sums of that result over batch and position = the projection's bias gradient (fixed order inside a
+ *   workgroup, 64-bit fixed-point atomics across the batch: deterministic; colsum_max as in qt_fake_quant_chain_bf16).  ws_dev:
+ *   qt_attention_train_backward_ws_bytes(heads) bytes of scratch, zero before the first launch (every launch leaves it zero). */
 int qt_attention_train_supported(long batch, int heads, int positions, int head_dim);
 int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, long stride_b, long stride_s, long stride_h,
                             const uint16_t *mask_dev, long mask_sb, long mask_sh, long mask_sq, const qt_chain_stage *fqs, uint16_t *probs_dev,
@@ -356,8 +362,10 @@ int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const 
 int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *qq_dev, const uint16_t *kq_dev, const uint16_t *vq_dev,
                                      long stride_b, long stride_s, long stride_h, const uint16_t *probs_dev, const uint16_t *pq_dev,
                                      const qt_chain_stage *fqs, uint16_t *grad_scores_dev, uint16_t *grad_q_dev, uint16_t *grad_k_dev,
-                                     uint16_t *grad_v_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
-                                     const uint16_t *lut_dev, void *stream);
+                                     uint16_t *grad_v_dev, const qt_chain_stage *grad_fqs, uint16_t *const *colsum_out_devs, float colsum_max,
+                                     void *ws_dev, size_t ws_bytes, long batch, int heads, int positions, int head_dim, float scaling,
+                                     const qt_format *fmt, const uint16_t *lut_dev, void *stream);
+size_t qt_attention_train_backward_ws_bytes(int heads);
 
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.

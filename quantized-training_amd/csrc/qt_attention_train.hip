@@ -299,6 +299,13 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
     stamp(10);
 }
 
+struct GradStage {
+    const float *scale;
+    uint32_t *amax;
+    uint16_t *out;                     // fq(gradient), [B, S, H, 64]; NULL: this gradient is not quantized here
+    uint16_t *colsum;                  // [H * 64] bf16 column sums of `out` over batch and position; NULL: not wanted
+};
+
 struct AttnTrainBwdArgs {
     const uint16_t *gy;                // [B, S, H, 64]
     const uint16_t *qq, *kq, *vq;
@@ -310,15 +317,23 @@ struct AttnTrainBwdArgs {
     int H, S;
     float scaling;
     FqDev fq[2];                       // grad of the result (av_matmul's backward-pre quantizer), grad of the scores (qk_matmul's)
+    // the projections' own backward-pre quantizers on dQ / dK / dV (each optional), and the column sums of their results = the bias
+    // gradients: 64-bit fixed-point accumulators per (tensor, column) and a ticket per (tensor, head), zero between launches
+    GradStage gs[3];
+    float colsum_max;
+    long long *acc;                    // [3][H * 64]
+    unsigned int *ticket;              // [3][H]
+    int B;
     unsigned long long *dbg;           // as in the forward, slots 32..
 };
 
 template <int KIND>
 __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileD + kTileS];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[5 * kTileD + kTileS];
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
-    __shared__ uint32_t s_amax[2][kThreads / 64];
-    unsigned char *Gs = lds, *Vs = lds + kTileD, *Ks = lds + 2 * kTileD, *Qs = lds + 3 * kTileD, *Ps = lds + 4 * kTileD;
+    __shared__ uint32_t s_amax[5][kThreads / 64];
+    __shared__ unsigned int s_old[3];
+    unsigned char *Gs = lds, *Vs = lds + kTileD, *Ks = lds + 2 * kTileD, *Qs = lds + 3 * kTileD, *Ps = lds + 4 * kTileD, *Ds = Ps + kTileS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, S = a.S, mt = S / 16, nvec_row = S / 8;
     const int gi = tid >> 4, li = tid & 15;
@@ -426,12 +441,12 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
         for (int n = 0; n < 8; ++n)
             if (n < mt) store_tile(Ps, kRowS, m0, n * 16, accp[n], lane);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) store_tile(Vs, kRowD, m0, n * 16, accv[n], lane);
+        for (int n = 0; n < 4; ++n) store_tile(Ds, kRowD, m0, n * 16, accv[n], lane);
     }
     stamp(3);
     lds_barrier();
     stamp(4);
-    // ---- dS = bf16(bf16((dP - sum dP P) P) * scaling), dS' = fq_e(dS): the row code of softmax_bwd_kernel<KIND, 1, 1, 16>; dV leaves
+    // ---- dS = bf16(bf16((dP - sum dP P) P) * scaling), dS' = fq_e(dS): the row code of softmax_bwd_kernel<KIND, 1, 1, 16>
     {
         const UniformDiv dv(sc[1]);
         auto row_body = [&](int it, const uint4 &pv) __attribute__((always_inline)) {
@@ -471,14 +486,6 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
         row_body(1, pr1);
         row_body(2, pr2);
         row_body(3, pr3);
-#pragma unroll
-        for (int i = 0; i < kVecIters; ++i) {
-            const int id = tid + i * kThreads;
-            if (id < S * 8) {
-                const int r = id >> 3, c = id & 7;
-                *(uint4 *)(a.dv + (((long)b * S + r) * a.H + h) * kD + c * 8) = *(const uint4 *)(Vs + r * kRowD + c * 16);
-            }
-        }
     }
     stamp(5);
     lds_barrier();
@@ -498,25 +505,93 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            store_tile(Gs, kRowD, m0, n * 16, accq[n], lane);      // (g and dV have left these tiles)
+            store_tile(Gs, kRowD, m0, n * 16, accq[n], lane);      // (g and v' have left these tiles)
             store_tile(Vs, kRowD, m0, n * 16, acck[n], lane);
         }
     }
     stamp(7);
     lds_barrier();
     stamp(8);
+    // ---- dQ, dK, dV leave, each through its projection's backward-pre quantizer where one rides along; per-thread column partials
+    float gsc[3];
+    uint32_t gamax[3] = {0u, 0u, 0u};
+    float col[3][8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        gsc[t] = a.gs[t].scale ? qt_bf2f(qt_f2bf(*a.gs[t].scale)) : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) col[t][e] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < kVecIters; ++i) {
         const int id = tid + i * kThreads;
         if (id < S * 8) {
             const int r = id >> 3, c = id & 7;
             const long off = (((long)b * S + r) * a.H + h) * kD + c * 8;
-            *(uint4 *)(a.dq + off) = *(const uint4 *)(Gs + r * kRowD + c * 16);
-            *(uint4 *)(a.dk + off) = *(const uint4 *)(Vs + r * kRowD + c * 16);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const unsigned char *tile = t == 0 ? Gs : (t == 1 ? Vs : Ds);
+                uint16_t *dst = t == 0 ? a.dq : (t == 1 ? a.dk : a.dv);
+                const uint4 y = *(const uint4 *)(tile + r * kRowD + c * 16);
+                *(uint4 *)(dst + off) = y;
+                if (a.gs[t].out) {
+                    const UniformDiv dv(gsc[t]);
+                    const uint4 z = chain_apply<KIND>(y, gsc[t], dv, rnd, gamax[t]);
+                    *(uint4 *)(a.gs[t].out + off) = z;
+                    const uint32_t zw[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        col[t][2 * j] += bf_lo(zw[j]);
+                        col[t][2 * j + 1] += bf_hi(zw[j]);
+                    }
+                }
+            }
         }
     }
     stamp(9);
-    amax_commit_w<2, kThreads / 64>(a.fq, amax, s_amax);
+    {
+        uint32_t am5[5] = {amax[0], amax[1], gamax[0], gamax[1], gamax[2]};
+        const FqDev f5[5] = {a.fq[0], a.fq[1], FqDev{a.gs[0].scale, a.gs[0].amax}, FqDev{a.gs[1].scale, a.gs[1].amax}, FqDev{a.gs[2].scale, a.gs[2].amax}};
+        amax_commit_w<5, kThreads / 64>(f5, am5, s_amax);
+    }
+    // ---- bias gradients: column sums of the quantized gradients.  Inside the workgroup: the 64 row lanes of a column in row order
+    // (fp32); across the batch: 64-bit fixed-point atomic adds and a ticket, as qt_fake_quant_chain_bf16 does (integer addition is
+    // associative: the result does not depend on the arrival order, and no cross-XCD fence is needed)
+    if (a.acc && (a.gs[0].colsum || a.gs[1].colsum || a.gs[2].colsum)) {
+        float *s_col = (float *)Ks;                            // [3][64 row lanes][65]: k', q' and the scores' tile are free now
+        const int rl = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_col[(t * 64 + rl) * 65 + c8 + e] = col[t][e];
+        lds_barrier();
+        const int t = tid >> 6, cc = tid & 63;                 // one thread per (tensor, column)
+        uint16_t *cs = t == 0 ? a.gs[0].colsum : (t == 1 ? a.gs[1].colsum : (t == 2 ? a.gs[2].colsum : nullptr));
+        const float tsc = t == 0 ? gsc[0] : (t == 1 ? gsc[1] : gsc[2]);
+        int E = 0;
+        (void)frexpf(a.colsum_max * tsc, &E);
+        if (t < 3 && cs) {
+            float part = 0.0f;
+            for (int r = 0; r < 64; ++r) part += s_col[(t * 64 + r) * 65 + cc];
+            const bool finite = part == part && fabsf(part) < 3.0e38f;
+            const long long fx = finite ? (long long)rintf(ldexpf(part, 42 - E)) : (1ll << 62);
+            (void)__hip_atomic_fetch_add(a.acc + ((long)t * a.H + h) * 64 + cc, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics are performed before its ticket is drawn
+        lds_barrier();
+        if (tid < 3) {
+            const bool want = tid == 0 ? a.gs[0].colsum != nullptr : (tid == 1 ? a.gs[1].colsum != nullptr : a.gs[2].colsum != nullptr);
+            s_old[tid] = want ? __hip_atomic_fetch_add(a.ticket + tid * a.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        }
+        lds_barrier();
+        if (t < 3 && cs && s_old[t] == (unsigned)a.B - 1u) {   // the batch's last arrival for this (tensor, head): read, re-zero, round
+            if (cc == 0) __hip_atomic_store(a.ticket + t * a.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long fx = __hip_atomic_exchange(a.acc + ((long)t * a.H + h) * 64 + cc, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float sum = ldexpf((float)fx, E - 42);
+            if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
+            cs[h * 64 + cc] = bf16_bits(sum);
+        }
+    }
     stamp(10);
 }
 
@@ -579,11 +654,16 @@ int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const 
         [&] { attn_train_fwd_kernel<QT_FMT_INT><<<grid, kThreads, 0, st>>>(a, *fmt, lut_dev); });
 }
 
+size_t qt_attention_train_backward_ws_bytes(int heads) {
+    return heads > 0 ? (size_t)3 * heads * kD * sizeof(long long) + (size_t)3 * heads * sizeof(unsigned int) : 0;
+}
+
 int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *qq_dev, const uint16_t *kq_dev, const uint16_t *vq_dev,
                                      long stride_b, long stride_s, long stride_h, const uint16_t *probs_dev, const uint16_t *pq_dev,
                                      const qt_chain_stage *fqs, uint16_t *grad_scores_dev, uint16_t *grad_q_dev, uint16_t *grad_k_dev,
-                                     uint16_t *grad_v_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
-                                     const uint16_t *lut_dev, void *stream) {
+                                     uint16_t *grad_v_dev, const qt_chain_stage *grad_fqs, uint16_t *const *colsum_out_devs, float colsum_max,
+                                     void *ws_dev, size_t ws_bytes, long batch, int heads, int positions, int head_dim, float scaling,
+                                     const qt_format *fmt, const uint16_t *lut_dev, void *stream) {
     if (!grad_out_dev || !qq_dev || !kq_dev || !vq_dev || !probs_dev || !pq_dev || !fqs || !grad_q_dev || !grad_k_dev || !grad_v_dev || !fmt ||
         !shape_ok(batch, heads, positions, head_dim))
         return QT_ERR_BAD_ARG;
@@ -599,6 +679,21 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     a.g_out = fqs[0].out_dev; a.ds_out = grad_scores_dev; a.dsq_out = fqs[1].out_dev;
     a.H = heads; a.S = positions; a.scaling = scaling;
     for (int i = 0; i < 2; ++i) a.fq[i] = FqDev{fqs[i].scale_f32_dev, fqs[i].amax_bits_dev};
+    a.B = (int)batch;
+    bool sums = false;
+    for (int i = 0; i < 3; ++i) {
+        if (!grad_fqs || !grad_fqs[i].out_dev) continue;
+        if ((uintptr_t)grad_fqs[i].out_dev & 15u) return QT_ERR_UNALIGNED;
+        a.gs[i] = GradStage{grad_fqs[i].scale_f32_dev, grad_fqs[i].amax_bits_dev, grad_fqs[i].out_dev, colsum_out_devs ? colsum_out_devs[i] : nullptr};
+        sums = sums || a.gs[i].colsum;
+    }
+    if (sums) {
+        if (!ws_dev || ws_bytes < qt_attention_train_backward_ws_bytes(heads) || !(colsum_max > 0.0f) || !(colsum_max < 3.0e38f)) return QT_ERR_BAD_ARG;
+        if ((uintptr_t)ws_dev & 15u) return QT_ERR_UNALIGNED;
+        a.colsum_max = colsum_max;
+        a.acc = (long long *)ws_dev;
+        a.ticket = (unsigned int *)((char *)ws_dev + (size_t)3 * heads * kD * sizeof(long long));
+    }
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_AT_STAMPS")) a.dbg = (unsigned long long *)strtoull(e, nullptr, 16);
 #endif

@@ -623,7 +623,7 @@ class _AttentionTrainFn(torch.autograd.Function):
     The result and the gradients are laid out [B, S, H, D], so the permute copies of the unfused path do not exist."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, mstrides, scaling, fqs, fq_o, efqs):
+    def forward(ctx, q, k, v, mask, mstrides, scaling, fqs, fq_o, efqs, lins):
         from .fake_quantize import _stream_ptr, _Stats, launch_scale_update
         B, H, S, D = q.shape
         dev = q.device
@@ -659,6 +659,7 @@ class _AttentionTrainFn(torch.autograd.Function):
         ctx.save_for_backward(qq, kq, vq, probs, pq)
         ctx.scaling = float(scaling)
         ctx.efqs = efqs
+        ctx.lins = lins
         return out.view(B, S, H, D)
 
     @staticmethod
@@ -675,7 +676,7 @@ class _AttentionTrainFn(torch.autograd.Function):
             g = ev(dout.view(B, S, H, D).permute(0, 2, 1, 3))               # the hooks' own calls, torch's kernels
             dp, dv = g @ vq.transpose(2, 3), pq.transpose(2, 3) @ g
             ds = eq(torch.ops.aten._softmax_backward_data(dp, probs, -1, probs.dtype) * ctx.scaling)
-            return ds @ kq, ds.transpose(2, 3) @ qq, dv, None, None, None, None, None, None
+            return ds @ kq, ds.transpose(2, 3) @ qq, dv, None, None, None, None, None, None, None
         st = _stream_ptr(qq)
         dq, dk, dv = (torch.empty((B, S, H, D), dtype=qq.dtype, device=dev) for _ in range(3))
         stages = (_native.QtChainStage * 2)()
@@ -693,15 +694,48 @@ class _AttentionTrainFn(torch.autograd.Function):
             stages[0].out_dev = g.data_ptr()
         if dsq is not None:
             stages[1].out_dev = dsq.data_ptr()
-        _native.check(_native.lib().qt_attention_train_backward_bf16(dout.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0),
-                                                                     qq.stride(2), qq.stride(1), probs.data_ptr(), pq.data_ptr(), stages,
-                                                                     ds.data_ptr() if ds is not None else None, dq.data_ptr(), dk.data_ptr(),
-                                                                     dv.data_ptr(), B, H, S, D, ctx.scaling, ctypes.byref(fmt), _lut_ptr(ev, fmt), st),
+        # the query / key / value projections' own backward-pre quantizers (single-member chains with the bias gradient, `plan`) ride on
+        # the gradients' way out: each finds its result when its hook is called on dQ / dK / dV viewed [B, S, H * D]
+        L = _native.lib()
+        gst = (_native.QtChainStage * 3)()
+        couts = (ctypes.c_void_p * 3)()
+        riders = []
+        for i, lin in enumerate(ctx.lins or ()):
+            head = _fq(getattr(lin, "error_pre_process", None), "0") if lin is not None else None
+            mem, colsum = _grad_chain(head)
+            if mem is None or len(mem) != 1 or _members_format(members + mem, dev) is None:
+                continue
+            fqg = mem[0][0]
+            if fqg._observe:
+                launch_scale_update(fqg.amax_history, fqg.scale, fqg.quant_max, fqg.force_scale_power_of_two, st)
+            o = torch.empty((B, S, H * D), dtype=qq.dtype, device=dev)
+            gst[i].scale_f32_dev = fqg.scale.data_ptr()
+            gst[i].amax_bits_dev = fqg.amax_history.data_ptr() if fqg._observe else None
+            gst[i].out_dev = o.data_ptr()
+            gst[i].src = -1
+            gb = None
+            if colsum is not None and colsum[1].out_features == H * D:
+                gb = torch.empty(H * D, dtype=torch.bfloat16, device=dev)
+                couts[i] = gb.data_ptr()
+            riders.append((mem, i, o, gb))
+        ws = _chain_scratch(L.qt_attention_train_backward_ws_bytes(H), dev) if any(r[3] is not None for r in riders) else None
+        _native.check(L.qt_attention_train_backward_bf16(dout.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2),
+                                                         qq.stride(1), probs.data_ptr(), pq.data_ptr(), stages, ds.data_ptr() if ds is not None else None,
+                                                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), gst if riders else None, couts if riders else None,
+                                                         _format_max(ev), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                                         B, H, S, D, ctx.scaling, ctypes.byref(fmt), _lut_ptr(ev, fmt), st),
                       "qt_attention_train_backward_bf16")
         STATS.attention += 1
         _served_call(ev, dout.view(B, S, H, D).permute(0, 2, 1, 3), g.permute(0, 2, 1, 3) if g is not None else None, dout.numel())
         _served_call(eq, ds, dsq, probs.numel())
-        return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None
+        grads = (dq, dk, dv)
+        for mem, i, o, gb in riders:
+            _hand_over(mem, grads[i].view(B, S, H * D), [o])
+            if gb is not None:
+                if len(_COLSUM) > 64:
+                    _COLSUM.clear()
+                _COLSUM[(o.data_ptr(), o._version, tuple(o.shape))] = gb
+        return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None, None
 
 
 def attention_enabled():
@@ -765,4 +799,5 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
         if (strides[0] | strides[1] | strides[2]) % 8 != 0 or m.data_ptr() % 16 != 0:
             return None
         mask = m
-    return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs)
+    lins = tuple(getattr(attn, n, None) for n in ("query", "key", "value"))
+    return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins)

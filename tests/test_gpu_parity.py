@@ -2236,10 +2236,37 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     ds_out, dsq_out = (torch.empty_like(probs), torch.empty_like(probs)) if keep else (None, None)
     if keep:
         est[0].out_dev, est[1].out_dev = g_out.data_ptr(), dsq_out.data_ptr()
-    nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
-                                                probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if keep else None, dq.data_ptr(), dk.data_ptr(),
-                                                dv.data_ptr(), B, H, S, D, scaling, ctypes.byref(fmt5), lut5.data_ptr(), stream()),
-             "qt_attention_train_backward_bf16")
+    # the projections' own backward-pre quantizers riding on dQ / dK / dV, with the bias gradients (dK's without its column sums)
+    gsc = [torch.tensor([x], dtype=torch.float32, device=dev) for x in ((2.0 ** -22, 2.0 ** -23, 2.0 ** -21) if pow2 else (2.3e-7, 1.9e-7, 3.3e-7))]
+    gam = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in gsc]
+    gout = [torch.full((B, S, H * D), float("nan"), dtype=torch.bfloat16, device=dev) for _ in gsc]
+    gbias = [torch.full((H * D,), float("nan"), dtype=torch.bfloat16, device=dev) for _ in gsc]
+    gst = (nv.QtChainStage * 3)()
+    couts = (ctypes.c_void_p * 3)()
+    for i in range(3):
+        gst[i].scale_f32_dev, gst[i].amax_bits_dev, gst[i].out_dev, gst[i].src = gsc[i].data_ptr(), gam[i].data_ptr(), gout[i].data_ptr(), -1
+        couts[i] = gbias[i].data_ptr() if i != 1 else None
+    ws = torch.zeros(L.qt_attention_train_backward_ws_bytes(H), dtype=torch.uint8, device=dev)
+    for rep_ in range(2):              # twice: the second launch finds the scratch as the first left it (zero) and must give the same sums
+        first = [t.clone() for t in gbias]
+        nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
+                                                    probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if keep else None, dq.data_ptr(), dk.data_ptr(),
+                                                    dv.data_ptr(), gst, couts, 57344.0, ws.data_ptr(), ws.numel(), B, H, S, D, scaling, ctypes.byref(fmt5),
+                                                    lut5.data_ptr(), stream()), "qt_attention_train_backward_bf16")
+    assert int(ws.count_nonzero()) == 0
+    for i, grad in enumerate((dq, dk, dv)):
+        want, a = fq(grad, 0, fmt5, lut5, gsc[i])
+        assert torch.equal(gout[i].view(torch.int16), want.view(B, S, H * D).view(torch.int16)), i
+        if i != 1:
+            assert torch.equal(gbias[i].view(torch.int16), first[i].view(torch.int16)), i
+            ref = gout[i].double().sum((0, 1))
+            err = (gbias[i].double() - ref).abs()
+            assert bool((err <= 2.0 ** -7 * ref.abs() + 2.0 ** -12 * float(gout[i].double().abs().sum((0, 1)).max())).all()), (i, float(err.max()))
+        else:
+            assert bool(torch.isnan(gbias[i].float()).all())
+    # (the amax slots saw two launches of the same data: max is idempotent)
+    for i, grad in enumerate((dq, dk, dv)):
+        assert float(gam[i]) == float(grad.float().abs().max()), i
     g, a0 = fq(gy.permute(0, 2, 1, 3), 0, fmt5, lut5, esc[0])
     assert torch.equal(eam[0].view(torch.int32), a0.view(torch.int32))
     if keep:

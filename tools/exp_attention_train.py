@@ -62,11 +62,22 @@ def main():
     for i in range(2):
         est[i].scale_f32_dev, est[i].amax_bits_dev, est[i].out_dev, est[i].src = esc[i].data_ptr(), eam[i].data_ptr(), None, -1
     dq, dk, dv = (torch.empty(B, S, H, D, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    # the projections' backward-pre quantizers and bias gradients riding on the gradients' way out
+    gsc = [torch.tensor([x], dtype=torch.float32, device=DEV) for x in (1.0e-7, 1.0e-7, 1.0e-7)]
+    gam = [torch.zeros(1, dtype=torch.float32, device=DEV) for _ in gsc]
+    gout = [torch.empty(B, S, H * D, dtype=torch.bfloat16, device=DEV) for _ in gsc]
+    gb = [torch.empty(H * D, dtype=torch.bfloat16, device=DEV) for _ in gsc]
+    gst = (_native.QtChainStage * 3)()
+    couts = (ctypes.c_void_p * 3)()
+    for i in range(3):
+        gst[i].scale_f32_dev, gst[i].amax_bits_dev, gst[i].out_dev, gst[i].src = gsc[i].data_ptr(), gam[i].data_ptr(), gout[i].data_ptr(), -1
+        couts[i] = gb[i].data_ptr()
+    ws = torch.zeros(L.qt_attention_train_backward_ws_bytes(H), dtype=torch.uint8, device=DEV)
 
     def bwd():
         _native.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
-                                                         probs.data_ptr(), pq.data_ptr(), est, None, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, D,
-                                                         0.125, ctypes.byref(fmt5), lut5.data_ptr(), st), "bwd")
+                                                         probs.data_ptr(), pq.data_ptr(), est, None, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), gst, couts, 57344.0,
+                                                         ws.data_ptr(), ws.numel(), B, H, S, D, 0.125, ctypes.byref(fmt5), lut5.data_ptr(), st), "bwd")
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
     for name, fn, labels, base in (("forward", fwd, FWD, 0), ("backward", bwd, BWD, 32)):
         for _ in range(3):

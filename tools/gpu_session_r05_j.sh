@@ -10,9 +10,6 @@ for v in "QT_TRAIN_ATTENTION=1" "QT_TRAIN_ATTENTION=0"; do
 echo "== $v"; env $v python bench.py $W 2>&1 | ms
 done
 done
-for g in 192 256 320 384 512; do
-echo "== tuning build QT_CHAIN_WGS=$g"; QT_HIP_LIB=tools/build/libqt_hip_tuning.so QT_CHAIN_WGS=$g python bench.py $W 2>&1 | ms
-done
 rm -rf gpurun_out/prof_train_stats
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train_stats -- python3 bench.py --workload roberta-mrpc-int8-e5m2-train --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_train4.log 2>&1
 python tools/window_breakdown.py gpurun_out/prof_train_stats --windows 3 --layers 1 --anchor scale_update_multi_kernel > gpurun_out/train_j_breakdown.txt 2>&1
