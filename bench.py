@@ -513,6 +513,15 @@ def encoder_workload(a, device, world, rank, multi, sync):
         harness.train_steps(model, batches[2:3], torch.optim.AdamW(model.parameters(), lr=2e-5))
         sync()
         elems, calls = STATS.elements, STATS.calls
+        experiment = None
+        if os.environ.get("QT_BENCH_NO_OBSERVE") == "1":
+            # experiment only (tools/, profiles/): the step with every observer frozen -- no amax atomics, no scale updates -- prices the
+            # delayed-scaling bookkeeping; the line says so and is no measurement of the workload
+            from quantized_training.fake_quantize import FusedAmaxObsFakeQuantize
+            for mod in model.modules():
+                if isinstance(mod, FusedAmaxObsFakeQuantize):
+                    mod.disable_observer()
+            experiment = "observers frozen (QT_BENCH_NO_OBSERVE=1): NOT the workload"
         step = harness.GraphedTrainStep(model, opt)
         step.capture(batches[0], warmup=3)
         for i in range(a.warmup):
@@ -531,6 +540,8 @@ def encoder_workload(a, device, world, rank, multi, sync):
         what = (f"RoBERTa-base classifier (12 layers, hidden 768, random init) MRPC-style TRAINING step [{B}, {S}]: fake-quant activation={a.activation} "
                 f"weight={a.weight}, E5M2 gradients (--quantize_backprop gemm,residual), clip 1.0, AdamW")
         launch = "hipGraph replay (forward + backward + optimizer)"
+        if experiment:
+            what = "[" + experiment + "] " + what
         shape_w = (768, 3072)
     t = torch.tensor([el], device=device, dtype=torch.float64)
     if multi:
