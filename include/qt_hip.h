@@ -367,6 +367,22 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
                                      const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 size_t qt_attention_train_backward_ws_bytes(int heads);
 
+/* ---- the gradients that meet at one tensor of a training step, added in one launch (round 5) ----------------------------------------
+ * A LayerNorm's output feeds several consumers; in the backward pass every consuming Linear's grad_input passes the Linear's backward
+ * quantizer (quantize.py:147-148: register_full_backward_hook, `--quantize_backprop ...,residual`) and the autograd engine adds the
+ * arrivals one by one.  sum = (((first + y_0) + y_1) + ...), y_i = fq_i(x_i) (items[i].fq != 0: exactly qt_fake_quant_bf16 with that
+ * scale and amax slot; y_i also written to out_dev when given) or x_i itself; every addition is torch's bf16 add (fp32, one rounding),
+ * taken in the order given.  count <= 4, n % 8 == 0, pointers 16-byte aligned; the quantized items share `fmt`. */
+typedef struct {
+    const uint16_t *x_dev;
+    int fq;
+    const float *scale_f32_dev;
+    uint32_t *amax_bits_dev;
+    uint16_t *out_dev;
+} qt_fanin_item;
+int qt_grad_fanin_bf16(const uint16_t *first_dev, const qt_fanin_item *items, int count, uint16_t *sum_dev, size_t n, const qt_format *fmt,
+                       const uint16_t *lut_dev, void *stream);
+
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
  *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)

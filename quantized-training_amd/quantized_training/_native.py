@@ -35,6 +35,12 @@ class QtOperandQ(ctypes.Structure):
     _fields_ = [("fmt", QtFormat), ("lut_dev", c_void_p), ("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p)]
 
 
+class QtFaninItem(ctypes.Structure):
+    """qt_fanin_item of include/qt_hip.h"""
+    _fields_ = [("x_dev", ctypes.c_void_p), ("fq", ctypes.c_int), ("scale_f32_dev", ctypes.c_void_p), ("amax_bits_dev", ctypes.c_void_p),
+                ("out_dev", ctypes.c_void_p)]
+
+
 class QtChainStage(ctypes.Structure):
     _fields_ = [("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p), ("out_dev", c_void_p), ("src", ctypes.c_int)]
 
@@ -96,6 +102,7 @@ SIGNATURES = {
                                                  _P, _P, _P, _P]),
     "qt_softmax_fq_probs_bf16": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P, _P, _P]),
     "qt_softmax_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
+    "qt_grad_fanin_bf16": (c_int, [_P, POINTER(QtFaninItem), c_int, _P, ctypes.c_size_t, _FMT, _P, _P]),
     "qt_attention_train_supported": (c_int, [c_long, c_int, c_int, c_int]),
     "qt_attention_train_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, POINTER(QtChainStage), _P, _P, c_long, c_int,
                                         c_int, c_int, c_float, _FMT, _P, _P]),

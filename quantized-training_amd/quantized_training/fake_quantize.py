@@ -791,6 +791,12 @@ class FusedAmaxObsFakeQuantize(FakeQuantizeBase):
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
         self.__dict__["_qt_calls"] = self.__dict__.get("_qt_calls", 0) + 1      # harness.GraphedTrainStep reads this
+        if "_qt_deferred" in self.__dict__:
+            # training step: this backward quantizer's call is evaluated by the fan-in launch of the node its result goes to (train_fusions.py)
+            from . import train_fusions
+            out = train_fusions.take_deferred(self, X)
+            if out is not None:
+                return out
         if "_qt_chain_result" in self.__dict__ or "_qt_chain" in self.__dict__:
             # training-step chains (train_fusions.py): a chain launch already evaluated this call, or this call heads a chain
             from . import train_fusions

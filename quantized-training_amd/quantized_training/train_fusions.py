@@ -17,6 +17,7 @@ Nothing here changes a value: the launches are the same functions of the same in
 in another (fixed) order than qt_colsum_bf16's."""
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -31,11 +32,13 @@ class _Counters:
     colsums = 0           # bias gradients handed over
     misses = 0            # members that received another tensor than predicted
     attention = 0         # attention-core launches (forward or backward), each standing for 4 / 2 fake-quantizer calls
+    fanins = 0            # gradient fan-in launches (qt_grad_fanin_bf16)
+    deferred = 0          # backward fake-quantizer calls evaluated inside a fan-in launch
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = 0
+        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = 0
         cls.missed = []
 
 
@@ -188,13 +191,18 @@ def take_member_result(fq, X):
     if pend is None:
         return None
     fq.__dict__["_qt_chain_result"] = None
-    ptr, version, shape, out, _keep, connected = pend
+    ptr, version, shape, out, _keep, connected = pend[:6]
+    arm = pend[6] if len(pend) > 6 else None
     from .fake_quantize import _Stats, _take_preupdate, _PrecomputedFakeQuant
     if X.data_ptr() == ptr and X._version == version and tuple(X.shape) == shape and (X.is_contiguous() or X.stride() == _keep.stride()):
         STATS.members += 1
         _Stats.add(X.numel())
         if fq._observe:
             _take_preupdate(fq.amax_history)                   # the batched scale update (or the chain's own) served this call
+        if arm is not None:
+            # this call's result is an output of the producing kernel's own autograd node (`connected`): what comes back for it goes to
+            # that node alone, so the consuming Linear's backward quantizer may leave its call to the node's fan-in launch (take_deferred)
+            arm[0].__dict__["_qt_deferred"] = (tuple(X.shape), arm[1])
         if not connected and torch.is_grad_enabled() and X.requires_grad:
             return _PrecomputedFakeQuant.apply(X, out)         # the straight-through gradient of this call (fake_quantize.py:250-252)
         return out
@@ -326,12 +334,97 @@ def _stages(members, like, st):
     return stages, outs
 
 
-def _hand_over(members, produced, outs):
-    """Leaves every member's result for its call: member i will be called on `produced` (src -1) or on member src's result."""
+def _hand_over(members, produced, outs, connected=False, arm=None):
+    """Leaves every member's result for its call: member i will be called on `produced` (src -1) or on member src's result.
+    connected: the results are outputs of the producer's autograd node (no straight-through node is added when they are handed out);
+    arm[i]: the backward fake-quantizer to arm for a deferred call once member i took its result (take_deferred)."""
     for i, (fq, src) in enumerate(members):
         want = produced if src < 0 else outs[src]
-        fq.__dict__["_qt_chain_result"] = (want.data_ptr(), want._version, tuple(want.shape), outs[i], want, False)
+        fq.__dict__["_qt_chain_result"] = (want.data_ptr(), want._version, tuple(want.shape), outs[i], want, connected, arm[i] if arm else None)
     STATS.chains += 1
+
+
+class _Token:
+    __slots__ = ("__weakref__",)
+
+
+_PENDING = {}             # data_ptr of a placeholder -> (the gradient a deferred backward fake-quantizer call received, the quantizer, the placeholder)
+
+
+def fanin_enabled():
+    return producers_enabled() and os.environ.get("QT_TRAIN_FANIN", "1") != "0"
+
+
+def take_deferred(fq, X):
+    """Called at the top of a fake-quantizer's forward when a producer launch armed it (`_qt_deferred`, one shot): this is the backward
+    quantizer of a Linear whose input is an output of a LayerNorm's autograd node, called by the Linear's backward hook on grad_input
+    (quantize.py:147-148 upstream).  The call's bookkeeping happens here -- scale update, counters -- and its result is a placeholder
+    that only that node's backward will see: its fan-in launch (qt_grad_fanin_bf16) evaluates the call on the way into the sum the
+    engine would have formed.  Anything unexpected: None, and the call proceeds as usual."""
+    armed = fq.__dict__.pop("_qt_deferred", None)
+    if armed is None or armed[1]() is None or torch.is_grad_enabled() or not fanin_enabled():
+        return None                    # (armed[1]: weak reference to the producing node's token -- a graph that was dropped arms nothing)
+    shape = armed[0]
+    if not (X.is_cuda and X.dtype == torch.bfloat16 and X.is_contiguous() and tuple(X.shape) == shape and X.numel() % 8 == 0 and X.data_ptr() % 16 == 0
+            and not _hooked(fq) and _member_ok(fq, X.device) and _members_format([(fq, -1)], X.device) is not None):
+        return None
+    from .fake_quantize import _Stats, _stream_ptr, launch_scale_update
+    if fq._observe:
+        launch_scale_update(fq.amax_history, fq.scale, fq.quant_max, fq.force_scale_power_of_two, _stream_ptr(X))
+    STATS.members += 1
+    STATS.deferred += 1
+    _Stats.add(X.numel())
+    hold = torch.empty_like(X)
+    if len(_PENDING) > 64:
+        _PENDING.clear()
+    _PENDING[hold.data_ptr()] = (X, fq, hold)
+    return hold
+
+
+def _fanin(first, arrivals):
+    """first + arrivals in order, as the engine adds them (bf16 adds); an arrival that is a deferred call's placeholder is evaluated on
+    the way (its fake-quantizer on the gradient the call received).  One launch."""
+    from .fake_quantize import _stream_ptr, _hip_fake_quant, _launch_format
+    dev = first.device
+    items = []
+    for g in arrivals:
+        pend = _PENDING.pop(g.data_ptr(), None)
+        if pend is not None and pend[2].numel() == g.numel():
+            items.append((pend[0], pend[1], pend[2]))
+        else:
+            items.append((g.contiguous(), None, None))
+    quant = [(fq, -1) for _, fq, _ in items if fq is not None]
+    fmt = _members_format(quant, dev) if quant else None
+    if quant and fmt is None:
+        # (deferred calls of different formats: each as its own launch after all; their updates and counts are done)
+        for i, (raw, fq, hold) in enumerate(items):
+            if fq is not None:
+                f1 = _launch_format(fq._qt_format, fq.qmap)
+                _hip_fake_quant(raw, hold, f1, fq.qmap, fq.scale, fq.amax_history if fq._observe else None, False, None)
+                items[i] = (hold, None, None)
+        quant = []
+    if fmt is None:
+        fmt = _native.QtFormat(_native.QT_FMT_FP_SAT, 2, -14, 0.0, 57344.0)       # (no quantized item: the format is not read)
+    out = torch.empty_like(first)
+    first = first.contiguous()
+    L = _native.lib()
+    st = _stream_ptr(first)
+    pos = 0
+    while pos < len(items):
+        part = items[pos:pos + 4]
+        arr = (_native.QtFaninItem * len(part))()
+        for i, (raw, fq, _hold) in enumerate(part):
+            arr[i].x_dev = raw.data_ptr()
+            arr[i].fq = 1 if fq is not None else 0
+            arr[i].scale_f32_dev = fq.scale.data_ptr() if fq is not None else None
+            arr[i].amax_bits_dev = fq.amax_history.data_ptr() if fq is not None and fq._observe else None
+            arr[i].out_dev = None
+        _native.check(L.qt_grad_fanin_bf16(first.data_ptr(), arr, len(part), out.data_ptr(), first.numel(), ctypes.byref(fmt),
+                                           _lut_ptr(quant[0][0], fmt) if quant else None, st), "qt_grad_fanin_bf16")
+        STATS.fanins += 1
+        first = out
+        pos += 4
+    return out
 
 
 def _lut_ptr(head, fmt):
@@ -360,7 +453,7 @@ class _LayerNormTrainFn(torch.autograd.Function):
     gradient chain of the residual add in front of it, and the dense layer's bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, consumers, grad_head):
+    def forward(ctx, x, weight, bias, eps, consumers, grad_head, posts=None):
         from .fake_quantize import _stream_ptr
         cols = x.shape[-1]
         rows = x.numel() // cols
@@ -374,24 +467,36 @@ class _LayerNormTrainFn(torch.autograd.Function):
         _native.check(_native.lib().qt_layernorm_train_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                                             rstd.data_ptr(), rows, cols, float(eps), stages, len(members), ctypes.byref(fmt),
                                                             _lut_ptr(members[0][0], fmt), st), "qt_layernorm_train_bf16")
-        _hand_over(members, y, outs)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.grad_head = grad_head
-        return y
+        ctx.fan = posts is not None
+        if posts is None:
+            _hand_over(members, y, outs)
+            return y
+        ctx.token = _Token()
+        ref = weakref.ref(ctx.token)
+        # the consumers' results are outputs of THIS node: what comes back for each arrives here separately, and the sum the engine
+        # would have formed one launch per arrival is formed in one (`_fanin`), the consumers' deferred backward quantizers on the way
+        _hand_over(members, y, outs, connected=True, arm=[(p, ref) if p is not None else None for p in posts])
+        return (y,) + tuple(outs)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *gouts):
         from .fake_quantize import _stream_ptr
         x, weight, bias, mean, rstd = ctx.saved_tensors
         cols = x.shape[-1]
         rows = x.numel() // cols
+        pad = (None,) if ctx.fan else ()
+        arrivals = [g for g in reversed(gouts) if g is not None]      # the engine's order: the consumers last to first, after dy
+        if arrivals:
+            dy = _fanin(dy if dy is not None else torch.zeros_like(x), arrivals)
         dy = dy.contiguous()
         members, colsum = _grad_chain(ctx.grad_head)
         fmt = _members_format(members, x.device) if members is not None else None
         if fmt is None or dy.dtype != torch.bfloat16 or dy.data_ptr() % 16:
             gx, gw, gb = torch.ops.aten.native_layer_norm_backward(dy, x, [cols], mean.view(*x.shape[:-1], 1), rstd.view(*x.shape[:-1], 1), weight, bias,
                                                                    [True, True, True])
-            return gx, gw, gb, None, None, None
+            return (gx, gw, gb, None, None, None) + pad
         if colsum is not None and colsum[1].out_features != cols:
             colsum = None
         L = _native.lib()
@@ -414,7 +519,7 @@ class _LayerNormTrainFn(torch.autograd.Function):
             if len(_COLSUM) > 64:
                 _COLSUM.clear()
             _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gbias
-        return dx, gw, gb, None, None, None
+        return (dx, gw, gb, None, None, None) + pad
 
 
 def layernorm_or_none(norm, x):
@@ -426,15 +531,24 @@ def layernorm_or_none(norm, x):
             and norm.weight.dtype == torch.bfloat16 and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
             and x.data_ptr() % 16 == 0 and not norm._forward_hooks and not norm._forward_pre_hooks and not norm._backward_hooks):
         return None
-    consumers = []
+    consumers, posts = [], []
     for lin in norm.__dict__.get("_qt_consumers") or []:
+        for f in (getattr(lin, "error_post_process", None) or {}).values():
+            f.__dict__.pop("_qt_deferred", None)               # (nothing armed by an earlier forward survives this one)
         holder = getattr(lin, "activation_pre_process", None)
         fq = _fq(holder, "0")
         if fq is None or len(holder) != 1:
             return None
         consumers.append(fq)
+        # the consumer's backward quantizer on its grad_input (quantize.py:147-148, `--quantize_backprop ...,residual`), if it is the only
+        # thing hooked onto the Linear's backward: its call may be deferred to this node's fan-in launch
+        ph = getattr(lin, "error_post_process", None)
+        post = _fq(ph, "0") if ph is not None and len(ph) == 1 and len(lin._backward_hooks) == 1 else None
+        posts.append(post if post is not None and _member_ok(post, x.device) and not _hooked(post) else None)
     if not consumers or len(consumers) > 4 or _members_format([(f, -1) for f in consumers], x.device) is None:
         return None
+    if fanin_enabled() and x.requires_grad:
+        return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"), posts)[0]
     return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"))
 
 

@@ -2297,6 +2297,43 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     assert not any(bool(torch.isnan(t.float()).any()) for t in (dq, dk, dv))
 
 
+@pytest.mark.parametrize("n,kinds", [(2048 * 768, (1, 1, 1)), (2048 * 768, (1,)), (37 * 264, (0, 1, 1, 0)), (8 * 8, (0, 0))])
+def test_grad_fanin_equals_the_fake_quantizer_launches_and_torch_adds(nv, n, kinds):
+    """qt_grad_fanin_bf16: sum = (((first + y_0) + y_1) + ...) with y_i = fq_i(x_i) (kind 1) or x_i (kind 0) is bit for bit what the
+    separate launches give -- qt_fake_quant_bf16 per quantized item (its amax included) and torch's bf16 adds in the same order."""
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    dev = torch.device("cuda")
+    torch.manual_seed(n + len(kinds))
+    lut = qt_pkg.get_quantization_map("fp8_e5m2", dev)
+    fmt = _launch_format(nv.format_for("fp8_e5m2"), lut)
+    first = (torch.randn(n, device=dev) * 1e-3).bfloat16()
+    xs = [(torch.randn(n, device=dev) * 10.0 ** (-3 - i)).bfloat16() for i in range(len(kinds))]
+    sc = [torch.tensor([3.0e-8 * (i + 1)], dtype=torch.float32, device=dev) for i in range(len(kinds))]
+    am = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in kinds]
+    outs = [torch.empty_like(first) if i % 2 == 0 else None for i in range(len(kinds))]
+    items = (nv.QtFaninItem * len(kinds))()
+    for i, kd in enumerate(kinds):
+        items[i].x_dev, items[i].fq = xs[i].data_ptr(), kd
+        items[i].scale_f32_dev, items[i].amax_bits_dev = (sc[i].data_ptr(), am[i].data_ptr()) if kd else (None, None)
+        items[i].out_dev = outs[i].data_ptr() if (kd and outs[i] is not None) else None
+    total = torch.empty_like(first)
+    nv.check(L.qt_grad_fanin_bf16(first.data_ptr(), items, len(kinds), total.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_grad_fanin_bf16")
+    ref = first
+    for i, kd in enumerate(kinds):
+        y = xs[i]
+        if kd:
+            y = torch.empty_like(xs[i])
+            a = torch.zeros(1, dtype=torch.float32, device=dev)
+            nv.check(L.qt_fake_quant_bf16(xs[i].data_ptr(), y.data_ptr(), n, ctypes.byref(fmt), lut.data_ptr(), sc[i].data_ptr(), a.data_ptr(), stream()), "fq")
+            assert torch.equal(am[i].view(torch.int32), a.view(torch.int32)), i
+            if outs[i] is not None:
+                assert torch.equal(outs[i].view(torch.int16), y.view(torch.int16)), i
+        ref = ref + y
+    assert torch.equal(total.view(torch.int16), ref.view(torch.int16))
+
+
 def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
     """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
     the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,

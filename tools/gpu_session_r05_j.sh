@@ -3,10 +3,10 @@ mkdir -p gpurun_out
 W="--workload roberta-mrpc-int8-e5m2-train --steps 5 --warmup 2 --no-roofline --no-cpu-baseline"
 ms() { tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
 {
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "attention_train" 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "attention_train or fanin" 2>&1 | tail -25
 timeout 1500 python -m pytest tests/test_gpu_models.py -q -m gpu -k "training or train" 2>&1 | tail -40
 for r in 1 2; do
-for v in "QT_TRAIN_ATTENTION=1" "QT_TRAIN_ATTENTION=0"; do
+for v in "QT_TRAIN_FANIN=1" "QT_TRAIN_FANIN=0"; do
 echo "== $v"; env $v python bench.py $W 2>&1 | ms
 done
 done
