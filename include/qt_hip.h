@@ -383,6 +383,15 @@ typedef struct {
 int qt_grad_fanin_bf16(const uint16_t *first_dev, const qt_fanin_item *items, int count, uint16_t *sum_dev, size_t n, const qt_format *fmt,
                        const uint16_t *lut_dev, void *stream);
 
+/* ---- nn.Embedding's weight gradient inside a training step (round 5; outside the reference package, inside the measured step) ------
+ * Bit for bit torch's embedding_dense_backward for <= 3072 indices (embedding_backward_feature_kernel: per 16-row chunk the fp32 sum of
+ * the rows of an index in row order, rounded to bf16 and added to the table row in bf16, chunks in order; rows naming padding_idx
+ * skipped) as two launches instead of one workgroup's walk over all chunks.  grad [n][cols] bf16, ids [n] int64, partials_dev
+ * [n][cols] bf16 scratch, grad_weight_dev [num_rows][cols] bf16 ZERO-FILLED by the caller (torch allocates it with at::zeros);
+ * padding_idx < 0: none; no bounds check of the indices (torch has none either).  cols % 8 == 0, n <= 3072. */
+int qt_embedding_backward_bf16(const uint16_t *grad_dev, const long *ids_dev, long n, long cols, long padding_idx, long num_rows,
+                               uint16_t *partials_dev, uint16_t *grad_weight_dev, void *stream);
+
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.
  *     modules/qat/linear.py:40-41   F.linear(input, self.weight_fake_quant(self.weight), self.bias)

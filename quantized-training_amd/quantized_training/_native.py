@@ -103,6 +103,7 @@ SIGNATURES = {
     "qt_softmax_fq_probs_bf16": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P, _P, _P]),
     "qt_softmax_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
     "qt_grad_fanin_bf16": (c_int, [_P, POINTER(QtFaninItem), c_int, _P, ctypes.c_size_t, _FMT, _P, _P]),
+    "qt_embedding_backward_bf16": (c_int, [_P, _P, c_long, c_long, c_long, c_long, _P, _P, _P]),
     "qt_attention_train_supported": (c_int, [c_long, c_int, c_int, c_int]),
     "qt_attention_train_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, POINTER(QtChainStage), _P, _P, c_long, c_int,
                                         c_int, c_int, c_float, _FMT, _P, _P]),

@@ -594,6 +594,15 @@ def _intermediate_forward(self, hidden_states):
     return self._qt_hf_forward(hidden_states)
 
 
+def _embedding_forward(self, input):
+    if torch.is_grad_enabled() and input.is_cuda:
+        from . import train_fusions
+        y = train_fusions.embedding_or_none(self, input)     # a training step: torch's lookup, the weight gradient as two parallel launches
+        if y is not None:
+            return y
+    return torch.nn.Embedding.forward(self, input)
+
+
 def apply_bert_fusions(model):
     """Called by quantize(): BERT / RoBERTa encoder layers (anything shaped like HF's BertLayer) get the one-launch
     LayerNorm / GELU forwards and a q / k / v sibling group.  Returns the number of layers touched."""
@@ -609,6 +618,10 @@ def apply_bert_fusions(model):
     for mod in model.modules():                                   # the embedding LayerNorm feeds the first layer
         if type(mod).__name__.endswith("Embeddings") and isinstance(getattr(mod, "LayerNorm", None), torch.nn.LayerNorm):
             prev_norm = mod.LayerNorm
+            if layers:
+                for emb in mod.children():                        # word / position / token-type tables: their weight gradient in a training step
+                    if type(emb) is torch.nn.Embedding:
+                        _bind(emb, _embedding_forward)
             break
     for i, mod in enumerate(layers):
         inner = mod.attention.self

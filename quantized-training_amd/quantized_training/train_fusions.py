@@ -34,11 +34,12 @@ class _Counters:
     attention = 0         # attention-core launches (forward or backward), each standing for 4 / 2 fake-quantizer calls
     fanins = 0            # gradient fan-in launches (qt_grad_fanin_bf16)
     deferred = 0          # backward fake-quantizer calls evaluated inside a fan-in launch
+    embeddings = 0        # embedding weight gradients by qt_embedding_backward_bf16
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = 0
+        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = 0
         cls.missed = []
 
 
@@ -915,3 +916,46 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
         mask = m
     lins = tuple(getattr(attn, n, None) for n in ("query", "key", "value"))
     return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins)
+
+
+class _EmbeddingTrainFn(torch.autograd.Function):
+    """nn.Embedding inside a training step: torch's lookup forward; the weight gradient by qt_embedding_backward_bf16 -- bit for bit
+    torch's embedding_dense_backward (its <= 3072-index path: per 16-row chunk a partial sum per index, folded into the table row in
+    bf16, chunk after chunk), two parallel launches instead of one workgroup's walk over all chunks (134 us per table, three tables)."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.rows = weight.shape[0]
+        ctx.pad = -1 if padding_idx is None else int(padding_idx)
+        return torch.nn.functional.embedding(ids, weight, padding_idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fake_quantize import _stream_ptr
+        (ids,) = ctx.saved_tensors
+        cols = g.shape[-1]
+        g2 = g.contiguous().view(-1, cols)
+        idf = ids.reshape(-1).contiguous()
+        n = idf.numel()
+        if not (g2.dtype == torch.bfloat16 and 0 < n <= 3072 and cols % 8 == 0 and g2.data_ptr() % 16 == 0 and idf.dtype == torch.int64):
+            return torch.ops.aten.embedding_dense_backward(g, ids, ctx.rows, ctx.pad, False), None, None
+        gw = torch.zeros((ctx.rows, cols), dtype=torch.bfloat16, device=g.device)
+        part = torch.empty_like(g2)
+        _native.check(_native.lib().qt_embedding_backward_bf16(g2.data_ptr(), idf.data_ptr(), n, cols, ctx.pad, ctx.rows, part.data_ptr(), gw.data_ptr(),
+                                                               _stream_ptr(g2)), "qt_embedding_backward_bf16")
+        STATS.embeddings += 1
+        return gw, None, None
+
+
+def embedding_or_none(emb, ids):
+    """`emb(ids)` of a training step through _EmbeddingTrainFn, or None: a plain dense bf16 table on the device (no max_norm, no
+    scale_grad_by_freq, not sparse), int64 indices, at most 3072 of them (beyond that torch's gradient takes another, sort-based path
+    with other sums), nothing hooked onto the module."""
+    w = emb.weight
+    if not (producers_enabled() and os.environ.get("QT_TRAIN_EMBEDDING", "1") != "0" and torch.is_grad_enabled() and w.requires_grad and w.is_cuda
+            and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] % 8 == 0 and w.is_contiguous() and ids.is_cuda and ids.dtype == torch.int64
+            and 0 < ids.numel() <= 3072 and emb.max_norm is None and not emb.scale_grad_by_freq and not emb.sparse
+            and not emb._forward_hooks and not emb._forward_pre_hooks and not emb._backward_hooks and not emb._backward_pre_hooks):
+        return None
+    return _EmbeddingTrainFn.apply(w, ids, emb.padding_idx)

@@ -1152,11 +1152,15 @@ def test_training_attention_core_is_one_launch_each_way(monkeypatch):
         assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
 
 
-def test_training_gradient_fanin_changes_launches_not_values(monkeypatch):
-    """train_fusions._fanin: the gradients that meet at a LayerNorm's output (its consumers' grad_inputs, each through the consumer's
-    backward quantizer, and the residual path's) are added by one launch in the engine's order instead of one fake-quantizer launch and one
-    add per arrival.  Three steps with and without it (everything else on): every loss, every fake-quantizer's scale and amax history
-    and every parameter BIT-IDENTICAL, the same fake-quantized element and call counts; the counters say the launches ran."""
+@pytest.mark.parametrize("switch", ["QT_TRAIN_FANIN", "QT_TRAIN_EMBEDDING"])
+def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
+    """Two fusions of the training step that reproduce torch's arithmetic exactly, each switched off and on with everything else on; three
+    steps: every loss, every fake-quantizer's scale and amax history and every parameter BIT-IDENTICAL, the same fake-quantized element
+    and call counts; the counters say the launches ran.
+      QT_TRAIN_FANIN      train_fusions._fanin: the gradients that meet at a LayerNorm's output (its consumers' grad_inputs, each through
+                          the consumer's backward quantizer, and the residual path's) added by one launch in the engine's order instead of
+                          one fake-quantizer launch and one add per arrival
+      QT_TRAIN_EMBEDDING  qt_embedding_backward_bf16 instead of torch's embedding_dense_backward for the three embedding tables"""
     import copy
     from transformers import RobertaConfig, RobertaForSequenceClassification
     from quantized_training import train_fusions
@@ -1168,8 +1172,8 @@ def test_training_gradient_fanin_changes_launches_not_values(monkeypatch):
     g = torch.Generator().manual_seed(1)
     batches = [{"input_ids": torch.randint(3, 500, (8, 64), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)} for _ in range(3)]
 
-    def run(fanin):
-        monkeypatch.setenv("QT_TRAIN_FANIN", "1" if fanin else "0")
+    def run(on):
+        monkeypatch.setenv(switch, "1" if on else "0")
         m = copy.deepcopy(base).cuda().train()
         qt.quantize(m, _args(*_TRAIN_FLAGS))
         opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
@@ -1178,27 +1182,31 @@ def test_training_gradient_fanin_changes_launches_not_values(monkeypatch):
         losses = harness.train_steps(m, batches, opt)
         state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
         params = {n: p.detach().clone() for n, p in m.named_parameters()}
-        return losses, state, params, (train_fusions.STATS.fanins, train_fusions.STATS.deferred, train_fusions.STATS.misses), (STATS.elements, STATS.calls)
+        T = train_fusions.STATS
+        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses), (STATS.elements, STATS.calls)
     det = torch.are_deterministic_algorithms_enabled()
     torch.use_deterministic_algorithms(True, warn_only=True)
     try:
         plain = run(False)
         again = run(False)
-        fan = run(True)
+        fused = run(True)
     finally:
         torch.use_deterministic_algorithms(det)
     if again[0] != plain[0] or any(not torch.equal(plain[2][k], again[2][k]) for k in plain[2]):
         pytest.skip("the kernels of this path are not run-to-run bit-identical on this box: nothing to compare bit for bit")
-    assert plain[3] == (0, 0, 0), plain[3]
-    # steps 2 and 3; per step: the embedding norm and the first layer's output norm (each feeds a query / key / value group: 3 deferred
-    # calls) and the two attention-output norms (the FFN's first dense layer: 1)
-    assert fan[3] == (2 * 4, 2 * 8, 0), (fan[3], train_fusions.STATS.missed)
-    assert fan[4] == plain[4]
-    assert fan[0] == plain[0], (plain[0], fan[0])
-    bad = [k for k in plain[1] if not (torch.equal(plain[1][k][0], fan[1][k][0]) and torch.equal(plain[1][k][1], fan[1][k][1]))]
+    if switch == "QT_TRAIN_FANIN":
+        assert plain[3][:2] == (0, 0) and plain[3][3] == 0, plain[3]
+        # steps 2 and 3; per step: the embedding norm and the first layer's output norm (each feeds a query / key / value group: 3
+        # deferred calls) and the two attention-output norms (the FFN's first dense layer: 1)
+        assert fused[3][:2] == (2 * 4, 2 * 8) and fused[3][3] == 0, (fused[3], train_fusions.STATS.missed)
+    else:
+        assert plain[3][2] == 0 and fused[3][2] == 3 * 3 and fused[3][3] == 0, (plain[3], fused[3])      # three tables, three steps
+    assert fused[4] == plain[4]
+    assert fused[0] == plain[0], (plain[0], fused[0])
+    bad = [k for k in plain[1] if not (torch.equal(plain[1][k][0], fused[1][k][0]) and torch.equal(plain[1][k][1], fused[1][k][1]))]
     assert not bad, (len(bad), bad[:8])
     for k in plain[2]:
-        assert torch.equal(plain[2][k], fan[2][k]), k
+        assert torch.equal(plain[2][k], fused[2][k]), k
 
 
 def test_graphed_batch_runs_the_weight_passes_of_the_pair_route_as_one_launch():

@@ -2334,6 +2334,33 @@ def test_grad_fanin_equals_the_fake_quantizer_launches_and_torch_adds(nv, n, kin
     assert torch.equal(total.view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("n,rows,cols,kind,pad", [(2048, 50265, 768, "words", 1), (2048, 514, 768, "positions", 1), (2048, 1, 768, "one", -1),
+                                                  (1000, 300, 256, "words", 7), (3072, 64, 128, "words", -1), (16, 5, 8, "one", -1)])
+def test_embedding_backward_is_torchs_bit_for_bit(nv, n, rows, cols, kind, pad):
+    """qt_embedding_backward_bf16 against torch.ops.aten.embedding_dense_backward (the <= 3072-index path): the same chunked fold, so the
+    same bits -- tables with few and with many duplicates per index (a position table: every index once per sequence; a one-row
+    token-type table: every token), padding rows, a token count that does not fill its last chunk."""
+    L = nv.lib()
+    dev = torch.device("cuda")
+    torch.manual_seed(n + rows)
+    if kind == "words":
+        ids = torch.randint(0, rows, (n,), device=dev)
+        ids[::7] = ids[3]                                        # a heavy hitter
+        if pad >= 0:
+            ids[5::11] = pad
+    elif kind == "positions":
+        ids = (torch.arange(n, device=dev) % 128) + 2
+        ids[::9] = pad
+    else:
+        ids = torch.zeros(n, dtype=torch.int64, device=dev)
+    grad = torch.randn(n, cols, device=dev).bfloat16()
+    want = torch.ops.aten.embedding_dense_backward(grad, ids, rows, pad, False)
+    part = torch.empty_like(grad)
+    got = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
+    nv.check(L.qt_embedding_backward_bf16(grad.data_ptr(), ids.data_ptr(), n, cols, pad, rows, part.data_ptr(), got.data_ptr(), stream()), "qt_embedding_backward_bf16")
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), int((got.view(torch.int16) != want.view(torch.int16)).sum())
+
+
 def test_lt_fp8_gemm_algorithm_is_a_committed_table_and_runs_are_bit_equal_across_processes(nv):
     """The library FP8 GEMM runs the suggestion the committed table names (fused._LT_ALGO_TABLE; nothing is timed in the product):
     the choice is reported (routes_report), two fresh processes produce bit-identical outputs for a tabled and an untabled shape,
