@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kChunk = 16;             // rows per chunk: torch's BLOCKDIMY on ROCm
 constexpr int kEmbBlock = 128;         // threads: one 16-byte vector (8 features) each
+constexpr int kAhead = 16;             // partial rows a fold keeps in flight
 
 __global__ __launch_bounds__(kEmbBlock) void embed_partials_kernel(const uint4 *__restrict__ grad, const long *__restrict__ ids, long n, int nvec,
                                                                    long pad, uint4 *__restrict__ part) {
@@ -59,37 +60,47 @@ __global__ __launch_bounds__(kEmbBlock) void embed_partials_kernel(const uint4 *
 __global__ __launch_bounds__(kEmbBlock) void embed_fold_kernel(const uint4 *__restrict__ part, const long *__restrict__ ids, long n, int nvec, long pad,
                                                                uint4 *__restrict__ grad_weight) {
     __shared__ unsigned int s_bits[96];                         // occurrences of this token's index among rows i .. n - 1 (n <= 3072)
+    __shared__ int s_ids[3072];                                 // the indices (table rows fit an int), staged once: every scan below reads LDS
     __shared__ int s_seen;
     const long i = blockIdx.x;
     const long idx = ids[i];
     if (idx == pad) return;
     if (threadIdx.x == 0) s_seen = 0;
     for (int w = threadIdx.x; w < 96; w += kEmbBlock) s_bits[w] = 0u;
+#pragma unroll 8
+    for (int j = threadIdx.x; j < (int)n; j += kEmbBlock) s_ids[j] = (int)ids[j];
     __syncthreads();
     bool seen = false;
-    for (long j = threadIdx.x; j < i; j += kEmbBlock) seen = seen || (ids[j] == idx);
+    for (int j = threadIdx.x; j < (int)i; j += kEmbBlock) seen = seen || (s_ids[j] == (int)idx);
     if (seen) s_seen = 1;
-    for (long j = i + threadIdx.x; j < n; j += kEmbBlock)
-        if (ids[j] == idx) atomicOr(&s_bits[(j - i) >> 5], 1u << ((j - i) & 31));
+    for (int j = (int)i + threadIdx.x; j < (int)n; j += kEmbBlock)
+        if (s_ids[j] == (int)idx) atomicOr(&s_bits[j >> 5], 1u << (j & 31));      // (absolute row numbers: a chunk is an aligned half word)
     __syncthreads();
     if (s_seen) return;                                         // an earlier token owns this index
+    // every chunk's leader (its first row with this index), in parallel: chunk c = bits 16 c .. 16 c + 15
+    __shared__ int s_lead[3072 / kChunk];
+    const int c_first = (int)(i / kChunk), c_end = (int)((n + kChunk - 1) / kChunk);
+    for (int c = c_first + threadIdx.x; c < c_end; c += kEmbBlock) {
+        const unsigned int hw = (s_bits[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
+        s_lead[c] = hw ? c * kChunk + (__ffs(hw) - 1) : -1;
+    }
+    __syncthreads();
     for (int v = threadIdx.x; v < nvec; v += kEmbBlock) {
         float w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = 0.0f;
-        long last_chunk = -1;
-        const int words = (int)((n - i + 31) >> 5);
-        for (int wd = 0; wd < words; ++wd) {
-            unsigned int m = s_bits[wd];
-            while (m) {
-                const int b = __ffs(m) - 1;
-                m &= m - 1u;
-                const long j = i + (long)wd * 32 + b;
-                const long c = j / kChunk;
-                if (c == last_chunk) continue;                  // not its chunk's leader: summed into the leader's partial already
-                last_chunk = c;
-                const uint4 p = part[j * nvec + v];
-                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+        for (int c0 = c_first; c0 < c_end; c0 += kAhead) {      // sixteen chunks' partial rows in flight, folded in chunk order
+            uint4 p[kAhead];
+            int lead[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                lead[u] = c0 + u < c_end ? s_lead[c0 + u] : -1;
+                if (lead[u] >= 0) p[u] = part[(long)lead[u] * nvec + v];
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (lead[u] < 0) continue;
+                const uint32_t pw[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t r = pack_bf16x2(w[2 * k] + bf_lo(pw[k]), w[2 * k + 1] + bf_hi(pw[k]));      // W += s, in bf16
