@@ -288,6 +288,31 @@ int qt_fake_quant_chain_bf16(const uint16_t *x_dev, long rows, long cols, const 
                              size_t ws_bytes, void *stream);
 size_t qt_fake_quant_chain_ws_bytes(long rows, long cols);
 
+/* ---- the gradients that meet at one tensor of a training step, added in one launch (round 5) ----------------------------------------
+ * A LayerNorm's output feeds several consumers; in the backward pass every consuming Linear's grad_input passes the Linear's backward
+ * quantizer (quantize.py:147-148: register_full_backward_hook, `--quantize_backprop ...,residual`) and the autograd engine adds the
+ * arrivals one by one.  sum = (((first + y_0) + y_1) + ...), y_i = fq_i(x_i) (items[i].fq != 0: exactly qt_fake_quant_bf16 with that
+ * scale and amax slot; y_i also written to out_dev when given) or x_i itself; every addition is torch's bf16 add (fp32, one rounding),
+ * taken in the order given.  count <= 4, n % 8 == 0, pointers 16-byte aligned; the quantized items share `fmt`. */
+typedef struct {
+    const uint16_t *x_dev;
+    int fq;
+    const float *scale_f32_dev;
+    uint32_t *amax_bits_dev;
+    uint16_t *out_dev;
+} qt_fanin_item;
+int qt_grad_fanin_bf16(const uint16_t *first_dev, const qt_fanin_item *items, int count, uint16_t *sum_dev, size_t n, const qt_format *fmt,
+                       const uint16_t *lut_dev, void *stream);
+
+/* ---- nn.Embedding's weight gradient inside a training step (round 5; outside the reference package, inside the measured step) ------
+ * Bit for bit torch's embedding_dense_backward for <= 3072 indices (embedding_backward_feature_kernel: per 16-row chunk the fp32 sum of
+ * the rows of an index in row order, rounded to bf16 and added to the table row in bf16, chunks in order; rows naming padding_idx
+ * skipped) as two launches instead of one workgroup's walk over all chunks.  grad [n][cols] bf16, ids [n] int64, partials_dev
+ * [n][cols] bf16 scratch, grad_weight_dev [num_rows][cols] bf16 ZERO-FILLED by the caller (torch allocates it with at::zeros);
+ * padding_idx < 0: none; no bounds check of the indices (torch has none either).  cols % 8 == 0, n <= 3072. */
+int qt_embedding_backward_bf16(const uint16_t *grad_dev, const long *ids_dev, long n, long cols, long padding_idx, long num_rows,
+                               uint16_t *partials_dev, uint16_t *grad_weight_dev, void *stream);
+
 /* ---- the model's own elementwise kernels of a TRAINING step, with the fake-quantizer calls that follow them (round 5) -------------
  * The reference's examples run HF's blocks under autograd (run_glue_no_trainer.py:647-667) with the hooks of quantize.py:116-179
  * around every GEMM: a LayerNorm / GELU / softmax kernel of torch's, then one fake-quantizer launch per hook.  These entry points
@@ -303,7 +328,8 @@ size_t qt_fake_quant_chain_ws_bytes(long rows, long cols);
  *   layer_norm_grad_input), stages on grad_in; grad_weight = sum_rows grad_out * xhat, grad_bias = sum_rows grad_out and, with
  *   colsum_stage >= 0, the column sums of that stage's result, each as fp32 partial sums per workgroup (part_dev:
  *   qt_layernorm_train_backward_groups(rows) x 3 x cols floats, caller-owned scratch) added in workgroup order by a second small
- *   launch: deterministic.
+ *   launch: deterministic.  fan_items (nullable, fan_count <= 3): further gradients that arrive for the LayerNorm's result --
+ *   grad_out is replaced by qt_grad_fanin_bf16(grad_out, fan_items) as it is loaded (same sum, same bits, no launch of its own).
  * qt_softmax_fq_probs_bf16: qt_softmax_fq_bf16 that also writes the unquantized probabilities (probs_dev, nullable).
  * qt_softmax_backward_chain_bf16: grad_scores = bf16(bf16((dP - sum dP P) P) * scaling) (torch's _softmax_backward_data, then the
  *   scaling's backward; the additive mask's backward is the identity), stages on grad_scores (qk_matmul's backward-pre quantizer).
@@ -320,7 +346,8 @@ long qt_layernorm_train_backward_groups(long rows);
 int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
                                      const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
                                      const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage, float *part_dev, size_t part_bytes,
-                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, void *stream);
+                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, const qt_fanin_item *fan_items,
+                                     int fan_count, void *stream);
 int qt_softmax_fq_probs_bf16(const uint16_t *scores_dev, const uint16_t *mask_dev, uint16_t *out_dev, uint16_t *probs_dev, long batch, int heads,
                              int q_len, long cols, long mask_sb, long mask_sh, long mask_sq, float scaling, const qt_format *fmt,
                              const uint16_t *lut_dev, const float *scale_f32_dev, uint32_t *amax_bits_dev, void *stream);
@@ -366,31 +393,6 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
                                      void *ws_dev, size_t ws_bytes, long batch, int heads, int positions, int head_dim, float scaling,
                                      const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 size_t qt_attention_train_backward_ws_bytes(int heads);
-
-/* ---- the gradients that meet at one tensor of a training step, added in one launch (round 5) ----------------------------------------
- * A LayerNorm's output feeds several consumers; in the backward pass every consuming Linear's grad_input passes the Linear's backward
- * quantizer (quantize.py:147-148: register_full_backward_hook, `--quantize_backprop ...,residual`) and the autograd engine adds the
- * arrivals one by one.  sum = (((first + y_0) + y_1) + ...), y_i = fq_i(x_i) (items[i].fq != 0: exactly qt_fake_quant_bf16 with that
- * scale and amax slot; y_i also written to out_dev when given) or x_i itself; every addition is torch's bf16 add (fp32, one rounding),
- * taken in the order given.  count <= 4, n % 8 == 0, pointers 16-byte aligned; the quantized items share `fmt`. */
-typedef struct {
-    const uint16_t *x_dev;
-    int fq;
-    const float *scale_f32_dev;
-    uint32_t *amax_bits_dev;
-    uint16_t *out_dev;
-} qt_fanin_item;
-int qt_grad_fanin_bf16(const uint16_t *first_dev, const qt_fanin_item *items, int count, uint16_t *sum_dev, size_t n, const qt_format *fmt,
-                       const uint16_t *lut_dev, void *stream);
-
-/* ---- nn.Embedding's weight gradient inside a training step (round 5; outside the reference package, inside the measured step) ------
- * Bit for bit torch's embedding_dense_backward for <= 3072 indices (embedding_backward_feature_kernel: per 16-row chunk the fp32 sum of
- * the rows of an index in row order, rounded to bf16 and added to the table row in bf16, chunks in order; rows naming padding_idx
- * skipped) as two launches instead of one workgroup's walk over all chunks.  grad [n][cols] bf16, ids [n] int64, partials_dev
- * [n][cols] bf16 scratch, grad_weight_dev [num_rows][cols] bf16 ZERO-FILLED by the caller (torch allocates it with at::zeros);
- * padding_idx < 0: none; no bounds check of the indices (torch has none either).  cols % 8 == 0, n <= 3072. */
-int qt_embedding_backward_bf16(const uint16_t *grad_dev, const long *ids_dev, long n, long cols, long padding_idx, long num_rows,
-                               uint16_t *partials_dev, uint16_t *grad_weight_dev, void *stream);
 
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for
  * stateless E4M3 / E5M2 specs): y[M][sum n] = x . [fq(W_0); fq(W_1); ...]^T (+ bias_i), bf16 out, fp32 accumulation.

@@ -507,6 +507,11 @@ struct LnBwdArgs {
     float *part;              // [workgroup][3][cols] fp32: dgamma, dbeta, column sums of stage `colsum_stage`
     int colsum_stage;         // -1: none (that slab is not written)
     ChainStageDev st[kChainMax];
+    // gradients that arrive for the LayerNorm's result next to dy (qt_grad_fanin_bf16's sum, formed while dy is loaded):
+    // dy := (((dy + y_0) + y_1) + y_2), y_i = fq_i(fan_x[i]) (fan[i].scale / .amax; .src != 0) or fan_x[i] itself, every add in bf16
+    int nfan;
+    const uint4 *fan_x[3];
+    ChainStageDev fan[kChainMax];   // [0..2]: scale, amax; out unused; src: 1 = through the fake-quantizer, 0 = plain
 };
 
 template <int KIND, int NS, int BLOCK>
@@ -521,6 +526,13 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
     for (int i = 0; i < NS; ++i) {
         sc[i] = a.st[i].scale ? qt_bf2f(qt_f2bf(*a.st[i].scale)) : 1.0f;
         amax[i] = 0u;
+    }
+    float fsc[3];
+    uint32_t famax[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fsc[i] = (i < a.nfan && a.fan[i].src && a.fan[i].scale) ? qt_bf2f(qt_f2bf(*a.fan[i].scale)) : 1.0f;
+        famax[i] = 0u;
     }
     float dg[kLnMaxVec][8], db[kLnMaxVec][8], cs[kLnMaxVec][8];
 #pragma unroll
@@ -543,7 +555,28 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
         for (int i = 0; i < kLnMaxVec; ++i) {
             const int c = lane + i * 64;
             if (c < a.nvec) {
-                const uint4 d = a.dy[base + c], x = a.x[base + c];
+                uint4 d = a.dy[base + c];
+                const uint4 x = a.x[base + c];
+                if (a.nfan > 0) {                                  // (uniform) the other arrivals, in the engine's order
+                    uint4 fx[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (t < a.nfan) fx[t] = a.fan_x[t][base + c];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (t >= a.nfan) break;
+                        uint4 y = fx[t];
+                        if (a.fan[t].src) {
+                            const UniformDiv fdv(fsc[t]);
+                            y = chain_apply<KIND>(fx[t], fsc[t], fdv, rnd, famax[t]);
+                        }
+                        const uint32_t aw[4] = {d.x, d.y, d.z, d.w}, bw[4] = {y.x, y.y, y.z, y.w};
+                        d = uint4{pack_bf16x2(bf_lo(aw[0]) + bf_lo(bw[0]), bf_hi(aw[0]) + bf_hi(bw[0])),
+                                  pack_bf16x2(bf_lo(aw[1]) + bf_lo(bw[1]), bf_hi(aw[1]) + bf_hi(bw[1])),
+                                  pack_bf16x2(bf_lo(aw[2]) + bf_lo(bw[2]), bf_hi(aw[2]) + bf_hi(bw[2])),
+                                  pack_bf16x2(bf_lo(aw[3]) + bf_lo(bw[3]), bf_hi(aw[3]) + bf_hi(bw[3]))};
+                    }
+                }
                 const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, xw[4] = {x.x, x.y, x.z, x.w}, gw[4] = {gam[i].x, gam[i].y, gam[i].z, gam[i].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -619,6 +652,11 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
         __syncthreads();
     }
     chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
+    if (a.nfan > 0) {                                              // (uniform) the amax slots of the arrivals' fake-quantizers
+        __syncthreads();                                           // s_amax is read by the commit above
+        __shared__ uint32_t s_famax[3][BLOCK / 64];
+        chain_amax_commit<3, BLOCK>(a.fan, famax, s_famax);
+    }
 }
 
 // dgamma, dbeta (and the bias gradient) of one LayerNorm backward: the workgroups' partial sums added in a fixed order -- a workgroup owns
@@ -1844,8 +1882,10 @@ long qt_layernorm_train_backward_groups(long rows) { return rows <= 0 ? 0 : (row
 int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
                                      const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,
                                      const qt_format *fmt, const uint16_t *lut_dev, int colsum_stage, float *part_dev, size_t part_bytes,
-                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, void *stream) {
+                                     uint16_t *grad_weight_dev, uint16_t *grad_bias_dev, uint16_t *colsum_out_dev, const qt_fanin_item *fan_items,
+                                     int fan_count, void *stream) {
     if (rows * cols == 0) return QT_OK;
+    if (fan_count < 0 || fan_count > 3 || (fan_count > 0 && !fan_items)) return QT_ERR_BAD_ARG;
     if (!grad_out_dev || !x_dev || !weight_dev || !mean_dev || !rstd_dev || !grad_in_dev || !fmt || !part_dev || !grad_weight_dev || !grad_bias_dev ||
         rows < 0 || cols < 8 || cols % 8 || cols > 64 * 8 * kLnMaxVec || nstage < 1 || colsum_stage >= nstage || (colsum_stage >= 0 && !colsum_out_dev))
         return QT_ERR_BAD_ARG;
@@ -1857,6 +1897,14 @@ int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     a.dx = (uint4 *)grad_in_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.rows_per_wave = 1;
     a.part = part_dev; a.colsum_stage = colsum_stage < 0 ? -1 : colsum_stage;
     if (const int rc = chain_stage_args(stages, nstage, a.st)) return rc;
+    a.nfan = fan_count;
+    for (int i = 0; i < fan_count; ++i) {
+        if (!fan_items[i].x_dev) return QT_ERR_BAD_ARG;
+        if ((uintptr_t)fan_items[i].x_dev & 15u) return QT_ERR_UNALIGNED;
+        a.fan_x[i] = (const uint4 *)fan_items[i].x_dev;
+        a.fan[i] = ChainStageDev{fan_items[i].fq ? fan_items[i].scale_f32_dev : nullptr, fan_items[i].fq ? fan_items[i].amax_bits_dev : nullptr, nullptr,
+                                 fan_items[i].fq ? 1 : 0};
+    }
     hipStream_t st = (hipStream_t)stream;
     auto grid = [&](int) { return groups; };
     QT_LN_DISPATCH(ln_train_bwd_kernel, a, grid)

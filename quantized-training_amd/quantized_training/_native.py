@@ -99,7 +99,7 @@ SIGNATURES = {
     "qt_layernorm_train_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
     "qt_layernorm_train_backward_groups": (c_long, [c_long]),
     "qt_layernorm_train_backward_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, _P, c_size_t,
-                                                 _P, _P, _P, _P]),
+                                                 _P, _P, _P, POINTER(QtFaninItem), c_int, _P]),
     "qt_softmax_fq_probs_bf16": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, c_long, c_long, c_long, c_long, c_float, _FMT, _P, _P, _P, _P]),
     "qt_softmax_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
     "qt_grad_fanin_bf16": (c_int, [_P, POINTER(QtFaninItem), c_int, _P, ctypes.c_size_t, _FMT, _P, _P]),

@@ -382,11 +382,10 @@ def take_deferred(fq, X):
     return hold
 
 
-def _fanin(first, arrivals):
-    """first + arrivals in order, as the engine adds them (bf16 adds); an arrival that is a deferred call's placeholder is evaluated on
-    the way (its fake-quantizer on the gradient the call received).  One launch."""
-    from .fake_quantize import _stream_ptr, _hip_fake_quant, _launch_format
-    dev = first.device
+def _fanin_items(arrivals, dev):
+    """(items, fmt, lut): the arrivals as (tensor, fake-quantizer or None) -- a deferred call's placeholder becomes the gradient the call
+    received and its quantizer --, the one launch format of the quantized ones (None: nothing to quantize) and its map pointer."""
+    from .fake_quantize import _hip_fake_quant, _launch_format
     items = []
     for g in arrivals:
         pend = _PENDING.pop(g.data_ptr(), None)
@@ -404,6 +403,25 @@ def _fanin(first, arrivals):
                 _hip_fake_quant(raw, hold, f1, fq.qmap, fq.scale, fq.amax_history if fq._observe else None, False, None)
                 items[i] = (hold, None, None)
         quant = []
+    return [(raw, fq) for raw, fq, _ in items], fmt, (_lut_ptr(quant[0][0], fmt) if quant else None)
+
+
+def _fanin_array(part):
+    arr = (_native.QtFaninItem * len(part))()
+    for i, (raw, fq) in enumerate(part):
+        arr[i].x_dev = raw.data_ptr()
+        arr[i].fq = 1 if fq is not None else 0
+        arr[i].scale_f32_dev = fq.scale.data_ptr() if fq is not None else None
+        arr[i].amax_bits_dev = fq.amax_history.data_ptr() if fq is not None and fq._observe else None
+        arr[i].out_dev = None
+    return arr
+
+
+def _fanin(first, arrivals, prepared=None):
+    """first + arrivals in order, as the engine adds them (bf16 adds); an arrival that is a deferred call's placeholder is evaluated on
+    the way (its fake-quantizer on the gradient the call received).  One launch (per four arrivals)."""
+    from .fake_quantize import _stream_ptr
+    items, fmt, lut = prepared if prepared is not None else _fanin_items(arrivals, first.device)
     if fmt is None:
         fmt = _native.QtFormat(_native.QT_FMT_FP_SAT, 2, -14, 0.0, 57344.0)       # (no quantized item: the format is not read)
     out = torch.empty_like(first)
@@ -413,15 +431,8 @@ def _fanin(first, arrivals):
     pos = 0
     while pos < len(items):
         part = items[pos:pos + 4]
-        arr = (_native.QtFaninItem * len(part))()
-        for i, (raw, fq, _hold) in enumerate(part):
-            arr[i].x_dev = raw.data_ptr()
-            arr[i].fq = 1 if fq is not None else 0
-            arr[i].scale_f32_dev = fq.scale.data_ptr() if fq is not None else None
-            arr[i].amax_bits_dev = fq.amax_history.data_ptr() if fq is not None and fq._observe else None
-            arr[i].out_dev = None
-        _native.check(L.qt_grad_fanin_bf16(first.data_ptr(), arr, len(part), out.data_ptr(), first.numel(), ctypes.byref(fmt),
-                                           _lut_ptr(quant[0][0], fmt) if quant else None, st), "qt_grad_fanin_bf16")
+        _native.check(L.qt_grad_fanin_bf16(first.data_ptr(), _fanin_array(part), len(part), out.data_ptr(), first.numel(), ctypes.byref(fmt), lut, st),
+                      "qt_grad_fanin_bf16")
         STATS.fanins += 1
         first = out
         pos += 4
@@ -489,11 +500,21 @@ class _LayerNormTrainFn(torch.autograd.Function):
         rows = x.numel() // cols
         pad = (None,) if ctx.fan else ()
         arrivals = [g for g in reversed(gouts) if g is not None]      # the engine's order: the consumers last to first, after dy
-        if arrivals:
-            dy = _fanin(dy if dy is not None else torch.zeros_like(x), arrivals)
-        dy = dy.contiguous()
         members, colsum = _grad_chain(ctx.grad_head)
         fmt = _members_format(members, x.device) if members is not None else None
+        ride = None
+        if arrivals:
+            if dy is None:
+                dy = torch.zeros_like(x)
+            prepared = _fanin_items(arrivals, x.device)
+            # the sum is formed by the backward kernel itself while it loads dy -- when that kernel runs (a gradient chain behind this
+            # LayerNorm), the arrivals' quantizers share its format and there are at most three; else by a launch of its own
+            if (fmt is not None and len(prepared[0]) <= 3 and dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.data_ptr() % 16 == 0
+                    and (prepared[1] is None or prepared[1].key() == fmt.key()) and all(t.data_ptr() % 16 == 0 for t, _ in prepared[0])):
+                ride = prepared[0]
+            else:
+                dy = _fanin(dy, arrivals, prepared)
+        dy = dy.contiguous()
         if fmt is None or dy.dtype != torch.bfloat16 or dy.data_ptr() % 16:
             gx, gw, gb = torch.ops.aten.native_layer_norm_backward(dy, x, [cols], mean.view(*x.shape[:-1], 1), rstd.view(*x.shape[:-1], 1), weight, bias,
                                                                    [True, True, True])
@@ -512,8 +533,11 @@ class _LayerNormTrainFn(torch.autograd.Function):
         _native.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                                                          rows, cols, stages, len(members), ctypes.byref(fmt), _lut_ptr(members[0][0], fmt),
                                                          colsum[0] if colsum is not None else -1, part.data_ptr(), part.numel() * 4, gw.data_ptr(),
-                                                         gb.data_ptr(), gbias.data_ptr() if gbias is not None else None, st),
+                                                         gb.data_ptr(), gbias.data_ptr() if gbias is not None else None,
+                                                         _fanin_array(ride) if ride else None, len(ride) if ride else 0, st),
                       "qt_layernorm_train_backward_bf16")
+        if ride:
+            STATS.fanins += 1
         _hand_over(members, dx, outs)
         if gbias is not None:
             g = outs[colsum[0]]

@@ -2039,7 +2039,7 @@ def test_layernorm_train_kernels_against_torch_and_the_single_passes(nv, rows, c
     part = torch.empty(groups * 3 * cols, dtype=torch.float32, device="cuda")
     nv.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), rows, cols, stages, 4,
                                                 ctypes.byref(fmt), lut.data_ptr(), 3, part.data_ptr(), part.numel() * 4, gw.data_ptr(), gb.data_ptr(),
-                                                gbias.data_ptr(), stream()), "qt_layernorm_train_backward_bf16")
+                                                gbias.data_ptr(), None, 0, stream()), "qt_layernorm_train_backward_bf16")
     rx, rw, rb = torch.ops.aten.native_layer_norm_backward(dy, x, [cols], mean.view(rows, 1), rstd.view(rows, 1), w, b, [True, True, True])
     scale = float(rx.float().abs().max())
     assert float((dx.float() - rx.float()).abs().max()) <= 2.0 ** -7 * scale
@@ -2055,8 +2055,35 @@ def test_layernorm_train_kernels_against_torch_and_the_single_passes(nv, rows, c
     gw2, gb2 = torch.empty_like(gw), torch.empty_like(gb)
     nv.check(L.qt_layernorm_train_backward_bf16(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), rows, cols, stages, 4,
                                                 ctypes.byref(fmt), lut.data_ptr(), -1, part.data_ptr(), part.numel() * 4, gw2.data_ptr(), gb2.data_ptr(), None,
-                                                stream()), "qt_layernorm_train_backward_bf16")
+                                                None, 0, stream()), "qt_layernorm_train_backward_bf16")
     assert torch.equal(gw.view(torch.int16), gw2.view(torch.int16)) and torch.equal(gb.view(torch.int16), gb2.view(torch.int16))
+    # further gradients arriving for the LayerNorm's result, summed while grad_out is loaded: the launch on (first, arrivals) equals the
+    # launch on qt_grad_fanin_bf16(first, arrivals) bit for bit -- every output, every amax slot
+    first = (torch.randn(rows, cols, device="cuda") * 2e-5).bfloat16()
+    xs = [(torch.randn(rows, cols, device="cuda") * 1e-5).bfloat16() for _ in range(3)]
+    fsc = [torch.tensor([v], dtype=torch.float32, device="cuda") for v in (1.3e-9, 0.0, 2.2e-9)]
+    for use in (0, 1):
+        fam = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(3)]
+        items = (nv.QtFaninItem * 3)()
+        for i in range(3):
+            items[i].x_dev, items[i].fq = xs[i].data_ptr(), (0 if i == 1 else 1)
+            items[i].scale_f32_dev, items[i].amax_bits_dev = (fsc[i].data_ptr(), fam[i].data_ptr()) if i != 1 else (None, None)
+        stages, fmt, lut, outs, check = _chain_setup(nv, "fp8_e5m2", (2.1e-9, 1.7e-9, 2.6e-9, 1.0), dx, (-1, 0, 0, 1))
+        dxs, gws, gbs, gcs = torch.empty_like(x), torch.empty_like(gw), torch.empty_like(gb), torch.empty_like(gb)
+        if use == 0:
+            total = torch.empty_like(first)
+            nv.check(L.qt_grad_fanin_bf16(first.data_ptr(), items, 3, total.data_ptr(), first.numel(), ctypes.byref(fmt), lut.data_ptr(), stream()), "fanin")
+            args = (total, None, 0)
+        else:
+            args = (first, items, 3)
+        nv.check(L.qt_layernorm_train_backward_bf16(args[0].data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dxs.data_ptr(), rows, cols,
+                                                    stages, 4, ctypes.byref(fmt), lut.data_ptr(), 3, part.data_ptr(), part.numel() * 4, gws.data_ptr(),
+                                                    gbs.data_ptr(), gcs.data_ptr(), args[1], args[2], stream()), "qt_layernorm_train_backward_bf16")
+        got = [t.clone() for t in (dxs, gws, gbs, gcs, *outs, *fam)]
+        if use == 0:
+            ref_run = got
+    for a_, b_ in zip(ref_run, got):
+        assert torch.equal(a_.view(torch.int16 if a_.dtype == torch.bfloat16 else torch.int32), b_.view(torch.int16 if b_.dtype == torch.bfloat16 else torch.int32))
 
 
 @pytest.mark.parametrize("rows,cols", [(2048, 3072), (77, 64)])
