@@ -500,7 +500,10 @@ def encoder_workload(a, device, world, rank, multi, sync):
         shape_w = (768, 3072)
     else:
         from transformers import RobertaConfig, RobertaForSequenceClassification
-        model = RobertaForSequenceClassification(RobertaConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(device).bfloat16()
+        # dropout 0: the fused training paths (train_fusions.py) cover the deterministic step; QT_BENCH_DROPOUT=p runs HF's default-style
+        # dropout instead (an experiment: the attention core, the softmax kernel and the four-member gradient chains then decline)
+        drop = float(os.environ.get("QT_BENCH_DROPOUT", "0") or 0)
+        model = RobertaForSequenceClassification(RobertaConfig(num_labels=2, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop)).to(device).bfloat16()
         qt.quantize(model, qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--error",
                                                            "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm",
                                                            "--quantize_backprop", "gemm,residual", "--bf16"]))
@@ -538,7 +541,7 @@ def encoder_workload(a, device, world, rank, multi, sync):
         sync()
         el = time.perf_counter() - t0
         what = (f"RoBERTa-base classifier (12 layers, hidden 768, random init) MRPC-style TRAINING step [{B}, {S}]: fake-quant activation={a.activation} "
-                f"weight={a.weight}, E5M2 gradients (--quantize_backprop gemm,residual), clip 1.0, AdamW")
+                f"weight={a.weight}, E5M2 gradients (--quantize_backprop gemm,residual), dropout {drop:g}, clip 1.0, AdamW")
         launch = "hipGraph replay (forward + backward + optimizer)"
         if experiment:
             what = "[" + experiment + "] " + what

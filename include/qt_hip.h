@@ -369,6 +369,9 @@ int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_
  * q, k, v: [batch, heads, positions, 64] views given by the element strides of batch, position and head (the 64 values of a head
  *   contiguous, strides % 8 == 0); fqs[0..2].out_dev (q', k', v') are written with the SAME strides and are what the backward reads.
  * mask: additive bf16, nullable, element strides of (batch, head, query row), columns contiguous.
+ * drop_keep_dev (nullable): attention-probability dropout (modeling_bert.py:152 upstream, between the softmax and av_matmul): a keep mask
+ *   [batch, heads, positions, positions] of bytes (1 = keep) drawn by the caller; P_d = bf16(P * keep * drop_scale), drop_scale =
+ *   1 / (1 - p) -- torch's dropout arithmetic; P' = fq3(P_d); the backward applies bf16(dP * keep * drop_scale) before the softmax's.
  * probs_dev, fqs[3].out_dev: P and P', [batch, heads, positions, positions].  out_dev, fqs[4].out_dev (nullable): O and fq4(O) in
  *   [batch, positions, heads, 64] -- the layout the output projection reads, so no permute copy follows.
  * backward: grad_out_dev and grad_q/k/v_dev in [batch, positions, heads, 64]; fqs[0] = e0 (av_matmul's backward-pre quantizer),
@@ -384,14 +387,14 @@ int qt_softmax_backward_chain_bf16(const uint16_t *grad_probs_dev, const uint16_
 int qt_attention_train_supported(long batch, int heads, int positions, int head_dim);
 int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, long stride_b, long stride_s, long stride_h,
                             const uint16_t *mask_dev, long mask_sb, long mask_sh, long mask_sq, const qt_chain_stage *fqs, uint16_t *probs_dev,
-                            uint16_t *out_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
-                            const uint16_t *lut_dev, void *stream);
+                            uint16_t *out_dev, const uint8_t *drop_keep_dev, float drop_scale, long batch, int heads, int positions, int head_dim,
+                            float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *qq_dev, const uint16_t *kq_dev, const uint16_t *vq_dev,
                                      long stride_b, long stride_s, long stride_h, const uint16_t *probs_dev, const uint16_t *pq_dev,
                                      const qt_chain_stage *fqs, uint16_t *grad_scores_dev, uint16_t *grad_q_dev, uint16_t *grad_k_dev,
                                      uint16_t *grad_v_dev, const qt_chain_stage *grad_fqs, uint16_t *const *colsum_out_devs, float colsum_max,
-                                     void *ws_dev, size_t ws_bytes, long batch, int heads, int positions, int head_dim, float scaling,
-                                     const qt_format *fmt, const uint16_t *lut_dev, void *stream);
+                                     void *ws_dev, size_t ws_bytes, const uint8_t *drop_keep_dev, float drop_scale, long batch, int heads,
+                                     int positions, int head_dim, float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream);
 size_t qt_attention_train_backward_ws_bytes(int heads);
 
 /* ---- A9 on the FP8 matrix cores with the weight fake-quantizer fused into the GEMM (the default Linear route for

@@ -101,6 +101,8 @@ struct AttnTrainFwdArgs {
     int H, S;
     float scaling;
     FqDev fq[5];                       // q, k, v, probabilities, result
+    const uint8_t *drop;               // optional dropout on the probabilities: keep mask [B, H, S, S] (1 = keep), P_d = bf16(P * keep * drop_scale)
+    float drop_scale;                  // 1 / (1 - p)
     unsigned long long *dbg;           // tuning build, QT_AT_STAMPS = device address: s_memtime stamps of workgroup 0, waves 0 and 7 (16 slots each)
 };
 
@@ -243,7 +245,19 @@ __global__ __launch_bounds__(kThreads) void attn_train_fwd_kernel(AttnTrainFwdAr
                 if (!dead) {
                     pv = uint4{pack_bf16x2(t[0] * inv, t[1] * inv), pack_bf16x2(t[2] * inv, t[3] * inv), pack_bf16x2(t[4] * inv, t[5] * inv),
                                pack_bf16x2(t[6] * inv, t[7] * inv)};
-                    qv = chain_apply<KIND>(pv, s, dv, rnd, amax[3]);
+                    uint4 dv8 = pv;
+                    if (a.drop) {                              // torch's dropout: (P * keep) * scale in fp32, one rounding
+                        const uint2 mk = *(const uint2 *)(a.drop + ((long)bh * S + row) * S + li * 8);
+                        const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+                        uint32_t r[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t m = j < 2 ? mk.x >> (16 * j) : mk.y >> (16 * (j - 2));
+                            r[j] = pack_bf16x2((m & 0xFFu) ? bf_lo(pw[j]) * a.drop_scale : 0.0f, (m & 0xFF00u) ? bf_hi(pw[j]) * a.drop_scale : 0.0f);
+                        }
+                        dv8 = uint4{r[0], r[1], r[2], r[3]};
+                    }
+                    qv = chain_apply<KIND>(dv8, s, dv, rnd, amax[3]);
                 }
                 *(uint4 *)(Pr + row * kRowS + li * 16) = pv;
                 *(uint4 *)(Ss + row * kRowS + li * 16) = qv;
@@ -324,6 +338,8 @@ struct AttnTrainBwdArgs {
     long long *acc;                    // [3][H * 64]
     unsigned int *ticket;              // [3][H]
     int B;
+    const uint8_t *drop;               // the forward's keep mask: dP := bf16(dP * keep * drop_scale) before the softmax backward
+    float drop_scale;
     unsigned long long *dbg;           // as in the forward, slots 32..
 };
 
@@ -352,6 +368,7 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     const uint4 z4 = {0u, 0u, 0u, 0u};
     uint4 xg0 = z4, xg1 = z4, xq0 = z4, xq1 = z4, xk0 = z4, xk1 = z4, xv0 = z4, xv1 = z4;
     uint4 xp0 = z4, xp1 = z4, xp2 = z4, xp3 = z4, pr0 = z4, pr1 = z4, pr2 = z4, pr3 = z4;
+    uint2 mk0 = {0u, 0u}, mk1 = mk0, mk2 = mk0, mk3 = mk0;
     auto vec_load = [&](int i, uint4 &g, uint4 &q, uint4 &k, uint4 &v) __attribute__((always_inline)) {
         const int id = tid + i * kThreads;
         if (id < S * 8) {
@@ -363,20 +380,21 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             v = *(const uint4 *)(a.vq + off);
         }
     };
-    auto row_load = [&](int it, uint4 &xp, uint4 &pr) __attribute__((always_inline)) {
+    auto row_load = [&](int it, uint4 &xp, uint4 &pr, uint2 &mk) __attribute__((always_inline)) {
         const int row = gi + it * (kThreads / 16);
         if (row < S && li < nvec_row) {
             const long o = ((long)bh * S + row) * S + li * 8;
             xp = *(const uint4 *)(a.pq + o);
             pr = *(const uint4 *)(a.probs + o);
+            if (a.drop) mk = *(const uint2 *)(a.drop + o);
         }
     };
     vec_load(0, xg0, xq0, xk0, xv0);
     vec_load(1, xg1, xq1, xk1, xv1);
-    row_load(0, xp0, pr0);
-    row_load(1, xp1, pr1);
-    row_load(2, xp2, pr2);
-    row_load(3, xp3, pr3);
+    row_load(0, xp0, pr0, mk0);
+    row_load(1, xp1, pr1, mk1);
+    row_load(2, xp2, pr2, mk2);
+    row_load(3, xp3, pr3, mk3);
     const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kThreads);
     float sc[2];
     uint32_t amax[2];
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     // ---- dS = bf16(bf16((dP - sum dP P) P) * scaling), dS' = fq_e(dS): the row code of softmax_bwd_kernel<KIND, 1, 1, 16>
     {
         const UniformDiv dv(sc[1]);
-        auto row_body = [&](int it, const uint4 &pv) __attribute__((always_inline)) {
+        auto row_body = [&](int it, const uint4 &pv, const uint2 &mk) __attribute__((always_inline)) {
             const int row = gi + it * (kThreads / 16);
             if (row >= S) return;                              // (uniform per workgroup: S is a multiple of 32)
             const bool act = li < nvec_row;
@@ -457,7 +475,15 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             float dot = 0.0f;
             if (act) {
                 const uint4 gv = *(const uint4 *)(Ps + row * kRowS + li * 16);
-                const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
+                uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+                const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+                if (a.drop) {                                  // the dropout's backward: (dP * keep) * scale, one rounding
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t m = j < 2 ? mk.x >> (16 * j) : mk.y >> (16 * (j - 2));
+                        gw[j] = pack_bf16x2((m & 0xFFu) ? bf_lo(gw[j]) * a.drop_scale : 0.0f, (m & 0xFF00u) ? bf_hi(gw[j]) * a.drop_scale : 0.0f);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     g[2 * j] = bf_lo(gw[j]); g[2 * j + 1] = bf_hi(gw[j]);
@@ -482,10 +508,10 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
                 if (a.dsq_out) *(uint4 *)(a.dsq_out + ((long)bh * S + row) * S + li * 8) = dsq;
             }
         };
-        row_body(0, pr0);
-        row_body(1, pr1);
-        row_body(2, pr2);
-        row_body(3, pr3);
+        row_body(0, pr0, mk0);
+        row_body(1, pr1, mk1);
+        row_body(2, pr2, mk2);
+        row_body(3, pr3, mk3);
     }
     stamp(5);
     lds_barrier();
@@ -626,8 +652,8 @@ int qt_attention_train_supported(long batch, int heads, int positions, int head_
 
 int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const uint16_t *v_dev, long stride_b, long stride_s, long stride_h,
                             const uint16_t *mask_dev, long mask_sb, long mask_sh, long mask_sq, const qt_chain_stage *fqs, uint16_t *probs_dev,
-                            uint16_t *out_dev, long batch, int heads, int positions, int head_dim, float scaling, const qt_format *fmt,
-                            const uint16_t *lut_dev, void *stream) {
+                            uint16_t *out_dev, const uint8_t *drop_keep_dev, float drop_scale, long batch, int heads, int positions, int head_dim,
+                            float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream) {
     if (!q_dev || !k_dev || !v_dev || !fqs || !probs_dev || !out_dev || !fmt || !shape_ok(batch, heads, positions, head_dim)) return QT_ERR_BAD_ARG;
     for (int i = 0; i < 4; ++i)
         if (!fqs[i].out_dev) return QT_ERR_BAD_ARG;
@@ -642,6 +668,8 @@ int qt_attention_train_bf16(const uint16_t *q_dev, const uint16_t *k_dev, const 
     a.probs = probs_dev; a.pq = fqs[3].out_dev;
     a.out = out_dev; a.oq = fqs[4].out_dev;
     a.H = heads; a.S = positions; a.scaling = scaling;
+    if ((uintptr_t)drop_keep_dev & 7u) return QT_ERR_UNALIGNED;
+    a.drop = drop_keep_dev; a.drop_scale = drop_scale;
     for (int i = 0; i < 5; ++i) a.fq[i] = FqDev{fqs[i].scale_f32_dev, fqs[i].amax_bits_dev};
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_AT_STAMPS")) a.dbg = (unsigned long long *)strtoull(e, nullptr, 16);
@@ -662,8 +690,8 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
                                      long stride_b, long stride_s, long stride_h, const uint16_t *probs_dev, const uint16_t *pq_dev,
                                      const qt_chain_stage *fqs, uint16_t *grad_scores_dev, uint16_t *grad_q_dev, uint16_t *grad_k_dev,
                                      uint16_t *grad_v_dev, const qt_chain_stage *grad_fqs, uint16_t *const *colsum_out_devs, float colsum_max,
-                                     void *ws_dev, size_t ws_bytes, long batch, int heads, int positions, int head_dim, float scaling,
-                                     const qt_format *fmt, const uint16_t *lut_dev, void *stream) {
+                                     void *ws_dev, size_t ws_bytes, const uint8_t *drop_keep_dev, float drop_scale, long batch, int heads,
+                                     int positions, int head_dim, float scaling, const qt_format *fmt, const uint16_t *lut_dev, void *stream) {
     if (!grad_out_dev || !qq_dev || !kq_dev || !vq_dev || !probs_dev || !pq_dev || !fqs || !grad_q_dev || !grad_k_dev || !grad_v_dev || !fmt ||
         !shape_ok(batch, heads, positions, head_dim))
         return QT_ERR_BAD_ARG;
@@ -680,6 +708,8 @@ int qt_attention_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     a.H = heads; a.S = positions; a.scaling = scaling;
     for (int i = 0; i < 2; ++i) a.fq[i] = FqDev{fqs[i].scale_f32_dev, fqs[i].amax_bits_dev};
     a.B = (int)batch;
+    if ((uintptr_t)drop_keep_dev & 7u) return QT_ERR_UNALIGNED;
+    a.drop = drop_keep_dev; a.drop_scale = drop_scale;
     bool sums = false;
     for (int i = 0; i < 3; ++i) {
         if (!grad_fqs || !grad_fqs[i].out_dev) continue;

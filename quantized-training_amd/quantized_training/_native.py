@@ -105,11 +105,11 @@ SIGNATURES = {
     "qt_grad_fanin_bf16": (c_int, [_P, POINTER(QtFaninItem), c_int, _P, ctypes.c_size_t, _FMT, _P, _P]),
     "qt_embedding_backward_bf16": (c_int, [_P, _P, c_long, c_long, c_long, c_long, _P, _P, _P]),
     "qt_attention_train_supported": (c_int, [c_long, c_int, c_int, c_int]),
-    "qt_attention_train_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, POINTER(QtChainStage), _P, _P, c_long, c_int,
-                                        c_int, c_int, c_float, _FMT, _P, _P]),
+    "qt_attention_train_bf16": (c_int, [_P, _P, _P, c_long, c_long, c_long, _P, c_long, c_long, c_long, POINTER(QtChainStage), _P, _P, _P, c_float,
+                                        c_long, c_int, c_int, c_int, c_float, _FMT, _P, _P]),
     "qt_attention_train_backward_bf16": (c_int, [_P, _P, _P, _P, c_long, c_long, c_long, _P, _P, POINTER(QtChainStage), _P, _P, _P, _P,
-                                                 POINTER(QtChainStage), POINTER(ctypes.c_void_p), c_float, _P, ctypes.c_size_t, c_long, c_int,
-                                                 c_int, c_int, c_float, _FMT, _P, _P]),
+                                                 POINTER(QtChainStage), POINTER(ctypes.c_void_p), c_float, _P, ctypes.c_size_t, _P, c_float, c_long,
+                                                 c_int, c_int, c_int, c_float, _FMT, _P, _P]),
     "qt_attention_train_backward_ws_bytes": (ctypes.c_size_t, [c_int]),
     "qt_build_rowparams": (c_int, [_P, POINTER(QtRowParams)]),
     "qt_rowparams_apply_host": (c_uint16, [POINTER(QtRowParams), c_uint16, POINTER(c_int)]),

@@ -618,6 +618,8 @@ def apply_bert_fusions(model):
     for mod in model.modules():                                   # the embedding LayerNorm feeds the first layer
         if type(mod).__name__.endswith("Embeddings") and isinstance(getattr(mod, "LayerNorm", None), torch.nn.LayerNorm):
             prev_norm = mod.LayerNorm
+            if isinstance(getattr(mod, "dropout", None), torch.nn.Dropout):
+                prev_norm.__dict__["_qt_dropout_after"] = mod.dropout      # HF: embeddings = dropout(LayerNorm(...)): active, the consumers read another tensor
             if layers:
                 for emb in mod.children():                        # word / position / token-type tables: their weight gradient in a training step
                     if type(emb) is torch.nn.Embedding:

@@ -246,8 +246,8 @@ def plan(model):
     """Attaches chains to the fake-quantizers of `model` from its module structure; returns how many.  Call it once the lazily
     created fake-quantizers exist (after a first training step); idempotent.
       * output blocks `LayerNorm(residual(dropout(dense(h)), x))` (modules/quantizable/attention.py::_bert_output_forward; upstream
-        modeling_bert.py:174-214) with inactive dropout, backward: residual.error_pre_process[0] -> residual.error_post_process[0], [1]
-        -> dense.error_pre_process[0] (+ the dense layer's bias gradient);
+        modeling_bert.py:174-214), backward: residual.error_pre_process[0] -> residual.error_post_process[0], [1] and -- with inactive
+        dropout, whose backward otherwise sits in between -- -> dense.error_pre_process[0] (+ the dense layer's bias gradient);
       * every other QAT Linear with a backward-pre quantizer: that call + the bias gradient;
       * attention blocks whose query / key / value read one tensor, forward: the three input quantizers."""
     from .modules.qat.linear import Linear as QATLinear
@@ -260,8 +260,7 @@ def plan(model):
         dense, res, ln = getattr(mod, "dense", None), getattr(mod, "residual", None), getattr(mod, "LayerNorm", None)
         if isinstance(dense, QATLinear) and res is not None and ln is not None and getattr(type(mod), "_qt_twin", False):
             drop = getattr(mod, "dropout", None)
-            if drop is not None and getattr(drop, "p", 0.0) != 0.0:
-                continue
+            dropping = drop is not None and getattr(drop, "p", 0.0) != 0.0      # the dropout's backward then sits between the add and the dense layer
             pre = _fq(getattr(res, "error_pre_process", None), "0")
             p0, p1 = _fq(getattr(res, "error_post_process", None), "0"), _fq(getattr(res, "error_post_process", None), "1")
             dpre = _fq(getattr(dense, "error_pre_process", None), "0")
@@ -271,7 +270,7 @@ def plan(model):
             colsum = None
             if p0 is not None and p1 is not None and len(res.error_post_process) == 2:
                 members += [(p0, 0), (p1, 0)]
-                if dpre is not None and len(dense.error_pre_process) == 1:
+                if not dropping and dpre is not None and len(dense.error_pre_process) == 1:
                     members.append((dpre, 1))
                     colsum = (3, dense)
             if len(members) > 1:
@@ -556,6 +555,9 @@ def layernorm_or_none(norm, x):
             and norm.weight.dtype == torch.bfloat16 and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
             and x.data_ptr() % 16 == 0 and not norm._forward_hooks and not norm._forward_pre_hooks and not norm._backward_hooks):
         return None
+    after = norm.__dict__.get("_qt_dropout_after")
+    if after is not None and after.training and after.p > 0.0:
+        return None                                            # (the consumers read dropout(norm(x)), not this launch's result)
     consumers, posts = [], []
     for lin in norm.__dict__.get("_qt_consumers") or []:
         for f in (getattr(lin, "error_post_process", None) or {}).values():
@@ -762,7 +764,7 @@ class _AttentionTrainFn(torch.autograd.Function):
     The result and the gradients are laid out [B, S, H, D], so the permute copies of the unfused path do not exist."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, mstrides, scaling, fqs, fq_o, efqs, lins):
+    def forward(ctx, q, k, v, mask, mstrides, scaling, fqs, fq_o, efqs, lins, drop_p=0.0):
         from .fake_quantize import _stream_ptr, _Stats, launch_scale_update
         B, H, S, D = q.shape
         dev = q.device
@@ -784,9 +786,14 @@ class _AttentionTrainFn(torch.autograd.Function):
             stages[i].out_dev = outs[i].data_ptr()
             stages[i].src = -1
         msb, msh, msq = mstrides
+        # attention-probability dropout (between the softmax and av_matmul): the keep mask is drawn by torch's generator (one launch;
+        # seeds and stream capture behave as for nn.Dropout), the kernels apply torch's dropout arithmetic with it, forward and backward
+        keep = torch.empty((B, H, S, S), dtype=torch.uint8, device=dev).bernoulli_(1.0 - drop_p) if drop_p > 0.0 else None
+        ctx.drop_scale = 1.0 / (1.0 - drop_p) if drop_p > 0.0 else 1.0
         _native.check(_native.lib().qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1),
                                                             mask.data_ptr() if mask is not None else None, msb, msh, msq, stages, probs.data_ptr(),
-                                                            out.data_ptr(), B, H, S, D, float(scaling), ctypes.byref(fmt), _lut_ptr(fqs[0], fmt), st),
+                                                            out.data_ptr(), keep.data_ptr() if keep is not None else None, ctx.drop_scale, B, H, S, D,
+                                                            float(scaling), ctypes.byref(fmt), _lut_ptr(fqs[0], fmt), st),
                       "qt_attention_train_bf16")
         STATS.attention += 1
         # the four hook calls this launch stands for, in the hooks' order (qk_matmul: q, k^T; av_matmul: P, v): counted as the hooks count
@@ -795,7 +802,7 @@ class _AttentionTrainFn(torch.autograd.Function):
             _served_call(fq, x, y)
         if fq_o is not None:
             _hand_over([(fq_o, -1)], out, [oq])                # (called by the output projection's own hook, on `out` viewed [B, S, H * D])
-        ctx.save_for_backward(qq, kq, vq, probs, pq)
+        ctx.save_for_backward(*((qq, kq, vq, probs, pq) + ((keep,) if keep is not None else ())))
         ctx.scaling = float(scaling)
         ctx.efqs = efqs
         ctx.lins = lins
@@ -804,7 +811,8 @@ class _AttentionTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         from .fake_quantize import _stream_ptr, _Stats, launch_scale_update
-        qq, kq, vq, probs, pq = ctx.saved_tensors
+        qq, kq, vq, probs, pq = ctx.saved_tensors[:5]
+        keep = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
         B, H, S, D = qq.shape
         dev = qq.device
         ev, eq = ctx.efqs
@@ -814,8 +822,10 @@ class _AttentionTrainFn(torch.autograd.Function):
         if fmt is None or dout.dtype != torch.bfloat16 or dout.data_ptr() % 16:
             g = ev(dout.view(B, S, H, D).permute(0, 2, 1, 3))               # the hooks' own calls, torch's kernels
             dp, dv = g @ vq.transpose(2, 3), pq.transpose(2, 3) @ g
+            if keep is not None:
+                dp = torch.ops.aten.native_dropout_backward(dp, keep.bool(), ctx.drop_scale)
             ds = eq(torch.ops.aten._softmax_backward_data(dp, probs, -1, probs.dtype) * ctx.scaling)
-            return ds @ kq, ds.transpose(2, 3) @ qq, dv, None, None, None, None, None, None, None
+            return ds @ kq, ds.transpose(2, 3) @ qq, dv, None, None, None, None, None, None, None, None
         st = _stream_ptr(qq)
         dq, dk, dv = (torch.empty((B, S, H, D), dtype=qq.dtype, device=dev) for _ in range(3))
         stages = (_native.QtChainStage * 2)()
@@ -862,7 +872,8 @@ class _AttentionTrainFn(torch.autograd.Function):
                                                          qq.stride(1), probs.data_ptr(), pq.data_ptr(), stages, ds.data_ptr() if ds is not None else None,
                                                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), gst if riders else None, couts if riders else None,
                                                          _format_max(ev), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
-                                                         B, H, S, D, ctx.scaling, ctypes.byref(fmt), _lut_ptr(ev, fmt), st),
+                                                         keep.data_ptr() if keep is not None else None, ctx.drop_scale, B, H, S, D, ctx.scaling,
+                                                         ctypes.byref(fmt), _lut_ptr(ev, fmt), st),
                       "qt_attention_train_backward_bf16")
         STATS.attention += 1
         _served_call(ev, dout.view(B, S, H, D).permute(0, 2, 1, 3), g.permute(0, 2, 1, 3) if g is not None else None, dout.numel())
@@ -874,7 +885,7 @@ class _AttentionTrainFn(torch.autograd.Function):
                 if len(_COLSUM) > 64:
                     _COLSUM.clear()
                 _COLSUM[(o.data_ptr(), o._version, tuple(o.shape))] = gb
-        return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None, None
+        return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None, None, None
 
 
 def attention_enabled():
@@ -884,7 +895,7 @@ def attention_enabled():
 def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout):
     """The attention core of a quantizable attention block inside a training step through _AttentionTrainFn -- the result in
     [B, S, H, D] -- or None (the caller takes the sub-modules one by one): head_dim 64 and 32..128 positions, q / k / v views of one
-    layout, no active dropout, nothing but the reference's own hooks on qk_matmul / av_matmul (forward-pre on both inputs, backward-pre;
+    layout, nothing but the reference's own hooks on qk_matmul / av_matmul (forward-pre on both inputs, backward-pre;
     quantize.py:143-148) and none on the scaling or the softmax, and every one of those fake-quantizers already created (the first
     step creates them)."""
     if not (attention_enabled() and torch.is_grad_enabled() and query.is_cuda and query.dtype == torch.bfloat16 and query.dim() == 4
@@ -897,7 +908,8 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
     if (query.stride() != key.stride() or query.stride() != value.stride() or query.stride(3) != 1 or any(s % 8 for s in query.stride()[:3])
             or any(t.data_ptr() % 16 for t in (query, key, value))):
         return None
-    if dropout and attn.training:
+    drop_p = float(dropout) if (dropout and attn.training) else 0.0
+    if not 0.0 <= drop_p < 1.0:
         return None
     for name in ("attn_scaling", "softmax"):
         mod = getattr(attn, name, None)
@@ -939,7 +951,7 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
             return None
         mask = m
     lins = tuple(getattr(attn, n, None) for n in ("query", "key", "value"))
-    return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins)
+    return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins, drop_p)
 
 
 class _EmbeddingTrainFn(torch.autograd.Function):

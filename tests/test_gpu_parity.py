@@ -2169,14 +2169,16 @@ def _products_close(got, ref64, share=1e-2):
     return ok
 
 
-@pytest.mark.parametrize("B,H,S,masked,pow2", [(16, 12, 128, True, True), (2, 3, 64, False, True), (3, 5, 96, True, False), (1, 2, 32, False, False)])
-def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, masked, pow2):
+@pytest.mark.parametrize("B,H,S,masked,pow2,drop", [(16, 12, 128, True, True, 0.0), (2, 3, 64, False, True, 0.1), (3, 5, 96, True, False, 0.0),
+                                                     (1, 2, 32, False, False, 0.25), (4, 12, 128, True, True, 0.1)])
+def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, masked, pow2, drop):
     """qt_attention_train_bf16 / qt_attention_train_backward_bf16 against the launches of the unfused training step: the fake-quantizers
     (own launches of qt_fake_quant_bf16, amax included), torch.matmul for the four products, qt_softmax_fq_probs_bf16 and
     qt_softmax_backward_chain_bf16 for the softmax.  With power-of-two scales every dot of int8 values is exact in fp32 whatever the
     order of its additions, so the forward has to agree BIT FOR BIT (q', k', v', P, P', the result and its quantized form, every amax),
     and so do dV and the amax of both gradient quantizers; dQ / dK (E5M2 values of many binades: order-dependent in fp32) and every
-    product under general scales are held to the fp64 product rounded once."""
+    product under general scales are held to the fp64 product rounded once.  drop > 0: attention-probability dropout with a given keep
+    mask -- torch's own dropout arithmetic (native_dropout_backward on the mask) between the softmax and the fake-quantizer, both ways."""
     import quantized_training as qt_pkg
     from quantized_training.fake_quantize import _launch_format
     L = nv.lib()
@@ -2207,9 +2209,14 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     stages = (nv.QtChainStage * 5)()
     for i in range(5):
         stages[i].scale_f32_dev, stages[i].amax_bits_dev, stages[i].out_dev, stages[i].src = sc[i].data_ptr(), am[i].data_ptr(), outs[i].data_ptr(), -1
+    keep = torch.empty(B, H, S, S, dtype=torch.uint8, device=dev).bernoulli_(1.0 - drop) if drop else None
+    dscale = 1.0 / (1.0 - drop)
+
+    def dropped(t):                    # torch's masked-scale arithmetic (what nn.functional.dropout computes for this mask)
+        return torch.ops.aten.native_dropout_backward(t, keep.bool(), dscale) if drop else t
     nv.check(L.qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1), mask.data_ptr() if masked else None,
-                                       mask.stride(0) if masked else 0, 0, 0, stages, probs.data_ptr(), out.data_ptr(), B, H, S, D, scaling,
-                                       ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_attention_train_bf16")
+                                       mask.stride(0) if masked else 0, 0, 0, stages, probs.data_ptr(), out.data_ptr(), keep.data_ptr() if drop else None,
+                                       dscale, B, H, S, D, scaling, ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_attention_train_bf16")
 
     def fq(x, i, f=fmt, lt=lut, scl=None):
         x = x.contiguous()
@@ -2229,6 +2236,8 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
                                         mask.stride(0) if masked else 0, 0, 0, scaling, ctypes.byref(fmt), lut.data_ptr(), sc[3].data_ptr(), a3.data_ptr(),
                                         stream()), "qt_softmax_fq_probs_bf16")
     o_log = out.view(B, S, H, D).permute(0, 2, 1, 3)
+    if drop:
+        pq_ref, a3 = fq(dropped(p_ref), 3)
     if pow2:
         assert torch.equal(probs.view(torch.int16), p_ref.view(torch.int16)) and torch.equal(pq.view(torch.int16), pq_ref.view(torch.int16))
         assert torch.equal(am[3].view(torch.int32), a3.view(torch.int32))
@@ -2238,7 +2247,7 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
         d = (probs.float() - p_ref.float()).abs()
         assert float((d > 0).float().mean()) <= 2e-2 and float(d.max()) <= 2.0 ** -5, (float((d > 0).float().mean()), float(d.max()))
     # (whatever the scales) P' is the fake-quantizer of the kernel's own P, the result the product of its own P' and v', fq4 of its own result
-    want, a = fq(probs, 3)
+    want, a = fq(dropped(probs), 3)
     assert torch.equal(pq.view(torch.int16), want.view(torch.int16)) and torch.equal(am[3].view(torch.int32), a.view(torch.int32))
     assert _products_close(o_log, torch.matmul(pq.double(), vq.contiguous().double()))
     want, a = fq(out, 4)
@@ -2278,8 +2287,8 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
         first = [t.clone() for t in gbias]
         nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
                                                     probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if keep else None, dq.data_ptr(), dk.data_ptr(),
-                                                    dv.data_ptr(), gst, couts, 57344.0, ws.data_ptr(), ws.numel(), B, H, S, D, scaling, ctypes.byref(fmt5),
-                                                    lut5.data_ptr(), stream()), "qt_attention_train_backward_bf16")
+                                                    dv.data_ptr(), gst, couts, 57344.0, ws.data_ptr(), ws.numel(), keep.data_ptr() if drop else None, dscale,
+                                                    B, H, S, D, scaling, ctypes.byref(fmt5), lut5.data_ptr(), stream()), "qt_attention_train_backward_bf16")
     assert int(ws.count_nonzero()) == 0
     for i, grad in enumerate((dq, dk, dv)):
         want, a = fq(grad, 0, fmt5, lut5, gsc[i])
@@ -2302,7 +2311,7 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
         assert torch.equal(dsq_out.view(torch.int16), want.view(torch.int16)) and torch.equal(eam[1].view(torch.int32), a.view(torch.int32))
     dv_log, dq_log, dk_log = (t.permute(0, 2, 1, 3) for t in (dv, dq, dk))
     assert _products_close(dv_log, torch.matmul(pq.double().transpose(2, 3), g.double()))
-    dp_ref = torch.matmul(g, vq.contiguous().transpose(2, 3))
+    dp_ref = dropped(torch.matmul(g, vq.contiguous().transpose(2, 3))).contiguous()
     ds_ref, dsq_ref = torch.empty_like(probs), torch.empty_like(probs)
     a1 = torch.zeros(1, dtype=torch.float32, device=dev)
     st1 = (nv.QtChainStage * 1)()

@@ -53,7 +53,7 @@ def main():
 
     def fwd():
         _native.check(L.qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1), mask.data_ptr(),
-                                                mask.stride(0), 0, 0, stages, probs.data_ptr(), out.data_ptr(), B, H, S, D, 0.125, ctypes.byref(fmt),
+                                                mask.stride(0), 0, 0, stages, probs.data_ptr(), out.data_ptr(), None, 1.0, B, H, S, D, 0.125, ctypes.byref(fmt),
                                                 lut.data_ptr(), st), "fwd")
     gy = (torch.randn(B, S, H, D, device=DEV) * 1e-3).bfloat16()
     esc = [torch.tensor([x], dtype=torch.float32, device=DEV) for x in (1.1e-7, 0.9e-7)]
@@ -77,7 +77,7 @@ def main():
     def bwd():
         _native.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
                                                          probs.data_ptr(), pq.data_ptr(), est, None, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), gst, couts, 57344.0,
-                                                         ws.data_ptr(), ws.numel(), B, H, S, D, 0.125, ctypes.byref(fmt5), lut5.data_ptr(), st), "bwd")
+                                                         ws.data_ptr(), ws.numel(), None, 1.0, B, H, S, D, 0.125, ctypes.byref(fmt5), lut5.data_ptr(), st), "bwd")
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
     for name, fn, labels, base in (("forward", fwd, FWD, 0), ("backward", bwd, BWD, 32)):
         for _ in range(3):
