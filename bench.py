@@ -45,6 +45,8 @@ WORKLOADS = {
     "llama-13b-posit8_2": ("llama", "llama-2-13b", "posit8_2", "posit8_2"),
     "bert-base-squad-e4m3": ("bert", "bert-base", "e4m3", "e4m3"),
     "roberta-mrpc-int8-e5m2-train": ("roberta", "roberta-base", "int8,qs=per_tensor_symmetric", "int8,qs=per_tensor_symmetric"),
+    # the same step with HF's default dropout (0.1 on the hidden states and the attention probabilities), as a fine-tune from a checkpoint runs
+    "roberta-mrpc-int8-e5m2-train-dropout": ("roberta", "roberta-base", "int8,qs=per_tensor_symmetric", "int8,qs=per_tensor_symmetric"),
 }
 
 
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="llama-7b-e4m3", choices=sorted(WORKLOADS),
                     help="BASELINE.json configs: llama-7b-e4m3 = configs[2] (the headline, default), bert-base-squad-e4m3 = configs[1], "
-                         "llama-13b-posit8_2 = configs[3] on the GPUs given, roberta-mrpc-int8-e5m2-train = configs[4]")
+                         "llama-13b-posit8_2 = configs[3] on the GPUs given, roberta-mrpc-int8-e5m2-train = configs[4] (dropout 0; -dropout: HF's default 0.1)")
     ap.add_argument("--model", default=None, help="(llama workloads) override the model shape")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the line is then marked invalid)")
     ap.add_argument("--max_length", type=int, default=1024)
@@ -109,10 +111,10 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-SECONDARY = ("bert-base-squad-e4m3", "llama-13b-posit8_2", "roberta-mrpc-int8-e5m2-train")
+SECONDARY = ("bert-base-squad-e4m3", "llama-13b-posit8_2", "roberta-mrpc-int8-e5m2-train", "roberta-mrpc-int8-e5m2-train-dropout")
 
 
-def secondary_legs(budget_s=150.0):
+def secondary_legs(budget_s=190.0):
     """The other BASELINE.json configs that fit one GPU, three timed steps each, AFTER the headline leg (which alone is `value`): each
     one runs as a child process of its own (`bench.py --workload ...`: model built, timed, freed), so the driver's default command
     times them too.  A leg that fails or runs out of budget is reported as such, never fatal."""
@@ -502,7 +504,7 @@ def encoder_workload(a, device, world, rank, multi, sync):
         from transformers import RobertaConfig, RobertaForSequenceClassification
         # dropout 0: the fused training paths (train_fusions.py) cover the deterministic step; QT_BENCH_DROPOUT=p runs HF's default-style
         # dropout instead (an experiment: the attention core, the softmax kernel and the four-member gradient chains then decline)
-        drop = float(os.environ.get("QT_BENCH_DROPOUT", "0") or 0)
+        drop = float(os.environ.get("QT_BENCH_DROPOUT", "0") or 0) or (0.1 if a.workload.endswith("-dropout") else 0.0)
         model = RobertaForSequenceClassification(RobertaConfig(num_labels=2, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop)).to(device).bfloat16()
         qt.quantize(model, qt.add_qspec_args().parse_args(["--activation", a.activation, "--weight", a.weight, "--error",
                                                            "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm",
