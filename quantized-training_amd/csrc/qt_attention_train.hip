@@ -396,13 +396,15 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     row_load(2, xp2, pr2, mk2);
     row_load(3, xp3, pr3, mk3);
     const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kThreads);
-    float sc[2];
+    float sc[2], gsc[3];
     uint32_t amax[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         sc[i] = a.fq[i].scale ? qt_bf2f(qt_f2bf(*a.fq[i].scale)) : 1.0f;
         amax[i] = 0u;
     }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) gsc[t] = a.gs[t].scale ? qt_bf2f(qt_f2bf(*a.gs[t].scale)) : 1.0f;      // (read here: a dependent global load each)
     // ---- g = fq_e(dO), q', k', v', P' into LDS
     {
         const UniformDiv dg(sc[0]);
@@ -538,71 +540,85 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     stamp(7);
     lds_barrier();
     stamp(8);
-    // ---- dQ, dK, dV leave, each through its projection's backward-pre quantizer where one rides along; per-thread column partials
-    float gsc[3];
+    // ---- dQ, dK, dV through their projections' backward-pre quantizers where one rides along (results held in registers: every
+    // global store of the launch is issued at the very end, where nothing waits behind it); per-thread column partials
     uint32_t gamax[3] = {0u, 0u, 0u};
     float col[3][8];
+    uint4 zq[kVecIters][3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        gsc[t] = a.gs[t].scale ? qt_bf2f(qt_f2bf(*a.gs[t].scale)) : 1.0f;
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) col[t][e] = 0.0f;
-    }
 #pragma unroll
     for (int i = 0; i < kVecIters; ++i) {
         const int id = tid + i * kThreads;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) zq[i][t] = uint4{0u, 0u, 0u, 0u};
         if (id < S * 8) {
             const int r = id >> 3, c = id & 7;
-            const long off = (((long)b * S + r) * a.H + h) * kD + c * 8;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
+                if (!a.gs[t].out) continue;
                 const unsigned char *tile = t == 0 ? Gs : (t == 1 ? Vs : Ds);
-                uint16_t *dst = t == 0 ? a.dq : (t == 1 ? a.dk : a.dv);
                 const uint4 y = *(const uint4 *)(tile + r * kRowD + c * 16);
-                *(uint4 *)(dst + off) = y;
-                if (a.gs[t].out) {
-                    const UniformDiv dv(gsc[t]);
-                    const uint4 z = chain_apply<KIND>(y, gsc[t], dv, rnd, gamax[t]);
-                    *(uint4 *)(a.gs[t].out + off) = z;
-                    const uint32_t zw[4] = {z.x, z.y, z.z, z.w};
+                const UniformDiv dv(gsc[t]);
+                const uint4 z = chain_apply<KIND>(y, gsc[t], dv, rnd, gamax[t]);
+                zq[i][t] = z;
+                const uint32_t zw[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        col[t][2 * j] += bf_lo(zw[j]);
-                        col[t][2 * j + 1] += bf_hi(zw[j]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    col[t][2 * j] += bf_lo(zw[j]);
+                    col[t][2 * j + 1] += bf_hi(zw[j]);
                 }
             }
         }
     }
     stamp(9);
+    // ---- the five amax slots and the bias gradients: column sums of the quantized gradients -- inside the workgroup the 64 row lanes of
+    // a column in row order (fp32); across the batch 64-bit fixed-point atomic adds and a ticket, as qt_fake_quant_chain_bf16 does
+    // (integer addition is associative: the result does not depend on the arrival order, and no cross-XCD fence is needed).  All the
+    // launch's atomics are issued together, one wait, then the tickets: two round trips, not one per step
+    const bool sums = a.acc && (a.gs[0].colsum || a.gs[1].colsum || a.gs[2].colsum);
+    float *s_col = (float *)Ks;                                // [3][64 row lanes][65]: k', q' and the scores' tile are free now
     {
-        uint32_t am5[5] = {amax[0], amax[1], gamax[0], gamax[1], gamax[2]};
-        const FqDev f5[5] = {a.fq[0], a.fq[1], FqDev{a.gs[0].scale, a.gs[0].amax}, FqDev{a.gs[1].scale, a.gs[1].amax}, FqDev{a.gs[2].scale, a.gs[2].amax}};
-        amax_commit_w<5, kThreads / 64>(f5, am5, s_amax);
-    }
-    // ---- bias gradients: column sums of the quantized gradients.  Inside the workgroup: the 64 row lanes of a column in row order
-    // (fp32); across the batch: 64-bit fixed-point atomic adds and a ticket, as qt_fake_quant_chain_bf16 does (integer addition is
-    // associative: the result does not depend on the arrival order, and no cross-XCD fence is needed)
-    if (a.acc && (a.gs[0].colsum || a.gs[1].colsum || a.gs[2].colsum)) {
-        float *s_col = (float *)Ks;                            // [3][64 row lanes][65]: k', q' and the scores' tile are free now
-        const int rl = tid >> 3, c8 = (tid & 7) * 8;
+        const uint32_t am5[5] = {amax[0], amax[1], gamax[0], gamax[1], gamax[2]};
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_col[(t * 64 + rl) * 65 + c8 + e] = col[t][e];
-        lds_barrier();
-        const int t = tid >> 6, cc = tid & 63;                 // one thread per (tensor, column)
-        uint16_t *cs = t == 0 ? a.gs[0].colsum : (t == 1 ? a.gs[1].colsum : (t == 2 ? a.gs[2].colsum : nullptr));
-        const float tsc = t == 0 ? gsc[0] : (t == 1 ? gsc[1] : gsc[2]);
-        int E = 0;
-        (void)frexpf(a.colsum_max * tsc, &E);
-        if (t < 3 && cs) {
-            float part = 0.0f;
-            for (int r = 0; r < 64; ++r) part += s_col[(t * 64 + r) * 65 + cc];
-            const bool finite = part == part && fabsf(part) < 3.0e38f;
-            const long long fx = finite ? (long long)rintf(ldexpf(part, 42 - E)) : (1ll << 62);
-            (void)__hip_atomic_fetch_add(a.acc + ((long)t * a.H + h) * 64 + cc, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t m = wave_max_u32(am5[i]);
+            if (lane == 0) s_amax[i][wave] = m;
         }
+        if (sums) {
+            const int rl = tid >> 3, c8 = (tid & 7) * 8;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_col[(t * 64 + rl) * 65 + c8 + e] = col[t][e];
+        }
+    }
+    lds_barrier();
+    const int t = tid >> 6, cc = tid & 63;                     // waves 0..2: one thread per (tensor, column); wave 3: the amax slots
+    uint16_t *cs = t == 0 ? a.gs[0].colsum : (t == 1 ? a.gs[1].colsum : (t == 2 ? a.gs[2].colsum : nullptr));
+    const float tsc = t == 0 ? gsc[0] : (t == 1 ? gsc[1] : gsc[2]);
+    int E = 0;
+    (void)frexpf(a.colsum_max * tsc, &E);
+    if (sums && t < 3 && cs) {
+        float part = 0.0f;
+        for (int r = 0; r < 64; ++r) part += s_col[(t * 64 + r) * 65 + cc];
+        const bool finite = part == part && fabsf(part) < 3.0e38f;
+        const long long fx = finite ? (long long)rintf(ldexpf(part, 42 - E)) : (1ll << 62);
+        (void)__hip_atomic_fetch_add(a.acc + ((long)t * a.H + h) * 64 + cc, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == 3 && cc < 5) {
+        uint32_t *slot = cc == 0 ? a.fq[0].amax : (cc == 1 ? a.fq[1].amax : (cc == 2 ? a.gs[0].amax : (cc == 3 ? a.gs[1].amax : a.gs[2].amax)));
+        uint32_t m = 0u;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) {
+            const uint32_t v = cc == 0 ? s_amax[0][k] : (cc == 1 ? s_amax[1][k] : (cc == 2 ? s_amax[2][k] : (cc == 3 ? s_amax[3][k] : s_amax[4][k])));
+            m = m > v ? m : v;
+        }
+        if (slot && m != 0u) atomicMax(slot, m);
+    }
+    if (sums) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics are performed before its ticket is drawn
         lds_barrier();
         if (tid < 3) {
@@ -616,6 +632,21 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
             float sum = ldexpf((float)fx, E - 42);
             if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
             cs[h * 64 + cc] = bf16_bits(sum);
+        }
+    }
+    // ---- everything leaves (the gradient tiles are still in LDS: Gs, Vs, Ds are not touched by the column sums)
+#pragma unroll
+    for (int i = 0; i < kVecIters; ++i) {
+        const int id = tid + i * kThreads;
+        if (id < S * 8) {
+            const int r = id >> 3, c = id & 7;
+            const long off = (((long)b * S + r) * a.H + h) * kD + c * 8;
+            *(uint4 *)(a.dq + off) = *(const uint4 *)(Gs + r * kRowD + c * 16);
+            *(uint4 *)(a.dk + off) = *(const uint4 *)(Vs + r * kRowD + c * 16);
+            *(uint4 *)(a.dv + off) = *(const uint4 *)(Ds + r * kRowD + c * 16);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (a.gs[t].out) *(uint4 *)(a.gs[t].out + off) = zq[i][t];
         }
     }
     stamp(10);

@@ -14,7 +14,14 @@ result out, counted once.  Should it receive anything else, it re-zeroes its ama
 computes as usual.  Chains are planned from the modules' structure (`plan`), never from a trace.
 
 Nothing here changes a value: the launches are the same functions of the same inputs; the bias gradient's fp32 column sums are added
-in another (fixed) order than qt_colsum_bf16's."""
+in another (fixed) order than qt_colsum_bf16's.
+
+PRODUCER kernels (second half of the file) go one step further: LayerNorm, GELU, softmax and the whole attention core of a training
+step as autograd Functions on kernels that compute torch's arithmetic with torch's rounding points and evaluate the fake-quantizer
+calls around them in their own launch (_LayerNormTrainFn, _GeluTrainFn, _SoftmaxTrainFn, _AttentionTrainFn); the gradients that meet
+at a LayerNorm's output are summed by that LayerNorm's backward (take_deferred, _fanin); nn.Embedding's weight gradient is torch's
+bit for bit (_EmbeddingTrainFn).  Switches: QT_TRAIN_CHAINS, QT_TRAIN_COLSUM, QT_TRAIN_PRODUCERS, QT_TRAIN_ATTENTION, QT_TRAIN_FANIN,
+QT_TRAIN_EMBEDDING (README)."""
 import ctypes
 import os
 import weakref

@@ -2267,10 +2267,10 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     for i in range(2):
         est[i].scale_f32_dev, est[i].amax_bits_dev, est[i].out_dev, est[i].src = esc[i].data_ptr(), eam[i].data_ptr(), None, -1
     dq, dk, dv = (torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(3))
-    keep = masked                      # with and without the optional outputs (g, dS, dS')
-    g_out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev) if keep else None
-    ds_out, dsq_out = (torch.empty_like(probs), torch.empty_like(probs)) if keep else (None, None)
-    if keep:
+    extras = masked                    # with and without the optional outputs (g, dS, dS')
+    g_out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev) if extras else None
+    ds_out, dsq_out = (torch.empty_like(probs), torch.empty_like(probs)) if extras else (None, None)
+    if extras:
         est[0].out_dev, est[1].out_dev = g_out.data_ptr(), dsq_out.data_ptr()
     # the projections' own backward-pre quantizers riding on dQ / dK / dV, with the bias gradients (dK's without its column sums)
     gsc = [torch.tensor([x], dtype=torch.float32, device=dev) for x in ((2.0 ** -22, 2.0 ** -23, 2.0 ** -21) if pow2 else (2.3e-7, 1.9e-7, 3.3e-7))]
@@ -2286,7 +2286,7 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     for rep_ in range(2):              # twice: the second launch finds the scratch as the first left it (zero) and must give the same sums
         first = [t.clone() for t in gbias]
         nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
-                                                    probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if keep else None, dq.data_ptr(), dk.data_ptr(),
+                                                    probs.data_ptr(), pq.data_ptr(), est, ds_out.data_ptr() if extras else None, dq.data_ptr(), dk.data_ptr(),
                                                     dv.data_ptr(), gst, couts, 57344.0, ws.data_ptr(), ws.numel(), keep.data_ptr() if drop else None, dscale,
                                                     B, H, S, D, scaling, ctypes.byref(fmt5), lut5.data_ptr(), stream()), "qt_attention_train_backward_bf16")
     assert int(ws.count_nonzero()) == 0
@@ -2305,7 +2305,7 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
         assert float(gam[i]) == float(grad.float().abs().max()), i
     g, a0 = fq(gy.permute(0, 2, 1, 3), 0, fmt5, lut5, esc[0])
     assert torch.equal(eam[0].view(torch.int32), a0.view(torch.int32))
-    if keep:
+    if extras:
         assert torch.equal(g_out.permute(0, 2, 1, 3).contiguous().view(torch.int16), g.view(torch.int16))
         want, a = fq(ds_out, 1, fmt5, lut5, esc[1])
         assert torch.equal(dsq_out.view(torch.int16), want.view(torch.int16)) and torch.equal(eam[1].view(torch.int32), a.view(torch.int32))
@@ -2322,7 +2322,7 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     if pow2:
         assert torch.equal(dv_log.contiguous().view(torch.int16), torch.matmul(pq.transpose(2, 3), g).view(torch.int16))
         assert torch.equal(eam[1].view(torch.int32), a1.view(torch.int32))
-        if keep:
+        if extras:
             assert torch.equal(ds_out.view(torch.int16), ds_ref.view(torch.int16)) and torch.equal(dsq_out.view(torch.int16), dsq_ref.view(torch.int16))
         assert _products_close(dq_log, rq) and _products_close(dk_log, rk)
     else:
