@@ -1730,13 +1730,16 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
 }
 
 // strips x bands of one chain launch: about 192 workgroups, bands of whole 64-row groups, at most 32 bands
-static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows) {
+static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows, int pre_op = 0) {
     strips = (int)((cols / 8 + kChainStripV - 1) / kChainStripV);
     const long groups = (rows + kChainRowLanes - 1) / kChainRowLanes;           // 64-row groups
     int target = 192;                                              // measured (profiles/r05_chain_geometry.txt): 96 and 384 workgroups are both slower
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_WGS")) target = atoi(e) > 0 ? atoi(e) : target;          // tools/ only
+    if (pre_op != 0)
+        if (const char *e = getenv("QT_CHAIN_WGS_PRE")) target = atoi(e) > 0 ? atoi(e) : target;  // the GELU launches alone
 #endif
+    (void)pre_op;
     long want = (target + strips - 1) / strips;
     if (want < 1) want = 1;
     if (want > 32) want = 32;
@@ -1765,7 +1768,7 @@ static int chain_launch(const uint16_t *x_dev, const uint16_t *x2_dev, int pre_o
         if ((uintptr_t)stages[i].out_dev & 15u) return QT_ERR_UNALIGNED;
         a.st[i] = ChainStageDev{stages[i].scale_f32_dev, stages[i].amax_bits_dev, (uint4 *)stages[i].out_dev, stages[i].src};
     }
-    chain_geometry(rows, cols, a.strips, a.bands, a.band_rows);
+    chain_geometry(rows, cols, a.strips, a.bands, a.band_rows, pre_op);
     a.colsum_stage = -1;
     if (colsum_stage >= 0) {
         if (colsum_stage >= nstage || !colsum_out_dev || !(colsum_max > 0.0f) || !(colsum_max < 3.0e38f)) return QT_ERR_BAD_ARG;

@@ -426,12 +426,22 @@ def _fanin_array(part):
 def _fanin(first, arrivals, prepared=None):
     """first + arrivals in order, as the engine adds them (bf16 adds); an arrival that is a deferred call's placeholder is evaluated on
     the way (its fake-quantizer on the gradient the call received).  One launch (per four arrivals)."""
-    from .fake_quantize import _stream_ptr
+    from .fake_quantize import _stream_ptr, _hip_fake_quant, _launch_format
     items, fmt, lut = prepared if prepared is not None else _fanin_items(arrivals, first.device)
+    first = first.contiguous()
+    if not (first.dtype == torch.bfloat16 and first.numel() % 8 == 0 and first.data_ptr() % 16 == 0
+            and all(t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() == first.numel() and t.data_ptr() % 16 == 0 for t, _ in items)):
+        # something the launch would refuse (an offset view, another dtype): the launches it stands for, one by one
+        for raw, fq in items:
+            if fq is not None:
+                y = torch.empty_like(raw)
+                _hip_fake_quant(raw.contiguous(), y, _launch_format(fq._qt_format, fq.qmap), fq.qmap, fq.scale, fq.amax_history if fq._observe else None, False, None)
+                raw = y
+            first = first + raw.view_as(first)
+        return first
     if fmt is None:
         fmt = _native.QtFormat(_native.QT_FMT_FP_SAT, 2, -14, 0.0, 57344.0)       # (no quantized item: the format is not read)
     out = torch.empty_like(first)
-    first = first.contiguous()
     L = _native.lib()
     st = _stream_ptr(first)
     pos = 0
