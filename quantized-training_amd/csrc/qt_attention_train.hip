@@ -16,9 +16,19 @@
 // own scale and amax slot, and every rounding point listed above is kept.  What the backward needs is written once (q', k', v', P, P');
 // the result and the three gradients are written in the [B, S, H, D] layout their consumers read, so no permute copy remains.
 //
+// Riding along: attention-probability dropout with a caller-drawn keep mask (torch's masked-scale arithmetic, both ways); forward, the
+// output projection's input quantizer on the result; backward, the q / k / v projections' own backward-pre quantizers on dQ / dK / dV
+// and the column sums of their results = the three bias gradients (64-bit fixed-point atomics across the batch: deterministic).
+//
 // Bit-defined against the launches it replaces: the fake-quantizers (exactly), the softmax forward and backward (the row code of
 // qt_softmax.hip: same lanes per row, same order of the row sums).  Not bit-defined: the order in which a matrix instruction adds
-// the products of a dot (the library GEMM's is not defined either) -- tests/test_gpu_parity.py states the tolerance.
+// the products of a dot (the library GEMM's is not defined either) -- with power-of-two scales every dot of int8 values is exact in
+// fp32, and tests/test_gpu_parity.py then demands bit equality with the launches replaced; else it states the tolerance.
+//
+// Shape of a launch: 512 threads, one workgroup per CU (LDS).  Every global read is issued before anything waits (named registers:
+// arrays of loaded vectors went through scratch memory), barriers order LDS only (`s_waitcnt lgkmcnt(0); s_barrier` -- __syncthreads()
+// would drain every global store in flight), every global store leaves in the last phase.  profiles/r05_attention_train_stamps.txt has
+// the cycles per phase; a 1024-thread variant halved the vector phases and lost it all in the barriers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
