@@ -323,7 +323,9 @@ int qt_embedding_backward_bf16(const uint16_t *grad_dev, const long *ids_dev, lo
  * qt_gelu_backward_chain_bf16: grad_in = bf16(grad_out * (Phi(x) + x phi(x))) (torch's GeluBackward), stages on grad_in, optional
  *   column sums of one stage (see qt_fake_quant_chain_bf16).
  * qt_layernorm_train_bf16: y = LayerNorm(x) over the last dimension (fp32 statistics, biased variance, one rounding), mean / rstd
- *   [rows] fp32 kept for the backward, stages on y.  cols <= 1024.
+ *   [rows] fp32 kept for the backward, stages on y.  cols <= 1024.  residual_dev / sum_dev (both or neither): the residual add in
+ *   front of the LayerNorm (modeling_bert.py:188, 212 upstream) in the same launch -- sum = bf16(x + residual) (torch's add) is
+ *   written to sum_dev (what the backward needs as the LayerNorm's input) and normalised.
  * qt_layernorm_train_backward_bf16: grad_in = rstd (g - mean(g) - xhat mean(g xhat)), g = grad_out * weight (torch's
  *   layer_norm_grad_input), stages on grad_in; grad_weight = sum_rows grad_out * xhat, grad_bias = sum_rows grad_out and, with
  *   colsum_stage >= 0, the column sums of that stage's result, each as fp32 partial sums per workgroup (part_dev:
@@ -341,7 +343,7 @@ int qt_gelu_backward_chain_bf16(const uint16_t *grad_out_dev, const uint16_t *x_
                                 float colsum_max, uint16_t *colsum_out_dev, void *ws_dev, size_t ws_bytes, void *stream);
 int qt_layernorm_train_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, const uint16_t *bias_dev, uint16_t *y_dev, float *mean_dev,
                             float *rstd_dev, long rows, long cols, float eps, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
-                            const uint16_t *lut_dev, void *stream);
+                            const uint16_t *lut_dev, const uint16_t *residual_dev, uint16_t *sum_dev, void *stream);
 long qt_layernorm_train_backward_groups(long rows);
 int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_t *x_dev, const uint16_t *weight_dev, const float *mean_dev,
                                      const float *rstd_dev, uint16_t *grad_in_dev, long rows, long cols, const qt_chain_stage *stages, int nstage,

@@ -418,6 +418,8 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
 constexpr int kLnMaxVec = 2;
 struct LnTrainArgs {
     const uint4 *x, *w, *b;
+    const uint4 *x2;          // optional: the residual connection -- the row normalised is bf16(x + x2) (torch's add), written to `sum`
+    uint4 *sum;
     uint4 *y;
     float *mean, *rstd;
     long rows;
@@ -448,6 +450,12 @@ __global__ __launch_bounds__(BLOCK) void ln_train_fwd_kernel(LnTrainArgs a, qt_f
             const int c = lane + i * 64;
             if (c < a.nvec) {
                 v[i] = a.x[base + c];
+                if (a.x2) {                                        // (uniform)
+                    const uint4 r = a.x2[base + c];
+                    v[i] = uint4{pack_bf16x2(bf_lo(v[i].x) + bf_lo(r.x), bf_hi(v[i].x) + bf_hi(r.x)), pack_bf16x2(bf_lo(v[i].y) + bf_lo(r.y), bf_hi(v[i].y) + bf_hi(r.y)),
+                                 pack_bf16x2(bf_lo(v[i].z) + bf_lo(r.z), bf_hi(v[i].z) + bf_hi(r.z)), pack_bf16x2(bf_lo(v[i].w) + bf_lo(r.w), bf_hi(v[i].w) + bf_hi(r.w))};
+                    a.sum[base + c] = v[i];
+                }
                 sum += (bf_lo(v[i].x) + bf_hi(v[i].x)) + (bf_lo(v[i].y) + bf_hi(v[i].y)) + (bf_lo(v[i].z) + bf_hi(v[i].z)) + (bf_lo(v[i].w) + bf_hi(v[i].w));
             }
         }
@@ -1863,14 +1871,16 @@ static int chain_stage_args(const qt_chain_stage *stages, int nstage, ChainStage
 
 int qt_layernorm_train_bf16(const uint16_t *x_dev, const uint16_t *weight_dev, const uint16_t *bias_dev, uint16_t *y_dev, float *mean_dev,
                             float *rstd_dev, long rows, long cols, float eps, const qt_chain_stage *stages, int nstage, const qt_format *fmt,
-                            const uint16_t *lut_dev, void *stream) {
+                            const uint16_t *lut_dev, const uint16_t *residual_dev, uint16_t *sum_dev, void *stream) {
     if (rows * cols == 0) return QT_OK;
     if (!x_dev || !weight_dev || !bias_dev || !y_dev || !mean_dev || !rstd_dev || !fmt || rows < 0 || cols < 8 || cols % 8 || cols > 64 * 8 * kLnMaxVec ||
         nstage < 1)
         return QT_ERR_BAD_ARG;
-    if (((uintptr_t)x_dev | (uintptr_t)weight_dev | (uintptr_t)bias_dev | (uintptr_t)y_dev) & 15u) return QT_ERR_UNALIGNED;
+    if (((uintptr_t)x_dev | (uintptr_t)weight_dev | (uintptr_t)bias_dev | (uintptr_t)y_dev | (uintptr_t)residual_dev | (uintptr_t)sum_dev) & 15u) return QT_ERR_UNALIGNED;
+    if ((residual_dev != nullptr) != (sum_dev != nullptr)) return QT_ERR_BAD_ARG;
     LnTrainArgs a{};
     a.x = (const uint4 *)x_dev; a.w = (const uint4 *)weight_dev; a.b = (const uint4 *)bias_dev; a.y = (uint4 *)y_dev;
+    a.x2 = (const uint4 *)residual_dev; a.sum = (uint4 *)sum_dev;
     a.mean = mean_dev; a.rstd = rstd_dev; a.rows = rows; a.nvec = (int)(cols / 8); a.inv_cols = 1.0f / (float)cols; a.eps = eps;
     if (const int rc = chain_stage_args(stages, nstage, a.st)) return rc;
     hipStream_t st = (hipStream_t)stream;

@@ -96,7 +96,7 @@ SIGNATURES = {
     "qt_fake_quant_chain_ws_bytes": (c_size_t, [c_long, c_long]),
     "qt_gelu_chain_bf16": (c_int, [_P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
     "qt_gelu_backward_chain_bf16": (c_int, [_P, _P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
-    "qt_layernorm_train_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P]),
+    "qt_layernorm_train_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, c_float, POINTER(QtChainStage), c_int, _FMT, _P, _P, _P, _P]),
     "qt_layernorm_train_backward_groups": (c_long, [c_long]),
     "qt_layernorm_train_backward_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, _P, c_size_t,
                                                  _P, _P, _P, POINTER(QtFaninItem), c_int, _P]),

@@ -193,6 +193,11 @@ class LlamaAttention(QuantizableAttentionCore):
 # ---- output blocks: LayerNorm(dense(x) + residual) ------------------------------------------------
 def _bert_output_forward(self, hidden_states, input_tensor):
     hidden_states = self.dropout(self.dense(hidden_states))
+    if torch.is_grad_enabled() and hidden_states.is_cuda:
+        from ...train_fusions import add_layernorm_or_none as train_add_layernorm
+        fused = train_add_layernorm(self, hidden_states, input_tensor)      # a training step: the residual add inside the LayerNorm launch
+        if fused is not None:
+            return fused
     from ...model_fusions import add_layernorm_or_none
     fused = add_layernorm_or_none(self, hidden_states, input_tensor)      # one launch on device under no_grad
     if fused is not None:

@@ -17,10 +17,28 @@ class _BinaryOp(torch.nn.Module):
         return type(self).fn(lhs, rhs)
 
 
+class _LazyAdd(torch.autograd.Function):
+    """lhs + rhs whose VALUES the next kernel writes (train_fusions.add_layernorm_or_none: the LayerNorm launch forms the sum and stores it
+    into this result's memory): the autograd node and the module call -- with the backward hooks hanging on it -- exist as usual."""
+
+    @staticmethod
+    def forward(ctx, lhs, rhs):
+        return torch.empty_like(lhs)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class AddFunctional(_BinaryOp):
     """residual connections hang here"""
 
     fn = staticmethod(torch.add)
+
+    def forward(self, lhs, rhs):
+        if self.__dict__.pop("_qt_lazy_add", False) and lhs.shape == rhs.shape and lhs.dtype == rhs.dtype:
+            return _LazyAdd.apply(lhs, rhs)
+        return torch.add(lhs, rhs)
 
 
 class MulFunctional(_BinaryOp):

@@ -42,11 +42,12 @@ class _Counters:
     fanins = 0            # gradient fan-in launches (qt_grad_fanin_bf16)
     deferred = 0          # backward fake-quantizer calls evaluated inside a fan-in launch
     embeddings = 0        # embedding weight gradients by qt_embedding_backward_bf16
+    addlns = 0            # residual adds formed inside a LayerNorm launch
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = 0
+        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = 0
         cls.missed = []
 
 
@@ -481,7 +482,7 @@ class _LayerNormTrainFn(torch.autograd.Function):
     gradient chain of the residual add in front of it, and the dense layer's bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, consumers, grad_head, posts=None):
+    def forward(ctx, x, weight, bias, eps, consumers, grad_head, posts=None, addends=None):
         from .fake_quantize import _stream_ptr
         cols = x.shape[-1]
         rows = x.numel() // cols
@@ -492,9 +493,13 @@ class _LayerNormTrainFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         stages, outs = _stages(members, x, st)
-        _native.check(_native.lib().qt_layernorm_train_bf16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+        # addends (h, r): x is the residual add's result whose values nobody has computed yet (functional_modules._LazyAdd) -- this launch
+        # forms bf16(h + r), stores it into x's memory (the backward reads it there) and normalises it
+        src, res = (addends[0], addends[1]) if addends is not None else (x, None)
+        _native.check(_native.lib().qt_layernorm_train_bf16(src.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                                             rstd.data_ptr(), rows, cols, float(eps), stages, len(members), ctypes.byref(fmt),
-                                                            _lut_ptr(members[0][0], fmt), st), "qt_layernorm_train_bf16")
+                                                            _lut_ptr(members[0][0], fmt), res.data_ptr() if res is not None else None,
+                                                            x.data_ptr() if res is not None else None, st), "qt_layernorm_train_bf16")
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.grad_head = grad_head
         ctx.fan = posts is not None
@@ -514,7 +519,7 @@ class _LayerNormTrainFn(torch.autograd.Function):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         cols = x.shape[-1]
         rows = x.numel() // cols
-        pad = (None,) if ctx.fan else ()
+        pad = (None, None) if ctx.fan else ()
         arrivals = [g for g in reversed(gouts) if g is not None]      # the engine's order: the consumers last to first, after dy
         members, colsum = _grad_chain(ctx.grad_head)
         fmt = _members_format(members, x.device) if members is not None else None
@@ -563,10 +568,10 @@ class _LayerNormTrainFn(torch.autograd.Function):
         return (dx, gw, gb, None, None, None) + pad
 
 
-def layernorm_or_none(norm, x):
-    """`norm(x)` of a training step through _LayerNormTrainFn, or None (the caller runs the module): bf16 device tensors under grad mode,
-    rows of at most 1024 columns, and at least one consuming Linear whose input quantizer can ride on the launch (`_qt_consumers`,
-    set by model_fusions.apply_bert_fusions)."""
+def _layernorm_plan(norm, x):
+    """(consumers' input quantizers, their Linears' deferrable backward quantizers) when `norm(x)` of a training step can go through
+    _LayerNormTrainFn, or None: bf16 device tensors under grad mode, rows of at most 1024 columns, and at least one consuming Linear whose
+    input quantizer can ride on the launch (`_qt_consumers`, set by model_fusions.apply_bert_fusions)."""
     if not (producers_enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
             and type(norm) is torch.nn.LayerNorm and norm.elementwise_affine and norm.bias is not None and len(norm.normalized_shape) == 1
             and norm.weight.dtype == torch.bfloat16 and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
@@ -591,9 +596,41 @@ def layernorm_or_none(norm, x):
         posts.append(post if post is not None and _member_ok(post, x.device) and not _hooked(post) else None)
     if not consumers or len(consumers) > 4 or _members_format([(f, -1) for f in consumers], x.device) is None:
         return None
+    return consumers, posts
+
+
+def layernorm_or_none(norm, x):
+    """`norm(x)` of a training step through _LayerNormTrainFn, or None (the caller runs the module)."""
+    plan_ = _layernorm_plan(norm, x)
+    if plan_ is None:
+        return None
+    consumers, posts = plan_
     if fanin_enabled() and x.requires_grad:
-        return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"), posts)[0]
+        return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"), posts, None)[0]
     return _LayerNormTrainFn.apply(x, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"))
+
+
+def add_layernorm_or_none(block, h, r):
+    """`block.LayerNorm(block.residual(h, r))` of a training step with the add inside the LayerNorm launch, or None.  The residual module
+    is still CALLED -- its backward hooks (the gradient chain of `plan`) hang on that call -- but told to leave the sum's values to the
+    launch (functional_modules._LazyAdd); nothing may hook its forward or read the sum in between."""
+    from .modules.quantizable.functional_modules import AddFunctional
+    norm, res = getattr(block, "LayerNorm", None), getattr(block, "residual", None)
+    if not (fanin_enabled() and os.environ.get("QT_TRAIN_ADDLN", "1") != "0" and type(res) is AddFunctional and norm is not None
+            and h.shape == r.shape and h.dtype == r.dtype and r.is_cuda and r.is_contiguous() and r.data_ptr() % 16 == 0 and h.requires_grad
+            and not res._forward_hooks and not res._forward_pre_hooks and getattr(res, "activation_pre_process", None) is None):
+        return None
+    plan_ = _layernorm_plan(norm, h)
+    if plan_ is None:
+        return None
+    consumers, posts = plan_
+    res.__dict__["_qt_lazy_add"] = True
+    try:
+        s_ = res(h, r)
+    finally:
+        res.__dict__.pop("_qt_lazy_add", None)
+    STATS.addlns += 1
+    return _LayerNormTrainFn.apply(s_, norm.weight, norm.bias, norm.eps, consumers, norm.__dict__.get("_qt_grad_head"), posts, (h, r))[0]
 
 
 class _GeluTrainFn(torch.autograd.Function):

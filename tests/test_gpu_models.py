@@ -1167,7 +1167,7 @@ def test_training_attention_core_is_one_launch_each_way(monkeypatch, drop):
         assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
 
 
-@pytest.mark.parametrize("switch", ["QT_TRAIN_FANIN", "QT_TRAIN_EMBEDDING"])
+@pytest.mark.parametrize("switch", ["QT_TRAIN_FANIN", "QT_TRAIN_EMBEDDING", "QT_TRAIN_ADDLN"])
 def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
     """Two fusions of the training step that reproduce torch's arithmetic exactly, each switched off and on with everything else on; three
     steps: every loss, every fake-quantizer's scale and amax history and every parameter BIT-IDENTICAL, the same fake-quantized element
@@ -1175,7 +1175,9 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
       QT_TRAIN_FANIN      train_fusions._fanin: the gradients that meet at a LayerNorm's output (its consumers' grad_inputs, each through
                           the consumer's backward quantizer, and the residual path's) added by one launch in the engine's order instead of
                           one fake-quantizer launch and one add per arrival
-      QT_TRAIN_EMBEDDING  qt_embedding_backward_bf16 instead of torch's embedding_dense_backward for the three embedding tables"""
+      QT_TRAIN_EMBEDDING  qt_embedding_backward_bf16 instead of torch's embedding_dense_backward for the three embedding tables
+      QT_TRAIN_ADDLN      the residual add in front of a LayerNorm formed by the LayerNorm launch (the residual module is still called, its
+                          result's values left to that launch)"""
     import copy
     from transformers import RobertaConfig, RobertaForSequenceClassification
     from quantized_training import train_fusions
@@ -1198,7 +1200,7 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
         params = {n: p.detach().clone() for n, p in m.named_parameters()}
         T = train_fusions.STATS
-        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses), (STATS.elements, STATS.calls)
+        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses, T.addlns), (STATS.elements, STATS.calls)
     det = torch.are_deterministic_algorithms_enabled()
     torch.use_deterministic_algorithms(True, warn_only=True)
     try:
@@ -1214,8 +1216,11 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         # steps 2 and 3; per step: the embedding norm and the first layer's output norm (each feeds a query / key / value group: 3
         # deferred calls) and the two attention-output norms (the FFN's first dense layer: 1)
         assert fused[3][:2] == (2 * 4, 2 * 8) and fused[3][3] == 0, (fused[3], train_fusions.STATS.missed)
-    else:
+    elif switch == "QT_TRAIN_EMBEDDING":
         assert plain[3][2] == 0 and fused[3][2] == 3 * 3 and fused[3][3] == 0, (plain[3], fused[3])      # three tables, three steps
+    else:
+        # steps 2 and 3: every output block whose LayerNorm has a consuming Linear behind it (all but the last layer's output block)
+        assert plain[3][4] == 0 and fused[3][4] == 2 * 3 and fused[3][3] == 0, (plain[3], fused[3])
     assert fused[4] == plain[4]
     assert fused[0] == plain[0], (plain[0], fused[0])
     bad = [k for k in plain[1] if not (torch.equal(plain[1][k][0], fused[1][k][0]) and torch.equal(plain[1][k][1], fused[1][k][1]))]

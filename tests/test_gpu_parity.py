@@ -2021,7 +2021,26 @@ def test_layernorm_train_kernels_against_torch_and_the_single_passes(nv, rows, c
     rstd = torch.empty(rows, dtype=torch.float32, device="cuda")
     stages, fmt, lut, outs, check = _chain_setup(nv, "int8", (0.031, 0.029, 0.04), x, (-1, -1, -1))
     nv.check(L.qt_layernorm_train_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, stages, 3,
-                                       ctypes.byref(fmt), lut.data_ptr(), stream()), "qt_layernorm_train_bf16")
+                                       ctypes.byref(fmt), lut.data_ptr(), None, None, stream()), "qt_layernorm_train_bf16")
+    # the residual add in the same launch: x = h + r formed on the way equals the launch on torch's sum bit for bit (y, statistics, stages,
+    # amax), and the sum it leaves is torch's
+    h = (torch.randn(rows, cols, device="cuda") * 1.5).bfloat16()
+    r_ = (x.float() - h.float()).bfloat16()
+    xs = h + r_
+    res_a = []
+    for fusedadd in (False, True):
+        st2, fmt2, lut2, outs2, _ = _chain_setup(nv, "int8", (0.031, 0.029, 0.04), x, (-1, -1, -1))
+        y2, m2, r2, s2 = torch.empty_like(x), torch.empty_like(mean), torch.empty_like(rstd), torch.full_like(x, float("nan"))
+        am2 = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(3)]
+        for i in range(3):
+            st2[i].amax_bits_dev = am2[i].data_ptr()
+        nv.check(L.qt_layernorm_train_bf16((h if fusedadd else xs).data_ptr(), w.data_ptr(), b.data_ptr(), y2.data_ptr(), m2.data_ptr(), r2.data_ptr(), rows, cols,
+                                           1e-5, st2, 3, ctypes.byref(fmt2), lut2.data_ptr(), r_.data_ptr() if fusedadd else None,
+                                           s2.data_ptr() if fusedadd else None, stream()), "qt_layernorm_train_bf16")
+        res_a.append([t.clone() for t in (y2, m2, r2, *outs2, *am2)] + ([s2.clone()] if fusedadd else []))
+    for a_, b_ in zip(res_a[0], res_a[1]):
+        assert torch.equal(a_.view(torch.int16 if a_.dtype == torch.bfloat16 else torch.int32), b_.view(torch.int16 if b_.dtype == torch.bfloat16 else torch.int32))
+    assert torch.equal(res_a[1][-1].view(torch.int16), xs.view(torch.int16))
     ref = torch.nn.functional.layer_norm(x, (cols,), w, b, 1e-5)
     big = ref.float().abs() >= 2.0 ** -4                        # (outputs near zero come from a cancellation: compare those absolutely)
     assert _ulp_close(torch.where(big, y, ref), ref, 5e-3)
