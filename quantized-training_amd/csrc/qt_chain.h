@@ -77,11 +77,40 @@ struct ChainStageDev {
     int src;                  // -1: x; else the stage whose result this one reads
 };
 
+// One vector through one stage: amax of the input, the quotient x / s (fast form; a vector with an element the fast form cannot decide
+// takes the IEEE division for all eight -- the same values fq_vec's redo computes), the format's rounding ONCE, the product with s.
+// Written out here instead of through fq_vec: that instantiates the rounding code per division variant and again for its redo path --
+// three to four copies per call site, and these kernels have up to seven call sites and run once through their code per launch.
 template <int KIND>
 __device__ __forceinline__ uint4 chain_apply(uint4 v, float s, const UniformDiv &dv, const Rounder<KIND> &rnd, uint32_t &amax) {
-    if (s == 1.0f) return fq_vec<kIoBf16, KIND, kDivUnit, true>(v, dv, rnd, amax);
-    if (dv.safe) return fq_vec<kIoBf16, KIND, kDivFast, true>(v, dv, rnd, amax);
-    return fq_vec<kIoBf16, KIND, kDivExact, true>(v, dv, rnd, amax);
+    (void)s;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t q[4], r[4];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = w[i] << 16, hi = w[i] & 0xFFFF0000u;
+        const uint32_t a0 = lo & 0x7FFFFFFFu, a1 = hi & 0x7FFFFFFFu;
+        amax = amax > a0 ? amax : a0;                              // integer order == float order on |x|; NaN patterns win -> propagate
+        amax = amax > a1 ? amax : a1;
+        q[i] = pack_bf16x2(dv.fast16(qt_u2f(lo), bad), dv.fast16(qt_u2f(hi), bad));
+    }
+    if (__builtin_expect(bad || !dv.safe, 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = pack_bf16x2(dv.exact(qt_u2f(w[i] << 16)), dv.exact(qt_u2f(w[i] & 0xFFFF0000u)));
+    }
+    if constexpr (KIND == kFmtRows) {
+        fq_rows_words<4, false>(q, r, rnd);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r0 = rnd(q[i] << 16), r1 = rnd(q[i] & 0xFFFF0000u);       // (images on the format's grid: exact in bf16)
+            r[i] = (r0 >> 16) | (r1 & 0xFFFF0000u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(bf_lo(r[i]) * dv.s, bf_hi(r[i]) * dv.s);
+    return uint4{r[0], r[1], r[2], r[3]};
 }
 
 // A table format's row words (4 - 8 KiB behind the map's 65 536 entries) into LDS: a chain applies several fake-quantizers per vector, and
