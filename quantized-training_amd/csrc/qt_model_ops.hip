@@ -36,7 +36,10 @@ struct NormExtra {
     int e5m2[2];
 };
 
-template <int FQ, bool ADD = false, int EXTRA = 0>
+// NV: 16-byte vectors per thread the loops are unrolled for (2, 4 or 8, picked by the row length: the headline's 4096-element rows
+// need 2 -- unrolled for 8 the kernel was 35 KB of code, most of it jumped over, fetched with a cold instruction cache on every one of
+// its 63 launches per window)
+template <int FQ, bool ADD = false, int EXTRA = 0, int NV = kNormMaxVec>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ w,
                                                                uint4 *__restrict__ y, int nvec, float inv_cols, float eps,
                                                                uint2 *__restrict__ y8, qt_format fmt,
@@ -51,10 +54,10 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
     Rounder<kFmtRows> rnd{fmt, FQ == 3 ? map + QT_MAP_ENTRIES : nullptr, map};
     const size_t row = blockIdx.x;
     const uint4 *xr = x + row * (size_t)nvec;
-    uint4 v[kNormMaxVec];
+    uint4 v[NV];
     float ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < kNormMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = threadIdx.x + i * kNormThreads;
         if (c < nvec) {
             v[i] = xr[c];
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
     for (int i = 0; i < kNormThreads / 64; ++i) tot += s_part[i];
     const float r = rsqrtf(tot * inv_cols + eps);
 #pragma unroll
-    for (int i = 0; i < kNormMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = threadIdx.x + i * kNormThreads;
         if (c < nvec) {
             const uint4 ww = w[c];
@@ -118,6 +121,13 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4 *__re
             if ((FQ != 1 && FQ != 2) || y) y[row * (size_t)nvec + c] = uint4{o[0], o[1], o[2], o[3]};      // NULL with FP8 codes: codes only
         }
     }
+}
+
+template <int FQ, bool ADD, int EXTRA, typename... A>
+void launch_rms(unsigned rows, int nvec, hipStream_t st, A... args) {
+    if (nvec <= 2 * kNormThreads) rmsnorm_kernel<FQ, ADD, EXTRA, 2><<<rows, kNormThreads, 0, st>>>(args...);
+    else if (nvec <= 4 * kNormThreads) rmsnorm_kernel<FQ, ADD, EXTRA, 4><<<rows, kNormThreads, 0, st>>>(args...);
+    else rmsnorm_kernel<FQ, ADD, EXTRA, 8><<<rows, kNormThreads, 0, st>>>(args...);
 }
 
 // gate / up rows may be column slices of one wider GEMM output: row r of an operand starts at r * rs vectors (rs = cv,
@@ -438,7 +448,8 @@ struct LnArgs {
 };
 
 // G threads per row (64: one wavefront, rows up to 1024 elements keep <= 2 vectors per lane; 256: the whole workgroup)
-template <int G, int FQ, bool ADD>
+// NV: vectors per lane the loops are unrolled for (as rmsnorm_kernel's)
+template <int G, int FQ, bool ADD, int NV = kNormMaxVec>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     constexpr int RPB = 256 / G;
     __shared__ float s_part[2][4];
@@ -446,10 +457,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const long row = (long)blockIdx.x * RPB + sub;
     if (G == 64 && row >= a.rows) return;                    // whole wavefronts leave; no workgroup barrier on this path
     const size_t base = (size_t)row * (size_t)a.nvec;
-    uint4 v[kNormMaxVec];
+    uint4 v[NV];
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < kNormMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * G;
         if (c < a.nvec) {
             v[i] = a.x[base + c];
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const float mean = reduce(sum, 0) * a.inv_cols;
     float sq = 0.0f;
 #pragma unroll
-    for (int i = 0; i < kNormMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * G;
         if (c < a.nvec) {
             const uint32_t q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     }
     const float rstd = rsqrtf(reduce(sq, 1) * a.inv_cols + a.eps);
 #pragma unroll
-    for (int i = 0; i < kNormMaxVec; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * G;
         if (c < a.nvec) {
             const uint4 ww = a.w[c], bb = a.b[c];
@@ -538,11 +549,18 @@ int fp8_code_of(const qt_format *f) {                       // 1 E4M3, 2 E5M2, 0
     return 0;
 }
 
+template <int G, bool ADD, int NV>
+void launch_layernorm_nv(const LnArgs &a, int fq, unsigned blocks, hipStream_t st) {
+    if (fq == 2) layernorm_kernel<G, 2, ADD, NV><<<blocks, 256, 0, st>>>(a);
+    else if (fq == 1) layernorm_kernel<G, 1, ADD, NV><<<blocks, 256, 0, st>>>(a);
+    else layernorm_kernel<G, 0, ADD, NV><<<blocks, 256, 0, st>>>(a);
+}
+
 template <int G, bool ADD>
 void launch_layernorm(const LnArgs &a, int fq, unsigned blocks, hipStream_t st) {
-    if (fq == 2) layernorm_kernel<G, 2, ADD><<<blocks, 256, 0, st>>>(a);
-    else if (fq == 1) layernorm_kernel<G, 1, ADD><<<blocks, 256, 0, st>>>(a);
-    else layernorm_kernel<G, 0, ADD><<<blocks, 256, 0, st>>>(a);
+    if (a.nvec <= 2 * G) launch_layernorm_nv<G, ADD, 2>(a, fq, blocks, st);
+    else if (a.nvec <= 4 * G) launch_layernorm_nv<G, ADD, 4>(a, fq, blocks, st);
+    else launch_layernorm_nv<G, ADD, 8>(a, fq, blocks, st);
 }
 
 int launch_status() {
@@ -553,7 +571,7 @@ int launch_status() {
 template <int FQ, bool ADD, int EXTRA>
 void launch_norm_consumers(const uint16_t *x, const uint16_t *residual, const uint16_t *weight, uint16_t *sum, uint16_t *y, uint8_t *y8,
                                   long rows, int nvec, float inv, float eps, const qt_format &f, const NormExtra &ex, hipStream_t st) {
-    rmsnorm_kernel<FQ, ADD, EXTRA><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps,
+    launch_rms<FQ, ADD, EXTRA>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps,
                                                                            (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, ex);
 }
 
@@ -700,7 +718,7 @@ int qt_rmsnorm_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, long
     if (!x || !weight || !y || rows < 0 || cols < 0) return QT_ERR_BAD_ARG;
     if (cols % 8 || cols > (long)kNormThreads * kNormMaxVec * 8 || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15u))
         return QT_ERR_UNALIGNED;
-    rmsnorm_kernel<0><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+    launch_rms<0, false, 0>((unsigned)rows, (int)(cols / 8), (hipStream_t)stream, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
                                                                                 (int)(cols / 8), 1.0f / (float)cols, eps, nullptr,
                                                                                 qt_format{});
     return launch_status();
@@ -717,10 +735,10 @@ int qt_rmsnorm_fq8_bf16(const uint16_t *x, const uint16_t *weight, uint16_t *y, 
         ((uintptr_t)y8 & 7u))
         return QT_ERR_UNALIGNED;
     if (e5m2)
-        rmsnorm_kernel<2><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+        launch_rms<2, false, 0>((unsigned)rows, (int)(cols / 8), (hipStream_t)stream, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
                                                                                     (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
     else
-        rmsnorm_kernel<1><<<(unsigned)rows, kNormThreads, 0, (hipStream_t)stream>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
+        launch_rms<1, false, 0>((unsigned)rows, (int)(cols / 8), (hipStream_t)stream, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y,
                                                                                     (int)(cols / 8), 1.0f / (float)cols, eps, (uint2 *)y8, *fmt);
     return launch_status();
 }
@@ -738,9 +756,9 @@ int qt_add_rmsnorm_bf16(const uint16_t *x, const uint16_t *residual, const uint1
     const int nvec = (int)(cols / 8);
     const float inv = 1.0f / (float)cols;
     const qt_format f = fq ? *fmt : qt_format{};
-    if (fq == 2) rmsnorm_kernel<2, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
-    else if (fq == 1) rmsnorm_kernel<1, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
-    else rmsnorm_kernel<0, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum);
+    if (fq == 2) launch_rms<2, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
+    else if (fq == 1) launch_rms<1, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum);
+    else launch_rms<0, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum);
     return launch_status();
 }
 
@@ -758,9 +776,9 @@ int qt_add_rmsnorm_sumfq_bf16(const uint16_t *x, const uint16_t *residual, const
     const int nvec = (int)(cols / 8);
     const float inv = 1.0f / (float)cols;
     const qt_format f = fq ? *fmt : qt_format{};
-    if (fq == 2) rmsnorm_kernel<2, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
-    else if (fq == 1) rmsnorm_kernel<1, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
-    else rmsnorm_kernel<0, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    if (fq == 2) launch_rms<2, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    else if (fq == 1) launch_rms<1, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, (uint2 *)y8, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
+    else launch_rms<0, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, f, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, sfq, *sum_fmt);
     return launch_status();
 }
 
@@ -1004,8 +1022,8 @@ int qt_rmsnorm_map_bf16(const uint16_t *x, const uint16_t *residual, const uint1
     hipStream_t st = (hipStream_t)stream;
     const int nvec = (int)(cols / 8);
     const float inv = 1.0f / (float)cols;
-    if (residual) rmsnorm_kernel<3, true><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, quantize_sum ? 3 : 0, qt_format{}, map);
-    else rmsnorm_kernel<3, false><<<(unsigned)rows, kNormThreads, 0, st>>>((const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, nullptr, nullptr, NormExtra{}, 0, qt_format{}, map);
+    if (residual) launch_rms<3, true, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, (const uint4 *)residual, (uint4 *)sum, NormExtra{}, quantize_sum ? 3 : 0, qt_format{}, map);
+    else launch_rms<3, false, 0>((unsigned)rows, nvec, st, (const uint4 *)x, (const uint4 *)weight, (uint4 *)y, nvec, inv, eps, nullptr, *fmt, nullptr, nullptr, NormExtra{}, 0, qt_format{}, map);
     return launch_status();
 }
 
