@@ -262,6 +262,10 @@ struct RopeFqArgs {
 // (scalar) and one 32-bit division per vector (64-bit index arithmetic per vector cost more than the rotation itself).
 // A token with fewer than 256 vectors (BERT-base: 96) would leave most of the workgroup idle: a workgroup then takes `tpb` consecutive
 // tokens and spreads their vectors over its threads (two more 32-bit divisions per vector).
+// CODES: the launch's one mode is "FP8 codes by the hardware conversion, no inner quantizer, no table" (the headline's): the other modes'
+// code is not even in the kernel then -- it is all jumped over at run time anyway, but a launch walks its code once with a cold
+// instruction cache, and every jump over a few KB is another miss (the norm kernels' lesson)
+template <bool CODES = false>
 __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, uint32_t tpb, size_t tokens) {
     const uint32_t dv = (uint32_t)a.r.D / 8, half = dv / 2, nv = (uint32_t)a.r.H * dv;
     const uint32_t S = (uint32_t)a.r.S;
@@ -286,7 +290,7 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a0 = rbf(bf_lo(X[j]) * bf_lo(C[j])), a1 = rbf(bf_hi(X[j]) * bf_hi(C[j]));
-                if (a.inner) {
+                if (!CODES && a.inner) {
                     if (a.map) {                                         // table format: the same map as the result's (host-checked)
                         const Rounder<kFmtRows> rin{a.fmt, a.rows_lds, a.map};
                         a0 = qt_u2f(rin(qt_f2u(a0)));
@@ -301,7 +305,7 @@ __device__ __forceinline__ void rope_fq_token(const RopeFqArgs &a, size_t bs0, u
             }
         }
         const size_t o = (((size_t)b * (size_t)a.r.H + h) * (size_t)a.r.S + s) * dv + d8;     // [B][H][S][D] order
-        if (a.y8) {                                          // exact E4M3 / E5M2 (checked on the host): hardware conversion
+        if (CODES || a.y8) {                                 // exact E4M3 / E5M2 (checked on the host): hardware conversion
             const uint2 codes = a.e5m2 ? fq8_hw_vec8<true>(out, a.fmt) : fq8_hw_vec8<false>(out, a.fmt);
             *(uint2 *)(a.y8 + o * 8) = codes;
         } else if (a.map) {                                  // table format, row form
@@ -347,14 +351,14 @@ struct ValueArgs {
     qt_format fmt;
 };
 
-template <bool VE5M2, int VD>
+template <bool VE5M2, int VD, bool CODES = false>
 __global__ __launch_bounds__(256) void rope_fq_value_kernel(RopeFqArgs q, RopeFqArgs k, ValueArgs v, unsigned rope_blocks, unsigned tpb) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[VD * 128];
     if (blockIdx.x < rope_blocks) {
         const size_t tokens = (size_t)q.r.B * (size_t)q.r.S;
         for (size_t bs = (size_t)blockIdx.x * tpb; bs < tokens; bs += (size_t)rope_blocks * tpb) {
-            rope_fq_token(q, bs, tpb, tokens);
-            rope_fq_token(k, bs, tpb, tokens);
+            rope_fq_token<CODES>(q, bs, tpb, tokens);
+            rope_fq_token<CODES>(k, bs, tpb, tokens);
         }
     } else {
         const unsigned vb = blockIdx.x - rope_blocks;
@@ -984,10 +988,14 @@ static int rope_fq_launch(const uint16_t *q, const uint16_t *k, const uint16_t *
     const unsigned total = (unsigned)blocks + (unsigned)(B * Hk * (S / 128));
     const bool ve5 = is_e5m2(fmt_v);
     if (D == 128) {
-        if (ve5) rope_fq_value_kernel<true, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        const bool codes = aq.y8 && ak.y8 && !aq.inner && !ak.inner && !aq.map && !ak.map;       // (one mode for the whole launch)
+        if (codes && !ve5) rope_fq_value_kernel<false, 128, true><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        else if (ve5) rope_fq_value_kernel<true, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
         else rope_fq_value_kernel<false, 128><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
     } else {
-        if (ve5) rope_fq_value_kernel<true, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        const bool codes = aq.y8 && ak.y8 && !aq.inner && !ak.inner && !aq.map && !ak.map;
+        if (codes && !ve5) rope_fq_value_kernel<false, 64, true><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
+        else if (ve5) rope_fq_value_kernel<true, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
         else rope_fq_value_kernel<false, 64><<<total, 256, 0, st>>>(aq, ak, av, (unsigned)blocks, tpb);
     }
     return launch_status();
