@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define QT_ABI_VERSION 1
+/* 2 (round 6): qt_fp8_gemm's last argument is the heuristic suggestion index (`algo`), no longer a 0 / 1 `tune` flag; the training
+ * entry points (qt_attention_train_*, qt_grad_fanin_bf16, qt_embedding_backward_bf16, qt_fake_quant_chain_bf16) exist.  A caller built
+ * against 1 must not bind this library, and the package refuses a library that reports anything else. */
+#define QT_ABI_VERSION 2
 #define QT_MAP_ENTRIES 65536
 
 typedef enum qt_status {
@@ -411,6 +414,13 @@ size_t qt_attention_train_backward_ws_bytes(int heads);
 int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
                        const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream);
 
+/* Host-only query: how qt_linear_fq8_bf16 (pair 0, n_total = sum n) or qt_mlp_fq8_bf16 (pair 1, n_total = N: the gate / up pairs)
+ * cuts a problem on the current device -- tiles_m x tiles_n workgroups of 256 rows x groups_lo..groups_hi 16-column groups (gate and
+ * up groups both counted in pair mode) -- and which kernel variant runs it: 0 = two k tiles per step (narrow tiles), 2 / 4 = one
+ * k tile per step with that many weight pieces per wave, 6 = six pieces with two register sets each (the widest tiles).  The parity
+ * tests enumerate it over the package's route tables so that every (variant, tile width) a default route can reach is covered. */
+int qt_linear_fq8_plan(int M, long n_total, int K, int pair, int *tiles_m, int *tiles_n, int *groups_lo, int *groups_hi, int *variant);
+
 /* ---- The gated MLP front half as ONE launch (LLaMA: modeling_llama.LlamaMLP.forward, act_fn(gate_proj(x)) * up_proj(x), whose
  * result is the down projection's fake-quantized input): both fake-quant Linears of A9 (modules/qat/linear.py:40-41, stateless
  * E4M3 / E5M2 weight specs) on the same FP8-coded activation, then, per output element, in the module chain's arithmetic:
@@ -770,6 +780,11 @@ int qt_fp8_gemm(const uint8_t *a8_dev, int a_format, const uint8_t *b8_dev, int 
 int qt_fp8_gemm_tune(const uint8_t *a8_dev, int a_format, const uint8_t *b8_dev, int b_format, int b_is_kn, void *c_bf16_dev,
                      const void *bias_bf16_dev, long batch, int M, int N, int K, long a_batch_stride, long b_batch_stride,
                      long c_batch_stride, void *workspace_dev, size_t workspace_bytes, int *best, float *us, int max_us, void *stream);
+
+/* hipblasLtGetVersion of the library qt_fp8_gemm resolved in this process (0: none, or it does not say).  The position of a kernel in
+ * the library's suggestion list belongs to ONE build of the library: the package's committed algorithm table names the version it was
+ * measured on and passes algo 0 (the library's first suggestion) under any other. */
+int qt_fp8_gemm_library_version(void);
 
 /* Bench helper: times `iters` back-to-back launches of the fused per-tensor pass with HIP events
  * on `stream` and returns the mean milliseconds per launch in *ms_out (bench.py roofline leg).

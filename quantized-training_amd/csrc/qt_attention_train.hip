@@ -611,11 +611,11 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
     const float tsc = t == 0 ? gsc[0] : (t == 1 ? gsc[1] : gsc[2]);
     int E = 0;
     (void)frexpf(a.colsum_max * tsc, &E);
+    const FxPlan fxp = fx_plan((long)a.B * S, a.B);           // one arrival per batch element, S rows each
     if (sums && t < 3 && cs) {
         float part = 0.0f;
         for (int r = 0; r < 64; ++r) part += s_col[(t * 64 + r) * 65 + cc];
-        const bool finite = part == part && fabsf(part) < 3.0e38f;
-        const long long fx = finite ? (long long)rintf(ldexpf(part, 42 - E)) : (1ll << 62);
+        const long long fx = fx_encode(part, E, fxp);          // NaN / Inf: the poison term (qt_chain.h)
         (void)__hip_atomic_fetch_add(a.acc + ((long)t * a.H + h) * 64 + cc, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (t == 3 && cc < 5) {
@@ -639,9 +639,7 @@ __global__ __launch_bounds__(kThreads) void attn_train_bwd_kernel(AttnTrainBwdAr
         if (t < 3 && cs && s_old[t] == (unsigned)a.B - 1u) {   // the batch's last arrival for this (tensor, head): read, re-zero, round
             if (cc == 0) __hip_atomic_store(a.ticket + t * a.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long long fx = __hip_atomic_exchange(a.acc + ((long)t * a.H + h) * 64 + cc, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float sum = ldexpf((float)fx, E - 42);
-            if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
-            cs[h * 64 + cc] = bf16_bits(sum);
+            cs[h * 64 + cc] = bf16_bits(fx_decode(fx, E, fxp));
         }
     }
     // ---- everything leaves (the gradient tiles are still in LDS: Gs, Vs, Ds are not touched by the column sums)

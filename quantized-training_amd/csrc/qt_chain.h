@@ -8,6 +8,32 @@ namespace {
 constexpr int kIoBf16 = 0;
 constexpr int kIoF32 = 1;
 
+// ---- cross-workgroup column sums in 64-bit fixed point (bias gradients: the chain kernel's bands, the attention backward's batch) -----
+// `arrivals` workgroups each add one partial sum per column to a zeroed accumulator; the one that draws the last ticket reads it.
+// One unit = 2^(E - shift), E = exponent of the largest value an element can take.  A partial sum that is NaN / Inf adds `poison`
+// = 2^p instead, p = 62 - ceil(log2 arrivals): at most `arrivals` of them cannot wrap (sum < 2^63).  shift = min(42, p - 2 -
+// ceil(log2 rows)) keeps the sum of ALL finite terms (|.| <= rows 2^shift) at or below 2^(p-2), so a total >= 2^(p-1) says "some
+// partial was not finite" whatever else was added, and a clean total can never reach it.  (Round 5 added 2^62 per flagged partial:
+// 4, 8, 16 or 32 of them wrapped to exactly zero and a fully-NaN gradient came out as a finite bias gradient.)
+struct FxPlan {
+    int shift;
+    long long poison;
+};
+__device__ __forceinline__ FxPlan fx_plan(long rows, int arrivals) {
+    const int lr = rows > 1 ? 64 - __clzll((unsigned long long)(rows - 1)) : 0;
+    const int lk = arrivals > 1 ? 32 - __clz((unsigned)(arrivals - 1)) : 0;
+    const int p = 62 - lk;
+    const int sh = p - 2 - lr;
+    return FxPlan{sh < 42 ? sh : 42, 1ll << p};
+}
+__device__ __forceinline__ long long fx_encode(float part, int E, const FxPlan &f) {
+    const bool finite = part == part && fabsf(part) < 3.0e38f;
+    return finite ? (long long)rintf(ldexpf(part, f.shift - E)) : f.poison;
+}
+__device__ __forceinline__ float fx_decode(long long fx, int E, const FxPlan &f) {
+    return fx >= (f.poison >> 1) ? qt_u2f(0x7FC00000u) : ldexpf((float)fx, E - f.shift);
+}
+
 #ifndef QT_BF_LO_HI
 #define QT_BF_LO_HI
 __device__ __forceinline__ float bf_lo(uint32_t w) { return qt_u2f(w << 16); }          // the two bf16 halves of a packed word

@@ -3,23 +3,31 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Only gfx942 / gfx950 implement what these kernels rely on (cache-policy bits of the split-K hand-off, the scaled matrix instructions,
-// LDS-DMA widths); ARCH is a Makefile variable, so say so at compile time.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "libqt_hip is written for gfx950 (MI355X); gfx942 is the only other target its inline assembly is valid for"
+// Written for gfx950 only: the scaled matrix instructions (v_mfma_scale_f32_16x16x128_f8f6f4), v_mfma_f32_16x16x32_bf16, the
+// v_cvt_scalef32_pk_* conversions, 16-byte LDS-DMA and the 160 KiB LDS budgets do not exist on any other target.  ARCH is a Makefile
+// variable, so say so at compile time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libqt_hip is written for gfx950 (MI355X) only"
 #endif
 
 // hipFuncSetAttribute is per DEVICE, a `static bool` is per process: the package runs models on several devices of one process
-// (_native.note_device), and the second device would never get the large-LDS attribute.  One bit per device ordinal.
+// (_native.note_device), and the second device would never get the large-LDS attribute.  One bit per device ordinal.  The ordinal
+// needed() looked up travels to done() in a thread_local: the object itself is a function-local static shared by every host thread
+// (ctypes releases the GIL), and a member would let thread B's device overwrite thread A's between its needed() and done().
 struct QtOncePerDevice {
     unsigned long long bits = 0;
-    int dev = 0;
+    static int &current() {
+        static thread_local int dev = 0;
+        return dev;
+    }
     bool needed() {
+        int &dev = current();
         dev = 0;
         (void)hipGetDevice(&dev);
         return dev < 0 || dev > 63 || !((__atomic_load_n(&bits, __ATOMIC_ACQUIRE) >> dev) & 1ull);
     }
     void done() {
+        const int dev = current();
         if (dev >= 0 && dev <= 63) __atomic_fetch_or(&bits, 1ull << dev, __ATOMIC_RELEASE);
     }
 };

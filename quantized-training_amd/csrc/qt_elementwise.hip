@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     // by agent-scope atomic adds -- integer addition is associative, so the result does not depend on the arrival order, and atomics are
     // coherent across the XCDs' L2s without the release fence a plain hand-off would need (on this part that fence writes back the whole
     // L2: + 30 us behind 12 MB of results, measured).  The band that draws the strip's last ticket reads the sums (atomically), rounds
-    // them to bf16 and leaves the accumulators zero.  Fixed point: one unit = 2^(E - 42), E = exponent of the largest value the stage
+    // them to bf16 and leaves the accumulators zero.  Fixed point (fx_plan, qt_chain.h): one unit = 2^(E - 42) up to 8192 rows, E = exponent of the largest value the stage
     // can produce (format maximum x scale): a band's fp32 partial sum converts exactly unless it is below 2^-42 of that.
     constexpr int kC = kChainStripV * 8;
     for (int half = kChainRowLanes / 2; half >= 1; half >>= 1) {
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     int E;
     (void)frexpf(a.colsum_max * s_cs, &E);                          // max value < 2^E
     long long *acc = a.acc + (size_t)strip * kC;
+    const FxPlan fxp = fx_plan(a.rows, a.bands);
     if (a.bands == 1) {
         const int c = strip * kC + t;
         if (t < kC && c < a.cv * 8) a.colsum_out[c] = (uint16_t)(pack_bf16x2(s_col[0][t], 0.0f) & 0xFFFFu);
@@ -388,9 +389,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     }
     if (t < kC) {
         const float part = s_col[0][t];
-        long long fx = (part == part && fabsf(part) < 3.0e38f) ? (long long)rintf(ldexpf(part, 42 - E)) : 0ll;
-        // a NaN / Inf in a column is recorded in the accumulator's top bits (bit 62 set survives any sum of 2^53-sized terms)
-        if (!(part == part && fabsf(part) < 3.0e38f)) fx = 1ll << 62;
+        const long long fx = fx_encode(part, E, fxp);                // NaN / Inf: the poison term (qt_chain.h)
         (void)__hip_atomic_fetch_add(acc + t, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // returning form: performed when it returns
     }
     __syncthreads();
@@ -402,8 +401,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     if (t < kC) {
         const int c = strip * kC + t;
         const long long fx = __hip_atomic_exchange(acc + t, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read and re-zero
-        float sum = ldexpf((float)fx, E - 42);
-        if (fx >= (1ll << 61) || fx <= -(1ll << 61)) sum = qt_u2f(0x7FC00000u);
+        const float sum = fx_decode(fx, E, fxp);
         if (c < a.cv * 8) a.colsum_out[c] = (uint16_t)(pack_bf16x2(sum, 0.0f) & 0xFFFFu);
     }
 }

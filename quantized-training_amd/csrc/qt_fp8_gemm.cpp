@@ -34,6 +34,7 @@ struct Api {
     decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
     decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
     decltype(&hipblasLtMatmul) Matmul = nullptr;
+    decltype(&hipblasLtGetVersion) GetVersion = nullptr;      // optional
     bool ok = false;
 };
 
@@ -56,6 +57,7 @@ Api &api() {
         QT_SYM(Heuristic, "hipblasLtMatmulAlgoGetHeuristic")
         QT_SYM(Matmul, "hipblasLtMatmul")
 #undef QT_SYM
+        a.GetVersion = (decltype(a.GetVersion))dlsym(h, "hipblasLtGetVersion");
         a.ok = true;
     });
     return a;
@@ -200,4 +202,16 @@ extern "C" int qt_fp8_gemm_tune(const uint8_t *a8, int a_format, const uint8_t *
     if (cs != hipStreamCaptureStatusNone) return QT_ERR_BAD_ARG;
     return fp8_gemm(a8, a_format, b8, b_format, b_is_kn, c_bf16, bias_bf16, batch, M, N, K, a_batch_stride, b_batch_stride, c_batch_stride,
                     workspace, workspace_bytes, 0, best, us, max_us, stream);
+}
+
+extern "C" int qt_fp8_gemm_library_version(void) {
+    Api &L = api();
+    if (!L.ok || !L.GetVersion) return 0;
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipblasLtHandle_t &h = g_handles[dev];
+    if (!h && L.Create(&h) != HIPBLAS_STATUS_SUCCESS) return 0;
+    int v = 0;
+    return L.GetVersion(h, &v) == HIPBLAS_STATUS_SUCCESS ? v : 0;
 }

@@ -76,6 +76,9 @@ struct Args {
     int pair;
     uint8_t *y8;
     qt_format out_fmt;        // the output fake-quantizer (E4M3 / E5M2 closed form, unit scale)
+#ifdef QT_TUNING_BUILD
+    unsigned long long *stamps;   // tools/ only (QT_FQ8_STAMPS = device address): per workgroup {cycles, 100 MHz ticks} around the tile
+#endif
 };
 
 // Column tile tn of tiles_n: first unit (16-column group, or gate / up pair) and unit count.  The gextra tiles that are one unit wider
@@ -990,6 +993,21 @@ struct LinearFq8R2 {
     }
 };
 
+// tools/ only: the clock the chip holds inside a tile = cycles (s_memtime) per 100 MHz tick (s_memrealtime), per workgroup
+#ifdef QT_TUNING_BUILD
+#define QT_FQ8_STAMP_BEGIN                                                              \
+    unsigned long long qt_c0 = 0, qt_r0 = 0;                                            \
+    if (a.stamps) { qt_c0 = __builtin_amdgcn_s_memtime(); qt_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define QT_FQ8_STAMP_END                                                                \
+    if (a.stamps && t == 0) {                                                           \
+        a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - qt_c0;                \
+        a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - qt_r0;        \
+    }
+#else
+#define QT_FQ8_STAMP_BEGIN
+#define QT_FQ8_STAMP_END
+#endif
+
 template <int FX, int FW, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_r2[];
@@ -1008,6 +1026,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
     using L = LinearFq8R2<FX, FW, ABL>;
+    QT_FQ8_STAMP_BEGIN
     bool redo;
     switch (ntw) {                                          // wave-uniform
         case 0: redo = L::template run<0>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
@@ -1015,6 +1034,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r2_kernel(Args a) {
         default: redo = L::template run<2>(a, lds_r2, m0, tg0, nt, jbase, w, l); break;
     }
     if (redo) slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
+    QT_FQ8_STAMP_END
 }
 
 template <int FX, int FW, int NB, bool PAIR, int ABL = 0>
@@ -1039,6 +1059,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
     const int wn = w >> 2;
     const int ntw = wn == 0 ? nt0 : nt - nt0, jbase = wn == 0 ? 0 : nt0;
     using L = LinearFq8R<FX, FW, NB, PAIR, ABL>;
+    QT_FQ8_STAMP_BEGIN
     bool redo;
     switch (ntw) {                                          // wave-uniform
         case 0: redo = L::template run<0>(a, lds_r, m0, tg0, nt, jbase, w, l); break;
@@ -1053,6 +1074,7 @@ __global__ __launch_bounds__(512, 1) void linear_fq8r_kernel(Args a) {
         if constexpr (PAIR) slow_tile_pair<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
         else slow_tile<FX, FW>(a, m0, tg0, jbase, ntw, w, l);
     }
+    QT_FQ8_STAMP_END
 }
 
 int cu_count() {
@@ -1185,9 +1207,48 @@ int plan_fq8(int M, long groups, Fq8Plan &p) {
     return QT_OK;
 }
 
+// pair mode (qt_mlp_fq8_bf16): column tiles in gate / up pairs, at most six pairs (twelve column groups) each, whole rounds over the
+// CUs; gbase / gextra count PAIRS
+int plan_mlp(int M, long pairs, Fq8Plan &p) {
+    const int cus = cu_count();
+    p.tiles_m = (M + kTM - 1) / kTM;
+    const long tn_min = (pairs + 5) / 6;
+    const long rounds = (p.tiles_m * tn_min + cus - 1) / cus;
+    long tn = rounds * cus / p.tiles_m;
+    if (tn < tn_min) tn = tn_min;
+    if (tn > pairs) tn = pairs;
+    p.tiles_n = (int)tn;
+    p.gbase = (int)(pairs / tn);
+    p.gextra = (int)(pairs % tn);
+    const int worst_nt = 2 * (p.gbase + (p.gextra ? 1 : 0));
+    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
+    p.nb = (worst_nt * 4 + 7) / 8;
+    return QT_OK;
+}
+
+// which kernel launch<>() picks for a plan: 0 = R2 (two k tiles per step), 2 / 4 = R with that many weight pieces per wave,
+// 6 = R with six pieces and two register sets per piece (the widest tiles)
+int variant_of(const Fq8Plan &p, int K, bool pair) {
+    if (!pair && p.nb <= 2 && K % (2 * kBK) == 0) return 0;
+    return p.nb <= 2 ? 2 : (p.nb <= 4 ? 4 : 6);
+}
+
 }  // namespace
 
 extern "C" {
+
+int qt_linear_fq8_plan(int M, long n_total, int K, int pair, int *tiles_m, int *tiles_n, int *groups_lo, int *groups_hi, int *variant) {
+    if (M < 1 || n_total < 16 || n_total % 16 != 0 || K < kBK || K % kBK != 0) return QT_ERR_BAD_ARG;
+    Fq8Plan p;
+    if (const int rc = pair ? plan_mlp(M, n_total / 16, p) : plan_fq8(M, n_total / 16, p)) return rc;
+    const int unit = pair ? 2 : 1;
+    if (tiles_m) *tiles_m = p.tiles_m;
+    if (tiles_n) *tiles_n = p.tiles_n;
+    if (groups_lo) *groups_lo = unit * p.gbase;
+    if (groups_hi) *groups_hi = unit * (p.gbase + (p.gextra ? 1 : 0));
+    if (variant) *variant = variant_of(p, K, pair != 0);
+    return QT_OK;
+}
 
 int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
                        const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream) {
@@ -1214,6 +1275,7 @@ int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *cons
     a.dbg = 0;
 #ifdef QT_TUNING_BUILD
     if (const char *e_dbg = getenv("QT_FQ8_DEBUG")) a.dbg = atoi(e_dbg);
+    if (const char *e_st = getenv("QT_FQ8_STAMPS")) a.stamps = (unsigned long long *)strtoull(e_st, nullptr, 0);
 #endif
     int nseg = 0, g0 = 0;
     for (int i = 0; i < count; ++i) {
@@ -1245,24 +1307,13 @@ int qt_mlp_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *w_gate_
     if ((bias_gate_dev && ((uintptr_t)bias_gate_dev & 7u)) || (bias_up_dev && ((uintptr_t)bias_up_dev & 7u))) return QT_ERR_UNALIGNED;
     Args a{};
     a.x8 = x8_dev; a.y = h_dev; a.y8 = h8_dev; a.M = M; a.K = K; a.ldc = N; a.pair = 1; a.out_fmt = *out_format;
-    a.tiles_m = (M + kTM - 1) / kTM;
-    // column tiles in gate / up pairs: at most six pairs (twelve column groups) each, whole rounds over the CUs
-    const long pairs = N / 16;
-    const int cus = cu_count();
-    const long tn_min = (pairs + 5) / 6;
-    const long rounds = (a.tiles_m * tn_min + cus - 1) / cus;
-    long tn = rounds * cus / a.tiles_m;
-    if (tn < tn_min) tn = tn_min;
-    if (tn > pairs) tn = pairs;
-    a.tiles_n = (int)tn;
-    a.gbase = (int)(pairs / tn);
-    a.gextra = (int)(pairs % tn);
-    const int worst_nt = 2 * (a.gbase + (a.gextra ? 1 : 0));
-    if (worst_nt > kMaxNT) return QT_ERR_BAD_ARG;
-    a.nb = (worst_nt * 4 + 7) / 8;
+    Fq8Plan p;
+    if (const int rc = plan_mlp(M, N / 16, p)) return rc;
+    a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.gbase = p.gbase; a.gextra = p.gextra; a.nb = p.nb;
     a.dbg = 0;
 #ifdef QT_TUNING_BUILD
     if (const char *e_dbg = getenv("QT_FQ8_DEBUG")) a.dbg = atoi(e_dbg);
+    if (const char *e_st = getenv("QT_FQ8_STAMPS")) a.stamps = (unsigned long long *)strtoull(e_st, nullptr, 0);
 #endif
     a.seg[0].w = w_gate_dev; a.seg[0].bias = bias_gate_dev; a.seg[0].g0 = 0;
     a.seg[1].w = w_up_dev; a.seg[1].bias = bias_up_dev; a.seg[1].g0 = 0;

@@ -60,6 +60,8 @@ _FMT = POINTER(QtFormat)
 _OPQ = POINTER(QtOperandQ)
 
 # name -> (restype, argtypes); mirrors include/qt_hip.h one to one
+ABI_VERSION = 2          # include/qt_hip.h QT_ABI_VERSION
+
 SIGNATURES = {
     "qt_abi_version": (c_int, []),
     "qt_status_string": (c_char_p, [c_int]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
+    "qt_linear_fq8_plan": (c_int, [c_int, c_long, c_int, c_int, _P, _P, _P, _P, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "qt_fake_quant_chain_bf16": (c_int, [_P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
     "qt_fake_quant_chain_ws_bytes": (c_size_t, [c_long, c_long]),
@@ -171,6 +174,7 @@ SIGNATURES = {
                                 _FMT, _P, _P, c_long, c_long, c_long, _FMT, _P]),
     "qt_fp8_gemm": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_long, c_int, c_int, c_int, c_long, c_long, c_long, _P,
                            c_size_t, c_int, _P]),
+    "qt_fp8_gemm_library_version": (c_int, []),
     "qt_fp8_gemm_tune": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_long, c_int, c_int, c_int, c_long, c_long, c_long, _P,
                            c_size_t, POINTER(c_int), _P, c_int, _P]),
     "qt_mx_pack": (c_int, [_P, _P, c_int, _P, _P, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_int,
@@ -234,8 +238,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.qt_abi_version() != 1:
-            raise QtError("libqt_hip.so ABI version mismatch")
+        if L.qt_abi_version() != ABI_VERSION:
+            raise QtError(f"{LIB_PATH}: ABI version {L.qt_abi_version()}, this package binds {ABI_VERSION} (include/qt_hip.h QT_ABI_VERSION): "
+                          "rebuild with `make -C quantized-training_amd`")
         _lib = _GuardedLib(L)
     return _lib
 

@@ -515,12 +515,28 @@ _LT_ALGO_TABLE = {
     (192, 384, 384, 64, 0, 0): 12,        # BERT-base Q.K^T chain: 56.3 / 66.6
     (192, 384, 64, 384, 1, 0): 5,         # BERT-base P.V chain: 13.5 / 32.6
 }
+# The positions above are positions in the suggestion list of ONE build of the library (hipblasLtGetVersion; ROCm 7.2.0's hipBLASLt
+# 1.2.1).  Under any other build the same index would silently name another kernel, so the table is ignored there: every shape runs the
+# library's first suggestion and routes_report() says so ("lt:library_version").
+_LT_ALGO_TABLE_LIBRARY = 100201
 LT_ALGOS = {}              # what ran: "bxMxNxK[kn][+bias]" -> index (routes_report)
+_LT_LIBRARY = {"version": None}
+
+
+def lt_table_applies():
+    """True when the resolved hipBLASLt is the build _LT_ALGO_TABLE was measured on (or does not report a version at all)."""
+    if _LT_LIBRARY["version"] is None:
+        _LT_LIBRARY["version"] = int(_native.lib().qt_fp8_gemm_library_version())
+        if _LT_LIBRARY["version"] not in (0, _LT_ALGO_TABLE_LIBRARY):
+            LT_ALGOS["lt:library_version"] = f"{_LT_LIBRARY['version']} != table's {_LT_ALGO_TABLE_LIBRARY}: first suggestion everywhere"
+    return _LT_LIBRARY["version"] in (0, _LT_ALGO_TABLE_LIBRARY)
 
 
 def lt_algo_index(batch, M, N, K, b_is_kn, with_bias):
     forced = os.environ.get("QT_LT_ALGO")                     # tools only: the tuner's A/B runs
     idx = int(forced) if forced is not None else _LT_ALGO_TABLE.get((batch, M, N, K, int(bool(b_is_kn)), int(bool(with_bias))), 0)
+    if forced is None and idx and not lt_table_applies():
+        idx = 0
     LT_ALGOS.setdefault(f"lt:{batch}x{M}x{N}x{K}{'kn' if b_is_kn else ''}{'+bias' if with_bias else ''}", idx)
     return idx
 

@@ -43,6 +43,68 @@ def _enabled():
     return os.environ.get("QT_FUSED_MODEL_OPS", "1") != "0"
 
 
+# ---- the Hugging Face layout the rebound forwards were written against --------------------------------------------------------------
+# The fused forwards below RESTATE pieces of transformers' modules (statement for statement: the image's transformers 5.x) and read
+# their attributes by name.  Another transformers release may rename an attribute or change what a forward does; a restated forward
+# would then compute something else without any error.  So every rebinding is preceded by a layout check -- forward parameter names
+# and the attributes the restated code reads -- and a family whose layout differs keeps Hugging Face's own code, with ONE warning
+# saying what differed (quantization_mappings.py:27-72 upstream pins the same classes by import).
+_LLAMA_LAYOUT = {
+    "LlamaRMSNorm": (["self", "hidden_states"], ("weight", "variance_epsilon")),
+    "LlamaMLP": (["self", "x"], ("gate_proj", "up_proj", "down_proj", "act_fn")),
+    "LlamaRotaryEmbedding": (["self", "x", "position_ids"], ()),
+    "LlamaAttention": (None, ("q_proj", "k_proj", "v_proj", "o_proj", "head_dim")),
+    "LlamaDecoderLayer": (None, ("input_layernorm", "post_attention_layernorm", "self_attn", "mlp")),   # (its forward: _LAYER_PARAMS below)
+}
+_ROPE_PARAMS = ["q", "k", "cos", "sin", "unsqueeze_dim"]
+
+
+def _forward_params(cls):
+    import inspect
+    try:
+        return list(inspect.signature(cls.forward).parameters)
+    except (TypeError, ValueError):
+        return None
+
+
+def llama_layout_problems(model, ml):
+    """What differs between `model`'s LLaMA modules and the layout the restated forwards assume ([] = nothing)."""
+    problems = []
+    for mod in model.modules():
+        for name, (params, attrs) in _LLAMA_LAYOUT.items():
+            cls = getattr(ml, name, None)
+            if cls is None or not isinstance(mod, cls):
+                continue
+            base = cls if not getattr(type(mod), "_qt_twin", False) else type(mod).__mro__[1]
+            have = _forward_params(base)
+            if params is not None and have != params:
+                problems.append(f"{name}.forward takes {have}, the restated one {params}")
+            missing = [a for a in attrs if not hasattr(mod, a)]
+            if missing:
+                problems.append(f"{name} has no attribute {missing}")
+    import inspect
+    rope = getattr(ml, "apply_rotary_pos_emb", None)
+    rope = getattr(rope, "_qt_original", rope)
+    have = list(inspect.signature(rope).parameters) if rope is not None else None
+    if have != _ROPE_PARAMS:
+        problems.append(f"apply_rotary_pos_emb takes {have}, the routed one {_ROPE_PARAMS}")
+    return sorted(set(problems))
+
+
+def bert_layer_layout_problems(layer):
+    """The same for one BERT / RoBERTa-shaped encoder layer (the attributes apply_bert_fusions and the fused forwards read)."""
+    problems = []
+    inter = layer.intermediate
+    if not hasattr(inter, "intermediate_act_fn"):
+        problems.append(f"{type(inter).__name__} has no attribute intermediate_act_fn")
+    have = _forward_params(type(inter))
+    if have != ["self", "hidden_states"]:
+        problems.append(f"{type(inter).__name__}.forward takes {have}, the restated one ['self', 'hidden_states']")
+    if not isinstance(getattr(inter, "dense", None), torch.nn.Module):
+        problems.append(f"{type(inter).__name__}.dense is not a module")
+    return problems
+
+
 def _tracing(t):
     """True while torch.export / make_fx traces the caller (the module-level rotary patch is process-wide, so an export of ANOTHER model
     can pass through it): traced tensors have no storage, and a HIP launch must never end up inside an exported graph unseen."""
@@ -614,6 +676,10 @@ def apply_bert_fusions(model):
                 and hasattr(getattr(att, "output", None), "LayerNorm") and hasattr(getattr(mod, "intermediate", None), "dense")
                 and hasattr(getattr(mod, "output", None), "LayerNorm") and hasattr(mod.output, "dense")):
             layers.append(mod)
+    problems = sorted({p for mod in layers for p in bert_layer_layout_problems(mod)})
+    if problems:
+        _declined("BERT-style launch fusions (LayerNorm / GELU forwards, q / k / v groups)", "; ".join(problems))
+        return 0
     prev_norm = None
     for mod in model.modules():                                   # the embedding LayerNorm feeds the first layer
         if type(mod).__name__.endswith("Embeddings") and isinstance(getattr(mod, "LayerNorm", None), torch.nn.LayerNorm):
@@ -1020,6 +1086,12 @@ def apply_llama_fusions(model):
     try:
         from transformers.models.llama import modeling_llama as ml
     except Exception:  # noqa: BLE001
+        return 0
+    if not any(isinstance(mod, (ml.LlamaRMSNorm, ml.LlamaMLP, ml.LlamaAttention)) for mod in model.modules()):
+        return 0
+    problems = llama_layout_problems(model, ml)
+    if problems:
+        _declined("LLaMA launch fusions (RMSNorm / MLP / rotary forwards, q / k / v groups)", "; ".join(problems))
         return 0
     n = 0
     for mod in model.modules():

@@ -233,6 +233,17 @@ def _swap_forward(module, forward):
     base = type(module)
     if getattr(base, "_qt_twin", False):
         return module
+    # The twin's forward RESTATES the Hugging Face forward it replaces (with the residual add as a hooked module).  If this transformers
+    # release's block takes other arguments, or lacks a sub-module the restated code calls, the restatement is of another block: refuse
+    # loudly instead of computing something else (upstream pins the classes by copying their source, quantization_mappings.py:27-72).
+    import inspect
+    have, want = list(inspect.signature(base.forward).parameters), list(inspect.signature(forward).parameters)
+    missing = [a for a in ("dense", "LayerNorm") if not hasattr(module, a)]
+    if have != want or missing:
+        raise NotImplementedError(
+            f"quantized_training: {base.__module__}.{base.__name__} does not have the layout its quantizable twin restates "
+            f"(forward takes {have}, the twin {want}; missing sub-modules {missing}): this transformers release is not supported for "
+            f"--quantize_forward/--quantize_backprop residual")
     key = (base, forward)
     twin = _TWIN_CACHE.get(key)
     if twin is None:

@@ -20,8 +20,8 @@ PRODUCER kernels (second half of the file) go one step further: LayerNorm, GELU,
 step as autograd Functions on kernels that compute torch's arithmetic with torch's rounding points and evaluate the fake-quantizer
 calls around them in their own launch (_LayerNormTrainFn, _GeluTrainFn, _SoftmaxTrainFn, _AttentionTrainFn); the gradients that meet
 at a LayerNorm's output are summed by that LayerNorm's backward (take_deferred, _fanin); nn.Embedding's weight gradient is torch's
-bit for bit (_EmbeddingTrainFn).  Switches: QT_TRAIN_CHAINS, QT_TRAIN_COLSUM, QT_TRAIN_PRODUCERS, QT_TRAIN_ATTENTION, QT_TRAIN_FANIN,
-QT_TRAIN_EMBEDDING (README)."""
+bit for bit (_EmbeddingTrainFn).  One debug mask, QT_TRAIN_DEBUG (an integer, default 0 = every fusion on; DEBUG_BITS below), switches
+fusions OFF for A/B runs and tests -- rounds 4-5 had grown seven separate switches."""
 import ctypes
 import os
 import weakref
@@ -54,8 +54,27 @@ class _Counters:
 STATS = _Counters
 
 
+# QT_TRAIN_DEBUG: bits that switch a fusion OFF (values never change: every fusion computes what the launches it replaces compute).
+#   1 chains     no chained fake-quantizer launches at all (implies everything below: they are built on chains)
+#   2 colsum     bias gradients by qt_colsum_bf16 instead of riding on the chain launches
+#   4 producers  torch's own LayerNorm / GELU / softmax kernels (implies attention, fanin, embedding, addln)
+#   8 attention  the attention core as its sub-modules (library GEMMs, qt_softmax_*)
+#  16 fanin      one fake-quantizer launch and one add per gradient arriving at a LayerNorm output (implies addln)
+#  32 embedding  torch's embedding_dense_backward
+#  64 addln      the residual add in front of a LayerNorm as its own launch
+DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64}
+
+
+def _on(name):
+    try:
+        mask = int(os.environ.get("QT_TRAIN_DEBUG", "0") or "0", 0)
+    except ValueError:
+        raise ValueError(f"QT_TRAIN_DEBUG={os.environ.get('QT_TRAIN_DEBUG')!r}: an integer mask of {DEBUG_BITS}") from None
+    return not (mask & DEBUG_BITS[name])
+
+
 def enabled():
-    return os.environ.get("QT_TRAIN_CHAINS", "1") != "0"
+    return _on("chains")
 
 
 class Chain:
@@ -68,14 +87,25 @@ class Chain:
         self.name = name
 
 
-_COLSUM = {}              # (data_ptr, version, shape) of a grad_output -> its column sums (one-shot, taken by the Linear's backward)
+_COLSUM = {}              # (data_ptr, version, shape) of a grad_output -> (that tensor, its column sums): one-shot, taken by the Linear's backward
+
+
+def put_colsum(g, gb):
+    """Leaves the column sums of `g` for the Linear whose backward receives `g`.  The entry holds `g` itself: while it exists the address
+    cannot be handed to another tensor, so a key can only ever match the tensor it was made for (an entry nobody takes -- a chain miss, a
+    Linear that did not go through _LinearColsumBias -- used to outlive its tensor and could match a later gradient at the same address).
+    More than 64 entries: the OLDEST go (never all of them); a Linear whose entry went computes its own sums."""
+    while len(_COLSUM) >= 64:
+        del _COLSUM[next(iter(_COLSUM))]
+    _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = (g, gb)
 
 
 def take_colsum(g):
     hit = _COLSUM.pop((g.data_ptr(), g._version, tuple(g.shape)), None)
-    if hit is not None:
-        STATS.colsums += 1
-    return hit
+    if hit is None:
+        return None
+    STATS.colsums += 1
+    return hit[1]
 
 
 def _member_ok(fq, device):
@@ -143,7 +173,7 @@ def run_chain(head, chain, X):
     if fmt0.kind not in (_native.QT_FMT_LUT, _native.QT_FMT_FP_SAT, _native.QT_FMT_INT):
         return None
     need_grad = torch.is_grad_enabled() and X.requires_grad
-    colsum = chain.colsum if os.environ.get("QT_TRAIN_COLSUM", "1") != "0" else None
+    colsum = chain.colsum if _on("colsum") else None
     if colsum is not None and (need_grad or colsum[1].bias is None or not colsum[1].bias.requires_grad or colsum[1].out_features != cols):
         colsum = None
     st = _stream_ptr(X)
@@ -170,9 +200,7 @@ def run_chain(head, chain, X):
         _native.check(rc, "qt_fake_quant_chain_bf16")
         if gb is not None:
             g = outs[colsum[0]]
-            if len(_COLSUM) > 64:
-                _COLSUM.clear()
-            _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gb
+            put_colsum(g, gb)
         return outs
 
     with torch.no_grad():
@@ -240,6 +268,9 @@ def ensure_planned(model):
     return None
 
 
+_PLAN_WARNED = False
+
+
 def unplan(model):
     from .fake_quantize import FusedAmaxObsFakeQuantize
     for m in model.modules():
@@ -261,6 +292,27 @@ def plan(model):
     from .modules.qat.linear import Linear as QATLinear
     unplan(model)
     if not enabled():
+        return 0
+    # the module layout the chains are read from: output blocks are this package's twins (modules/quantizable/attention.py) with
+    # .dense / .residual / .LayerNorm, attention blocks carry .query / .key / .value beside .qk_matmul / .av_matmul.  A tree that has the
+    # twins but not those names (another transformers layout, a model edited after quantize()) gets NO chains and one warning -- never
+    # chains planned from half of a block.
+    problems = []
+    for name, mod in model.named_modules():
+        if getattr(type(mod), "_qt_twin", False) and hasattr(mod, "residual"):
+            missing = [a for a in ("dense", "LayerNorm") if not isinstance(getattr(mod, a, None), torch.nn.Module)]
+            if missing:
+                problems.append(f"{name} ({type(mod).__name__}) has no sub-module {missing}")
+        if hasattr(mod, "qk_matmul") != hasattr(mod, "av_matmul") or (
+                hasattr(mod, "qk_matmul") and hasattr(mod, "query") and not all(hasattr(mod, a) for a in ("key", "value"))):
+            problems.append(f"{name} ({type(mod).__name__}) is not a query / key / value + qk_matmul / av_matmul attention block")
+    if problems:
+        global _PLAN_WARNED
+        if not _PLAN_WARNED:
+            _PLAN_WARNED = True
+            import logging
+            logging.getLogger(__name__).warning("quantized_training: training-step launch fusions are OFF for this model, its module layout "
+                                                "is not the one they are planned from: %s", "; ".join(problems[:4]))
         return 0
     n = 0
     chained = set()
@@ -306,7 +358,7 @@ def plan(model):
 
 # ---- producer kernels of a training step that evaluate the chain behind them in their own launch ---------------------------------
 def producers_enabled():
-    return enabled() and os.environ.get("QT_TRAIN_PRODUCERS", "1") != "0"
+    return enabled() and _on("producers")
 
 
 def _members_format(members, dev):
@@ -356,11 +408,13 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
-_PENDING = {}             # data_ptr of a placeholder -> (the gradient a deferred backward fake-quantizer call received, the quantizer, the placeholder)
+_PENDING = {}             # data_ptr of a placeholder -> (the gradient a deferred backward fake-quantizer call received, the quantizer, the
+#                           placeholder -- held, so its address is not reused while the entry exists --, weak reference to the graph's token)
+_HOLDS = weakref.WeakValueDictionary()      # data_ptr -> every placeholder still alive, to tell one that lost its entry from a real gradient
 
 
 def fanin_enabled():
-    return producers_enabled() and os.environ.get("QT_TRAIN_FANIN", "1") != "0"
+    return producers_enabled() and _on("fanin")
 
 
 def take_deferred(fq, X):
@@ -384,8 +438,12 @@ def take_deferred(fq, X):
     _Stats.add(X.numel())
     hold = torch.empty_like(X)
     if len(_PENDING) > 64:
-        _PENDING.clear()
-    _PENDING[hold.data_ptr()] = (X, fq, hold)
+        # only entries whose autograd graph is gone (their token died: nothing can deliver those placeholders any more); a placeholder of
+        # a backward that is still running is never dropped -- it is uninitialised memory that only its entry can turn into a gradient
+        for k in [k for k, v in _PENDING.items() if v[3]() is None]:
+            del _PENDING[k]
+    _PENDING[hold.data_ptr()] = (X, fq, hold, armed[1])
+    _HOLDS[hold.data_ptr()] = hold
     return hold
 
 
@@ -399,6 +457,9 @@ def _fanin_items(arrivals, dev):
         if pend is not None and pend[2].numel() == g.numel():
             items.append((pend[0], pend[1], pend[2]))
         else:
+            if pend is None and _HOLDS.get(g.data_ptr()) is g:
+                raise RuntimeError("train_fusions: a deferred fake-quantizer call's placeholder arrived without its pending entry "
+                                   "(it holds no gradient); set QT_TRAIN_DEBUG=16 (no fan-in launches) and report this")
             items.append((g.contiguous(), None, None))
     quant = [(fq, -1) for _, fq, _ in items if fq is not None]
     fmt = _members_format(quant, dev) if quant else None
@@ -465,7 +526,7 @@ def _grad_chain(head):
     chain = head.__dict__.get("_qt_chain") if head is not None else None
     if chain is None or chain.members[0][0] is not head:
         return None, None
-    colsum = chain.colsum if os.environ.get("QT_TRAIN_COLSUM", "1") != "0" else None
+    colsum = chain.colsum if _on("colsum") else None
     if colsum is not None and (colsum[1].bias is None or not colsum[1].bias.requires_grad):
         colsum = None
     return chain.members, colsum
@@ -562,9 +623,7 @@ class _LayerNormTrainFn(torch.autograd.Function):
         _hand_over(members, dx, outs)
         if gbias is not None:
             g = outs[colsum[0]]
-            if len(_COLSUM) > 64:
-                _COLSUM.clear()
-            _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gbias
+            put_colsum(g, gbias)
         return (dx, gw, gb, None, None, None) + pad
 
 
@@ -616,7 +675,7 @@ def add_layernorm_or_none(block, h, r):
     launch (functional_modules._LazyAdd); nothing may hook its forward or read the sum in between."""
     from .modules.quantizable.functional_modules import AddFunctional
     norm, res = getattr(block, "LayerNorm", None), getattr(block, "residual", None)
-    if not (fanin_enabled() and os.environ.get("QT_TRAIN_ADDLN", "1") != "0" and type(res) is AddFunctional and norm is not None
+    if not (fanin_enabled() and _on("addln") and type(res) is AddFunctional and norm is not None
             and h.shape == r.shape and h.dtype == r.dtype and r.is_cuda and r.is_contiguous() and r.data_ptr() % 16 == 0 and h.requires_grad
             and not res._forward_hooks and not res._forward_pre_hooks and getattr(res, "activation_pre_process", None) is None):
         return None
@@ -682,9 +741,7 @@ class _GeluTrainFn(torch.autograd.Function):
         _hand_over(members, dx, outs)
         if gbias is not None:
             g = outs[colsum[0]]
-            if len(_COLSUM) > 64:
-                _COLSUM.clear()
-            _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = gbias
+            put_colsum(g, gbias)
         return dx, None, None
 
 
@@ -936,14 +993,12 @@ class _AttentionTrainFn(torch.autograd.Function):
         for mem, i, o, gb in riders:
             _hand_over(mem, grads[i].view(B, S, H * D), [o])
             if gb is not None:
-                if len(_COLSUM) > 64:
-                    _COLSUM.clear()
-                _COLSUM[(o.data_ptr(), o._version, tuple(o.shape))] = gb
+                put_colsum(o, gb)
         return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None, None, None
 
 
 def attention_enabled():
-    return producers_enabled() and os.environ.get("QT_TRAIN_ATTENTION", "1") != "0"
+    return producers_enabled() and _on("attention")
 
 
 def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout):
@@ -1043,7 +1098,7 @@ def embedding_or_none(emb, ids):
     scale_grad_by_freq, not sparse), int64 indices, at most 3072 of them (beyond that torch's gradient takes another, sort-based path
     with other sums), nothing hooked onto the module."""
     w = emb.weight
-    if not (producers_enabled() and os.environ.get("QT_TRAIN_EMBEDDING", "1") != "0" and torch.is_grad_enabled() and w.requires_grad and w.is_cuda
+    if not (producers_enabled() and _on("embedding") and torch.is_grad_enabled() and w.requires_grad and w.is_cuda
             and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] % 8 == 0 and w.is_contiguous() and ids.is_cuda and ids.dtype == torch.int64
             and 0 < ids.numel() <= 3072 and emb.max_norm is None and not emb.scale_grad_by_freq and not emb.sparse
             and not emb._forward_hooks and not emb._forward_pre_hooks and not emb._backward_hooks and not emb._backward_pre_hooks):

@@ -1965,6 +1965,55 @@ def test_fake_quant_chain_equals_the_single_passes(nv, dtype, scales, rows, cols
                                           stream()) == nv.QT_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("rows", [256, 1024, 2048, 4096])           # one 64-column strip: 4, 16, 32 and 32 bands of 64-row groups
+def test_chain_column_sums_keep_non_finite_gradients(nv, rows):
+    """The bias gradient the chain launch carries (grad_output.sum(0), run_glue_no_trainer.py:660-667) over a diverged step: a column whose
+    every band holds a NaN must come out NaN, as torch's sum does -- round 5 recorded a non-finite band partial as 2^62 in the fixed-point
+    accumulator, and 4, 8, 16 or 32 of those wrapped to exactly zero.  Also: one poisoned band among finite ones, a column
+    whose finite partial sums are as large as the format allows (every element at the maximum: the finite total must stay clear of the
+    poison threshold), and clean columns beside them unchanged."""
+    L = nv.lib()
+    cols = 64
+    dtype = "fp8_e5m2"
+    fmt = nv.format_for(dtype)
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    lut = qt_pkg.get_quantization_map(dtype, torch.device("cuda"))
+    fmt = _launch_format(fmt, lut)
+    fmax = 57344.0
+    torch.manual_seed(rows)
+    x = torch.randn(rows, cols, device="cuda").bfloat16()
+    x[:, 0] = float("nan")                      # every band poisoned
+    x[:, 1] = float("inf")                      # (fp8_e5m2 keeps Inf: fake_quantize.py:63-80 -> the sum is Inf or NaN, never finite)
+    x[rows // 2, 2] = float("nan")              # one band poisoned
+    x[:, 3] = fmax                              # largest finite total: rows x max
+    x[:, 4] = -fmax
+    x[::2, 5] = float("nan")                    # half the rows
+    sc = torch.ones(1, dtype=torch.float32, device="cuda")
+    out = torch.empty_like(x)
+    am = torch.zeros(1, dtype=torch.float32, device="cuda")
+    stages = (nv.QtChainStage * 1)()
+    stages[0].scale_f32_dev, stages[0].amax_bits_dev, stages[0].out_dev, stages[0].src = sc.data_ptr(), am.data_ptr(), out.data_ptr(), -1
+    wb = L.qt_fake_quant_chain_ws_bytes(rows, cols)
+    ws = torch.zeros(max(wb, 16), dtype=torch.uint8, device="cuda")
+    gb = torch.empty(cols, dtype=torch.bfloat16, device="cuda")
+    for _ in range(2):                          # twice: the accumulators must be left zero by the poisoned launch too
+        nv.check(L.qt_fake_quant_chain_bf16(x.data_ptr(), rows, cols, stages, 1, ctypes.byref(fmt), lut.data_ptr(), 0, fmax, gb.data_ptr(),
+                                            ws.data_ptr(), wb, stream()), "qt_fake_quant_chain_bf16")
+        torch.cuda.synchronize()
+        assert not bool(ws.any())
+        ref = out.double().sum(0)
+        got = gb.double()
+        for c in (0, 2, 5):
+            assert bool(torch.isnan(got[c])), (c, float(got[c]))
+        assert not bool(torch.isfinite(got[1])), float(got[1])
+        assert bool(torch.isfinite(got[3])) and bool(torch.isfinite(got[4]))
+        clean = torch.ones(cols, dtype=torch.bool, device="cuda")
+        clean[[0, 1, 2, 5]] = False
+        tol = ref.abs() * 2.0 ** -7 + out.double().abs().sum(0) * 2.0 ** -20 + 1e-30
+        assert bool(((got - ref).abs() <= tol)[clean].all())
+
+
 def _chain_setup(nv, dtype, scales, like, src):
     """Stage array + outputs + amax slots for a producer kernel, and a checker: every stage equals its own qt_fake_quant_bf16 launch on the
     tensor it reads (bit for bit, amax included)."""
@@ -2352,6 +2401,71 @@ def test_attention_train_kernels_against_the_launches_they_replace(nv, B, H, S, 
     assert not any(bool(torch.isnan(t.float()).any()) for t in (dq, dk, dv))
 
 
+@pytest.mark.parametrize("B", [4, 16, 32])
+def test_attention_train_backward_bias_sums_keep_nan(nv, B):
+    """The attention backward sums the projections' bias gradients over the batch in fixed point, one arrival per batch element
+    (qt_attention_train.hip).  A fully-NaN incoming gradient (a diverged step) must leave NaN bias gradients, as torch's
+    grad_output.sum(0) does, for 4, 16 and 32 arrivals (round 5's 2^62 marker wrapped to zero at exactly these counts), and the scratch
+    must be left zero for the next launch."""
+    import quantized_training as qt_pkg
+    from quantized_training.fake_quantize import _launch_format
+    L = nv.lib()
+    H, S, D = 2, 64, 64
+    dev = torch.device("cuda")
+    torch.manual_seed(B)
+    lut = qt_pkg.get_quantization_map("int8", dev)
+    fmt = _launch_format(nv.format_for("int8"), lut)
+    lut5 = qt_pkg.get_quantization_map("fp8_e5m2", dev)
+    fmt5 = _launch_format(nv.format_for("fp8_e5m2"), lut5)
+
+    def proj():
+        return torch.randn(B, S, H * D, device=dev).bfloat16().view(B, S, H, D).permute(0, 2, 1, 3)
+    q, k, v = proj(), proj(), proj()
+    sc = [torch.tensor([x], dtype=torch.float32, device=dev) for x in (2.0 ** -5, 2.0 ** -5, 2.0 ** -5, 2.0 ** -7, 2.0 ** -4)]
+    am = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in sc]
+    qq, kq, vq = (torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=dev) for _ in range(3))
+    probs = torch.empty(B, H, S, S, dtype=torch.bfloat16, device=dev)
+    pq = torch.empty_like(probs)
+    out = torch.empty(B, S, H * D, dtype=torch.bfloat16, device=dev)
+    oq = torch.empty_like(out)
+    outs = [qq, kq, vq, pq, oq]
+    stages = (nv.QtChainStage * 5)()
+    for i in range(5):
+        stages[i].scale_f32_dev, stages[i].amax_bits_dev, stages[i].out_dev, stages[i].src = sc[i].data_ptr(), am[i].data_ptr(), outs[i].data_ptr(), -1
+    nv.check(L.qt_attention_train_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), q.stride(2), q.stride(1), None, 0, 0, 0, stages,
+                                       probs.data_ptr(), out.data_ptr(), None, 1.0, B, H, S, D, 0.125, ctypes.byref(fmt), lut.data_ptr(), stream()),
+             "qt_attention_train_bf16")
+    esc = [torch.tensor([2.0 ** -24], dtype=torch.float32, device=dev) for _ in range(2)]
+    eam = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in esc]
+    est = (nv.QtChainStage * 2)()
+    for i in range(2):
+        est[i].scale_f32_dev, est[i].amax_bits_dev, est[i].out_dev, est[i].src = esc[i].data_ptr(), eam[i].data_ptr(), None, -1
+    gsc = [torch.tensor([2.0 ** -22], dtype=torch.float32, device=dev) for _ in range(3)]
+    gam = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in gsc]
+    gout = [torch.empty(B, S, H * D, dtype=torch.bfloat16, device=dev) for _ in gsc]
+    gbias = [torch.zeros(H * D, dtype=torch.bfloat16, device=dev) for _ in gsc]
+    gst = (nv.QtChainStage * 3)()
+    couts = (ctypes.c_void_p * 3)()
+    for i in range(3):
+        gst[i].scale_f32_dev, gst[i].amax_bits_dev, gst[i].out_dev, gst[i].src = gsc[i].data_ptr(), gam[i].data_ptr(), gout[i].data_ptr(), -1
+        couts[i] = gbias[i].data_ptr()
+    dq, dk, dv = (torch.empty(B, S, H, D, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    ws = torch.zeros(L.qt_attention_train_backward_ws_bytes(H), dtype=torch.uint8, device=dev)
+    for gy_kind in ("nan", "finite"):          # the finite launch afterwards finds clean scratch and gives finite sums
+        gy = torch.full((B, S, H, D), float("nan"), device=dev).bfloat16() if gy_kind == "nan" else (torch.randn(B, S, H, D, device=dev) * 1e-3).bfloat16()
+        nv.check(L.qt_attention_train_backward_bf16(gy.data_ptr(), qq.data_ptr(), kq.data_ptr(), vq.data_ptr(), qq.stride(0), qq.stride(2), qq.stride(1),
+                                                    probs.data_ptr(), pq.data_ptr(), est, None, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), gst, couts,
+                                                    57344.0, ws.data_ptr(), ws.numel(), None, 1.0, B, H, S, D, 0.125, ctypes.byref(fmt5), lut5.data_ptr(),
+                                                    stream()), "qt_attention_train_backward_bf16")
+        torch.cuda.synchronize()
+        assert int(ws.count_nonzero()) == 0
+        for i in range(3):
+            if gy_kind == "nan":
+                assert bool(torch.isnan(gbias[i].float()).all()), (i, int(torch.isnan(gbias[i].float()).sum()))
+            else:
+                assert bool(torch.isfinite(gbias[i].float()).all()), i
+
+
 @pytest.mark.parametrize("n,kinds", [(2048 * 768, (1, 1, 1)), (2048 * 768, (1,)), (37 * 264, (0, 1, 1, 0)), (8 * 8, (0, 0))])
 def test_grad_fanin_equals_the_fake_quantizer_launches_and_torch_adds(nv, n, kinds):
     """qt_grad_fanin_bf16: sum = (((first + y_0) + y_1) + ...) with y_i = fq_i(x_i) (kind 1) or x_i (kind 0) is bit for bit what the
@@ -2455,6 +2569,19 @@ print("HASH", " ".join(out), fused.routes_report())
         del os.environ["QT_LT_ALGO"]
     bound = (a.float().abs() @ b.float().abs().t())
     assert bool(((y3.float() - y0.float()).abs() <= y0.float().abs() * 2.0 ** -7 + bound * 2.0 ** -14).all())
+    # the table's indices belong to one build of the library: under any other the first suggestion runs, and the report says so
+    assert nv.lib().qt_fp8_gemm_library_version() == fused._LT_ALGO_TABLE_LIBRARY, nv.lib().qt_fp8_gemm_library_version()
+    saved = (fused._LT_ALGO_TABLE_LIBRARY, dict(fused._LT_LIBRARY), dict(fused.LT_ALGOS))
+    try:
+        fused._LT_ALGO_TABLE_LIBRARY, fused._LT_LIBRARY["version"] = saved[0] + 1, None
+        fused.LT_ALGOS.clear()
+        assert fused.lt_algo_index(1, 6144, 768, 3072, False, True) == 0
+        assert "lt:library_version" in fused.LT_ALGOS and fused.LT_ALGOS["lt:1x6144x768x3072+bias"] == 0
+    finally:
+        fused._LT_ALGO_TABLE_LIBRARY = saved[0]
+        fused._LT_LIBRARY.update(saved[1])
+        fused.LT_ALGOS.clear()
+        fused.LT_ALGOS.update(saved[2])
 
 
 def test_splitk_scratch_is_per_stream_and_per_capture(nv):
@@ -2529,6 +2656,120 @@ def test_linear_fq8_wide_tiles_redo_overflowing_weights(nv, pair):
     nv.check(nv.lib().qt_mlp_fq8_bf16(x8.data_ptr(), 0, Wf.data_ptr(), Wu.data_ptr(), None, None, N, 0, h.data_ptr(), h8.data_ptr(),
                                       ctypes.byref(fmt), M, K, stream()), "qt_mlp_fq8_bf16")
     assert torch.equal(h.view(torch.int16), want.view(torch.int16)) and torch.equal(h8, want8)
+
+
+def _fq8_plan(nv, M, N, K, pair=False):
+    v = [ctypes.c_int(0) for _ in range(5)]
+    nv.check(nv.lib().qt_linear_fq8_plan(M, N, K, int(pair), *[ctypes.byref(x) for x in v]), "qt_linear_fq8_plan")
+    return tuple(x.value for x in v)                   # tiles_m, tiles_n, groups_lo, groups_hi, variant
+
+
+def _fq8_fused_shapes():
+    """Every problem shape a DEFAULT route hands to the fused FP8 GEMM: the committed route table's fused entries (fused._FQ8_TABLE:
+    BASELINE's configs) -- enumerated, not hand-picked -- plus shapes that reach the remaining (variant, tile width) classes of the
+    planner (two weight pieces with an odd k-tile count: variant 2; four pieces: variant 4)."""
+    from quantized_training import fused                       # (conftest.py put the package on sys.path)
+    shapes = sorted(k for k, v in fused._FQ8_TABLE.items() if v)
+    return shapes + [(1024, 4096, 4224), (512, 4096, 4096), (1024, 8192, 1152)]
+
+
+@pytest.mark.parametrize("wdtype", ["e4m3", "e5m2"])
+@pytest.mark.parametrize("shape", _fq8_fused_shapes(), ids=lambda s: "x".join(map(str, s)))
+def test_linear_fq8_every_planned_tile_variant_on_all_weight_patterns(nv, shape, wdtype):
+    """fp8.py:10-67 through qt_linear_fq8_bf16 for EVERY (kernel variant, tile width) the planner returns for the shapes of the route
+    table (qt_linear_fq8_plan: two-k-tile narrow tiles, one-k-tile tiles with 2 / 4 / 6 weight pieces, the two-register-set loop) at
+    the table's own M and N -- the planner's tile cut depends on those and on K only through K % 256, which the test's K keeps.  A
+    wrong-result bug lived for two rounds in one variant's redo vote because the all-pattern tests ran other tile widths.
+    Identity activation: y[m][n] = fq(W)[n][m], compared bit for bit with the ORACLE's value map.
+      fast:  every weight row cycles through the bf16 patterns whose result is finite in the format -- no tile takes the redo path,
+             every tile position converts every such pattern with the hardware conversion;
+      redo:  every row cycles through ALL 65 536 patterns, non-finite ones zeroed -- every tile overflows and is redone with the
+             closed form (saturation to the format maximum);
+      raw:   all patterns as they are -- rows holding +-Inf / NaN must come out all-NaN (0 * NaN), the others exact."""
+    M, N, Kreal = shape
+    Kt = min(512, M) if Kreal % 256 == 0 else min(384, M)          # keeps K % 256 (the narrow-tile variant's condition)
+    Kt = max(Kt - Kt % 128, 128)
+    plan = _fq8_plan(nv, M, N, Kreal)
+    assert plan == _fq8_plan(nv, M, N, Kt), (plan, _fq8_plan(nv, M, N, Kt))      # the test problem is cut like the real one
+    qmap = o.get_quantization_map(wdtype)
+    vals = o.bf16_to_f32(qmap)
+    pats = np.arange(65536, dtype=np.uint16)
+    raw = o.bf16_to_f32(pats)
+    # patterns the HARDWARE conversion rounds to a finite code: below the midpoint between the format maximum and the next grid point
+    inrange = pats[np.isfinite(raw) & (np.abs(raw) < (464.0 if wdtype == "e4m3" else 61440.0))]
+    x8 = _codes_of(nv, torch.eye(Kt, device="cuda").bfloat16()[:M] if M < Kt else torch.cat(
+        [torch.eye(Kt, device="cuda"), torch.zeros(M - Kt, Kt, device="cuda")]).bfloat16(), "e4m3")
+    rows = min(M, Kt)
+
+    def run(name, bits):
+        W = torch.from_numpy(np.resize(bits, N * Kt).astype(np.uint16).view(np.int16).reshape(N, Kt).copy()).cuda().view(torch.bfloat16)
+        exp = o.canon_nan16(o.vmap_bf16(np.resize(bits, N * Kt).astype(np.uint16), qmap)).reshape(N, Kt)[:, :rows]
+        y = _linear_fq8(nv, x8, "e4m3", [W], wdtype)
+        got = o.canon_nan16(host_u16(y[:rows].t().contiguous().view(torch.int16)))
+        nan_rows = (o.canon_nan16(o.vmap_bf16(np.resize(bits, N * Kt).astype(np.uint16), qmap)).reshape(N, Kt) == 0x7FC0).any(axis=1)
+        same = (got == exp) | (((got | exp) & 0x7FFF) == 0)         # the sign of a zero is not part of a product
+        assert same[~nan_rows].all(), (name, plan, int((~same[~nan_rows]).sum()), np.argwhere(~same & ~nan_rows[:, None])[:4].tolist())
+        assert (got[nan_rows] == 0x7FC0).all(), (name, plan)
+        return int(nan_rows.sum())
+
+    assert run("fast", inrange) == 0
+    sane = pats.copy()
+    sane[~np.isfinite(raw)] = 0
+    assert run("redo", sane) == 0
+    assert run("raw", pats) > 0
+    print(f"[fq8 plan] {M}x{N}x{Kreal} {wdtype}: tiles {plan[0]}x{plan[1]}, {plan[2]}..{plan[3]} groups, variant {plan[4]}")
+
+
+def test_linear_fq8_planned_variants_are_all_covered(nv):
+    """The shapes of the test above reach every class the planner can return: each kernel variant (0, 2, 4, 6), and for the one-k-tile
+    variants both the narrowest and the widest tile it serves; every fused entry of the route table is among them."""
+    seen = {}
+    for (M, N, K) in _fq8_fused_shapes():
+        tm, tn, lo, hi, var = _fq8_plan(nv, M, N, K)
+        seen.setdefault(var, set()).update((lo, hi))
+    assert set(seen) == {0, 2, 4, 6}, seen
+    assert max(seen[6]) == 12 and min(seen[6]) >= 9 and max(seen[4]) <= 8 and max(seen[0]) <= 4, seen
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 11008, 4096), (512, 11008, 4096), (1024, 4096, 4096), (256, 1536, 512)])
+def test_mlp_fq8_planned_pair_tiles_on_all_weight_patterns(nv, M, N, K):
+    """qt_mlp_fq8_bf16 (pair mode) at the shapes of fused._MLP_TABLE and at narrower pair tiles (eight / four groups): the gate AND the
+    up weight cycle through all 65 536 bf16 patterns (non-finite ones zeroed: every tile is redone) resp. the in-range ones (no tile
+    is), identity activation -- the one launch must equal, bit for bit, the oracle-checked separate launches: two
+    qt_linear_fq8_bf16 products (the test above pins them to the oracle) + qt_silu_mul_fq8_bf16."""
+    from quantized_training import fused
+    assert all(k in [(1024, 11008, 4096), (512, 11008, 4096)] for k in fused._MLP_TABLE)
+    Kt = min(512, M)
+    plan = _fq8_plan(nv, M, N, K, pair=True)
+    assert plan == _fq8_plan(nv, M, N, Kt, pair=True)
+    pats = np.arange(65536, dtype=np.uint16)
+    raw = o.bf16_to_f32(pats)
+    sane = pats.copy()
+    sane[~np.isfinite(raw)] = 0
+    inrange = pats[np.isfinite(raw) & (np.abs(raw) < 464.0)]
+    x8 = _codes_of(nv, torch.cat([torch.eye(Kt, device="cuda"), torch.zeros(max(M - Kt, 0), Kt, device="cuda")]).bfloat16()[:M], "e4m3")
+    fmt = nv.format_for("e4m3")
+    for name, gbits, ubits in (("redo", sane, sane[::-1]), ("fast", inrange, inrange[::-1]), ("mixed", sane, inrange)):
+        Wg = torch.from_numpy(np.resize(gbits, N * Kt).astype(np.uint16).view(np.int16).reshape(N, Kt).copy()).cuda().view(torch.bfloat16)
+        Wu = torch.from_numpy(np.resize(ubits, N * Kt).astype(np.uint16).view(np.int16).reshape(N, Kt).copy()).cuda().view(torch.bfloat16)
+        g = _linear_fq8(nv, x8, "e4m3", [Wg], "e4m3")
+        u = _linear_fq8(nv, x8, "e4m3", [Wu], "e4m3")
+        want = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        want8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+        nv.check(nv.lib().qt_silu_mul_fq8_bf16(g.data_ptr(), u.data_ptr(), want.data_ptr(), want8.data_ptr(), M, N, N, N, ctypes.byref(fmt),
+                                               stream()), "qt_silu_mul_fq8_bf16")
+        h = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        h8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+        nv.check(nv.lib().qt_mlp_fq8_bf16(x8.data_ptr(), 0, Wg.data_ptr(), Wu.data_ptr(), None, None, N, 0, h.data_ptr(), h8.data_ptr(),
+                                          ctypes.byref(fmt), M, Kt, stream()), "qt_mlp_fq8_bf16")
+        assert torch.equal(o_canon(h), o_canon(want)) and torch.equal(h8, want8), (name, plan)
+
+
+def o_canon(t):
+    """bf16 tensor as int16 bits with every NaN rewritten to one pattern (the payload is not part of the contract)."""
+    b = t.view(torch.int16).clone()
+    b[torch.isnan(t.float())] = 0x7FC0
+    return b
 
 
 # ---- qt_linear_fqt_bf16: bf16 GEMM with ANY value map applied to the weights in its operand path --------------------------

@@ -349,12 +349,27 @@ class _PeftStyleLoraLinear(nn.Module):
         self.fan_in_fan_out = fan_in_fan_out
 
 
+def _close_bits(got, want_bits, shape, rel):
+    """A device result against the reference's bf16 bits: within `rel` of the largest magnitude (the device's GEMMs add in another order
+    than the CPU's)."""
+    want = _from_bits16(want_bits, shape).float()
+    return bool(((got.detach().float().cpu() - want).abs() <= rel * float(want.abs().max()) + 1e-30).all())
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
 @pytest.mark.parametrize("case", LORA, ids=[c["name"] for c in LORA])
-def test_lora_qat_linear_matches_reference_steps(case):
+def test_lora_qat_linear_matches_reference_steps(case, device):
+    """modules/qat/lora.py:34-55 upstream, against steps recorded from the reference (tests/golden/gen_golden.py): on CPU tensors bit for
+    bit; on the device (the three weight fake-quantizer calls per forward run as HIP launches, the products as device GEMMs) the
+    delayed-scaling scale bit for bit or one bf16 step of the merged weight's amax away, outputs and adapter gradients within 2^-6 of
+    their largest magnitude (another summation order in the rank-r product and the projection)."""
     from quantized_training.modules.qat import LoraLinear
     n, fin, fout, r = case["name"], case["in"], case["out"], case["r"]
     key = lambda k: LORA_NPZ[(n + "/" + k).replace("/", "__")]
     flt = _PeftStyleLoraLinear(fin, fout, r, case["fan_in_fan_out"])
+    if device != "cpu":
+        _lora_on_device(case, flt, key, device)
+        return
     with torch.no_grad():
         flt.base_layer.weight.copy_(_from_bits16(key("w"), flt.base_layer.weight.shape))
         flt.base_layer.bias.copy_(_from_bits16(key("b"), (fout,)))
@@ -382,3 +397,35 @@ def test_lora_qat_linear_matches_reference_steps(case):
     x = _from_bits16(key("0/x"), (5, fin))
     w = layer.weight.T if case["fan_in_fan_out"] else layer.weight
     assert torch.equal(layer(x), torch.nn.functional.linear(x, w, layer.bias))
+
+
+def _lora_on_device(case, flt, key, device):
+    from quantized_training.modules.qat import LoraLinear
+    from quantized_training.fake_quantize import STATS
+    fin, fout, r = case["in"], case["out"], case["r"]
+    with torch.no_grad():
+        flt.base_layer.weight.copy_(_from_bits16(key("w"), flt.base_layer.weight.shape))
+        flt.base_layer.bias.copy_(_from_bits16(key("b"), (fout,)))
+        flt.lora_A["default"].weight.copy_(_from_bits16(key("A"), (r, fin)))
+        flt.lora_B["default"].weight.copy_(_from_bits16(key("B"), (fout, r)))
+    flt = flt.to(device)
+    flt.qconfig = qt.get_qconfig(None, qt.QuantizationSpec.from_str(case["spec"]), None)
+    layer = LoraLinear.from_float(flt).to(device)
+    a, b = flt.lora_A["default"].weight, flt.lora_B["default"].weight
+    opt = torch.optim.SGD([a, b], lr=case["lr"])
+    STATS.reset()
+    for step in range(case["steps"]):
+        x = _from_bits16(key(f"{step}/x"), (5, fin)).to(device)
+        y = layer(x)
+        opt.zero_grad()
+        y.float().square().mean().backward()
+        assert y.is_cuda and _close_bits(y, key(f"{step}/y"), (5, fout), 2.0 ** -6), step
+        assert _close_bits(a.grad, key(f"{step}/gA"), (r, fin), 2.0 ** -5), step
+        assert _close_bits(b.grad, key(f"{step}/gB"), (fout, r), 2.0 ** -5), step
+        got = float(layer.weight_fake_quant.scale.detach().float().reshape(-1)[0])
+        want = float(torch.from_numpy(key(f"{step}/scale").view(np.float32).copy()).reshape(-1)[0])
+        assert abs(got - want) <= 2.0 ** -7 * abs(want), (step, got, want)
+        opt.step()
+    assert layer.weight.grad is None
+    # three fake-quantizer calls per forward (A, B, the merged weight), all counted by the device path's statistics
+    assert STATS.calls >= 3 * case["steps"], STATS.calls

@@ -21,7 +21,7 @@ python tools/window_breakdown.py gpurun_out/prof_bert_stats --windows 3 --layers
 find gpurun_out/prof_13b_posit gpurun_out/prof_train_stats gpurun_out/prof_bert_stats -name "*kernel_trace.csv" -delete
 head -12 gpurun_out/window_breakdown_13b_posit.txt; head -8 gpurun_out/train_step_breakdown.txt; head -8 gpurun_out/bert_batch_breakdown.txt
 # training step A/B on this box, the chain microbenchmark
-timeout 1500 python tools/ab_env.py --workload roberta-mrpc-int8-e5m2-train --reps 2 --steps 10 "" QT_TRAIN_EMBEDDING=0 QT_TRAIN_FANIN=0 QT_TRAIN_ATTENTION=0 QT_TRAIN_PRODUCERS=0 QT_TRAIN_COLSUM=0 QT_TRAIN_CHAINS=0 QT_BENCH_NO_OBSERVE=1 > gpurun_out/train_step_ab.txt 2>&1; cat gpurun_out/train_step_ab.txt
+timeout 1500 python tools/ab_env.py --workload roberta-mrpc-int8-e5m2-train --reps 2 --steps 10 "" QT_TRAIN_DEBUG=32 QT_TRAIN_DEBUG=16 QT_TRAIN_DEBUG=8 QT_TRAIN_DEBUG=4 QT_TRAIN_DEBUG=2 QT_TRAIN_DEBUG=1 QT_BENCH_NO_OBSERVE=1 > gpurun_out/train_step_ab.txt 2>&1; cat gpurun_out/train_step_ab.txt
 QT_HIP_LIB=tools/build/libqt_hip_tuning.so timeout 600 python tools/exp_attention_train.py 2>&1 | grep -v Warn > gpurun_out/attention_train_stamps.txt; cat gpurun_out/attention_train_stamps.txt | cut -c1-250
 timeout 600 python tools/exp_chain.py > gpurun_out/chain_microbench.txt 2>&1; cat gpurun_out/chain_microbench.txt | cut -c1-220
 # value-map GEMM PMC passes (unchanged kernel: the traffic entry of the bench line's secondary roofline)
