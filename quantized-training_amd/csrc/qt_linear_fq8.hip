@@ -183,7 +183,12 @@ __device__ __forceinline__ void silu_mul4(const float (&gt)[4], const float (&up
 // ABL (timing experiments only, QT_FQ8_ABLATE; results are garbage): 1 no multiplications, 2 no weight items (load / convert /
 // ds_write), 3 no activation DMA, 4 no fragment reads and no multiplications.  Measured at 1024 x 11008 x 4096 (55.6 us whole):
 // 48.8 / 39.5 / 47.9 / 48.5 us -- the k loop is paced by the operand streams (76 KB per step and CU), not by the matrix core.
-template <int FX, int FW, int NB, bool PAIR = false, int ABL = 0>
+// PF > 0 (round 6): every wave also touches, PF k tiles ahead, its share of the weight lines this column tile will need -- one 4-byte
+// load per 128-byte line, result never read.  The tiles_m workgroups that share a column tile run in lock step on one XCD, so today all
+// of them wait out the HBM miss of each weight line together (TCC: 19 % misses, but every weight request sees the miss latency);
+// brought into that XCD's L2 ahead of time the demand loads are L2 hits.  Measured ceiling of the idea: -12 % (every column tile
+// reading the first tile's weights, QT_FQ8_DEBUG=256, round 5).  Each workgroup prefetches 1 / tiles_m of the tile's lines.
+template <int FX, int FW, int NB, bool PAIR = false, int ABL = 0, int PF = 0>
 struct LinearFq8R {
     static constexpr int kADepth = 3;
     // ABL == 20 (not an ablation: the two-register-set variant): every weight piece has TWO register sets, so a weight request has two
@@ -194,6 +199,14 @@ struct LinearFq8R {
     static constexpr bool W2 = (ABL == 20);
     static constexpr int kWSets = W2 ? 2 : 1;
     static constexpr int kWWait = 2 * NB + 3;               // queue entries allowed behind a weight request when its registers are read
+    // PF kernels count exactly.  A weight request of set S is read two steps after it was issued; behind it in the queue are the rest
+    // of its own step's requests, one whole step (4 activation pieces + NB requests) and the reading step's 4 pieces and first requests:
+    // 2 NB + 7, plus the two prefetch loads issued at the two step starts in between.  (2 NB + 3 above is that count for step 0, whose
+    // requests were issued back to back in the prologue; kept for every step it is four entries too strict -- harmless while every
+    // entry is an L2 hit that lands within a step, but a prefetch load is an HBM miss by design and must never be waited for.)
+    static constexpr int kWWaitFirst = 2 * NB + 3 + (PF > 0 ? 1 : 0);
+    static constexpr int kWWaitSteady = PF > 0 ? 2 * NB + 9 : kWWait;
+    static constexpr int kStepWait = 4 + 2 * NB + (PF > 0 ? 1 : 0);      // behind the activation pieces of the step that starts
     static constexpr int kWBytes = NB * 4 * 1024;           // FP8 weight tile: up to 8 NB pieces of 4 rows x 128 bytes
     static constexpr int kLds = kADepth * kABytes + 2 * kWBytes;
     static constexpr int kItems = 4 + NB;
@@ -253,15 +266,56 @@ struct LinearFq8R {
             gw[i] = ub[i] + w_lane;
             wdst[i] = row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + (c & 1) * 8;
         }
+        // ---- L2 prefetch of the weight stream (PF > 0): this wave's lines of the tile's 32 nt lines per k tile (two per weight row)
+        const uint8_t *pf_base = nullptr;                     // wave-uniform: first row this wave touches, k tile 0
+        uint32_t pf_lane = 0;                                  // the lane's line inside the wave's span
+        if constexpr (PF > 0) {
+            const int tm_ = m0 / kTM;
+            if constexpr (PAIR) {
+                // waves 0-3: the gate rows of the tile's pairs, waves 4-7: the up rows; rows [P0 16, (P0 + nt / 2) 16) of each matrix
+                const int lines = 16 * nt;                                        // per matrix and k tile
+                const int lc = (lines + a.tiles_m - 1) / a.tiles_m, lw = (lc + 3) / 4;
+                int first = tm_ * lc + (w & 3) * lw;
+                first = first < lines - 1 ? first : lines - 1;
+                const int mine = min(lw, lines - first);
+                const int ln = first + min(l, mine - 1);
+                const uint16_t *wb = (w >> 2) ? a.seg[1].w : a.seg[0].w;
+                pf_base = (const uint8_t *)wb + (long)((tg0 / 2) * 16) * a.K * 2;
+                pf_lane = (uint32_t)(ln >> 1) * (uint32_t)a.K * 2u + (uint32_t)(ln & 1) * 128u;
+            } else {
+                const int lines = 32 * nt;
+                const int lc = (lines + a.tiles_m - 1) / a.tiles_m, lw = (lc + 7) / 8;
+                int first = tm_ * lc + w * lw;
+                first = first < lines - 1 ? first : lines - 1;
+                // the span stays inside the weight that holds its first row (a tile may straddle two weights of a q / k / v launch)
+                const int grp0 = tg0 + (first >> 5);
+                const SegRef sg = seg_lookup(a, grp0);
+                int seg_end_grp = tg0 + nt;                                       // first group past this weight inside the tile
+                if (a.nseg > 1 && a.seg[1].g0 > grp0 && a.seg[1].g0 < seg_end_grp) seg_end_grp = a.seg[1].g0;
+                if (a.nseg > 2 && a.seg[2].g0 > grp0 && a.seg[2].g0 < seg_end_grp) seg_end_grp = a.seg[2].g0;
+                if (a.nseg > 3 && a.seg[3].g0 > grp0 && a.seg[3].g0 < seg_end_grp) seg_end_grp = a.seg[3].g0;
+                const int last = (seg_end_grp - tg0) * 32 - 1;
+                const int mine = min(lw, last - first + 1);
+                const int ln = first + min(l, mine - 1) - (grp0 - tg0) * 32;       // line relative to group grp0's first row
+                pf_base = (const uint8_t *)sg.w + (long)((grp0 - sg.g0) * 16) * a.K * 2;
+                pf_lane = (uint32_t)(ln >> 1) * (uint32_t)a.K * 2u + (uint32_t)(ln & 1) * 128u;
+            }
+        }
+        uint32_t pf_sink = 0;
+        auto prefetch_w = [&](int kt) __attribute__((always_inline)) {
+            if constexpr (PF > 0)
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(pf_lane), "s"(pf_base + (long)kt * (2 * kBK)) : "memory");
+        };
         u32x4 wr[kWSets][NB];
         auto load_w_asm = [](u32x4 &dst, uint32_t lane_off, const uint8_t *base) __attribute__((always_inline)) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base) : "memory");
         };
-        auto wait_w_asm = [](u32x4 &reg) __attribute__((always_inline)) {
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(kWWait) : "memory");
+        auto wait_w_asm = [](u32x4 &reg, auto first) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(decltype(first)::value ? kWWaitFirst : kWWaitSteady) : "memory");
         };
+        // (sc: the register set, + 2 when the step is the k loop's first -- its wait count differs, see kWWaitFirst)
         auto load_w = [&](auto ic, auto sc, int kt) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value, S = decltype(sc)::value;
+            constexpr int I = decltype(ic)::value, S = decltype(sc)::value & 1;
             if constexpr (W2) load_w_asm(wr[S][I], w_lane, ub[I] + (long)kt * (2 * kBK));
             else wr[S][I] = *(const u32x4 *)(gw[I] + (long)kt * (2 * kBK));
         };
@@ -280,8 +334,8 @@ struct LinearFq8R {
             asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
         };
         auto store_w = [&](auto ic, auto sc, uint32_t wbase) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value, S = decltype(sc)::value;
-            if constexpr (W2) wait_w_asm(wr[S][I]);
+            constexpr int I = decltype(ic)::value, S = decltype(sc)::value & 1;
+            if constexpr (W2) wait_w_asm(wr[S][I], std::integral_constant<bool, (decltype(sc)::value >= 2)>{});
             const u32x2 codes = {cvt_bf16x4<FW == 1>(wr[S][I].x, wr[S][I].y), cvt_bf16x4<FW == 1>(wr[S][I].z, wr[S][I].w)};
             const uint32_t addr = wbase + wdst[I];
             ds_write64(addr, codes);
@@ -410,8 +464,9 @@ struct LinearFq8R {
         auto one_step = [&](auto sc, int kt, int ahead) __attribute__((always_inline)) {
             // this wave's FP8 codes of step kt are written (lgkmcnt) and its activation pieces have landed: they are older in the
             // vector-memory queue than the weight loads of step kt, which the conversions of the previous step waited for
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NB) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W2 ? kStepWait : 4 + 2 * NB) : "memory");
             __builtin_amdgcn_s_barrier();                    // ... every wave's; and every wave is done with step kt - 1
+            if constexpr (PF > 0) prefetch_w(min(kt + PF, klast));
             const int ka = min(kt + 2, klast), kb = min(kt + ahead, klast);
             const uint32_t sa_ = l0 + a_slot * kABytes, sb_ = w0 + (kt & 1) * kWBytes, ws = w0 + ((kt + 1) & 1) * kWBytes;
             compute(sc, sa_, sb_, ka, l0 + a_tgt * kABytes, ws, kb);
@@ -442,7 +497,7 @@ struct LinearFq8R {
             load_all(kS1, min(1, klast));
             load_all(kS0, min(2, klast));
             int kt = 0;
-            one_step(kS1, kt, 3);
+            one_step(std::integral_constant<int, 2 + (kWSets - 1)>{}, kt, 3);          // (set 1, first step)
             for (kt = 1; kt + 1 < nk; kt += 2) {
                 one_step(kS0, kt, 3);
                 one_step(kS1, kt + 1, 3);
@@ -458,6 +513,7 @@ struct LinearFq8R {
 #pragma unroll
             for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(wr[0][i]), "+v"(wr[kWSets - 1][i]));
         }
+        if constexpr (PF > 0) asm volatile("" : "+v"(pf_sink));          // the prefetch loads' landing register stays reserved until here
         // Overflowed or non-finite weights (and NaN activations) leave NaN / Inf in the accumulators: such a tile is redone
         // by slow_tile.  The workgroup-wide vote goes through LDS (the rings are dead here).
         bool bad = false;

@@ -515,10 +515,10 @@ _LT_ALGO_TABLE = {
     (192, 384, 384, 64, 0, 0): 12,        # BERT-base Q.K^T chain: 56.3 / 66.6
     (192, 384, 64, 384, 1, 0): 5,         # BERT-base P.V chain: 13.5 / 32.6
 }
-# The positions above are positions in the suggestion list of ONE build of the library (hipblasLtGetVersion; ROCm 7.2.0's hipBLASLt
+# The positions above are positions in the suggestion list of ONE build of the library (hipblasLtGetVersion; ROCm 7.2.0: hipblasLtGetVersion = 100000;
 # 1.2.1).  Under any other build the same index would silently name another kernel, so the table is ignored there: every shape runs the
 # library's first suggestion and routes_report() says so ("lt:library_version").
-_LT_ALGO_TABLE_LIBRARY = 100201
+_LT_ALGO_TABLE_LIBRARY = 100000
 LT_ALGOS = {}              # what ran: "bxMxNxK[kn][+bias]" -> index (routes_report)
 _LT_LIBRARY = {"version": None}
 
