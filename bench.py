@@ -223,6 +223,21 @@ def roofline_leg(device, weight_dtype="e4m3", model_shape=(4096, 11008)):
     # round 1, still what every other spec and the pair route run) and the library GEMM it fed are reported beside it.
     tf_, srcf = profiled_traffic(("fused_gemm", "hbm_bytes_per_launch"))
     fused["traffic"], fused["traffic_source"] = tf_, srcf
+    # The matrix core's share of the launch by HARDWARE COUNTER (north_star: "rocprof showing ... MFMA utilisation for the GEMM"):
+    # SQ_VALU_MFMA_BUSY_CYCLES per SIMD (a property of the kernel: instructions x 32 cycles, measured by rocprofv3 --pmc) and the clock the
+    # chip holds inside this kernel on random data (in-kernel stamps), both from profiles/r06_linear_fq8_pmc.json, against THIS run's
+    # launch duration.  `frac` above prices flops / time against 5 PF at the nominal 2.4 GHz; at the clock the part actually holds the
+    # peak is lower by clock / 2400, which `frac_at_held_clock` applies.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_linear_fq8_pmc.json")))
+        busy_us = pmc["mfma_busy_cycles_per_simd"] / pmc["in_kernel_clock_mhz_random"]
+        fused["mfma_busy"] = {"share_of_launch": round(busy_us / (fused["ms_per_launch"] * 1e3), 4), "busy_us": round(busy_us, 2),
+                              "busy_cycles_per_simd": pmc["mfma_busy_cycles_per_simd"], "in_kernel_clock_mhz": pmc["in_kernel_clock_mhz_random"],
+                              "in_kernel_clock_mhz_on_zero_operands": pmc["in_kernel_clock_mhz_zeros"],
+                              "frac_at_held_clock": round(fused["frac"] * 2400.0 / pmc["in_kernel_clock_mhz_random"], 4),
+                              "source": "profiles/r06_linear_fq8_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES; s_memtime / s_memrealtime stamps)"}
+    except Exception:  # noqa: BLE001
+        fused["mfma_busy"] = None
     fused["elementwise_pass"] = pass_leg
     fused["library_gemm"] = lib
     return fused
