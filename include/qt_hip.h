@@ -414,6 +414,24 @@ size_t qt_attention_train_backward_ws_bytes(int heads);
 int qt_linear_fq8_bf16(const uint8_t *x8_dev, int x_format, const uint16_t *const *w_devs, const uint16_t *const *bias_devs,
                        const int *ns, int count, int w_format, uint16_t *y_dev, int M, int K, void *stream);
 
+/* ---- A9 under autograd: the three bf16 GEMMs of a QAT Linear in a TRAINING step (modules/qat/linear.py:40-41 called by
+ * run_glue_no_trainer.py:655-668; the hooks of quantize.py:116-179 have already fake-quantized every operand):
+ *     C[M][N] (bf16) = op(A) . op(B) (+ bias[N], bf16), fp32 accumulation, one rounding
+ *         forward   y  = x  . Wq^T + b     trans_a 0: A = x  [M][K], row stride lda     trans_b 0: B = Wq [N][K], row stride ldb
+ *         dgrad     gx = gy . Wq           trans_a 0: A = gy [M][K]                      trans_b 1: B = Wq [K][N]
+ *         wgrad     gW = gy^T . x          trans_a 1: A = gy [K][M]                      trans_b 1: B = x  [K][N]
+ * `count` (1..4) problems of ONE shape in one launch (query / key / value), each with its own pointers; `problems` is a HOST array.
+ * K % 64 == 0, M % 8 == 0, N % 8 == 0, lda / ldb % 8 == 0, ldc % 4 == 0, a / b 16-byte and c / bias 8-byte aligned -- anything else returns
+ * QT_ERR_BAD_ARG / QT_ERR_UNALIGNED and the caller keeps torch's GEMM.  Deterministic: the order of an element's additions is fixed. */
+typedef struct qt_gemm_problem {
+    const uint16_t *a;
+    const uint16_t *b;
+    const uint16_t *bias;     /* nullable */
+    uint16_t *c;
+} qt_gemm_problem;
+int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
+                       void *stream);
+
 /* Host-only query: how qt_linear_fq8_bf16 (pair 0, n_total = sum n) or qt_mlp_fq8_bf16 (pair 1, n_total = N: the gate / up pairs)
  * cuts a problem on the current device -- tiles_m x tiles_n workgroups of 256 rows x groups_lo..groups_hi 16-column groups (gate and
  * up groups both counted in pair mode) -- and which kernel variant runs it: 0 = two k tiles per step (narrow tiles), 2 / 4 = one

@@ -41,6 +41,11 @@ class QtFaninItem(ctypes.Structure):
                 ("out_dev", ctypes.c_void_p)]
 
 
+class QtGemmProblem(ctypes.Structure):
+    """qt_gemm_problem of include/qt_hip.h"""
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("c", ctypes.c_void_p)]
+
+
 class QtChainStage(ctypes.Structure):
     _fields_ = [("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p), ("out_dev", c_void_p), ("src", ctypes.c_int)]
 
@@ -93,6 +98,7 @@ SIGNATURES = {
     "qt_fake_quant_pc_bf16": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
+    "qt_train_gemm_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, _P]),
     "qt_linear_fq8_plan": (c_int, [c_int, c_long, c_int, c_int, _P, _P, _P, _P, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "qt_fake_quant_chain_bf16": (c_int, [_P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),

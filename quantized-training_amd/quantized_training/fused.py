@@ -76,6 +76,8 @@ def routes_report():
     (bench.py puts them into its JSON line)."""
     out = dict(sorted(ROUTES.items()))
     out.update(sorted(LT_ALGOS.items()))
+    from .modules.qat.linear import GEMM_ROUTES                # the training step's products (csrc/qt_train_gemm.hip or torch's GEMM)
+    out.update(sorted(GEMM_ROUTES.items()))
     return out
 
 

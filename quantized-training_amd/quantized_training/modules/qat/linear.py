@@ -12,6 +12,48 @@ from torch.nn.utils.parametrize import (
 __all__ = ["Linear"]
 
 
+GEMM_ROUTES = {}          # "train:<kind> MxNxK" -> "in_tree_bf16_gemm" | "library_bf16_gemm" (fused.routes_report)
+
+
+def train_gemm_enabled():
+    import os
+    return os.environ.get("QT_TRAIN_GEMM", "1") != "0"
+
+
+def train_gemm_or_none(a, b, bias, trans_a, trans_b, kind):
+    """C = op(a) . op(b) (+ bias) through qt_train_gemm_bf16 (csrc/qt_train_gemm.hip), or None when the kernel does not take the problem
+    (the caller then runs torch's GEMM).  a: [M, K] or, trans_a, [K, M]; b: [N, K] (a Linear weight) or, trans_b, [K, N]."""
+    import ctypes
+    from ... import _native
+    if not (train_gemm_enabled() and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+            and a.stride(1) == 1 and b.stride(1) == 1):
+        return None
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[1] if trans_b else b.shape[0]
+    if (b.shape[0] if trans_b else b.shape[1]) != K:
+        return None
+    ok = (K >= 256 and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+          and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+          and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N and bias.data_ptr() % 8 == 0)))
+    key = f"train:{kind} {M}x{N}x{K}"
+    if not ok:
+        GEMM_ROUTES.setdefault(key, "library_bf16_gemm")
+        return None
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    prob = (_native.QtGemmProblem * 1)()
+    prob[0].a, prob[0].b, prob[0].c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    prob[0].bias = bias.data_ptr() if bias is not None else None
+    _native.note_device(a.device.index)
+    rc = _native.lib().qt_train_gemm_bf16(prob, 1, int(trans_a), int(trans_b), M, N, K, a.stride(0), b.stride(0), N,
+                                          ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED):
+        GEMM_ROUTES.setdefault(key, "library_bf16_gemm")
+        return None
+    _native.check(rc, "qt_train_gemm_bf16")
+    GEMM_ROUTES.setdefault(key, "in_tree_bf16_gemm")
+    return c
+
+
 class _LinearColsumBias(torch.autograd.Function):
     """F.linear whose backward computes the bias gradient -- grad_output.sum(0), on the gradient the backward-pre hook already
     fake-quantized (quantize.py:116-179) -- with qt_colsum_bf16 (fp32 sums in a fixed order, one rounding) instead of torch's generic
@@ -21,6 +63,10 @@ class _LinearColsumBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
+        x2 = x.reshape(-1, x.shape[-1])
+        y = train_gemm_or_none(x2, w, b, False, False, "forward") if x2.is_contiguous() and w.is_contiguous() else None
+        if y is not None:
+            return y.view(*x.shape[:-1], w.shape[0])
         return F.linear(x, w, b)
 
     @staticmethod
@@ -30,10 +76,17 @@ class _LinearColsumBias(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy2 = gy.reshape(-1, gy.shape[-1])
         gx = gw = gb = None
+        x2 = x.reshape(-1, x.shape[-1])
+        gyc = gy2 if gy2.is_contiguous() else None            # (a permuted view: torch's GEMMs take it as it is)
         if ctx.needs_input_grad[0]:
-            gx = gy2.mm(w).view(x.shape)
+            # gx = gy . Wq: the weight is read with its rows as the contraction index (trans_b)
+            gx = train_gemm_or_none(gyc, w, None, False, True, "dgrad") if gyc is not None and w.is_contiguous() else None
+            gx = gx.view(x.shape) if gx is not None else gy2.mm(w).view(x.shape)
         if ctx.needs_input_grad[1]:
-            gw = gy2.t().mm(x.reshape(-1, x.shape[-1]))
+            # gW = gy^T . x: both operands are read with the token index as the contraction index (trans_a, trans_b)
+            gw = train_gemm_or_none(gyc, x2, None, True, True, "wgrad") if gyc is not None and x2.is_contiguous() else None
+            if gw is None:
+                gw = gy2.t().mm(x2)
         if ctx.needs_input_grad[2]:
             from ... import train_fusions
             gb = train_fusions.take_colsum(gy)          # the launch that fake-quantized this gradient summed its columns on the way
@@ -77,9 +130,11 @@ class Linear(nn.Linear):
         # (opt-in) in eval with a frozen / stateless weight fake-quantizer the quantized weight is kept, see fused.py
         wq = cached_weight(self, "dense", lambda: self.weight_fake_quant(self.weight))
         b = self.bias
-        if (b is not None and b.requires_grad and torch.is_grad_enabled() and input.is_cuda and input.dtype == torch.bfloat16
-                and wq.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and self.out_features % 8 == 0):
-            return _LinearColsumBias.apply(input, wq, b)          # training on the device: the bias gradient through qt_colsum_bf16
+        if (torch.is_grad_enabled() and input.is_cuda and input.dtype == torch.bfloat16 and wq.dtype == torch.bfloat16
+                and (b is None or b.dtype == torch.bfloat16) and self.out_features % 8 == 0 and (input.requires_grad or wq.requires_grad)):
+            # training on the device: the three products on the in-tree GEMM (csrc/qt_train_gemm.hip), the bias gradient through
+            # qt_colsum_bf16 or the chain launch that fake-quantized grad_output
+            return _LinearColsumBias.apply(input, wq, b)
         return F.linear(input, wq, b)
 
     @classmethod

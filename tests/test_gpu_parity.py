@@ -2466,6 +2466,86 @@ def test_attention_train_backward_bias_sums_keep_nan(nv, B):
                 assert bool(torch.isfinite(gbias[i].float()).all()), i
 
 
+@pytest.mark.parametrize("layout", ["forward", "dgrad", "wgrad", "tn"])
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2048, 3072, 768), (2048, 768, 3072), (768, 768, 2048), (3072, 768, 2048), (768, 3072, 2048),
+                                   (200, 72, 256), (8, 8, 256), (136, 264, 320), (2048, 2304, 768)])
+def test_train_gemm_against_fp64_products(nv, layout, M, N, K):
+    """qt_train_gemm_bf16, the three products of a QAT Linear under autograd (modules/qat/linear.py:40-41 and its backward): every layout
+    (k-contiguous operands through ds_read_b128, operands with the contraction index as the row index through gfx950's transposing
+    ds_read_b64_tr_b16), the shapes of a RoBERTa-base layer at [16, 128] and ragged ones (partial tiles in both directions), one and
+    three problems per launch, with and without bias: every element within one bf16 rounding of the fp64 product of the same operands
+    plus fp32 accumulation (2^-8 |ref| + 2^-18 sum |a||b|), and run-to-run bit-identical (the order of an element's additions is fixed)."""
+    ta, tb = {"forward": (0, 0), "dgrad": (0, 1), "wgrad": (1, 1), "tn": (1, 0)}[layout]
+    torch.manual_seed(M + N + K)
+    L = nv.lib()
+    count = 3 if (M, N, K) in ((2048, 768, 768), (768, 768, 2048), (200, 72, 256)) else 1
+    As = [(torch.randn((K, M) if ta else (M, K), device="cuda") * 0.5).bfloat16() for _ in range(count)]
+    Bs = [(torch.randn((K, N) if tb else (N, K), device="cuda") * 0.05).bfloat16() for _ in range(count)]
+    biases = [torch.randn(N, device="cuda").bfloat16() if i % 2 == 0 else None for i in range(count)]
+
+    def run():
+        Cs = [torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+        arr = (nv.QtGemmProblem * count)()
+        for i in range(count):
+            arr[i].a, arr[i].b, arr[i].c = As[i].data_ptr(), Bs[i].data_ptr(), Cs[i].data_ptr()
+            arr[i].bias = biases[i].data_ptr() if biases[i] is not None else None
+        nv.check(L.qt_train_gemm_bf16(arr, count, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()), "qt_train_gemm_bf16")
+        return Cs
+    first, again = run(), run()
+    for i in range(count):
+        a = (As[i].t() if ta else As[i]).double()
+        b = (Bs[i] if tb else Bs[i].t()).double()
+        ref = a @ b + (biases[i].double() if biases[i] is not None else 0.0)
+        tol = ref.abs() * 2.0 ** -8 + (a.abs() @ b.abs()) * 2.0 ** -18 + 1e-30
+        err = (first[i].double() - ref).abs()
+        assert bool((err <= tol).all()), (i, float((err / tol).max()))
+        assert torch.equal(first[i].view(torch.int16), again[i].view(torch.int16))
+    # what it refuses (the caller keeps torch's GEMM)
+    arr = (nv.QtGemmProblem * 1)()
+    arr[0].a, arr[0].b, arr[0].c = As[0].data_ptr(), Bs[0].data_ptr(), first[0].data_ptr()
+    assert L.qt_train_gemm_bf16(arr, 1, ta, tb, M, N, 96, As[0].stride(0), Bs[0].stride(0), N, stream()) == nv.QT_ERR_BAD_ARG       # K % 64, K < 256
+    assert L.qt_train_gemm_bf16(arr, 5, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()) == nv.QT_ERR_BAD_ARG
+    arr[0].a = As[0].data_ptr() + 2
+    assert L.qt_train_gemm_bf16(arr, 1, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()) == nv.QT_ERR_UNALIGNED
+
+
+def test_qat_linear_training_products_run_in_tree_and_match_autograd(nv, monkeypatch):
+    """A QAT Linear under autograd on the device: forward, input gradient and weight gradient through qt_train_gemm_bf16 (routes_report
+    says so), against the same layer with QT_TRAIN_GEMM=0 (torch's GEMMs): every result within two bf16 roundings of each other, the
+    bias gradient identical (it does not come from a GEMM)."""
+    import quantized_training as qt_pkg
+    from quantized_training import fused
+    from quantized_training.modules.qat import linear as qlin
+    torch.manual_seed(5)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QT_TRAIN_GEMM", mode)
+        qlin.GEMM_ROUTES.clear()
+        torch.manual_seed(5)
+        lin = torch.nn.Linear(768, 3072).cuda().bfloat16()
+        model = torch.nn.Sequential(lin)
+        args = qt_pkg.add_qspec_args().parse_args(["--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
+                                                   "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm",
+                                                   "--quantize_backprop", "gemm", "--bf16"])
+        qt_pkg.quantize(model, args)
+        model.train()
+        x = torch.randn(16, 128, 768, device="cuda").bfloat16().requires_grad_(True)
+        for _ in range(2):                              # the second step runs with real scales
+            model.zero_grad(set_to_none=True)
+            x.grad = None
+            y = model(x)
+            (y.float() * torch.linspace(-1, 1, 3072, device="cuda")).mean().backward()
+        res[mode] = (y.detach().float(), x.grad.float(), model[0].weight.grad.float(), model[0].bias.grad.float(), dict(fused.routes_report()))
+    routes = res["1"][4]
+    for kind, shape in (("forward", "2048x3072x768"), ("dgrad", "2048x768x3072"), ("wgrad", "3072x768x2048")):
+        assert routes.get(f"train:{kind} {shape}") == "in_tree_bf16_gemm", routes
+    assert not any(k.startswith("train:") for k in res["0"][4])
+    for i, name in enumerate(("output", "input gradient", "weight gradient")):
+        a, b = res["1"][i], res["0"][i]
+        assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2.0 ** -10 * float(b.abs().max())).all()), (name, float((a - b).abs().max()))
+    assert torch.equal(res["1"][3], res["0"][3])
+
+
 @pytest.mark.parametrize("n,kinds", [(2048 * 768, (1, 1, 1)), (2048 * 768, (1,)), (37 * 264, (0, 1, 1, 0)), (8 * 8, (0, 0))])
 def test_grad_fanin_equals_the_fake_quantizer_launches_and_torch_adds(nv, n, kinds):
     """qt_grad_fanin_bf16: sum = (((first + y_0) + y_1) + ...) with y_i = fq_i(x_i) (kind 1) or x_i (kind 0) is bit for bit what the
