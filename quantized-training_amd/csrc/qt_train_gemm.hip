@@ -282,23 +282,24 @@ int launch_tile(Args &a, hipStream_t st) {
     return e == hipSuccess ? QT_OK : (int)e;
 }
 
-// Tile choice: the largest tile that still gives the launch a workgroup for (almost) every CU; small tiles move more operand bytes per
-// flop through each CU's L1, large ones leave CUs idle.  A fixed rule of the problem sizes and the CU count: no timing, every process
-// and rank cuts a shape the same way.
-void pick_tile(const Args &a, int &bm, int &bn) {
+// Tile choice, a fixed rule of the layout, the problem sizes and the CU count (no timing: every process and rank cuts a shape the same
+// way), from the sweep in profiles/r06_train_gemm.txt: every tile shape lands within 15 % of the others -- what paces these launches is
+// the rate at which a CU's LDS-DMA requests are served (about 30-60 GB/s per CU), not the tile -- and the best of them is
+//   k-contiguous A (forward, dgrad):  128 x 64 tiles (two workgroups per CU) where they give at least half a workgroup per CU, else 64 x 64;
+//   transposed A (wgrad):             128 x 128 tiles under the same condition (3072 x 768: 144 tiles), else 64 x 64 (768 x 768: 144 tiles).
+// A 256 x 128 tile and whole-CU rings of 6-8 stages were built and measured too: no faster (19.4 against 19.0 us at 2048 x 3072 x 768).
+void pick_tile(const Args &a, bool trans_a, int &bm, int &bn) {
     const int cus = cu_count();
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    bm = 64; bn = 64;
-    for (int i = 0; i < 4; ++i) {
-        const long tiles = (long)a.count * ((a.M + cand[i][0] - 1) / cand[i][0]) * ((a.N + cand[i][1] - 1) / cand[i][1]);
-        if (tiles * 8 >= (long)cus * 7) { bm = cand[i][0]; bn = cand[i][1]; return; }
-    }
+    const int big_m = 128, big_n = trans_a ? 128 : 64;
+    const long tiles = (long)a.count * ((a.M + big_m - 1) / big_m) * ((a.N + big_n - 1) / big_n);
+    if (tiles * 2 >= cus) { bm = big_m; bn = big_n; }
+    else { bm = 64; bn = 64; }
 }
 
 template <bool TA, bool TB>
 int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
     int bm, bn;
-    pick_tile(a, bm, bn);
+    pick_tile(a, TA, bm, bn);
     if (force_bm) bm = force_bm;
     if (force_bn) bn = force_bn;
     if (bm == 128 && bn == 128) return launch_tile<TA, TB, 128, 128>(a, st);
