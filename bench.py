@@ -150,7 +150,7 @@ def profiled_traffic(key):
     """HBM bytes per launch of the roofline kernels from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE x 2 on gfx950 as the microarchitecture guide prescribes).  Collected by
     tools/gpu_session_prof.sh on the same launch, NOT in this run: the JSON names the file next to the number."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:

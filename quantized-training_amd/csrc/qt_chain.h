@@ -177,6 +177,11 @@ __device__ __forceinline__ void chain_stages(const ChainStageDev (&st)[kChainMax
     }
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence over ALL address spaces: it waits for every global store
+// the wave has in flight (s_waitcnt vmcnt(0)) -- behind a kernel's result stores that is a full store round trip (1-2 us) in front of
+// every LDS exchange.  Nothing that meets in LDS below (amax slots, column partials) depends on another wave's GLOBAL accesses.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // amax of every stage: wave, workgroup (LDS [NS][BLOCK / 64]), then at most one atomic per stage and workgroup
 template <int NS, int BLOCK>
 __device__ __forceinline__ void chain_amax_commit(const ChainStageDev (&st)[kChainMax], const uint32_t (&amax)[NS], uint32_t (*s_amax)[BLOCK / 64]) {
@@ -186,7 +191,7 @@ __device__ __forceinline__ void chain_amax_commit(const ChainStageDev (&st)[kCha
         const uint32_t m = wave_max_u32(amax[i]);
         if (lane == 0) s_amax[i][wave] = m;
     }
-    __syncthreads();
+    lds_only_barrier();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (t == i * 64 && st[i].amax) {                         // one lane of wave i

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
             const int r = i / kC, c = i % kC;
             s_col[r][c] += s_col[r + half][c];
         }
-        __syncthreads();
+        lds_only_barrier();                                         // (six rounds: none of them waits for the result stores in flight)
     }
     float s_cs = 1.0f;
 #pragma unroll
@@ -540,22 +540,23 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
         fsc[i] = (i < a.nfan && a.fan[i].src && a.fan[i].scale) ? qt_bf2f(qt_f2bf(*a.fan[i].scale)) : 1.0f;
         famax[i] = 0u;
     }
-    float dg[kLnMaxVec][8], db[kLnMaxVec][8], cs[kLnMaxVec][8];
+    // One row per wave (qt_layernorm_train_backward_groups).  The row's dy, x^ and the column-sum stage's result stay in registers until
+    // the waves' column partials meet in LDS below: rounds 4-5 also carried three loop accumulators for "rows_per_wave" rows that the host
+    // never asked for -- 48 registers that pushed the four-stage kernel to 256 VGPRs and 18 spilled ones (scratch traffic in the hot loop).
+    float xh[kLnMaxVec][8], dyv[kLnMaxVec][8], csv[kLnMaxVec][8];
 #pragma unroll
     for (int i = 0; i < kLnMaxVec; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = cs[i][e] = 0.0f;
+        for (int e = 0; e < 8; ++e) xh[i][e] = dyv[i][e] = csv[i][e] = 0.0f;
     uint4 gam[kLnMaxVec];
 #pragma unroll
     for (int i = 0; i < kLnMaxVec; ++i)
         if (lane + i * 64 < a.nvec) gam[i] = a.w[lane + i * 64];
-    const long band0 = (long)blockIdx.x * RPB * a.rows_per_wave;
-    for (int k = 0; k < a.rows_per_wave; ++k) {
-        const long row = band0 + (long)k * RPB + wave;
-        if (row >= a.rows) break;                                  // (wave-uniform)
+    const long row = (long)blockIdx.x * RPB + wave;
+    if (row < a.rows) {                                            // (wave-uniform)
         const size_t base = (size_t)row * (size_t)a.nvec;
         const float mean = a.mean[row], rstd = a.rstd[row];
-        float xh[kLnMaxVec][8], g[kLnMaxVec][8], dyv[kLnMaxVec][8];
+        float g[kLnMaxVec][8];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < kLnMaxVec; ++i) {
@@ -618,18 +619,13 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
                 uint4 res[NS];
                 chain_stages<KIND, NS>(a.st, sc, rnd, dxv, base + c, amax, res);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    dg[i][e] += dyv[i][e] * xh[i][e];
-                    db[i][e] += dyv[i][e];
-                }
-#pragma unroll
                 for (int s_ = 0; s_ < NS; ++s_) {
                     if (a.colsum_stage == s_) {
                         const uint32_t rw[4] = {res[s_].x, res[s_].y, res[s_].z, res[s_].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            cs[i][2 * j] += bf_lo(rw[j]);
-                            cs[i][2 * j + 1] += bf_hi(rw[j]);
+                            csv[i][2 * j] = bf_lo(rw[j]);
+                            csv[i][2 * j + 1] = bf_hi(rw[j]);
                         }
                     }
                 }
@@ -647,15 +643,15 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
 #pragma unroll
         for (int i = 0; i < kLnMaxVec; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s_red[wave][(lane + i * 64) * 8 + e] = qn == 0 ? dg[i][e] : (qn == 1 ? db[i][e] : cs[i][e]);
-        __syncthreads();
+            for (int e = 0; e < 8; ++e) s_red[wave][(lane + i * 64) * 8 + e] = qn == 0 ? dyv[i][e] * xh[i][e] : (qn == 1 ? dyv[i][e] : csv[i][e]);
+        lds_only_barrier();                                         // (not __syncthreads: the row's result stores stay in flight)
         for (int c = threadIdx.x; c < cols; c += BLOCK) {
             float sum = 0.0f;
 #pragma unroll
             for (int w = 0; w < RPB; ++w) sum += s_red[w][c];
             mine[(size_t)qn * cols + c] = sum;
         }
-        __syncthreads();
+        lds_only_barrier();
     }
     chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
     if (a.nfan > 0) {                                              // (uniform) the amax slots of the arrivals' fake-quantizers
