@@ -92,6 +92,7 @@ class _LinearColsumBias(torch.autograd.Function):
             gb = train_fusions.take_colsum(gy)          # the launch that fake-quantized this gradient summed its columns on the way
             if gb is not None:
                 return gx, gw, gb
+            train_fusions.STATS.colsum_fallbacks += 1
             g = gy2 if gy2.is_contiguous() else gy2.contiguous()
             if g.dtype != torch.bfloat16 or g.data_ptr() % 16 or g.shape[1] % 8 or g.shape[0] == 0:
                 gb = gy2.sum(0)                         # a view at an odd storage offset, another dtype: what F.linear's backward does

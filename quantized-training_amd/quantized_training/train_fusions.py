@@ -37,6 +37,7 @@ class _Counters:
     chains = 0            # chain launches
     members = 0           # fake-quantizer calls served by a chain launch (heads included)
     colsums = 0           # bias gradients handed over
+    colsum_fallbacks = 0  # bias gradients a Linear summed itself (qt_colsum_bf16: no launch had left them)
     misses = 0            # members that received another tensor than predicted
     attention = 0         # attention-core launches (forward or backward), each standing for 4 / 2 fake-quantizer calls
     fanins = 0            # gradient fan-in launches (qt_grad_fanin_bf16)
@@ -47,7 +48,7 @@ class _Counters:
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = 0
+        cls.chains = cls.members = cls.colsums = cls.colsum_fallbacks = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = 0
         cls.missed = []
 
 

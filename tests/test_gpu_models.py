@@ -541,19 +541,22 @@ def test_graphed_training_step_equals_eager_steps_where_the_fused_kernels_engage
                 if i == 1:
                     train_fusions.ensure_planned(m)     # (GraphedTrainStep.capture plans after its first warm-up step)
                 opt.zero_grad(set_to_none=True)
+                train_fusions.STATS.reset()
                 loss = m(**b).loss
                 loss.backward()
                 torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0, error_if_nonfinite=False)
                 opt.step()
                 losses.append(float(loss.detach()))
             losses = losses[3:]
+            eager_last = dict(colsums=train_fusions.STATS.colsums, colsum_fallbacks=train_fusions.STATS.colsum_fallbacks,
+                              chains=train_fusions.STATS.chains, misses=train_fusions.STATS.misses)
         else:
             losses = []
             step = Probe(m, opt)
             step.capture(batches[0], warmup=3)
             T = train_fusions.STATS
             captured = dict(attention=T.attention, fanins=T.fanins, embeddings=T.embeddings, addlns=T.addlns, chains=T.chains, misses=T.misses,
-                            deferred=T.deferred, colsums=T.colsums)
+                            deferred=T.deferred, colsums=T.colsums, colsum_fallbacks=T.colsum_fallbacks)
             for b in batches[1:]:
                 losses.append(float(step.replay(b)))
         state = {n: (mod.scale.detach().clone(), mod.amax_history.detach().clone()) for n, mod in m.named_modules()
@@ -562,7 +565,9 @@ def test_graphed_training_step_equals_eager_steps_where_the_fused_kernels_engage
         torch.cuda.synchronize()
         dirty = {str(k): int(v.count_nonzero()) for k, v in train_fusions._SCRATCH.items() if int(v.count_nonzero())}
         assert not dirty, (mode, "a launch left the shared column-sum scratch non-zero", dirty)
-    print(f"\n[graph == eager, {size}, dropout {drop}] captured pass: {captured}")
+    print(f"\n[graph == eager, {size}, dropout {drop}] captured pass: {captured}; last eager step: {eager_last}")
+    # the bias gradients of both modes come from the same launches (a Linear that sums its own takes another order of additions)
+    assert captured["colsums"] == eager_last["colsums"] and captured["colsum_fallbacks"] == eager_last["colsum_fallbacks"], (captured, eager_last)
     layers = cfg.num_hidden_layers
     if drop == 0.0:
         assert captured["attention"] == 2 * layers and captured["fanins"] > 0 and captured["addlns"] > 0, captured
