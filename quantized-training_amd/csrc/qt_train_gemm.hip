@@ -255,6 +255,40 @@ __global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
     }
 }
 
+// ---- skinny forward products (a classifier head: [16, 768] -> [16, 2]).  hipBLASLt runs such a shape as a split-K kernel whose partial
+// sums meet through atomics: the order of the additions, and now and then the last bit of a logit, changes from launch to launch -- the
+// one GEMM of the training step that is not bit-reproducible (profiles/r06_graph_eager_determinism.txt).  One wave per output element,
+// lanes stride over k, a fixed-order butterfly: deterministic, and at M N <= 4096 a few microseconds.
+struct SkinnyArgs {
+    const uint16_t *a, *b, *bias;
+    uint16_t *c;
+    int M, N, K;
+    long lda, ldb, ldc;
+};
+__global__ __launch_bounds__(256) void train_gemm_skinny_kernel(SkinnyArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long out = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (out >= (long)a.M * a.N) return;                                 // (wave-uniform)
+    const int m = (int)(out / a.N), n = (int)(out % a.N);
+    const uint16_t *x = a.a + (long)m * a.lda, *w = a.b + (long)n * a.ldb;
+    float acc = 0.0f;
+    for (int k = lane * 8; k < a.K; k += 64 * 8) {
+        const uint4 xv = *(const uint4 *)(x + k), wv = *(const uint4 *)(w + k);
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = fmaf(qt_u2f(xw[j] << 16), qt_u2f(ww[j] << 16), acc);
+            acc = fmaf(qt_u2f(xw[j] & 0xFFFF0000u), qt_u2f(ww[j] & 0xFFFF0000u), acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        if (a.bias) acc += qt_u2f((uint32_t)a.bias[n] << 16);
+        a.c[(long)m * a.ldc + n] = (uint16_t)(pack_bf16x2(acc, 0.0f) & 0xFFFFu);
+    }
+}
+
 int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -316,6 +350,17 @@ int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, 
                        void *stream) {
     if (!problems || count < 1 || count > kMaxProblems || M < 0 || N < 0 || K < 0) return QT_ERR_BAD_ARG;
     if ((long)M * N == 0) return QT_OK;
+    if (!trans_a && !trans_b && count == 1 && (N < 8 || N % 8 != 0) && (long)M * N <= 4096) {
+        // a skinny forward product (classifier heads): the deterministic one-wave-per-output kernel
+        const qt_gemm_problem &p = problems[0];
+        if (!p.a || !p.b || !p.c || K < 8 || K % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return QT_ERR_BAD_ARG;
+        if (((uintptr_t)p.a | (uintptr_t)p.b) & 15u) return QT_ERR_UNALIGNED;
+        if (((uintptr_t)p.c | (uintptr_t)p.bias) & 1u) return QT_ERR_UNALIGNED;
+        const SkinnyArgs sa{p.a, p.b, p.bias, p.c, M, N, K, lda, ldb, ldc};
+        train_gemm_skinny_kernel<<<(unsigned)(((long)M * N + 3) / 4), 256, 0, (hipStream_t)stream>>>(sa);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? QT_OK : (int)e;
+    }
     // (what the package's callers check before they come here; anything else keeps the library GEMM)
     if (K < 4 * kBK || K % kBK != 0 || M % 8 != 0 || N % 8 != 0 || M < 8 || N < 8 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) return QT_ERR_BAD_ARG;
     Args a{};

@@ -32,9 +32,11 @@ def train_gemm_or_none(a, b, bias, trans_a, trans_b, kind):
     N = b.shape[1] if trans_b else b.shape[0]
     if (b.shape[0] if trans_b else b.shape[1]) != K:
         return None
-    ok = (K >= 256 and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
-          and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
-          and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N and bias.data_ptr() % 8 == 0)))
+    skinny = not trans_a and not trans_b and (N < 8 or N % 8 != 0) and M * N <= 4096          # a classifier head: one wave per output, deterministic
+    ok = (a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+          and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N
+                                and bias.data_ptr() % (2 if skinny else 8) == 0))
+          and ((K >= 8 and K % 8 == 0) if skinny else (K >= 256 and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8)))
     key = f"train:{kind} {M}x{N}x{K}"
     if not ok:
         GEMM_ROUTES.setdefault(key, "library_bf16_gemm")
@@ -132,7 +134,7 @@ class Linear(nn.Linear):
         wq = cached_weight(self, "dense", lambda: self.weight_fake_quant(self.weight))
         b = self.bias
         if (torch.is_grad_enabled() and input.is_cuda and input.dtype == torch.bfloat16 and wq.dtype == torch.bfloat16
-                and (b is None or b.dtype == torch.bfloat16) and self.out_features % 8 == 0 and (input.requires_grad or wq.requires_grad)):
+                and (b is None or b.dtype == torch.bfloat16) and (input.requires_grad or wq.requires_grad)):
             # training on the device: the three products on the in-tree GEMM (csrc/qt_train_gemm.hip), the bias gradient through
             # qt_colsum_bf16 or the chain launch that fake-quantized grad_output
             return _LinearColsumBias.apply(input, wq, b)

@@ -2509,6 +2509,32 @@ def test_train_gemm_against_fp64_products(nv, layout, M, N, K):
     assert L.qt_train_gemm_bf16(arr, 1, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()) == nv.QT_ERR_UNALIGNED
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 2, 768), (16, 3, 1024), (128, 5, 64), (1, 1, 8)])
+def test_train_gemm_skinny_forward_is_deterministic_and_exact(nv, M, N, K):
+    """A classifier head's forward product ([16, 768] -> [16, 2], run_glue_no_trainer.py's RobertaClassificationHead.out_proj): the library
+    runs such a shape as a split-K kernel whose partial sums meet through atomics, so the last bit of a logit can change from launch to
+    launch; qt_train_gemm_bf16 takes N < 8 (or N % 8 != 0) at M N <= 4096 on a one-wave-per-output kernel with a fixed order of additions:
+    within one bf16 rounding of the fp64 product, and 50 launches bit-identical."""
+    torch.manual_seed(M * N + K)
+    L = nv.lib()
+    a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    b = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    bias = torch.randn(N, device="cuda").bfloat16()
+    outs = []
+    for i in range(50):
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        arr = (nv.QtGemmProblem * 1)()
+        arr[0].a, arr[0].b, arr[0].bias, arr[0].c = a.data_ptr(), b.data_ptr(), bias.data_ptr(), c.data_ptr()
+        nv.check(L.qt_train_gemm_bf16(arr, 1, 0, 0, M, N, K, K, K, N, stream()), "qt_train_gemm_bf16")
+        outs.append(c)
+    ref = a.double() @ b.double().t() + bias.double()
+    tol = ref.abs() * 2.0 ** -8 + (a.double().abs() @ b.double().abs().t()) * 2.0 ** -18 + 1e-30
+    assert bool(((outs[0].double() - ref).abs() <= tol).all())
+    assert all(torch.equal(outs[0].view(torch.int16), o_.view(torch.int16)) for o_ in outs[1:])
+    arr[0].a = a.data_ptr()
+    assert L.qt_train_gemm_bf16(arr, 1, 0, 1, M, N, K, K, K, N, stream()) == nv.QT_ERR_BAD_ARG        # only the forward layout is taken skinny
+
+
 def test_qat_linear_training_products_run_in_tree_and_match_autograd(nv, monkeypatch):
     """A QAT Linear under autograd on the device: forward, input gradient and weight gradient through qt_train_gemm_bf16 (routes_report
     says so), against the same layer with QT_TRAIN_GEMM=0 (torch's GEMMs): every result within two bf16 roundings of each other, the
