@@ -4,18 +4,17 @@
 // quantize.py:116-179): per layer and step one forward product and, in the backward, the input gradient and the weight gradient -- on
 // operands the fake-quantizers have already rounded (bf16 VALUES of int8 / E5M2 codes times a scale).  Rounds 1-5 ran those 18 products
 // per encoder layer on hipBLASLt: 216 launches of 12-28 us for 2.4-9.7 GFLOP each (0.08-0.2 of the bf16 peak: launch- and tile-
-// quantisation-bound), with q / k / v as three launches per direction, and -- measured in round 6 -- a replayed graph of the step that
-// now and then differed from the eager loop in the last bits.  Here:
+// quantisation-bound), with q / k / v as three launches per direction.  Here:
 //     C[M][N] (bf16) = op(A) . op(B) (+ bias[N]),   fp32 accumulation on v_mfma_f32_16x16x32_bf16, ONE rounding to bf16
 //         forward   y  = x  . Wq^T + b     A = x  [M][K]  (k contiguous)            B = Wq [N][K]  (k contiguous)
 //         dgrad     gx = gy . Wq           A = gy [M][K]  (k contiguous)            B = Wq [K][N]  (n contiguous: trans_b)
 //         wgrad     gW = gy^T . x          A = gy [K][M]  (m contiguous: trans_a)   B = x  [K][N]  (n contiguous: trans_b)
-// for up to four problems of ONE shape per launch (query / key / value: same x, three weights -- one launch each way instead of three).
-// The summation order of an output element is fixed by the tile walk (k tiles in ascending order, 32 products per matrix instruction):
-// run-to-run and eager-vs-graph bit-identical by construction.
+// for up to four problems of ONE shape per launch (query / key / value: 16.9 us for the three against 3 x 7.7; the package still issues them
+// one by one -- under autograd the three calls arrive at different times).  The summation order of an output element is fixed by the
+// tile walk (k tiles in ascending order, 32 products per matrix instruction): the same bits on every launch.
 //
-// Work decomposition.  A workgroup of 512 threads (8 waves, 4 x 2) owns a BM x BN tile, BM, BN in {64, 128} picked on the host so that
-// the launch has at least ~one workgroup per CU where the problem allows; k tiles of 64 through an LDS ring of 3-4 stages filled by
+// Work decomposition.  A workgroup of 512 threads (8 waves, 4 x 2) owns a BM x BN tile -- 128 x 64, 128 x 128 or 64 x 64 by a fixed rule
+// of the layout and the problem size (pick_tile) --; k tiles of 64 through an LDS ring of 3-4 stages filled by
 // LDS-DMA (global_load_lds_dwordx4, hand-counted vmcnt: two or three k tiles in flight per workgroup), one barrier per k tile.
 // Operands whose contraction index is contiguous are staged as [rows][64 k] images of 128-byte rows (16-byte chunks XOR-swizzled by
 // (row >> 1) & 7, one ds_read_b128 per fragment).  Operands stored with the contraction index as the ROW index (trans_a / trans_b) are
