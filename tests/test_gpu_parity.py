@@ -3007,6 +3007,55 @@ def test_linear_fqt_vs_fp64_product_of_the_quantized_operands(nv, M, Ns, K, dtyp
     assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() / tol).max())
 
 
+# every problem shape the value-map GEMM's route rule (fused.fqt_route_is_fused) sends to it in BASELINE's configs: configs[3] (LLaMA-2-13B,
+# posit(8,2)) and a 7B-shaped model under a table format -- (M, [n per weight], K)
+_FQT_ROUTE_SHAPES = [(1024, [5120, 5120, 5120], 5120), (1024, [13824, 13824], 5120), (1024, [5120], 13824), (1024, [32000], 5120), (1024, [5120], 5120),
+                     (1024, [4096, 4096, 4096], 4096), (1024, [11008, 11008], 4096), (1024, [4096], 11008), (1024, [4096], 4096), (1024, [32000], 4096)]
+
+
+@pytest.mark.parametrize("wdtype", ["posit8_2", "int8"])
+@pytest.mark.parametrize("M,Ns,K", _FQT_ROUTE_SHAPES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_linear_fqt_every_routed_shape_on_all_weight_patterns(nv, M, Ns, K, wdtype):
+    """qt_linear_fqt_ws_bf16 at the FULL shapes the route rule hands to it (the shapes are enumerated, the rule decides which of them run
+    here: the others are skipped) -- so the tile cut and the split-K plan are the ones the window runs (three workgroups per tile at the
+    13B down projection, four at the 7B one, none for the wide outputs; sibling launches of two and three weights).  Identity activation
+    placed at a k offset inside the LAST k range (so a split's partial sums travel through the workspace and the tile's redo is decided
+    by whichever workgroup draws the last ticket): y[m][n] = fq(W)[n][k0 + m], compared bit for bit with the ORACLE's value map for
+    weights that cycle through all 65 536 bf16 patterns (non-finite ones zeroed, then raw: rows holding +-Inf / NaN must be all-NaN)."""
+    from quantized_training import fused
+    if not fused.fqt_route_is_fused(M, Ns, K, torch.device("cuda")):
+        pytest.skip("the route rule keeps this shape on the weight pass + library GEMM")
+    N = sum(Ns)
+    ks = _fqt_plan(nv, M, N, K)[0]
+    k0 = K - M if K > M else 0
+    rows = min(M, K)
+    x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+    x[torch.arange(rows), k0 + torch.arange(rows)] = 1.0
+    qmap = o.get_quantization_map(wdtype)
+    pats = np.arange(65536, dtype=np.uint16)
+    raw = o.bf16_to_f32(pats)
+    sane = pats.copy()
+    sane[~np.isfinite(raw)] = 0
+    torch.manual_seed(K)
+    for name, bits in (("sane", sane), ("raw", pats)):
+        ws, exp_parts = [], []
+        for i, n in enumerate(Ns):
+            W = (torch.randn(n, K, device="cuda") * 0.05).bfloat16()
+            blk = np.resize(np.roll(bits, 977 * i), n * rows).astype(np.uint16).reshape(n, rows)
+            W[:, k0:k0 + rows] = torch.from_numpy(blk.view(np.int16).copy()).cuda().view(torch.bfloat16)
+            ws.append(W)
+            exp_parts.append(o.canon_nan16(o.vmap_bf16(blk, qmap)))
+        exp = np.concatenate(exp_parts)                                  # [N][rows]
+        y = _linear_fqt(nv, x, ws, wdtype)
+        got = o.canon_nan16(host_u16(y[:rows].t().contiguous().view(torch.int16)))
+        nan_rows = (exp == 0x7FC0).any(axis=1)
+        same = (got == exp) | (((got | exp) & 0x7FFF) == 0)
+        assert same[~nan_rows].all(), (name, ks, int((~same[~nan_rows]).sum()), np.argwhere(~same & ~nan_rows[:, None])[:4].tolist())
+        assert (got[nan_rows] == 0x7FC0).all(), (name, ks)
+        assert (nan_rows.sum() > 0) == (name == "raw" and bool((o.canon_nan16(qmap) == 0x7FC0).any()))
+    print(f"[fqt route] {M}x{Ns}x{K} {wdtype}: split-K {ks}")
+
+
 def test_linear_fqt_split_k_plan_and_workspace_contract(nv):
     """qt_linear_fqt_plan: no split for wide outputs or short K; 3 workgroups per tile at the 13B down projection, 4 at the 7B one;
     qt_linear_fqt_ws_bf16 refuses a workspace smaller than the plan's instead of writing past it."""
