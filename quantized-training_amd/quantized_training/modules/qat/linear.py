@@ -56,6 +56,37 @@ def train_gemm_or_none(a, b, bias, trans_a, trans_b, kind):
     return c
 
 
+def train_gemm_group(As, Bs, trans_a, trans_b, kind):
+    """Up to four products of ONE shape as one launch of qt_train_gemm_bf16 (query / key / value: the three input gradients, the three
+    weight gradients); returns the list of results, or None when the kernel does not take the problems."""
+    import ctypes
+    from ... import _native
+    n = len(As)
+    if not (train_gemm_enabled() and 1 <= n <= 4 and len(Bs) == n):
+        return None
+    a0, b0 = As[0], Bs[0]
+    for a, b in zip(As, Bs):
+        if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.is_contiguous()
+                and b.is_contiguous() and a.shape == a0.shape and b.shape == b0.shape and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+            return None
+    M, K = (a0.shape[1], a0.shape[0]) if trans_a else (a0.shape[0], a0.shape[1])
+    N = b0.shape[1] if trans_b else b0.shape[0]
+    if (b0.shape[0] if trans_b else b0.shape[1]) != K or not (K >= 256 and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8):
+        return None
+    Cs = [torch.empty((M, N), dtype=torch.bfloat16, device=a0.device) for _ in range(n)]
+    prob = (_native.QtGemmProblem * n)()
+    for i in range(n):
+        prob[i].a, prob[i].b, prob[i].bias, prob[i].c = As[i].data_ptr(), Bs[i].data_ptr(), None, Cs[i].data_ptr()
+    _native.note_device(a0.device.index)
+    rc = _native.lib().qt_train_gemm_bf16(prob, n, int(trans_a), int(trans_b), M, N, K, a0.stride(0), b0.stride(0), N,
+                                          ctypes.c_void_p(torch.cuda.current_stream(a0.device).cuda_stream))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED):
+        return None
+    _native.check(rc, "qt_train_gemm_bf16")
+    GEMM_ROUTES.setdefault(f"train:{kind} {n}x({M}x{N}x{K})", "in_tree_bf16_gemm, one launch")
+    return Cs
+
+
 class _LinearColsumBias(torch.autograd.Function):
     """F.linear whose backward computes the bias gradient -- grad_output.sum(0), on the gradient the backward-pre hook already
     fake-quantized (quantize.py:116-179) -- with qt_colsum_bf16 (fp32 sums in a fixed order, one rounding) instead of torch's generic
@@ -80,11 +111,19 @@ class _LinearColsumBias(torch.autograd.Function):
         gx = gw = gb = None
         x2 = x.reshape(-1, x.shape[-1])
         gyc = gy2 if gy2.is_contiguous() else None            # (a permuted view: torch's GEMMs take it as it is)
-        if ctx.needs_input_grad[0]:
+        from ... import train_fusions
+        done = train_fusions.take_linear_grads(gy, x, w)      # query / key / value: the attention backward launched all six products as two
+        if done is not None:
+            gx, gw = done
+            if not ctx.needs_input_grad[0]:
+                gx = None
+            if not ctx.needs_input_grad[1]:
+                gw = None
+        if done is None and ctx.needs_input_grad[0]:
             # gx = gy . Wq: the weight is read with its rows as the contraction index (trans_b)
             gx = train_gemm_or_none(gyc, w, None, False, True, "dgrad") if gyc is not None and w.is_contiguous() else None
             gx = gx.view(x.shape) if gx is not None else gy2.mm(w).view(x.shape)
-        if ctx.needs_input_grad[1]:
+        if done is None and ctx.needs_input_grad[1]:
             # gW = gy^T . x: both operands are read with the token index as the contraction index (trans_a, trans_b)
             gw = train_gemm_or_none(gyc, x2, None, True, True, "wgrad") if gyc is not None and x2.is_contiguous() else None
             if gw is None:
@@ -137,6 +176,10 @@ class Linear(nn.Linear):
                 and (b is None or b.dtype == torch.bfloat16) and (input.requires_grad or wq.requires_grad)):
             # training on the device: the three products on the in-tree GEMM (csrc/qt_train_gemm.hip), the bias gradient through
             # qt_colsum_bf16 or the chain launch that fake-quantized grad_output
+            # what the backward will multiply with, for train_fusions.group_qkv_backward -- weak references: the autograd node keeps both
+            # alive until its backward has run, and nothing here may extend the life of a step's tensors (or of its autograd graph)
+            import weakref
+            self.__dict__["_qt_train_xw"] = (weakref.ref(input), weakref.ref(wq))
             return _LinearColsumBias.apply(input, wq, b)
         return F.linear(input, wq, b)
 

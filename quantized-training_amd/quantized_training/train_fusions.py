@@ -44,11 +44,12 @@ class _Counters:
     deferred = 0          # backward fake-quantizer calls evaluated inside a fan-in launch
     embeddings = 0        # embedding weight gradients by qt_embedding_backward_bf16
     addlns = 0            # residual adds formed inside a LayerNorm launch
+    qkv_groups = 0        # query / key / value backward products launched as one dgrad + one wgrad launch
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.colsum_fallbacks = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = 0
+        cls.chains = cls.members = cls.colsums = cls.colsum_fallbacks = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = cls.qkv_groups = 0
         cls.missed = []
 
 
@@ -63,7 +64,8 @@ STATS = _Counters
 #  16 fanin      one fake-quantizer launch and one add per gradient arriving at a LayerNorm output (implies addln)
 #  32 embedding  torch's embedding_dense_backward
 #  64 addln      the residual add in front of a LayerNorm as its own launch
-DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64}
+# 128 qkvgemm    the input and weight gradients of query / key / value as six launches instead of two
+DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128}
 
 
 def _on(name):
@@ -99,6 +101,57 @@ def put_colsum(g, gb):
     while len(_COLSUM) >= 64:
         del _COLSUM[next(iter(_COLSUM))]
     _COLSUM[(g.data_ptr(), g._version, tuple(g.shape))] = (g, gb)
+
+
+_LINEAR_GRADS = {}        # (data_ptr, version, shape) of a grad_output -> (that tensor, identity of x and Wq, grad_input, grad_weight): one-shot, like _COLSUM
+
+
+def group_qkv_backward(lins, gys):
+    """The attention backward has just produced the (fake-quantized) grad_outputs of the query / key / value projections: their three
+    input gradients gy . Wq and three weight gradients gy^T . x go out as TWO launches of qt_train_gemm_bf16 (three problems each: 17 / 19 us
+    against 3 x 8 / 3 x 11) instead of six when the three Linear nodes run; each node then finds its pair (take_linear_grads), checked
+    against the very x and Wq it saved.  Same tiles, same order of additions as the single launches: bit-identical."""
+    from .modules.qat.linear import train_gemm_group
+    if not _on("qkvgemm") or len(lins) != 3 or len(gys) != 3:
+        return False
+    xs, ws, g2 = [], [], []
+    for lin, gy in zip(lins, gys):
+        xw = lin.__dict__.get("_qt_train_xw") if lin is not None else None
+        if xw is None or gy is None:
+            return False
+        x, w = xw[0](), xw[1]()
+        if x is None or w is None:
+            return False
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and w.is_contiguous() and gy.is_contiguous()
+                and gy.shape[:-1] == x.shape[:-1] and gy.shape[-1] == w.shape[0] and w.shape[1] == x.shape[-1]):
+            return False
+        xs.append(x.reshape(-1, x.shape[-1])); ws.append(w); g2.append(gy.reshape(-1, gy.shape[-1]))
+    gxs = train_gemm_group(g2, ws, False, True, "dgrad q/k/v")
+    if gxs is None:
+        return False
+    gws = train_gemm_group(g2, xs, True, True, "wgrad q/k/v")
+    if gws is None:
+        return False
+    for lin, gy, x2, w, gx, gw in zip(lins, gys, xs, ws, gxs, gws):
+        x = lin.__dict__["_qt_train_xw"][0]()
+        while len(_LINEAR_GRADS) >= 16:
+            del _LINEAR_GRADS[next(iter(_LINEAR_GRADS))]
+        # (x and Wq are remembered by address and version, not by reference: Wq carries the step's autograd graph, and a reference that
+        # outlives a stream capture's end broke the graph's instantiation)
+        _LINEAR_GRADS[(gy.data_ptr(), gy._version, tuple(gy.shape))] = (gy, (x.data_ptr(), x._version, tuple(x.shape), w.data_ptr(), w._version),
+                                                                          gx.view(x.shape), gw)
+    STATS.qkv_groups += 1
+    return True
+
+
+def take_linear_grads(gy, x, w):
+    hit = _LINEAR_GRADS.pop((gy.data_ptr(), gy._version, tuple(gy.shape)), None)
+    if hit is None:
+        return None
+    _, ident, gx, gw = hit
+    if ident != (x.data_ptr(), x._version, tuple(x.shape), w.data_ptr(), w._version):
+        return None                    # (another forward of the same Linear in between: the node multiplies what IT saved)
+    return gx, gw
 
 
 def take_colsum(g):
@@ -995,6 +1048,8 @@ class _AttentionTrainFn(torch.autograd.Function):
             _hand_over(mem, grads[i].view(B, S, H * D), [o])
             if gb is not None:
                 put_colsum(o, gb)
+        if len(riders) == 3 and [r[1] for r in riders] == [0, 1, 2]:
+            group_qkv_backward(ctx.lins, [r[2] for r in riders])       # the projections' six backward products as two launches
         return dq.permute(0, 2, 1, 3), dk.permute(0, 2, 1, 3), dv.permute(0, 2, 1, 3), None, None, None, None, None, None, None, None
 
 

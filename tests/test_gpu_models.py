@@ -1427,7 +1427,7 @@ def test_training_attention_core_is_one_launch_each_way(monkeypatch, drop):
         assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
 
 
-@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln"])
+@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln", "qkvgemm"])
 def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
     """Two fusions of the training step that reproduce torch's arithmetic exactly, each switched off and on with everything else on; three
     steps: every loss, every fake-quantizer's scale and amax history and every parameter BIT-IDENTICAL, the same fake-quantized element
@@ -1437,7 +1437,9 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
                           one fake-quantizer launch and one add per arrival
       embedding (32)      qt_embedding_backward_bf16 instead of torch's embedding_dense_backward for the three embedding tables
       addln (64)          the residual add in front of a LayerNorm formed by the LayerNorm launch (the residual module is still called, its
-                          result's values left to that launch)"""
+                          result's values left to that launch)
+      qkvgemm (128)       the six backward products of query / key / value (three input gradients, three weight gradients) launched by the
+                          attention backward as two three-problem launches of qt_train_gemm_bf16 instead of six single ones"""
     import copy
     from transformers import RobertaConfig, RobertaForSequenceClassification
     from quantized_training import train_fusions
@@ -1460,7 +1462,7 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
         params = {n: p.detach().clone() for n, p in m.named_parameters()}
         T = train_fusions.STATS
-        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses, T.addlns), (STATS.elements, STATS.calls)
+        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses, T.addlns, T.qkv_groups), (STATS.elements, STATS.calls)
     det = torch.are_deterministic_algorithms_enabled()
     torch.use_deterministic_algorithms(True, warn_only=True)
     try:
@@ -1478,6 +1480,8 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         assert fused[3][:2] == (2 * 4, 2 * 8) and fused[3][3] == 0, (fused[3], train_fusions.STATS.missed)
     elif switch == "embedding":
         assert plain[3][2] == 0 and fused[3][2] == 3 * 3 and fused[3][3] == 0, (plain[3], fused[3])      # three tables, three steps
+    elif switch == "qkvgemm":
+        assert plain[3][5] == 0 and fused[3][5] == 2 * 2 and fused[3][3] == 0, (plain[3], fused[3])      # layers x steps 2..3
     else:
         # steps 2 and 3: every output block whose LayerNorm has a consuming Linear behind it (all but the last layer's output block)
         assert plain[3][4] == 0 and fused[3][4] == 2 * 3 and fused[3][3] == 0, (plain[3], fused[3])
