@@ -31,7 +31,7 @@ extern "C" {
 /* 2 (round 6): qt_fp8_gemm's last argument is the heuristic suggestion index (`algo`), no longer a 0 / 1 `tune` flag; the training
  * entry points (qt_attention_train_*, qt_grad_fanin_bf16, qt_embedding_backward_bf16, qt_fake_quant_chain_bf16) exist.  A caller built
  * against 1 must not bind this library, and the package refuses a library that reports anything else. */
-#define QT_ABI_VERSION 2
+#define QT_ABI_VERSION 3
 #define QT_MAP_ENTRIES 65536
 
 typedef enum qt_status {
@@ -431,6 +431,34 @@ typedef struct qt_gemm_problem {
 } qt_gemm_problem;
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
                        void *stream);
+
+/* ---- H3's step end: clip_grad_norm_(max_norm) and the AdamW update of every parameter tensor in three launches -----------------------
+ *     run_glue_no_trainer.py:655-668   accelerator.clip_grad_norm_(model.parameters(), 1.0); optimizer.step()
+ * The arithmetic is torch's, which the reference calls: torch.nn.utils.clip_grad_norm_ on bf16 gradients (per-tensor norms and the
+ * coefficient rounded to bf16 where torch's tensors are bf16) and torch.optim.AdamW's fused kernel (torch 2.10, ATen/native/cuda/
+ * fused_adam_utils.cuh:27-98: hyper-parameters in double, state in fp32, one rounding per stored value).  bf16 parameters, gradients,
+ * exp_avg, exp_avg_sq; amsgrad / maximize / grad scaler are not covered (the caller keeps torch's optimizer for those).
+ * qt_adamw_tensor: one parameter tensor.  step_dev (nullable): torch's capturable step count, incremented by the call; NULL: `step` is
+ * the count AFTER this update, kept by the host.  lr_dev (nullable): the learning rate read on the device (a tensor lr), else `lr`.
+ * qt_clip_adamw_plan (host): fills first_chunk of every entry and chunk_tensor_out[chunk] = tensor index (nullable; `capacity` entries);
+ * returns the number of 8192-element chunks = workgroups of a launch.  The table and the chunk map are then copied to the device by the
+ * caller (tensors_dev, chunk_tensor_dev).  ws_dev: qt_clip_adamw_ws_bytes(ntensors, nchunks) bytes, 16-byte aligned, caller-owned.
+ * max_norm <= 0: no clipping.  total_norm_out_dev (nullable, fp32 holding the bf16 value torch returns).  phases: 1 = norm and
+ * coefficient only (kept in ws_dev), 2 = step counts + update with the coefficient in ws_dev, 3 = both.  The gradients are NOT rewritten
+ * (torch's clip scales them in place; the loop drops them right after the step).  Deterministic: every sum has a fixed order. */
+typedef struct qt_adamw_tensor {
+    void *param_dev, *grad_dev, *exp_avg_dev, *exp_avg_sq_dev;
+    float *step_dev;
+    const float *lr_dev;
+    long numel;
+    long first_chunk;
+    double lr, beta1, beta2, eps, weight_decay;
+    double step;
+} qt_adamw_tensor;
+long qt_clip_adamw_plan(qt_adamw_tensor *tensors_host, int ntensors, int32_t *chunk_tensor_out, long capacity);
+size_t qt_clip_adamw_ws_bytes(int ntensors, long nchunks);
+int qt_clip_adamw_bf16(qt_adamw_tensor *tensors_dev, const int32_t *chunk_tensor_dev, int ntensors, long nchunks, float max_norm,
+                       float *total_norm_out_dev, void *ws_dev, size_t ws_bytes, int phases, void *stream);
 
 /* Host-only query: how qt_linear_fq8_bf16 (pair 0, n_total = sum n) or qt_mlp_fq8_bf16 (pair 1, n_total = N: the gate / up pairs)
  * cuts a problem on the current device -- tiles_m x tiles_n workgroups of 256 rows x groups_lo..groups_hi 16-column groups (gate and

@@ -253,6 +253,31 @@ __global__ __launch_bounds__(256) void fq_gather_vec_kernel(const void *__restri
 // writes its result; optionally the fp32 column sums of one stage's result are produced on the way (the bias gradient of the Linear
 // behind it: grad_output.sum(0), run_glue_no_trainer.py:660-667) -- rows are dealt to workgroups in bands, a lane adds its rows in
 // row order, the lanes of a column in lane order, the workgroups in workgroup order (last arriver, through a workspace): deterministic.
+// Tuning build only (tools/exp_train_stamps.py): s_memrealtime (100 MHz, one counter for the whole chip) of wave 0 and of the last wave
+// of a workgroup at a few points of the chain / LayerNorm-backward kernels.  QT_EW_STAMPS = device address of [launch][512 workgroups][16]
+// slots; every launch the host issues takes the next region (a captured graph keeps the region of its capture).
+#ifdef QT_TUNING_BUILD
+#define QT_EW_STAMP_FIELD unsigned long long *dbg;
+#define QT_EW_STAMP(a, slot)                                                                                                     \
+    do {                                                                                                                         \
+        if ((a).dbg && blockIdx.x < 512 && (threadIdx.x & 63) == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64))      \
+            (a).dbg[(size_t)blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + (slot)] = __builtin_amdgcn_s_memrealtime();                \
+    } while (0)
+#define QT_EW_STAMP_HEAD(a, tag)                                                                                                 \
+    do {                                                                                                                         \
+        if ((a).dbg && blockIdx.x < 512 && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)(tag) << 32) | gridDim.x; \
+    } while (0)
+static unsigned long long *ew_stamp_region() {
+    const char *e = getenv("QT_EW_STAMPS");
+    if (!e) return nullptr;
+    static int launch = 0;
+    return (unsigned long long *)strtoull(e, nullptr, 0) + (size_t)(launch++ % 256) * 512 * 16;
+}
+#else
+#define QT_EW_STAMP_FIELD
+#define QT_EW_STAMP(a, slot)
+#define QT_EW_STAMP_HEAD(a, tag)
+#endif
 constexpr int kChainBlock = 512, kChainStripV = 8, kChainRowLanes = kChainBlock / kChainStripV;
 // Work decomposition: a workgroup (512 threads: up to 256 registers, the row form keeps many live) owns a STRIP of 64 columns (8 vectors =
 // one 128-byte line per row) x a BAND of rows; lane (rl = t / 8, v = t % 8) walks rows rl, rl + 64, ... of the band, two or four loads in flight.  Column sums: a lane adds its rows in row order,
@@ -278,6 +303,7 @@ struct ChainArgs {
     const uint4 *x2;
     uint4 *pre_out;
     int table_in_lds;         // table formats: stage the row words in LDS (else gather them from global memory)
+    QT_EW_STAMP_FIELD
 };
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -303,7 +329,10 @@ __device__ __forceinline__ uint4 chain_prologue(int op, uint4 q, uint4 q2) {
 template <int KIND, int NS>
 __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    QT_EW_STAMP(a, 0);
+    QT_EW_STAMP_HEAD(a, 0x100 + NS * 16 + (a.colsum_stage >= 0 ? 1 : 0) + (a.pre_op << 1));
     const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock, a.table_in_lds != 0);
+    QT_EW_STAMP(a, 1);
     const int t = threadIdx.x;
     const int v = t % kChainStripV, rl = t / kChainStripV;
     const int strip = blockIdx.x % a.strips, band = blockIdx.x / a.strips;
@@ -354,11 +383,13 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     // ---- amax of every stage's input: wave, then workgroup, then at most one atomic per stage and workgroup
     __shared__ uint32_t s_amax[NS][kChainBlock / 64];
     __shared__ float s_col[kChainRowLanes][kChainStripV * 8 + 1];
+    QT_EW_STAMP(a, 2);
     if (a.colsum_stage >= 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_col[rl][v * 8 + e] = col[e];
     }
     chain_amax_commit<NS, kChainBlock>(a.st, amax, s_amax);          // (its barrier also covers s_col)
+    QT_EW_STAMP(a, 3);
     if (a.colsum_stage < 0) return;
     // ---- column sums: the row lanes of a column in a fixed-order tree; then the bands of a strip meet in 64-bit FIXED-POINT accumulators
     // by agent-scope atomic adds -- integer addition is associative, so the result does not depend on the arrival order, and atomics are
@@ -374,6 +405,7 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
         }
         lds_only_barrier();                                         // (six rounds: none of them waits for the result stores in flight)
     }
+    QT_EW_STAMP(a, 4);
     float s_cs = 1.0f;
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -393,9 +425,11 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
         (void)__hip_atomic_fetch_add(acc + t, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // returning form: performed when it returns
     }
     __syncthreads();
+    QT_EW_STAMP(a, 5);
     __shared__ unsigned int s_old;
     if (t == 0) s_old = __hip_atomic_fetch_add(a.ticket + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    QT_EW_STAMP(a, 6);
     if (s_old != (unsigned)a.bands - 1u) return;
     if (t == 0) __hip_atomic_store(a.ticket + strip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < kC) {
@@ -518,13 +552,17 @@ struct LnBwdArgs {
     int nfan;
     const uint4 *fan_x[3];
     ChainStageDev fan[kChainMax];   // [0..2]: scale, amax; out unused; src: 1 = through the fake-quantizer, 0 = plain
+    QT_EW_STAMP_FIELD
 };
 
 template <int KIND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_format fmt, const uint16_t *__restrict__ lut) {
     constexpr int RPB = BLOCK / 64;
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
+    QT_EW_STAMP(a, 0);
+    QT_EW_STAMP_HEAD(a, 0x200 + NS * 16 + a.nfan * 2 + (a.colsum_stage >= 0 ? 1 : 0));
     const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, BLOCK);
+    QT_EW_STAMP(a, 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[NS];
     uint32_t amax[NS];
@@ -606,6 +644,7 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
             s2 += __shfl_xor(s2, off, 64);
         }
         const float c1 = s1 * a.inv_cols, c2 = s2 * a.inv_cols;
+        QT_EW_STAMP(a, 2);
 #pragma unroll
         for (int i = 0; i < kLnMaxVec; ++i) {
             const int c = lane + i * 64;
@@ -632,6 +671,7 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
             }
         }
     }
+    QT_EW_STAMP(a, 3);
     // ---- the waves' column partials meet in LDS, quantity by quantity, and are added in wave order
     __shared__ float s_red[RPB][kLnMaxVec * 64 * 8];
     __shared__ uint32_t s_amax[NS][BLOCK / 64];
@@ -653,12 +693,14 @@ __global__ __launch_bounds__(BLOCK) void ln_train_bwd_kernel(LnBwdArgs a, qt_for
         }
         lds_only_barrier();
     }
+    QT_EW_STAMP(a, 4);
     chain_amax_commit<NS, BLOCK>(a.st, amax, s_amax);
     if (a.nfan > 0) {                                              // (uniform) the amax slots of the arrivals' fake-quantizers
         __syncthreads();                                           // s_amax is read by the commit above
         __shared__ uint32_t s_famax[3][BLOCK / 64];
         chain_amax_commit<3, BLOCK>(a.fan, famax, s_famax);
     }
+    QT_EW_STAMP(a, 5);
 }
 
 // dgamma, dbeta (and the bias gradient) of one LayerNorm backward: the workgroups' partial sums added in a fixed order -- a workgroup owns
@@ -1764,6 +1806,7 @@ static int chain_launch(const uint16_t *x_dev, const uint16_t *x2_dev, int pre_o
     a.table_in_lds = 1;
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_LDS")) a.table_in_lds = atoi(e);                          // tools/ only
+    a.dbg = ew_stamp_region();
 #endif
     for (int i = 0; i < nstage; ++i) {
         if (stages[i].src >= i || stages[i].src < -1) return QT_ERR_BAD_ARG;
@@ -1914,6 +1957,9 @@ int qt_layernorm_train_backward_bf16(const uint16_t *grad_out_dev, const uint16_
     }
     hipStream_t st = (hipStream_t)stream;
     auto grid = [&](int) { return groups; };
+#ifdef QT_TUNING_BUILD
+    a.dbg = ew_stamp_region();
+#endif
     QT_LN_DISPATCH(ln_train_bwd_kernel, a, grid)
     if (const int rc = launch_status()) return rc;
     ln_train_reduce_kernel<<<dim3((unsigned)((cols + 63) / 64), colsum_stage >= 0 ? 3u : 2u), 256, 0, st>>>(part_dev, (int)groups, (int)cols, grad_weight_dev,

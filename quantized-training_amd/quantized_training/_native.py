@@ -46,6 +46,13 @@ class QtGemmProblem(ctypes.Structure):
     _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("c", ctypes.c_void_p)]
 
 
+class QtAdamwTensor(ctypes.Structure):
+    """qt_adamw_tensor of include/qt_hip.h"""
+    _fields_ = [("param_dev", c_void_p), ("grad_dev", c_void_p), ("exp_avg_dev", c_void_p), ("exp_avg_sq_dev", c_void_p), ("step_dev", c_void_p),
+                ("lr_dev", c_void_p), ("numel", c_long), ("first_chunk", c_long), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("step", ctypes.c_double)]
+
+
 class QtChainStage(ctypes.Structure):
     _fields_ = [("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p), ("out_dev", c_void_p), ("src", ctypes.c_int)]
 
@@ -65,7 +72,7 @@ _FMT = POINTER(QtFormat)
 _OPQ = POINTER(QtOperandQ)
 
 # name -> (restype, argtypes); mirrors include/qt_hip.h one to one
-ABI_VERSION = 2          # include/qt_hip.h QT_ABI_VERSION
+ABI_VERSION = 3          # include/qt_hip.h QT_ABI_VERSION
 
 SIGNATURES = {
     "qt_abi_version": (c_int, []),
@@ -100,6 +107,9 @@ SIGNATURES = {
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_train_gemm_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, _P]),
     "qt_linear_fq8_plan": (c_int, [c_int, c_long, c_int, c_int, _P, _P, _P, _P, _P]),
+    "qt_clip_adamw_plan": (c_long, [_P, c_int, _P, c_long]),
+    "qt_clip_adamw_ws_bytes": (c_size_t, [c_int, c_long]),
+    "qt_clip_adamw_bf16": (c_int, [_P, _P, c_int, c_long, c_float, _P, _P, c_size_t, c_int, _P]),
     "qt_linear_fq8_bf16": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "qt_fake_quant_chain_bf16": (c_int, [_P, c_long, c_long, POINTER(QtChainStage), c_int, _FMT, _P, c_int, c_float, _P, _P, c_size_t, _P]),
     "qt_fake_quant_chain_ws_bytes": (c_size_t, [c_long, c_long]),

@@ -78,6 +78,8 @@ def routes_report():
     out.update(sorted(LT_ALGOS.items()))
     from .modules.qat.linear import GEMM_ROUTES                # the training step's products (csrc/qt_train_gemm.hip or torch's GEMM)
     out.update(sorted(GEMM_ROUTES.items()))
+    from .optim import ROUTES as OPT_ROUTES                    # clip_grad_norm_ + optimizer.step() (csrc/qt_optimizer.hip or torch's launches)
+    out.update(sorted(OPT_ROUTES.items()))
     return out
 
 

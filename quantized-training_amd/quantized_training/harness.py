@@ -362,7 +362,7 @@ def train_steps(model, batches, optimizer, lr_scheduler=None, max_grad_norm: flo
     model.train()
     device = next(model.parameters()).device
     losses = []
-    from . import train_fusions
+    from . import optim, train_fusions
     for step, batch in enumerate(batches):
         train_fusions.ensure_planned(model)                 # launch fusions over the fake-quantizers that exist by now (values unchanged)
         batch = {k: v.to(device) for k, v in batch.items()}
@@ -370,8 +370,9 @@ def train_steps(model, batches, optimizer, lr_scheduler=None, max_grad_norm: flo
         losses.append(float(loss.detach().float()))
         (loss / gradient_accumulation_steps).backward()
         if step % gradient_accumulation_steps == 0 or step == len(batches) - 1:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm, error_if_nonfinite=True)
-            optimizer.step()
+            # clip_grad_norm_ + optimizer.step(): three launches over the optimizer's own state for torch.optim.AdamW on bf16 device
+            # parameters (optim.py), torch's own calls otherwise
+            optim.clip_and_step(model.parameters(), optimizer, max_grad_norm, error_if_nonfinite=True)
             if lr_scheduler is not None:
                 lr_scheduler.step()
             optimizer.zero_grad()
@@ -401,6 +402,7 @@ class GraphedTrainStep:
         self.scales = None                # fake_quantize.BatchedScaleUpdate over the fake-quantizers a step calls
 
     def _step(self, batch):
+        from . import optim
         if self.scales is not None:
             self.scales.launch()          # every delayed-scaling update of the step in one launch (356 -> 1 for RoBERTa-base)
         if self.weights is not None:
@@ -408,9 +410,7 @@ class GraphedTrainStep:
                                           # only change in optimizer.step() below
         loss = self.model(**batch).loss
         loss.backward()
-        if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm, error_if_nonfinite=False)
-        self.optimizer.step()
+        optim.clip_and_step(self.model.parameters(), self.optimizer, self.max_grad_norm, error_if_nonfinite=False)
         return loss.detach().float()
 
     def capture(self, example_batch, warmup: int = 3):

@@ -65,7 +65,7 @@ STATS = _Counters
 #  32 embedding  torch's embedding_dense_backward
 #  64 addln      the residual add in front of a LayerNorm as its own launch
 # 128 qkvgemm    the input and weight gradients of query / key / value as six launches instead of two
-DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128}
+DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128, "optimizer": 256}
 
 
 def _on(name):

@@ -19,7 +19,7 @@ MAPS = np.load(os.path.join(G, "maps.npz"))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = _native.lib()
-    assert L.qt_abi_version() == 2
+    assert L.qt_abi_version() == 3
     header = open(os.path.join(ROOT, "include", "qt_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(qt_[a-z0-9_]+)\s*\(", header))
