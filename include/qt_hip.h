@@ -431,6 +431,17 @@ typedef struct qt_gemm_problem {
 } qt_gemm_problem;
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
                        void *stream);
+/* Both backward products of `count` (1..4) Linears of ONE shape -- query / key / value, or a single Linear -- in one launch:
+ *     gx[i] [T][I] = gy[i] [T][O] . wq[i] [O][I]          gw[i] [O][I] = gy[i]^T . x[i] [T][I]
+ * the same tiles in the same k order as qt_train_gemm_bf16(trans_a 0, trans_b 1) and (1, 1) compute: bit for bit their results.
+ * `items` is a HOST array.  T, O multiples of 64 and >= 256, I % 8 == 0, ld_gy / ld_w / ld_x % 8 == 0, ld_gx / ld_gw % 4 == 0; gy / wq / x
+ * 16-byte, gx / gw 8-byte aligned -- anything else returns QT_ERR_BAD_ARG / QT_ERR_UNALIGNED and the caller issues the two single launches. */
+typedef struct qt_linear_backward {
+    const uint16_t *gy, *wq, *x;
+    uint16_t *gx, *gw;
+} qt_linear_backward;
+int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int T, int O, int I, long ld_gy, long ld_w, long ld_x, long ld_gx,
+                                long ld_gw, void *stream);
 
 /* ---- H3's step end: clip_grad_norm_(max_norm) and the AdamW update of every parameter tensor in three launches -----------------------
  *     run_glue_no_trainer.py:655-668   accelerator.clip_grad_norm_(model.parameters(), 1.0); optimizer.step()

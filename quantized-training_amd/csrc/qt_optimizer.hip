@@ -93,7 +93,15 @@ __global__ __launch_bounds__(1024) void adamw_finalize_kernel(qt_adamw_tensor *_
         for (int t = wave; t < ntensors; t += 16) {
             const long c0 = tensors[t].first_chunk, c1 = t + 1 < ntensors ? tensors[t + 1].first_chunk : nchunks;
             double s = 0.0;
-            for (long c = c0 + lane; c < c1; c += 64) s += (double)partial[c];
+            long c = c0 + lane;
+            for (; c + 7 * 64 < c1; c += 8 * 64) {                   // eight loads in flight (the embedding matrix alone has ~4700 chunks)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partial[c + u * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (double)v[u];
+            }
+            for (; c < c1; c += 64) s += (double)partial[c];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
             const float norm = bf16_round(sqrtf((float)s));           // torch._foreach_norm: fp32 sum, sqrt, result in the gradients' dtype

@@ -116,22 +116,34 @@ __device__ __forceinline__ void drain(int &kt, F &&compute) {
     if constexpr (D > 0) drain<D - 1, PIECES>(kt, compute);
 }
 
+// One output tile: `tile` of problem P (column tile tile / tiles_m, row tile tile % tiles_m); `lds`: the workgroup's dynamic LDS
+// (Ring<BM, BN>::kBytes of it).
+// the problem of workgroup `block` (compile-time indices only into the kernel arguments: a run-time index, or a reference to the
+// argument struct, copies it to scratch memory)
+#define QT_TG_PICK(a, block, P, tile)                                      \
+    const int tile = (block) % ((a).tiles_m * (a).tiles_n);                \
+    Problem P = (a).p[0];                                                  \
+    {                                                                      \
+        const int prob_ = (block) / ((a).tiles_m * (a).tiles_n);           \
+        if (prob_ == 1) P = (a).p[1];                                      \
+        if (prob_ == 2) P = (a).p[2];                                      \
+        if (prob_ == 3) P = (a).p[3];                                      \
+    }
+struct Dims {
+    int M, N, K;
+    long lda, ldb, ldc;
+    int tiles_m;
+};
+#define QT_TG_DIMS(a) Dims{(a).M, (a).N, (a).K, (a).lda, (a).ldb, (a).ldc, (a).tiles_m}
+
 template <bool TA, bool TB, int BM, int BN>
-__global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
+__device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const int tile, unsigned char *lds) {
     constexpr int kAImg = BM * kBK * 2;                                 // bytes of the A image inside a stage
     constexpr int kStage = Ring<BM, BN>::kStage, S = Ring<BM, BN>::kStages;
     constexpr int kAV = BM / 64, kBV = BN / 64;                         // DMA pieces (1 KiB) per wave and k tile
     constexpr int kPieces = kAV + kBV;
     constexpr int WM = BM / 64, WN = BN / 32;                           // 16 x 16 output tiles per wave: the wave owns (BM / 4) x (BN / 2)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wr = wave >> 1, wc = wave & 1;      // wr 0..3, wc 0..1
-    const int tiles = a.tiles_m * a.tiles_n;
-    const int prob = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    // (compile-time indices only into the kernel arguments: a run-time index would copy the struct to scratch memory)
-    Problem P = a.p[0];
-    if (prob == 1) P = a.p[1];
-    if (prob == 2) P = a.p[2];
-    if (prob == 3) P = a.p[3];
     // consecutive workgroups walk the row tiles of one column tile: they share its B tile while it is hot in L2
     const int tn = tile / a.tiles_m, tm = tile % a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -254,6 +266,30 @@ __global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
     }
 }
 
+template <bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    QT_TG_PICK(a, (int)blockIdx.x, P, tile)
+    gemm_tile<TA, TB, BM, BN>(P, QT_TG_DIMS(a), tile, lds);
+}
+
+// The two backward products of a Linear (or of query / key / value together) in ONE launch: the weight gradient's tiles first (their
+// k range is the token count, the longest of the step), the input gradient's 128 x 64 tiles behind them.  Alone, each of the two leaves
+// a quarter to a half of the CUs idle (144-192 workgroups of one partial wave) and pays its own launch, ring fill and drain; together the
+// second product's workgroups start on the CUs the first one leaves free.  Same tiles, same k order as the separate launches: same bits.
+template <int BMW, int BNW>
+__global__ __launch_bounds__(kThreads) void train_gemm_backward_kernel(Args w, Args d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nw = w.count * w.tiles_m * w.tiles_n;
+    if ((int)blockIdx.x < nw) {
+        QT_TG_PICK(w, (int)blockIdx.x, P, tile)
+        gemm_tile<true, true, BMW, BNW>(P, QT_TG_DIMS(w), tile, lds);
+    } else {
+        QT_TG_PICK(d, (int)blockIdx.x - nw, P, tile)
+        gemm_tile<false, true, 128, 64>(P, QT_TG_DIMS(d), tile, lds);
+    }
+}
+
 // ---- skinny forward products (a classifier head: [16, 768] -> [16, 2]).  hipBLASLt runs such a shape as a split-K kernel whose partial
 // sums meet through atomics: the order of the additions, and now and then the last bit of a logit, changes from launch to launch -- the
 // one GEMM of the training step that is not bit-reproducible (profiles/r06_graph_eager_determinism.txt).  One wave per output element,
@@ -341,9 +377,54 @@ int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
     return launch_tile<TA, TB, 64, 64>(a, st);
 }
 
+template <int BMW, int BNW>
+int launch_backward(Args &w, Args &d, hipStream_t st) {
+    constexpr int kLds = Ring<BMW, BNW>::kBytes > Ring<128, 64>::kBytes ? Ring<BMW, BNW>::kBytes : Ring<128, 64>::kBytes;
+    if (w.K / kBK < Ring<BMW, BNW>::kStages - 1 || d.K / kBK < Ring<128, 64>::kStages - 1) return QT_ERR_BAD_ARG;
+    static QtOncePerDevice configured;
+    if (configured.needed()) {
+        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_backward_kernel<BMW, BNW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        configured.done();
+    }
+    w.tiles_m = (w.M + BMW - 1) / BMW;
+    w.tiles_n = (w.N + BNW - 1) / BNW;
+    d.tiles_m = (d.M + 127) / 128;
+    d.tiles_n = (d.N + 63) / 64;
+    const long grid = (long)w.count * w.tiles_m * w.tiles_n + (long)d.count * d.tiles_m * d.tiles_n;
+    train_gemm_backward_kernel<BMW, BNW><<<(unsigned)grid, kThreads, kLds, st>>>(w, d);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QT_OK : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
+
+int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int T, int O, int I, long ld_gy, long ld_w, long ld_x, long ld_gx,
+                                long ld_gw, void *stream) {
+    if (!items || count < 1 || count > kMaxProblems || T < 0 || O < 0 || I < 0) return QT_ERR_BAD_ARG;
+    if ((long)T * O * I == 0) return QT_ERR_BAD_ARG;                   // (an empty product: the caller's single launches handle it)
+    // dgrad: gx [T][I] = gy [T][O] . Wq [O][I] -- k = O;   wgrad: gW [O][I] = gy^T [O][T] . x [T][I] -- k = T
+    if (O < 4 * kBK || O % kBK != 0 || T < 4 * kBK || T % kBK != 0 || I % 8 != 0 || I < 8 || T % 8 != 0 || O % 8 != 0) return QT_ERR_BAD_ARG;
+    if (ld_gy % 8 != 0 || ld_w % 8 != 0 || ld_x % 8 != 0 || ld_gx % 4 != 0 || ld_gw % 4 != 0) return QT_ERR_BAD_ARG;
+    Args w{}, d{};
+    for (int i = 0; i < count; ++i) {
+        const qt_linear_backward &p = items[i];
+        if (!p.gy || !p.wq || !p.x || !p.gx || !p.gw) return QT_ERR_BAD_ARG;
+        if (((uintptr_t)p.gy | (uintptr_t)p.wq | (uintptr_t)p.x) & 15u) return QT_ERR_UNALIGNED;
+        if (((uintptr_t)p.gx | (uintptr_t)p.gw) & 7u) return QT_ERR_UNALIGNED;
+        d.p[i] = Problem{p.gy, p.wq, nullptr, p.gx};
+        w.p[i] = Problem{p.gy, p.x, nullptr, p.gw};
+    }
+    d.count = w.count = count;
+    d.M = T; d.N = I; d.K = O; d.lda = ld_gy; d.ldb = ld_w; d.ldc = ld_gx;
+    w.M = O; w.N = I; w.K = T; w.lda = ld_gy; w.ldb = ld_x; w.ldc = ld_gw;
+    int bm, bn;
+    pick_tile(w, true, bm, bn);                                        // the weight gradient's tile by the rule of the single launches
+    hipStream_t st = (hipStream_t)stream;
+    return bm == 128 ? launch_backward<128, 128>(w, d, st) : launch_backward<64, 64>(w, d, st);
+}
 
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
                        void *stream) {

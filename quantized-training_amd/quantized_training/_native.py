@@ -53,6 +53,11 @@ class QtAdamwTensor(ctypes.Structure):
                 ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("step", ctypes.c_double)]
 
 
+class QtLinearBackward(ctypes.Structure):
+    """qt_linear_backward of include/qt_hip.h"""
+    _fields_ = [("gy", c_void_p), ("wq", c_void_p), ("x", c_void_p), ("gx", c_void_p), ("gw", c_void_p)]
+
+
 class QtChainStage(ctypes.Structure):
     _fields_ = [("scale_f32_dev", c_void_p), ("amax_bits_dev", c_void_p), ("out_dev", c_void_p), ("src", ctypes.c_int)]
 
@@ -106,6 +111,7 @@ SIGNATURES = {
     "qt_fake_quant_pc_f32": (c_int, [_P, _P, c_size_t, c_size_t, c_size_t, _FMT, _P, _P, _P, _P]),
     "qt_linear_fq_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _OPQ, _OPQ, _P]),
     "qt_train_gemm_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, _P]),
+    "qt_train_gemm_backward_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, _P]),
     "qt_linear_fq8_plan": (c_int, [c_int, c_long, c_int, c_int, _P, _P, _P, _P, _P]),
     "qt_clip_adamw_plan": (c_long, [_P, c_int, _P, c_long]),
     "qt_clip_adamw_ws_bytes": (c_size_t, [c_int, c_long]),

@@ -87,6 +87,42 @@ def train_gemm_group(As, Bs, trans_a, trans_b, kind):
     return Cs
 
 
+def train_gemm_backward(gys, ws, xs, kind):
+    """Both backward products of up to four Linears of ONE shape -- gx_i = gy_i . Wq_i and gW_i = gy_i^T . x_i -- as ONE launch
+    (qt_train_gemm_backward_bf16: the weight gradients' tiles and the input gradients' tiles share the chip); returns (gxs, gws) or None
+    when the kernel does not take the problems (the caller then issues the products one by one).  Bit for bit the single launches' results."""
+    import ctypes
+    from ... import _native
+    n = len(gys)
+    if not (train_gemm_enabled() and 1 <= n <= 4 and len(ws) == n and len(xs) == n):
+        return None
+    from ... import train_fusions
+    if not train_fusions._on("pairgemm"):
+        return None
+    g0, w0, x0 = gys[0], ws[0], xs[0]
+    for g, w, x in zip(gys, ws, xs):
+        for t, t0 in ((g, g0), (w, w0), (x, x0)):
+            if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.is_contiguous() and t.shape == t0.shape and t.data_ptr() % 16 == 0):
+                return None
+    T, O = g0.shape
+    I = w0.shape[1]
+    if w0.shape[0] != O or tuple(x0.shape) != (T, I) or not (T >= 256 and T % 64 == 0 and O >= 256 and O % 64 == 0 and I >= 8 and I % 8 == 0):
+        return None
+    gxs = [torch.empty((T, I), dtype=torch.bfloat16, device=g0.device) for _ in range(n)]
+    gws = [torch.empty((O, I), dtype=torch.bfloat16, device=g0.device) for _ in range(n)]
+    items = (_native.QtLinearBackward * n)()
+    for i in range(n):
+        items[i].gy, items[i].wq, items[i].x, items[i].gx, items[i].gw = (gys[i].data_ptr(), ws[i].data_ptr(), xs[i].data_ptr(), gxs[i].data_ptr(),
+                                                                          gws[i].data_ptr())
+    _native.note_device(g0.device.index)
+    rc = _native.lib().qt_train_gemm_backward_bf16(items, n, T, O, I, O, I, I, I, I, ctypes.c_void_p(torch.cuda.current_stream(g0.device).cuda_stream))
+    if rc in (_native.QT_ERR_BAD_ARG, _native.QT_ERR_UNALIGNED):
+        return None
+    _native.check(rc, "qt_train_gemm_backward_bf16")
+    GEMM_ROUTES.setdefault(f"train:dgrad + wgrad {kind}{n}x({T}x{O}x{I})" if n > 1 else f"train:dgrad + wgrad {kind}{T}x{O}x{I}", "in_tree_bf16_gemm, one launch")
+    return gxs, gws
+
+
 class _LinearColsumBias(torch.autograd.Function):
     """F.linear whose backward computes the bias gradient -- grad_output.sum(0), on the gradient the backward-pre hook already
     fake-quantized (quantize.py:116-179) -- with qt_colsum_bf16 (fp32 sums in a fixed order, one rounding) instead of torch's generic
@@ -119,6 +155,11 @@ class _LinearColsumBias(torch.autograd.Function):
                 gx = None
             if not ctx.needs_input_grad[1]:
                 gw = None
+        if done is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gyc is not None and w.is_contiguous() and x2.is_contiguous():
+            both = train_gemm_backward([gyc], [w], [x2], "")      # the two products in one launch
+            if both is not None:
+                done = (both[0][0].view(x.shape), both[1][0])
+                gx, gw = done
         if done is None and ctx.needs_input_grad[0]:
             # gx = gy . Wq: the weight is read with its rows as the contraction index (trans_b)
             gx = train_gemm_or_none(gyc, w, None, False, True, "dgrad") if gyc is not None and w.is_contiguous() else None

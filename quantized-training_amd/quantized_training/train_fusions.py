@@ -65,7 +65,10 @@ STATS = _Counters
 #  32 embedding  torch's embedding_dense_backward
 #  64 addln      the residual add in front of a LayerNorm as its own launch
 # 128 qkvgemm    the input and weight gradients of query / key / value as six launches instead of two
-DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128, "optimizer": 256}
+# 256 optimizer  torch's own clip_grad_norm_ + optimizer.step() launches (optim.py)
+# 512 pairgemm   a Linear's input and weight gradient as two launches instead of one (q / k / v: two instead of one)
+DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128, "optimizer": 256,
+              "pairgemm": 512}
 
 
 def _on(name):
@@ -111,7 +114,7 @@ def group_qkv_backward(lins, gys):
     input gradients gy . Wq and three weight gradients gy^T . x go out as TWO launches of qt_train_gemm_bf16 (three problems each: 17 / 19 us
     against 3 x 8 / 3 x 11) instead of six when the three Linear nodes run; each node then finds its pair (take_linear_grads), checked
     against the very x and Wq it saved.  Same tiles, same order of additions as the single launches: bit-identical."""
-    from .modules.qat.linear import train_gemm_group
+    from .modules.qat.linear import train_gemm_backward, train_gemm_group
     if not _on("qkvgemm") or len(lins) != 3 or len(gys) != 3:
         return False
     xs, ws, g2 = [], [], []
@@ -126,12 +129,16 @@ def group_qkv_backward(lins, gys):
                 and gy.shape[:-1] == x.shape[:-1] and gy.shape[-1] == w.shape[0] and w.shape[1] == x.shape[-1]):
             return False
         xs.append(x.reshape(-1, x.shape[-1])); ws.append(w); g2.append(gy.reshape(-1, gy.shape[-1]))
-    gxs = train_gemm_group(g2, ws, False, True, "dgrad q/k/v")
-    if gxs is None:
-        return False
-    gws = train_gemm_group(g2, xs, True, True, "wgrad q/k/v")
-    if gws is None:
-        return False
+    both = train_gemm_backward(g2, ws, xs, "q/k/v ")              # all six products in ONE launch
+    if both is not None:
+        gxs, gws = both
+    else:
+        gxs = train_gemm_group(g2, ws, False, True, "dgrad q/k/v")
+        if gxs is None:
+            return False
+        gws = train_gemm_group(g2, xs, True, True, "wgrad q/k/v")
+        if gws is None:
+            return False
     for lin, gy, x2, w, gx, gw in zip(lins, gys, xs, ws, gxs, gws):
         x = lin.__dict__["_qt_train_xw"][0]()
         while len(_LINEAR_GRADS) >= 16:

@@ -1427,7 +1427,7 @@ def test_training_attention_core_is_one_launch_each_way(monkeypatch, drop):
         assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
 
 
-@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln", "qkvgemm"])
+@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln", "qkvgemm", "pairgemm"])
 def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
     """Two fusions of the training step that reproduce torch's arithmetic exactly, each switched off and on with everything else on; three
     steps: every loss, every fake-quantizer's scale and amax history and every parameter BIT-IDENTICAL, the same fake-quantized element
@@ -1439,7 +1439,9 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
       addln (64)          the residual add in front of a LayerNorm formed by the LayerNorm launch (the residual module is still called, its
                           result's values left to that launch)
       qkvgemm (128)       the six backward products of query / key / value (three input gradients, three weight gradients) launched by the
-                          attention backward as two three-problem launches of qt_train_gemm_bf16 instead of six single ones"""
+                          attention backward as one launch (two with bit 512) instead of six single ones
+      pairgemm (512)      a Linear's input and weight gradient in ONE launch of qt_train_gemm_backward_bf16 (query / key / value: all six
+                          products) instead of two launches of qt_train_gemm_bf16"""
     import copy
     from transformers import RobertaConfig, RobertaForSequenceClassification
     from quantized_training import train_fusions
@@ -1458,11 +1460,14 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         opt = torch.optim.AdamW(m.parameters(), lr=2e-5)
         train_fusions.STATS.reset()
         STATS.reset()
+        from quantized_training.modules.qat import linear as qlin
+        qlin.GEMM_ROUTES.clear()
         losses = harness.train_steps(m, batches, opt)
         state = {n: (mod.scale.clone(), mod.amax_history.clone()) for n, mod in m.named_modules() if isinstance(mod, FusedAmaxObsFakeQuantize)}
         params = {n: p.detach().clone() for n, p in m.named_parameters()}
         T = train_fusions.STATS
-        return losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses, T.addlns, T.qkv_groups), (STATS.elements, STATS.calls)
+        return (losses, state, params, (T.fanins, T.deferred, T.embeddings, T.misses, T.addlns, T.qkv_groups), (STATS.elements, STATS.calls),
+                dict(qlin.GEMM_ROUTES))
     det = torch.are_deterministic_algorithms_enabled()
     torch.use_deterministic_algorithms(True, warn_only=True)
     try:
@@ -1482,6 +1487,12 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         assert plain[3][2] == 0 and fused[3][2] == 3 * 3 and fused[3][3] == 0, (plain[3], fused[3])      # three tables, three steps
     elif switch == "qkvgemm":
         assert plain[3][5] == 0 and fused[3][5] == 2 * 2 and fused[3][3] == 0, (plain[3], fused[3])      # layers x steps 2..3
+    elif switch == "pairgemm":
+        pairs = [k for k in fused[5] if k.startswith("train:dgrad + wgrad")]
+        # tokens x out x in: q / k / v together, the attention output dense, the two FFN Linears
+        assert sorted(pairs) == ["train:dgrad + wgrad 512x256x256", "train:dgrad + wgrad 512x256x512", "train:dgrad + wgrad 512x512x256",
+                                 "train:dgrad + wgrad q/k/v 3x(512x256x256)"], fused[5]
+        assert not any(k.startswith("train:dgrad + wgrad") for k in plain[5]), plain[5]
     else:
         # steps 2 and 3: every output block whose LayerNorm has a consuming Linear behind it (all but the last layer's output block)
         assert plain[3][4] == 0 and fused[3][4] == 2 * 3 and fused[3][3] == 0, (plain[3], fused[3])

@@ -2509,6 +2509,48 @@ def test_train_gemm_against_fp64_products(nv, layout, M, N, K):
     assert L.qt_train_gemm_bf16(arr, 1, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()) == nv.QT_ERR_UNALIGNED
 
 
+@pytest.mark.parametrize("T,O,I,count", [(2048, 768, 768, 3), (2048, 768, 768, 1), (2048, 3072, 768, 1), (2048, 768, 3072, 1), (256, 320, 72, 2),
+                                         (320, 256, 8, 4)])
+def test_train_gemm_backward_pair_equals_the_two_single_launches(nv, T, O, I, count):
+    """qt_train_gemm_backward_bf16: the input gradients gy . Wq and the weight gradients gy^T . x of one to four Linears of one shape in ONE
+    launch (modules/qat/linear.py:40-41 under autograd; query / key / value of a RoBERTa layer, its three other Linears, ragged shapes
+    with partial tiles): bit for bit what qt_train_gemm_bf16 gives for (trans_a 0, trans_b 1) and (1, 1) -- the same tiles in the same
+    k order -- and, like them, within one bf16 rounding of the fp64 products."""
+    torch.manual_seed(T + O + I + count)
+    L = nv.lib()
+    gys = [(torch.randn(T, O, device="cuda") * 0.05).bfloat16() for _ in range(count)]
+    ws = [(torch.randn(O, I, device="cuda") * 0.05).bfloat16() for _ in range(count)]
+    xs = [(torch.randn(T, I, device="cuda") * 0.5).bfloat16() for _ in range(count)]
+    gxs = [torch.full((T, I), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+    gws = [torch.full((O, I), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+    items = (nv.QtLinearBackward * count)()
+    for i in range(count):
+        items[i].gy, items[i].wq, items[i].x, items[i].gx, items[i].gw = gys[i].data_ptr(), ws[i].data_ptr(), xs[i].data_ptr(), gxs[i].data_ptr(), gws[i].data_ptr()
+    nv.check(L.qt_train_gemm_backward_bf16(items, count, T, O, I, O, I, I, I, I, stream()), "qt_train_gemm_backward_bf16")
+
+    def single(As, Bs, ta, tb, M, N, K):
+        Cs = [torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+        arr = (nv.QtGemmProblem * count)()
+        for i in range(count):
+            arr[i].a, arr[i].b, arr[i].bias, arr[i].c = As[i].data_ptr(), Bs[i].data_ptr(), None, Cs[i].data_ptr()
+        nv.check(L.qt_train_gemm_bf16(arr, count, ta, tb, M, N, K, As[0].stride(0), Bs[0].stride(0), N, stream()), "qt_train_gemm_bf16")
+        return Cs
+    d1 = single(gys, ws, 0, 1, T, I, O)
+    w1 = single(gys, xs, 1, 1, O, I, T)
+    for i in range(count):
+        assert torch.equal(gxs[i].view(torch.int16), d1[i].view(torch.int16)), ("input gradient", i)
+        assert torch.equal(gws[i].view(torch.int16), w1[i].view(torch.int16)), ("weight gradient", i)
+        for got, a, b in ((gxs[i], gys[i].double(), ws[i].double()), (gws[i], gys[i].t().double(), xs[i].double())):
+            ref = a @ b
+            tol = ref.abs() * 2.0 ** -8 + (a.abs() @ b.abs()) * 2.0 ** -18 + 1e-30
+            assert bool(((got.double() - ref).abs() <= tol).all())
+    # what it refuses (the caller issues the two single launches)
+    assert L.qt_train_gemm_backward_bf16(items, count, 96, O, I, O, I, I, I, I, stream()) == nv.QT_ERR_BAD_ARG       # T % 64, T < 256
+    assert L.qt_train_gemm_backward_bf16(items, 5, T, O, I, O, I, I, I, I, stream()) == nv.QT_ERR_BAD_ARG
+    items[0].x = xs[0].data_ptr() + 2
+    assert L.qt_train_gemm_backward_bf16(items, count, T, O, I, O, I, I, I, I, stream()) == nv.QT_ERR_UNALIGNED
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 2, 768), (16, 3, 1024), (128, 5, 64), (1, 1, 8)])
 def test_train_gemm_skinny_forward_is_deterministic_and_exact(nv, M, N, K):
     """A classifier head's forward product ([16, 768] -> [16, 2], run_glue_no_trainer.py's RobertaClassificationHead.out_proj): the library
@@ -2563,9 +2605,31 @@ def test_qat_linear_training_products_run_in_tree_and_match_autograd(nv, monkeyp
             (y.float() * torch.linspace(-1, 1, 3072, device="cuda")).mean().backward()
         res[mode] = (y.detach().float(), x.grad.float(), model[0].weight.grad.float(), model[0].bias.grad.float(), dict(fused.routes_report()))
     routes = res["1"][4]
-    for kind, shape in (("forward", "2048x3072x768"), ("dgrad", "2048x768x3072"), ("wgrad", "3072x768x2048")):
-        assert routes.get(f"train:{kind} {shape}") == "in_tree_bf16_gemm", routes
+    assert routes.get("train:forward 2048x3072x768") == "in_tree_bf16_gemm", routes
+    assert routes.get("train:dgrad + wgrad 2048x3072x768") == "in_tree_bf16_gemm, one launch", routes      # tokens x out x in
     assert not any(k.startswith("train:") for k in res["0"][4])
+    # the two backward products as two launches (QT_TRAIN_DEBUG bit 512): the same bits
+    monkeypatch.setenv("QT_TRAIN_GEMM", "1")
+    monkeypatch.setenv("QT_TRAIN_DEBUG", "512")
+    qlin.GEMM_ROUTES.clear()
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(768, 3072).cuda().bfloat16()
+    model = torch.nn.Sequential(lin)
+    qt_pkg.quantize(model, qt_pkg.add_qspec_args().parse_args(["--activation", "int8,qs=per_tensor_symmetric", "--weight", "int8,qs=per_tensor_symmetric",
+                                                               "--error", "fp8_e5m2,qs=per_tensor_symmetric,qmax=57344,ahl=10", "--quantize_forward", "gemm",
+                                                               "--quantize_backprop", "gemm", "--bf16"]))
+    model.train()
+    x = torch.randn(16, 128, 768, device="cuda").bfloat16().requires_grad_(True)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        x.grad = None
+        y = model(x)
+        (y.float() * torch.linspace(-1, 1, 3072, device="cuda")).mean().backward()
+    monkeypatch.delenv("QT_TRAIN_DEBUG")
+    single = dict(fused.routes_report())
+    for kind, shape in (("dgrad", "2048x768x3072"), ("wgrad", "3072x768x2048")):
+        assert single.get(f"train:{kind} {shape}") == "in_tree_bf16_gemm", single
+    assert torch.equal(x.grad.float(), res["1"][1]) and torch.equal(model[0].weight.grad.float(), res["1"][2])
     for i, name in enumerate(("output", "input gradient", "weight gradient")):
         a, b = res["1"][i], res["0"][i]
         assert bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2.0 ** -10 * float(b.abs().max())).all()), (name, float((a - b).abs().max()))
