@@ -1773,11 +1773,15 @@ int qt_fake_quant_bf16_fp8(const uint16_t *x, uint16_t *y, uint8_t *y8, size_t n
     return launch_status();
 }
 
-// strips x bands of one chain launch: about 192 workgroups, bands of whole 64-row groups, at most 32 bands
+// strips x bands of one chain launch: about one workgroup per CU, bands of whole 64-row groups, at most 32 bands
 static void chain_geometry(long rows, long cols, int &strips, int &bands, long &band_rows, int pre_op = 0) {
     strips = (int)((cols / 8 + kChainStripV - 1) / kChainStripV);
     const long groups = (rows + kChainRowLanes - 1) / kChainRowLanes;           // 64-row groups
-    int target = 192;                                              // measured (profiles/r05_chain_geometry.txt): 96 and 384 workgroups are both slower
+    // measured: 96 and 384 workgroups are both slower than 192 on [2048, 768] (profiles/r05_chain_geometry.txt; 192 and 256 cut that shape
+    // the same way: 12 strips x 16 bands).  On [2048, 3072] -- the GELU launches, bound by their erf / exp arithmetic, not by memory
+    // (tools/exp_train_stamps.py: 20 of 26 us between the loads and the last store) -- 192 left a quarter of the CUs idle: 48 strips x 6
+    // bands instead of x 4 took 0.12 ms off the configs[4] step (profiles/r06_train_step_ab.txt).
+    int target = 256;
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_WGS")) target = atoi(e) > 0 ? atoi(e) : target;          // tools/ only
     if (pre_op != 0)

@@ -56,13 +56,16 @@ def train_gemm_or_none(a, b, bias, trans_a, trans_b, kind):
     return c
 
 
-def train_gemm_group(As, Bs, trans_a, trans_b, kind):
-    """Up to four products of ONE shape as one launch of qt_train_gemm_bf16 (query / key / value: the three input gradients, the three
-    weight gradients); returns the list of results, or None when the kernel does not take the problems."""
+def train_gemm_group(As, Bs, trans_a, trans_b, kind, biases=None, outs=None):
+    """Up to four products of ONE shape as one launch of qt_train_gemm_bf16 (query / key / value: the three forward products, the three
+    input gradients, the three weight gradients); returns the list of results (`outs` when given), or None when the kernel does not take
+    the problems."""
     import ctypes
     from ... import _native
     n = len(As)
     if not (train_gemm_enabled() and 1 <= n <= 4 and len(Bs) == n):
+        return None
+    if biases is not None and any(b is not None and not (b.dtype == torch.bfloat16 and b.is_contiguous() and b.data_ptr() % 8 == 0) for b in biases):
         return None
     a0, b0 = As[0], Bs[0]
     for a, b in zip(As, Bs):
@@ -73,10 +76,13 @@ def train_gemm_group(As, Bs, trans_a, trans_b, kind):
     N = b0.shape[1] if trans_b else b0.shape[0]
     if (b0.shape[0] if trans_b else b0.shape[1]) != K or not (K >= 256 and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8):
         return None
-    Cs = [torch.empty((M, N), dtype=torch.bfloat16, device=a0.device) for _ in range(n)]
+    if biases is not None and any(b is not None and b.numel() != N for b in biases):
+        return None
+    Cs = outs if outs is not None else [torch.empty((M, N), dtype=torch.bfloat16, device=a0.device) for _ in range(n)]
     prob = (_native.QtGemmProblem * n)()
     for i in range(n):
-        prob[i].a, prob[i].b, prob[i].bias, prob[i].c = As[i].data_ptr(), Bs[i].data_ptr(), None, Cs[i].data_ptr()
+        prob[i].a, prob[i].b, prob[i].c = As[i].data_ptr(), Bs[i].data_ptr(), Cs[i].data_ptr()
+        prob[i].bias = biases[i].data_ptr() if biases is not None and biases[i] is not None else None
     _native.note_device(a0.device.index)
     rc = _native.lib().qt_train_gemm_bf16(prob, n, int(trans_a), int(trans_b), M, N, K, a0.stride(0), b0.stride(0), N,
                                           ctypes.c_void_p(torch.cuda.current_stream(a0.device).cuda_stream))
@@ -85,6 +91,47 @@ def train_gemm_group(As, Bs, trans_a, trans_b, kind):
     _native.check(rc, "qt_train_gemm_bf16")
     GEMM_ROUTES.setdefault(f"train:{kind} {n}x({M}x{N}x{K})", "in_tree_bf16_gemm, one launch")
     return Cs
+
+
+# ---- the forward products of query / key / value as one launch ---------------------------------------------------------------------------
+# Hugging Face's self-attention block calls the three projections one after the other on the same hidden states and only reshapes their
+# results before it hands them to the attention function.  A projection that train_fusions marked as such a member (the fused training
+# attention engaged behind it on an earlier step) returns its output tensor UNWRITTEN and leaves the product here; the third member's
+# forward -- or, whatever came in between, the attention function's entry, the next other Linear, any backward -- launches what is
+# pending: three problems of one shape as ONE launch of qt_train_gemm_bf16 (17 us against 3 x 8-11), otherwise one by one.
+_FWD_PENDING = []         # (x2, wq, bias, y2)
+
+
+def flush_forward():
+    if not _FWD_PENDING:
+        return
+    todo = list(_FWD_PENDING)
+    _FWD_PENDING.clear()
+    from ... import train_fusions
+    if len(todo) == 3 and train_gemm_group([t[0] for t in todo], [t[1] for t in todo], False, False, "forward q/k/v", [t[2] for t in todo],
+                                           [t[3] for t in todo]) is not None:
+        train_fusions.STATS.qkv_forward_groups += 1
+        return
+    for x2, w, b, y2 in todo:
+        if train_gemm_group([x2], [w], False, False, "forward (deferred)", [b], [y2]) is None:
+            y2.copy_(F.linear(x2, w, b))
+
+
+def _defer_forward(x2, w, b):
+    """The output tensor of a q / k / v member, its product left pending; None when the grouped kernel would not take it."""
+    M, K = x2.shape
+    N = w.shape[0]
+    if not (train_gemm_enabled() and x2.is_contiguous() and w.is_contiguous() and w.shape[1] == K and K >= 256 and K % 64 == 0 and M % 8 == 0
+            and N % 8 == 0 and M >= 8 and N >= 8 and x2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (b is None or (b.dtype == torch.bfloat16 and b.is_contiguous() and b.numel() == N and b.data_ptr() % 8 == 0))):
+        return None
+    if _FWD_PENDING and (_FWD_PENDING[0][0].shape != x2.shape or _FWD_PENDING[0][1].shape != w.shape):
+        flush_forward()
+    y2 = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    _FWD_PENDING.append((x2, w, b, y2))
+    if len(_FWD_PENDING) == 3:
+        flush_forward()
+    return y2
 
 
 def train_gemm_backward(gys, ws, xs, kind):
@@ -130,9 +177,14 @@ class _LinearColsumBias(torch.autograd.Function):
     linear backward runs (grad_output . W and grad_output^T . x)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, defer=False):
         ctx.save_for_backward(x, w)
         x2 = x.reshape(-1, x.shape[-1])
+        if defer:
+            y = _defer_forward(x2, w, b)
+            if y is not None:
+                return y.view(*x.shape[:-1], w.shape[0])
+        flush_forward()
         y = train_gemm_or_none(x2, w, b, False, False, "forward") if x2.is_contiguous() and w.is_contiguous() else None
         if y is not None:
             return y.view(*x.shape[:-1], w.shape[0])
@@ -142,6 +194,7 @@ class _LinearColsumBias(torch.autograd.Function):
     def backward(ctx, gy):
         import ctypes
         from ... import _native
+        flush_forward()
         x, w = ctx.saved_tensors
         gy2 = gy.reshape(-1, gy.shape[-1])
         gx = gw = gb = None
@@ -173,7 +226,7 @@ class _LinearColsumBias(torch.autograd.Function):
             from ... import train_fusions
             gb = train_fusions.take_colsum(gy)          # the launch that fake-quantized this gradient summed its columns on the way
             if gb is not None:
-                return gx, gw, gb
+                return gx, gw, gb, None
             train_fusions.STATS.colsum_fallbacks += 1
             g = gy2 if gy2.is_contiguous() else gy2.contiguous()
             if g.dtype != torch.bfloat16 or g.data_ptr() % 16 or g.shape[1] % 8 or g.shape[0] == 0:
@@ -187,7 +240,7 @@ class _LinearColsumBias(torch.autograd.Function):
                     gb = gy2.sum(0)
                 else:
                     _native.check(rc, "qt_colsum_bf16")
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class Linear(nn.Linear):
@@ -221,7 +274,11 @@ class Linear(nn.Linear):
             # alive until its backward has run, and nothing here may extend the life of a step's tensors (or of its autograd graph)
             import weakref
             self.__dict__["_qt_train_xw"] = (weakref.ref(input), weakref.ref(wq))
-            return _LinearColsumBias.apply(input, wq, b)
+            defer = False
+            if self.__dict__.get("_qt_qkv_member", False) and not self._forward_hooks:
+                from ... import train_fusions
+                defer = train_fusions._on("qkvfwd")
+            return _LinearColsumBias.apply(input, wq, b, defer)
         return F.linear(input, wq, b)
 
     @classmethod

@@ -82,6 +82,8 @@ def _causal_mask(q_len, k_len, dtype, device):
 def quantizable_attention_forward(module, query, key, value, attention_mask, scaling=None, dropout=0.0, **kwargs):
     """Drop-in for HF's ``eager_attention_forward`` that goes through the module's hookable ops:
     ``av_matmul(softmax(attn_scaling(qk_matmul(q, k^T), scale) + mask), v)``."""
+    from ..qat.linear import flush_forward
+    flush_forward()                            # projections whose forward products are still pending (a training step: one launch for q / k / v)
     n_rep = getattr(module, "num_key_value_groups", 1)
     key = _repeat_kv(key, n_rep)
     value = _repeat_kv(value, n_rep)

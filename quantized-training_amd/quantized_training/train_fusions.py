@@ -45,11 +45,12 @@ class _Counters:
     embeddings = 0        # embedding weight gradients by qt_embedding_backward_bf16
     addlns = 0            # residual adds formed inside a LayerNorm launch
     qkv_groups = 0        # query / key / value backward products launched as one dgrad + one wgrad launch
+    qkv_forward_groups = 0   # query / key / value forward products launched together
     missed = []           # ... their names and what differed (the first few)
 
     @classmethod
     def reset(cls):
-        cls.chains = cls.members = cls.colsums = cls.colsum_fallbacks = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = cls.qkv_groups = 0
+        cls.chains = cls.members = cls.colsums = cls.colsum_fallbacks = cls.misses = cls.attention = cls.fanins = cls.deferred = cls.embeddings = cls.addlns = cls.qkv_groups = cls.qkv_forward_groups = 0
         cls.missed = []
 
 
@@ -67,8 +68,9 @@ STATS = _Counters
 # 128 qkvgemm    the input and weight gradients of query / key / value as six launches instead of two
 # 256 optimizer  torch's own clip_grad_norm_ + optimizer.step() launches (optim.py)
 # 512 pairgemm   a Linear's input and weight gradient as two launches instead of one (q / k / v: two instead of one)
+# 1024 qkvfwd    the forward products of query / key / value as three launches instead of one
 DEBUG_BITS = {"chains": 1, "colsum": 2, "producers": 4, "attention": 8, "fanin": 16, "embedding": 32, "addln": 64, "qkvgemm": 128, "optimizer": 256,
-              "pairgemm": 512}
+              "pairgemm": 512, "qkvfwd": 1024}
 
 
 def _on(name):
@@ -107,6 +109,18 @@ def put_colsum(g, gb):
 
 
 _LINEAR_GRADS = {}        # (data_ptr, version, shape) of a grad_output -> (that tensor, identity of x and Wq, grad_input, grad_weight): one-shot, like _COLSUM
+
+
+def _mark_qkv_members(lins):
+    """The three projections in front of an attention core that runs as _AttentionTrainFn: from the next step on their forward products
+    go out as one launch (modules/qat/linear.py, flush_forward).  Only QAT Linears of one shape without forward hooks of their own (a hook
+    would see the output before the launch that writes it)."""
+    from .modules.qat.linear import Linear as QATLinear
+    if not all(type(l) is QATLinear and not l._forward_hooks and l.weight.shape == lins[0].weight.shape and (l.bias is None) == (lins[0].bias is None)
+               for l in lins):
+        return
+    for l in lins:
+        l.__dict__["_qt_qkv_member"] = True
 
 
 def group_qkv_backward(lins, gys):
@@ -1123,6 +1137,7 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
             return None
         mask = m
     lins = tuple(getattr(attn, n, None) for n in ("query", "key", "value"))
+    _mark_qkv_members(lins)
     return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins, drop_p)
 
 

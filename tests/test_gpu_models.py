@@ -1427,7 +1427,7 @@ def test_training_attention_core_is_one_launch_each_way(monkeypatch, drop):
         assert abs(sa - sb) <= 0.3 * max(abs(sa), abs(sb)), (k, sa, sb)
 
 
-@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln", "qkvgemm", "pairgemm"])
+@pytest.mark.parametrize("switch", ["fanin", "embedding", "addln", "qkvgemm", "pairgemm", "qkvfwd"])
 def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
     """Two fusions of the training step that reproduce torch's arithmetic exactly, each switched off and on with everything else on; three
     steps: every loss, every fake-quantizer's scale and amax history and every parameter BIT-IDENTICAL, the same fake-quantized element
@@ -1440,6 +1440,8 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
                           result's values left to that launch)
       qkvgemm (128)       the six backward products of query / key / value (three input gradients, three weight gradients) launched by the
                           attention backward as one launch (two with bit 512) instead of six single ones
+      qkvfwd (1024)       the forward products of query / key / value in one launch (the projections return their outputs unwritten;
+                          the third one, or the attention function's entry, launches the three problems together)
       pairgemm (512)      a Linear's input and weight gradient in ONE launch of qt_train_gemm_backward_bf16 (query / key / value: all six
                           products) instead of two launches of qt_train_gemm_bf16"""
     import copy
@@ -1487,6 +1489,8 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         assert plain[3][2] == 0 and fused[3][2] == 3 * 3 and fused[3][3] == 0, (plain[3], fused[3])      # three tables, three steps
     elif switch == "qkvgemm":
         assert plain[3][5] == 0 and fused[3][5] == 2 * 2 and fused[3][3] == 0, (plain[3], fused[3])      # layers x steps 2..3
+    elif switch == "qkvfwd":
+        assert "train:forward q/k/v 3x(512x256x256)" in fused[5] and not any("forward q/k/v" in k for k in plain[5]), (plain[5], fused[5])
     elif switch == "pairgemm":
         pairs = [k for k in fused[5] if k.startswith("train:dgrad + wgrad")]
         # tokens x out x in: q / k / v together, the attention output dense, the two FFN Linears
