@@ -443,7 +443,7 @@ typedef struct qt_linear_backward {
 int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int T, int O, int I, long ld_gy, long ld_w, long ld_x, long ld_gx,
                                 long ld_gw, void *stream);
 
-/* ---- H3's step end: clip_grad_norm_(max_norm) and the AdamW update of every parameter tensor in three launches -----------------------
+/* ---- H3's step end: clip_grad_norm_(max_norm) and the AdamW update of every parameter tensor in four launches ------------------------
  *     run_glue_no_trainer.py:655-668   accelerator.clip_grad_norm_(model.parameters(), 1.0); optimizer.step()
  * The arithmetic is torch's, which the reference calls: torch.nn.utils.clip_grad_norm_ on bf16 gradients (per-tensor norms and the
  * coefficient rounded to bf16 where torch's tensors are bf16) and torch.optim.AdamW's fused kernel (torch 2.10, ATen/native/cuda/

@@ -331,7 +331,14 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
     __shared__ uint4 s_rows[KIND == kFmtRows ? 512 : 1];
     QT_EW_STAMP(a, 0);
     QT_EW_STAMP_HEAD(a, 0x100 + NS * 16 + (a.colsum_stage >= 0 ? 1 : 0) + (a.pre_op << 1));
-    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock, a.table_in_lds != 0);
+    // (a run-time choice of where the row table lies makes its pointer generic: every row gather becomes a flat_load.  The product build
+    // always stages the table; the tuning build keeps the switch.)
+#ifdef QT_TUNING_BUILD
+    const bool rows_in_lds = a.table_in_lds != 0;
+#else
+    constexpr bool rows_in_lds = true;
+#endif
+    const Rounder<KIND> rnd = chain_rounder<KIND>(fmt, lut, s_rows, kChainBlock, rows_in_lds);
     QT_EW_STAMP(a, 1);
     const int t = threadIdx.x;
     const int v = t % kChainStripV, rl = t / kChainStripV;
@@ -1780,7 +1787,11 @@ static void chain_geometry(long rows, long cols, int &strips, int &bands, long &
     // measured: 96 and 384 workgroups are both slower than 192 on [2048, 768] (profiles/r05_chain_geometry.txt; 192 and 256 cut that shape
     // the same way: 12 strips x 16 bands).  On [2048, 3072] -- the GELU launches, bound by their erf / exp arithmetic, not by memory
     // (tools/exp_train_stamps.py: 20 of 26 us between the loads and the last store) -- 192 left a quarter of the CUs idle: 48 strips x 6
-    // bands instead of x 4 took 0.12 ms off the configs[4] step (profiles/r06_train_step_ab.txt).
+    // bands instead of x 4 took 0.12 ms off the configs[4] step (profiles/r06_train_step_ab.txt).  Tried on the GELU launches afterwards,
+    // none faster (profiles/r06_chain_experiments.txt): GELU(x) / its derivative gathered from per-device tables over all bf16 inputs
+    // (from global memory, and from a 19 KiB slice in LDS), four rows in flight per lane instead of two (133 registers: 22.9 -> 29.7 us),
+    // a strip-less variant for launches without column sums (consecutive lanes on consecutive vectors).  What is left of these launches
+    // is not their arithmetic and not their access pattern.
     int target = 256;
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_WGS")) target = atoi(e) > 0 ? atoi(e) : target;          // tools/ only

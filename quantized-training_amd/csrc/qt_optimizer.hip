@@ -1,10 +1,11 @@
 // qt_optimizer.hip -- the end of a fine-tuning step (H3: run_glue_no_trainer.py:655-668 upstream): clip_grad_norm_(max_norm) and the
-// AdamW update of every parameter tensor, three launches for the whole model instead of torch's ~33 (8 + 8 + 8 multi-tensor launches,
+// AdamW update of every parameter tensor, four launches for the whole model instead of torch's ~33 (8 + 8 + 8 multi-tensor launches,
 // a norm clean-up and eight scalar kernels for the coefficient).
 //
 //   sumsq     one workgroup per 8192-element chunk of one gradient: the chunk's sum of squares (fp32), in a fixed order
-//   finalize  one workgroup: per-tensor norms (the chunks of a tensor added in chunk order, in fp64), rounded to bf16 as
-//             torch._foreach_norm returns them for bf16 gradients; total = bf16(sqrt(sum norm_t^2)); the coefficient exactly as
+//   norms     one wave per tensor: the chunks of a tensor added in a fixed order in fp64, the norm rounded to bf16 as
+//             torch._foreach_norm returns it for bf16 gradients
+//   finalize  one workgroup: total = bf16(sqrt(sum norm_t^2)); the coefficient exactly as
 //             torch.nn.utils.clip_grad_norm_ forms it in bf16 -- t = bf16(total + 1e-6), r = bf16(1 / t), c = min(bf16(r * max_norm), 1);
 //             every tensor's step count + 1 and its two bias corrections
 //   apply     one workgroup per chunk: g' = bf16(g * c) (the in-place _foreach_mul_ of the clip; g itself is left alone -- the loop
@@ -82,32 +83,37 @@ struct OptScalars {
     float total_norm;         // bf16 value
 };
 
-__global__ __launch_bounds__(1024) void adamw_finalize_kernel(qt_adamw_tensor *__restrict__ tensors, int ntensors, long nchunks, const float *__restrict__ partial,
+// one wave per tensor: the chunks of the tensor added in a fixed order (lanes stride over them, a butterfly in fp64), the norm rounded to
+// bf16 as torch._foreach_norm returns it for bf16 gradients; its square goes to the finalize launch
+__global__ __launch_bounds__(64) void adamw_tensor_norms_kernel(const qt_adamw_tensor *__restrict__ tensors, int ntensors, long nchunks,
+                                                               const float *__restrict__ partial, double *__restrict__ norm_sq) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const long c0 = tensors[t].first_chunk, c1 = t + 1 < ntensors ? tensors[t + 1].first_chunk : nchunks;
+    double s = 0.0;
+    long c = c0 + lane;
+    for (; c + 7 * 64 < c1; c += 8 * 64) {                            // eight loads in flight (the embedding matrix alone has ~4700 chunks)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[c + u * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; c < c1; c += 64) s += (double)partial[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float norm = bf16_round(sqrtf((float)s));                   // fp32 sum, sqrt, result in the gradients' dtype
+    if (lane == 0) norm_sq[t] = (double)norm * (double)norm;
+}
+
+__global__ __launch_bounds__(1024) void adamw_finalize_kernel(qt_adamw_tensor *__restrict__ tensors, int ntensors, const double *__restrict__ norm_sq,
                                                               float max_norm, float2 *__restrict__ bias_corr, OptScalars *__restrict__ scalars,
                                                               float *__restrict__ total_norm_out, int do_norm, int do_steps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ double s_sq[16];
+    __shared__ double s_sq[1024];
     const bool clip = do_norm && max_norm > 0.0f;
     if (clip) {
-        double acc = 0.0;                                            // this wave's tensors, in tensor order
-        for (int t = wave; t < ntensors; t += 16) {
-            const long c0 = tensors[t].first_chunk, c1 = t + 1 < ntensors ? tensors[t + 1].first_chunk : nchunks;
-            double s = 0.0;
-            long c = c0 + lane;
-            for (; c + 7 * 64 < c1; c += 8 * 64) {                   // eight loads in flight (the embedding matrix alone has ~4700 chunks)
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = partial[c + u * 64];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s += (double)v[u];
-            }
-            for (; c < c1; c += 64) s += (double)partial[c];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            const float norm = bf16_round(sqrtf((float)s));           // torch._foreach_norm: fp32 sum, sqrt, result in the gradients' dtype
-            acc += (double)norm * (double)norm;
-        }
-        if (lane == 0) s_sq[wave] = acc;
+        double acc = 0.0;                                            // thread i: tensors i, i + 1024, ... in that order
+        for (int t = threadIdx.x; t < ntensors; t += 1024) acc += norm_sq[t];
+        s_sq[threadIdx.x] = acc;
     }
     // step counts and bias corrections (fused_adam_utils.cuh:128-136: 1 - pow(beta, step) in double, sqrt of the second)
     for (int t = threadIdx.x; do_steps && t < ntensors; t += 1024) {
@@ -121,12 +127,16 @@ __global__ __launch_bounds__(1024) void adamw_finalize_kernel(qt_adamw_tensor *_
         bias_corr[t] = float2{(float)bc1, (float)sqrt(bc2)};
     }
     __syncthreads();
+    if (clip) {                                                      // a fixed-order tree over the 1024 slots
+        for (int half = 512; half >= 1; half >>= 1) {
+            if ((int)threadIdx.x < half) s_sq[threadIdx.x] += s_sq[threadIdx.x + half];
+            __syncthreads();
+        }
+    }
     if (threadIdx.x == 0 && do_norm) {
         float coef = 1.0f, total = 0.0f;
         if (clip) {
-            double sum = 0.0;
-            for (int w = 0; w < 16; ++w) sum += s_sq[w];
-            total = bf16_round(sqrtf((float)sum));                   // linalg.vector_norm over the stacked bf16 norms
+            total = bf16_round(sqrtf((float)s_sq[0]));               // linalg.vector_norm over the stacked bf16 norms
             const float t1 = bf16_round(total + 1e-6f);              // clip_grad.py: max_norm / (total_norm + 1e-6), python scalar / tensor
             const float r = bf16_round(1.0f / t1);                   //   = tensor.reciprocal() * max_norm
             coef = bf16_round(r * max_norm);
@@ -239,7 +249,7 @@ extern "C" long qt_clip_adamw_plan(qt_adamw_tensor *tensors_host, int ntensors, 
 
 extern "C" size_t qt_clip_adamw_ws_bytes(int ntensors, long nchunks) {
     if (ntensors < 0 || nchunks < 0) return 0;
-    return (size_t)nchunks * sizeof(float) + (size_t)ntensors * sizeof(float2) + 64;
+    return (size_t)nchunks * sizeof(float) + (size_t)ntensors * (sizeof(float2) + sizeof(double)) + 64;
 }
 
 extern "C" int qt_clip_adamw_bf16(qt_adamw_tensor *tensors_dev, const int32_t *chunk_tensor_dev, int ntensors, long nchunks, float max_norm,
@@ -251,14 +261,18 @@ extern "C" int qt_clip_adamw_bf16(qt_adamw_tensor *tensors_dev, const int32_t *c
     if (((uintptr_t)ws_dev & 15u) || ((uintptr_t)tensors_dev & 7u)) return QT_ERR_UNALIGNED;
     OptScalars *scalars = (OptScalars *)ws_dev;
     float2 *bias_corr = (float2 *)((char *)ws_dev + 64);
-    float *partial = (float *)(bias_corr + ntensors);
+    double *norm_sq = (double *)(bias_corr + ntensors);
+    float *partial = (float *)(norm_sq + ntensors);
     hipStream_t st = (hipStream_t)stream;
     const bool clip = max_norm > 0.0f;
     // phases: 1 = the norm and the coefficient (left in the workspace; total_norm_out written), 2 = step counts + the update with the
-    // coefficient the workspace holds.  3 = both, three launches.  A caller that must look at the norm first (error_if_nonfinite)
+    // coefficient the workspace holds.  3 = both, four launches.  A caller that must look at the norm first (error_if_nonfinite)
     // issues 1, reads total_norm_out, then 2.
-    if ((phases & 1) && clip && nchunks > 0) adamw_sumsq_kernel<<<(unsigned)nchunks, kOptBlock, 0, st>>>(tensors_dev, chunk_tensor_dev, partial);
-    adamw_finalize_kernel<<<1, 1024, 0, st>>>(tensors_dev, ntensors, nchunks, partial, max_norm, bias_corr, scalars, total_norm_out_dev, phases & 1,
+    if ((phases & 1) && clip) {
+        if (nchunks > 0) adamw_sumsq_kernel<<<(unsigned)nchunks, kOptBlock, 0, st>>>(tensors_dev, chunk_tensor_dev, partial);
+        adamw_tensor_norms_kernel<<<(unsigned)ntensors, 64, 0, st>>>(tensors_dev, ntensors, nchunks, partial, norm_sq);
+    }
+    adamw_finalize_kernel<<<1, 1024, 0, st>>>(tensors_dev, ntensors, norm_sq, max_norm, bias_corr, scalars, total_norm_out_dev, phases & 1,
                                               (phases & 2) ? 1 : 0);
     if ((phases & 2) && nchunks > 0) adamw_apply_kernel<<<(unsigned)nchunks, kOptBlock, 0, st>>>(tensors_dev, chunk_tensor_dev, bias_corr, scalars, clip ? 1 : 0);
     return opt_launch_status();

@@ -3,7 +3,7 @@
 Upstream (examples/text_classification/run_glue_no_trainer.py:469-474, 655-668) builds `torch.optim.AdamW` over two parameter groups
 and calls `accelerator.clip_grad_norm_(model.parameters(), 1.0)`, `optimizer.step()`, `lr_scheduler.step()`, `optimizer.zero_grad()`.
 On a RoBERTa-base classifier torch spends 33 launches and 0.95 ms on the first two (one multi-tensor launch per ~25 tensors for the
-norms, the scaling and the update; ten scalar kernels for the coefficient).  `clip_and_step` does the same arithmetic in three launches
+norms, the scaling and the update; ten scalar kernels for the coefficient).  `clip_and_step` does the same arithmetic in four launches
 over the optimizer's OWN state: the `torch.optim.AdamW` object stays what the caller built -- its `state` / `state_dict()`, parameter
 groups, learning-rate schedulers and checkpoints keep working -- only the launches differ.
 
@@ -201,5 +201,5 @@ def clip_and_step(parameters, optimizer, max_norm=None, error_if_nonfinite=False
     else:
         launch(3)
     optimizer._opt_called = True                                # what a patched optimizer.step() tells torch's LR schedulers
-    ROUTES["train:clip + optimizer"] = f"in_tree_clip_adamw, 3 launches ({plan.ntensors} tensors, {plan.nchunks} chunks)"
+    ROUTES["train:clip + optimizer"] = f"in_tree_clip_adamw, 4 launches ({plan.ntensors} tensors, {plan.nchunks} chunks)"
     return plan.total_norm.to(torch.bfloat16) if max_norm is not None else None
