@@ -254,24 +254,24 @@ __global__ __launch_bounds__(256) void fq_gather_vec_kernel(const void *__restri
 // behind it: grad_output.sum(0), run_glue_no_trainer.py:660-667) -- rows are dealt to workgroups in bands, a lane adds its rows in
 // row order, the lanes of a column in lane order, the workgroups in workgroup order (last arriver, through a workspace): deterministic.
 // Tuning build only (tools/exp_train_stamps.py): s_memrealtime (100 MHz, one counter for the whole chip) of wave 0 and of the last wave
-// of a workgroup at a few points of the chain / LayerNorm-backward kernels.  QT_EW_STAMPS = device address of [launch][512 workgroups][16]
+// of a workgroup at a few points of the chain / LayerNorm-backward kernels.  QT_EW_STAMPS = device address of [launch][512 workgroups][32]
 // slots; every launch the host issues takes the next region (a captured graph keeps the region of its capture).
 #ifdef QT_TUNING_BUILD
-#define QT_EW_STAMP_FIELD unsigned long long *dbg;
+#define QT_EW_STAMP_FIELD unsigned long long *dbg; int ablate;
 #define QT_EW_STAMP(a, slot)                                                                                                     \
     do {                                                                                                                         \
         if ((a).dbg && blockIdx.x < 512 && (threadIdx.x & 63) == 0 && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64))      \
-            (a).dbg[(size_t)blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + (slot)] = __builtin_amdgcn_s_memrealtime();                \
+            (a).dbg[(size_t)blockIdx.x * 32 + (threadIdx.x ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memrealtime();                \
     } while (0)
 #define QT_EW_STAMP_HEAD(a, tag)                                                                                                 \
     do {                                                                                                                         \
-        if ((a).dbg && blockIdx.x < 512 && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)(tag) << 32) | gridDim.x; \
+        if ((a).dbg && blockIdx.x < 512 && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 32 + 7] = ((unsigned long long)(tag) << 32) | gridDim.x; \
     } while (0)
 static unsigned long long *ew_stamp_region() {
     const char *e = getenv("QT_EW_STAMPS");
     if (!e) return nullptr;
     static int launch = 0;
-    return (unsigned long long *)strtoull(e, nullptr, 0) + (size_t)(launch++ % 256) * 512 * 16;
+    return (unsigned long long *)strtoull(e, nullptr, 0) + (size_t)(launch++ % 256) * 512 * 32;
 }
 #else
 #define QT_EW_STAMP_FIELD
@@ -366,15 +366,38 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
                     if (a.pre_op == 2) q2[u] = a.x2[r * a.cv + cvec];
                 }
             }
+#ifdef QT_TUNING_BUILD
+            if (a.dbg) {                                             // (diagnosis: the first two rounds split into load wait and the rest)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (r0 == r_begin + rl) QT_EW_STAMP(a, 8);
+                else if (r0 == r_begin + rl + (long)kChainRowLanes * kChainUnroll) QT_EW_STAMP(a, 10);
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < kChainUnroll; ++u) {
                 const long r = r0 + (long)u * kChainRowLanes;
                 if (r >= r_end) continue;
                 const size_t idx = (size_t)(r * a.cv + cvec);
+#ifdef QT_TUNING_BUILD
+                // QT_CHAIN_ABLATE (timing only, results are garbage): 1 = no GELU arithmetic, 2 = no fake-quantizer stages
+                const uint4 val = (a.ablate & 1) ? q[u] : chain_prologue(a.pre_op, q[u], q2[u]);
+                if (a.pre_op && a.pre_out) a.pre_out[idx] = val;
+                uint4 res[NS];
+                if (a.ablate & 2) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        res[i] = val;
+                        if (a.st[i].out) a.st[i].out[idx] = val;
+                    }
+                } else {
+                    chain_stages<KIND, NS>(a.st, sc, rnd, val, idx, amax, res);
+                }
+#else
                 const uint4 val = chain_prologue(a.pre_op, q[u], q2[u]);
                 if (a.pre_op && a.pre_out) a.pre_out[idx] = val;
                 uint4 res[NS];
                 chain_stages<KIND, NS>(a.st, sc, rnd, val, idx, amax, res);
+#endif
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     if (a.colsum_stage == i) {
@@ -385,6 +408,12 @@ __global__ __launch_bounds__(kChainBlock) void fq_chain_kernel(ChainArgs a, qt_f
                     }
                 }
             }
+#ifdef QT_TUNING_BUILD
+            if (a.dbg) {
+                if (r0 == r_begin + rl) QT_EW_STAMP(a, 9);
+                else if (r0 == r_begin + rl + (long)kChainRowLanes * kChainUnroll) QT_EW_STAMP(a, 11);
+            }
+#endif
         }
     }
     // ---- amax of every stage's input: wave, then workgroup, then at most one atomic per stage and workgroup
@@ -1787,11 +1816,11 @@ static void chain_geometry(long rows, long cols, int &strips, int &bands, long &
     // measured: 96 and 384 workgroups are both slower than 192 on [2048, 768] (profiles/r05_chain_geometry.txt; 192 and 256 cut that shape
     // the same way: 12 strips x 16 bands).  On [2048, 3072] -- the GELU launches, bound by their erf / exp arithmetic, not by memory
     // (tools/exp_train_stamps.py: 20 of 26 us between the loads and the last store) -- 192 left a quarter of the CUs idle: 48 strips x 6
-    // bands instead of x 4 took 0.12 ms off the configs[4] step (profiles/r06_train_step_ab.txt).  Tried on the GELU launches afterwards,
-    // none faster (profiles/r06_chain_experiments.txt): GELU(x) / its derivative gathered from per-device tables over all bf16 inputs
-    // (from global memory, and from a 19 KiB slice in LDS), four rows in flight per lane instead of two (133 registers: 22.9 -> 29.7 us),
-    // a strip-less variant for launches without column sums (consecutive lanes on consecutive vectors).  What is left of these launches
-    // is not their arithmetic and not their access pattern.
+    // bands instead of x 4 took 0.12 ms off the configs[4] step (profiles/r06_train_step_ab.txt).  Tried on the GELU launches afterwards
+    // without gain in the replayed step (profiles/r06_chain_experiments.txt): four rows in flight per lane instead of two (133 registers:
+    // 22.9 -> 29.7 us), a strip-less variant for launches without column sums, GELU(x) / GELU'(x) gathered from tables (global memory;
+    // a 19 KiB slice in LDS).  One wave's arithmetic runs under the load latency of the SIMD's other wave: what such a launch spends is
+    // its dependent load -> arithmetic -> store rounds plus ~7 us of fixed start and end.
     int target = 256;
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_WGS")) target = atoi(e) > 0 ? atoi(e) : target;          // tools/ only
@@ -1821,6 +1850,7 @@ static int chain_launch(const uint16_t *x_dev, const uint16_t *x2_dev, int pre_o
     a.table_in_lds = 1;
 #ifdef QT_TUNING_BUILD
     if (const char *e = getenv("QT_CHAIN_LDS")) a.table_in_lds = atoi(e);                          // tools/ only
+    if (const char *e = getenv("QT_CHAIN_ABLATE")) a.ablate = atoi(e);                             // tools/ only: timing, garbage results
     a.dbg = ew_stamp_region();
 #endif
     for (int i = 0; i < nstage; ++i) {

@@ -6,7 +6,9 @@ Every workgroup (first 512) of fq_chain_kernel / ln_train_bwd_kernel stamps s_me
 last wave at a few points (QT_EW_STAMPS, csrc/qt_elementwise.hip).  The step is captured into a hipGraph as bench.py does and replayed;
 each captured launch keeps its own stamp region, so the last replay's stamps of every launch are read back together.  Printed per
 launch: tag (0x1NS. chain, 0x2NS. LayerNorm backward), grid, the launch's span (first start -> last end), the spread of workgroup
-starts, and the median over workgroups of each phase (us after the workgroup's own start).
+starts, and the median over workgroups of each phase (us after the workgroup's own start; the last four columns of a chain launch: round 1
+loads arrived / round 1 done / round 2 loads arrived / round 2 done; QT_CHAIN_ABLATE=1 / 2 / 3 times the launches without their GELU
+arithmetic / fake-quantizer stages / both).
 """
 import os
 import sys
@@ -23,7 +25,7 @@ from transformers import RobertaConfig, RobertaForSequenceClassification  # noqa
 
 NL = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda:0")
-REGION = 512 * 16
+REGION = 512 * 32
 stamps = torch.zeros(256 * REGION, dtype=torch.int64, device=dev)
 torch.manual_seed(0)
 model = RobertaForSequenceClassification(RobertaConfig(num_labels=2, num_hidden_layers=NL, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).to(dev).bfloat16()
@@ -42,7 +44,7 @@ del os.environ["QT_EW_STAMPS"]
 for i in range(5):
     step2.replay(batches[1 + i])
 torch.cuda.synchronize()
-s = stamps.cpu().view(256, 512, 16)
+s = stamps.cpu().view(256, 512, 32)
 print("launch  tag    grid   span_us  start_spread_us | wave 0: phases (median us after own start) | last wave: phases")
 rows = []
 for li in range(256):
@@ -53,15 +55,15 @@ for li in range(256):
     n = min(grid, 512)
     r = s[li, :n].double() / 100.0       # us
     t0 = r[:, 0]
-    w0 = r[:, :7]
-    w7 = r[:, 8:15]
+    w0 = torch.cat([r[:, :7], r[:, 8:12]], dim=1)
+    w7 = torch.cat([r[:, 16:23], r[:, 24:28]], dim=1)
     ends = torch.maximum(w0.max(dim=1).values, w7.max(dim=1).values)
     span = float(ends.max() - t0.min())
     spread = float(t0.max() - t0.min())
 
     def phases(w):
         out = []
-        for k in range(1, 7):
+        for k in range(1, w.shape[1]):
             col = w[:, k]
             ok = col > 0
             out.append(f"{float((col[ok] - t0[ok]).median()):6.2f}" if ok.any() else "     -")
