@@ -110,7 +110,9 @@ for src, dst in (("window_breakdown.txt", "window_breakdown.txt"), ("window_brea
                  # round 5
                  ("train_step_sequence.txt", "train_step_sequence.txt"), ("train_step_ab.txt", "train_step_ab.txt"), ("chain_microbench.txt", "chain_microbench.txt"),
                  ("bench_roberta-mrpc-int8-e5m2-train-dropout.json", "roberta_mrpc_train_dropout_bench.json"),
-                 ("attention_train_stamps.txt", "attention_train_stamps.txt")):
+                 ("attention_train_stamps.txt", "attention_train_stamps.txt"),
+                 # round 6
+                 ("train_stamps.txt", "train_stamps.txt"), ("graph_branches.txt", "graph_branches.txt")):
     clean(os.path.join(G, src), os.path.join(out, f"{tag}_{dst}"))
 for pattern, dst in (("prof_13b_posit/*/*kernel_stats.csv", "13b_posit8_2_kernel_stats.csv"), ("prof_mx_gemm/*/*kernel_stats.csv", "mx_gemm_kernel_stats.csv"),
                      ("prof_mx_layer/*/*kernel_stats.csv", "mx_layer_kernel_stats.csv"),

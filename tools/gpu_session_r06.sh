@@ -21,7 +21,10 @@ python tools/window_breakdown.py gpurun_out/prof_bert_stats --windows 3 --layers
 find gpurun_out/prof_13b_posit gpurun_out/prof_train_stats gpurun_out/prof_bert_stats -name "*kernel_trace.csv" -delete
 head -12 gpurun_out/window_breakdown_13b_posit.txt; head -8 gpurun_out/train_step_breakdown.txt; head -8 gpurun_out/bert_batch_breakdown.txt
 # training step A/B on this box, the chain microbenchmark
-timeout 1500 python tools/ab_env.py --workload roberta-mrpc-int8-e5m2-train --reps 2 --steps 10 "" QT_TRAIN_GEMM=0 QT_TRAIN_DEBUG=8 QT_TRAIN_DEBUG=4 QT_TRAIN_DEBUG=1 > gpurun_out/train_step_ab.txt 2>&1; cat gpurun_out/train_step_ab.txt
+# (QT_TRAIN_DEBUG 1920 = 128 + 256 + 512 + 1024: the launch structure of the round's first half -- single GEMM launches, torch's clip + optimizer)
+timeout 2400 python tools/ab_env.py --workload roberta-mrpc-int8-e5m2-train --reps 2 --steps 10 "" QT_TRAIN_DEBUG=256 QT_TRAIN_DEBUG=512 QT_TRAIN_DEBUG=1024 QT_TRAIN_DEBUG=128 QT_TRAIN_DEBUG=1920 "QT_TRAIN_DEBUG=1920 QT_TRAIN_GEMM=0" QT_TRAIN_DEBUG=8 QT_TRAIN_DEBUG=4 QT_TRAIN_DEBUG=1 > gpurun_out/train_step_ab.txt 2>&1; cat gpurun_out/train_step_ab.txt
+timeout 600 python tools/exp_train_stamps.py 12 > gpurun_out/train_stamps.txt 2>&1; tail -5 gpurun_out/train_stamps.txt
+timeout 300 python tools/exp_graph_branches.py > gpurun_out/graph_branches.txt 2>&1; cat gpurun_out/graph_branches.txt
 # value-map GEMM PMC passes (unchanged kernel: the traffic entry of the bench line's secondary roofline)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_fqt -- python3 tools/roofline_fqt.py > gpurun_out/prof_fqt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_fqt -- python3 tools/roofline_fqt.py > gpurun_out/pmc_fetch_fqt.log 2>&1
