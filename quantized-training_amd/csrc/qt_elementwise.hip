@@ -975,16 +975,28 @@ __global__ __launch_bounds__(kMultiBlock) void fq_multi_kernel(const qt_fq_item_
         rnd.glut = lut;
         __syncthreads();
     }
-    // the tensor this tile belongs to: last item whose first tile is <= blockIdx.x (uniform: every lane walks the same way)
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].first <= (unsigned long long)blockIdx.x) lo = mid;
-        else hi = mid - 1;
+    // the tensor this tile belongs to: the last item whose first tile is <= blockIdx.x.  Wave 0 looks at all items at once (lane l at
+    // items l, l + 64, ...: independent loads, one round trip) -- a binary search is log2(count) DEPENDENT loads, 3-5 us in front of a
+    // tile that takes 3
+    __shared__ int s_item;
+    if (threadIdx.x < 64) {
+        int best = 0;
+        for (int j = (int)threadIdx.x; j < count; j += 64)
+            if (items[j].first <= (unsigned long long)blockIdx.x) best = j;          // (`first` ascends with j)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+        if (threadIdx.x == 0) s_item = best;
     }
-    const qt_fq_item_dev it = items[lo];
+    __syncthreads();
+    const qt_fq_item_dev it = items[s_item];
     const size_t v0 = ((size_t)blockIdx.x - it.first) * kMultiTile;
     const float s = qt_bf2f(qt_f2bf(*it.scale));
+    // (pointers that come out of memory are generic to the compiler: say that they are global, or every access is a flat_ instruction)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4_t *gload_t;
+    typedef __attribute__((address_space(1))) u32x4_t *gstore_t;
+    const gload_t gx = (gload_t)(const void *)it.x;
+    const gstore_t gy = (gstore_t)(void *)it.y;
     const UniformDiv dv(s);
     uint32_t amax = 0;
     auto run = [&](auto divc, auto obsc) __attribute__((always_inline)) {
@@ -994,13 +1006,17 @@ __global__ __launch_bounds__(kMultiBlock) void fq_multi_kernel(const qt_fq_item_
 #pragma unroll
         for (int u = 0; u < kMultiUnroll; ++u) {
             const size_t i = v0 + (size_t)u * kMultiBlock + threadIdx.x;
-            v[u] = i < it.nvec ? it.x[i] : uint4{0u, 0u, 0u, 0u};
+            v[u] = uint4{0u, 0u, 0u, 0u};
+            if (i < it.nvec) {
+                const u32x4_t t = gx[i];
+                v[u] = uint4{t.x, t.y, t.z, t.w};
+            }
         }
 #pragma unroll
         for (int u = 0; u < kMultiUnroll; ++u) {
             const size_t i = v0 + (size_t)u * kMultiBlock + threadIdx.x;
             const uint4 r = fq_vec<kIoBf16, KIND, DIV, OBS>(v[u], dv, rnd, amax);
-            if (i < it.nvec) it.y[i] = r;
+            if (i < it.nvec) gy[i] = u32x4_t{r.x, r.y, r.z, r.w};
         }
     };
     const bool obs = it.amax != nullptr;                      // uniform
@@ -1031,21 +1047,32 @@ constexpr int kMulti8Tile = 256 * 4;
 
 template <bool E5M2>
 __global__ __launch_bounds__(256) void fq8_items_kernel(const qt_fq8_item_dev *__restrict__ items, int count, qt_format fmt) {
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].first <= (unsigned long long)blockIdx.x) lo = mid;
-        else hi = mid - 1;
+    // (the tile's tensor by one round of independent loads, its pointers declared global: see fq_multi_kernel)
+    __shared__ int s_item;
+    if (threadIdx.x < 64) {
+        int best = 0;
+        for (int j = (int)threadIdx.x; j < count; j += 64)
+            if (items[j].first <= (unsigned long long)blockIdx.x) best = j;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+        if (threadIdx.x == 0) s_item = best;
     }
-    const qt_fq8_item_dev it = items[lo];
+    __syncthreads();
+    const qt_fq8_item_dev it = items[s_item];
     const size_t p0 = ((size_t)blockIdx.x - it.first) * kMulti8Tile;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) u32x4_t *const gx = (const __attribute__((address_space(1))) u32x4_t *)(const void *)it.x;
     uint32_t mag = 0;
     uint4 v0[4], v1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const size_t i = p0 + (size_t)u * 256 + threadIdx.x;
-        if (i < it.npair) { v0[u] = it.x[2 * i]; v1[u] = it.x[2 * i + 1]; }
-        else { v0[u] = v1[u] = uint4{0u, 0u, 0u, 0u}; }
+        v0[u] = v1[u] = uint4{0u, 0u, 0u, 0u};
+        if (i < it.npair) {
+            const u32x4_t a = gx[2 * i], b = gx[2 * i + 1];
+            v0[u] = uint4{a.x, a.y, a.z, a.w};
+            v1[u] = uint4{b.x, b.y, b.z, b.w};
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
