@@ -96,9 +96,10 @@ def train_gemm_group(As, Bs, trans_a, trans_b, kind, biases=None, outs=None):
 # ---- the forward products of query / key / value as one launch ---------------------------------------------------------------------------
 # Hugging Face's self-attention block calls the three projections one after the other on the same hidden states and only reshapes their
 # results before it hands them to the attention function.  A projection that train_fusions marked as such a member (the fused training
-# attention engaged behind it on an earlier step) returns its output tensor UNWRITTEN and leaves the product here; the third member's
-# forward -- or, whatever came in between, the attention function's entry, the next other Linear, any backward -- launches what is
-# pending: three problems of one shape as ONE launch of qt_train_gemm_bf16 (17 us against 3 x 8-11), otherwise one by one.
+# attention engaged behind it on an earlier step) returns its output tensor UNWRITTEN -- only while that block's forward is running
+# (train_fusions.attention_block_active) -- and leaves the product here; the third member's forward -- or, whatever came in between, the
+# attention function's entry, the end of the block's forward, the next other Linear, any backward -- launches what is pending: three
+# problems of one shape as ONE launch of qt_train_gemm_bf16 (17 us against 3 x 8-11), otherwise one by one.
 _FWD_PENDING = []         # (x2, wq, bias, y2)
 
 
@@ -275,9 +276,10 @@ class Linear(nn.Linear):
             import weakref
             self.__dict__["_qt_train_xw"] = (weakref.ref(input), weakref.ref(wq))
             defer = False
-            if self.__dict__.get("_qt_qkv_member", False) and not self._forward_hooks:
+            owner = self.__dict__.get("_qt_qkv_member")
+            if owner is not None and not self._forward_hooks:
                 from ... import train_fusions
-                defer = train_fusions._on("qkvfwd")
+                defer = train_fusions.attention_block_active(owner) and train_fusions._on("qkvfwd")
             return _LinearColsumBias.apply(input, wq, b, defer)
         return F.linear(input, wq, b)
 

@@ -111,16 +111,44 @@ def put_colsum(g, gb):
 _LINEAR_GRADS = {}        # (data_ptr, version, shape) of a grad_output -> (that tensor, identity of x and Wq, grad_input, grad_weight): one-shot, like _COLSUM
 
 
-def _mark_qkv_members(lins):
+_ATTN_ACTIVE = []         # the self-attention modules whose forward is running (innermost last)
+
+
+def _attn_enter(module, args, kwargs=None):
+    _ATTN_ACTIVE.append(module)
+
+
+def _attn_leave(module, args, output):
+    from .modules.qat.linear import flush_forward
+    if _ATTN_ACTIVE and _ATTN_ACTIVE[-1] is module:
+        _ATTN_ACTIVE.pop()
+    flush_forward()                    # (nothing a projection left pending outlives the block that called it)
+
+
+def attention_block_active(owner_ref):
+    """True while the forward of the self-attention block `owner_ref` (a weak reference) is running."""
+    owner = owner_ref() if owner_ref is not None else None
+    return owner is not None and bool(_ATTN_ACTIVE) and _ATTN_ACTIVE[-1] is owner
+
+
+def _mark_qkv_members(attn, lins):
     """The three projections in front of an attention core that runs as _AttentionTrainFn: from the next step on their forward products
-    go out as one launch (modules/qat/linear.py, flush_forward).  Only QAT Linears of one shape without forward hooks of their own (a hook
-    would see the output before the launch that writes it)."""
+    go out as one launch (modules/qat/linear.py, flush_forward) -- but only INSIDE the forward of this very block (hooks on the block say
+    when): Hugging Face's self-attention forward only reshapes the three results before it hands them to the attention function, whereas a
+    projection called from anywhere else must return a written tensor.  Only QAT Linears of one shape without forward hooks of their own
+    (a hook would see the output before the launch that writes it)."""
+    import weakref
     from .modules.qat.linear import Linear as QATLinear
     if not all(type(l) is QATLinear and not l._forward_hooks and l.weight.shape == lins[0].weight.shape and (l.bias is None) == (lins[0].bias is None)
                for l in lins):
         return
+    if not attn.__dict__.get("_qt_qkv_hooks", False):
+        attn.register_forward_pre_hook(_attn_enter)
+        attn.register_forward_hook(_attn_leave, always_call=True)
+        attn.__dict__["_qt_qkv_hooks"] = True
+    ref = weakref.ref(attn)
     for l in lins:
-        l.__dict__["_qt_qkv_member"] = True
+        l.__dict__["_qt_qkv_member"] = ref
 
 
 def group_qkv_backward(lins, gys):
@@ -1137,7 +1165,7 @@ def attention_or_none(attn, query, key, value, attention_mask, scaling, dropout)
             return None
         mask = m
     lins = tuple(getattr(attn, n, None) for n in ("query", "key", "value"))
-    _mark_qkv_members(lins)
+    _mark_qkv_members(attn, lins)
     return _AttentionTrainFn.apply(query, key, value, mask, strides, scaling, fqs, fq_o, efqs, lins, drop_p)
 
 

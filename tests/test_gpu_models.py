@@ -1508,6 +1508,43 @@ def test_training_exact_fusions_change_launches_not_values(monkeypatch, switch):
         assert torch.equal(plain[2][k], fused[2][k]), k
 
 
+def test_a_projection_called_outside_its_attention_block_returns_a_written_tensor(monkeypatch):
+    """The forward products of query / key / value are deferred (their outputs returned unwritten, one launch for the three) only while
+    the forward of the self-attention block that owns them is running.  After a training step has marked the members, calling one of them
+    directly -- a probe, a user hook, another model wiring -- gives the same tensor as with the deferral switched off, nothing is left
+    pending, and a whole block forward leaves nothing pending either."""
+    import copy
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    from quantized_training import train_fusions
+    from quantized_training.modules.qat import linear as qlin
+    torch.manual_seed(0)
+    cfg = RobertaConfig(hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512, vocab_size=500,
+                        max_position_embeddings=70, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = RobertaForSequenceClassification(cfg).bfloat16().cuda().train()
+    qt.quantize(m, _args(*_TRAIN_FLAGS))
+    g = torch.Generator().manual_seed(1)
+    batches = [{"input_ids": torch.randint(3, 500, (8, 64), generator=g), "labels": torch.randint(0, 2, (8,), generator=g)} for _ in range(2)]
+    harness.train_steps(m, batches, torch.optim.AdamW(m.parameters(), lr=2e-5))
+    attn = m.roberta.encoder.layer[0].attention.self
+    assert attn.query.__dict__.get("_qt_qkv_member") is not None and attn.__dict__.get("_qt_qkv_hooks")
+    x = torch.randn(8, 64, 256, device="cuda").bfloat16().requires_grad_(True)
+    state = copy.deepcopy(attn.query.state_dict())
+    outs = []
+    for dbg in ("0", str(train_fusions.DEBUG_BITS["qkvfwd"])):
+        monkeypatch.setenv("QT_TRAIN_DEBUG", dbg)
+        attn.query.load_state_dict(state)                # (the input quantizer's amax history advances with every call)
+        y = attn.query(x)
+        assert not qlin._FWD_PENDING
+        outs.append(y.detach().clone())
+    assert torch.equal(outs[0], outs[1])
+    monkeypatch.setenv("QT_TRAIN_DEBUG", "0")
+    qlin.GEMM_ROUTES.clear()
+    out = m.roberta.encoder.layer[0].attention.self(x)
+    assert not qlin._FWD_PENDING and not train_fusions._ATTN_ACTIVE
+    assert any(k.startswith("train:forward q/k/v") for k in qlin.GEMM_ROUTES), qlin.GEMM_ROUTES
+    assert bool(torch.isfinite(out[0].float()).all())
+
+
 def test_graphed_batch_runs_the_weight_passes_of_the_pair_route_as_one_launch():
     """BERT-base-shaped layers at [16, 384] (BASELINE configs[1]): three of the four Linear shapes take the weight pass + library FP8
     GEMM (fused._FQ8_TABLE); harness.GraphedBatch logs those passes during a warm-up forward and captures them as ONE launch
