@@ -120,8 +120,18 @@ __device__ __forceinline__ void drain(int &kt, F &&compute) {
 // (Ring<BM, BN>::kBytes of it).
 // the problem of workgroup `block` (compile-time indices only into the kernel arguments: a run-time index, or a reference to the
 // argument struct, copies it to scratch memory)
-#define QT_TG_PICK(a, block, P, tile)                                      \
-    const int tile = (block) % ((a).tiles_m * (a).tiles_n);                \
+// Workgroups go to the eight XCDs round robin (workgroup b to XCD b % 8), each with its own L2.  Where the row-tile count is a multiple
+// of 8 the walk "row tiles of one column tile first" already gives an XCD two or three row tiles for ALL column tiles (it fetches an
+// eighth of A and shares every B tile between its workgroups).  Where it is not (768 / 64 = 12 row tiles: the small weight gradients) an
+// XCD's tiles are scattered over the whole product and every L2 fetches both operands whole; there the tiles are dealt out so that XCD x
+// takes a contiguous run of the walk -- one and a half column tiles with all their row tiles.
+__device__ __forceinline__ int xcd_run(int b, int total) {
+    const int x = b & 7, j = b >> 3, q = total >> 3, r = total & 7;
+    return x * q + (x < r ? x : r) + j;
+}
+#define QT_TG_PICK(a, block, P, tile_)                                     \
+    const int tiles_##tile_ = (a).tiles_m * (a).tiles_n;                   \
+    const int tile_ = ((a).tiles_m & 7) ? xcd_run((block) % tiles_##tile_, tiles_##tile_) : (block) % tiles_##tile_; \
     Problem P = (a).p[0];                                                  \
     {                                                                      \
         const int prob_ = (block) / ((a).tiles_m * (a).tiles_n);           \
