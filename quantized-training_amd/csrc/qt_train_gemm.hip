@@ -49,6 +49,9 @@ struct Args {
     int count, M, N, K;
     long lda, ldb, ldc;
     int tiles_m, tiles_n;
+#ifdef QT_TUNING_BUILD
+    unsigned long long *dbg;
+#endif
 };
 
 // [rows][64 k] image, 128-byte rows: byte offset of 16-byte chunk `ch` (0..7) of row `row`
@@ -104,7 +107,9 @@ __device__ __forceinline__ void wait_and_barrier() {       // at most N of this 
 template <int BM, int BN>
 struct Ring {
     static constexpr int kStage = (BM + BN) * kBK * 2;                  // 16 / 24 / 32 KiB
-    static constexpr int kStages = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 192 ? 3 : 4);
+    // (128 x 192: 3 x 40 KiB; a fourth stage -- the whole LDS of a CU -- changes nothing: with 24 multiplications and 16 fragment reads per
+    // wave and k tile that shape is paced by the LDS reads, 0.76 us per k tile, not by the operands in flight)
+    static constexpr int kStages = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 192 ? 3 : ((BM + BN) <= 256 ? 4 : 3));
     static constexpr int kBytes = kStage * kStages;
 };
 
@@ -143,8 +148,18 @@ struct Dims {
     int M, N, K;
     long lda, ldb, ldc;
     int tiles_m;
+    unsigned long long *dbg;       // tuning build (QT_TG_STAMPS = device address): s_memrealtime of wave 0 at four points, per workgroup
 };
-#define QT_TG_DIMS(a) Dims{(a).M, (a).N, (a).K, (a).lda, (a).ldb, (a).ldc, (a).tiles_m}
+#ifdef QT_TUNING_BUILD
+#define QT_TG_DIMS(a) Dims{(a).M, (a).N, (a).K, (a).lda, (a).ldb, (a).ldc, (a).tiles_m, (a).dbg}
+#define QT_TG_STAMP(a, slot)                                                                                     \
+    do {                                                                                                         \
+        if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define QT_TG_DIMS(a) Dims{(a).M, (a).N, (a).K, (a).lda, (a).ldb, (a).ldc, (a).tiles_m, nullptr}
+#define QT_TG_STAMP(a, slot)
+#endif
 
 template <bool TA, bool TB, int BM, int BN>
 __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const int tile, unsigned char *lds) {
@@ -246,15 +261,18 @@ __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const i
     // ---- k loop: S - 1 k tiles in flight.  Iteration kt: this wave's pieces of tile kt have landed (all but the (S - 2) kPieces youngest
     // entries of its queue are done), barrier (every wave's have, and every wave is done reading the stage tile kt + S - 1 goes to -- the
     // one tile kt - 1 was read from), request tile kt + S - 1, multiply tile kt.  The host guarantees nk >= S - 1.
+    QT_TG_STAMP(a, 0);
 #pragma unroll
     for (int kt = 0; kt < S - 1; ++kt) request();
     int kt = 0;
     for (; kt + S - 1 < nk; ++kt) {
         wait_and_barrier<(S - 2) * kPieces>();
+        if (kt == 0) QT_TG_STAMP(a, 1);                                 // the first k tile has landed
         request();
         compute(kt);
     }
     drain<S - 2, kPieces>(kt, compute);
+    QT_TG_STAMP(a, 2);
 
     // ---- epilogue: lane (r, g) of tile (i, j) holds C[row0 + r][col0 + 4 g .. + 3]
 #pragma unroll
@@ -274,6 +292,7 @@ __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const i
                                                                  pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
         }
     }
+    QT_TG_STAMP(a, 3);
 }
 
 template <bool TA, bool TB, int BM, int BN>
@@ -381,6 +400,17 @@ int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
     pick_tile(a, TA, bm, bn);
     if (force_bm) bm = force_bm;
     if (force_bn) bn = force_bn;
+    if constexpr (!TA && !TB) {
+        // Forward products wide enough for it: 128 x 192 tiles.  The timeline of a launch (tools/exp_train_gemm_stamps.py) shows what paces
+        // these kernels: a CU moves its operands at 85-100 GB/s whatever the tile, and 768 tiles of 128 x 64 are three per CU -- two
+        // together, then one alone at a third of the rate.  128 x 192 tiles are one per CU (2048 x 3072: 256; q / k / v together: 192)
+        // and need 491 KB per CU instead of 885.
+        const int cus = cu_count();
+        const long tm = (a.M + 127) / 128;
+        const long t64 = (long)a.count * tm * ((a.N + 63) / 64), t192 = (long)a.count * tm * (a.N / 192);
+        if (!force_bm && !force_bn && a.N % 192 == 0 && t64 > 2L * cus && t192 * 10 >= 7L * cus) return launch_tile<false, false, 128, 192>(a, st);
+        if (force_bm == 128 && force_bn == 192) return launch_tile<false, false, 128, 192>(a, st);
+    }
     if (bm == 128 && bn == 128) return launch_tile<TA, TB, 128, 128>(a, st);
     if (bm == 128) return launch_tile<TA, TB, 128, 64>(a, st);
     if (bn == 128) return launch_tile<TA, TB, 64, 128>(a, st);
@@ -464,8 +494,9 @@ int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, 
     a.count = count; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     int fbm = 0, fbn = 0;
 #ifdef QT_TUNING_BUILD
+    if (const char *e = getenv("QT_TG_STAMPS")) a.dbg = (unsigned long long *)strtoull(e, nullptr, 0);   // tools/ only
     if (const char *e = getenv("QT_TRAIN_GEMM_TILE")) {             // tools/ only: "128x64"
-        if (sscanf(e, "%dx%d", &fbm, &fbn) != 2 || (fbm != 64 && fbm != 128) || (fbn != 64 && fbn != 128)) fbm = fbn = 0;
+        if (sscanf(e, "%dx%d", &fbm, &fbn) != 2 || (fbm != 64 && fbm != 128) || (fbn != 64 && fbn != 128 && fbn != 192)) fbm = fbn = 0;
     }
 #endif
     hipStream_t st = (hipStream_t)stream;

@@ -2468,12 +2468,12 @@ def test_attention_train_backward_bias_sums_keep_nan(nv, B):
 
 @pytest.mark.parametrize("layout", ["forward", "dgrad", "wgrad", "tn"])
 @pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2048, 3072, 768), (2048, 768, 3072), (768, 768, 2048), (3072, 768, 2048), (768, 3072, 2048),
-                                   (200, 72, 256), (8, 8, 256), (136, 264, 320), (2048, 2304, 768)])
+                                   (200, 72, 256), (8, 8, 256), (136, 264, 320), (2048, 2304, 768), (1992, 3072, 320)])
 def test_train_gemm_against_fp64_products(nv, layout, M, N, K):
     """qt_train_gemm_bf16, the three products of a QAT Linear under autograd (modules/qat/linear.py:40-41 and its backward): every layout
     (k-contiguous operands through ds_read_b128, operands with the contraction index as the row index through gfx950's transposing
-    ds_read_b64_tr_b16), the shapes of a RoBERTa-base layer at [16, 128] and ragged ones (partial tiles in both directions), one and
-    three problems per launch, with and without bias: every element within one bf16 rounding of the fp64 product of the same operands
+    ds_read_b64_tr_b16), the shapes of a RoBERTa-base layer at [16, 128] and ragged ones (partial tiles in both directions; the wide forward
+    products take 128 x 192 tiles -- 2048 / 1992 x 3072, 2048 x 2304, q / k / v together), one and three problems per launch, with and without bias: every element within one bf16 rounding of the fp64 product of the same operands
     plus fp32 accumulation (2^-8 |ref| + 2^-18 sum |a||b|), and run-to-run bit-identical (the order of an element's additions is fixed)."""
     ta, tb = {"forward": (0, 0), "dgrad": (0, 1), "wgrad": (1, 1), "tn": (1, 0)}[layout]
     torch.manual_seed(M + N + K)
