@@ -161,10 +161,10 @@ struct Dims {
 #define QT_TG_STAMP(a, slot)
 #endif
 
-template <bool TA, bool TB, int BM, int BN>
+template <bool TA, bool TB, int BM, int BN, int SS = 0>
 __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const int tile, unsigned char *lds) {
     constexpr int kAImg = BM * kBK * 2;                                 // bytes of the A image inside a stage
-    constexpr int kStage = Ring<BM, BN>::kStage, S = Ring<BM, BN>::kStages;
+    constexpr int kStage = Ring<BM, BN>::kStage, S = SS ? SS : Ring<BM, BN>::kStages;      // (SS: a deeper ring for a lone workgroup per CU)
     constexpr int kAV = BM / 64, kBV = BN / 64;                         // DMA pieces (1 KiB) per wave and k tile
     constexpr int kPieces = kAV + kBV;
     constexpr int WM = BM / 64, WN = BN / 32;                           // 16 x 16 output tiles per wave: the wave owns (BM / 4) x (BN / 2)
@@ -295,11 +295,11 @@ __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const i
     QT_TG_STAMP(a, 3);
 }
 
-template <bool TA, bool TB, int BM, int BN>
+template <bool TA, bool TB, int BM, int BN, int SS = 0>
 __global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     QT_TG_PICK(a, (int)blockIdx.x, P, tile)
-    gemm_tile<TA, TB, BM, BN>(P, QT_TG_DIMS(a), tile, lds);
+    gemm_tile<TA, TB, BM, BN, SS>(P, QT_TG_DIMS(a), tile, lds);
 }
 
 // The two backward products of a Linear (or of query / key / value together) in ONE launch: the weight gradient's tiles first (their
@@ -363,19 +363,21 @@ int cu_count() {
     return n;
 }
 
-template <bool TA, bool TB, int BM, int BN>
+template <bool TA, bool TB, int BM, int BN, int SS = 0>
 int launch_tile(Args &a, hipStream_t st) {
-    constexpr int kLds = Ring<BM, BN>::kBytes;
-    if (a.K / kBK < Ring<BM, BN>::kStages - 1) return QT_ERR_BAD_ARG;
+    constexpr int kStages = SS ? SS : Ring<BM, BN>::kStages;
+    constexpr int kLds = Ring<BM, BN>::kStage * kStages;
+    static_assert(kLds <= 160 * 1024, "the ring does not fit a CU's LDS");
+    if (a.K / kBK < kStages - 1) return QT_ERR_BAD_ARG;
     static QtOncePerDevice configured;
     if (configured.needed()) {
-        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_kernel<TA, TB, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_kernel<TA, TB, BM, BN, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured.done();
     }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    train_gemm_kernel<TA, TB, BM, BN><<<a.count * a.tiles_m * a.tiles_n, kThreads, kLds, st>>>(a);
+    train_gemm_kernel<TA, TB, BM, BN, SS><<<a.count * a.tiles_m * a.tiles_n, kThreads, kLds, st>>>(a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -410,6 +412,15 @@ int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
         const long t64 = (long)a.count * tm * ((a.N + 63) / 64), t192 = (long)a.count * tm * (a.N / 192);
         if (!force_bm && !force_bn && a.N % 192 == 0 && t64 > 2L * cus && t192 * 10 >= 7L * cus) return launch_tile<false, false, 128, 192>(a, st);
         if (force_bm == 128 && force_bn == 192) return launch_tile<false, false, 128, 192>(a, st);
+        // One 128 x 64 tile per CU or fewer and a long contraction (2048 x 768 x 3072: 192 tiles, 48 k tiles): the workgroup is alone on
+        // its CU and the LDS holds six stages.  Measured (profiles/r06_train_gemm_stamps.txt): 23.5 -> 22.5 us at K = 3072, 7.1 -> 6.9 at K = 768
+        // -- five k tiles in flight instead of two shorten the k tile from 0.45 to 0.41 us only: what paces a lone workgroup is not the
+        // requests in flight (nor the order of request and multiplications in a k tile, nor the LDS latency: both tried).
+        int deep = (bm == 128 && bn == 64 && (long)a.count * ((a.M + 127) / 128) * ((a.N + 63) / 64) <= cus && a.K / kBK >= 16) ? 1 : 0;
+#ifdef QT_TUNING_BUILD
+        if (const char *e = getenv("QT_TRAIN_GEMM_DEEP")) deep = atoi(e);
+#endif
+        if (deep && bm == 128 && bn == 64) return launch_tile<false, false, 128, 64, 6>(a, st);
     }
     if (bm == 128 && bn == 128) return launch_tile<TA, TB, 128, 128>(a, st);
     if (bm == 128) return launch_tile<TA, TB, 128, 64>(a, st);
