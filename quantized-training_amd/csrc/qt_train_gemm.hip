@@ -63,8 +63,9 @@ __device__ __forceinline__ int off_rows(int row, int ch) { return row * 128 + ((
 // is XORed with a value that is distinct over {q, 8 + q} (RB = 256) resp. over the rows of equal parity among them (RB = 128).
 template <int RB>
 __device__ __forceinline__ int s_tr(int row) {
+    static_assert(RB == 128 || RB == 256 || RB == 384, "row lengths of 64, 128 and 192 columns");
     if constexpr (RB == 256) return (row & 3) | (((row >> 3) & 1) << 2);
-    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);     // (RB = 384: rows start at bank group 12 r mod 8 = 4 r mod 8, as with RB = 128)
 }
 template <int RB>
 __device__ __forceinline__ int off_tr(int row, int ch) {       // 16-byte chunk `ch` of k row `row`
@@ -187,8 +188,8 @@ __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const i
             const int row = piece * 8 + (lane >> 3), pos = lane & 7, ch = pos ^ ((row >> 1) & 7);
             sa[v] = (const unsigned char *)(P.a + (long)min(m0 + row, a.M - 1) * a.lda + ch * 8);
         } else {
-            constexpr int RB = BM * 2, kRows = 1024 / RB, kPos = RB / 16;
-            const int row = piece * kRows + lane / kPos, pos = lane % kPos;
+            constexpr int RB = BM * 2, kPos = RB / 16;
+            const int row = (piece * 64 + lane) / kPos, pos = (piece * 64 + lane) % kPos;       // (the image's 16-byte chunks in order)
             const int ch = (((pos >> 1) ^ s_tr<RB>(row)) << 1) | (pos & 1);
             sa[v] = (const unsigned char *)(P.a + (long)row * a.lda + min(m0 + ch * 8, a.M - 8));
         }
@@ -201,8 +202,8 @@ __device__ __forceinline__ void gemm_tile(const Problem P, const Dims a, const i
             const int row = piece * 8 + (lane >> 3), pos = lane & 7, ch = pos ^ ((row >> 1) & 7);
             sb[v] = (const unsigned char *)(P.b + (long)min(n0 + row, a.N - 1) * a.ldb + ch * 8);
         } else {
-            constexpr int RB = BN * 2, kRows = 1024 / RB, kPos = RB / 16;
-            const int row = piece * kRows + lane / kPos, pos = lane % kPos;
+            constexpr int RB = BN * 2, kPos = RB / 16;
+            const int row = (piece * 64 + lane) / kPos, pos = (piece * 64 + lane) % kPos;
             const int ch = (((pos >> 1) ^ s_tr<RB>(row)) << 1) | (pos & 1);
             sb[v] = (const unsigned char *)(P.b + (long)row * a.ldb + min(n0 + ch * 8, a.N - 8));
         }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
 // k range is the token count, the longest of the step), the input gradient's 128 x 64 tiles behind them.  Alone, each of the two leaves
 // a quarter to a half of the CUs idle (144-192 workgroups of one partial wave) and pays its own launch, ring fill and drain; together the
 // second product's workgroups start on the CUs the first one leaves free.  Same tiles, same k order as the separate launches: same bits.
-template <int BMW, int BNW>
+template <int BMW, int BNW, int BND>
 __global__ __launch_bounds__(kThreads) void train_gemm_backward_kernel(Args w, Args d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nw = w.count * w.tiles_m * w.tiles_n;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void train_gemm_backward_kernel(Args w, A
         gemm_tile<true, true, BMW, BNW>(P, QT_TG_DIMS(w), tile, lds);
     } else {
         QT_TG_PICK(d, (int)blockIdx.x - nw, P, tile)
-        gemm_tile<false, true, 128, 64>(P, QT_TG_DIMS(d), tile, lds);
+        gemm_tile<false, true, 128, BND>(P, QT_TG_DIMS(d), tile, lds);
     }
 }
 
@@ -428,22 +429,22 @@ int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
     return launch_tile<TA, TB, 64, 64>(a, st);
 }
 
-template <int BMW, int BNW>
+template <int BMW, int BNW, int BND>
 int launch_backward(Args &w, Args &d, hipStream_t st) {
-    constexpr int kLds = Ring<BMW, BNW>::kBytes > Ring<128, 64>::kBytes ? Ring<BMW, BNW>::kBytes : Ring<128, 64>::kBytes;
-    if (w.K / kBK < Ring<BMW, BNW>::kStages - 1 || d.K / kBK < Ring<128, 64>::kStages - 1) return QT_ERR_BAD_ARG;
+    constexpr int kLds = Ring<BMW, BNW>::kBytes > Ring<128, BND>::kBytes ? Ring<BMW, BNW>::kBytes : Ring<128, BND>::kBytes;
+    if (w.K / kBK < Ring<BMW, BNW>::kStages - 1 || d.K / kBK < Ring<128, BND>::kStages - 1) return QT_ERR_BAD_ARG;
     static QtOncePerDevice configured;
     if (configured.needed()) {
-        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_backward_kernel<BMW, BNW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_backward_kernel<BMW, BNW, BND>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured.done();
     }
     w.tiles_m = (w.M + BMW - 1) / BMW;
     w.tiles_n = (w.N + BNW - 1) / BNW;
     d.tiles_m = (d.M + 127) / 128;
-    d.tiles_n = (d.N + 63) / 64;
+    d.tiles_n = (d.N + BND - 1) / BND;
     const long grid = (long)w.count * w.tiles_m * w.tiles_n + (long)d.count * d.tiles_m * d.tiles_n;
-    train_gemm_backward_kernel<BMW, BNW><<<(unsigned)grid, kThreads, kLds, st>>>(w, d);
+    train_gemm_backward_kernel<BMW, BNW, BND><<<(unsigned)grid, kThreads, kLds, st>>>(w, d);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -474,7 +475,15 @@ int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int 
     int bm, bn;
     pick_tile(w, true, bm, bn);                                        // the weight gradient's tile by the rule of the single launches
     hipStream_t st = (hipStream_t)stream;
-    return bm == 128 ? launch_backward<128, 128>(w, d, st) : launch_backward<64, 64>(w, d, st);
+    if (bm != 128) return launch_backward<64, 64, 64>(w, d, st);
+    // the input gradient's tiles: 128 x 192 under the forward's rule (gx [2048][3072]: 256 tiles instead of 768) -- only beside 128 x 128
+    // weight-gradient tiles, whose ring already takes a CU's LDS for one workgroup (beside 64 x 64 tiles the larger ring would halve
+    // THEIR residency)
+    const int cus = cu_count();
+    const long tm = (d.M + 127) / 128;
+    const long t64 = (long)count * tm * ((d.N + 63) / 64), t192 = (long)count * tm * (d.N / 192);
+    if (d.N % 192 == 0 && t64 > 2L * cus && t192 * 10 >= 7L * cus) return launch_backward<128, 128, 192>(w, d, st);
+    return launch_backward<128, 128, 64>(w, d, st);
 }
 
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
