@@ -476,14 +476,11 @@ int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int 
     pick_tile(w, true, bm, bn);                                        // the weight gradient's tile by the rule of the single launches
     hipStream_t st = (hipStream_t)stream;
     if (bm != 128) return launch_backward<64, 64, 64>(w, d, st);
-    // the input gradient's tiles: 128 x 192 under the forward's rule (gx [2048][3072]: 256 tiles instead of 768) -- only beside 128 x 128
-    // weight-gradient tiles, whose ring already takes a CU's LDS for one workgroup (beside 64 x 64 tiles the larger ring would halve
-    // THEIR residency)
-    const int cus = cu_count();
-    const long tm = (d.M + 127) / 128;
-    const long t64 = (long)count * tm * ((d.N + 63) / 64), t192 = (long)count * tm * (d.N / 192);
-    if (d.N % 192 == 0 && t64 > 2L * cus && t192 * 10 >= 7L * cus) return launch_backward<128, 128, 192>(w, d, st);
-    return launch_backward<128, 128, 64>(w, d, st);
+    // Beside the input gradient's 128 x 64 tiles the weight gradient takes 128 x 64 tiles too: their ring leaves room for a second
+    // workgroup on the CU.  A 128 x 128 tile's ring fills the LDS -- the CUs that hold one take no other tile until it is done: gW [3072][768]
+    // + gx [2048][768] (k = 3072) 43.2 -> 34.9 us, the step 5.66 -> 5.57 ms.  Also measured for gW [768][3072] + gx [2048][3072]: 128 x 128
+    // beside 128 x 192 input-gradient tiles (256 instead of 768 of them) 5.564-5.570 ms against 5.536-5.560 with everything 64 wide.
+    return launch_backward<128, 64, 64>(w, d, st);
 }
 
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
