@@ -113,8 +113,15 @@ class _Plan:
             self.ws = torch.zeros(max(int(L.qt_clip_adamw_ws_bytes(n, nchunks)), 64), dtype=torch.uint8, device=dev)
             self.total_norm = torch.zeros((), dtype=torch.float32, device=dev)
             self.ntensors, self.nchunks = n, int(nchunks)
-        self.table_host.copy_(torch.from_numpy(arr.copy()))
-        self.table_dev.copy_(self.table_host, non_blocking=True)      # (pinned source: legal inside a stream capture, replayed with the graph)
+        if torch.cuda.is_current_stream_capturing():
+            # pinned source + asynchronous copy: legal inside a stream capture, and the copy node reads the buffer at every replay -- the
+            # plan is frozen from here on (clip_and_step), nothing rewrites it
+            self.table_host.copy_(torch.from_numpy(arr.copy()))
+            self.table_dev.copy_(self.table_host, non_blocking=True)
+        else:
+            # eager: a copy from pageable memory returns when the source has been read -- an asynchronous copy from the one pinned buffer
+            # could still be queued when the NEXT step (new gradient addresses) rewrites that buffer
+            self.table_dev.copy_(torch.from_numpy(arr.copy()))
 
 
 def _plan_for(optimizer):
