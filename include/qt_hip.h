@@ -30,7 +30,8 @@ extern "C" {
 
 /* 2 (round 6): qt_fp8_gemm's last argument is the heuristic suggestion index (`algo`), no longer a 0 / 1 `tune` flag; the training
  * entry points (qt_attention_train_*, qt_grad_fanin_bf16, qt_embedding_backward_bf16, qt_fake_quant_chain_bf16) exist.  A caller built
- * against 1 must not bind this library, and the package refuses a library that reports anything else. */
+ * against 1 must not bind this library, and the package refuses a library that reports anything else.
+ * 3 (round 6): qt_train_gemm_backward_bf16 and the step-end entry points (qt_clip_adamw_plan / _ws_bytes / _bf16) exist. */
 #define QT_ABI_VERSION 3
 #define QT_MAP_ENTRIES 65536
 
