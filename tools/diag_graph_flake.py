@@ -33,8 +33,8 @@ def run(mode, batched=True):
             opt.zero_grad(set_to_none=True)
             loss = m(**b).loss
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0, error_if_nonfinite=False)
-            opt.step()
+            from quantized_training import optim
+            optim.clip_and_step(m.parameters(), opt, 1.0)              # (what harness.train_steps calls: the in-tree step end unless QT_TRAIN_DEBUG has bit 256)
     else:
         step = harness.GraphedTrainStep(m, opt, batch_scale_updates=batched, batch_weight_passes=batched)
         step.capture(batches[0], warmup=3)
@@ -47,7 +47,10 @@ def run(mode, batched=True):
     return state, params
 
 
-for mask, batched in ((0, True), (0, False), (8, True), (16, True), (32, True), (64, True), (2, True), (4, True), (1, True)):
+CASES = ((0, True), (0, False), (8, True), (16, True), (32, True), (64, True), (2, True), (4, True), (1, True))
+if os.environ.get("MASKS"):                     # e.g. MASKS=0,256: these masks only, batched launches
+    CASES = tuple((int(m), True) for m in os.environ["MASKS"].split(","))
+for mask, batched in CASES:
     os.environ["QT_TRAIN_DEBUG"] = str(mask)
     ref = run("eager")
     nbad, shown = 0, 0
