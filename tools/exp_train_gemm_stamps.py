@@ -68,5 +68,8 @@ def run(M, N, K, ta, tb, count=1):
         print(f"   workgroups {lo:4d}..: start {float((seg[:, 0] - t0).median()):6.2f}  end {float((seg[:, 3] - t0).median()):6.2f}")
 
 
-for shape in ((2048, 3072, 768, 0, 0, 1), (2048, 768, 768, 0, 0, 3), (2048, 768, 768, 0, 0, 1), (2048, 768, 3072, 0, 0, 1), (3072, 768, 2048, 1, 1, 1)):
+SHAPES = ((2048, 3072, 768, 0, 0, 1), (2048, 768, 768, 0, 0, 3), (2048, 768, 768, 0, 0, 1), (2048, 768, 3072, 0, 0, 1), (3072, 768, 2048, 1, 1, 1))
+if os.environ.get("SHAPES"):                    # e.g. SHAPES=2048x2048x2048 (forward layout, one problem)
+    SHAPES = tuple(tuple(int(v) for v in sh.split("x")) + (0, 0, 1) for sh in os.environ["SHAPES"].split(","))
+for shape in SHAPES:
     run(*shape)
