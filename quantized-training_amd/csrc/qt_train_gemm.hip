@@ -63,9 +63,9 @@ __device__ __forceinline__ int off_rows(int row, int ch) { return row * 128 + ((
 // is XORed with a value that is distinct over {q, 8 + q} (RB = 256) resp. over the rows of equal parity among them (RB = 128).
 template <int RB>
 __device__ __forceinline__ int s_tr(int row) {
-    static_assert(RB == 128 || RB == 256 || RB == 384, "row lengths of 64, 128 and 192 columns");
+    static_assert(RB == 128 || RB == 256, "row lengths of 64 and 128 columns (192: 384-byte rows start at bank group 4 r mod 8 like 128-byte ones and take their formula -- built, measured, not used)");
     if constexpr (RB == 256) return (row & 3) | (((row >> 3) & 1) << 2);
-    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);     // (RB = 384: rows start at bank group 12 r mod 8 = 4 r mod 8, as with RB = 128)
+    else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
 }
 template <int RB>
 __device__ __forceinline__ int off_tr(int row, int ch) {       // 16-byte chunk `ch` of k row `row`
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void train_gemm_kernel(Args a) {
 // k range is the token count, the longest of the step), the input gradient's 128 x 64 tiles behind them.  Alone, each of the two leaves
 // a quarter to a half of the CUs idle (144-192 workgroups of one partial wave) and pays its own launch, ring fill and drain; together the
 // second product's workgroups start on the CUs the first one leaves free.  Same tiles, same k order as the separate launches: same bits.
-template <int BMW, int BNW, int BND>
+template <int BMW, int BNW>
 __global__ __launch_bounds__(kThreads) void train_gemm_backward_kernel(Args w, Args d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nw = w.count * w.tiles_m * w.tiles_n;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void train_gemm_backward_kernel(Args w, A
         gemm_tile<true, true, BMW, BNW>(P, QT_TG_DIMS(w), tile, lds);
     } else {
         QT_TG_PICK(d, (int)blockIdx.x - nw, P, tile)
-        gemm_tile<false, true, 128, BND>(P, QT_TG_DIMS(d), tile, lds);
+        gemm_tile<false, true, 128, 64>(P, QT_TG_DIMS(d), tile, lds);
     }
 }
 
@@ -429,22 +429,22 @@ int launch(Args &a, hipStream_t st, int force_bm, int force_bn) {
     return launch_tile<TA, TB, 64, 64>(a, st);
 }
 
-template <int BMW, int BNW, int BND>
+template <int BMW, int BNW>
 int launch_backward(Args &w, Args &d, hipStream_t st) {
-    constexpr int kLds = Ring<BMW, BNW>::kBytes > Ring<128, BND>::kBytes ? Ring<BMW, BNW>::kBytes : Ring<128, BND>::kBytes;
-    if (w.K / kBK < Ring<BMW, BNW>::kStages - 1 || d.K / kBK < Ring<128, BND>::kStages - 1) return QT_ERR_BAD_ARG;
+    constexpr int kLds = Ring<BMW, BNW>::kBytes > Ring<128, 64>::kBytes ? Ring<BMW, BNW>::kBytes : Ring<128, 64>::kBytes;
+    if (w.K / kBK < Ring<BMW, BNW>::kStages - 1 || d.K / kBK < Ring<128, 64>::kStages - 1) return QT_ERR_BAD_ARG;
     static QtOncePerDevice configured;
     if (configured.needed()) {
-        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_backward_kernel<BMW, BNW, BND>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        const hipError_t e = hipFuncSetAttribute((const void *)train_gemm_backward_kernel<BMW, BNW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return (int)e;
         configured.done();
     }
     w.tiles_m = (w.M + BMW - 1) / BMW;
     w.tiles_n = (w.N + BNW - 1) / BNW;
     d.tiles_m = (d.M + 127) / 128;
-    d.tiles_n = (d.N + BND - 1) / BND;
+    d.tiles_n = (d.N + 63) / 64;
     const long grid = (long)w.count * w.tiles_m * w.tiles_n + (long)d.count * d.tiles_m * d.tiles_n;
-    train_gemm_backward_kernel<BMW, BNW, BND><<<(unsigned)grid, kThreads, kLds, st>>>(w, d);
+    train_gemm_backward_kernel<BMW, BNW><<<(unsigned)grid, kThreads, kLds, st>>>(w, d);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QT_OK : (int)e;
 }
@@ -475,12 +475,12 @@ int qt_train_gemm_backward_bf16(const qt_linear_backward *items, int count, int 
     int bm, bn;
     pick_tile(w, true, bm, bn);                                        // the weight gradient's tile by the rule of the single launches
     hipStream_t st = (hipStream_t)stream;
-    if (bm != 128) return launch_backward<64, 64, 64>(w, d, st);
+    if (bm != 128) return launch_backward<64, 64>(w, d, st);
     // Beside the input gradient's 128 x 64 tiles the weight gradient takes 128 x 64 tiles too: their ring leaves room for a second
     // workgroup on the CU.  A 128 x 128 tile's ring fills the LDS -- the CUs that hold one take no other tile until it is done: gW [3072][768]
     // + gx [2048][768] (k = 3072) 43.2 -> 34.9 us, the step 5.66 -> 5.57 ms.  Also measured for gW [768][3072] + gx [2048][3072]: 128 x 128
     // beside 128 x 192 input-gradient tiles (256 instead of 768 of them) 5.564-5.570 ms against 5.536-5.560 with everything 64 wide.
-    return launch_backward<128, 64, 64>(w, d, st);
+    return launch_backward<128, 64>(w, d, st);
 }
 
 int qt_train_gemm_bf16(const qt_gemm_problem *problems, int count, int trans_a, int trans_b, int M, int N, int K, long lda, long ldb, long ldc,
